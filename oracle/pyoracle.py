@@ -1,0 +1,277 @@
+"""TEST INFRASTRUCTURE — NOT PRODUCT CODE.
+
+ctypes bindings for the two CPU checkers:
+
+* ``Oracle``  -> oracle/librs_oracle.so   (plain-C restatement, rs_oracle.c)
+* ``Ref``     -> oracle/_ref/libref.so    (the real reference compiled in place; only
+                 buildable where /root/reference exists, the .so travels to the GPU box)
+
+Both expose the same method names so tests can run one function against the other.
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+i8p = np.ctypeslib.ndpointer(np.int8, flags="C_CONTIGUOUS")
+
+
+def build(ref=True):
+    """make the oracle (and oracle/_ref when the reference tree is present)."""
+    subprocess.check_call(["make", "-s", "-f", os.path.join(HERE, "Makefile"),
+                           os.path.join(HERE, "librs_oracle.so")])
+    if ref:
+        subprocess.check_call(["make", "-s", "-f", os.path.join(HERE, "Makefile"), "ref"])
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class _Base:
+    prefix = ""
+
+    def _fn(self, name, restype, argtypes):
+        f = getattr(self.lib, self.prefix + name)
+        f.restype = restype
+        f.argtypes = argtypes
+        return f
+
+    def _common(self):
+        self._mat4_inverse = self._fn("mat4_inverse", None, [f32p, f32p])
+        self._mat4_mul = self._fn("mat4_mul", None, [f32p, f32p, f32p])
+        self._translate = self._fn("translate", None, [f32p, f32p, f32p])
+        self._rotate = self._fn("rotate", None, [f32p, C.c_float, f32p, f32p])
+        self._xform_points = self._fn("xform_points", None, [f32p, f32p, C.c_int64, C.c_int, f32p])
+        self._normalize = self._fn("normalize", None, [f32p, C.c_int64, f32p])
+        self._mean = self._fn("mean", C.c_float, [f32p, C.c_int])
+        self._stddev = self._fn("stddev", C.c_float, [C.c_float, f32p, C.c_int])
+        self._grid_create = self._fn("grid_create", C.c_void_p, [f32p, C.c_int32, C.c_float])
+        self._grid_destroy = self._fn("grid_destroy", None, [C.c_void_p])
+        self._grid_info = self._fn("grid_info", None, [C.c_void_p, i64p, C.POINTER(C.c_double), f32p,
+                                                       C.POINTER(C.c_uint32)])
+        self._radius_search = self._fn("radius_search", C.c_uint64,
+                                       [C.c_void_p, f32p, C.c_int64, C.c_float, C.c_int64, C.c_int,
+                                        f32p, i32p, i64p])
+        self._icp_estimate = self._fn("icp_estimate_pt2pl", C.c_float, [f32p, f32p, f32p, f32p, C.c_int32, f32p])
+
+    # -- helpers ---------------------------------------------------------------------
+    def mat4_inverse(self, m):
+        o = np.empty(16, np.float32); self._mat4_inverse(_f32(m).ravel(), o); return o
+
+    def mat4_mul(self, a, b):
+        o = np.empty(16, np.float32); self._mat4_mul(_f32(a).ravel(), _f32(b).ravel(), o); return o
+
+    def translate(self, m, t):
+        o = np.empty(16, np.float32); self._translate(_f32(m).ravel(), _f32(t), o); return o
+
+    def rotate(self, m, angle, axis):
+        o = np.empty(16, np.float32); self._rotate(_f32(m).ravel(), float(angle), _f32(axis), o); return o
+
+    def xform_points(self, m, pts, is_point=1):
+        pts = _f32(pts); o = np.empty_like(pts)
+        self._xform_points(_f32(m).ravel(), pts, len(pts), int(is_point), o); return o
+
+    def normalize(self, v):
+        v = _f32(v); o = np.empty_like(v); self._normalize(v, len(v), o); return o
+
+    def mean(self, v):
+        v = _f32(v); return self._mean(v, len(v))
+
+    def stddev(self, mean, v):
+        v = _f32(v); return self._stddev(float(mean), v, len(v))
+
+    # -- grid ------------------------------------------------------------------------
+    def grid_create(self, pts, radius):
+        pts = _f32(pts)
+        return self._grid_create(pts, len(pts), float(radius))
+
+    def grid_destroy(self, g):
+        self._grid_destroy(g)
+
+    def grid_info(self, g):
+        dims = np.zeros(3, np.int64); cell = C.c_double(); minp = np.zeros(3, np.float32); mb = C.c_uint32()
+        self._grid_info(g, dims, C.byref(cell), minp, C.byref(mb))
+        return dims, cell.value, minp, mb.value
+
+    def radius_search(self, g, query, radius, k, sort=1):
+        query = _f32(query); nq = len(query)
+        d = np.zeros((nq, k), np.float32); i = np.zeros((nq, k), np.int32); nn = np.zeros(nq, np.int64)
+        total = self._radius_search(g, query, nq, float(radius), int(k), int(sort), d, i, nn)
+        return d, i, nn, total
+
+    def icp_estimate_pt2pl(self, p1, p2, n2, w, T1):
+        T = _f32(T1).ravel().copy()
+        err = self._icp_estimate(_f32(p1), _f32(p2), _f32(n2), _f32(w), len(w), T)
+        return err, T
+
+
+class Oracle(_Base):
+    prefix = "orc_"
+
+    def __init__(self):
+        path = os.path.join(HERE, "librs_oracle.so")
+        if not os.path.exists(path):
+            build(ref=False)
+        self.lib = C.CDLL(path)
+        self._common()
+        self._find_corrs = self._fn("icp_find_corrs", C.c_int32,
+                                    [f32p, f32p, C.c_int32, f32p, f32p, C.c_int32, C.c_void_p, f32p, f32p,
+                                     C.c_float, C.c_float, f32p, f32p, f32p, f32p, f32p])
+        self._icp_align = self._fn("icp_align", C.c_float,
+                                   [f32p, f32p, C.c_int32, f32p, f32p, C.c_int32, f32p, f32p, C.c_float, C.c_float,
+                                    C.POINTER(C.c_int32)])
+        self._scores = self._fn("alignment_scores", None,
+                                [C.c_void_p, f32p, f32p, f32p, C.c_int32, f32p, C.c_int32, C.c_int32, f32p])
+        self._icp_gate = self._fn("icp_gate", C.c_int, [C.c_float, C.c_float])
+        self._score_gate = self._fn("score_gate", C.c_int, [C.c_float])
+        self._label_gate = self._fn("label_gate", C.c_int, [C.c_float])
+        self.lib.orc_arrangement_to_labels.restype = None
+        self.lib.orc_assign_labels.restype = None
+
+    def icp_find_corrs(self, pts1, nor1, pts2, nor2, T1, T2, max_dist, max_angle):
+        pts1, nor1, pts2, nor2 = map(_f32, (pts1, nor1, pts2, nor2))
+        n1 = len(pts1)
+        g = self.grid_create(pts2, max_dist)
+        out = [np.zeros((n1, 3), np.float32) for _ in range(4)]
+        w = np.zeros(n1, np.float32)
+        nc = self._find_corrs(pts1, nor1, n1, pts2, nor2, len(pts2), g, _f32(T1).ravel(), _f32(T2).ravel(),
+                              float(max_dist), float(max_angle), *out, w)
+        self.grid_destroy(g)
+        return [o[:nc] for o in out] + [w[:nc]]
+
+    def icp_align(self, pts1, nor1, pts2, nor2, T1, T2, max_dist, max_angle):
+        pts1, nor1, pts2, nor2 = map(_f32, (pts1, nor1, pts2, nor2))
+        T = _f32(T1).ravel().copy(); it = C.c_int32()
+        err = self._icp_align(pts1, nor1, len(pts1), pts2, nor2, len(pts2), T, _f32(T2).ravel(),
+                              float(max_dist), float(max_angle), C.byref(it))
+        return err, T, it.value
+
+    def alignment_scores(self, scene_pos, scene_nor, obj_pos, obj_nor, poses, k, scene_grid=None):
+        scene_pos, scene_nor, obj_pos, obj_nor = map(_f32, (scene_pos, scene_nor, obj_pos, obj_nor))
+        poses = _f32(poses).reshape(-1, 16)
+        g = scene_grid if scene_grid is not None else self.grid_create(scene_pos, 0.05)
+        out = np.zeros(len(poses), np.float32)
+        self._scores(g, scene_nor, obj_pos, obj_nor, len(obj_pos), poses, len(poses), int(k), out)
+        if scene_grid is None:
+            self.grid_destroy(g)
+        return out
+
+    class _Obj(C.Structure):
+        _fields_ = [("pos", C.c_void_p), ("nor", C.c_void_p), ("n", C.c_int32), ("grid", C.c_void_p),
+                    ("class_idx", C.c_int32), ("is_static", C.c_int32)]
+
+    class _Plc(C.Structure):
+        _fields_ = [("pose", C.c_float * 16), ("object_idx", C.c_int32), ("uidx", C.c_int32)]
+
+    def arrangement_to_labels(self, scene_pos, scene_nor, objects, placements, radius=0.05,
+                              prioritize_static=0, unlabelled_class_idx=0):
+        """objects: list of dict(pos, nor, class_idx, is_static); placements: list of dict(pose, object_idx, uidx)."""
+        scene_pos, scene_nor = _f32(scene_pos), _f32(scene_nor)
+        n = len(scene_pos)
+        keep = []
+        objs = (self._Obj * max(1, len(objects)))()
+        grids = []
+        for i, o in enumerate(objects):
+            p, nn_ = _f32(o["pos"]), _f32(o["nor"]); keep += [p, nn_]
+            g = self.grid_create(p, 0.05); grids.append(g)
+            objs[i].pos = p.ctypes.data; objs[i].nor = nn_.ctypes.data; objs[i].n = len(p); objs[i].grid = g
+            objs[i].class_idx = int(o["class_idx"]); objs[i].is_static = int(o["is_static"])
+        plcs = (self._Plc * max(1, len(placements)))()
+        for i, pl in enumerate(placements):
+            plcs[i].pose[:] = [float(x) for x in _f32(pl["pose"]).ravel()]
+            plcs[i].object_idx = int(pl["object_idx"]); plcs[i].uidx = int(pl["uidx"])
+        labels = np.zeros(n, np.int8); mind = np.zeros(n, np.float32)
+        order = np.zeros(max(1, len(placements)), np.int32)
+        cls = np.zeros(n, np.int32); inst = np.zeros(n, np.int32)
+        self.lib.orc_arrangement_to_labels.argtypes = [f32p, f32p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                                                       C.c_float, C.c_int, C.c_int32, i8p, f32p, i32p, i32p, i32p]
+        self.lib.orc_arrangement_to_labels(scene_pos, scene_nor, n, C.addressof(objs), C.addressof(plcs),
+                                           len(placements), float(radius), int(prioritize_static),
+                                           int(unlabelled_class_idx), labels, mind, order, cls, inst)
+        for g in grids:
+            self.grid_destroy(g)
+        return dict(labels=labels, min_dists=mind, order=order[:len(placements)], class_ids=cls, instance_ids=inst)
+
+    def icp_gate(self, dot, max_angle):
+        return self._icp_gate(float(dot), float(max_angle))
+
+    def score_gate(self, dot):
+        return self._score_gate(float(dot))
+
+    def label_gate(self, dot):
+        return self._label_gate(float(dot))
+
+
+class Ref(_Base):
+    prefix = "ref_"
+
+    @staticmethod
+    def available(omp=False):
+        return os.path.exists(os.path.join(HERE, "_ref", "libref_omp.so" if omp else "libref.so"))
+
+    def __init__(self, omp=False):
+        path = os.path.join(HERE, "_ref", "libref_omp.so" if omp else "libref.so")
+        self.lib = C.CDLL(path)
+        self._common()
+        self._find_corrs = self._fn("icp_find_corrs", C.c_int32,
+                                    [f32p, f32p, C.c_int32, f32p, f32p, C.c_int32, f32p, f32p,
+                                     C.c_float, C.c_float, f32p, f32p, f32p, f32p, f32p])
+        self._icp_align = self._fn("icp_align", C.c_float,
+                                   [f32p, f32p, C.c_int32, f32p, f32p, C.c_int32, f32p, f32p, C.c_float, C.c_float])
+        self._scene_create = self._fn("scene_create", C.c_void_p, [f32p, f32p, C.c_int64])
+        self._scene_destroy = self._fn("scene_destroy", None, [C.c_void_p])
+        self._scene_grid = self._fn("scene_grid", C.c_void_p, [C.c_void_p])
+        self._scores = self._fn("alignment_scores", None,
+                                [C.c_void_p, f32p, f32p, C.c_int32, f32p, C.c_int32, C.c_int32, f32p])
+        self._label_gate = self._fn("label_gate", C.c_int, [f32p, f32p, f32p])
+        self._label_gate_dot = self._fn("label_gate_dot", C.c_int, [C.c_float])
+        self._num_threads = self._fn("num_threads", C.c_int, [])
+
+    def num_threads(self):
+        return self._num_threads()
+
+    def icp_find_corrs(self, pts1, nor1, pts2, nor2, T1, T2, max_dist, max_angle):
+        pts1, nor1, pts2, nor2 = map(_f32, (pts1, nor1, pts2, nor2))
+        n1 = len(pts1)
+        out = [np.zeros((n1, 3), np.float32) for _ in range(4)]
+        w = np.zeros(n1, np.float32)
+        nc = self._find_corrs(pts1, nor1, n1, pts2, nor2, len(pts2), _f32(T1).ravel(), _f32(T2).ravel(),
+                              float(max_dist), float(max_angle), *out, w)
+        return [o[:nc] for o in out] + [w[:nc]]
+
+    def icp_align(self, pts1, nor1, pts2, nor2, T1, T2, max_dist, max_angle):
+        pts1, nor1, pts2, nor2 = map(_f32, (pts1, nor1, pts2, nor2))
+        T = _f32(T1).ravel().copy()
+        err = self._icp_align(pts1, nor1, len(pts1), pts2, nor2, len(pts2), T, _f32(T2).ravel(),
+                              float(max_dist), float(max_angle))
+        return err, T, None
+
+    def alignment_scores(self, scene_pos, scene_nor, obj_pos, obj_nor, poses, k, scene=None):
+        scene_pos, scene_nor, obj_pos, obj_nor = map(_f32, (scene_pos, scene_nor, obj_pos, obj_nor))
+        poses = _f32(poses).reshape(-1, 16)
+        s = scene if scene is not None else self._scene_create(scene_pos, scene_nor, len(scene_pos))
+        out = np.zeros(len(poses), np.float32)
+        self._scores(s, obj_pos, obj_nor, len(obj_pos), poses, len(poses), int(k), out)
+        if scene is None:
+            self._scene_destroy(s)
+        return out
+
+    def scene_create(self, scene_pos, scene_nor):
+        return self._scene_create(scene_pos, scene_nor, len(scene_pos))
+
+    def scene_destroy(self, s):
+        self._scene_destroy(s)
+
+    def label_gate(self, pose, n_scene, n_obj):
+        return self._label_gate(_f32(pose).ravel(), _f32(n_scene), _f32(n_obj))
+
+    def label_gate_dot(self, dot):
+        return self._label_gate_dot(float(dot))

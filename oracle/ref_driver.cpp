@@ -1,0 +1,227 @@
+// TEST INFRASTRUCTURE — NOT PRODUCT CODE.
+//
+// oracle/_ref: the *real* reference hot path, compiled from the sources where
+// they lie under /root/reference (nothing is copied into this repo), exposed
+// over a flat C ABI so that tests / golden-vector generation / the CPU-baseline
+// leg of bench.py can call it on raw arrays.
+//
+// This TU plays the role apps/pose_proposal/main.cpp:1-38 plays in the
+// reference build: it switches on the single-header implementations and then
+// only *calls* reference functions.  The second TU of the library is the
+// reference's own apps/pose_proposal/pose_proposal.cpp, compiled in place
+// (see oracle/Makefile).  lib/rs/rs_pointcloud_filters.cpp is NOT built: it
+// needs the un-vendored gco-v3.0 header (README.md:12-13), and writing a
+// stand-in for it is not allowed — so the label loop is pinned through its
+// primitives (radius search K=1, mat4 inverse/transpose, normalise) instead.
+//
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+// load the resulting oracle/_ref/libref*.so.
+
+#define MSH_STD_IMPLEMENTATION
+#define MSH_PLY_IMPLEMENTATION
+#define MSH_ARGPARSE_IMPLEMENTATION
+#define MSH_VEC_MATH_IMPLEMENTATION
+#define MSH_GEOMETRY_IMPLEMENTATION
+#define MSH_HASH_GRID_IMPLEMENTATION
+#define RS_POINTCLOUD_IMPLEMENTATION
+#define RS_DISTANCE_FUNCTION_IMPLEMENTATION
+#define RS_DATABASE_IMPLEMENTATION
+#define FILEPATH_HELPERS_IMPLEMENTATION
+#define HASHTABLE_IMPLEMENTATION
+#define ICP_IMPLEMENTATION
+
+#include <cassert>
+#include <cmath>
+#include <cstring>
+#include <cstdint>
+#include <cstdarg>
+#include <cstddef>
+#include <cstdbool>
+#include <cstdio>
+#include <cstdlib>
+#include <cfloat>
+#include <cctype>
+
+#include "msh/msh_std.h"
+#include "msh/msh_argparse.h"
+#include "msh/msh_vec_math.h"
+#include "msh/msh_geometry.h"
+#include "msh/msh_ply.h"
+#include "msh/msh_hash_grid.h"
+#include "mg/hashtable.h"
+#include "icp.h"
+#include "filepath_helpers.h"
+#include "rs_pointcloud.h"
+#include "rs_database.h"
+#include "rs_distance_function.h"
+#include "pose_proposal.h"
+
+// pose_proposal.cpp uses these msh_array instantiations (same reason as
+// apps/pose_proposal/main.cpp:40-45).
+template int* msh_array__grow<int>(int* arr, unsigned long long new_len, unsigned long long elem_size );
+template rs_object_placement* msh_array__grow<rs_object_placement>(rs_object_placement* arr, unsigned long long new_len, unsigned long long elem_size );
+template pose_proposal* msh_array__grow<pose_proposal>(pose_proposal* arr, unsigned long long new_len, unsigned long long elem_size );
+template pose_proposal** msh_array__grow<pose_proposal*>(pose_proposal** arr, unsigned long long new_len, unsigned long long elem_size );
+template mark* msh_array__grow<mark>(mark* arr, unsigned long long new_len, unsigned long long elem_size );
+
+extern "C" {
+
+// ---- msh_hash_grid ---------------------------------------------------------
+void* ref_grid_create( const float* pts, int32_t n, float radius )
+{
+  msh_hash_grid_t* hg = (msh_hash_grid_t*)calloc( 1, sizeof(msh_hash_grid_t) );
+  msh_hash_grid_init_3d( hg, pts, n, radius );
+  return hg;
+}
+
+void ref_grid_destroy( void* g )
+{
+  msh_hash_grid_t* hg = (msh_hash_grid_t*)g;
+  if( hg->bin_table ) { msh_hg_map_free( hg->bin_table ); }
+  msh_hash_grid_term( hg );
+  free( hg );
+}
+
+void ref_grid_info( void* g, int64_t* dims, double* cell, float* minp, uint32_t* max_in_bin )
+{
+  msh_hash_grid_t* hg = (msh_hash_grid_t*)g;
+  dims[0] = hg->width; dims[1] = hg->height; dims[2] = hg->depth;
+  *cell = hg->cell_size;
+  minp[0] = hg->min_pt.x; minp[1] = hg->min_pt.y; minp[2] = hg->min_pt.z;
+  *max_in_bin = hg->max_n_pts_in_bin;
+}
+
+// n_neighbors is returned as int64 (the reference writes size_t).
+uint64_t ref_radius_search( void* g, const float* query, int64_t nq, float radius,
+                            int64_t k, int sort, float* dists, int32_t* inds, int64_t* nn )
+{
+  msh_hash_grid_search_desc_t d;
+  memset( &d, 0, sizeof(d) );
+  d.query_pts = (float*)query; d.n_query_pts = (size_t)nq;
+  d.distances_sq = dists; d.indices = inds; d.n_neighbors = (size_t*)nn;
+  d.radius = radius; d.max_n_neigh = (size_t)k; d.sort = sort;
+  return (uint64_t)msh_hash_grid_radius_search( (msh_hash_grid_t*)g, &d );
+}
+
+// ---- msh_vec_math helpers --------------------------------------------------
+void ref_mat4_inverse( const float* m, float* out )
+{ msh_mat4_t a; memcpy( a.data, m, 64 ); msh_mat4_t r = msh_mat4_inverse( a ); memcpy( out, r.data, 64 ); }
+void ref_mat4_mul( const float* a_, const float* b_, float* out )
+{ msh_mat4_t a, b; memcpy( a.data, a_, 64 ); memcpy( b.data, b_, 64 );
+  msh_mat4_t r = msh_mat4_mul( a, b ); memcpy( out, r.data, 64 ); }
+void ref_translate( const float* m, const float* t, float* out )
+{ msh_mat4_t a; memcpy( a.data, m, 64 ); msh_mat4_t r = msh_translate( a, msh_vec3( t[0], t[1], t[2] ) ); memcpy( out, r.data, 64 ); }
+void ref_rotate( const float* m, float angle, const float* axis, float* out )
+{ msh_mat4_t a; memcpy( a.data, m, 64 ); msh_mat4_t r = msh_rotate( a, angle, msh_vec3( axis[0], axis[1], axis[2] ) ); memcpy( out, r.data, 64 ); }
+void ref_xform_points( const float* m, const float* in, int64_t n, int is_point, float* out )
+{
+  msh_mat4_t a; memcpy( a.data, m, 64 );
+  for( int64_t i = 0; i < n; ++i )
+  {
+    msh_vec3_t v = msh_mat4_vec3_mul( a, msh_vec3( in[3*i], in[3*i+1], in[3*i+2] ), is_point );
+    out[3*i] = v.x; out[3*i+1] = v.y; out[3*i+2] = v.z;
+  }
+}
+void ref_normalize( const float* in, int64_t n, float* out )
+{
+  for( int64_t i = 0; i < n; ++i )
+  {
+    msh_vec3_t v = msh_vec3_normalize( msh_vec3( in[3*i], in[3*i+1], in[3*i+2] ) );
+    out[3*i] = v.x; out[3*i+1] = v.y; out[3*i+2] = v.z;
+  }
+}
+float ref_mean( const float* v, int n ) { return msh_compute_mean( v, n ); }
+float ref_stddev( float mean, float* v, int n ) { return msh_compute_stddev( mean, v, n ); }
+
+// ---- icp -------------------------------------------------------------------
+float ref_icp_align( float* pts1, float* nor1, int32_t n1, float* pts2, float* nor2, int32_t n2,
+                     float* T1, const float* T2, float max_dist, float max_angle )
+{
+  msh_mat4_t t1, t2; memcpy( t1.data, T1, 64 ); memcpy( t2.data, T2, 64 );
+  float err = icp_align( (msh_vec3_t*)pts1, (msh_vec3_t*)nor1, n1, (msh_vec3_t*)pts2, (msh_vec3_t*)nor2, n2,
+                         &t1, t2, max_dist, max_angle, false );
+  memcpy( T1, t1.data, 64 );
+  return err;
+}
+
+// One icp_find_corrs call (lib/rs/icp.h:306-412); outputs are copied into
+// caller arrays of capacity n1.  Returns n_corrs.
+int32_t ref_icp_find_corrs( float* pts1, float* nor1, int32_t n1, float* pts2, float* nor2, int32_t n2,
+                            const float* T1, const float* T2, float max_dist, float max_angle,
+                            float* c_pts1, float* c_nor1, float* c_pts2, float* c_nor2, float* w )
+{
+  msh_mat4_t t1, t2; memcpy( t1.data, T1, 64 ); memcpy( t2.data, T2, 64 );
+  msh_hash_grid_t index1 = {0}; msh_hash_grid_t index2 = {0};
+  msh_hash_grid_init_3d( &index1, pts1, n1, max_dist );
+  msh_hash_grid_init_3d( &index2, pts2, n2, max_dist );
+  msh_vec3_t *cp1 = NULL, *cn1 = NULL, *cp2 = NULL, *cn2 = NULL; float* cw = NULL; int32_t nc = 0;
+  icp_find_corrs( (msh_vec3_t*)pts1, (msh_vec3_t*)nor1, n1, &index1, (msh_vec3_t*)pts2, (msh_vec3_t*)nor2, n2, &index2,
+                  t1, t2, &cp1, &cn1, &cp2, &cn2, &cw, &nc, max_dist, max_angle );
+  memcpy( c_pts1, cp1, nc * 12 ); memcpy( c_nor1, cn1, nc * 12 );
+  memcpy( c_pts2, cp2, nc * 12 ); memcpy( c_nor2, cn2, nc * 12 ); memcpy( w, cw, nc * 4 );
+  free( cp1 ); free( cn1 ); free( cp2 ); free( cn2 ); free( cw );
+  if( index1.bin_table ) msh_hg_map_free( index1.bin_table );
+  if( index2.bin_table ) msh_hg_map_free( index2.bin_table );
+  msh_hash_grid_term( &index1 ); msh_hash_grid_term( &index2 );
+  return nc;
+}
+
+float ref_icp_estimate_pt2pl( float* p1, float* p2, float* n2, float* w, int32_t n, float* T1 )
+{
+  msh_mat4_t t1; memcpy( t1.data, T1, 64 );
+  float err = icp_estimate_rigid_xform_pt2pl( (msh_vec3_t*)p1, (msh_vec3_t*)p2, (msh_vec3_t*)n2, w, n, &t1 );
+  memcpy( T1, t1.data, 64 );
+  return err;
+}
+
+// ---- alignment score (apps/pose_proposal/pose_proposal.cpp:93-158) ---------
+// The scene handle owns a level-1 grid built exactly as
+// rs_pointcloud_compute_search_grid does (lib/rs/rs_pointcloud.h:849-863,
+// radius 0.05).  Object points are presented as level `query_lvl` = 1 arrays.
+typedef struct ref_scene { rs_pointcloud_t pc; } ref_scene_t;
+
+void* ref_scene_create( float* pos, float* nor, int64_t n )
+{
+  ref_scene_t* s = (ref_scene_t*)calloc( 1, sizeof(ref_scene_t) );
+  s->pc.positions[1] = (msh_vec3_t*)pos; s->pc.normals[1] = (msh_vec3_t*)nor; s->pc.n_pts[1] = (size_t)n;
+  s->pc.search_grids[1] = (msh_hash_grid_t*)calloc( 1, sizeof(msh_hash_grid_t) );
+  msh_hash_grid_init_3d( s->pc.search_grids[1], pos, (int32_t)n, 0.05f );
+  return s;
+}
+void ref_scene_destroy( void* sp )
+{
+  ref_scene_t* s = (ref_scene_t*)sp;
+  if( s->pc.search_grids[1]->bin_table ) msh_hg_map_free( s->pc.search_grids[1]->bin_table );
+  msh_hash_grid_term( s->pc.search_grids[1] ); free( s->pc.search_grids[1] ); free( s );
+}
+void* ref_scene_grid( void* sp ) { return ((ref_scene_t*)sp)->pc.search_grids[1]; }
+
+// scores[p] = mgs_compute_object_alignment_score(object, scene, 1, 1, poses[p], storage(max_n_neigh))
+void ref_alignment_scores( void* sp, float* obj_pos, float* obj_nor, int32_t n_obj,
+                           const float* poses, int32_t n_poses, int32_t max_n_neigh, float* scores )
+{
+  ref_scene_t* s = (ref_scene_t*)sp;
+  rs_pointcloud_t obj; memset( &obj, 0, sizeof(obj) );
+  obj.positions[1] = (msh_vec3_t*)obj_pos; obj.normals[1] = (msh_vec3_t*)obj_nor; obj.n_pts[1] = (size_t)n_obj;
+  tmp_score_calc_storage_t st = allocate_tmp_calc_storage( n_obj, (int32_t)s->pc.n_pts[1], max_n_neigh );
+  for( int32_t p = 0; p < n_poses; ++p )
+  {
+    msh_mat4_t x; memcpy( x.data, poses + 16 * p, 64 );
+    scores[p] = mgs_compute_object_alignment_score( &obj, &s->pc, 1, 1, x, &st );
+  }
+  free_tmp_calc_storage( &st );
+}
+
+int ref_num_threads( void )
+{
+#if defined(_OPENMP)
+  int n = 1;
+  #pragma omp parallel
+  { n = omp_get_num_threads(); }
+  return n;
+#else
+  return 1;
+#endif
+}
+
+} // extern "C"

@@ -1,0 +1,989 @@
+/* TEST INFRASTRUCTURE — NOT PRODUCT CODE.  See rs_oracle.h for scope and parity status.
+ *
+ * Plain C11, single thread, no FMA contraction (-ffp-contract=off, no -march): the
+ * reference is x86-64 SSE2 scalar float as shipped (apps/<app>/CMakeLists.txt set no -march).
+ * Every float expression below keeps the reference's operand order and its
+ * float/double promotions; comments name the reference lines being restated.
+ */
+#include "rs_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------
+ * Small linear algebra, column-major float[16]  (lib/msh/msh_vec_math.h)
+ * ---------------------------------------------------------------------------------------- */
+
+typedef struct { float x, y, z; } v3;
+
+static v3 v3_make( float x, float y, float z ) { v3 r = { x, y, z }; return r; }
+static v3 v3_sub( v3 a, v3 b ) { return v3_make( a.x - b.x, a.y - b.y, a.z - b.z ); }
+static v3 v3_add( v3 a, v3 b ) { return v3_make( a.x + b.x, a.y + b.y, a.z + b.z ); }
+static v3 v3_scale( v3 a, float s ) { return v3_make( a.x * s, a.y * s, a.z * s ); }
+/* msh_vec_math.h:890 */
+static float v3_dot( v3 a, v3 b ) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+/* msh_vec_math.h:974 */
+static v3 v3_cross( v3 a, v3 b )
+{
+  return v3_make( a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x );
+}
+/* msh_vec_math.h:868: reciprocal of sqrtf, then three multiplies */
+static v3 v3_unit( v3 v )
+{
+  float inv = 1.0f / sqrtf( v.x * v.x + v.y * v.y + v.z * v.z );
+  return v3_make( v.x * inv, v.y * inv, v.z * inv );
+}
+static v3 v3_load( const float* p, int64_t i ) { return v3_make( p[3*i], p[3*i+1], p[3*i+2] ); }
+static void v3_store( float* p, int64_t i, v3 v ) { p[3*i] = v.x; p[3*i+1] = v.y; p[3*i+2] = v.z; }
+
+/* msh_vec_math.h:1554-1561: m0*x + m4*y + m8*z + (float)is_point*m12, left to right */
+static v3 m4_apply( const float* m, v3 v, int is_point )
+{
+  float w = (float)is_point;
+  v3 o;
+  o.x = m[0] * v.x + m[4] * v.y + m[ 8] * v.z + w * m[12];
+  o.y = m[1] * v.x + m[5] * v.y + m[ 9] * v.z + w * m[13];
+  o.z = m[2] * v.x + m[6] * v.y + m[10] * v.z + w * m[14];
+  return o;
+}
+
+void orc_xform_points( const float* m, const float* in, int64_t n, int is_point, float* out )
+{
+  for( int64_t i = 0; i < n; ++i ) { v3_store( out, i, m4_apply( m, v3_load( in, i ), is_point ) ); }
+}
+
+void orc_normalize( const float* in, int64_t n, float* out )
+{
+  for( int64_t i = 0; i < n; ++i ) { v3_store( out, i, v3_unit( v3_load( in, i ) ) ); }
+}
+
+/* msh_vec_math.h:1441-1476: out(r,c) = sum_k b(k,c)*a(r,k), k ascending, written b*a */
+void orc_mat4_mul( const float* a, const float* b, float* out )
+{
+  float o[16];
+  for( int c = 0; c < 4; ++c )
+  {
+    for( int r = 0; r < 4; ++r )
+    {
+      o[4*c + r] = b[4*c + 0] * a[r] + b[4*c + 1] * a[4 + r] + b[4*c + 2] * a[8 + r] + b[4*c + 3] * a[12 + r];
+    }
+  }
+  memcpy( out, o, sizeof(o) );
+}
+
+/* msh_vec_math.h:1938 */
+void orc_mat4_transpose( const float* m, float* out )
+{
+  float o[16];
+  for( int c = 0; c < 4; ++c ) { for( int r = 0; r < 4; ++r ) { o[4*c + r] = m[4*r + c]; } }
+  memcpy( out, o, sizeof(o) );
+}
+
+/* msh_vec_math.h:1818-1905: cofactor ("Cramer") inverse; two banks of six 2x2 minors, the
+ * sixteen cofactors written with the reference's sign pattern and term order, det from
+ * row 0, then every cofactor multiplied by 1.0f/det. */
+void orc_mat4_inverse( const float* m, float* out )
+{
+  float C[16], s[6];
+
+  s[0] = m[10] * m[15] - m[14] * m[11];
+  s[1] = m[ 6] * m[11] - m[10] * m[ 7];
+  s[2] = m[ 2] * m[ 7] - m[ 6] * m[ 3];
+  s[3] = m[ 6] * m[15] - m[14] * m[ 7];
+  s[4] = m[ 2] * m[11] - m[10] * m[ 3];
+  s[5] = m[ 2] * m[15] - m[14] * m[ 3];
+
+  C[0] = m[5] * s[0] - m[9] * s[3] + m[13] * s[1];
+  C[1] = m[9] * s[5] - m[1] * s[0] - m[13] * s[4];
+  C[2] = m[1] * s[3] - m[5] * s[5] + m[13] * s[2];
+  C[3] = m[5] * s[4] - m[9] * s[2] - m[ 1] * s[1];
+
+  C[4] = m[8] * s[3] - m[4] * s[0] - m[12] * s[1];
+  C[5] = m[0] * s[0] - m[8] * s[5] + m[12] * s[4];
+  C[6] = m[4] * s[5] - m[0] * s[3] - m[12] * s[2];
+  C[7] = m[0] * s[1] - m[4] * s[4] + m[ 8] * s[2];
+
+  s[0] = m[ 8] * m[13] - m[12] * m[ 9];
+  s[1] = m[ 4] * m[ 9] - m[ 8] * m[ 5];
+  s[2] = m[ 0] * m[ 5] - m[ 4] * m[ 1];
+  s[3] = m[ 4] * m[13] - m[12] * m[ 5];
+  s[4] = m[ 0] * m[ 9] - m[ 8] * m[ 1];
+  s[5] = m[ 0] * m[13] - m[12] * m[ 1];
+
+  C[ 8] = m[ 7] * s[0] - m[11] * s[3] + m[15] * s[1];
+  C[ 9] = m[11] * s[5] - m[ 3] * s[0] - m[15] * s[4];
+  C[10] = m[ 3] * s[3] - m[ 7] * s[5] + m[15] * s[2];
+  C[11] = m[ 7] * s[4] - m[ 3] * s[1] - m[11] * s[2];
+
+  C[12] = m[10] * s[3] - m[ 6] * s[0] - m[14] * s[1];
+  C[13] = m[ 2] * s[0] - m[10] * s[5] + m[14] * s[4];
+  C[14] = m[ 6] * s[5] - m[ 2] * s[3] - m[14] * s[2];
+  C[15] = m[ 2] * s[1] - m[ 6] * s[4] + m[10] * s[2];
+
+  float det = m[0] * C[0] + m[4] * C[1] + m[8] * C[2] + m[12] * C[3];
+  float inv_det = 1.0f / det;
+  for( int i = 0; i < 16; ++i ) { out[i] = inv_det * C[i]; }
+}
+
+/* msh_vec_math.h:2064-2074: col3' = (col0*tx + col1*ty) + (col2*tz + col3); the vec4
+ * scalar multiply at :718-725 goes through double, which rounds like a float multiply. */
+void orc_translate( const float* m, const float* t, float* out )
+{
+  float o[16];
+  memcpy( o, m, sizeof(o) );
+  for( int r = 0; r < 4; ++r )
+  {
+    float a = (float)( (double)m[r]     * (double)t[0] );
+    float b = (float)( (double)m[4 + r] * (double)t[1] );
+    float c = (float)( (double)m[8 + r] * (double)t[2] );
+    o[12 + r] = ( a + b ) + ( c + m[12 + r] );
+  }
+  memcpy( out, o, sizeof(o) );
+}
+
+/* msh_vec_math.h:2089-2132: axis-angle rotation matrix R (cosf/sinf), result = m * R on the
+ * first three columns: col_j' = col0*R(0,j) + (col1*R(1,j) + col2*R(2,j)). */
+void orc_rotate( const float* m, float angle, const float* axis_in, float* out )
+{
+  float c = cosf( angle );
+  float s = sinf( angle );
+  float t = 1.0f - c;
+  v3 ax = v3_unit( v3_make( axis_in[0], axis_in[1], axis_in[2] ) );
+
+  float R[16];
+  memset( R, 0, sizeof(R) );
+  R[ 0] = c + ax.x * ax.x * t;
+  R[ 5] = c + ax.y * ax.y * t;
+  R[10] = c + ax.z * ax.z * t;
+  float p = ax.x * ax.y * t, q = ax.z * s;
+  R[1] = p + q;  R[4] = p - q;
+  p = ax.x * ax.z * t;  q = ax.y * s;
+  R[2] = p - q;  R[8] = p + q;
+  p = ax.y * ax.z * t;  q = ax.x * s;
+  R[6] = p + q;  R[9] = p - q;
+
+  float o[16];
+  for( int j = 0; j < 3; ++j )
+  {
+    for( int r = 0; r < 4; ++r )
+    {
+      float a = (float)( (double)m[r]     * (double)R[4*j + 0] );
+      float b = (float)( (double)m[4 + r] * (double)R[4*j + 1] );
+      float d = (float)( (double)m[8 + r] * (double)R[4*j + 2] );
+      o[4*j + r] = a + ( b + d );
+    }
+  }
+  for( int r = 0; r < 4; ++r ) { o[12 + r] = m[12 + r]; }
+  memcpy( out, o, sizeof(o) );
+}
+
+/* lib/msh/msh_std.h:1779-1816: sequential float sum, divided by (float)n */
+float orc_mean( const float* v, int n )
+{
+  float acc = 0;
+  for( int i = 0; i < n; ++i ) { acc += v[i]; }
+  return acc / (float)n;
+}
+
+/* lib/msh/msh_std.h:1800-1825: sequential float sum of squares; sqrt evaluated in double */
+float orc_stddev( float mean, const float* v, int n )
+{
+  float sq = 0.0f;
+  for( int i = 0; i < n; ++i ) { sq += v[i] * v[i]; }
+  return (float)sqrt( sq / (float)n - mean * mean );
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Paired (distance, index) sort  (lib/msh/msh_hash_grid.h:579-703)
+ * Needed verbatim in behaviour: the order it leaves equal keys in decides which of two
+ * equidistant neighbours a consumer sees first.
+ * ---------------------------------------------------------------------------------------- */
+
+static void pair_swap( float* d, int32_t* x, int a, int b )
+{
+  float td = d[a]; d[a] = d[b]; d[b] = td;
+  int32_t tx = x[a]; x[a] = x[b]; x[b] = tx;
+}
+
+/* :579-603 — insertion sort, an element stops behind the first one not greater than it */
+static void pair_insertion_sort( float* d, int32_t* x, int n )
+{
+  for( int i = 1; i < n; ++i )
+  {
+    float key = d[i];
+    int32_t kx = x[i];
+    int j = i;
+    while( j > 0 && !( key >= d[j-1] ) ) { d[j] = d[j-1]; x[j] = x[j-1]; --j; }
+    if( j != i ) { d[j] = key; x[j] = kx; }
+  }
+}
+
+/* :605-696 — median-of-three quicksort that leaves runs of <= 12 unsorted.  The pivot is
+ * parked at slot 0 and stays there; the left part handed on is [0, j). */
+static void pair_quick_sort( float* d, int32_t* x, int n )
+{
+  while( n > 12 )
+  {
+    int mid = n >> 1;
+    int lo_lt_mid = d[0] < d[mid];
+    int mid_lt_hi = d[mid] < d[n-1];
+    if( lo_lt_mid != mid_lt_hi )
+    {
+      int lo_lt_hi = d[0] < d[n-1];
+      int z = ( lo_lt_hi == mid_lt_hi ) ? 0 : n - 1;
+      pair_swap( d, x, z, mid );
+    }
+    pair_swap( d, x, 0, mid );
+
+    int i = 1, j = n - 1;
+    for( ;; )
+    {
+      while( d[i] < d[0] ) { ++i; }
+      while( d[0] < d[j] ) { --j; }
+      if( i >= j ) { break; }
+      pair_swap( d, x, i, j );
+      ++i; --j;
+    }
+    if( j < n - i )
+    {
+      pair_quick_sort( d, x, j );
+      d += i; x += i; n -= i;
+    }
+    else
+    {
+      pair_quick_sort( d + i, x + i, n - i );
+      n = j;
+    }
+  }
+}
+
+/* :698-703 */
+static void pair_sort( float* d, int32_t* x, int n )
+{
+  pair_quick_sort( d, x, n );
+  pair_insertion_sort( d, x, n );
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Bounded result store: plain array until it fills, then a max-heap
+ * (lib/msh/msh_hash_grid.h:705-824)
+ * ---------------------------------------------------------------------------------------- */
+
+typedef struct
+{
+  size_t cap, len;
+  float worst;
+  float* d;
+  int32_t* x;
+  int heaped;
+} kstore;
+
+/* :706-728 */
+static void heap_sift_down( float* d, int32_t* x, size_t len, size_t at )
+{
+  for( ;; )
+  {
+    size_t big = at, l = 2 * at + 1, r = 2 * at + 2;
+    if( l < len && d[l] > d[at] )  { big = l; }
+    if( r < len && d[r] > d[big] ) { big = r; }
+    if( big == at ) { return; }
+    pair_swap( d, x, (int)at, (int)big );
+    at = big;
+  }
+}
+
+/* :751-767 — a parent that is >= the new key stops the climb */
+static void heap_sift_up_last( float* d, int32_t* x, size_t len )
+{
+  int64_t i = (int64_t)len - 1;
+  float key = d[i];
+  int32_t kx = x[i];
+  while( i > 0 )
+  {
+    int64_t parent = ( i - 1 ) >> 1;
+    if( d[parent] >= key ) { break; }
+    d[i] = d[parent]; x[i] = x[parent];
+    i = parent;
+  }
+  d[i] = key; x[i] = kx;
+}
+
+/* :796-824 */
+static void kstore_offer( kstore* s, float dist, int32_t idx )
+{
+  if( s->len >= s->cap && dist >= s->worst ) { return; }
+
+  if( s->len >= s->cap )
+  {
+    /* :736-749 heap_pop: root goes to the last slot (overwritten just below), the array
+     * shrinks by one and the new root sinks. */
+    pair_swap( s->d, s->x, 0, (int)s->len - 1 );
+    s->len--;
+    if( s->len > 0 ) { heap_sift_down( s->d, s->x, s->len, 0 ); }
+  }
+
+  s->d[s->len] = dist;
+  s->x[s->len] = idx;
+  s->len++;
+
+  if( s->heaped ) { heap_sift_up_last( s->d, s->x, s->len ); }
+
+  if( s->len >= s->cap && !s->heaped )
+  {
+    /* :730-734 heap_make: sift down from len/2 to 0 */
+    for( int64_t i = (int64_t)( s->len >> 1 ); i >= 0; --i ) { heap_sift_down( s->d, s->x, s->len, (size_t)i ); }
+    s->heaped = 1;
+  }
+
+  if( s->heaped )              { s->worst = s->d[0]; }
+  else if( s->worst <= dist )  { s->worst = dist; }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Uniform grid index  (lib/msh/msh_hash_grid.h:388-541)
+ * The reference keeps a bin->slot hash map; only "is the bin occupied, and which points in
+ * which order" is observable, so this restatement keeps the occupied bin ids sorted and
+ * binary-searches them.  Points of a bin stay in input order; bins are laid out by
+ * ascending id (:511-532).
+ * ---------------------------------------------------------------------------------------- */
+
+typedef struct { float x, y, z; int32_t i; } cell_pt;
+
+struct orc_grid
+{
+  int64_t w, h, d;
+  double cell, inv_cell;
+  int32_t slab;
+  float minx, miny, minz, maxx, maxy, maxz;
+  uint64_t n_bins;
+  uint64_t* bin_ids;     /* ascending */
+  uint32_t* bin_begin;   /* n_bins + 1 */
+  cell_pt* pts;
+  uint32_t max_in_bin;
+  int32_t n_pts;
+};
+
+typedef struct { uint64_t bin; int32_t i; } bin_key;
+
+static int bin_key_cmp( const void* a, const void* b )
+{
+  const bin_key* p = (const bin_key*)a;
+  const bin_key* q = (const bin_key*)b;
+  if( p->bin != q->bin ) { return p->bin < q->bin ? -1 : 1; }
+  return ( p->i > q->i ) - ( p->i < q->i );
+}
+
+orc_grid_t* orc_grid_create( const float* pts, int32_t n, float radius )
+{
+  orc_grid_t* g = (orc_grid_t*)calloc( 1, sizeof(orc_grid_t) );
+
+  /* :413-434 bounding box, seeded with +-1e9, widened by 1e-4 */
+  g->minx = g->miny = g->minz =  1e9;
+  g->maxx = g->maxy = g->maxz = -1e9;
+  for( int32_t i = 0; i < n; ++i )
+  {
+    float x = pts[3*i], y = pts[3*i+1], z = pts[3*i+2];
+    g->minx = ( g->minx > x ) ? x : g->minx;
+    g->miny = ( g->miny > y ) ? y : g->miny;
+    g->minz = ( g->minz > z ) ? z : g->minz;
+    g->maxx = ( g->maxx < x ) ? x : g->maxx;
+    g->maxy = ( g->maxy < y ) ? y : g->maxy;
+    g->maxz = ( g->maxz < z ) ? z : g->maxz;
+  }
+  g->maxx += 0.0001f; g->maxy += 0.0001f; g->maxz += 0.0001f;
+  g->minx -= 0.0001f; g->miny -= 0.0001f; g->minz -= 0.0001f;
+
+  /* :437-451 */
+  float ex = g->maxx - g->minx, ey = g->maxy - g->miny, ez = g->maxz - g->minz;
+  float emax = ex > ey ? ex : ey; emax = emax > ez ? emax : ez;
+  if( radius > 0.0 ) { g->cell = 2.0 * radius; }
+  else               { g->cell = emax / ( 32 * sqrtf( 3.0f ) ); }
+  g->w = (int)( ex / g->cell + 1.0 );
+  g->h = (int)( ey / g->cell + 1.0 );
+  g->d = (int)( ez / g->cell + 1.0 );
+  g->inv_cell = 1.0f / g->cell;
+  g->slab = (int32_t)( g->h * g->w );
+  g->n_pts = n;
+
+  /* :458-475 bin id of every point: (uint64)((p - min) * inv_cell), float subtract, double product */
+  bin_key* keys = (bin_key*)malloc( (size_t)( n > 0 ? n : 1 ) * sizeof(bin_key) );
+  for( int32_t i = 0; i < n; ++i )
+  {
+    uint64_t ix = (uint64_t)( ( pts[3*i]   - g->minx ) * g->inv_cell );
+    uint64_t iy = (uint64_t)( ( pts[3*i+1] - g->miny ) * g->inv_cell );
+    uint64_t iz = (uint64_t)( ( pts[3*i+2] - g->minz ) * g->inv_cell );
+    keys[i].bin = iz * (uint64_t)(int64_t)g->slab + iy * (uint64_t)g->w + ix;   /* :377 */
+    keys[i].i = i;
+  }
+  qsort( keys, (size_t)n, sizeof(bin_key), bin_key_cmp );
+
+  g->pts = (cell_pt*)malloc( (size_t)( n > 0 ? n : 1 ) * sizeof(cell_pt) );
+  g->bin_ids = (uint64_t*)malloc( (size_t)( n > 0 ? n : 1 ) * sizeof(uint64_t) );
+  g->bin_begin = (uint32_t*)malloc( (size_t)( n + 1 ) * sizeof(uint32_t) );
+  for( int32_t s = 0; s < n; ++s )
+  {
+    int32_t i = keys[s].i;
+    g->pts[s].x = pts[3*i]; g->pts[s].y = pts[3*i+1]; g->pts[s].z = pts[3*i+2]; g->pts[s].i = i;
+    if( s == 0 || keys[s].bin != keys[s-1].bin )
+    {
+      g->bin_ids[g->n_bins] = keys[s].bin;
+      g->bin_begin[g->n_bins] = (uint32_t)s;
+      g->n_bins++;
+    }
+  }
+  g->bin_begin[g->n_bins] = (uint32_t)n;
+  for( uint64_t b = 0; b < g->n_bins; ++b )
+  {
+    uint32_t len = g->bin_begin[b+1] - g->bin_begin[b];
+    if( len > g->max_in_bin ) { g->max_in_bin = len; }
+  }
+  free( keys );
+  return g;
+}
+
+void orc_grid_destroy( orc_grid_t* g )
+{
+  if( !g ) { return; }
+  free( g->pts ); free( g->bin_ids ); free( g->bin_begin ); free( g );
+}
+
+void orc_grid_info( const orc_grid_t* g, int64_t dims[3], double* cell, float minp[3], uint32_t* max_in_bin )
+{
+  dims[0] = g->w; dims[1] = g->h; dims[2] = g->d;
+  *cell = g->cell;
+  minp[0] = g->minx; minp[1] = g->miny; minp[2] = g->minz;
+  *max_in_bin = g->max_in_bin;
+}
+
+static int64_t grid_find_bin( const orc_grid_t* g, uint64_t bin )
+{
+  int64_t lo = 0, hi = (int64_t)g->n_bins - 1;
+  while( lo <= hi )
+  {
+    int64_t mid = ( lo + hi ) >> 1;
+    if( g->bin_ids[mid] == bin ) { return mid; }
+    if( g->bin_ids[mid] < bin ) { lo = mid + 1; } else { hi = mid - 1; }
+  }
+  return -1;
+}
+
+/* :826-862 — every point of one bin against the query; strict `<` against radius² which
+ * arrives as a *float* parameter (the caller's double product is narrowed at the call). */
+static void grid_scan_bin( const orc_grid_t* g, uint64_t bin, float radius_sq, const float* q, kstore* s )
+{
+  int64_t b = grid_find_bin( g, bin );
+  if( b < 0 ) { return; }
+  const cell_pt* p = g->pts + g->bin_begin[b];
+  uint32_t n = g->bin_begin[b+1] - g->bin_begin[b];
+  float qx = q[0], qy = q[1], qz = q[2];
+  for( uint32_t i = 0; i < n; ++i )
+  {
+    float vx = p[i].x - qx;
+    float vy = p[i].y - qy;
+    float vz = p[i].z - qz;
+    float dist_sq = vx * vx + vy * vy + vz * vz;
+    if( dist_sq < radius_sq ) { kstore_offer( s, dist_sq, p[i].i ); }
+  }
+}
+
+/* :1090-1259 (single-thread path) */
+uint64_t orc_radius_search( const orc_grid_t* g, const float* query, int64_t nq, float radius_f,
+                            int64_t k, int sort, float* dists, int32_t* inds, int64_t* nn )
+{
+  enum { MAX_BINS = 512 };
+  int32_t bin_id[MAX_BINS];
+  float bin_d2[MAX_BINS];
+
+  const double radius = radius_f;
+  const double cs = g->cell, ics = g->inv_cell;
+  const int64_t w = g->w, h = g->h, d = g->d;
+  const uint64_t slab = (uint64_t)(int64_t)g->slab;
+  const double radius_sq = radius * radius;
+  uint32_t total = 0;
+
+  for( int64_t qi = 0; qi < nq; ++qi )
+  {
+    const float* qp = query + 3 * qi;
+    float* drow = dists + qi * k;
+    int32_t* xrow = inds + qi * k;
+    kstore st;
+    st.cap = (size_t)k; st.len = 0; st.worst = -FLT_MAX; st.heaped = 0; st.d = drow; st.x = xrow;  /* :781-790 */
+
+    /* :1150-1183 query relative to the grid origin (float), cell ranges by C truncation */
+    float qx = qp[0] - g->minx, qy = qp[1] - g->miny, qz = qp[2] - g->minz;
+    int64_t ix = (int64_t)( qx * ics ), iy = (int64_t)( qy * ics ), iz = (int64_t)( qz * ics );
+    int64_t opx = (int64_t)( ( qx + radius ) * ics ) - ix, onx = (int64_t)( ( qx - radius ) * ics ) - ix;
+    int64_t opy = (int64_t)( ( qy + radius ) * ics ) - iy, ony = (int64_t)( ( qy - radius ) * ics ) - iy;
+    int64_t opz = (int64_t)( ( qz + radius ) * ics ) - iz, onz = (int64_t)( ( qz - radius ) * ics ) - iz;
+
+    /* :1184-1225 candidate bins with a per-bin lower bound on distance² */
+    uint32_t nb = 0;
+    int full = 0;
+    float dx, dy, dz;
+    for( int64_t oz = onz; oz <= opz && !full; ++oz )
+    {
+      int64_t cz = iz + oz;
+      if( cz < 0 || cz >= d ) { continue; }
+      if( oz < 0 )      { dz = (float)( qz - ( cz + 1 ) * cs ); }
+      else if( oz > 0 ) { dz = (float)( cz * cs - qz ); }
+      else              { dz = 0.0f; }
+      for( int64_t oy = ony; oy <= opy && !full; ++oy )
+      {
+        int64_t cy = iy + oy;
+        if( cy < 0 || cy >= h ) { continue; }
+        if( oy < 0 )      { dy = (float)( qy - ( cy + 1 ) * cs ); }
+        else if( oy > 0 ) { dy = (float)( cy * cs - qy ); }
+        else              { dy = 0.0f; }
+        for( int64_t ox = onx; ox <= opx; ++ox )
+        {
+          int64_t cx = ix + ox;
+          if( cx < 0 || cx >= w ) { continue; }
+          if( nb >= MAX_BINS ) { full = 1; break; }                 /* :1213 goto */
+          bin_id[nb] = (int32_t)( (uint64_t)cz * slab + (uint64_t)cy * (uint64_t)w + (uint64_t)cx );
+          if( ox < 0 )      { dx = (float)( qx - ( cx + 1 ) * cs ); }
+          else if( ox > 0 ) { dx = (float)( cx * cs - qx ); }
+          else              { dx = 0.0f; }
+          bin_d2[nb] = dz * dz + dy * dy + dx * dx;
+          nb++;
+        }
+      }
+    }
+
+    /* :1227-1237 nearest bins first; stop once the store is full and its worst entry is no
+     * farther than the next bin's bound */
+    pair_sort( bin_d2, bin_id, (int)nb );
+    for( uint32_t b = 0; b < nb; ++b )
+    {
+      grid_scan_bin( g, (uint64_t)(int64_t)bin_id[b], (float)radius_sq, qp, &st );
+      if( st.len >= (size_t)k && st.worst <= bin_d2[b] ) { break; }
+    }
+
+    if( sort ) { pair_sort( drow, xrow, (int)st.len ); }   /* :1240 */
+    if( nn ) { nn[qi] = (int64_t)st.len; }
+    total += (uint32_t)st.len;
+  }
+  return total;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Normal gates
+ * ---------------------------------------------------------------------------------------- */
+
+/* lib/rs/icp.h:372-374: dot clamped below at 0, acosf, strict < max_angle (float) */
+int orc_icp_gate( float dot, float max_angle )
+{
+  float c = dot > 0.0f ? dot : 0.0f;
+  return acosf( c ) < max_angle;
+}
+
+/* pose_proposal.cpp:99,138-141: double acos of the clamped float dot; angle - 35deg < 1e-6.
+ * msh_deg2rad(x) = x * 0.005555555556 * MSH_PI (lib/msh/msh_std.h:618,625). */
+#define ORC_PI 3.1415926535897932384626433832
+static double deg2rad( double x ) { return x * 0.005555555556 * ORC_PI; }
+
+int orc_score_gate( float dot_f )
+{
+  double dot = dot_f;
+  dot = dot > 0.0f ? dot : 0.0f;
+  double angle = acos( dot );
+  return ( angle - deg2rad( 35.0 ) ) < 0.000001;
+}
+
+/* rs_pointcloud_filters.cpp:769-770: in that TU ("math.h" preamble) acos/fabs on a float
+ * pick the float overloads (checked in oracle/_ref: ref_label_gate_dot calls acosf); the
+ * float angle is then compared, as a double, with 70 degrees. */
+int orc_label_gate( float dot )
+{
+  float angle = acosf( fabsf( dot ) );
+  return (double)angle < deg2rad( 70.0 );
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Point-to-plane ICP  (lib/rs/icp.h)
+ * ---------------------------------------------------------------------------------------- */
+
+/* :306-412 with caller-provided output arrays */
+int32_t orc_icp_find_corrs( const float* pts1, const float* nor1, int32_t n1,
+                            const float* pts2, const float* nor2, int32_t n2, const orc_grid_t* index2,
+                            const float* T1, const float* T2, float max_dist, float max_angle,
+                            float* c_pts1, float* c_nor1, float* c_pts2, float* c_nor2, float* w )
+{
+  (void)n2;
+  enum { MAX_NN = 16 };
+  float T2i[16];
+  orc_mat4_inverse( T2, T2i );
+
+  size_t cap = (size_t)( n1 > 0 ? n1 : 1 );
+  float* dists = (float*)malloc( cap * MAX_NN * sizeof(float) );
+  int32_t* ind = (int32_t*)malloc( cap * MAX_NN * sizeof(int32_t) );
+  int64_t* nnb = (int64_t*)malloc( cap * sizeof(int64_t) );
+  float* qpos = (float*)malloc( cap * 3 * sizeof(float) );
+  float* qnor = (float*)malloc( cap * 3 * sizeof(float) );
+
+  /* :339-347 two successive mat*vec per point and per normal */
+  for( int32_t i = 0; i < n1; ++i )
+  {
+    v3 p = m4_apply( T1, v3_load( pts1, i ), 1 );
+    v3 n = m4_apply( T1, v3_load( nor1, i ), 0 );
+    v3_store( qpos, i, m4_apply( T2i, p, 1 ) );
+    v3_store( qnor, i, m4_apply( T2i, n, 0 ) );
+  }
+
+  orc_radius_search( index2, qpos, n1, max_dist, MAX_NN, 1, dists, ind, nnb );   /* :349-359 */
+
+  /* :361-391 first neighbour (ascending distance) whose normal passes the gate */
+  int32_t ic = 0;
+  for( int32_t i = 0; i < n1; ++i )
+  {
+    int32_t best = -1;
+    float dist = 0.0f, dot = 0.0f;
+    v3 nq = v3_load( qnor, i );
+    for( int64_t j = 0; j < nnb[i]; ++j )
+    {
+      int32_t i2 = ind[(size_t)i * MAX_NN + (size_t)j];
+      dot = v3_dot( v3_load( nor2, i2 ), nq );
+      dot = dot > 0.0f ? dot : 0.0f;
+      if( acosf( dot ) < max_angle ) { best = i2; dist = dists[(size_t)i * MAX_NN + (size_t)j]; break; }
+    }
+    if( best != -1 )
+    {
+      v3_store( c_pts1, ic, v3_load( qpos, i ) );
+      v3_store( c_nor1, ic, nq );
+      v3_store( c_pts2, ic, v3_load( pts2, best ) );
+      v3_store( c_nor2, ic, v3_load( nor2, best ) );
+      w[ic] = ( 1.0f - dist / max_dist ) * dot;          /* :387 dist² over un-squared radius */
+      dists[ic] = dist;                                   /* :388 compaction in place */
+      ic++;
+    }
+  }
+
+  /* :393-402 zero the weight of every correspondence with dist² > 2.5 * stddev(dist²) */
+  float mean = orc_mean( dists, ic );
+  float sd = orc_stddev( mean, dists, ic );
+  if( sd > 0.000001 )
+  {
+    for( int32_t i = 0; i < ic; ++i ) { if( dists[i] > 2.5f * sd ) { w[i] = 0.0; } }
+  }
+
+  free( qpos ); free( qnor ); free( nnb ); free( dists ); free( ind );
+  return ic;
+}
+
+/* :136-148 */
+static v3 weighted_centroid( const float* pts, const float* w, int32_t n )
+{
+  v3 c = v3_make( 0.0f, 0.0f, 0.0f );
+  float total = 0.0f;
+  for( int32_t i = 0; i < n; ++i )
+  {
+    total += w[i];
+    c = v3_add( c, v3_scale( v3_load( pts, i ), w[i] ) );
+  }
+  float inv = 1.0f / total;                     /* msh_vec3_scalar_div, msh_vec_math.h:754-758 */
+  return v3_scale( c, inv );
+}
+
+/* lib/rs/lineqn.h:153-196 (N = 6 takes the general branch) */
+static int ldlt_factor6( double A[6][6], double rdiag[6] )
+{
+  double v[5];
+  for( int i = 0; i < 6; ++i )
+  {
+    for( int k = 0; k < i; ++k ) { v[k] = A[i][k] * rdiag[k]; }
+    for( int j = i; j < 6; ++j )
+    {
+      double sum = A[i][j];
+      for( int k = 0; k < i; ++k ) { sum -= v[k] * A[j][k]; }
+      if( i == j )
+      {
+        if( sum == 0 ) { return 0; }
+        rdiag[i] = 1 / sum;
+      }
+      else { A[j][i] = sum; }
+    }
+  }
+  return 1;
+}
+
+/* lib/rs/lineqn.h:200-218 */
+static void ldlt_solve6( double A[6][6], const double rdiag[6], const double b[6], double x[6] )
+{
+  for( int i = 0; i < 6; ++i )
+  {
+    double sum = b[i];
+    for( int k = 0; k < i; ++k ) { sum -= A[i][k] * x[k]; }
+    x[i] = sum * rdiag[i];
+  }
+  for( int i = 5; i >= 0; --i )
+  {
+    double sum = 0;
+    for( int k = i + 1; k < 6; ++k ) { sum += A[k][i] * x[k]; }
+    x[i] -= sum * rdiag[i];
+  }
+}
+
+/* :210-298 */
+float orc_icp_estimate_pt2pl( const float* p1, const float* p2, const float* n2, const float* w,
+                              int32_t n, float* T1 )
+{
+  v3 c1 = weighted_centroid( p1, w, n );
+  v3 c2 = weighted_centroid( p2, w, n );
+
+  double sum = 0.0, total_weight = 0.0;
+  /* TL/TR/BR as column-major 3x3 float accumulators: M[3*col+row] += (a_row*b_col)*w */
+  float TL[9] = {0}, TR[9] = {0}, BR[9] = {0}, rhs[6] = {0};
+  for( int32_t i = 0; i < n; ++i )
+  {
+    v3 p = v3_sub( v3_load( p1, i ), c1 );
+    v3 q = v3_sub( v3_load( p2, i ), c2 );
+    v3 nn = v3_load( n2, i );
+    float wi = w[i];
+    v3 dd = v3_sub( p, q );
+    v3 c = v3_cross( p, nn );
+    float s = v3_dot( dd, nn );
+    const float cv[3] = { c.x, c.y, c.z }, nv[3] = { nn.x, nn.y, nn.z };
+    for( int col = 0; col < 3; ++col )
+    {
+      for( int row = 0; row < 3; ++row )
+      {
+        TL[3*col + row] = TL[3*col + row] + ( cv[row] * cv[col] ) * wi;
+        TR[3*col + row] = TR[3*col + row] + ( cv[row] * nv[col] ) * wi;
+        BR[3*col + row] = BR[3*col + row] + ( nv[row] * nv[col] ) * wi;
+      }
+    }
+    rhs[0] += wi * c.x * s;  rhs[1] += wi * c.y * s;  rhs[2] += wi * c.z * s;
+    rhs[3] += wi * nn.x * s; rhs[4] += wi * nn.y * s; rhs[5] += wi * nn.z * s;
+    sum += wi * s * s;
+    total_weight += wi;
+  }
+  float err = (float)sqrt( sum / total_weight );
+
+  /* :267-273 — row r<3: [TL(r,0..2) | TR(r,0..2)];  row 3+r: [TR(0..2,r) | BR(r,0..2)] */
+  double C[6][6], b[6], x[6] = {0}, rdiag[6] = {0};
+  for( int r = 0; r < 3; ++r )
+  {
+    for( int c = 0; c < 3; ++c )
+    {
+      C[r][c]       = TL[3*c + r];
+      C[r][3 + c]   = TR[3*c + r];
+      C[3 + r][c]   = TR[3*r + c];
+      C[3 + r][3+c] = BR[3*c + r];
+    }
+  }
+  for( int i = 0; i < 6; ++i ) { b[i] = -rhs[i]; }
+  ldlt_factor6( C, rdiag );        /* return flag ignored, :276 */
+  ldlt_solve6( C, rdiag, b, x );
+
+  /* :280-295 */
+  static const float ident[16] = { 1,0,0,0, 0,1,0,0, 0,0,1,0, 0,0,0,1 };
+  static const float ax_x[3] = { 1, 0, 0 }, ax_y[3] = { 0, 1, 0 }, ax_z[3] = { 0, 0, 1 };
+  float T[16];
+  float t0[3] = { c1.x, c1.y, c1.z };
+  float t1[3] = { (float)x[3], (float)x[4], (float)x[5] };
+  float t2[3] = { -c1.x, -c1.y, -c1.z };
+  orc_translate( ident, t0, T );
+  orc_translate( T, t1, T );
+  orc_rotate( T, (float)x[0], ax_x, T );
+  orc_rotate( T, (float)x[1], ax_y, T );
+  orc_rotate( T, (float)x[2], ax_z, T );
+  orc_translate( T, t2, T );
+  orc_mat4_mul( T, T1, T1 );
+  return err;
+}
+
+/* :416-500 */
+float orc_icp_align( const float* pts1, const float* nor1, int32_t n1,
+                     const float* pts2, const float* nor2, int32_t n2,
+                     float* T1, const float* T2, float max_dist, float max_angle, int32_t* n_iters )
+{
+  orc_grid_t* index2 = orc_grid_create( pts2, n2, max_dist );   /* :437; index1 (:436) is never searched */
+  size_t cap = (size_t)( n1 > 0 ? n1 : 1 );
+  float* cp1 = (float*)malloc( cap * 12 ); float* cn1 = (float*)malloc( cap * 12 );
+  float* cp2 = (float*)malloc( cap * 12 ); float* cn2 = (float*)malloc( cap * 12 );
+  float* cw  = (float*)malloc( cap * 4 );
+
+  float prev_err = 1e6, err = 1e6;
+  int32_t iters = 0;
+  for( int i = 0; i < 100; ++i )
+  {
+    prev_err = err;
+    int32_t nc = orc_icp_find_corrs( pts1, nor1, n1, pts2, nor2, n2, index2, T1, T2, max_dist, max_angle,
+                                     cp1, cn1, cp2, cn2, cw );
+    iters++;
+    if( nc == 0 ) { break; }                                     /* :455-459 */
+    float total_weight = 0.0;
+    for( int32_t j = 0; j < nc; ++j ) { total_weight += cw[j]; }
+    if( total_weight <= 1e-7 ) { break; }                        /* :466-470 */
+
+    err = orc_icp_estimate_pt2pl( cp1, cp2, cn2, cw, nc, T1 );   /* :477 */
+    float delta = fabsf( prev_err - err );
+    if( i > 5 && delta < 1e-5 ) { break; }                       /* :489 */
+    double nd = max_dist * 0.95;                                 /* :493 msh_max( max_dist * 0.95, 0.05 ) */
+    max_dist = (float)( nd > 0.05 ? nd : 0.05 );
+  }
+  if( n_iters ) { *n_iters = iters; }
+  free( cp1 ); free( cn1 ); free( cp2 ); free( cn2 ); free( cw );
+  orc_grid_destroy( index2 );
+  return err;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Alignment score  (apps/pose_proposal/pose_proposal.cpp:93-158, search_lvl = 1)
+ * ---------------------------------------------------------------------------------------- */
+
+void orc_alignment_scores( const orc_grid_t* scene_grid, const float* scene_nor,
+                           const float* obj_pos, const float* obj_nor, int32_t n_obj,
+                           const float* poses, int32_t n_poses, int32_t K, float* scores )
+{
+  const float search_radius = 0.1f;               /* search_radii[1], :98 */
+  const double max_angle = deg2rad( 35.0 );       /* :99 */
+  const double sigma = search_radius;             /* :100 */
+  const double alpha = 0.05, beta = 1.0 - alpha;  /* :102-103 */
+
+  size_t cap = (size_t)( n_obj > 0 ? n_obj : 1 );
+  float* qpos = (float*)malloc( cap * 12 );
+  float* qnor = (float*)malloc( cap * 12 );
+  float* d2 = (float*)malloc( cap * (size_t)K * 4 );
+  int32_t* ix = (int32_t*)malloc( cap * (size_t)K * 4 );
+  int64_t* nn = (int64_t*)malloc( cap * 8 );
+
+  for( int32_t p = 0; p < n_poses; ++p )
+  {
+    const float* X = poses + 16 * p;
+    orc_xform_points( X, obj_pos, n_obj, 1, qpos );            /* :106-112 */
+    orc_xform_points( X, obj_nor, n_obj, 0, qnor );
+    orc_radius_search( scene_grid, qpos, n_obj, search_radius, K, 1, d2, ix, nn );   /* :115-124 */
+
+    double overall = 0.0;
+    for( int32_t i = 0; i < n_obj; ++i )                       /* :127-153 */
+    {
+      double best_d2 = -1.0, best_angle = 0.0;
+      v3 n = v3_load( qnor, i );
+      for( int64_t j = 0; j < nn[i]; ++j )
+      {
+        int32_t k = ix[(size_t)i * (size_t)K + (size_t)j];
+        double dot = v3_dot( v3_load( scene_nor, k ), n );
+        dot = dot > 0.0f ? dot : 0.0f;
+        double angle = acos( dot );
+        if( angle - max_angle < 0.000001 )
+        {
+          best_d2 = d2[(size_t)i * (size_t)K + (size_t)j];
+          best_angle = angle;
+          break;
+        }
+      }
+      if( best_d2 < -0.0001 ) { continue; }
+      double normals_compat = exp( -( best_angle * best_angle ) / ( 2.0 * 0.5 * 0.5 ) );
+      double dist_compat = exp( -best_d2 / ( 2.0 * sigma * sigma ) );        /* :36-40 */
+      overall += alpha * normals_compat + beta * dist_compat;
+    }
+    overall /= (double)n_obj;
+    scores[p] = (float)overall;
+  }
+  free( qpos ); free( qnor ); free( d2 ); free( ix ); free( nn );
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Label transfer  (lib/rs/rs_pointcloud_filters.cpp:724-879)
+ * ---------------------------------------------------------------------------------------- */
+
+/* :738-778 */
+void orc_assign_labels( const float* scene_pos, const float* scene_nor, int32_t n_scene,
+                        const orc_object_t* objects, const orc_placement_t* plc,
+                        int32_t start, int32_t end, float radius, int8_t* labels, float* min_dists )
+{
+  size_t cap = (size_t)( n_scene > 0 ? n_scene : 1 );
+  float* q = (float*)malloc( cap * 12 );
+  float* d2 = (float*)malloc( cap * 4 );
+  int32_t* ix = (int32_t*)malloc( cap * 4 );
+  int64_t* nn = (int64_t*)malloc( cap * 8 );
+
+  for( int32_t i = start; i < end; ++i )
+  {
+    const orc_object_t* obj = &objects[plc[i].object_idx];
+    float inv[16], nmat[16];
+    orc_mat4_inverse( plc[i].pose, inv );
+    orc_mat4_transpose( plc[i].pose, nmat );
+    orc_xform_points( inv, scene_pos, n_scene, 1, q );                              /* :753-756 */
+    orc_radius_search( obj->grid, q, n_scene, radius, 1, 0, d2, ix, nn );            /* :758, sort = 0 */
+
+    for( int32_t j = 0; j < n_scene; ++j )                                           /* :760-776 */
+    {
+      if( nn[j] > 0 && d2[j] < min_dists[j] )
+      {
+        v3 n1 = m4_apply( nmat, v3_load( scene_nor, j ), 0 );
+        v3 n2 = v3_load( obj->nor, ix[j] );
+        float dot = v3_dot( v3_unit( n1 ), v3_unit( n2 ) );
+        if( orc_label_gate( dot ) )
+        {
+          min_dists[j] = d2[j];
+          labels[j] = (int8_t)( i + 1 );
+        }
+      }
+    }
+  }
+  free( q ); free( d2 ); free( ix ); free( nn );
+}
+
+typedef struct { orc_placement_t p; int32_t key; int32_t orig; } plc_sort_rec;
+
+/* :724-736: the comparator returns (static_a<<10 | class_a) - (static_b<<10 | class_b) */
+static int plc_cmp( const void* a, const void* b )
+{
+  return ((const plc_sort_rec*)a)->key - ((const plc_sort_rec*)b)->key;
+}
+
+/* :780-879 */
+void orc_arrangement_to_labels( const float* scene_pos, const float* scene_nor, int32_t n_scene,
+                                const orc_object_t* objects, const orc_placement_t* placements, int32_t n_plc,
+                                float radius, int prioritize_static, int32_t unlabelled_class_idx,
+                                int8_t* labels, float* min_dists, int32_t* sorted_order,
+                                int32_t* class_ids, int32_t* instance_ids )
+{
+  for( int32_t i = 0; i < n_scene; ++i ) { labels[i] = 0; min_dists[i] = 1e9; }      /* :799-802, :820 */
+
+  /* :823-827 libc qsort of a copy (glibc's qsort is a stable merge sort when it can
+   * allocate its scratch buffer, so equal keys keep their arrangement order) */
+  plc_sort_rec* rec = (plc_sort_rec*)malloc( (size_t)( n_plc > 0 ? n_plc : 1 ) * sizeof(plc_sort_rec) );
+  for( int32_t i = 0; i < n_plc; ++i )
+  {
+    const orc_object_t* o = &objects[placements[i].object_idx];
+    rec[i].p = placements[i];
+    rec[i].key = ( o->is_static << 10 ) | o->class_idx;
+    rec[i].orig = i;
+  }
+  qsort( rec, (size_t)n_plc, sizeof(plc_sort_rec), plc_cmp );
+  orc_placement_t* sorted = (orc_placement_t*)malloc( (size_t)( n_plc > 0 ? n_plc : 1 ) * sizeof(orc_placement_t) );
+  for( int32_t i = 0; i < n_plc; ++i ) { sorted[i] = rec[i].p; if( sorted_order ) { sorted_order[i] = rec[i].orig; } }
+
+  /* :830-835 index of the first static placement, 0 when there is none */
+  int32_t first_static = 0;
+  for( int32_t i = 0; i < n_plc; ++i )
+  {
+    if( objects[sorted[i].object_idx].is_static ) { first_static = i; break; }
+  }
+
+  orc_assign_labels( scene_pos, scene_nor, n_scene, objects, sorted, 0, first_static, radius, labels, min_dists );   /* :837-839 */
+  if( prioritize_static ) { for( int32_t i = 0; i < n_scene; ++i ) { min_dists[i] = 1e9; } }                           /* :841-844 */
+  float radius2 = prioritize_static ? radius : 1.5f * radius;                                                          /* :845 */
+  orc_assign_labels( scene_pos, scene_nor, n_scene, objects, sorted, first_static, n_plc, radius2, labels, min_dists ); /* :846-848 */
+
+  /* :851-869 */
+  for( int32_t i = 0; i < n_scene; ++i )
+  {
+    if( labels[i] == 0 )
+    {
+      if( class_ids ) { class_ids[i] = unlabelled_class_idx; }
+      if( instance_ids ) { instance_ids[i] = 1024; }             /* RSPF_MAX_INSTANCES, :20 */
+    }
+    else
+    {
+      const orc_placement_t* pl = &sorted[labels[i] - 1];
+      if( class_ids ) { class_ids[i] = objects[pl->object_idx].class_idx; }
+      if( instance_ids ) { instance_ids[i] = pl->uidx; }
+    }
+  }
+  free( sorted ); free( rec );
+}

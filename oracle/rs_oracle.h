@@ -1,0 +1,107 @@
+/* TEST INFRASTRUCTURE — NOT PRODUCT CODE.
+ *
+ * rs_oracle: a plain-C, single-threaded CPU restatement of the Rescan hot path
+ * (bounded-K radius search, point-to-plane ICP, alignment score, label
+ * transfer), written from the reference's behaviour, each function citing the
+ * reference file:line it follows (paths relative to /root/reference).
+ *
+ * Parity status: PINNED.  tests/test_oracle_vs_ref.py checks every function
+ * here bit-for-bit against oracle/_ref (the real reference compiled in place)
+ * on seeded inputs when /root/reference is present, and tests/golden/ holds
+ * vectors generated from oracle/_ref by oracle/gen_golden.py.  One exception:
+ * the *composition* of the label loop (lib/rs/rs_pointcloud_filters.cpp:738-879)
+ * is restated but not run against the reference, because that TU needs the
+ * un-vendored gco-v3.0 header; all primitives it calls (K=1 radius search,
+ * mat4 inverse/transpose/mat·vec, normalise, the acosf gate) are pinned.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use
+ * this library.  The product (rescan_amd/, include/) never links or loads it.
+ */
+#ifndef RS_ORACLE_H
+#define RS_ORACLE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_grid orc_grid_t;
+
+/* lib/msh/msh_hash_grid.h:388-541 (dim = 3) */
+orc_grid_t* orc_grid_create( const float* pts, int32_t n_pts, float radius );
+void        orc_grid_destroy( orc_grid_t* g );
+void        orc_grid_info( const orc_grid_t* g, int64_t dims[3], double* cell, float minp[3], uint32_t* max_in_bin );
+
+/* lib/msh/msh_hash_grid.h:1090-1259; nn[] is int64 (reference: size_t) */
+uint64_t orc_radius_search( const orc_grid_t* g, const float* query, int64_t nq, float radius,
+                            int64_t k, int sort, float* dists, int32_t* inds, int64_t* nn );
+
+/* lib/msh/msh_vec_math.h:1441,1554,1818,1938,2064,2089,868 — column-major float[16] */
+void orc_mat4_mul( const float* a, const float* b, float* out );
+void orc_mat4_inverse( const float* m, float* out );
+void orc_mat4_transpose( const float* m, float* out );
+void orc_translate( const float* m, const float* t, float* out );
+void orc_rotate( const float* m, float angle, const float* axis, float* out );
+void orc_xform_points( const float* m, const float* in, int64_t n, int is_point, float* out );
+void orc_normalize( const float* in, int64_t n, float* out );
+float orc_mean( const float* v, int n );                 /* lib/msh/msh_std.h:1811-1816 */
+float orc_stddev( float mean, const float* v, int n );   /* lib/msh/msh_std.h:1820-1825 */
+
+/* lib/rs/icp.h:306-412; output arrays have capacity n1; returns n_corrs */
+int32_t orc_icp_find_corrs( const float* pts1, const float* nor1, int32_t n1,
+                            const float* pts2, const float* nor2, int32_t n2, const orc_grid_t* index2,
+                            const float* T1, const float* T2, float max_dist, float max_angle,
+                            float* c_pts1, float* c_nor1, float* c_pts2, float* c_nor2, float* w );
+/* lib/rs/icp.h:210-298 */
+float orc_icp_estimate_pt2pl( const float* p1, const float* p2, const float* n2, const float* w,
+                              int32_t n, float* T1 );
+/* lib/rs/icp.h:416-500; n_iters (optional) receives the number of find_corrs calls made */
+float orc_icp_align( const float* pts1, const float* nor1, int32_t n1,
+                     const float* pts2, const float* nor2, int32_t n2,
+                     float* T1, const float* T2, float max_dist, float max_angle, int32_t* n_iters );
+
+/* apps/pose_proposal/pose_proposal.cpp:93-158 with search_lvl = 1 (radius 0.1, sigma 0.1);
+ * scene_grid must have been built with radius 0.05 (lib/rs/rs_pointcloud.h:862). */
+void orc_alignment_scores( const orc_grid_t* scene_grid, const float* scene_nor,
+                           const float* obj_pos, const float* obj_nor, int32_t n_obj,
+                           const float* poses, int32_t n_poses, int32_t max_n_neigh, float* scores );
+
+/* lib/rs/rs_pointcloud_filters.cpp:724-879 on raw arrays.
+ * placements: pose (16 floats each), object index, uidx; objects: level-1 cloud + grid
+ * (radius 0.05), class idx, static flag.  Outputs: labels (int8, 1-based index into the
+ * *sorted* arrangement, 0 = none), min_dists, sorted_order (permutation applied by the
+ * qsort at :826), class_ids / instance_ids per scene point (:851-869). */
+typedef struct orc_object
+{
+  const float* pos; const float* nor; int32_t n; const orc_grid_t* grid;
+  int32_t class_idx; int32_t is_static;
+} orc_object_t;
+
+typedef struct orc_placement
+{
+  float pose[16]; int32_t object_idx; int32_t uidx;
+} orc_placement_t;
+
+void orc_arrangement_to_labels( const float* scene_pos, const float* scene_nor, int32_t n_scene,
+                                const orc_object_t* objects, const orc_placement_t* placements, int32_t n_plc,
+                                float radius, int prioritize_static, int32_t unlabelled_class_idx,
+                                int8_t* labels, float* min_dists, int32_t* sorted_order,
+                                int32_t* class_ids, int32_t* instance_ids );
+
+/* One rspf__assign_temporary_labels pass (:738-778) over placements [start,end) of an
+ * already-ordered arrangement. */
+void orc_assign_labels( const float* scene_pos, const float* scene_nor, int32_t n_scene,
+                        const orc_object_t* objects, const orc_placement_t* placements,
+                        int32_t start, int32_t end, float radius, int8_t* labels, float* min_dists );
+
+/* The three normal gates, on a raw dot value (for threshold pinning). */
+int orc_icp_gate( float dot, float max_angle );    /* lib/rs/icp.h:372-374 */
+int orc_score_gate( float dot );                   /* pose_proposal.cpp:138-141 */
+int orc_label_gate( float dot );                   /* rs_pointcloud_filters.cpp:769-770 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif
