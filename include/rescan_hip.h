@@ -1,0 +1,168 @@
+/* rescan_hip.h — C ABI of librescan_hip.so, the MI355X (gfx950) implementation of Rescan's
+ * per-scan geometric hot path.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Every entry point names the reference interface it replaces (paths relative to the
+ * reference tree, mhalber/Rescan).  Matrices are column-major float[16] exactly like
+ * msh_mat4_t (lib/msh/msh_vec_math.h:187-191); point arrays are AoS float[3*n] exactly like
+ * msh_vec3_t* (lib/msh/msh_vec_math.h:159-164).
+ *
+ * Return convention: functions returning int give 0 on success and a negative RS_HIP_E_*
+ * code otherwise; rs_hip_last_error() describes the failure.  There is NO CPU fallback:
+ * without a usable HIP device every compute entry point fails with RS_HIP_E_NODEVICE.
+ */
+#ifndef RESCAN_HIP_H
+#define RESCAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RS_HIP_OK            0
+#define RS_HIP_E_NODEVICE   -1   /* no HIP device / runtime error at init */
+#define RS_HIP_E_ARG        -2   /* bad argument */
+#define RS_HIP_E_RUNTIME    -3   /* HIP runtime error during the call */
+#define RS_HIP_E_CAPACITY   -4   /* problem exceeds a documented limit */
+
+/* ---- runtime ----------------------------------------------------------------------- */
+
+/* Bind the calling process to HIP device `device` (one process per GPU). */
+int         rs_hip_init( int device );
+const char* rs_hip_last_error( void );
+/* Use an existing hipStream_t (e.g. torch's current stream) for all launches; NULL = the
+ * library's own stream. */
+int         rs_hip_set_stream( void* hip_stream );
+int         rs_hip_synchronize( void );
+/* ABI/version string, e.g. "rescan_hip 0.1 gfx950". */
+const char* rs_hip_version( void );
+
+/* Per-kernel timing with HIP events recorded on the launch stream.  While enabled, each
+ * launch of a hot kernel is bracketed by an event pair; rs_hip_profile_read() synchronises
+ * and returns launch count and summed milliseconds for kernel `name`
+ * ("nn_icp", "icp_moments", "nn_score", "nn_label", "nn_rows"). */
+int         rs_hip_profile_enable( int on );
+int         rs_hip_profile_reset( void );
+int         rs_hip_profile_read( const char* name, int64_t* launches, double* total_ms );
+
+/* ---- device-resident clouds -------------------------------------------------------- */
+
+/* A cloud = positions (+ optional normals) laid out in HBM as 16-byte records
+ * {x,y,z,orig_index} sorted by uniform-grid cell, plus the cell offset table: the device
+ * counterpart of a cloud level and its msh_hash_grid_t
+ * (lib/rs/rs_pointcloud.h:77-97,849-863; lib/msh/msh_hash_grid.h:248-269,388-541).
+ * cell_size > 0 : grid cell edge in metres (msh_hash_grid uses 2*radius; any value gives the
+ *                 same search results, it only changes speed).
+ * cell_size <= 0: one cell holding everything ("brute-tile" layout). */
+typedef struct rs_hip_cloud rs_hip_cloud_t;
+
+rs_hip_cloud_t* rs_hip_cloud_create( const float* pos, const float* nor /* may be NULL */,
+                                     int32_t n, float cell_size );
+void            rs_hip_cloud_destroy( rs_hip_cloud_t* c );
+int32_t         rs_hip_cloud_size( const rs_hip_cloud_t* c );
+/* bytes of HBM held by the cloud */
+int64_t         rs_hip_cloud_bytes( const rs_hip_cloud_t* c );
+
+/* ---- bounded-K radius search ------------------------------------------------------- */
+
+/* msh_hash_grid_radius_search (lib/msh/msh_hash_grid.h:1090-1259): for every query the
+ * (at most) k nearest target points with dist² < radius², row-major rows of stride k.
+ * Rows are always written in ascending (dist², index) order (the reference sorts when
+ * search_desc.sort != 0 and leaves heap order otherwise; ascending is a valid answer to
+ * both).  n_neighbors may be NULL.  Host pointers in, host pointers out.
+ * Returns the total neighbour count through *total (may be NULL). */
+int rs_hip_radius_search( const rs_hip_cloud_t* target, const float* query, int64_t n_query,
+                          float radius, int32_t k,
+                          float* distances_sq, int32_t* indices, size_t* n_neighbors,
+                          uint64_t* total );
+
+/* ---- point-to-plane ICP ------------------------------------------------------------- */
+
+/* icp_align (lib/rs/icp.h:416-500): aligns T1*source to T2*target; *T1 is updated in place,
+ * the last RMS error is returned through *err (1e6 if no iteration produced one).
+ * `source` and `target` must have normals.  max_iter: the reference uses 100.
+ * fixed_iters != 0 disables the convergence test at icp.h:489 (benchmark mode).
+ * n_iters (may be NULL) receives the number of correspondence searches made. */
+int rs_hip_icp_align( const rs_hip_cloud_t* source, const rs_hip_cloud_t* target,
+                      float* T1, const float* T2, float max_dist, float max_angle,
+                      int32_t max_iter, int32_t fixed_iters, float* err, int32_t* n_iters );
+
+/* Many independent icp_align problems of one (source, target) pair, one per start pose
+ * (apps/pose_proposal/main.cpp:190-202 runs exactly this loop): T1s is float[16*n], errs
+ * float[n], iters int32[n] (may be NULL).  All problems advance in lock-step launches. */
+int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* target,
+                            float* T1s, int32_t n, const float* T2, float max_dist, float max_angle,
+                            int32_t max_iter, int32_t fixed_iters, float* errs, int32_t* iters );
+
+/* icp_find_corrs (lib/rs/icp.h:306-412), one call: compacted correspondences in source
+ * order.  Output arrays are caller-allocated with capacity 3*n_source floats (weights:
+ * n_source); *n_corrs receives the count. */
+int rs_hip_icp_find_corrs( const rs_hip_cloud_t* source, const rs_hip_cloud_t* target,
+                           const float* T1, const float* T2, float max_dist, float max_angle,
+                           float* corr_pts1, float* corr_nor1, float* corr_pts2, float* corr_nor2,
+                           float* weights, int32_t* n_corrs );
+
+/* ---- alignment score ---------------------------------------------------------------- */
+
+/* mgs_compute_object_alignment_score (apps/pose_proposal/pose_proposal.cpp:93-158) for
+ * n_poses poses at once: scores[p] = score of `object` placed by poses[16*p..] against
+ * `scene`.  radius = search_radii[search_lvl] (0.1 at the reference's search_lvl = 1, also
+ * used as the distance sigma), max_n_neigh = 64 (proposal/verification) or 32 (refinement). */
+int rs_hip_alignment_scores( const rs_hip_cloud_t* object, const rs_hip_cloud_t* scene,
+                             const float* poses, int32_t n_poses, float radius, int32_t max_n_neigh,
+                             float* scores );
+
+/* ---- label transfer ----------------------------------------------------------------- */
+
+typedef struct rs_hip_placement
+{
+  float                 pose[16];   /* rs_obj_plcmnt_t.pose */
+  const rs_hip_cloud_t* object;     /* the placed object's level-1 cloud */
+  float                 radius;     /* search radius for this placement */
+} rs_hip_placement_t;
+
+/* rspf__assign_temporary_labels (lib/rs/rs_pointcloud_filters.cpp:738-778) over
+ * placements[0..n) in the given order, continuing from the caller's labels / min_dists
+ * (int8 / float, length = scene size, scene input order).  labels[j] receives
+ * label_base + i + 1 for the winning placement i. */
+int rs_hip_assign_labels( const rs_hip_cloud_t* scene, const rs_hip_placement_t* placements,
+                          int32_t n, int32_t label_base, int8_t* labels, float* min_dists );
+
+/* The per-placement "unary cost rows" of the same loop, for sharding placements across
+ * GPUs: rows[i*scene_n + j] = dist² of scene point j to placement i's nearest object point
+ * if one lies within the radius AND passes the 70° normal gate, +inf otherwise.
+ * rows_device != 0: `rows` is a device pointer (e.g. a torch tensor that will be
+ * all-gathered); otherwise a host pointer. */
+int rs_hip_label_rows( const rs_hip_cloud_t* scene, const rs_hip_placement_t* placements,
+                       int32_t n, float* rows, int rows_device );
+
+/* Ordered arg-min over gathered rows, host side: applies rows 0..n-1 in order with the
+ * strict `<` of rs_pointcloud_filters.cpp:763 (earlier placement wins ties). */
+void rs_hip_combine_label_rows( const float* rows, int32_t n_rows, int64_t scene_n, int32_t label_base,
+                                int8_t* labels, float* min_dists );
+
+/* rspf_arrangement_to_labels ordering + two passes (lib/rs/rs_pointcloud_filters.cpp:780-848):
+ * sorts placement indices (dynamic first, then by class index; stable), runs the dynamic
+ * pass with `radius` and the static pass with 1.5*radius (or resets min_dists when
+ * prioritize_static).  is_static / class_idx are per placement.  sorted_order (may be NULL)
+ * receives the permutation; labels index into the sorted order, 1-based, 0 = unlabelled. */
+int rs_hip_arrangement_to_labels( const rs_hip_cloud_t* scene,
+                                  const float* poses /* 16*n */, const rs_hip_cloud_t* const* objects /* n */,
+                                  const int32_t* is_static, const int32_t* class_idx, int32_t n,
+                                  float radius, int prioritize_static,
+                                  int8_t* labels, float* min_dists, int32_t* sorted_order );
+
+/* ---- host-side helpers shared by the drop-in shim (exact reference arithmetic) ------- */
+
+/* msh_mat4_inverse / msh_mat4_mul (lib/msh/msh_vec_math.h:1818-1905, 1441-1476) */
+void rs_hip_mat4_inverse( const float* m, float* out );
+void rs_hip_mat4_mul( const float* a, const float* b, float* out );
+/* icp_estimate_rigid_xform_pt2pl (lib/rs/icp.h:210-298) on host arrays (device reduction) */
+int  rs_hip_icp_estimate_pt2pl( const float* pts1, const float* pts2, const float* nor2,
+                                const float* weights, int32_t n, float* T1, float* err );
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RESCAN_HIP_H */

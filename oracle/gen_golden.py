@@ -1,0 +1,150 @@
+"""TEST INFRASTRUCTURE.  Generates tests/golden/*.npz from oracle/_ref — the real reference
+compiled in place from /root/reference (run in the build container only; the fixtures are
+committed so the GPU box, which has no /root/reference, can check against them).
+
+Each fixture holds the inputs and the reference's outputs for one hot-path function:
+
+  rows_*.npz     msh_hash_grid_radius_search rows (lib/msh/msh_hash_grid.h:1090-1259)
+  corrs_*.npz    one icp_find_corrs call (lib/rs/icp.h:306-412)
+  icp_*.npz      icp_align final pose + error (lib/rs/icp.h:416-500) for the three call-site
+                 parameter sets (pose_proposal main.cpp:195, rs_database.h:227, database_update.cpp:65)
+  scores_*.npz   mgs_compute_object_alignment_score for a list of poses (pose_proposal.cpp:93-158)
+  mat4.npz       msh_mat4_inverse / msh_mat4_mul / msh_translate / msh_rotate samples
+  gates.npz      accept/reject of the label normal gate over a sweep of dot values
+  labels_*.npz   rspf_arrangement_to_labels — produced by the C restatement (oracle/rs_oracle.c),
+                 NOT by the reference: lib/rs/rs_pointcloud_filters.cpp needs the un-vendored gco
+                 header and cannot be built here.  Its primitives are pinned by the files above.
+
+Usage:  python oracle/gen_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle.pyoracle import Oracle, Ref, build  # noqa: E402
+from rescan_amd import synth  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+I4 = np.eye(4, dtype=np.float32).ravel()
+
+
+def scene_small(seed=7, density=1200.0, timestep=1):
+    return synth.make_scene(seed=seed, density=density, timestep=timestep)
+
+
+def main():
+    build(ref=True)
+    R = Ref()
+    O = Oracle()
+    os.makedirs(OUT, exist_ok=True)
+    rng = np.random.default_rng(2024)
+    s = scene_small()
+    pts, nor = s["points"], s["normals"]
+    # the shared inputs are stored once: scene scan + the objects' model clouds and poses
+    np.savez_compressed(os.path.join(OUT, "scene.npz"), points=pts, normals=nor, instance_idx=s["instance_idx"],
+                        class_idx=s["class_idx"], n_obj=len(s["objects"]),
+                        **{f"obj{i}_pos": o["pos"] for i, o in enumerate(s["objects"])},
+                        **{f"obj{i}_nor": o["nor"] for i, o in enumerate(s["objects"])},
+                        obj_pose=np.stack([o["pose"] for o in s["objects"]]),
+                        obj_class=np.array([o["class_idx"] for o in s["objects"]], np.int32),
+                        obj_uidx=np.array([o["uidx"] for o in s["objects"]], np.int32))
+
+    # ---- radius-search rows --------------------------------------------------------
+    cases = [("k1_r005", 0.05, 1, 0.05), ("k16_r010", 0.10, 16, 0.10), ("k16_r006", 0.10, 16, 0.06),
+             ("k64_r010", 0.05, 64, 0.10), ("k8_r005", 0.05, 8, 0.05), ("k1_r0075", 0.05, 1, 0.075)]
+    for name, grid_radius, k, r in cases:
+        q = pts[rng.integers(0, len(pts), 1500)] + rng.normal(0, 0.02, (1500, 3)).astype(np.float32)
+        q[:40] += 5.0                      # outside the grid
+        q[40:80] -= np.float32(0.3)        # straddling the lower corner (negative grid coordinates)
+        g = R.grid_create(pts, grid_radius)
+        d, i, nn, tot = R.radius_search(g, q, r, k, 1)
+        R.grid_destroy(g)
+        np.savez_compressed(os.path.join(OUT, f"rows_{name}.npz"), query=q.astype(np.float32),
+                            grid_radius=np.float32(grid_radius), radius=np.float32(r), k=k,
+                            dists=d, inds=i, nn=nn, total=tot)
+
+    # ---- ICP -----------------------------------------------------------------------
+    params = [("pp", 0.10, 60.0), ("refine", 0.075, 50.0), ("fuse", 0.05, 10.0)]
+    for oi, o in enumerate(s["objects"]):
+        T0 = synth.perturbed_pose(o["pose"], rng)
+        for pname, md, deg in params:
+            ma = np.float32(np.deg2rad(np.float32(deg)))
+            c = R.icp_find_corrs(o["pos"], o["nor"], pts, nor, T0, I4, md, ma)
+            np.savez_compressed(os.path.join(OUT, f"corrs_{o['kind']}{oi}_{pname}.npz"),
+                                obj=oi, T1=T0, T2=I4,
+                                max_dist=np.float32(md), max_angle=ma,
+                                c_pts1=c[0], c_nor1=c[1], c_pts2=c[2], c_nor2=c[3], weights=c[4])
+            err, T, _ = R.icp_align(o["pos"], o["nor"], pts, nor, T0, I4, md, ma)
+            _, _, iters = O.icp_align(o["pos"], o["nor"], pts, nor, T0, I4, md, ma)
+            np.savez_compressed(os.path.join(OUT, f"icp_{o['kind']}{oi}_{pname}.npz"),
+                                obj=oi, T1=T0, T2=I4,
+                                max_dist=np.float32(md), max_angle=ma, err=np.float32(err), T_out=T, iters=iters)
+
+    # ---- scores --------------------------------------------------------------------
+    for oi, o in enumerate(s["objects"]):
+        poses = np.stack([synth.perturbed_pose(o["pose"], rng, 0.5, 0.15) for _ in range(30)] + [o["pose"]] +
+                         [synth.pose_matrix(a, (1.0 + 0.3 * a, 0.0, 2.0)) for a in (0.0, 1.0, 2.0)])
+        for K in (64, 32):
+            sc = R.alignment_scores(pts, nor, o["pos"], o["nor"], poses, K)
+            np.savez_compressed(os.path.join(OUT, f"scores_{o['kind']}{oi}_k{K}.npz"), obj=oi, poses=poses, k=K, scores=sc)
+
+    # ---- matrix helpers ------------------------------------------------------------
+    ms = rng.normal(size=(64, 16)).astype(np.float32)
+    ms[:8] = [synth.pose_matrix(a, rng.normal(size=3)) for a in rng.uniform(0, 6.28, 8)]
+    bs = rng.normal(size=(64, 16)).astype(np.float32)
+    ts = rng.normal(size=(64, 3)).astype(np.float32)
+    ang = rng.normal(size=64).astype(np.float32)
+    axes = np.tile(np.eye(3, dtype=np.float32), (22, 1))[:64]
+    np.savez_compressed(os.path.join(OUT, "mat4.npz"), m=ms, b=bs, t=ts, angle=ang, axis=axes,
+                        inverse=np.stack([R.mat4_inverse(m) for m in ms]),
+                        mul=np.stack([R.mat4_mul(m, b) for m, b in zip(ms, bs)]),
+                        translate=np.stack([R.translate(m, t) for m, t in zip(ms, ts)]),
+                        rotate=np.stack([R.rotate(m, a, ax) for m, a, ax in zip(ms, ang, axes)]))
+
+    # ---- label gate ----------------------------------------------------------------
+    c70 = np.float32(np.cos(np.deg2rad(70.0)))
+    xs = np.concatenate([np.linspace(-1.1, 1.1, 401).astype(np.float32),
+                         np.array([np.nextafter(c70, np.float32(0)), c70, np.nextafter(c70, np.float32(1))], np.float32)])
+    for _ in range(12):
+        xs = np.concatenate([xs, np.nextafter(xs[-3:], np.float32(1)), np.nextafter(xs[-6:-3], np.float32(0))])
+    np.savez_compressed(os.path.join(OUT, "gates.npz"), dot=xs,
+                        label_accept=np.array([R.label_gate_dot(x) for x in xs], np.int8))
+
+    # ---- labels (restatement; see module docstring) ---------------------------------
+    for tag, with_static in (("mixed", True), ("nostatic", False)):
+        objs = []
+        plcs = []
+        for oi, o in enumerate(s["objects"]):
+            objs.append(dict(pos=o["pos"], nor=o["nor"], class_idx=o["class_idx"], is_static=0))
+            plcs.append(dict(pose=synth.perturbed_pose(o["pose"], rng, 0.02, 0.01), object_idx=oi, uidx=o["uidx"]))
+        if with_static:
+            for cls_name, inst in (("floor", 0), ("wall", 1)):
+                m = s["instance_idx"] == inst
+                sub = rng.permutation(np.nonzero(m)[0])[::2]
+                objs.append(dict(pos=pts[sub], nor=nor[sub], class_idx=synth.CLASS_IDX[cls_name], is_static=1, sub=sub))
+                plcs.append(dict(pose=I4, object_idx=len(objs) - 1, uidx=inst))
+        order = rng.permutation(len(plcs))
+        plcs = [plcs[i] for i in order]
+        res = O.arrangement_to_labels(pts, nor, objs, plcs, 0.05, 0, 0)
+        np.savez_compressed(
+            os.path.join(OUT, f"labels_{tag}.npz"),
+            n_obj=len(objs), n_plc=len(plcs),
+            # objects beyond the scene's own are subsets of the scan, stored as index lists
+            **{f"obj{i}_sub": o["sub"].astype(np.int32) for i, o in enumerate(objs) if "sub" in o},
+            obj_class=np.array([o["class_idx"] for o in objs], np.int32),
+            obj_static=np.array([o["is_static"] for o in objs], np.int32),
+            plc_pose=np.stack([np.asarray(p["pose"], np.float32) for p in plcs]),
+            plc_obj=np.array([p["object_idx"] for p in plcs], np.int32),
+            plc_uidx=np.array([p["uidx"] for p in plcs], np.int32),
+            labels=res["labels"], min_dists=res["min_dists"], order=res["order"],
+            class_ids=res["class_ids"], instance_ids=res["instance_ids"])
+
+    total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
+    print(f"wrote {len(os.listdir(OUT))} fixtures, {total/1e6:.2f} MB")
+
+
+if __name__ == "__main__":
+    main()

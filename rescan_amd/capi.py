@@ -1,0 +1,262 @@
+"""ctypes binding of include/rescan_hip.h (librescan_hip.so) and a thin Python mirror of the
+reference's operator names for the hot path (icp_align, alignment scores, arrangement_to_labels).
+
+There is deliberately no CPU fallback here: if the HIP extension is missing, or no HIP device
+is usable, every call raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "librescan_hip.so")
+
+f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+i8p = np.ctypeslib.ndpointer(np.int8, flags="C_CONTIGUOUS")
+u64p = np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")
+
+# name -> (restype, argtypes); kept in one table so the symbol test can walk it.
+SIGNATURES = {
+    "rs_hip_init": (C.c_int, [C.c_int]),
+    "rs_hip_last_error": (C.c_char_p, []),
+    "rs_hip_set_stream": (C.c_int, [C.c_void_p]),
+    "rs_hip_synchronize": (C.c_int, []),
+    "rs_hip_version": (C.c_char_p, []),
+    "rs_hip_profile_enable": (C.c_int, [C.c_int]),
+    "rs_hip_profile_reset": (C.c_int, []),
+    "rs_hip_profile_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "rs_hip_cloud_create": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_int32, C.c_float]),
+    "rs_hip_cloud_destroy": (None, [C.c_void_p]),
+    "rs_hip_cloud_size": (C.c_int32, [C.c_void_p]),
+    "rs_hip_cloud_bytes": (C.c_int64, [C.c_void_p]),
+    "rs_hip_radius_search": (C.c_int, [C.c_void_p, f32p, C.c_int64, C.c_float, C.c_int32, f32p, i32p, u64p,
+                                       C.POINTER(C.c_uint64)]),
+    "rs_hip_icp_align": (C.c_int, [C.c_void_p, C.c_void_p, f32p, f32p, C.c_float, C.c_float, C.c_int32, C.c_int32,
+                                   C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
+    "rs_hip_icp_align_batch": (C.c_int, [C.c_void_p, C.c_void_p, f32p, C.c_int32, f32p, C.c_float, C.c_float,
+                                         C.c_int32, C.c_int32, f32p, i32p]),
+    "rs_hip_icp_find_corrs": (C.c_int, [C.c_void_p, C.c_void_p, f32p, f32p, C.c_float, C.c_float,
+                                        f32p, f32p, f32p, f32p, f32p, C.POINTER(C.c_int32)]),
+    "rs_hip_alignment_scores": (C.c_int, [C.c_void_p, C.c_void_p, f32p, C.c_int32, C.c_float, C.c_int32, f32p]),
+    "rs_hip_assign_labels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, i8p, f32p]),
+    "rs_hip_label_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int]),
+    "rs_hip_combine_label_rows": (None, [f32p, C.c_int32, C.c_int64, C.c_int32, i8p, f32p]),
+    "rs_hip_arrangement_to_labels": (C.c_int, [C.c_void_p, f32p, C.c_void_p, i32p, i32p, C.c_int32, C.c_float,
+                                               C.c_int, i8p, f32p, i32p]),
+    "rs_hip_mat4_inverse": (None, [f32p, f32p]),
+    "rs_hip_mat4_mul": (None, [f32p, f32p, f32p]),
+    "rs_hip_icp_estimate_pt2pl": (C.c_int, [f32p, f32p, f32p, f32p, C.c_int32, f32p, C.POINTER(C.c_float)]),
+}
+
+
+class RescanHipError(RuntimeError):
+    pass
+
+
+class Placement(C.Structure):
+    _fields_ = [("pose", C.c_float * 16), ("object", C.c_void_p), ("radius", C.c_float)]
+
+
+_lib = None
+
+
+def load():
+    """dlopen librescan_hip.so and attach signatures.  Raises if the extension was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RescanHipError(
+            f"{LIB_PATH} is missing: build it with `python -m rescan_amd.build` "
+            "(there is no CPU fallback for the hot path)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise RescanHipError(f"librescan_hip error {rc}: {load().rs_hip_last_error().decode()}")
+
+
+def init(device=0):
+    _check(load().rs_hip_init(int(device)))
+
+
+def set_stream(stream_handle):
+    _check(load().rs_hip_set_stream(C.c_void_p(stream_handle) if stream_handle else None))
+
+
+def synchronize():
+    _check(load().rs_hip_synchronize())
+
+
+def profile_enable(on=True):
+    load().rs_hip_profile_enable(1 if on else 0)
+
+
+def profile_reset():
+    load().rs_hip_profile_reset()
+
+
+def profile_read(name):
+    n = C.c_int64(); ms = C.c_double()
+    load().rs_hip_profile_read(name.encode(), C.byref(n), C.byref(ms))
+    return n.value, ms.value
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+IDENTITY = np.eye(4, dtype=np.float32).ravel()
+
+
+class Cloud:
+    """A device-resident cloud level + its grid index (rs_hip_cloud_t)."""
+
+    def __init__(self, pos, nor=None, cell_size=0.1):
+        lib = load()
+        pos = _f32(pos).reshape(-1, 3)
+        self.n = len(pos)
+        self._pos = pos
+        self._nor = None if nor is None else _f32(nor).reshape(-1, 3)
+        self.handle = lib.rs_hip_cloud_create(
+            pos.ctypes.data_as(C.c_void_p),
+            None if self._nor is None else self._nor.ctypes.data_as(C.c_void_p),
+            self.n, float(cell_size))
+        if not self.handle:
+            raise RescanHipError("rs_hip_cloud_create failed: " + lib.rs_hip_last_error().decode())
+
+    @property
+    def nbytes(self):
+        return load().rs_hip_cloud_bytes(self.handle)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            load().rs_hip_cloud_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def radius_search(target, query, radius, k):
+    """msh_hash_grid_radius_search: rows of the k nearest within radius, ascending."""
+    query = _f32(query).reshape(-1, 3)
+    nq = len(query)
+    d = np.zeros((nq, k), np.float32); i = np.zeros((nq, k), np.int32); nn = np.zeros(nq, np.uint64)
+    tot = C.c_uint64()
+    _check(load().rs_hip_radius_search(target.handle, query, nq, float(radius), int(k), d, i, nn, C.byref(tot)))
+    return d, i, nn.astype(np.int64), tot.value
+
+
+def icp_align(source, target, T1, T2=IDENTITY, max_dist=0.1, max_angle=np.deg2rad(60.0), max_iter=100,
+              fixed_iters=False):
+    """icp_align (lib/rs/icp.h:416-500).  Returns (err, T1_new, n_iters)."""
+    T = _f32(T1).ravel().copy()
+    err = C.c_float(); it = C.c_int32()
+    _check(load().rs_hip_icp_align(source.handle, target.handle, T, _f32(T2).ravel(), float(max_dist),
+                                   float(np.float32(max_angle)), int(max_iter), int(bool(fixed_iters)),
+                                   C.byref(err), C.byref(it)))
+    return err.value, T, it.value
+
+
+def icp_align_batch(source, target, T1s, T2=IDENTITY, max_dist=0.1, max_angle=np.deg2rad(60.0), max_iter=100,
+                    fixed_iters=False):
+    T = _f32(T1s).reshape(-1, 16).copy()
+    n = len(T)
+    errs = np.zeros(n, np.float32); its = np.zeros(n, np.int32)
+    _check(load().rs_hip_icp_align_batch(source.handle, target.handle, T, n, _f32(T2).ravel(), float(max_dist),
+                                         float(np.float32(max_angle)), int(max_iter), int(bool(fixed_iters)),
+                                         errs, its))
+    return errs, T, its
+
+
+def icp_find_corrs(source, target, T1, T2=IDENTITY, max_dist=0.1, max_angle=np.deg2rad(60.0)):
+    n1 = source.n
+    out = [np.zeros((max(n1, 1), 3), np.float32) for _ in range(4)]
+    w = np.zeros(max(n1, 1), np.float32)
+    nc = C.c_int32()
+    _check(load().rs_hip_icp_find_corrs(source.handle, target.handle, _f32(T1).ravel(), _f32(T2).ravel(),
+                                        float(max_dist), float(np.float32(max_angle)), *out, w, C.byref(nc)))
+    return [o[:nc.value] for o in out] + [w[:nc.value]]
+
+
+def icp_estimate_pt2pl(p1, p2, n2, w, T1):
+    T = _f32(T1).ravel().copy(); err = C.c_float()
+    _check(load().rs_hip_icp_estimate_pt2pl(_f32(p1), _f32(p2), _f32(n2), _f32(w), len(w), T, C.byref(err)))
+    return err.value, T
+
+
+def alignment_scores(obj, scene, poses, radius=0.1, max_n_neigh=64):
+    """mgs_compute_object_alignment_score for a batch of poses."""
+    poses = _f32(poses).reshape(-1, 16)
+    out = np.zeros(len(poses), np.float32)
+    _check(load().rs_hip_alignment_scores(obj.handle, scene.handle, poses, len(poses), float(radius),
+                                          int(max_n_neigh), out))
+    return out
+
+
+def _placements(poses, objects, radii):
+    n = len(objects)
+    arr = (Placement * max(1, n))()
+    poses = _f32(poses).reshape(-1, 16)
+    for i in range(n):
+        arr[i].pose[:] = [float(x) for x in poses[i]]
+        arr[i].object = objects[i].handle
+        arr[i].radius = float(radii[i])
+    return arr
+
+
+def assign_labels(scene, poses, objects, radii, labels, min_dists, label_base=0):
+    arr = _placements(poses, objects, radii)
+    _check(load().rs_hip_assign_labels(scene.handle, C.addressof(arr), len(objects), int(label_base), labels, min_dists))
+    return labels, min_dists
+
+
+def label_rows(scene, poses, objects, radii, out_device_ptr=None):
+    """Per-placement unary rows.  With out_device_ptr the rows stay on the GPU (for an all-gather)."""
+    arr = _placements(poses, objects, radii)
+    n = len(objects)
+    if out_device_ptr is not None:
+        _check(load().rs_hip_label_rows(scene.handle, C.addressof(arr), n, C.c_void_p(out_device_ptr), 1))
+        return None
+    rows = np.zeros((n, scene.n), np.float32)
+    _check(load().rs_hip_label_rows(scene.handle, C.addressof(arr), n, rows.ctypes.data_as(C.c_void_p), 0))
+    return rows
+
+
+def combine_label_rows(rows, labels, min_dists, label_base=0):
+    rows = _f32(rows)
+    load().rs_hip_combine_label_rows(rows, rows.shape[0], rows.shape[1], int(label_base), labels, min_dists)
+    return labels, min_dists
+
+
+def arrangement_to_labels(scene, poses, objects, is_static, class_idx, radius=0.05, prioritize_static=False):
+    """rspf_arrangement_to_labels ordering + both passes.  Returns dict(labels, min_dists, order)."""
+    n = len(objects)
+    handles = (C.c_void_p * max(1, n))(*[o.handle for o in objects])
+    labels = np.zeros(scene.n, np.int8); mind = np.zeros(scene.n, np.float32); order = np.zeros(max(1, n), np.int32)
+    _check(load().rs_hip_arrangement_to_labels(
+        scene.handle, _f32(poses).reshape(-1, 16), C.addressof(handles),
+        np.ascontiguousarray(is_static, np.int32), np.ascontiguousarray(class_idx, np.int32), n,
+        float(radius), int(bool(prioritize_static)), labels, mind, order))
+    return dict(labels=labels, min_dists=mind, order=order[:n])
+
+
+def mat4_inverse(m):
+    o = np.empty(16, np.float32); load().rs_hip_mat4_inverse(_f32(m).ravel(), o); return o
+
+
+def mat4_mul(a, b):
+    o = np.empty(16, np.float32); load().rs_hip_mat4_mul(_f32(a).ravel(), _f32(b).ravel(), o); return o

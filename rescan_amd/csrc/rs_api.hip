@@ -1,0 +1,801 @@
+// librescan_hip host side: the C ABI of include/rescan_hip.h.
+//
+// Owns device clouds (cell-sorted 16-byte records + cell offset table), persistent
+// workspaces, the ICP outer loop (searches and reductions on the GPU; the 6x6 LDLᵀ solve and
+// the pose composition on the host in the reference's own arithmetic, lib/rs/icp.h:267-295)
+// and the per-kernel HIP-event timing used by bench.py.  There is no CPU fallback: every
+// compute entry point fails with RS_HIP_E_NODEVICE when no HIP device is usable.
+
+#include "../../include/rescan_hip.h"
+#include "rs_device.h"
+#include "rs_math.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace rs;
+
+// ------------------------------------------------------------------------------------------
+// runtime state
+// ------------------------------------------------------------------------------------------
+
+namespace {
+
+char g_err[512] = "";
+int g_device = -1;
+bool g_ready = false;
+hipStream_t g_own_stream = nullptr;
+hipStream_t g_stream = nullptr;
+
+void set_err( const char* fmt, ... )
+{
+  va_list ap; va_start( ap, fmt ); vsnprintf( g_err, sizeof(g_err), fmt, ap ); va_end( ap );
+}
+
+#define HIP_TRY( expr, code_on_fail )                                                        \
+  do { hipError_t e_ = ( expr );                                                               \
+       if( e_ != hipSuccess ) { set_err( "%s failed: %s (%s:%d)", #expr, hipGetErrorString( e_ ), __FILE__, __LINE__ ); \
+                                return code_on_fail; } } while( 0 )
+
+int ensure_ready()
+{
+  if( g_ready ) return RS_HIP_OK;
+  return rs_hip_init( g_device >= 0 ? g_device : 0 );
+}
+
+// growable device / pinned-host buffers, kept for the life of the process
+struct DevBuf
+{
+  void* p = nullptr; size_t cap = 0;
+  int ensure( size_t bytes )
+  {
+    if( bytes <= cap ) return RS_HIP_OK;
+    if( p ) { HIP_TRY( hipFree( p ), RS_HIP_E_RUNTIME ); p = nullptr; cap = 0; }
+    size_t want = bytes + bytes / 4 + 256;
+    HIP_TRY( hipMalloc( &p, want ), RS_HIP_E_RUNTIME );
+    cap = want;
+    return RS_HIP_OK;
+  }
+  template <class T> T* as() { return (T*)p; }
+};
+struct PinBuf
+{
+  void* p = nullptr; size_t cap = 0;
+  int ensure( size_t bytes )
+  {
+    if( bytes <= cap ) return RS_HIP_OK;
+    if( p ) { HIP_TRY( hipHostFree( p ), RS_HIP_E_RUNTIME ); p = nullptr; cap = 0; }
+    size_t want = bytes + bytes / 4 + 256;
+    HIP_TRY( hipHostMalloc( &p, want, hipHostMallocDefault ), RS_HIP_E_RUNTIME );
+    cap = want;
+    return RS_HIP_OK;
+  }
+  template <class T> T* as() { return (T*)p; }
+};
+
+struct Workspace
+{
+  DevBuf T1, active, slot, d2, dot, corr_part, stats, mom_part, moments, wexp;   // ICP
+  DevBuf poses, score_part, scores;                                             // score
+  DevBuf plc, labels, mind;                                                     // labels
+  DevBuf q4, rd2, ridx, rnn, rows;                                              // rows / misc
+  DevBuf tmp_pos, tmp_pos2, tmp_nor2;                                           // estimate-only
+  PinBuf h_a, h_b, h_c;
+} g_ws;
+
+// ---- profiling ---------------------------------------------------------------------------
+bool g_prof = false;
+struct ProfEntry { std::vector<hipEvent_t> ev; int64_t launches = 0; double ms = 0.0; size_t pending = 0; };
+std::map<std::string, ProfEntry> g_profmap;
+
+struct ProfScope
+{
+  ProfEntry* e = nullptr; size_t at = 0;
+  ProfScope( const char* name )
+  {
+    if( !g_prof ) return;
+    e = &g_profmap[name];
+    at = e->pending;
+    while( e->ev.size() < at + 2 ) { hipEvent_t x; if( hipEventCreate( &x ) != hipSuccess ) { e = nullptr; return; } e->ev.push_back( x ); }
+    (void)hipEventRecord( e->ev[at], g_stream );
+  }
+  ~ProfScope()
+  {
+    if( !e ) return;
+    (void)hipEventRecord( e->ev[at + 1], g_stream );
+    e->pending = at + 2;
+  }
+};
+
+void prof_collect()
+{
+  for( auto& kv : g_profmap )
+  {
+    ProfEntry& e = kv.second;
+    for( size_t i = 0; i + 1 < e.pending; i += 2 )
+    {
+      float ms = 0.0f;
+      (void)hipEventSynchronize( e.ev[i + 1] );
+      if( hipEventElapsedTime( &ms, e.ev[i], e.ev[i + 1] ) == hipSuccess ) { e.ms += ms; e.launches++; }
+    }
+    e.pending = 0;
+  }
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------
+// clouds
+// ------------------------------------------------------------------------------------------
+
+struct rs_hip_cloud
+{
+  int32_t n = 0;
+  bool has_nor = false;
+  GridView view{};
+  float4* d_pos = nullptr;
+  float4* d_nor = nullptr;
+  uint32_t* d_cell_start = nullptr;
+  std::vector<int32_t> order;     // sorted slot -> original index
+  std::vector<float> h_pos, h_nor;  // original-order host copies (AoS)
+  float cell = 0.0f;
+  int64_t bytes = 0;
+};
+
+namespace {
+
+// Cell coordinate of a stored point along one axis; the kernels' axis_range() covers this
+// expression with a 0.01-cell margin.
+inline int cell_of( float v, float gmin, float inv_cell, int dim )
+{
+  float c = floorf( ( v - gmin ) * inv_cell );
+  if( !( c >= 0.0f ) ) c = 0.0f;
+  if( c > (float)( dim - 1 ) ) c = (float)( dim - 1 );
+  return (int)c;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* rs_hip_version( void ) { return "rescan_hip 0.1 gfx950"; }
+const char* rs_hip_last_error( void ) { return g_err; }
+
+int rs_hip_init( int device )
+{
+  int count = 0;
+  hipError_t e = hipGetDeviceCount( &count );
+  if( e != hipSuccess || count <= 0 )
+  {
+    set_err( "rs_hip_init: no HIP device (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString( e ) );
+    return RS_HIP_E_NODEVICE;
+  }
+  if( device < 0 || device >= count ) { set_err( "rs_hip_init: device %d out of range (%d devices)", device, count ); return RS_HIP_E_ARG; }
+  HIP_TRY( hipSetDevice( device ), RS_HIP_E_NODEVICE );
+  if( !g_own_stream ) HIP_TRY( hipStreamCreateWithFlags( &g_own_stream, hipStreamNonBlocking ), RS_HIP_E_NODEVICE );
+  if( !g_stream ) g_stream = g_own_stream;
+  g_device = device;
+  g_ready = true;
+  return RS_HIP_OK;
+}
+
+int rs_hip_set_stream( void* s )
+{
+  int rc = ensure_ready(); if( rc ) return rc;
+  g_stream = s ? (hipStream_t)s : g_own_stream;
+  return RS_HIP_OK;
+}
+
+int rs_hip_synchronize( void )
+{
+  int rc = ensure_ready(); if( rc ) return rc;
+  HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
+  return RS_HIP_OK;
+}
+
+int rs_hip_profile_enable( int on ) { g_prof = on != 0; return RS_HIP_OK; }
+int rs_hip_profile_reset( void )
+{
+  prof_collect();
+  for( auto& kv : g_profmap ) { kv.second.launches = 0; kv.second.ms = 0.0; }
+  return RS_HIP_OK;
+}
+int rs_hip_profile_read( const char* name, int64_t* launches, double* total_ms )
+{
+  prof_collect();
+  auto it = g_profmap.find( name ? name : "" );
+  if( it == g_profmap.end() ) { if( launches ) *launches = 0; if( total_ms ) *total_ms = 0.0; return RS_HIP_OK; }
+  if( launches ) *launches = it->second.launches;
+  if( total_ms ) *total_ms = it->second.ms;
+  return RS_HIP_OK;
+}
+
+// ---- cloud build -------------------------------------------------------------------------
+// Host counting sort by cell (stable: input order inside a cell, like msh_hash_grid.h:511-532),
+// then one upload.  The index is built once per cloud level and reused by every search.
+rs_hip_cloud_t* rs_hip_cloud_create( const float* pos, const float* nor, int32_t n, float cell_size )
+{
+  if( ensure_ready() != RS_HIP_OK ) return nullptr;
+  if( n < 0 || ( n > 0 && !pos ) ) { set_err( "rs_hip_cloud_create: bad arguments" ); return nullptr; }
+  rs_hip_cloud* c = new rs_hip_cloud();
+  c->n = n; c->has_nor = nor != nullptr;
+  c->h_pos.assign( pos, pos + (size_t)3 * n );
+  if( nor ) c->h_nor.assign( nor, nor + (size_t)3 * n );
+
+  float mn[3] = { 0, 0, 0 }, mx[3] = { 0, 0, 0 };
+  if( n > 0 ) { for( int a = 0; a < 3; ++a ) { mn[a] = FLT_MAX; mx[a] = -FLT_MAX; } }
+  for( int32_t i = 0; i < n; ++i )
+    for( int a = 0; a < 3; ++a ) { float v = pos[3*i+a]; if( v < mn[a] ) mn[a] = v; if( v > mx[a] ) mx[a] = v; }
+  for( int a = 0; a < 3; ++a ) { if( !( mx[a] >= mn[a] ) || !std::isfinite( mn[a] ) || !std::isfinite( mx[a] ) ) { mn[a] = 0; mx[a] = 0; } }
+
+  int dims[3] = { 1, 1, 1 };
+  float inv_cell = 0.0f, cell = cell_size;
+  if( cell_size > 0.0f && n > 0 )
+  {
+    for( ;; )
+    {
+      double cells = 1.0;
+      for( int a = 0; a < 3; ++a ) { dims[a] = (int)std::floor( ( (double)mx[a] - (double)mn[a] ) / (double)cell ) + 1; cells *= dims[a]; }
+      if( cells <= 48.0e6 ) break;
+      cell *= 2.0f;                          // keep the dense offset table below ~200 MB
+    }
+    inv_cell = 1.0f / cell;
+  }
+  c->cell = ( cell_size > 0.0f ) ? cell : 0.0f;
+  const size_t n_cells = (size_t)dims[0] * dims[1] * dims[2];
+
+  std::vector<uint32_t> start( n_cells + 1, 0u );
+  std::vector<uint32_t> cid( (size_t)n );
+  for( int32_t i = 0; i < n; ++i )
+  {
+    int cx = cell_of( pos[3*i],   mn[0], inv_cell, dims[0] );
+    int cy = cell_of( pos[3*i+1], mn[1], inv_cell, dims[1] );
+    int cz = cell_of( pos[3*i+2], mn[2], inv_cell, dims[2] );
+    uint32_t id = (uint32_t)( ( (size_t)cz * dims[1] + cy ) * dims[0] + cx );
+    cid[i] = id; start[id + 1]++;
+  }
+  for( size_t k = 0; k < n_cells; ++k ) start[k + 1] += start[k];
+  std::vector<uint32_t> fill( start.begin(), start.end() - 1 );
+  c->order.resize( (size_t)n );
+  std::vector<float4> spos( (size_t)n ), snor( nor ? (size_t)n : 0 );
+  for( int32_t i = 0; i < n; ++i )
+  {
+    uint32_t s = fill[cid[i]]++;
+    c->order[s] = i;
+    float w; std::memcpy( &w, &i, 4 );
+    spos[s] = make_float4( pos[3*i], pos[3*i+1], pos[3*i+2], w );
+    if( nor ) snor[s] = make_float4( nor[3*i], nor[3*i+1], nor[3*i+2], 0.0f );
+  }
+
+  auto fail = [&]( hipError_t e ) { set_err( "rs_hip_cloud_create: %s", hipGetErrorString( e ) ); rs_hip_cloud_destroy( c ); return (rs_hip_cloud_t*)nullptr; };
+  hipError_t e;
+  size_t pb = std::max<size_t>( 1, (size_t)n ) * sizeof(float4);
+  if( ( e = hipMalloc( (void**)&c->d_pos, pb ) ) != hipSuccess ) return fail( e );
+  if( nor && ( e = hipMalloc( (void**)&c->d_nor, pb ) ) != hipSuccess ) return fail( e );
+  if( ( e = hipMalloc( (void**)&c->d_cell_start, ( n_cells + 1 ) * 4 ) ) != hipSuccess ) return fail( e );
+  if( n > 0 )
+  {
+    if( ( e = hipMemcpy( c->d_pos, spos.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice ) ) != hipSuccess ) return fail( e );
+    if( nor && ( e = hipMemcpy( c->d_nor, snor.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice ) ) != hipSuccess ) return fail( e );
+  }
+  if( ( e = hipMemcpy( c->d_cell_start, start.data(), ( n_cells + 1 ) * 4, hipMemcpyHostToDevice ) ) != hipSuccess ) return fail( e );
+  c->bytes = (int64_t)( pb * ( nor ? 2 : 1 ) + ( n_cells + 1 ) * 4 );
+
+  GridView& v = c->view;
+  v.pos = c->d_pos; v.nor = c->d_nor; v.cell_start = c->d_cell_start;
+  v.minx = mn[0]; v.miny = mn[1]; v.minz = mn[2]; v.inv_cell = inv_cell;
+  v.w = dims[0]; v.h = dims[1]; v.d = dims[2]; v.n = n;
+  return c;
+}
+
+void rs_hip_cloud_destroy( rs_hip_cloud_t* c )
+{
+  if( !c ) return;
+  if( c->d_pos ) (void)hipFree( c->d_pos );
+  if( c->d_nor ) (void)hipFree( c->d_nor );
+  if( c->d_cell_start ) (void)hipFree( c->d_cell_start );
+  delete c;
+}
+
+int32_t rs_hip_cloud_size( const rs_hip_cloud_t* c ) { return c ? c->n : 0; }
+int64_t rs_hip_cloud_bytes( const rs_hip_cloud_t* c ) { return c ? c->bytes : 0; }
+
+void rs_hip_mat4_inverse( const float* m, float* out ) { Mat4 a; std::memcpy( a.m, m, 64 ); Mat4 r = mat4_inverse( a ); std::memcpy( out, r.m, 64 ); }
+void rs_hip_mat4_mul( const float* a_, const float* b_, float* out ) { Mat4 a, b; std::memcpy( a.m, a_, 64 ); std::memcpy( b.m, b_, 64 ); Mat4 r = mat4_mul( a, b ); std::memcpy( out, r.m, 64 ); }
+
+} // extern "C"
+
+// ------------------------------------------------------------------------------------------
+// ICP
+// ------------------------------------------------------------------------------------------
+
+namespace {
+
+inline float radius_sq_of( float r ) { return (float)( (double)r * (double)r ); }   // msh_hash_grid.h:1104,1111 + :828
+
+// Finish lib/rs/icp.h:210-298 from the 35 uncentred fp64 moments (layout: k_icp_moments).
+// Returns false when the reference would have stopped before estimating (Σw <= 1e-7, icp.h:466).
+bool icp_solve( const double* M, Mat4& T1, float& err )
+{
+  const double W = M[0];
+  if( (float)W <= 1e-7 ) return false;
+  const float c1f[3] = { (float)( M[1] / W ), (float)( M[2] / W ), (float)( M[3] / W ) };
+  const float c2f[3] = { (float)( M[4] / W ), (float)( M[5] / W ), (float)( M[6] / W ) };
+  const double c1[3] = { c1f[0], c1f[1], c1f[2] }, dl[3] = { (double)c1f[0] - c2f[0], (double)c1f[1] - c2f[1], (double)c1f[2] - c2f[2] };
+  const double Maa[3][3] = { { M[7], M[8], M[9] }, { M[8], M[10], M[11] }, { M[9], M[11], M[12] } };
+  double Man[3][3];
+  for( int r = 0; r < 3; ++r ) for( int c = 0; c < 3; ++c ) Man[r][c] = M[13 + 3*r + c];
+  const double Mnn[3][3] = { { M[22], M[23], M[24] }, { M[23], M[25], M[26] }, { M[24], M[26], M[27] } };
+  const double vae[3] = { M[28], M[29], M[30] }, vne[3] = { M[31], M[32], M[33] };
+  const double see = M[34];
+  // X v = c1 × v
+  const double X[3][3] = { { 0, -c1[2], c1[1] }, { c1[2], 0, -c1[0] }, { -c1[1], c1[0], 0 } };
+
+  auto mul = []( const double A[3][3], const double B[3][3], double O[3][3], bool tb ) {
+    for( int r = 0; r < 3; ++r ) for( int c = 0; c < 3; ++c ) { double s = 0; for( int k = 0; k < 3; ++k ) s += A[r][k] * ( tb ? B[c][k] : B[k][c] ); O[r][c] = s; } };
+  double XMnn[3][3], ManXt[3][3], XMnnXt[3][3];
+  mul( X, Mnn, XMnn, false );        // X·Mnn
+  mul( Man, X, ManXt, true );        // Man·Xᵀ
+  mul( XMnn, X, XMnnXt, true );      // X·Mnn·Xᵀ
+  double TL[3][3], TR[3][3];
+  for( int r = 0; r < 3; ++r ) for( int c = 0; c < 3; ++c )
+  {
+    TL[r][c] = Maa[r][c] - ManXt[r][c] - ManXt[c][r] + XMnnXt[r][c];   // Σw·c cᵀ, c = a - X n
+    TR[r][c] = Man[r][c] - XMnn[r][c];                                   // Σw·c nᵀ
+  }
+  double bc[3], bn[3], Mnn_d[3], Man_d[3], sum;
+  for( int r = 0; r < 3; ++r ) { Mnn_d[r] = 0; Man_d[r] = 0; for( int k = 0; k < 3; ++k ) { Mnn_d[r] += Mnn[r][k] * dl[k]; Man_d[r] += Man[r][k] * dl[k]; } }
+  for( int r = 0; r < 3; ++r )
+  {
+    double xv = 0, xm = 0;
+    for( int k = 0; k < 3; ++k ) { xv += X[r][k] * vne[k]; xm += X[r][k] * Mnn_d[k]; }
+    bc[r] = vae[r] - Man_d[r] - xv + xm;       // Σw·c·s,  s = e - δ·n
+    bn[r] = vne[r] - Mnn_d[r];                 // Σw·n·s
+  }
+  sum = see - 2.0 * ( dl[0] * vne[0] + dl[1] * vne[1] + dl[2] * vne[2] ) + ( dl[0] * Mnn_d[0] + dl[1] * Mnn_d[1] + dl[2] * Mnn_d[2] );
+  if( sum < 0.0 ) sum = 0.0;
+  err = (float)std::sqrt( sum / W );           // icp.h:253
+
+  double C[6][6], b[6], x[6] = { 0, 0, 0, 0, 0, 0 };    // icp.h:267-277
+  for( int r = 0; r < 3; ++r ) for( int c = 0; c < 3; ++c )
+  { C[r][c] = TL[r][c]; C[r][3+c] = TR[r][c]; C[3+r][c] = TR[c][r]; C[3+r][3+c] = Mnn[r][c]; }
+  for( int r = 0; r < 3; ++r ) { b[r] = -bc[r]; b[3+r] = -bn[r]; }
+  ldlt6_solve( C, b, x );
+
+  Mat4 T = mat4_identity();                    // icp.h:280-295
+  T = mat4_translate( T, c1f[0], c1f[1], c1f[2] );
+  T = mat4_translate( T, (float)x[3], (float)x[4], (float)x[5] );
+  T = mat4_rotate_axis( T, (float)x[0], 0 );
+  T = mat4_rotate_axis( T, (float)x[1], 1 );
+  T = mat4_rotate_axis( T, (float)x[2], 2 );
+  T = mat4_translate( T, -c1f[0], -c1f[1], -c1f[2] );
+  T1 = mat4_mul( T, T1 );
+  return true;
+}
+
+struct IcpCtx
+{
+  IcpLaunch L{};
+  int n_waves = 0;
+};
+
+int icp_prepare( IcpCtx& cx, const rs_hip_cloud_t* src, const rs_hip_cloud_t* tgt, int n_prob, const float* T2 )
+{
+  if( !src || !tgt || !src->has_nor || !tgt->has_nor ) { set_err( "icp: source and target clouds need normals" ); return RS_HIP_E_ARG; }
+  if( n_prob <= 0 ) { set_err( "icp: empty batch" ); return RS_HIP_E_ARG; }
+  IcpLaunch& L = cx.L;
+  L.tgt = tgt->view; L.qpos = src->d_pos; L.qnor = src->d_nor; L.nq = src->n; L.n_prob = n_prob; L.K = 16;   // icp.h:330
+  Mat4 t2; std::memcpy( t2.m, T2, 64 );
+  Mat4 t2i = mat4_inverse( t2 );                                                                             // icp.h:329
+  std::memcpy( L.T2i.m, t2i.m, 64 );
+  cx.n_waves = ( src->n + 63 ) / 64;
+  L.n_mom_blocks = std::max( 1, std::min( 256, ( src->n + 255 ) / 256 ) );
+  const size_t nq = std::max<size_t>( 1, (size_t)src->n ), np = (size_t)n_prob;
+  int rc;
+  if( ( rc = g_ws.T1.ensure( np * 64 ) ) || ( rc = g_ws.active.ensure( np * 4 ) ) ||
+      ( rc = g_ws.slot.ensure( np * nq * 4 ) ) || ( rc = g_ws.d2.ensure( np * nq * 4 ) ) || ( rc = g_ws.dot.ensure( np * nq * 4 ) ) ||
+      ( rc = g_ws.corr_part.ensure( np * std::max( 1, cx.n_waves ) * 3 * 8 ) ) || ( rc = g_ws.stats.ensure( np * 4 * 8 ) ) ||
+      ( rc = g_ws.mom_part.ensure( np * L.n_mom_blocks * ICP_NMOM * 8 ) ) || ( rc = g_ws.moments.ensure( np * ICP_NMOM * 8 ) ) ||
+      ( rc = g_ws.h_a.ensure( np * ( ICP_NMOM + 4 ) * 8 ) ) || ( rc = g_ws.h_b.ensure( np * 64 + np * 4 ) ) )
+    return rc;
+  L.T1 = g_ws.T1.as<float>(); L.active = g_ws.active.as<int>();
+  L.m_slot = g_ws.slot.as<int>(); L.m_d2 = g_ws.d2.as<float>(); L.m_dot = g_ws.dot.as<float>();
+  L.corr_part = g_ws.corr_part.as<double>(); L.stats = g_ws.stats.as<double>();
+  L.mom_part = g_ws.mom_part.as<double>(); L.moments = g_ws.moments.as<double>();
+  L.w_explicit = nullptr;
+  return RS_HIP_OK;
+}
+
+int icp_upload_state( IcpCtx& cx, const std::vector<Mat4>& T, const std::vector<int>& active )
+{
+  const size_t np = T.size();
+  float* hT = g_ws.h_b.as<float>();
+  int* hA = (int*)( hT + np * 16 );
+  for( size_t p = 0; p < np; ++p ) { std::memcpy( hT + 16 * p, T[p].m, 64 ); hA[p] = active[p]; }
+  HIP_TRY( hipMemcpyAsync( g_ws.T1.p, hT, np * 64, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipMemcpyAsync( g_ws.active.p, hA, np * 4, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+  return RS_HIP_OK;
+}
+
+void icp_set_radius( IcpCtx& cx, float max_dist, float tmin )
+{
+  cx.L.radius = max_dist; cx.L.radius_sq = radius_sq_of( max_dist ); cx.L.gate_tmin = tmin;
+}
+
+} // namespace
+
+extern "C" {
+
+int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* target,
+                            float* T1s, int32_t n, const float* T2, float max_dist, float max_angle,
+                            int32_t max_iter, int32_t fixed_iters, float* errs, int32_t* iters )
+{
+  int rc = ensure_ready(); if( rc ) return rc;
+  if( !T1s || !T2 || !errs ) { set_err( "icp_align: null argument" ); return RS_HIP_E_ARG; }
+  IcpCtx cx;
+  if( ( rc = icp_prepare( cx, source, target, n, T2 ) ) ) return rc;
+  const float tmin = icp_gate_threshold( max_angle );
+
+  std::vector<Mat4> T( n );
+  std::vector<int> active( n, 1 ), it_count( n, 0 );
+  std::vector<float> err( n, 1e6f ), prev( n, 1e6f );                 // icp.h:441-442
+  for( int p = 0; p < n; ++p ) std::memcpy( T[p].m, T1s + 16 * p, 64 );
+  if( source->n == 0 ) { for( int p = 0; p < n; ++p ) { errs[p] = 1e6f; if( iters ) iters[p] = 1; } return RS_HIP_OK; }   // n_corrs == 0 on the first search
+
+  double* hM = g_ws.h_a.as<double>();
+  double* hS = hM + (size_t)n * ICP_NMOM;
+  for( int i = 0; i < max_iter; ++i )                                  // icp.h:444
+  {
+    if( ( rc = icp_upload_state( cx, T, active ) ) ) return rc;
+    icp_set_radius( cx, max_dist, tmin );
+    { ProfScope ps( "nn_icp" ); launch_icp_corr( cx.L, g_stream ); }
+    launch_icp_stats( cx.L, g_stream );
+    { ProfScope ps( "icp_moments" ); launch_icp_moments( cx.L, g_stream ); }
+    HIP_TRY( hipMemcpyAsync( hM, g_ws.moments.p, (size_t)n * ICP_NMOM * 8, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+    HIP_TRY( hipMemcpyAsync( hS, g_ws.stats.p, (size_t)n * 4 * 8, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+    HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
+
+    int n_active = 0;
+    for( int p = 0; p < n; ++p )
+    {
+      if( !active[p] ) continue;
+      prev[p] = err[p];
+      it_count[p]++;
+      if( hS[4 * p] == 0.0 ) { active[p] = 0; continue; }             // icp.h:455-459 no correspondences
+      float e;
+      if( !icp_solve( hM + (size_t)p * ICP_NMOM, T[p], e ) ) { active[p] = 0; continue; }   // icp.h:466-470
+      err[p] = e;
+      if( getenv( "RS_HIP_DEBUG" ) )
+        fprintf( stderr, "[rs_hip icp] it %d prob %d n_corr %.0f mean %g sd %g W %.9g err %.9g max_dist %g T12 %g %g %g\n", i, p, hS[4*p], hS[4*p+1], hS[4*p+2],
+                 hM[(size_t)p * ICP_NMOM], (double)e, (double)max_dist, T[p].m[12], T[p].m[13], T[p].m[14] );
+      float delta = fabsf( prev[p] - err[p] );
+      if( !fixed_iters && i > 5 && delta < 1e-5 ) { active[p] = 0; continue; }               // icp.h:489
+      n_active++;
+    }
+    if( n_active == 0 ) break;
+    double nd = max_dist * 0.95;                                        // icp.h:493
+    max_dist = (float)( nd > 0.05 ? nd : 0.05 );
+  }
+  for( int p = 0; p < n; ++p ) { std::memcpy( T1s + 16 * p, T[p].m, 64 ); errs[p] = err[p]; if( iters ) iters[p] = it_count[p]; }
+  return RS_HIP_OK;
+}
+
+int rs_hip_icp_align( const rs_hip_cloud_t* source, const rs_hip_cloud_t* target,
+                      float* T1, const float* T2, float max_dist, float max_angle,
+                      int32_t max_iter, int32_t fixed_iters, float* err, int32_t* n_iters )
+{
+  float e = 1e6f; int32_t it = 0;
+  int rc = rs_hip_icp_align_batch( source, target, T1, 1, T2, max_dist, max_angle, max_iter, fixed_iters, &e, &it );
+  if( err ) *err = e;
+  if( n_iters ) *n_iters = it;
+  return rc;
+}
+
+int rs_hip_icp_find_corrs( const rs_hip_cloud_t* source, const rs_hip_cloud_t* target,
+                           const float* T1, const float* T2, float max_dist, float max_angle,
+                           float* corr_pts1, float* corr_nor1, float* corr_pts2, float* corr_nor2,
+                           float* weights, int32_t* n_corrs )
+{
+  int rc = ensure_ready(); if( rc ) return rc;
+  if( !T1 || !T2 || !n_corrs ) { set_err( "icp_find_corrs: null argument" ); return RS_HIP_E_ARG; }
+  IcpCtx cx;
+  if( ( rc = icp_prepare( cx, source, target, 1, T2 ) ) ) return rc;
+  *n_corrs = 0;
+  const int nq = source->n;
+  if( nq == 0 ) return RS_HIP_OK;
+  std::vector<Mat4> T( 1 ); std::memcpy( T[0].m, T1, 64 );
+  std::vector<int> active( 1, 1 );
+  if( ( rc = icp_upload_state( cx, T, active ) ) ) return rc;
+  icp_set_radius( cx, max_dist, icp_gate_threshold( max_angle ) );
+  { ProfScope ps( "nn_icp" ); launch_icp_corr( cx.L, g_stream ); }
+  std::vector<int> slot( nq ); std::vector<float> d2( nq ), dot( nq );
+  HIP_TRY( hipMemcpyAsync( slot.data(), cx.L.m_slot, (size_t)nq * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipMemcpyAsync( d2.data(), cx.L.m_d2, (size_t)nq * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipMemcpyAsync( dot.data(), cx.L.m_dot, (size_t)nq * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
+
+  // Back to source order and compact (icp.h:381-391).  The query positions/normals are
+  // re-derived on the host with the same two mat·vec products the kernel used.
+  std::vector<int> by_orig( nq );
+  for( int s = 0; s < nq; ++s ) by_orig[source->order[s]] = s;
+  Mat4 t2; std::memcpy( t2.m, T2, 64 ); Mat4 t2i = mat4_inverse( t2 );
+  auto apply = []( const Mat4& M, const float* v, float w, float* o ) {
+    o[0] = M.m[0] * v[0] + M.m[4] * v[1] + M.m[ 8] * v[2] + w * M.m[12];
+    o[1] = M.m[1] * v[0] + M.m[5] * v[1] + M.m[ 9] * v[2] + w * M.m[13];
+    o[2] = M.m[2] * v[0] + M.m[6] * v[1] + M.m[10] * v[2] + w * M.m[14]; };
+  std::vector<float> dists; dists.reserve( nq );
+  int ic = 0;
+  for( int i = 0; i < nq; ++i )
+  {
+    const int s = by_orig[i];
+    if( slot[s] < 0 ) continue;
+    const int i2 = target->order[slot[s]];
+    float t[3], qp[3], qn[3];
+    apply( T[0], &source->h_pos[3*i], 1.0f, t ); apply( t2i, t, 1.0f, qp );
+    apply( T[0], &source->h_nor[3*i], 0.0f, t ); apply( t2i, t, 0.0f, qn );
+    if( corr_pts1 ) std::memcpy( corr_pts1 + 3*ic, qp, 12 );
+    if( corr_nor1 ) std::memcpy( corr_nor1 + 3*ic, qn, 12 );
+    if( corr_pts2 ) std::memcpy( corr_pts2 + 3*ic, &target->h_pos[3*i2], 12 );
+    if( corr_nor2 ) std::memcpy( corr_nor2 + 3*ic, &target->h_nor[3*i2], 12 );
+    if( weights ) weights[ic] = ( 1.0f - d2[s] / max_dist ) * dot[s];       // icp.h:387
+    dists.push_back( d2[s] );
+    ic++;
+  }
+  // icp.h:393-402 with msh_compute_mean / msh_compute_stddev in source order (msh_std.h:1800-1825)
+  if( weights && ic > 0 )
+  {
+    float acc = 0; for( int i = 0; i < ic; ++i ) acc += dists[i];
+    float mean = acc / (float)ic;
+    float sq = 0.0f; for( int i = 0; i < ic; ++i ) sq += dists[i] * dists[i];
+    float sd = (float)std::sqrt( sq / (float)ic - mean * mean );
+    if( sd > 0.000001 ) for( int i = 0; i < ic; ++i ) if( dists[i] > 2.5f * sd ) weights[i] = 0.0;
+  }
+  *n_corrs = ic;
+  return RS_HIP_OK;
+}
+
+int rs_hip_icp_estimate_pt2pl( const float* pts1, const float* pts2, const float* nor2,
+                               const float* weights, int32_t n, float* T1, float* err )
+{
+  int rc = ensure_ready(); if( rc ) return rc;
+  if( !pts1 || !pts2 || !nor2 || !weights || !T1 || n <= 0 ) { set_err( "icp_estimate: bad arguments" ); return RS_HIP_E_ARG; }
+  // Present the correspondences to k_icp_moments as "query i matched slot i" with explicit weights.
+  const size_t nn = (size_t)n;
+  if( ( rc = g_ws.tmp_pos.ensure( nn * 16 ) ) || ( rc = g_ws.tmp_pos2.ensure( nn * 16 ) ) || ( rc = g_ws.tmp_nor2.ensure( nn * 16 ) ) ||
+      ( rc = g_ws.wexp.ensure( nn * 4 ) ) || ( rc = g_ws.slot.ensure( nn * 4 ) ) || ( rc = g_ws.d2.ensure( nn * 4 ) ) || ( rc = g_ws.dot.ensure( nn * 4 ) ) ||
+      ( rc = g_ws.T1.ensure( 64 ) ) || ( rc = g_ws.active.ensure( 4 ) ) || ( rc = g_ws.stats.ensure( 32 ) ) ||
+      ( rc = g_ws.mom_part.ensure( 256 * ICP_NMOM * 8 ) ) || ( rc = g_ws.moments.ensure( ICP_NMOM * 8 ) ) || ( rc = g_ws.h_a.ensure( ( ICP_NMOM + 4 ) * 8 ) ) )
+    return rc;
+  std::vector<float4> a( nn ), b( nn ), c( nn ); std::vector<int> sl( nn );
+  for( size_t i = 0; i < nn; ++i )
+  {
+    a[i] = make_float4( pts1[3*i], pts1[3*i+1], pts1[3*i+2], 0 );
+    b[i] = make_float4( pts2[3*i], pts2[3*i+1], pts2[3*i+2], 0 );
+    c[i] = make_float4( nor2[3*i], nor2[3*i+1], nor2[3*i+2], 0 );
+    sl[i] = (int)i;
+  }
+  Mat4 I = mat4_identity(); int one = 1; double zeros[4] = { 0, 0, 0, 0 };
+  HIP_TRY( hipMemcpyAsync( g_ws.tmp_pos.p, a.data(), nn * 16, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipMemcpyAsync( g_ws.tmp_pos2.p, b.data(), nn * 16, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipMemcpyAsync( g_ws.tmp_nor2.p, c.data(), nn * 16, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipMemcpyAsync( g_ws.wexp.p, weights, nn * 4, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipMemcpyAsync( g_ws.slot.p, sl.data(), nn * 4, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipMemcpyAsync( g_ws.T1.p, I.m, 64, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipMemcpyAsync( g_ws.active.p, &one, 4, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipMemcpyAsync( g_ws.stats.p, zeros, 32, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );     // host staging vectors go out of scope below
+  IcpLaunch L{};
+  L.tgt.pos = g_ws.tmp_pos2.as<float4>(); L.tgt.nor = g_ws.tmp_nor2.as<float4>(); L.tgt.n = n;
+  L.qpos = g_ws.tmp_pos.as<float4>(); L.qnor = nullptr; L.nq = n; L.n_prob = 1;
+  L.T1 = g_ws.T1.as<float>(); L.active = g_ws.active.as<int>(); std::memcpy( L.T2i.m, I.m, 64 );
+  L.radius = 1.0f; L.m_slot = g_ws.slot.as<int>(); L.m_d2 = g_ws.d2.as<float>(); L.m_dot = g_ws.dot.as<float>();
+  L.stats = g_ws.stats.as<double>(); L.mom_part = g_ws.mom_part.as<double>(); L.moments = g_ws.moments.as<double>();
+  L.n_mom_blocks = std::max( 1, std::min( 256, ( n + 255 ) / 256 ) ); L.w_explicit = g_ws.wexp.as<float>();
+  { ProfScope ps( "icp_moments" ); launch_icp_moments( L, g_stream ); }
+  double* hM = g_ws.h_a.as<double>();
+  HIP_TRY( hipMemcpyAsync( hM, g_ws.moments.p, ICP_NMOM * 8, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
+  Mat4 T; std::memcpy( T.m, T1, 64 );
+  float e = 0.0f;
+  // the reference has no Σw guard inside the estimator itself; keep T1 when the system is empty
+  if( icp_solve( hM, T, e ) ) std::memcpy( T1, T.m, 64 );
+  if( err ) *err = e;
+  return RS_HIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// alignment score
+// ------------------------------------------------------------------------------------------
+
+int rs_hip_alignment_scores( const rs_hip_cloud_t* object, const rs_hip_cloud_t* scene,
+                             const float* poses, int32_t n_poses, float radius, int32_t max_n_neigh,
+                             float* scores )
+{
+  int rc = ensure_ready(); if( rc ) return rc;
+  if( !object || !scene || !object->has_nor || !scene->has_nor || !poses || !scores || n_poses < 0 || max_n_neigh <= 0 )
+  { set_err( "alignment_scores: bad arguments" ); return RS_HIP_E_ARG; }
+  if( n_poses == 0 ) return RS_HIP_OK;
+  if( object->n == 0 ) { for( int p = 0; p < n_poses; ++p ) scores[p] = NAN; return RS_HIP_OK; }   // 0/0, pose_proposal.cpp:156
+  const int n_tiles = ( object->n + 63 ) / 64;
+  if( ( rc = g_ws.poses.ensure( (size_t)n_poses * 64 ) ) || ( rc = g_ws.score_part.ensure( (size_t)n_poses * n_tiles * 8 ) ) ||
+      ( rc = g_ws.scores.ensure( (size_t)n_poses * 4 ) ) )
+    return rc;
+  HIP_TRY( hipMemcpyAsync( g_ws.poses.p, poses, (size_t)n_poses * 64, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+  ScoreLaunch L{};
+  L.scene = scene->view; L.qpos = object->d_pos; L.qnor = object->d_nor; L.nq = object->n;
+  L.poses = g_ws.poses.as<float>(); L.radius_sq = radius_sq_of( radius ); L.gate_tmin = score_gate_threshold();
+  L.K = max_n_neigh; L.sigma = (double)radius; L.part = g_ws.score_part.as<double>(); L.scores = g_ws.scores.as<float>();
+  // the launch grid's y dimension is limited to 65535 poses per launch
+  for( int p0 = 0; p0 < n_poses; p0 += 65535 )
+  {
+    ScoreLaunch Lp = L;
+    Lp.n_poses = std::min( 65535, n_poses - p0 );
+    Lp.poses = L.poses + (size_t)p0 * 16; Lp.part = L.part + (size_t)p0 * n_tiles; Lp.scores = L.scores + p0;
+    ProfScope ps( "nn_score" );
+    launch_score( Lp, g_stream );
+  }
+  HIP_TRY( hipMemcpyAsync( scores, g_ws.scores.p, (size_t)n_poses * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
+  return RS_HIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// label transfer
+// ------------------------------------------------------------------------------------------
+
+static int label_upload_placements( const rs_hip_placement_t* pl, int32_t n )
+{
+  int rc;
+  if( ( rc = g_ws.plc.ensure( (size_t)n * sizeof(PlacementDev) ) ) || ( rc = g_ws.h_c.ensure( (size_t)n * sizeof(PlacementDev) ) ) ) return rc;
+  PlacementDev* h = g_ws.h_c.as<PlacementDev>();
+  for( int i = 0; i < n; ++i )
+  {
+    if( !pl[i].object || !pl[i].object->has_nor ) { set_err( "labels: placement %d has no object cloud with normals", i ); return RS_HIP_E_ARG; }
+    Mat4 pose; std::memcpy( pose.m, pl[i].pose, 64 );
+    Mat4 inv = mat4_inverse( pose ), nm = mat4_transpose( pose );       // rs_pointcloud_filters.cpp:750-751
+    h[i].g = pl[i].object->view;
+    std::memcpy( h[i].inv.m, inv.m, 64 ); std::memcpy( h[i].nmat.m, nm.m, 64 );
+    h[i].radius = pl[i].radius; h[i].radius_sq = radius_sq_of( pl[i].radius );
+  }
+  HIP_TRY( hipMemcpyAsync( g_ws.plc.p, h, (size_t)n * sizeof(PlacementDev), hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+  return RS_HIP_OK;
+}
+
+int rs_hip_assign_labels( const rs_hip_cloud_t* scene, const rs_hip_placement_t* placements,
+                          int32_t n, int32_t label_base, int8_t* labels, float* min_dists )
+{
+  int rc = ensure_ready(); if( rc ) return rc;
+  if( !scene || !scene->has_nor || !labels || !min_dists || n < 0 || ( n > 0 && !placements ) ) { set_err( "assign_labels: bad arguments" ); return RS_HIP_E_ARG; }
+  if( label_base + n > 127 ) { set_err( "assign_labels: more than 127 placements do not fit the reference's int8 labels" ); return RS_HIP_E_CAPACITY; }
+  if( n == 0 || scene->n == 0 ) return RS_HIP_OK;
+  const size_t ns = (size_t)scene->n;
+  if( ( rc = label_upload_placements( placements, n ) ) || ( rc = g_ws.labels.ensure( ns ) ) || ( rc = g_ws.mind.ensure( ns * 4 ) ) ) return rc;
+  HIP_TRY( hipMemcpyAsync( g_ws.labels.p, labels, ns, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipMemcpyAsync( g_ws.mind.p, min_dists, ns * 4, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+  LabelLaunch L{};
+  L.spos = scene->d_pos; L.snor = scene->d_nor; L.ns = scene->n; L.pl = g_ws.plc.as<PlacementDev>(); L.n_pl = n;
+  L.label_base = label_base; L.gate_tmin = label_gate_threshold();
+  L.labels = g_ws.labels.as<int8_t>(); L.min_d = g_ws.mind.as<float>(); L.rows = nullptr;
+  { ProfScope ps( "nn_label" ); launch_label( L, g_stream ); }
+  HIP_TRY( hipMemcpyAsync( labels, g_ws.labels.p, ns, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipMemcpyAsync( min_dists, g_ws.mind.p, ns * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
+  return RS_HIP_OK;
+}
+
+int rs_hip_label_rows( const rs_hip_cloud_t* scene, const rs_hip_placement_t* placements,
+                       int32_t n, float* rows, int rows_device )
+{
+  int rc = ensure_ready(); if( rc ) return rc;
+  if( !scene || !scene->has_nor || !rows || n < 0 || ( n > 0 && !placements ) ) { set_err( "label_rows: bad arguments" ); return RS_HIP_E_ARG; }
+  if( n == 0 || scene->n == 0 ) return RS_HIP_OK;
+  const size_t ns = (size_t)scene->n;
+  if( ( rc = label_upload_placements( placements, n ) ) ) return rc;
+  float* d_rows = rows;
+  if( !rows_device ) { if( ( rc = g_ws.rows.ensure( (size_t)n * ns * 4 ) ) ) return rc; d_rows = g_ws.rows.as<float>(); }
+  LabelLaunch L{};
+  L.spos = scene->d_pos; L.snor = scene->d_nor; L.ns = scene->n; L.pl = g_ws.plc.as<PlacementDev>(); L.n_pl = n;
+  L.label_base = 0; L.gate_tmin = label_gate_threshold(); L.labels = nullptr; L.min_d = nullptr; L.rows = d_rows;
+  { ProfScope ps( "nn_label" ); launch_label( L, g_stream ); }
+  if( !rows_device )
+  {
+    HIP_TRY( hipMemcpyAsync( rows, d_rows, (size_t)n * ns * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+    HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
+  }
+  return RS_HIP_OK;
+}
+
+void rs_hip_combine_label_rows( const float* rows, int32_t n_rows, int64_t scene_n, int32_t label_base,
+                                int8_t* labels, float* min_dists )
+{
+  for( int32_t k = 0; k < n_rows; ++k )
+  {
+    const float* r = rows + (size_t)k * scene_n;
+    for( int64_t j = 0; j < scene_n; ++j )
+      if( r[j] < min_dists[j] ) { min_dists[j] = r[j]; labels[j] = (int8_t)( label_base + k + 1 ); }   // rs_pointcloud_filters.cpp:763,772-773
+  }
+}
+
+int rs_hip_arrangement_to_labels( const rs_hip_cloud_t* scene,
+                                  const float* poses, const rs_hip_cloud_t* const* objects,
+                                  const int32_t* is_static, const int32_t* class_idx, int32_t n,
+                                  float radius, int prioritize_static,
+                                  int8_t* labels, float* min_dists, int32_t* sorted_order )
+{
+  int rc = ensure_ready(); if( rc ) return rc;
+  if( !scene || !labels || !min_dists || n < 0 || ( n > 0 && ( !poses || !objects || !is_static || !class_idx ) ) ) { set_err( "arrangement_to_labels: bad arguments" ); return RS_HIP_E_ARG; }
+  const int64_t ns = scene->n;
+  for( int64_t j = 0; j < ns; ++j ) { labels[j] = 0; min_dists[j] = 1e9; }                 // :799-802, :820
+  // :823-827 — qsort by (is_static << 10 | class_idx); glibc's qsort is a stable merge sort
+  std::vector<int32_t> ord( n );
+  for( int i = 0; i < n; ++i ) ord[i] = i;
+  std::stable_sort( ord.begin(), ord.end(), [&]( int a, int b ) {
+    return ( ( is_static[a] << 10 ) | class_idx[a] ) < ( ( is_static[b] << 10 ) | class_idx[b] ); } );
+  if( sorted_order ) for( int i = 0; i < n; ++i ) sorted_order[i] = ord[i];
+  int first_static = 0;                                                                      // :830-835
+  for( int i = 0; i < n; ++i ) if( is_static[ord[i]] ) { first_static = i; break; }
+  std::vector<rs_hip_placement_t> pl( n );
+  for( int i = 0; i < n; ++i )
+  {
+    std::memcpy( pl[i].pose, poses + 16 * ord[i], 64 ); pl[i].object = objects[ord[i]];
+    pl[i].radius = ( i < first_static ) ? radius : ( prioritize_static ? radius : 1.5f * radius );   // :837-848
+  }
+  if( ( rc = rs_hip_assign_labels( scene, pl.data(), first_static, 0, labels, min_dists ) ) ) return rc;
+  if( prioritize_static ) for( int64_t j = 0; j < ns; ++j ) min_dists[j] = 1e9;              // :841-844
+  return rs_hip_assign_labels( scene, pl.data() + first_static, n - first_static, first_static, labels, min_dists );
+}
+
+// ------------------------------------------------------------------------------------------
+// generic rows
+// ------------------------------------------------------------------------------------------
+
+int rs_hip_radius_search( const rs_hip_cloud_t* target, const float* query, int64_t n_query,
+                          float radius, int32_t k, float* distances_sq, int32_t* indices, size_t* n_neighbors,
+                          uint64_t* total )
+{
+  int rc = ensure_ready(); if( rc ) return rc;
+  if( !target || !query || !distances_sq || !indices || n_query < 0 || k <= 0 || !( radius > 0.0f ) ) { set_err( "radius_search: bad arguments" ); return RS_HIP_E_ARG; }
+  if( n_query > 0x7fffffff / 2 ) { set_err( "radius_search: too many queries for one call" ); return RS_HIP_E_CAPACITY; }
+  if( total ) *total = 0;
+  if( n_query == 0 ) return RS_HIP_OK;
+  const int nq = (int)n_query;
+  const GridView& g = target->view;
+  // order the queries by target cell so that each wave's 64 queries are neighbours
+  std::vector<std::pair<uint32_t, int>> key( nq );
+  for( int i = 0; i < nq; ++i )
+  {
+    int cx = cell_of( query[3*i], g.minx, g.inv_cell, g.w ), cy = cell_of( query[3*i+1], g.miny, g.inv_cell, g.h ), cz = cell_of( query[3*i+2], g.minz, g.inv_cell, g.d );
+    key[i] = { (uint32_t)( ( (size_t)cz * g.h + cy ) * g.w + cx ), i };
+  }
+  std::sort( key.begin(), key.end() );
+  std::vector<float4> q4( nq );
+  for( int s = 0; s < nq; ++s ) { int i = key[s].second; float w; std::memcpy( &w, &i, 4 ); q4[s] = make_float4( query[3*i], query[3*i+1], query[3*i+2], w ); }
+  const size_t nk = (size_t)nq * k;
+  if( ( rc = g_ws.q4.ensure( (size_t)nq * 16 ) ) || ( rc = g_ws.rd2.ensure( nk * 4 ) ) || ( rc = g_ws.ridx.ensure( nk * 4 ) ) || ( rc = g_ws.rnn.ensure( (size_t)nq * 4 ) ) ) return rc;
+  HIP_TRY( hipMemcpyAsync( g_ws.q4.p, q4.data(), (size_t)nq * 16, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipMemsetAsync( g_ws.rd2.p, 0, nk * 4, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipMemsetAsync( g_ws.ridx.p, 0, nk * 4, g_stream ), RS_HIP_E_RUNTIME );
+  RowsLaunch L{};
+  L.tgt = g; L.qpos = g_ws.q4.as<float4>(); L.nq = nq; L.K = k; L.radius = radius; L.radius_sq = radius_sq_of( radius );
+  L.d2 = g_ws.rd2.as<float>(); L.idx = g_ws.ridx.as<int>(); L.nn = g_ws.rnn.as<int>();
+  { ProfScope ps( "nn_rows" ); launch_rows( L, g_stream ); }
+  std::vector<int> nn( nq );
+  HIP_TRY( hipMemcpyAsync( distances_sq, L.d2, nk * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipMemcpyAsync( indices, L.idx, nk * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipMemcpyAsync( nn.data(), L.nn, (size_t)nq * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
+  uint64_t tot = 0;
+  for( int i = 0; i < nq; ++i ) { tot += (uint64_t)nn[i]; if( n_neighbors ) n_neighbors[i] = (size_t)nn[i]; }
+  if( total ) *total = tot;
+  return RS_HIP_OK;
+}
+
+} // extern "C"

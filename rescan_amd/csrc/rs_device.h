@@ -1,0 +1,103 @@
+// Shared host/device declarations for librescan_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace rs {
+
+// Device view of a cloud: 16-byte records sorted by grid cell, cell offset table.
+// pos[s] = {x, y, z, bitcast(original index)};  nor[s] = {nx, ny, nz, 0}.
+// cell id = (z*h + y)*w + x, so the cells of one (y,z) row are contiguous in x and a row's
+// x-interval [x0,x1] is the single span cell_start[row+x0] .. cell_start[row+x1+1].
+struct GridView
+{
+  const float4*   pos;
+  const float4*   nor;          // may be null
+  const uint32_t* cell_start;   // w*h*d + 1 entries
+  float minx, miny, minz;       // grid origin
+  float inv_cell;               // 1 / cell edge
+  int   w, h, d;
+  int   n;
+};
+
+struct Xform { float m[16]; };  // column-major, passed by value (lands in SGPRs)
+
+// One placement of the label kernel.
+struct PlacementDev
+{
+  GridView g;         // the placed object's cloud
+  Xform    inv;       // msh_mat4_inverse(pose)
+  Xform    nmat;      // msh_mat4_transpose(pose)
+  float    radius;    // search radius
+  float    radius_sq; // (float)((double)radius*(double)radius)
+};
+
+enum { ICP_NMOM = 35 };   // raw moments reduced per ICP iteration (see k_icp_moments)
+
+// ---- launchers (rs_kernels.hip) ----------------------------------------------------------
+struct IcpLaunch
+{
+  GridView     tgt;
+  const float4 *qpos, *qnor;   // source cloud, sorted order
+  int          nq;
+  int          n_prob;         // batch size
+  const float* T1;             // device, n_prob x 16
+  const int*   active;         // device, n_prob flags (0 = skip)
+  Xform        T2i;
+  float        radius, radius_sq, gate_tmin;
+  int          K;
+  // outputs / workspace (device)
+  int*    m_slot;   // n_prob x nq : matched target slot or -1
+  float*  m_d2;     // n_prob x nq
+  float*  m_dot;    // n_prob x nq
+  double* corr_part;  // n_prob x n_waves x 3
+  double* stats;      // n_prob x 4 : n_corr, mean, stddev, (unused)
+  double* mom_part;   // n_prob x n_mom_blocks x ICP_NMOM
+  double* moments;    // n_prob x ICP_NMOM
+  int     n_mom_blocks;
+  const float* w_explicit;   // if non-null: weights given per query (estimate-only entry point)
+};
+void launch_icp_corr( const IcpLaunch& L, hipStream_t st );
+void launch_icp_stats( const IcpLaunch& L, hipStream_t st );
+void launch_icp_moments( const IcpLaunch& L, hipStream_t st );
+
+struct ScoreLaunch
+{
+  GridView     scene;
+  const float4 *qpos, *qnor;
+  int          nq, n_poses;
+  const float* poses;      // device n_poses x 16
+  float        radius_sq, gate_tmin;
+  int          K;
+  double       sigma;      // (double)radius
+  double*      part;       // n_poses x n_tiles
+  float*       scores;     // n_poses
+};
+void launch_score( const ScoreLaunch& L, hipStream_t st );
+
+struct LabelLaunch
+{
+  const float4 *spos, *snor;   // scene cloud, sorted order
+  int          ns;
+  const PlacementDev* pl;      // device array
+  int          n_pl, label_base;
+  float        gate_tmin;
+  int8_t*      labels;         // scene original order (chain mode) or null
+  float*       min_d;          // scene original order (chain mode) or null
+  float*       rows;           // n_pl x ns rows (row mode) or null
+};
+void launch_label( const LabelLaunch& L, hipStream_t st );
+
+struct RowsLaunch
+{
+  GridView     tgt;
+  const float4* qpos;      // sorted queries, w = original query index
+  int          nq, K;
+  float        radius, radius_sq;
+  float*       d2;         // nq x K (original query order)
+  int*         idx;        // nq x K
+  int*         nn;         // nq
+};
+void launch_rows( const RowsLaunch& L, hipStream_t st );
+
+} // namespace rs

@@ -11,6 +11,11 @@ import numpy as np
 
 DENSITY = 6400.0
 JITTER = 0.0007
+# Normals of real scans are estimated from noisy points; perfectly axis-aligned synthetic normals
+# would make the ICP normal equations exactly rank-deficient whenever one face orientation drops
+# out of the correspondence set, and the reference's unpivoted LDL^T (lib/rs/lineqn.h:153-196) then
+# returns rounding noise.  A small angular perturbation keeps the systems well-posed.
+NORMAL_NOISE = 0.03
 
 
 def rot_y(angle):
@@ -101,9 +106,14 @@ CLASS_IDX = {"unlabelled": 0, "wall": 1, "floor": 2, "chair": 5, "table": 7, "sh
 STATIC_CLASSES = ("wall", "floor", "unlabelled")
 
 
+def noisy_normals(rng, N, sigma=NORMAL_NOISE):
+    N = N + rng.normal(0.0, sigma, N.shape)
+    return N / np.linalg.norm(N, axis=1, keepdims=True)
+
+
 def _finish(rng, P, N, jitter):
     P = P + rng.normal(0.0, jitter, P.shape)
-    return P.astype(np.float32), N.astype(np.float32)
+    return P.astype(np.float32), noisy_normals(rng, N).astype(np.float32)
 
 
 def make_object(kind, seed, density=DENSITY, scale=1.0, jitter=JITTER):
@@ -159,6 +169,7 @@ def make_scene(seed=7, width=3.2, depth=3.2, height=1.2, density=DENSITY, object
     cls = np.concatenate(cls).astype(np.int32); inst = np.concatenate(inst).astype(np.int32)
     rng_j = np.random.default_rng([seed, 3000 + timestep])
     P = P + rng_j.normal(0.0, jitter, P.shape)
+    N = noisy_normals(rng_j, N)
     if shuffle:
         perm = rng_j.permutation(len(P))
         P, N, cls, inst = P[perm], N[perm], cls[perm], inst[perm]

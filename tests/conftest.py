@@ -1,0 +1,74 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name)))
+
+
+@pytest.fixture(scope="session")
+def gscene():
+    """The shared golden inputs: scene scan + object model clouds."""
+    d = load_golden("scene.npz")
+    objs = [dict(pos=d[f"obj{i}_pos"], nor=d[f"obj{i}_nor"], pose=d["obj_pose"][i], class_idx=int(d["obj_class"][i]),
+                 uidx=int(d["obj_uidx"][i])) for i in range(int(d["n_obj"]))]
+    return dict(points=d["points"], normals=d["normals"], instance_idx=d["instance_idx"], objects=objs)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle.pyoracle import Oracle
+    return Oracle()
+
+
+def golden_files(prefix):
+    return sorted(f for f in os.listdir(GOLDEN) if f.startswith(prefix))
+
+
+def label_case(gscene, name):
+    """Rebuild the objects/placements of a labels_*.npz fixture."""
+    d = load_golden(name)
+    pts, nor = gscene["points"], gscene["normals"]
+    objs = []
+    for i in range(int(d["n_obj"])):
+        if f"obj{i}_sub" in d:
+            sub = d[f"obj{i}_sub"]
+            objs.append(dict(pos=np.ascontiguousarray(pts[sub]), nor=np.ascontiguousarray(nor[sub])))
+        else:
+            objs.append(dict(pos=gscene["objects"][i]["pos"], nor=gscene["objects"][i]["nor"]))
+        objs[-1]["class_idx"] = int(d["obj_class"][i]); objs[-1]["is_static"] = int(d["obj_static"][i])
+    plcs = [dict(pose=d["plc_pose"][k], object_idx=int(d["plc_obj"][k]), uidx=int(d["plc_uidx"][k]))
+            for k in range(int(d["n_plc"]))]
+    return d, objs, plcs
+
+
+def rows_equal_up_to_ties(d_a, i_a, nn_a, d_b, i_b, nn_b):
+    """Rows agree: same counts, identical distance rows, identical indices except inside runs
+    of exactly equal distances (where the reference's order is an accident of its sort)."""
+    assert (nn_a == nn_b).all()
+    k = d_a.shape[1]
+    valid = np.arange(k)[None, :] < nn_a[:, None]
+    assert (d_a[valid] == d_b[valid]).all()
+    diff = valid & (i_a != i_b)
+    if diff.any():
+        # every differing slot must sit in a tie run, and the index multisets of the row must agree
+        rows = np.nonzero(diff.any(axis=1))[0]
+        for r in rows:
+            n = int(nn_a[r])
+            for c in np.nonzero(diff[r])[0]:
+                tie = (c > 0 and d_a[r, c] == d_a[r, c - 1]) or (c + 1 < n and d_a[r, c] == d_a[r, c + 1])
+                assert tie, f"row {r} col {c}: index differs without a distance tie"
+    return int(diff.sum())
