@@ -1,0 +1,290 @@
+#!/usr/bin/env python3
+"""bench.py — point-pairs/sec of the Rescan hot path on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the three consumers over one synthetic 2-scan scene held in HBM
+(BASELINE.json configs[1]):
+
+  ICP-NN    whole-scan point-to-plane ICP, scan t1 (~1M pts) -> scan t0 (~1M pts), K=16,
+            r = 0.10 with the reference's 0.95 shrink schedule, 60°, 10 fixed iterations
+            (search + weights + normal-equation reduction on the GPU, 6x6 solve on the host)
+  score-NN  256 poses x 10k-point object against the 1M-point scan, K=64, r=0.10, 35° gate
+  label-NN  8 placements of ~50k-point objects against the 1M scene points, K=1, r=0.05
+
+point-pairs = sum of query points over all searches = 10*n_scan + 256*n_obj + 8*n_scan.
+Inputs are resident in HBM when the timed region starts; poses / scores / labels return to the
+host inside the timed region (they are the outputs the reference's callers consume).
+
+N > 1 (torchrun, one rank per GPU, RCCL): weak scaling — every rank processes its own scene of
+the same size (independent units) and the ranks all-gather the resulting poses,
+scores and label partials; value = pairs of all ranks / max-over-ranks time.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
+ICP_ITERS = 10
+N_POSES = 256
+N_PLACEMENTS = 8
+I4 = np.eye(4, dtype=np.float32).ravel()
+
+
+def build_workload(n_points, seed, knn):
+    from rescan_amd import capi, synth
+    s0 = synth.scene_for_point_count(int(n_points * 0.84), seed=seed, timestep=0)
+    s1 = synth.scene_for_point_count(int(n_points * 0.84), seed=seed, timestep=1)
+    cell = 0.1 if knn == "hash" else 0.0
+    w = {}
+    w["s0"], w["s1"] = s0, s1
+    w["scan0"] = capi.Cloud(s0["points"], s0["normals"], cell_size=cell)      # ICP target
+    w["scan1"] = capi.Cloud(s1["points"], s1["normals"], cell_size=cell)      # ICP source, score + label scene
+    rng = np.random.default_rng(seed + 5)
+    w["icp_T0"] = synth.perturbed_pose(I4, rng, 0.01, 0.01)
+    # score object: a table model resampled to ~10k points
+    op, on = synth.make_object("table", seed * 13 + 1, density=3800.0)
+    w["obj_score_np"] = (op, on)
+    w["obj_score"] = capi.Cloud(op, on, cell_size=0.1)
+    tbl = [o for o in s1["objects"] if o["kind"] == "table"][0]
+    w["score_poses"] = np.stack([synth.perturbed_pose(tbl["pose"], rng, 0.6, 0.25) for _ in range(N_POSES)])
+    # label placements: 8 scene objects with dense (~50k-point) model clouds, slightly mis-posed
+    plc = []
+    for k, o in enumerate(s1["objects"][:N_PLACEMENTS]):
+        dens = 50000.0 / max(1, len(o["pos"])) * synth.DENSITY
+        lp, ln = synth.make_object(o["kind"], seed * 7919 + k, density=dens)
+        plc.append(dict(cloud=capi.Cloud(lp, ln, cell_size=0.1), np=(lp, ln),
+                        pose=synth.perturbed_pose(o["pose"], rng, 0.01, 0.005), cls=o["class_idx"]))
+    w["plc"] = plc
+    w["n_scan0"], w["n_scan1"], w["n_obj"] = len(s0["points"]), len(s1["points"]), len(op)
+    w["pairs"] = dict(icp=ICP_ITERS * w["n_scan1"], score=N_POSES * w["n_obj"], label=len(plc) * w["n_scan1"])
+    return w
+
+
+def run_step(w, dist_ctx=None):
+    """One pass of the hot path.  Returns the outputs (poses, scores, labels)."""
+    from rescan_amd import capi
+    err, T, it = capi.icp_align(w["scan1"], w["scan0"], w["icp_T0"], I4, 0.10, np.deg2rad(60.0),
+                                max_iter=ICP_ITERS, fixed_iters=True)
+    scores = capi.alignment_scores(w["obj_score"], w["scan1"], w["score_poses"], 0.1, 64)
+    res = capi.arrangement_to_labels(w["scan1"], np.stack([p["pose"] for p in w["plc"]]),
+                                     [p["cloud"] for p in w["plc"]], [0] * len(w["plc"]),
+                                     [p["cls"] for p in w["plc"]], 0.05, False)
+    if dist_ctx is not None:
+        # exchange step: every rank receives every rank's poses / scores / label partials
+        import torch
+        dist, dev = dist_ctx
+        small = torch.from_numpy(np.concatenate([T, [err], scores]).astype(np.float32)).to(dev)
+        out = [torch.empty_like(small) for _ in range(dist.get_world_size())]
+        dist.all_gather(out, small)
+        lab = torch.from_numpy(res["labels"]).to(dev)
+        mind = torch.from_numpy(res["min_dists"]).to(dev)
+        # scenes differ slightly in size across ranks: pad to a common length
+        n = torch.tensor([lab.numel()], device=dev)
+        dist.all_reduce(n, op=dist.ReduceOp.MAX)
+        padl = torch.zeros(int(n.item()), dtype=lab.dtype, device=dev); padl[: lab.numel()] = lab
+        padm = torch.zeros(int(n.item()), dtype=mind.dtype, device=dev); padm[: mind.numel()] = mind
+        gl = [torch.empty_like(padl) for _ in range(dist.get_world_size())]
+        gm = [torch.empty_like(padm) for _ in range(dist.get_world_size())]
+        dist.all_gather(gl, padl); dist.all_gather(gm, padm)
+    return err, T, scores, res
+
+
+def cpu_baseline(w, budget_s=20.0):
+    """The reference itself (oracle/_ref, built from /root/reference in the build container and
+    shipped as a .so), timed on this host on a bounded sample of the same workload.  Grids are
+    prebuilt outside the timed region, mirroring 'inputs resident' on the GPU side."""
+    import ctypes
+    from oracle.pyoracle import Ref
+    out = {}
+    for omp in (True, False):
+        if not Ref.available(omp=omp):
+            continue
+        nthr = 1
+        if omp:
+            # The reference's OpenMP split (msh_hash_grid.h:1122-1133) underflows `high_lim - low_lim`
+            # when thread_idx * ceil(n/threads) > n, i.e. for many threads and query counts that are
+            # not a multiple of the thread count.  Use a power-of-two thread count and trim every
+            # sampled query set to a multiple of it, so the reference runs as its author intended.
+            avail = len(os.sched_getaffinity(0))
+            nthr = 1
+            while nthr * 2 <= min(avail, 128):
+                nthr *= 2
+            ctypes.CDLL("libgomp.so.1").omp_set_num_threads(nthr)
+        R = Ref(omp=omp)
+        cores = R.num_threads()
+        trim = lambda n: (n // nthr) * nthr  # noqa: E731
+        s0, s1 = w["s0"], w["s1"]
+        rng = np.random.default_rng(0)
+        # ICP-NN: one find_corrs iteration on a query sample against the full target
+        n_q = trim(min(len(s1["points"]), 200_000 if omp else 60_000))
+        sel = np.sort(rng.choice(len(s1["points"]), n_q, replace=False))
+        qp, qn = np.ascontiguousarray(s1["points"][sel]), np.ascontiguousarray(s1["normals"][sel])
+        g0 = R.grid_create(s0["points"], 0.10)                     # icp.h:437 (radius = max_dist)
+        t = time.perf_counter()
+        R.icp_find_corrs_grid(g0, qp, qn, s0["points"], s0["normals"], w["icp_T0"], I4, 0.10, np.float32(np.deg2rad(60.0)))
+        t_icp = (time.perf_counter() - t) / n_q
+        R.grid_destroy(g0)
+        # score-NN: a few poses of the same object against the full scene (grid radius 0.05)
+        scn = R.scene_create(s1["points"], s1["normals"])
+        n_p = 24 if omp else 8
+        op, on = w["obj_score_np"]
+        op, on = np.ascontiguousarray(op[: trim(len(op))]), np.ascontiguousarray(on[: trim(len(on))])
+        t = time.perf_counter()
+        R.alignment_scores(s1["points"], s1["normals"], op, on, w["score_poses"][:n_p], 64, scene=scn)
+        t_score = (time.perf_counter() - t) / (n_p * len(op))
+        R.scene_destroy(scn)
+        # label-NN: transform + K=1 search in the object's grid for a sample of scene points, 2 placements
+        # (the reference's label loop itself needs the un-vendored gco header; its gate loop is omitted,
+        #  which favours the CPU)
+        n_l = trim(min(len(s1["points"]), 400_000))
+        sel = np.sort(rng.choice(len(s1["points"]), n_l, replace=False))
+        sp = np.ascontiguousarray(s1["points"][sel])
+        t_label = 0.0
+        for p in w["plc"][:2]:
+            g = R.grid_create(p["np"][0], 0.05)
+            inv = R.mat4_inverse(p["pose"])
+            t = time.perf_counter()
+            q = R.xform_points(inv, sp, 1)
+            R.radius_search(g, q, 0.05, 1, 0)
+            t_label += time.perf_counter() - t
+            R.grid_destroy(g)
+        t_label /= 2 * n_l
+        pr = w["pairs"]
+        total = pr["icp"] + pr["score"] + pr["label"]
+        est = pr["icp"] * t_icp + pr["score"] * t_score + pr["label"] * t_label
+        out["omp" if omp else "single"] = dict(
+            value=total / est, unit="point-pairs/s", cores=cores, kind="reference",
+            sample=f"1 icp_find_corrs on {n_q} queries + {n_p} score poses x {len(op)} pts + 2 label placements x {n_l} pts; "
+                   f"per-pair times ICP {t_icp*1e9:.0f} ns, score {t_score*1e9:.0f} ns, label {t_label*1e9:.0f} ns, "
+                   f"combined in the GPU workload's mix")
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--points", type=int, default=1_000_000, help="points per scan")
+    ap.add_argument("--knn", choices=["hash", "brute"], default="hash",
+                    help="candidate layout: LDS spatial-hash cells (default) or one brute tile")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from rescan_amd import capi
+    capi.init(local_rank)
+    capi.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    w = build_workload(args.points, seed=11 + rank, knn=args.knn)
+    dist_ctx = (dist, dev) if dist is not None else None
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        run_step(w, dist_ctx)
+    capi.profile_enable(True)
+    capi.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run_step(w, dist_ctx)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    capi.profile_enable(False)
+
+    pairs_rank = sum(w["pairs"].values()) * args.steps
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        p = torch.tensor([pairs_rank], device=dev, dtype=torch.float64)
+        dist.all_reduce(p, op=dist.ReduceOp.SUM)
+        pairs_total = float(p.item())
+    else:
+        pairs_total = float(pairs_rank)
+
+    if rank == 0:
+        # dominant kernel: the ICP correspondence search (k_icp_corr)
+        prof = {k: capi.profile_read(k) for k in ("nn_icp", "icp_moments", "nn_score", "nn_label")}
+        dom = max(prof, key=lambda k: prof[k][1])
+        n_l, ms = prof[dom]
+        # algorithmic bytes per launch (SURVEY.md §8d / BASELINE.md §3.5)
+        if dom == "nn_icp":
+            bytes_launch = w["n_scan1"] * 56 + w["n_scan0"] * 16
+        elif dom == "nn_score":
+            bytes_launch = N_POSES * w["n_obj"] * 40 + w["n_scan1"] * 16
+        elif dom == "nn_label":
+            bytes_launch = len(w["plc"]) * w["n_scan1"] * 46 + sum(len(p["np"][0]) for p in w["plc"]) * 16
+        else:
+            bytes_launch = w["n_scan1"] * 56
+        avg_s = (ms / max(1, n_l)) * 1e-3
+        achieved = bytes_launch / avg_s / 1e9 if avg_s > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom)
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "point-pairs/sec (ICP-NN + score-NN + segment-NN) per scene",
+            "value": pairs_total / elapsed, "unit": "point-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: single scene, 2 timesteps, ~1M-pt scans on 1xMI355X per rank: "
+                                   "ICP-NN 10 it x scan->scan + score-NN 256 poses x 10k + label-NN 8 placements",
+                       "knn": "lds-hash-cells" if args.knn == "hash" else "brute-tile",
+                       "n_scan0": w["n_scan0"], "n_scan1": w["n_scan1"], "n_obj": w["n_obj"],
+                       "pairs_per_step": sum(w["pairs"].values()), "pairs_split": w["pairs"],
+                       "exchange": "all_gather(poses, scores, label partials)" if world > 1 else "none"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "avg_launch_ms": ms / max(1, n_l), "launches": n_l, "alg_bytes_per_launch": bytes_launch},
+            "kernel_ms_per_step": {k: v[1] / args.steps for k, v in prof.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                cb = cpu_baseline(w)
+                if "omp" in cb:
+                    line["cpu_baseline"] = cb["omp"]
+                    if "single" in cb:
+                        line["cpu_baseline_single_thread"] = cb["single"]
+                elif "single" in cb:
+                    line["cpu_baseline"] = cb["single"]
+            except Exception as e:  # the baseline is reported, never required for the GPU number
+                line["cpu_baseline"] = {"value": None, "unit": "point-pairs/s", "cores": 0, "kind": "reference",
+                                        "sample": f"unavailable: {e}"}
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

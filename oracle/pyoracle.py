@@ -231,6 +231,9 @@ class Ref(_Base):
         self._scene_grid = self._fn("scene_grid", C.c_void_p, [C.c_void_p])
         self._scores = self._fn("alignment_scores", None,
                                 [C.c_void_p, f32p, f32p, C.c_int32, f32p, C.c_int32, C.c_int32, f32p])
+        self._find_corrs_grid = self._fn("icp_find_corrs_grid", C.c_int32,
+                                         [C.c_void_p, f32p, f32p, C.c_int32, f32p, f32p, C.c_int32, f32p, f32p,
+                                          C.c_float, C.c_float])
         self._label_gate = self._fn("label_gate", C.c_int, [f32p, f32p, f32p])
         self._label_gate_dot = self._fn("label_gate_dot", C.c_int, [C.c_float])
         self._num_threads = self._fn("num_threads", C.c_int, [])
@@ -246,6 +249,11 @@ class Ref(_Base):
         nc = self._find_corrs(pts1, nor1, n1, pts2, nor2, len(pts2), _f32(T1).ravel(), _f32(T2).ravel(),
                               float(max_dist), float(max_angle), *out, w)
         return [o[:nc] for o in out] + [w[:nc]]
+
+    def icp_find_corrs_grid(self, grid2, pts1, nor1, pts2, nor2, T1, T2, max_dist, max_angle):
+        """One icp_find_corrs against a prebuilt grid of pts2; returns n_corrs only."""
+        return self._find_corrs_grid(grid2, pts1, nor1, len(pts1), pts2, nor2, len(pts2), _f32(T1).ravel(),
+                                     _f32(T2).ravel(), float(max_dist), float(max_angle))
 
     def icp_align(self, pts1, nor1, pts2, nor2, T1, T2, max_dist, max_angle):
         pts1, nor1, pts2, nor2 = map(_f32, (pts1, nor1, pts2, nor2))

@@ -166,6 +166,20 @@ int32_t ref_icp_find_corrs( float* pts1, float* nor1, int32_t n1, float* pts2, f
   return nc;
 }
 
+// icp_find_corrs against a prebuilt target grid (what one iteration of icp_align does after
+// :436-437); only the correspondence count is returned.  Used by the CPU-baseline timing.
+int32_t ref_icp_find_corrs_grid( void* index2, float* pts1, float* nor1, int32_t n1, float* pts2, float* nor2, int32_t n2,
+                                 const float* T1, const float* T2, float max_dist, float max_angle )
+{
+  msh_mat4_t t1, t2; memcpy( t1.data, T1, 64 ); memcpy( t2.data, T2, 64 );
+  msh_vec3_t *cp1 = NULL, *cn1 = NULL, *cp2 = NULL, *cn2 = NULL; float* cw = NULL; int32_t nc = 0;
+  icp_find_corrs( (msh_vec3_t*)pts1, (msh_vec3_t*)nor1, n1, (msh_hash_grid_t*)index2,
+                  (msh_vec3_t*)pts2, (msh_vec3_t*)nor2, n2, (msh_hash_grid_t*)index2,
+                  t1, t2, &cp1, &cn1, &cp2, &cn2, &cw, &nc, max_dist, max_angle );
+  free( cp1 ); free( cn1 ); free( cp2 ); free( cn2 ); free( cw );
+  return nc;
+}
+
 float ref_icp_estimate_pt2pl( float* p1, float* p2, float* n2, float* w, int32_t n, float* T1 )
 {
   msh_mat4_t t1; memcpy( t1.data, T1, 64 );

@@ -144,6 +144,12 @@ struct rs_hip_cloud
   float4* d_pos = nullptr;
   float4* d_nor = nullptr;
   uint32_t* d_cell_start = nullptr;
+  // query layout: the same points in Hilbert order, cut into tiles (one wave each)
+  QueryView qview{};
+  float4* d_qpos = nullptr;
+  float4* d_qnor = nullptr;
+  uint32_t* d_tiles = nullptr;
+  std::vector<int32_t> qorder;    // query slot -> original index
   std::vector<int32_t> order;     // sorted slot -> original index
   std::vector<float> h_pos, h_nor;  // original-order host copies (AoS)
   float cell = 0.0f;
@@ -160,6 +166,88 @@ inline int cell_of( float v, float gmin, float inv_cell, int dim )
   if( !( c >= 0.0f ) ) c = 0.0f;
   if( c > (float)( dim - 1 ) ) c = (float)( dim - 1 );
   return (int)c;
+}
+
+
+// ---- query layout ---------------------------------------------------------------------------
+// Index of a cell on a 3-D Hilbert curve with `bits` bits per axis (Skilling's transpose form).
+// Consecutive cells of the curve are face neighbours, so consecutive points are spatially close
+// wherever the surface is continuous.
+inline uint32_t hilbert3( uint32_t x, uint32_t y, uint32_t z, int bits )
+{
+  uint32_t X[3] = { x, y, z };
+  const uint32_t M = 1u << ( bits - 1 );
+  for( uint32_t Q = M; Q > 1; Q >>= 1 )
+  {
+    const uint32_t P = Q - 1;
+    for( int i = 0; i < 3; ++i )
+    {
+      if( X[i] & Q ) X[0] ^= P;
+      else { uint32_t t = ( X[0] ^ X[i] ) & P; X[0] ^= t; X[i] ^= t; }
+    }
+  }
+  X[1] ^= X[0]; X[2] ^= X[1];
+  uint32_t t = 0;
+  for( uint32_t Q = M; Q > 1; Q >>= 1 ) if( X[2] & Q ) t ^= Q - 1;
+  X[0] ^= t; X[1] ^= t; X[2] ^= t;
+  uint32_t h = 0;
+  for( int b = bits - 1; b >= 0; --b )
+    for( int i = 0; i < 3; ++i ) h = ( h << 1 ) | ( ( X[i] >> b ) & 1u );
+  return h;
+}
+
+// Hilbert order of the points + greedy tiling: a tile ends after 64 points or when adding the
+// next point would stretch its bounding box beyond `max_extent` on any axis (the curve crosses
+// empty space there).  Any tiling is correct — tiles only decide which candidates a wave
+// stages — so this is purely a load-balance / locality choice.
+void build_query_layout( const float* pos, int32_t n, float max_extent, std::vector<int32_t>& order, std::vector<uint32_t>& tiles )
+{
+  order.resize( (size_t)n ); tiles.clear(); tiles.push_back( 0u );
+  if( n == 0 ) return;
+  float mn[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, mx[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+  for( int32_t i = 0; i < n; ++i ) for( int a = 0; a < 3; ++a ) { float v = pos[3*i+a]; if( v < mn[a] ) mn[a] = v; if( v > mx[a] ) mx[a] = v; }
+  float ext = 0.0f;
+  for( int a = 0; a < 3; ++a ) { float e = mx[a] - mn[a]; if( std::isfinite( e ) && e > ext ) ext = e; }
+  const int bits = 10;
+  const float scale = ext > 0.0f ? (float)( 1 << bits ) / ext : 0.0f;
+  std::vector<uint64_t> key( (size_t)n );
+  for( int32_t i = 0; i < n; ++i )
+  {
+    uint32_t c[3];
+    for( int a = 0; a < 3; ++a )
+    {
+      float f = ( pos[3*i+a] - mn[a] ) * scale;
+      if( !( f >= 0.0f ) ) f = 0.0f;
+      if( f > (float)( ( 1 << bits ) - 1 ) ) f = (float)( ( 1 << bits ) - 1 );
+      c[a] = (uint32_t)f;
+    }
+    key[i] = ( (uint64_t)hilbert3( c[0], c[1], c[2], bits ) << 32 ) | (uint32_t)i;
+  }
+  std::sort( key.begin(), key.end() );
+  for( int32_t s = 0; s < n; ++s ) order[s] = (int32_t)( key[s] & 0xffffffffu );
+  float lo[3], hi[3]; int count = 0;
+  for( int32_t s = 0; s < n; ++s )
+  {
+    const float* p = pos + 3 * (size_t)order[s];
+    bool cut = count == 64;
+    if( !cut && count > 0 )
+      for( int a = 0; a < 3; ++a ) { float l = std::min( lo[a], p[a] ), h = std::max( hi[a], p[a] ); if( h - l > max_extent ) cut = true; }
+    if( cut ) { tiles.push_back( (uint32_t)s ); count = 0; }
+    if( count == 0 ) { for( int a = 0; a < 3; ++a ) { lo[a] = hi[a] = p[a]; } }
+    else for( int a = 0; a < 3; ++a ) { lo[a] = std::min( lo[a], p[a] ); hi[a] = std::max( hi[a], p[a] ); }
+    count++;
+  }
+  tiles.push_back( (uint32_t)n );
+}
+
+// Tile extent limit from the cloud's own sampling density: a full tile of 64 surface samples
+// spans about 8 sample spacings; allow half as much again, and never less than 0.25 m.
+float query_extent_limit( int32_t n, size_t occupied_cells, float cell )
+{
+  if( n <= 0 || occupied_cells == 0 || !( cell > 0.0f ) ) return FLT_MAX;
+  float per_cell = (float)n / (float)occupied_cells;
+  float spacing = cell / std::sqrt( std::max( per_cell, 1.0f ) );
+  return std::max( 0.25f, 12.0f * spacing );
 }
 
 } // namespace
@@ -293,6 +381,39 @@ rs_hip_cloud_t* rs_hip_cloud_create( const float* pos, const float* nor, int32_t
   v.pos = c->d_pos; v.nor = c->d_nor; v.cell_start = c->d_cell_start;
   v.minx = mn[0]; v.miny = mn[1]; v.minz = mn[2]; v.inv_cell = inv_cell;
   v.w = dims[0]; v.h = dims[1]; v.d = dims[2]; v.n = n;
+
+  // query layout (Hilbert order + tiles)
+  size_t occupied = 0;
+  for( size_t k = 0; k < n_cells; ++k ) occupied += ( start[k + 1] > start[k] ) ? 1 : 0;
+  float lim_cell = cell_size > 0.0f ? cell : 0.1f;
+  if( !( cell_size > 0.0f ) )
+  {
+    // brute layout has one cell: estimate the occupancy of a 0.1 m grid instead
+    double vol_cells = 1.0; for( int a = 0; a < 3; ++a ) vol_cells *= std::floor( ( (double)mx[a] - mn[a] ) / 0.1 ) + 1.0;
+    occupied = (size_t)std::max( 1.0, std::min( (double)n, std::pow( vol_cells, 2.0 / 3.0 ) ) );
+  }
+  std::vector<uint32_t> tiles;
+  build_query_layout( pos, n, query_extent_limit( n, occupied, lim_cell ), c->qorder, tiles );
+  std::vector<float4> qpos( (size_t)n ), qnor( nor ? (size_t)n : 0 );
+  for( int32_t s = 0; s < n; ++s )
+  {
+    int32_t i = c->qorder[s];
+    float w; std::memcpy( &w, &i, 4 );
+    qpos[s] = make_float4( pos[3*i], pos[3*i+1], pos[3*i+2], w );
+    if( nor ) qnor[s] = make_float4( nor[3*i], nor[3*i+1], nor[3*i+2], 0.0f );
+  }
+  if( ( e = hipMalloc( (void**)&c->d_qpos, pb ) ) != hipSuccess ) return fail( e );
+  if( nor && ( e = hipMalloc( (void**)&c->d_qnor, pb ) ) != hipSuccess ) return fail( e );
+  if( ( e = hipMalloc( (void**)&c->d_tiles, tiles.size() * 4 ) ) != hipSuccess ) return fail( e );
+  if( n > 0 )
+  {
+    if( ( e = hipMemcpy( c->d_qpos, qpos.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice ) ) != hipSuccess ) return fail( e );
+    if( nor && ( e = hipMemcpy( c->d_qnor, qnor.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice ) ) != hipSuccess ) return fail( e );
+  }
+  if( ( e = hipMemcpy( c->d_tiles, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice ) ) != hipSuccess ) return fail( e );
+  c->bytes += (int64_t)( pb * ( nor ? 2 : 1 ) + tiles.size() * 4 );
+  c->qview.pos = c->d_qpos; c->qview.nor = c->d_qnor; c->qview.tiles = c->d_tiles;
+  c->qview.n = n; c->qview.n_tiles = (int)tiles.size() - 1;
   return c;
 }
 
@@ -302,6 +423,9 @@ void rs_hip_cloud_destroy( rs_hip_cloud_t* c )
   if( c->d_pos ) (void)hipFree( c->d_pos );
   if( c->d_nor ) (void)hipFree( c->d_nor );
   if( c->d_cell_start ) (void)hipFree( c->d_cell_start );
+  if( c->d_qpos ) (void)hipFree( c->d_qpos );
+  if( c->d_qnor ) (void)hipFree( c->d_qnor );
+  if( c->d_tiles ) (void)hipFree( c->d_tiles );
   delete c;
 }
 
@@ -392,11 +516,11 @@ int icp_prepare( IcpCtx& cx, const rs_hip_cloud_t* src, const rs_hip_cloud_t* tg
   if( !src || !tgt || !src->has_nor || !tgt->has_nor ) { set_err( "icp: source and target clouds need normals" ); return RS_HIP_E_ARG; }
   if( n_prob <= 0 ) { set_err( "icp: empty batch" ); return RS_HIP_E_ARG; }
   IcpLaunch& L = cx.L;
-  L.tgt = tgt->view; L.qpos = src->d_pos; L.qnor = src->d_nor; L.nq = src->n; L.n_prob = n_prob; L.K = 16;   // icp.h:330
+  L.tgt = tgt->view; L.src = src->qview; L.n_prob = n_prob; L.K = 16;   // icp.h:330
   Mat4 t2; std::memcpy( t2.m, T2, 64 );
   Mat4 t2i = mat4_inverse( t2 );                                                                             // icp.h:329
   std::memcpy( L.T2i.m, t2i.m, 64 );
-  cx.n_waves = ( src->n + 63 ) / 64;
+  cx.n_waves = src->qview.n_tiles;
   L.n_mom_blocks = std::max( 1, std::min( 256, ( src->n + 255 ) / 256 ) );
   const size_t nq = std::max<size_t>( 1, (size_t)src->n ), np = (size_t)n_prob;
   int rc;
@@ -525,7 +649,7 @@ int rs_hip_icp_find_corrs( const rs_hip_cloud_t* source, const rs_hip_cloud_t* t
   // Back to source order and compact (icp.h:381-391).  The query positions/normals are
   // re-derived on the host with the same two mat·vec products the kernel used.
   std::vector<int> by_orig( nq );
-  for( int s = 0; s < nq; ++s ) by_orig[source->order[s]] = s;
+  for( int s = 0; s < nq; ++s ) by_orig[source->qorder[s]] = s;
   Mat4 t2; std::memcpy( t2.m, T2, 64 ); Mat4 t2i = mat4_inverse( t2 );
   auto apply = []( const Mat4& M, const float* v, float w, float* o ) {
     o[0] = M.m[0] * v[0] + M.m[4] * v[1] + M.m[ 8] * v[2] + w * M.m[12];
@@ -594,7 +718,7 @@ int rs_hip_icp_estimate_pt2pl( const float* pts1, const float* pts2, const float
   HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );     // host staging vectors go out of scope below
   IcpLaunch L{};
   L.tgt.pos = g_ws.tmp_pos2.as<float4>(); L.tgt.nor = g_ws.tmp_nor2.as<float4>(); L.tgt.n = n;
-  L.qpos = g_ws.tmp_pos.as<float4>(); L.qnor = nullptr; L.nq = n; L.n_prob = 1;
+  L.src.pos = g_ws.tmp_pos.as<float4>(); L.src.nor = nullptr; L.src.tiles = nullptr; L.src.n = n; L.src.n_tiles = 0; L.n_prob = 1;
   L.T1 = g_ws.T1.as<float>(); L.active = g_ws.active.as<int>(); std::memcpy( L.T2i.m, I.m, 64 );
   L.radius = 1.0f; L.m_slot = g_ws.slot.as<int>(); L.m_d2 = g_ws.d2.as<float>(); L.m_dot = g_ws.dot.as<float>();
   L.stats = g_ws.stats.as<double>(); L.mom_part = g_ws.mom_part.as<double>(); L.moments = g_ws.moments.as<double>();
@@ -624,13 +748,13 @@ int rs_hip_alignment_scores( const rs_hip_cloud_t* object, const rs_hip_cloud_t*
   { set_err( "alignment_scores: bad arguments" ); return RS_HIP_E_ARG; }
   if( n_poses == 0 ) return RS_HIP_OK;
   if( object->n == 0 ) { for( int p = 0; p < n_poses; ++p ) scores[p] = NAN; return RS_HIP_OK; }   // 0/0, pose_proposal.cpp:156
-  const int n_tiles = ( object->n + 63 ) / 64;
+  const int n_tiles = object->qview.n_tiles;
   if( ( rc = g_ws.poses.ensure( (size_t)n_poses * 64 ) ) || ( rc = g_ws.score_part.ensure( (size_t)n_poses * n_tiles * 8 ) ) ||
       ( rc = g_ws.scores.ensure( (size_t)n_poses * 4 ) ) )
     return rc;
   HIP_TRY( hipMemcpyAsync( g_ws.poses.p, poses, (size_t)n_poses * 64, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
   ScoreLaunch L{};
-  L.scene = scene->view; L.qpos = object->d_pos; L.qnor = object->d_nor; L.nq = object->n;
+  L.scene = scene->view; L.obj = object->qview;
   L.poses = g_ws.poses.as<float>(); L.radius_sq = radius_sq_of( radius ); L.gate_tmin = score_gate_threshold();
   L.K = max_n_neigh; L.sigma = (double)radius; L.part = g_ws.score_part.as<double>(); L.scores = g_ws.scores.as<float>();
   // the launch grid's y dimension is limited to 65535 poses per launch
@@ -681,7 +805,7 @@ int rs_hip_assign_labels( const rs_hip_cloud_t* scene, const rs_hip_placement_t*
   HIP_TRY( hipMemcpyAsync( g_ws.labels.p, labels, ns, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
   HIP_TRY( hipMemcpyAsync( g_ws.mind.p, min_dists, ns * 4, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
   LabelLaunch L{};
-  L.spos = scene->d_pos; L.snor = scene->d_nor; L.ns = scene->n; L.pl = g_ws.plc.as<PlacementDev>(); L.n_pl = n;
+  L.scene = scene->qview; L.pl = g_ws.plc.as<PlacementDev>(); L.n_pl = n;
   L.label_base = label_base; L.gate_tmin = label_gate_threshold();
   L.labels = g_ws.labels.as<int8_t>(); L.min_d = g_ws.mind.as<float>(); L.rows = nullptr;
   { ProfScope ps( "nn_label" ); launch_label( L, g_stream ); }
@@ -702,7 +826,7 @@ int rs_hip_label_rows( const rs_hip_cloud_t* scene, const rs_hip_placement_t* pl
   float* d_rows = rows;
   if( !rows_device ) { if( ( rc = g_ws.rows.ensure( (size_t)n * ns * 4 ) ) ) return rc; d_rows = g_ws.rows.as<float>(); }
   LabelLaunch L{};
-  L.spos = scene->d_pos; L.snor = scene->d_nor; L.ns = scene->n; L.pl = g_ws.plc.as<PlacementDev>(); L.n_pl = n;
+  L.scene = scene->qview; L.pl = g_ws.plc.as<PlacementDev>(); L.n_pl = n;
   L.label_base = 0; L.gate_tmin = label_gate_threshold(); L.labels = nullptr; L.min_d = nullptr; L.rows = d_rows;
   { ProfScope ps( "nn_label" ); launch_label( L, g_stream ); }
   if( !rows_device )
@@ -768,23 +892,20 @@ int rs_hip_radius_search( const rs_hip_cloud_t* target, const float* query, int6
   if( n_query == 0 ) return RS_HIP_OK;
   const int nq = (int)n_query;
   const GridView& g = target->view;
-  // order the queries by target cell so that each wave's 64 queries are neighbours
-  std::vector<std::pair<uint32_t, int>> key( nq );
-  for( int i = 0; i < nq; ++i )
-  {
-    int cx = cell_of( query[3*i], g.minx, g.inv_cell, g.w ), cy = cell_of( query[3*i+1], g.miny, g.inv_cell, g.h ), cz = cell_of( query[3*i+2], g.minz, g.inv_cell, g.d );
-    key[i] = { (uint32_t)( ( (size_t)cz * g.h + cy ) * g.w + cx ), i };
-  }
-  std::sort( key.begin(), key.end() );
+  // order the queries along a Hilbert curve and tile them, exactly like a cloud's query layout
+  std::vector<int32_t> qorder; std::vector<uint32_t> tiles;
+  build_query_layout( query, nq, std::max( 0.25f, 4.0f * radius ), qorder, tiles );
   std::vector<float4> q4( nq );
-  for( int s = 0; s < nq; ++s ) { int i = key[s].second; float w; std::memcpy( &w, &i, 4 ); q4[s] = make_float4( query[3*i], query[3*i+1], query[3*i+2], w ); }
+  for( int s = 0; s < nq; ++s ) { int i = qorder[s]; float w; std::memcpy( &w, &i, 4 ); q4[s] = make_float4( query[3*i], query[3*i+1], query[3*i+2], w ); }
   const size_t nk = (size_t)nq * k;
-  if( ( rc = g_ws.q4.ensure( (size_t)nq * 16 ) ) || ( rc = g_ws.rd2.ensure( nk * 4 ) ) || ( rc = g_ws.ridx.ensure( nk * 4 ) ) || ( rc = g_ws.rnn.ensure( (size_t)nq * 4 ) ) ) return rc;
+  if( ( rc = g_ws.q4.ensure( (size_t)nq * 16 ) ) || ( rc = g_ws.tmp_pos.ensure( tiles.size() * 4 ) ) || ( rc = g_ws.rd2.ensure( nk * 4 ) ) || ( rc = g_ws.ridx.ensure( nk * 4 ) ) || ( rc = g_ws.rnn.ensure( (size_t)nq * 4 ) ) ) return rc;
   HIP_TRY( hipMemcpyAsync( g_ws.q4.p, q4.data(), (size_t)nq * 16, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipMemcpyAsync( g_ws.tmp_pos.p, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
   HIP_TRY( hipMemsetAsync( g_ws.rd2.p, 0, nk * 4, g_stream ), RS_HIP_E_RUNTIME );
   HIP_TRY( hipMemsetAsync( g_ws.ridx.p, 0, nk * 4, g_stream ), RS_HIP_E_RUNTIME );
   RowsLaunch L{};
-  L.tgt = g; L.qpos = g_ws.q4.as<float4>(); L.nq = nq; L.K = k; L.radius = radius; L.radius_sq = radius_sq_of( radius );
+  L.tgt = g; L.q.pos = g_ws.q4.as<float4>(); L.q.nor = nullptr; L.q.tiles = g_ws.tmp_pos.as<uint32_t>(); L.q.n = nq; L.q.n_tiles = (int)tiles.size() - 1;
+  L.K = k; L.radius = radius; L.radius_sq = radius_sq_of( radius );
   L.d2 = g_ws.rd2.as<float>(); L.idx = g_ws.ridx.as<int>(); L.nn = g_ws.rnn.as<int>();
   { ProfScope ps( "nn_rows" ); launch_rows( L, g_stream ); }
   std::vector<int> nn( nq );

@@ -22,6 +22,18 @@ struct GridView
 
 struct Xform { float m[16]; };  // column-major, passed by value (lands in SGPRs)
 
+// Device view of a cloud used as a QUERY set: the same points in Hilbert-curve order, cut
+// into tiles of at most 64 consecutive points with a bounded spatial extent.  One wave
+// handles one tile, so the 64 lanes of a wave are always spatial neighbours and share one
+// small candidate box.  pos[s].w = bitcast(original index).
+struct QueryView
+{
+  const float4*   pos;
+  const float4*   nor;     // may be null
+  const uint32_t* tiles;   // n_tiles + 1 offsets into pos/nor
+  int n, n_tiles;
+};
+
 // One placement of the label kernel.
 struct PlacementDev
 {
@@ -38,8 +50,7 @@ enum { ICP_NMOM = 35 };   // raw moments reduced per ICP iteration (see k_icp_mo
 struct IcpLaunch
 {
   GridView     tgt;
-  const float4 *qpos, *qnor;   // source cloud, sorted order
-  int          nq;
+  QueryView    src;            // source cloud (query order)
   int          n_prob;         // batch size
   const float* T1;             // device, n_prob x 16
   const int*   active;         // device, n_prob flags (0 = skip)
@@ -50,7 +61,7 @@ struct IcpLaunch
   int*    m_slot;   // n_prob x nq : matched target slot or -1
   float*  m_d2;     // n_prob x nq
   float*  m_dot;    // n_prob x nq
-  double* corr_part;  // n_prob x n_waves x 3
+  double* corr_part;  // n_prob x n_tiles x 3
   double* stats;      // n_prob x 4 : n_corr, mean, stddev, (unused)
   double* mom_part;   // n_prob x n_mom_blocks x ICP_NMOM
   double* moments;    // n_prob x ICP_NMOM
@@ -64,8 +75,8 @@ void launch_icp_moments( const IcpLaunch& L, hipStream_t st );
 struct ScoreLaunch
 {
   GridView     scene;
-  const float4 *qpos, *qnor;
-  int          nq, n_poses;
+  QueryView    obj;
+  int          n_poses;
   const float* poses;      // device n_poses x 16
   float        radius_sq, gate_tmin;
   int          K;
@@ -77,8 +88,7 @@ void launch_score( const ScoreLaunch& L, hipStream_t st );
 
 struct LabelLaunch
 {
-  const float4 *spos, *snor;   // scene cloud, sorted order
-  int          ns;
+  QueryView    scene;          // scene cloud (query order)
   const PlacementDev* pl;      // device array
   int          n_pl, label_base;
   float        gate_tmin;
@@ -91,8 +101,8 @@ void launch_label( const LabelLaunch& L, hipStream_t st );
 struct RowsLaunch
 {
   GridView     tgt;
-  const float4* qpos;      // sorted queries, w = original query index
-  int          nq, K;
+  QueryView    q;          // queries (w = original query index)
+  int          K;
   float        radius, radius_sq;
   float*       d2;         // nq x K (original query order)
   int*         idx;        // nq x K

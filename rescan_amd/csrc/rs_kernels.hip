@@ -106,7 +106,10 @@ __device__ __forceinline__ CellBox wave_cell_box( const GridView& g, bool active
 // Stream every candidate of the cell box through this wave's LDS slice and call
 // f( P, j, slot ) for each: P = {x,y,z,bitcast(index)}, j = position inside the chunk (so
 // the matching normal is sn[j]), slot = position in the sorted cloud.  j and slot are
-// wave-uniform.
+// wave-uniform.  A chunk is always processed as 64 slots rounded up to a multiple of 4:
+// lanes beyond the span store a sentinel at +FLT_MAX whose dist² is +inf, so it can never be
+// "within the radius" and the inner loop needs no remainder handling (f may be called with
+// such sentinels; slot is then >= the span end and must only be used when P qualified).
 template <bool WITH_NOR, class F>
 __device__ __forceinline__ void sweep_box( const GridView& g, const CellBox& b, float4* sp, float4* sn, int lane, F&& f )
 {
@@ -120,13 +123,24 @@ __device__ __forceinline__ void sweep_box( const GridView& g, const CellBox& b, 
       for( uint32_t c0 = s; c0 < e; c0 += WAVE )
       {
         const uint32_t cnt = ( e - c0 < WAVE ) ? ( e - c0 ) : WAVE;
+        float4 P = make_float4( FLT_MAX, FLT_MAX, FLT_MAX, 0.0f ), N = make_float4( 0.0f, 0.0f, 0.0f, 0.0f );
         if( (uint32_t)lane < cnt )
         {
-          sp[lane] = g.pos[c0 + lane];
-          if( WITH_NOR ) sn[lane] = g.nor[c0 + lane];
+          P = g.pos[c0 + lane];
+          if( WITH_NOR ) N = g.nor[c0 + lane];
         }
+        sp[lane] = P;
+        if( WITH_NOR ) sn[lane] = N;
         wave_lds_fence();
-        for( uint32_t j = 0; j < cnt; ++j ) { f( sp[j], (int)j, (int)( c0 + j ) ); }
+        const uint32_t cnt4 = ( cnt + 3u ) & ~3u;
+        for( uint32_t j = 0; j < cnt4; j += 4 )
+        {
+          const float4 P0 = sp[j], P1 = sp[j + 1], P2 = sp[j + 2], P3 = sp[j + 3];
+          f( P0, (int)j, (int)( c0 + j ) );
+          f( P1, (int)j + 1, (int)( c0 + j + 1 ) );
+          f( P2, (int)j + 2, (int)( c0 + j + 2 ) );
+          f( P3, (int)j + 3, (int)( c0 + j + 3 ) );
+        }
         wave_lds_fence();
       }
     }
@@ -155,26 +169,29 @@ __device__ __forceinline__ Match gated_search( const GridView& g, bool active,
   CellBox box = wave_cell_box( g, active, qx, qy, qz, radius );
   if( box.empty ) return m;
 
-  int seen_closer = 0;   // candidates that were closer than the best-so-far when they were met
+  int seen_closer = 0;   // candidates that were no farther than the best-so-far when they were met
   sweep_box<true>( g, box, sp, sn, lane, [&]( float4 P, int j, int slot )
   {
     float vx = P.x - qx, vy = P.y - qy, vz = P.z - qz;
     float d2 = vx * vx + vy * vy + vz * vz;
-    int idx = __float_as_int( P.w );
-    bool closer = active && ( d2 < radius_sq ) && lex_less( d2, idx, m.d2, m.idx );
-    seen_closer += closer ? 1 : 0;
-    if( __any( closer ) )
+    // cheap superset of "precedes the best so far": ties are settled inside the rare branch
+    const bool maybe = active & ( d2 < radius_sq ) & ( d2 <= m.d2 );
+    seen_closer += maybe ? 1 : 0;
+    if( __any( maybe ) )
     {
+      const int idx = __float_as_int( P.w );
       float4 N = sn[j];
       float dot = N.x * nx + N.y * ny + N.z * nz;         // msh_vec3_dot( m, n )
       float dc = dot > 0.0f ? dot : 0.0f;                 // msh_max( dot, 0.0f )
-      if( closer && dc >= tmin && dc <= 1.0f ) { m.d2 = d2; m.idx = idx; m.dot = dc; m.slot = slot; m.found = true; }
+      if( maybe && lex_less( d2, idx, m.d2, m.idx ) && dc >= tmin && dc <= 1.0f )
+      { m.d2 = d2; m.idx = idx; m.dot = dc; m.slot = slot; m.found = true; }
     }
   } );
 
-  // Every candidate that precedes the final match was counted in seen_closer (it preceded
-  // the then-best, which the final match precedes or equals), and so was the match itself:
-  // seen_closer - 1 >= rank.  Only when that bound does not settle rank < K, count exactly.
+  // Every candidate that precedes the final match was counted in seen_closer (it was no
+  // farther than the then-best, which the final match precedes or equals), and so was the
+  // match itself: seen_closer - 1 >= rank.  Only when that bound does not settle rank < K,
+  // count exactly.
   bool need_rank = m.found && ( seen_closer - 1 >= K );
   if( __any( need_rank ) )
   {
@@ -184,7 +201,7 @@ __device__ __forceinline__ Match gated_search( const GridView& g, bool active,
       float vx = P.x - qx, vy = P.y - qy, vz = P.z - qz;
       float d2 = vx * vx + vy * vy + vz * vz;
       int idx = __float_as_int( P.w );
-      rank += ( need_rank && d2 < radius_sq && lex_less( d2, idx, m.d2, m.idx ) ) ? 1 : 0;
+      rank += ( need_rank & ( d2 < radius_sq ) & ( ( d2 < m.d2 ) | ( ( d2 == m.d2 ) & ( idx < m.idx ) ) ) ) ? 1 : 0;
     } );
     if( need_rank && rank >= K ) { m.found = false; m.slot = -1; }
   }
@@ -204,10 +221,11 @@ __global__ __launch_bounds__( BLOCK ) void k_icp_corr( IcpLaunch L )
   const int lane = threadIdx.x & ( WAVE - 1 );
   const int wib = threadIdx.x / WAVE;
   const int wave = blockIdx.x * WAVES_PER_BLOCK + wib;
-  const int n_waves = ( L.nq + WAVE - 1 ) / WAVE;
+  const int n_waves = L.src.n_tiles;
   if( wave >= n_waves ) return;
-  const int i = wave * WAVE + lane;
-  const bool active = i < L.nq;
+  const int i = (int)L.src.tiles[wave] + lane;
+  const bool active = i < (int)L.src.tiles[wave + 1];
+  const int nq = L.src.n;
 
   Xform T1;
 #pragma unroll
@@ -216,14 +234,14 @@ __global__ __launch_bounds__( BLOCK ) void k_icp_corr( IcpLaunch L )
   float qx = 0, qy = 0, qz = 0, nx = 0, ny = 0, nz = 0;
   if( active )
   {
-    float4 p = L.qpos[i], n = L.qnor[i];
+    float4 p = L.src.pos[i], n = L.src.nor[i];
     float tx, ty, tz;
     xform3( T1, p.x, p.y, p.z, 1.0f, tx, ty, tz );   xform3( L.T2i, tx, ty, tz, 1.0f, qx, qy, qz );
     xform3( T1, n.x, n.y, n.z, 0.0f, tx, ty, tz );   xform3( L.T2i, tx, ty, tz, 0.0f, nx, ny, nz );
   }
   Match m = gated_search( L.tgt, active, qx, qy, qz, nx, ny, nz, L.radius, L.radius_sq, L.gate_tmin, L.K,
                           s_pos[wib], s_nor[wib], lane );
-  const size_t o = (size_t)prob * L.nq + i;
+  const size_t o = (size_t)prob * nq + i;
   if( active ) { L.m_slot[o] = m.found ? m.slot : -1; L.m_d2[o] = m.d2; L.m_dot[o] = m.dot; }
 
   // statistics of dist² over correspondences (msh_compute_mean/stddev, msh_std.h:1800-1825)
@@ -244,7 +262,7 @@ __global__ __launch_bounds__( BLOCK ) void k_icp_stats( IcpLaunch L )
   __shared__ double red[3][BLOCK];
   const int prob = blockIdx.x;
   if( L.active[prob] == 0 ) return;
-  const int n_waves = ( L.nq + WAVE - 1 ) / WAVE;
+  const int n_waves = L.src.n_tiles;
   const double* in = L.corr_part + (size_t)prob * n_waves * 3;
   double a = 0, b = 0, c = 0;
   for( int w = threadIdx.x; w < n_waves; w += BLOCK ) { a += in[3*w]; b += in[3*w+1]; c += in[3*w+2]; }
@@ -295,9 +313,9 @@ __global__ __launch_bounds__( BLOCK ) void k_icp_moments( IcpLaunch L )
 #pragma unroll
   for( int k = 0; k < ICP_NMOM; ++k ) acc[k] = 0.0;
 
-  for( int i = blockIdx.x * BLOCK + threadIdx.x; i < L.nq; i += gridDim.x * BLOCK )
+  for( int i = blockIdx.x * BLOCK + threadIdx.x; i < L.src.n; i += gridDim.x * BLOCK )
   {
-    const size_t o = (size_t)prob * L.nq + i;
+    const size_t o = (size_t)prob * L.src.n + i;
     const int slot = L.m_slot[o];
     if( slot < 0 ) continue;
     const float d2 = L.m_d2[o];
@@ -308,7 +326,7 @@ __global__ __launch_bounds__( BLOCK ) void k_icp_moments( IcpLaunch L )
       w = ( 1.0f - __fdiv_rn( d2, L.radius ) ) * L.m_dot[o];         // icp.h:387
       if( use_sd && d2 > cut ) w = 0.0f;                              // icp.h:396-401
     }
-    float4 p4 = L.qpos[i];
+    float4 p4 = L.src.pos[i];
     float tx, ty, tz, px, py, pz;
     xform3( T1, p4.x, p4.y, p4.z, 1.0f, tx, ty, tz );
     xform3( L.T2i, tx, ty, tz, 1.0f, px, py, pz );
@@ -358,7 +376,7 @@ __global__ __launch_bounds__( WAVE ) void k_icp_moments_final( IcpLaunch L )
 
 void launch_icp_corr( const IcpLaunch& L, hipStream_t st )
 {
-  const int n_waves = ( L.nq + WAVE - 1 ) / WAVE;
+  const int n_waves = L.src.n_tiles;
   dim3 grid( ( n_waves + WAVES_PER_BLOCK - 1 ) / WAVES_PER_BLOCK, L.n_prob );
   hipLaunchKernelGGL( k_icp_corr, grid, dim3( BLOCK ), 0, st, L );
 }
@@ -384,10 +402,10 @@ __global__ __launch_bounds__( BLOCK ) void k_score( ScoreLaunch L )
   const int lane = threadIdx.x & ( WAVE - 1 );
   const int wib = threadIdx.x / WAVE;
   const int tile = blockIdx.x * WAVES_PER_BLOCK + wib;
-  const int n_tiles = ( L.nq + WAVE - 1 ) / WAVE;
+  const int n_tiles = L.obj.n_tiles;
   if( tile >= n_tiles ) return;
-  const int i = tile * WAVE + lane;
-  const bool active = i < L.nq;
+  const int i = (int)L.obj.tiles[tile] + lane;
+  const bool active = i < (int)L.obj.tiles[tile + 1];
 
   Xform X;
 #pragma unroll
@@ -395,7 +413,7 @@ __global__ __launch_bounds__( BLOCK ) void k_score( ScoreLaunch L )
   float qx = 0, qy = 0, qz = 0, nx = 0, ny = 0, nz = 0;
   if( active )
   {
-    float4 p = L.qpos[i], n = L.qnor[i];
+    float4 p = L.obj.pos[i], n = L.obj.nor[i];
     xform3( X, p.x, p.y, p.z, 1.0f, qx, qy, qz );      // :110
     xform3( X, n.x, n.y, n.z, 0.0f, nx, ny, nz );      // :111
   }
@@ -419,19 +437,19 @@ __global__ __launch_bounds__( BLOCK ) void k_score_final( ScoreLaunch L )
 {
   __shared__ double red[BLOCK];
   const int pose = blockIdx.x;
-  const int n_tiles = ( L.nq + WAVE - 1 ) / WAVE;
+  const int n_tiles = L.obj.n_tiles;
   const double* in = L.part + (size_t)pose * n_tiles;
   double a = 0.0;
   for( int t = threadIdx.x; t < n_tiles; t += BLOCK ) a += in[t];
   red[threadIdx.x] = a;
   __syncthreads();
   for( int s = BLOCK / 2; s > 0; s >>= 1 ) { if( threadIdx.x < s ) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
-  if( threadIdx.x == 0 ) L.scores[pose] = (float)( red[0] / (double)L.nq );
+  if( threadIdx.x == 0 ) L.scores[pose] = (float)( red[0] / (double)L.obj.n );
 }
 
 void launch_score( const ScoreLaunch& L, hipStream_t st )
 {
-  const int n_tiles = ( L.nq + WAVE - 1 ) / WAVE;
+  const int n_tiles = L.obj.n_tiles;
   dim3 grid( ( n_tiles + WAVES_PER_BLOCK - 1 ) / WAVES_PER_BLOCK, L.n_poses );
   hipLaunchKernelGGL( k_score, grid, dim3( BLOCK ), 0, st, L );
   hipLaunchKernelGGL( k_score_final, dim3( L.n_poses ), dim3( BLOCK ), 0, st, L );
@@ -457,12 +475,12 @@ __global__ __launch_bounds__( BLOCK ) void k_label( LabelLaunch L )
   const int lane = threadIdx.x & ( WAVE - 1 );
   const int wib = threadIdx.x / WAVE;
   const int wave = blockIdx.x * WAVES_PER_BLOCK + wib;
-  const int n_waves = ( L.ns + WAVE - 1 ) / WAVE;
+  const int n_waves = L.scene.n_tiles;
   if( wave >= n_waves ) return;
-  const int i = wave * WAVE + lane;
-  const bool active = i < L.ns;
+  const int i = (int)L.scene.tiles[wave] + lane;
+  const bool active = i < (int)L.scene.tiles[wave + 1];
   float4 p = make_float4( 0, 0, 0, 0 ), n = make_float4( 0, 0, 0, 0 );
-  if( active ) { p = L.spos[i]; n = L.snor[i]; }
+  if( active ) { p = L.scene.pos[i]; n = L.scene.nor[i]; }
   const int orig = __float_as_int( p.w );
 
   float best_min = 1e9f;
@@ -484,7 +502,7 @@ __global__ __launch_bounds__( BLOCK ) void k_label( LabelLaunch L )
         float vx = P.x - qx, vy = P.y - qy, vz = P.z - qz;
         float d2 = vx * vx + vy * vy + vz * vz;
         int idx = __float_as_int( P.w );
-        if( active && d2 < r2 && lex_less( d2, idx, bd2, bidx ) ) { bd2 = d2; bidx = idx; bslot = slot; }
+        if( active & ( d2 < r2 ) & ( ( d2 < bd2 ) | ( ( d2 == bd2 ) & ( idx < bidx ) ) ) ) { bd2 = d2; bidx = idx; bslot = slot; }
       } );
     }
     // :762-775 — found, strictly closer than the running minimum, and within 70° (either sign)
@@ -499,7 +517,7 @@ __global__ __launch_bounds__( BLOCK ) void k_label( LabelLaunch L )
       float dot = fabsf( n1x * n2x + n1y * n2y + n1z * n2z );                  // :769
       ok = ( dot >= L.gate_tmin ) && ( dot <= 1.0f );
     }
-    if( L.rows ) { if( active ) L.rows[(size_t)k * L.ns + orig] = ok ? bd2 : INFINITY; }
+    if( L.rows ) { if( active ) L.rows[(size_t)k * L.scene.n + orig] = ok ? bd2 : INFINITY; }
     else if( ok ) { best_min = bd2; label = L.label_base + k + 1; }
   }
   if( active && L.min_d ) { L.min_d[orig] = best_min; L.labels[orig] = (int8_t)label; }
@@ -507,7 +525,7 @@ __global__ __launch_bounds__( BLOCK ) void k_label( LabelLaunch L )
 
 void launch_label( const LabelLaunch& L, hipStream_t st )
 {
-  const int n_waves = ( L.ns + WAVE - 1 ) / WAVE;
+  const int n_waves = L.scene.n_tiles;
   dim3 grid( ( n_waves + WAVES_PER_BLOCK - 1 ) / WAVES_PER_BLOCK );
   hipLaunchKernelGGL( k_label, grid, dim3( BLOCK ), 0, st, L );
 }
@@ -525,12 +543,12 @@ __global__ __launch_bounds__( BLOCK ) void k_rows( RowsLaunch L )
   const int lane = threadIdx.x & ( WAVE - 1 );
   const int wib = threadIdx.x / WAVE;
   const int wave = blockIdx.x * WAVES_PER_BLOCK + wib;
-  const int n_waves = ( L.nq + WAVE - 1 ) / WAVE;
+  const int n_waves = L.q.n_tiles;
   if( wave >= n_waves ) return;
-  const int i = wave * WAVE + lane;
-  const bool active = i < L.nq;
+  const int i = (int)L.q.tiles[wave] + lane;
+  const bool active = i < (int)L.q.tiles[wave + 1];
   float4 q = make_float4( 0, 0, 0, 0 );
-  if( active ) q = L.qpos[i];
+  if( active ) q = L.q.pos[i];
   const int orig = __float_as_int( q.w );
   CellBox box = wave_cell_box( L.tgt, active, q.x, q.y, q.z, L.radius );
 
@@ -546,7 +564,9 @@ __global__ __launch_bounds__( BLOCK ) void k_rows( RowsLaunch L )
       float vx = P.x - q.x, vy = P.y - q.y, vz = P.z - q.z;
       float d2 = vx * vx + vy * vy + vz * vz;
       int idx = __float_as_int( P.w );
-      if( more && d2 < L.radius_sq && lex_less( pd2, pidx, d2, idx ) && lex_less( d2, idx, bd2, bidx ) ) { bd2 = d2; bidx = idx; }
+      const bool after_prev = ( pd2 < d2 ) | ( ( pd2 == d2 ) & ( pidx < idx ) );
+      const bool before_best = ( d2 < bd2 ) | ( ( d2 == bd2 ) & ( idx < bidx ) );
+      if( more & ( d2 < L.radius_sq ) & after_prev & before_best ) { bd2 = d2; bidx = idx; }
     } );
     if( more )
     {
@@ -559,7 +579,7 @@ __global__ __launch_bounds__( BLOCK ) void k_rows( RowsLaunch L )
 
 void launch_rows( const RowsLaunch& L, hipStream_t st )
 {
-  const int n_waves = ( L.nq + WAVE - 1 ) / WAVE;
+  const int n_waves = L.q.n_tiles;
   dim3 grid( ( n_waves + WAVES_PER_BLOCK - 1 ) / WAVES_PER_BLOCK );
   hipLaunchKernelGGL( k_rows, grid, dim3( BLOCK ), 0, st, L );
 }
