@@ -5,8 +5,11 @@
 // adjacent query points sweeps the grid cells overlapping its bounding box (+radius).
 // Candidate points of those cells stream HBM/L2 -> LDS in 64-record chunks (one coalesced
 // 1 KiB global load per wave), and every lane tests the same candidate at the same time
-// through an LDS broadcast read (ds_read_b128, all lanes one address: conflict-free).  Waves
-// never synchronise with each other: no workgroup barriers anywhere on the path.
+// through an LDS broadcast read (ds_read_b128, all lanes one address: conflict-free).
+// The four waves of a workgroup share ONE tile of 64 queries and split its candidate chunks
+// round-robin, so the time of the heaviest tile (cluttered corners hold ~6x the average
+// candidate count) is cut by four; they meet once, at the end, to merge their per-lane
+// results through LDS.  Inside the sweep waves never synchronise with each other.
 //
 // Arithmetic that decides *which* neighbour wins is kept in the reference's own order and
 // precision (the file is compiled with -ffp-contract=off):
@@ -30,6 +33,7 @@ namespace rs {
 #define WAVE 64
 #define BLOCK 256
 #define WAVES_PER_BLOCK (BLOCK / WAVE)
+#define TW WAVES_PER_BLOCK   // waves cooperating on one tile
 
 // ------------------------------------------------------------------------------------------
 // helpers
@@ -110,9 +114,12 @@ __device__ __forceinline__ CellBox wave_cell_box( const GridView& g, bool active
 // lanes beyond the span store a sentinel at +FLT_MAX whose dist² is +inf, so it can never be
 // "within the radius" and the inner loop needs no remainder handling (f may be called with
 // such sentinels; slot is then >= the span end and must only be used when P qualified).
+// Of the chunks met in sweep order, a wave takes those with (chunk number % n_share) == share.
 template <bool WITH_NOR, class F>
-__device__ __forceinline__ void sweep_box( const GridView& g, const CellBox& b, float4* sp, float4* sn, int lane, F&& f )
+__device__ __forceinline__ void sweep_box( const GridView& g, const CellBox& b, float4* sp, float4* sn, int lane,
+                                           int share, int n_share, F&& f )
 {
+  int chunk = 0;
   for( int z = b.z0; z <= b.z1; ++z )
   {
     for( int y = b.y0; y <= b.y1; ++y )
@@ -122,6 +129,7 @@ __device__ __forceinline__ void sweep_box( const GridView& g, const CellBox& b, 
       const uint32_t e = (uint32_t)uni( (int)g.cell_start[row + b.x1 + 1] );
       for( uint32_t c0 = s; c0 < e; c0 += WAVE )
       {
+        if( ( chunk++ % n_share ) != share ) continue;
         const uint32_t cnt = ( e - c0 < WAVE ) ? ( e - c0 ) : WAVE;
         float4 P = make_float4( FLT_MAX, FLT_MAX, FLT_MAX, 0.0f ), N = make_float4( 0.0f, 0.0f, 0.0f, 0.0f );
         if( (uint32_t)lane < cnt )
@@ -156,21 +164,35 @@ __device__ __forceinline__ bool lex_less( float d2a, int ia, float d2b, int ib )
 // Result of a gated search for one query.
 struct Match { float d2; int idx; float dot; int slot; bool found; };
 
+// Per-workgroup LDS: candidate staging of each wave + the per-lane merge slots.
+struct TileLds
+{
+  float4 pos[TW][WAVE];
+  float4 nor[TW][WAVE];
+  float  m_d2[TW][WAVE];
+  int    m_idx[TW][WAVE];
+  float  m_dot[TW][WAVE];
+  int    m_slot[TW][WAVE];
+  int    m_cnt[TW][WAVE];
+};
+
 // Nearest candidate within the radius whose normal passes  tmin <= max(dot,0) <= 1, accepted
 // only if fewer than K candidates (of any normal) precede it in (dist², index) order.
 // That is the reference's "first normal-compatible entry of the K-nearest list"
 // (lib/rs/icp.h:361-380, apps/pose_proposal/pose_proposal.cpp:127-147).
+// All TW waves of the workgroup call this with the SAME queries; each sweeps its share of the
+// candidate chunks and all return the same merged result.
 __device__ __forceinline__ Match gated_search( const GridView& g, bool active,
                                                float qx, float qy, float qz, float nx, float ny, float nz,
                                                float radius, float radius_sq, float tmin, int K,
-                                               float4* sp, float4* sn, int lane )
+                                               TileLds& lds, int wib, int lane )
 {
   Match m; m.d2 = INFINITY; m.idx = INT_MAX; m.dot = 0.0f; m.slot = -1; m.found = false;
   CellBox box = wave_cell_box( g, active, qx, qy, qz, radius );
-  if( box.empty ) return m;
+  if( box.empty ) return m;                       // identical in every wave of the workgroup
 
-  int seen_closer = 0;   // candidates that were no farther than the best-so-far when they were met
-  sweep_box<true>( g, box, sp, sn, lane, [&]( float4 P, int j, int slot )
+  int seen_closer = 0;   // candidates that were no farther than this wave's best-so-far when met
+  sweep_box<true>( g, box, lds.pos[wib], lds.nor[wib], lane, wib, TW, [&]( float4 P, int j, int slot )
   {
     float vx = P.x - qx, vy = P.y - qy, vz = P.z - qz;
     float d2 = vx * vx + vy * vy + vz * vz;
@@ -180,7 +202,7 @@ __device__ __forceinline__ Match gated_search( const GridView& g, bool active,
     if( __any( maybe ) )
     {
       const int idx = __float_as_int( P.w );
-      float4 N = sn[j];
+      float4 N = lds.nor[wib][j];
       float dot = N.x * nx + N.y * ny + N.z * nz;         // msh_vec3_dot( m, n )
       float dc = dot > 0.0f ? dot : 0.0f;                 // msh_max( dot, 0.0f )
       if( maybe && lex_less( d2, idx, m.d2, m.idx ) && dc >= tmin && dc <= 1.0f )
@@ -188,23 +210,44 @@ __device__ __forceinline__ Match gated_search( const GridView& g, bool active,
     }
   } );
 
-  // Every candidate that precedes the final match was counted in seen_closer (it was no
-  // farther than the then-best, which the final match precedes or equals), and so was the
-  // match itself: seen_closer - 1 >= rank.  Only when that bound does not settle rank < K,
-  // count exactly.
-  bool need_rank = m.found && ( seen_closer - 1 >= K );
-  if( __any( need_rank ) )
+  // merge the TW partial results of each lane
+  lds.m_d2[wib][lane] = m.d2; lds.m_idx[wib][lane] = m.idx; lds.m_dot[wib][lane] = m.dot;
+  lds.m_slot[wib][lane] = m.found ? m.slot : -1; lds.m_cnt[wib][lane] = seen_closer;
+  __syncthreads();
+  int seen_total = 0;
+  m.d2 = INFINITY; m.idx = INT_MAX; m.dot = 0.0f; m.slot = -1; m.found = false;
+#pragma unroll
+  for( int w = 0; w < TW; ++w )
+  {
+    seen_total += lds.m_cnt[w][lane];
+    const float d = lds.m_d2[w][lane]; const int ix = lds.m_idx[w][lane]; const int sl = lds.m_slot[w][lane];
+    if( sl >= 0 && lex_less( d, ix, m.d2, m.idx ) ) { m.d2 = d; m.idx = ix; m.dot = lds.m_dot[w][lane]; m.slot = sl; m.found = true; }
+  }
+
+  // Every candidate that precedes the final match was counted by the wave that met it (it was
+  // no farther than that wave's then-best, which the final match precedes or equals), and so
+  // was the match itself: seen_total - 1 >= rank.  Only when that bound does not settle
+  // rank < K, count exactly.
+  bool need_rank = m.found && ( seen_total - 1 >= K );
+  if( __any( need_rank ) )                         // same decision in every wave (same data)
   {
     int rank = 0;
-    sweep_box<false>( g, box, sp, sn, lane, [&]( float4 P, int, int )
+    sweep_box<false>( g, box, lds.pos[wib], lds.nor[wib], lane, wib, TW, [&]( float4 P, int, int )
     {
       float vx = P.x - qx, vy = P.y - qy, vz = P.z - qz;
       float d2 = vx * vx + vy * vy + vz * vz;
       int idx = __float_as_int( P.w );
       rank += ( need_rank & ( d2 < radius_sq ) & ( ( d2 < m.d2 ) | ( ( d2 == m.d2 ) & ( idx < m.idx ) ) ) ) ? 1 : 0;
     } );
+    __syncthreads();                               // everyone is done reading the first merge
+    lds.m_cnt[wib][lane] = rank;
+    __syncthreads();
+    rank = 0;
+#pragma unroll
+    for( int w = 0; w < TW; ++w ) rank += lds.m_cnt[w][lane];
     if( need_rank && rank >= K ) { m.found = false; m.slot = -1; }
   }
+  __syncthreads();                                 // merge slots may be reused by the caller's next search
   return m;
 }
 
@@ -214,17 +257,14 @@ __device__ __forceinline__ Match gated_search( const GridView& g, bool active,
 
 __global__ __launch_bounds__( BLOCK ) void k_icp_corr( IcpLaunch L )
 {
-  __shared__ float4 s_pos[WAVES_PER_BLOCK][WAVE];
-  __shared__ float4 s_nor[WAVES_PER_BLOCK][WAVE];
+  __shared__ TileLds lds;
   const int prob = blockIdx.y;
   if( L.active[prob] == 0 ) return;
   const int lane = threadIdx.x & ( WAVE - 1 );
   const int wib = threadIdx.x / WAVE;
-  const int wave = blockIdx.x * WAVES_PER_BLOCK + wib;
-  const int n_waves = L.src.n_tiles;
-  if( wave >= n_waves ) return;
-  const int i = (int)L.src.tiles[wave] + lane;
-  const bool active = i < (int)L.src.tiles[wave + 1];
+  const int tile = blockIdx.x;                           // one workgroup per tile
+  const int i = (int)L.src.tiles[tile] + lane;
+  const bool active = i < (int)L.src.tiles[tile + 1];
   const int nq = L.src.n;
 
   Xform T1;
@@ -240,7 +280,8 @@ __global__ __launch_bounds__( BLOCK ) void k_icp_corr( IcpLaunch L )
     xform3( T1, n.x, n.y, n.z, 0.0f, tx, ty, tz );   xform3( L.T2i, tx, ty, tz, 0.0f, nx, ny, nz );
   }
   Match m = gated_search( L.tgt, active, qx, qy, qz, nx, ny, nz, L.radius, L.radius_sq, L.gate_tmin, L.K,
-                          s_pos[wib], s_nor[wib], lane );
+                          lds, wib, lane );
+  if( wib != 0 ) return;                                 // every wave holds the merged result; wave 0 writes it
   const size_t o = (size_t)prob * nq + i;
   if( active ) { L.m_slot[o] = m.found ? m.slot : -1; L.m_d2[o] = m.d2; L.m_dot[o] = m.dot; }
 
@@ -251,7 +292,7 @@ __global__ __launch_bounds__( BLOCK ) void k_icp_corr( IcpLaunch L )
   c = wave_sum( c ); s1 = wave_sum( s1 ); s2 = wave_sum( s2 );
   if( lane == 0 )
   {
-    double* out = L.corr_part + ( (size_t)prob * n_waves + wave ) * 3;
+    double* out = L.corr_part + ( (size_t)prob * L.src.n_tiles + tile ) * 3;
     out[0] = c; out[1] = s1; out[2] = s2;
   }
 }
@@ -361,23 +402,24 @@ __global__ __launch_bounds__( BLOCK ) void k_icp_moments( IcpLaunch L )
   }
 }
 
-__global__ __launch_bounds__( WAVE ) void k_icp_moments_final( IcpLaunch L )
+// fixed-order tree over the per-block partials: one workgroup per (moment, problem)
+__global__ __launch_bounds__( BLOCK ) void k_icp_moments_final( IcpLaunch L )
 {
-  const int prob = blockIdx.x;
+  __shared__ double red[BLOCK];
+  const int prob = blockIdx.y, k = blockIdx.x;
   if( L.active[prob] == 0 ) return;
-  if( threadIdx.x < ICP_NMOM )
-  {
-    const double* in = L.mom_part + (size_t)prob * L.n_mom_blocks * ICP_NMOM;
-    double v = 0.0;
-    for( int b = 0; b < L.n_mom_blocks; ++b ) v += in[(size_t)b * ICP_NMOM + threadIdx.x];
-    L.moments[(size_t)prob * ICP_NMOM + threadIdx.x] = v;
-  }
+  const double* in = L.mom_part + (size_t)prob * L.n_mom_blocks * ICP_NMOM;
+  double v = 0.0;
+  for( int b = threadIdx.x; b < L.n_mom_blocks; b += BLOCK ) v += in[(size_t)b * ICP_NMOM + k];
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for( int s = BLOCK / 2; s > 0; s >>= 1 ) { if( threadIdx.x < s ) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+  if( threadIdx.x == 0 ) L.moments[(size_t)prob * ICP_NMOM + k] = red[0];
 }
 
 void launch_icp_corr( const IcpLaunch& L, hipStream_t st )
 {
-  const int n_waves = L.src.n_tiles;
-  dim3 grid( ( n_waves + WAVES_PER_BLOCK - 1 ) / WAVES_PER_BLOCK, L.n_prob );
+  dim3 grid( L.src.n_tiles, L.n_prob );
   hipLaunchKernelGGL( k_icp_corr, grid, dim3( BLOCK ), 0, st, L );
 }
 void launch_icp_stats( const IcpLaunch& L, hipStream_t st )
@@ -387,7 +429,7 @@ void launch_icp_stats( const IcpLaunch& L, hipStream_t st )
 void launch_icp_moments( const IcpLaunch& L, hipStream_t st )
 {
   hipLaunchKernelGGL( k_icp_moments, dim3( L.n_mom_blocks, L.n_prob ), dim3( BLOCK ), 0, st, L );
-  hipLaunchKernelGGL( k_icp_moments_final, dim3( L.n_prob ), dim3( WAVE ), 0, st, L );
+  hipLaunchKernelGGL( k_icp_moments_final, dim3( ICP_NMOM, L.n_prob ), dim3( BLOCK ), 0, st, L );
 }
 
 // ------------------------------------------------------------------------------------------
@@ -396,14 +438,12 @@ void launch_icp_moments( const IcpLaunch& L, hipStream_t st )
 
 __global__ __launch_bounds__( BLOCK ) void k_score( ScoreLaunch L )
 {
-  __shared__ float4 s_pos[WAVES_PER_BLOCK][WAVE];
-  __shared__ float4 s_nor[WAVES_PER_BLOCK][WAVE];
+  __shared__ TileLds lds;
   const int pose = blockIdx.y;
   const int lane = threadIdx.x & ( WAVE - 1 );
   const int wib = threadIdx.x / WAVE;
-  const int tile = blockIdx.x * WAVES_PER_BLOCK + wib;
+  const int tile = blockIdx.x;
   const int n_tiles = L.obj.n_tiles;
-  if( tile >= n_tiles ) return;
   const int i = (int)L.obj.tiles[tile] + lane;
   const bool active = i < (int)L.obj.tiles[tile + 1];
 
@@ -419,7 +459,8 @@ __global__ __launch_bounds__( BLOCK ) void k_score( ScoreLaunch L )
   }
   const float radius = (float)L.sigma;
   Match m = gated_search( L.scene, active, qx, qy, qz, nx, ny, nz, radius, L.radius_sq, L.gate_tmin, L.K,
-                          s_pos[wib], s_nor[wib], lane );
+                          lds, wib, lane );
+  if( wib != 0 ) return;
   double s = 0.0;
   if( active && m.found )
   {
@@ -449,8 +490,7 @@ __global__ __launch_bounds__( BLOCK ) void k_score_final( ScoreLaunch L )
 
 void launch_score( const ScoreLaunch& L, hipStream_t st )
 {
-  const int n_tiles = L.obj.n_tiles;
-  dim3 grid( ( n_tiles + WAVES_PER_BLOCK - 1 ) / WAVES_PER_BLOCK, L.n_poses );
+  dim3 grid( L.obj.n_tiles, L.n_poses );
   hipLaunchKernelGGL( k_score, grid, dim3( BLOCK ), 0, st, L );
   hipLaunchKernelGGL( k_score_final, dim3( L.n_poses ), dim3( BLOCK ), 0, st, L );
 }
@@ -471,14 +511,12 @@ __device__ __forceinline__ void unit3( float& x, float& y, float& z )
 
 __global__ __launch_bounds__( BLOCK ) void k_label( LabelLaunch L )
 {
-  __shared__ float4 s_pos[WAVES_PER_BLOCK][WAVE];
+  __shared__ TileLds lds;
   const int lane = threadIdx.x & ( WAVE - 1 );
   const int wib = threadIdx.x / WAVE;
-  const int wave = blockIdx.x * WAVES_PER_BLOCK + wib;
-  const int n_waves = L.scene.n_tiles;
-  if( wave >= n_waves ) return;
-  const int i = (int)L.scene.tiles[wave] + lane;
-  const bool active = i < (int)L.scene.tiles[wave + 1];
+  const int tile = blockIdx.x;
+  const int i = (int)L.scene.tiles[tile] + lane;
+  const bool active = i < (int)L.scene.tiles[tile + 1];
   float4 p = make_float4( 0, 0, 0, 0 ), n = make_float4( 0, 0, 0, 0 );
   if( active ) { p = L.scene.pos[i]; n = L.scene.nor[i]; }
   const int orig = __float_as_int( p.w );
@@ -492,18 +530,28 @@ __global__ __launch_bounds__( BLOCK ) void k_label( LabelLaunch L )
     const PlacementDev& pl = L.pl[k];
     float qx, qy, qz;
     xform3( pl.inv, p.x, p.y, p.z, 1.0f, qx, qy, qz );                         // :755
-    CellBox box = wave_cell_box( pl.g, active, qx, qy, qz, pl.radius );
+    CellBox box = wave_cell_box( pl.g, active, qx, qy, qz, pl.radius );        // same in all TW waves
     float bd2 = INFINITY; int bidx = INT_MAX, bslot = -1;
     if( !box.empty )
     {
       const float r2 = pl.radius_sq;
-      sweep_box<false>( pl.g, box, s_pos[wib], nullptr, lane, [&]( float4 P, int, int slot )
+      sweep_box<false>( pl.g, box, lds.pos[wib], nullptr, lane, wib, TW, [&]( float4 P, int, int slot )
       {
         float vx = P.x - qx, vy = P.y - qy, vz = P.z - qz;
         float d2 = vx * vx + vy * vy + vz * vz;
         int idx = __float_as_int( P.w );
         if( active & ( d2 < r2 ) & ( ( d2 < bd2 ) | ( ( d2 == bd2 ) & ( idx < bidx ) ) ) ) { bd2 = d2; bidx = idx; bslot = slot; }
       } );
+      lds.m_d2[wib][lane] = bd2; lds.m_idx[wib][lane] = bidx; lds.m_slot[wib][lane] = bslot;
+      __syncthreads();
+      bd2 = INFINITY; bidx = INT_MAX; bslot = -1;
+#pragma unroll
+      for( int w = 0; w < TW; ++w )
+      {
+        const float d = lds.m_d2[w][lane]; const int ix = lds.m_idx[w][lane]; const int sl = lds.m_slot[w][lane];
+        if( sl >= 0 && lex_less( d, ix, bd2, bidx ) ) { bd2 = d; bidx = ix; bslot = sl; }
+      }
+      __syncthreads();
     }
     // :762-775 — found, strictly closer than the running minimum, and within 70° (either sign)
     bool ok = false;
@@ -517,17 +565,15 @@ __global__ __launch_bounds__( BLOCK ) void k_label( LabelLaunch L )
       float dot = fabsf( n1x * n2x + n1y * n2y + n1z * n2z );                  // :769
       ok = ( dot >= L.gate_tmin ) && ( dot <= 1.0f );
     }
-    if( L.rows ) { if( active ) L.rows[(size_t)k * L.scene.n + orig] = ok ? bd2 : INFINITY; }
+    if( L.rows ) { if( active && wib == 0 ) L.rows[(size_t)k * L.scene.n + orig] = ok ? bd2 : INFINITY; }
     else if( ok ) { best_min = bd2; label = L.label_base + k + 1; }
   }
-  if( active && L.min_d ) { L.min_d[orig] = best_min; L.labels[orig] = (int8_t)label; }
+  if( active && wib == 0 && L.min_d ) { L.min_d[orig] = best_min; L.labels[orig] = (int8_t)label; }
 }
 
 void launch_label( const LabelLaunch& L, hipStream_t st )
 {
-  const int n_waves = L.scene.n_tiles;
-  dim3 grid( ( n_waves + WAVES_PER_BLOCK - 1 ) / WAVES_PER_BLOCK );
-  hipLaunchKernelGGL( k_label, grid, dim3( BLOCK ), 0, st, L );
+  hipLaunchKernelGGL( k_label, dim3( L.scene.n_tiles ), dim3( BLOCK ), 0, st, L );
 }
 
 // ------------------------------------------------------------------------------------------
@@ -559,7 +605,7 @@ __global__ __launch_bounds__( BLOCK ) void k_rows( RowsLaunch L )
   {
     if( !__any( more ) ) break;
     float bd2 = INFINITY; int bidx = INT_MAX;
-    sweep_box<false>( L.tgt, box, s_pos[wib], nullptr, lane, [&]( float4 P, int, int )
+    sweep_box<false>( L.tgt, box, s_pos[wib], nullptr, lane, 0, 1, [&]( float4 P, int, int )
     {
       float vx = P.x - q.x, vy = P.y - q.y, vz = P.z - q.z;
       float d2 = vx * vx + vy * vy + vz * vz;
