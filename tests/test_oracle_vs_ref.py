@@ -1,0 +1,119 @@
+"""CPU: the C restatement against the real reference (oracle/_ref, compiled in place from
+/root/reference) on fresh seeded inputs.  Runs wherever oracle/_ref/libref.so exists (the build
+container; the .so also travels to the GPU box)."""
+import numpy as np
+import pytest
+
+from oracle.pyoracle import Ref
+
+pytestmark = pytest.mark.skipif(not Ref.available(), reason="oracle/_ref not built (needs /root/reference)")
+I4 = np.eye(4, dtype=np.float32).ravel()
+
+
+@pytest.fixture(scope="module")
+def ref():
+    return Ref()
+
+
+@pytest.fixture(scope="module")
+def scene():
+    from rescan_amd import synth
+    return synth.make_scene(seed=13, density=1800.0, timestep=0, objects=("chair", "shelf", "table"))
+
+
+@pytest.mark.parametrize("grid_radius,k,r", [(0.05, 64, 0.1), (0.05, 1, 0.05), (0.1, 16, 0.1), (0.1, 16, 0.0663),
+                                              (0.05, 8, 0.05), (0.05, 1, 0.075), (0.02, 32, 0.1), (0.3, 4, 0.05)])
+def test_radius_search(oracle, ref, scene, grid_radius, k, r):
+    rng = np.random.default_rng(int(grid_radius * 1000) + k)
+    pts = scene["points"]
+    go, gr = oracle.grid_create(pts, grid_radius), ref.grid_create(pts, grid_radius)
+    io, ir = oracle.grid_info(go), ref.grid_info(gr)
+    assert (io[0] == ir[0]).all() and io[1] == ir[1] and (io[2] == ir[2]).all() and io[3] == ir[3]
+    q = pts[rng.integers(0, len(pts), 2000)] + rng.normal(0, 0.02, (2000, 3)).astype(np.float32)
+    q[:50] += 5.0
+    q[50:100] -= np.float32(0.4)
+    for sort in (1, 0):
+        a = oracle.radius_search(go, q, r, k, sort)
+        b = ref.radius_search(gr, q, r, k, sort)
+        assert (a[2] == b[2]).all() and a[3] == b[3]
+        m = np.arange(k)[None, :] < a[2][:, None]
+        assert (a[0][m] == b[0][m]).all() and (a[1][m] == b[1][m]).all()
+    oracle.grid_destroy(go); ref.grid_destroy(gr)
+
+
+def test_bin_cap_quirk(oracle, ref):
+    """radius >> cell: both stop collecting bins at 512 (msh_hash_grid.h:1101,1213)."""
+    rng = np.random.default_rng(0)
+    pts = rng.uniform(0, 1, (400, 3)).astype(np.float32)
+    q = rng.uniform(0, 1, (40, 3)).astype(np.float32)
+    go, gr = oracle.grid_create(pts, 0.02), ref.grid_create(pts, 0.02)
+    a, b = oracle.radius_search(go, q, 0.6, 32, 1), ref.radius_search(gr, q, 0.6, 32, 1)
+    assert (a[2] == b[2]).all() and (a[0] == b[0]).all() and (a[1] == b[1]).all()
+    oracle.grid_destroy(go); ref.grid_destroy(gr)
+
+
+def test_math(oracle, ref):
+    rng = np.random.default_rng(1)
+    for _ in range(200):
+        m = rng.normal(size=16).astype(np.float32); b = rng.normal(size=16).astype(np.float32)
+        t = rng.normal(size=3).astype(np.float32); v = rng.normal(size=(7, 3)).astype(np.float32)
+        assert (oracle.mat4_inverse(m) == ref.mat4_inverse(m)).all()
+        assert (oracle.mat4_mul(m, b) == ref.mat4_mul(m, b)).all()
+        assert (oracle.translate(m, t) == ref.translate(m, t)).all()
+        a = float(rng.normal())
+        for ax in np.eye(3, dtype=np.float32):
+            assert (oracle.rotate(m, a, ax) == ref.rotate(m, a, ax)).all()
+        ax = rng.normal(size=3).astype(np.float32)
+        assert (oracle.rotate(m, a, ax) == ref.rotate(m, a, ax)).all()
+        assert (oracle.xform_points(m, v, 1) == ref.xform_points(m, v, 1)).all()
+        assert (oracle.xform_points(m, v, 0) == ref.xform_points(m, v, 0)).all()
+        assert (oracle.normalize(v) == ref.normalize(v)).all()
+    x = rng.uniform(0, 0.01, 5000).astype(np.float32)
+    assert oracle.mean(x) == ref.mean(x) and oracle.stddev(oracle.mean(x), x) == ref.stddev(ref.mean(x), x)
+
+
+def test_icp_and_scores(oracle, ref, scene):
+    from rescan_amd import synth
+    rng = np.random.default_rng(2)
+    pts, nor = scene["points"], scene["normals"]
+    for o in scene["objects"]:
+        T0 = synth.perturbed_pose(o["pose"], rng)
+        for md, deg in ((0.10, 60.0), (0.075, 50.0), (0.05, 10.0)):
+            ma = np.float32(np.deg2rad(np.float32(deg)))
+            a = oracle.icp_find_corrs(o["pos"], o["nor"], pts, nor, T0, I4, md, ma)
+            b = ref.icp_find_corrs(o["pos"], o["nor"], pts, nor, T0, I4, md, ma)
+            assert all(x.shape == y.shape and (x == y).all() for x, y in zip(a, b))
+            e1, T1 = oracle.icp_estimate_pt2pl(a[0], a[2], a[3], a[4], T0)
+            e2, T2 = ref.icp_estimate_pt2pl(b[0], b[2], b[3], b[4], T0)
+            assert e1 == e2 and (T1 == T2).all()
+            ea, Ta, _ = oracle.icp_align(o["pos"], o["nor"], pts, nor, T0, I4, md, ma)
+            eb, Tb, _ = ref.icp_align(o["pos"], o["nor"], pts, nor, T0, I4, md, ma)
+            assert ea == eb and (Ta == Tb).all()
+        poses = np.stack([synth.perturbed_pose(o["pose"], rng, 0.5, 0.15) for _ in range(6)])
+        for K in (64, 32):
+            assert (oracle.alignment_scores(pts, nor, o["pos"], o["nor"], poses, K) ==
+                    ref.alignment_scores(pts, nor, o["pos"], o["nor"], poses, K)).all()
+
+
+def test_label_gate_matches_reference_tu(oracle, ref):
+    """The gate expression compiled with rs_pointcloud_filters.cpp's include preamble (acosf on
+    the float |dot|) vs the restatement, around the 70 degree threshold and over a sweep."""
+    c70 = np.float32(np.cos(np.deg2rad(70.0)))
+    xs = [np.float32(x) for x in np.linspace(-1.2, 1.2, 3001)]
+    x = c70
+    for _ in range(200):
+        x = np.nextafter(x, np.float32(1)); xs.append(x)
+    x = c70
+    for _ in range(200):
+        x = np.nextafter(x, np.float32(0)); xs.append(x)
+    for v in xs:
+        assert oracle.label_gate(v) == ref.label_gate_dot(v)
+    rng = np.random.default_rng(4)
+    from rescan_amd import synth
+    for _ in range(300):
+        pose = synth.pose_matrix(rng.uniform(0, 6.28), rng.normal(size=3))
+        n1 = rng.normal(size=3).astype(np.float32); n2 = rng.normal(size=3).astype(np.float32)
+        nm = oracle.xform_points(np.ascontiguousarray(pose.reshape(4, 4).T.ravel()), n1[None], 0)[0]
+        u1, u2 = oracle.normalize(nm[None])[0], oracle.normalize(n2[None])[0]
+        dot = np.float32(np.float32(np.float32(u1[0] * u2[0]) + np.float32(u1[1] * u2[1])) + np.float32(u1[2] * u2[2]))
+        assert oracle.label_gate(dot) == ref.label_gate(pose, n1, n2)
