@@ -1,0 +1,101 @@
+/* rescan_dropin.h — the reference's own entry points for the hot path, re-implemented on top of
+ * librescan_hip.so and exported under the reference's names by librescan_dropin.so, so that
+ * apps/pose_proposal and apps/segment_transfer link against it unchanged (INTEGRATION.md shows
+ * the two shadow headers a maintainer adds).
+ *
+ * Types are layout-identical to the reference's (sizes/offsets are checked by static asserts in
+ * rs_dropin.cpp and by tests/test_dropin_cpu.py):
+ *   msh_vec3_t        12 bytes {x,y,z}                       lib/msh/msh_vec_math.h:159-164
+ *   msh_mat4_t        64 bytes, column-major float[16]       lib/msh/msh_vec_math.h:187-191
+ *   msh_hash_grid_t   120 bytes, caller-allocated, zeroed    lib/msh/msh_hash_grid.h:248-269
+ *   msh_hash_grid_search_desc_t                              lib/msh/msh_hash_grid.h:196-216
+ */
+#ifndef RESCAN_DROPIN_H
+#define RESCAN_DROPIN_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rsd_vec3 { float x, y, z; } rsd_vec3_t;                 /* == msh_vec3_t */
+typedef struct rsd_mat4 { float data[16]; } rsd_mat4_t;               /* == msh_mat4_t */
+
+typedef struct rsd_hash_grid                                           /* == msh_hash_grid_t */
+{
+  size_t width, height, depth;
+  double cell_size;
+  float  min_pt[3];
+  float  max_pt[3];
+  void*  bin_table;        /* unused by the shim (NULL) */
+  void*  data_buffer;      /* holds the rs_hip_cloud_t* of this grid */
+  void*  offsets;          /* unused by the shim (NULL) */
+  int32_t  _slab_size;
+  double   _inv_cell_size;
+  uint8_t  _pts_dim;
+  uint16_t _num_threads;
+  int32_t  _dont_use_omp;
+  uint32_t max_n_pts_in_bin;
+  size_t   _n_pts;
+} rsd_hash_grid_t;
+
+typedef struct rsd_search_desc                                         /* == msh_hash_grid_search_desc_t */
+{
+  float*   query_pts;
+  size_t   n_query_pts;
+  float*   distances_sq;
+  int32_t* indices;
+  size_t*  n_neighbors;
+  float    radius;
+  union { size_t k; size_t max_n_neigh; };
+  int      sort;
+} rsd_search_desc_t;
+
+/* lib/msh/msh_hash_grid.h:218-230 */
+void   msh_hash_grid_init_3d( rsd_hash_grid_t* hg, const float* pts, const int32_t n_pts, const float radius );
+void   msh_hash_grid_term( rsd_hash_grid_t* hg );
+size_t msh_hash_grid_radius_search( const rsd_hash_grid_t* hg, rsd_search_desc_t* search_desc );
+
+/* lib/rs/icp.h:83-115 */
+float icp_align( rsd_vec3_t* pts1, rsd_vec3_t* nor1, int32_t n_pts1,
+                 rsd_vec3_t* pts2, rsd_vec3_t* nor2, int32_t n_pts2,
+                 rsd_mat4_t* T1, rsd_mat4_t T2, float max_dist, float max_angle, bool verbose );
+float icp_estimate_rigid_xform_pt2pl( rsd_vec3_t* pts1, rsd_vec3_t* pts2, rsd_vec3_t* nor2, float* weights,
+                                      int32_t n_pts, rsd_mat4_t* T1 );
+void  icp_find_corrs( rsd_vec3_t* pts1, rsd_vec3_t* nor1, int32_t n_pts1, rsd_hash_grid_t* idx1,
+                      rsd_vec3_t* pts2, rsd_vec3_t* nor2, int32_t n_pts2, rsd_hash_grid_t* idx2,
+                      rsd_mat4_t T1, rsd_mat4_t T2,
+                      rsd_vec3_t** corr_pts1, rsd_vec3_t** corr_nor1, rsd_vec3_t** corr_pts2, rsd_vec3_t** corr_nor2,
+                      float** weights, int32_t* n_corrs, float max_dist, float max_angle );
+
+/* The two C++-linkage consumers take rs_pointcloud_t / rsdb_t, which the shim does not know; the
+ * shadow copies of those functions call these flat entry points instead.
+ *
+ * mgs_compute_object_alignment_score (apps/pose_proposal/pose_proposal.cpp:93-158) for one pose:
+ * obj_* = object->positions/normals[query_lvl], scn_* = scene->positions/normals[search_lvl]. */
+float rsd_alignment_score( const rsd_vec3_t* obj_pos, const rsd_vec3_t* obj_nor, int32_t n_obj,
+                           const rsd_vec3_t* scn_pos, const rsd_vec3_t* scn_nor, int32_t n_scn,
+                           rsd_mat4_t xform, float search_radius, int32_t max_n_neigh );
+/* the same for a batch of poses (the grid-search loops at pose_proposal.cpp:213-244, 283-298) */
+int   rsd_alignment_scores( const rsd_vec3_t* obj_pos, const rsd_vec3_t* obj_nor, int32_t n_obj,
+                            const rsd_vec3_t* scn_pos, const rsd_vec3_t* scn_nor, int32_t n_scn,
+                            const rsd_mat4_t* xforms, int32_t n_poses, float search_radius, int32_t max_n_neigh,
+                            float* scores );
+/* rspf_arrangement_to_labels' search part (lib/rs/rs_pointcloud_filters.cpp:796-848): placements in
+ * arrangement order with per-placement static flag and class index; writes int8 labels (1-based
+ * index into the sorted arrangement, whose permutation is returned in sorted_order). */
+int   rsd_arrangement_to_labels( const rsd_vec3_t* scn_pos, const rsd_vec3_t* scn_nor, int32_t n_scn,
+                                 const rsd_vec3_t* const* obj_pos, const rsd_vec3_t* const* obj_nor, const int32_t* obj_n,
+                                 const rsd_mat4_t* poses, const int32_t* is_static, const int32_t* class_idx, int32_t n_plc,
+                                 float radius, bool prioritize_static, int8_t* labels, int32_t* sorted_order );
+
+/* Drop every cached device cloud (the shim caches uploads by host pointer + content hash). */
+void  rsd_cache_clear( void );
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -226,6 +226,24 @@ void ref_alignment_scores( void* sp, float* obj_pos, float* obj_nor, int32_t n_o
   free_tmp_calc_storage( &st );
 }
 
+// sizes/offsets of the boundary types, for the drop-in shim's layout test
+int64_t ref_layout( int what )
+{
+  switch( what )
+  {
+    case 0: return sizeof(msh_vec3_t);
+    case 1: return sizeof(msh_mat4_t);
+    case 2: return sizeof(msh_hash_grid_t);
+    case 3: return offsetof(msh_hash_grid_t, data_buffer);
+    case 4: return offsetof(msh_hash_grid_t, _n_pts);
+    case 5: return sizeof(msh_hash_grid_search_desc_t);
+    case 6: return offsetof(msh_hash_grid_search_desc_t, radius);
+    case 7: return offsetof(msh_hash_grid_search_desc_t, sort);
+    case 8: return offsetof(msh_hash_grid_t, cell_size);
+    default: return -1;
+  }
+}
+
 int ref_num_threads( void )
 {
 #if defined(_OPENMP)

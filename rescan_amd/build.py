@@ -6,8 +6,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librescan_hip.so")
+DROPIN = os.path.join(HERE, "librescan_dropin.so")
 SOURCES = ["rs_kernels.hip", "rs_api.hip"]
-HEADERS = ["rs_device.h", "rs_math.h", os.path.join("..", "..", "include", "rescan_hip.h")]
+HEADERS = ["rs_device.h", "rs_math.h", "rs_dropin.cpp", os.path.join("..", "..", "include", "rescan_hip.h"),
+           os.path.join("..", "..", "include", "rescan_dropin.h")]
 # -ffp-contract=off: the neighbour-deciding arithmetic must round exactly like the reference's
 # scalar SSE2 code (no FMA); see DESIGN.md.
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared",
@@ -15,7 +17,7 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fP
 
 
 def _stale():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(DROPIN):
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
@@ -35,6 +37,13 @@ def build(force=False, verbose=False):
         subprocess.check_call(cmd)
         objs.append(o)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    # the reference-named entry points (icp_align, msh_hash_grid_*) live in their own library so
+    # that they never collide with a reference build loaded in the same process
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall",
+           os.path.join(CSRC, "rs_dropin.cpp"), "-o", DROPIN, "-L" + HERE, "-lrescan_hip", "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -1,0 +1,216 @@
+// librescan_dropin.so — the reference's own symbol names for the hot path, forwarding to the
+// C ABI of librescan_hip.so (include/rescan_hip.h).  See include/rescan_dropin.h.
+//
+// Error behaviour follows the reference: no error codes on this path.  A failing
+// HIP call prints to stderr and leaves the caller's data untouched (icp_align returns the 1e6 it
+// would have returned had it never iterated, lib/rs/icp.h:441-442).  There is no CPU fallback.
+
+#include "../../include/rescan_dropin.h"
+#include "../../include/rescan_hip.h"
+
+#include <cmath>
+#include <cstddef>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <list>
+#include <vector>
+
+static_assert( sizeof(rsd_vec3_t) == 12, "msh_vec3_t is 12 bytes" );
+static_assert( sizeof(rsd_mat4_t) == 64, "msh_mat4_t is 64 bytes" );
+static_assert( sizeof(rsd_hash_grid_t) == 120, "msh_hash_grid_t is 120 bytes (lib/msh/msh_hash_grid.h:248-269)" );
+static_assert( offsetof(rsd_hash_grid_t, data_buffer) == 64, "data_buffer offset" );
+static_assert( offsetof(rsd_hash_grid_t, _n_pts) == 112, "_n_pts offset" );
+static_assert( sizeof(rsd_search_desc_t) == 64, "msh_hash_grid_search_desc_t is 64 bytes" );
+
+namespace {
+
+void complain( const char* where )
+{
+  fprintf( stderr, "[rescan_hip] %s: %s\n", where, rs_hip_last_error() );
+}
+
+// ---- device-cloud cache ------------------------------------------------------------------
+// The reference hands the same host arrays to the hot path over and over (the scene level for
+// every proposal, apps/pose_proposal/main.cpp:190-202).  Uploads are cached by
+// (pointers, count, cell size, content hash) and evicted least-recently-used.
+struct Entry
+{
+  const void* pos; const void* nor; int32_t n; float cell; uint64_t hash;
+  rs_hip_cloud_t* cloud;
+};
+std::list<Entry> g_cache;
+const size_t kMaxEntries = 64;
+
+uint64_t content_hash( const void* a, const void* b, size_t bytes )
+{
+  uint64_t h = 0x9e3779b97f4a7c15ull ^ bytes;
+  for( const void* src : { a, b } )
+  {
+    if( !src ) { h = ( h ^ 0x51ull ) * 0xff51afd7ed558ccdull; continue; }
+    const unsigned char* p = (const unsigned char*)src;
+    size_t i = 0;
+    for( ; i + 8 <= bytes; i += 8 ) { uint64_t w; std::memcpy( &w, p + i, 8 ); h = ( h ^ w ) * 0xff51afd7ed558ccdull; h ^= h >> 32; }
+    for( ; i < bytes; ++i ) { h = ( h ^ p[i] ) * 0x100000001b3ull; }
+  }
+  return h;
+}
+
+rs_hip_cloud_t* cached_cloud( const rsd_vec3_t* pos, const rsd_vec3_t* nor, int32_t n, float cell )
+{
+  const uint64_t h = content_hash( pos, nor, (size_t)( n > 0 ? n : 0 ) * 12 );
+  for( auto it = g_cache.begin(); it != g_cache.end(); ++it )
+    if( it->pos == pos && it->nor == nor && it->n == n && it->cell == cell && it->hash == h )
+    {
+      g_cache.splice( g_cache.begin(), g_cache, it );
+      return g_cache.front().cloud;
+    }
+  rs_hip_cloud_t* c = rs_hip_cloud_create( (const float*)pos, (const float*)nor, n, cell );
+  if( !c ) { complain( "cloud upload" ); return nullptr; }
+  g_cache.push_front( Entry{ pos, nor, n, cell, h, c } );
+  while( g_cache.size() > kMaxEntries ) { rs_hip_cloud_destroy( g_cache.back().cloud ); g_cache.pop_back(); }
+  return c;
+}
+
+} // namespace
+
+extern "C" {
+
+void rsd_cache_clear( void )
+{
+  for( auto& e : g_cache ) rs_hip_cloud_destroy( e.cloud );
+  g_cache.clear();
+}
+
+// ---- msh_hash_grid ------------------------------------------------------------------------
+
+void msh_hash_grid_init_3d( rsd_hash_grid_t* hg, const float* pts, const int32_t n_pts, const float radius )
+{
+  // cell = 2*radius like the reference (msh_hash_grid.h:443); a non-positive radius asks the
+  // reference for an extent-derived cell (:444) — any positive cell gives the same results here.
+  float cell = radius > 0.0f ? 2.0f * radius : 0.1f;
+  rs_hip_cloud_t* c = rs_hip_cloud_create( pts, nullptr, n_pts, cell );
+  if( !c ) complain( "msh_hash_grid_init_3d" );
+  hg->data_buffer = c;
+  hg->bin_table = nullptr; hg->offsets = nullptr;
+  hg->cell_size = cell; hg->_inv_cell_size = 1.0 / cell;
+  hg->_pts_dim = 3; hg->_num_threads = 1; hg->_n_pts = (size_t)( n_pts > 0 ? n_pts : 0 );
+}
+
+void msh_hash_grid_term( rsd_hash_grid_t* hg )
+{
+  if( hg->data_buffer ) rs_hip_cloud_destroy( (rs_hip_cloud_t*)hg->data_buffer );
+  std::memset( hg, 0, sizeof(*hg) );                     // the reference zeroes what it owns (:558-573)
+}
+
+size_t msh_hash_grid_radius_search( const rsd_hash_grid_t* hg, rsd_search_desc_t* d )
+{
+  if( !hg || !hg->data_buffer || !d ) return 0;
+  uint64_t total = 0;
+  int rc = rs_hip_radius_search( (const rs_hip_cloud_t*)hg->data_buffer, d->query_pts, (int64_t)d->n_query_pts, d->radius,
+                                 (int32_t)d->max_n_neigh, d->distances_sq, d->indices, d->n_neighbors, &total );
+  if( rc ) { complain( "msh_hash_grid_radius_search" ); return 0; }
+  return (size_t)total;
+}
+
+// ---- icp ----------------------------------------------------------------------------------
+
+float icp_align( rsd_vec3_t* pts1, rsd_vec3_t* nor1, int32_t n_pts1, rsd_vec3_t* pts2, rsd_vec3_t* nor2, int32_t n_pts2,
+                 rsd_mat4_t* T1, rsd_mat4_t T2, float max_dist, float max_angle, bool verbose )
+{
+  // the reference builds its grids with radius = max_dist (icp.h:436-437) -> cell 2*max_dist
+  rs_hip_cloud_t* src = cached_cloud( pts1, nor1, n_pts1, 2.0f * max_dist );
+  rs_hip_cloud_t* tgt = cached_cloud( pts2, nor2, n_pts2, 2.0f * max_dist );
+  float err = 1e6f; int32_t iters = 0;
+  if( !src || !tgt ) return err;
+  rsd_mat4_t t = *T1;
+  int rc = rs_hip_icp_align( src, tgt, t.data, T2.data, max_dist, max_angle, 100, 0, &err, &iters );
+  if( rc ) { complain( "icp_align" ); return 1e6f; }
+  *T1 = t;
+  if( verbose ) printf( " ICP: %d iterations on the GPU, final error %7.5f\n", iters, err );
+  return err;
+}
+
+float icp_estimate_rigid_xform_pt2pl( rsd_vec3_t* pts1, rsd_vec3_t* pts2, rsd_vec3_t* nor2, float* weights,
+                                      int32_t n_pts, rsd_mat4_t* T1 )
+{
+  float err = 0.0f;
+  if( rs_hip_icp_estimate_pt2pl( (const float*)pts1, (const float*)pts2, (const float*)nor2, weights, n_pts, T1->data, &err ) )
+    complain( "icp_estimate_rigid_xform_pt2pl" );
+  return err;
+}
+
+void icp_find_corrs( rsd_vec3_t* pts1, rsd_vec3_t* nor1, int32_t n_pts1, rsd_hash_grid_t* idx1,
+                     rsd_vec3_t* pts2, rsd_vec3_t* nor2, int32_t n_pts2, rsd_hash_grid_t* idx2,
+                     rsd_mat4_t T1, rsd_mat4_t T2,
+                     rsd_vec3_t** corr_pts1, rsd_vec3_t** corr_nor1, rsd_vec3_t** corr_pts2, rsd_vec3_t** corr_nor2,
+                     float** weights, int32_t* n_corrs, float max_dist, float max_angle )
+{
+  (void)idx1;
+  // Output arrays come from libc malloc because reference code frees them (icp.h:317-327,
+  // including its habit of never freeing corr_nor1).
+  if( *corr_pts1 ) { free( *corr_pts1 ); *corr_pts1 = NULL; }
+  if( *corr_pts2 ) { free( *corr_pts2 ); *corr_pts2 = NULL; }
+  if( *corr_nor2 ) { free( *corr_nor2 ); *corr_nor2 = NULL; }
+  if( *weights )   { free( *weights );   *weights = NULL; }
+  const size_t cap = (size_t)( n_pts1 > 0 ? n_pts1 : 1 );
+  *corr_pts1 = (rsd_vec3_t*)malloc( cap * sizeof(rsd_vec3_t) );
+  *corr_pts2 = (rsd_vec3_t*)malloc( cap * sizeof(rsd_vec3_t) );
+  *corr_nor1 = (rsd_vec3_t*)malloc( cap * sizeof(rsd_vec3_t) );
+  *corr_nor2 = (rsd_vec3_t*)malloc( cap * sizeof(rsd_vec3_t) );
+  *weights   = (float*)malloc( cap * sizeof(float) );
+  *n_corrs = 0;
+  float cell = ( idx2 && idx2->cell_size > 0.0 ) ? (float)idx2->cell_size : 2.0f * max_dist;
+  rs_hip_cloud_t* src = cached_cloud( pts1, nor1, n_pts1, cell );
+  rs_hip_cloud_t* tgt = cached_cloud( pts2, nor2, n_pts2, cell );
+  if( !src || !tgt ) return;
+  if( rs_hip_icp_find_corrs( src, tgt, T1.data, T2.data, max_dist, max_angle, (float*)*corr_pts1, (float*)*corr_nor1,
+                             (float*)*corr_pts2, (float*)*corr_nor2, *weights, n_corrs ) )
+  { complain( "icp_find_corrs" ); *n_corrs = 0; }
+}
+
+// ---- the two C++-linkage consumers, flattened ----------------------------------------------
+
+int rsd_alignment_scores( const rsd_vec3_t* obj_pos, const rsd_vec3_t* obj_nor, int32_t n_obj,
+                          const rsd_vec3_t* scn_pos, const rsd_vec3_t* scn_nor, int32_t n_scn,
+                          const rsd_mat4_t* xforms, int32_t n_poses, float search_radius, int32_t max_n_neigh, float* scores )
+{
+  // scene level grids use radius 0.05 -> cell 0.10 (lib/rs/rs_pointcloud.h:862)
+  rs_hip_cloud_t* obj = cached_cloud( obj_pos, obj_nor, n_obj, 0.1f );
+  rs_hip_cloud_t* scn = cached_cloud( scn_pos, scn_nor, n_scn, 0.1f );
+  if( !obj || !scn ) return RS_HIP_E_RUNTIME;
+  int rc = rs_hip_alignment_scores( obj, scn, (const float*)xforms, n_poses, search_radius, max_n_neigh, scores );
+  if( rc ) complain( "alignment_scores" );
+  return rc;
+}
+
+float rsd_alignment_score( const rsd_vec3_t* obj_pos, const rsd_vec3_t* obj_nor, int32_t n_obj,
+                           const rsd_vec3_t* scn_pos, const rsd_vec3_t* scn_nor, int32_t n_scn,
+                           rsd_mat4_t xform, float search_radius, int32_t max_n_neigh )
+{
+  float s = 0.0f;
+  rsd_alignment_scores( obj_pos, obj_nor, n_obj, scn_pos, scn_nor, n_scn, &xform, 1, search_radius, max_n_neigh, &s );
+  return s;
+}
+
+int rsd_arrangement_to_labels( const rsd_vec3_t* scn_pos, const rsd_vec3_t* scn_nor, int32_t n_scn,
+                               const rsd_vec3_t* const* obj_pos, const rsd_vec3_t* const* obj_nor, const int32_t* obj_n,
+                               const rsd_mat4_t* poses, const int32_t* is_static, const int32_t* class_idx, int32_t n_plc,
+                               float radius, bool prioritize_static, int8_t* labels, int32_t* sorted_order )
+{
+  rs_hip_cloud_t* scn = cached_cloud( scn_pos, scn_nor, n_scn, 0.1f );
+  if( !scn ) return RS_HIP_E_RUNTIME;
+  std::vector<const rs_hip_cloud_t*> objs( (size_t)( n_plc > 0 ? n_plc : 0 ) );
+  for( int i = 0; i < n_plc; ++i )
+  {
+    objs[i] = cached_cloud( obj_pos[i], obj_nor[i], obj_n[i], 0.1f );
+    if( !objs[i] ) return RS_HIP_E_RUNTIME;
+  }
+  std::vector<float> min_dists( (size_t)( n_scn > 0 ? n_scn : 0 ) );
+  int rc = rs_hip_arrangement_to_labels( scn, (const float*)poses, objs.data(), is_static, class_idx, n_plc, radius,
+                                         prioritize_static ? 1 : 0, labels, min_dists.data(), sorted_order );
+  if( rc ) complain( "arrangement_to_labels" );
+  return rc;
+}
+
+} // extern "C"

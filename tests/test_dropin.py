@@ -1,0 +1,121 @@
+"""The drop-in boundary: librescan_dropin.so exports the reference's own symbol names
+(icp_align, icp_find_corrs, msh_hash_grid_*) with the reference's struct layouts."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden_files, load_golden
+
+DROPIN = os.path.join(ROOT, "rescan_amd", "librescan_dropin.so")
+
+
+class Mat4(C.Structure):
+    _fields_ = [("data", C.c_float * 16)]
+
+
+class HashGrid(C.Structure):                       # msh_hash_grid_t, lib/msh/msh_hash_grid.h:248-269
+    _fields_ = [("width", C.c_size_t), ("height", C.c_size_t), ("depth", C.c_size_t), ("cell_size", C.c_double),
+                ("min_pt", C.c_float * 3), ("max_pt", C.c_float * 3), ("bin_table", C.c_void_p),
+                ("data_buffer", C.c_void_p), ("offsets", C.c_void_p), ("_slab_size", C.c_int32),
+                ("_inv_cell_size", C.c_double), ("_pts_dim", C.c_uint8), ("_num_threads", C.c_uint16),
+                ("_dont_use_omp", C.c_int32), ("max_n_pts_in_bin", C.c_uint32), ("_n_pts", C.c_size_t)]
+
+
+class SearchDesc(C.Structure):                     # msh_hash_grid_search_desc_t, :196-216
+    _fields_ = [("query_pts", C.c_void_p), ("n_query_pts", C.c_size_t), ("distances_sq", C.c_void_p),
+                ("indices", C.c_void_p), ("n_neighbors", C.c_void_p), ("radius", C.c_float),
+                ("max_n_neigh", C.c_size_t), ("sort", C.c_int)]
+
+
+def declared():
+    hdr = open(os.path.join(ROOT, "include", "rescan_dropin.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b((?:icp|msh_hash_grid|rsd)_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_symbols_and_layout():
+    from rescan_amd import build
+    build.build()
+    out = subprocess.check_output(["nm", "-D", "--defined-only", DROPIN], text=True)
+    exported = set(re.findall(r" T ([a-z0-9_]+)", out))
+    names = declared()
+    assert {"icp_align", "icp_find_corrs", "icp_estimate_rigid_xform_pt2pl", "msh_hash_grid_init_3d",
+            "msh_hash_grid_term", "msh_hash_grid_radius_search"} <= set(names)
+    assert set(names) <= exported
+    assert C.sizeof(HashGrid) == 120 and HashGrid.data_buffer.offset == 64 and HashGrid._n_pts.offset == 112
+    assert C.sizeof(SearchDesc) == 64 and C.sizeof(Mat4) == 64
+
+
+def test_layout_matches_the_reference_headers():
+    from oracle.pyoracle import Ref
+    if not Ref.available():
+        pytest.skip("oracle/_ref not built")
+    lib = Ref().lib
+    lib.ref_layout.restype = C.c_int64
+    want = [12, 64, C.sizeof(HashGrid), HashGrid.data_buffer.offset, HashGrid._n_pts.offset, C.sizeof(SearchDesc),
+            SearchDesc.radius.offset, SearchDesc.sort.offset, HashGrid.cell_size.offset]
+    assert [lib.ref_layout(i) for i in range(9)] == want
+
+
+@pytest.fixture(scope="module")
+def dropin():
+    from rescan_amd import capi
+    capi.init(0)
+    lib = C.CDLL(DROPIN)
+    lib.icp_align.restype = C.c_float
+    lib.icp_align.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                              C.POINTER(Mat4), Mat4, C.c_float, C.c_float, C.c_bool]
+    lib.msh_hash_grid_radius_search.restype = C.c_size_t
+    lib.rsd_alignment_scores.restype = C.c_int
+    return lib
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fname", golden_files("icp_")[:4])
+def test_icp_align_by_reference_name(dropin, gscene, fname):
+    g = load_golden(fname)
+    o = gscene["objects"][int(g["obj"])]
+    T1 = Mat4(); T1.data[:] = [float(x) for x in g["T1"]]
+    T2 = Mat4(); T2.data[:] = [float(x) for x in g["T2"]]
+    pts2, nor2 = gscene["points"], gscene["normals"]
+    for _ in range(2):                       # second call hits the device-cloud cache
+        T = Mat4(); T.data[:] = T1.data[:]
+        err = dropin.icp_align(o["pos"].ctypes.data, o["nor"].ctypes.data, len(o["pos"]), pts2.ctypes.data,
+                               nor2.ctypes.data, len(pts2), C.byref(T), T2, float(g["max_dist"]),
+                               float(g["max_angle"]), False)
+        got = np.array(T.data[:], np.float32)
+        assert np.linalg.norm(got.astype(np.float64) - g["T_out"]) < 1e-4 and abs(err - float(g["err"])) < 1e-5
+
+
+@pytest.mark.gpu
+def test_hash_grid_by_reference_name(dropin, gscene):
+    g = load_golden("rows_k16_r010.npz")
+    hg = HashGrid()
+    pts = gscene["points"]
+    dropin.msh_hash_grid_init_3d(C.byref(hg), pts.ctypes.data, len(pts), C.c_float(float(g["grid_radius"])))
+    assert hg.data_buffer and hg._n_pts == len(pts)
+    q = g["query"]; k = int(g["k"])
+    d = np.zeros((len(q), k), np.float32); i = np.zeros((len(q), k), np.int32); nn = np.zeros(len(q), np.uint64)
+    sd = SearchDesc(q.ctypes.data, len(q), d.ctypes.data, i.ctypes.data, nn.ctypes.data, float(g["radius"]), k, 1)
+    tot = dropin.msh_hash_grid_radius_search(C.byref(hg), C.byref(sd))
+    assert tot == int(g["total"]) and (nn.astype(np.int64) == g["nn"]).all()
+    valid = np.arange(k)[None, :] < g["nn"][:, None]
+    assert (d[valid] == g["dists"][valid]).all()
+    dropin.msh_hash_grid_term(C.byref(hg))
+    assert not hg.data_buffer and hg.width == 0
+
+
+@pytest.mark.gpu
+def test_scores_by_flat_entry(dropin, gscene):
+    g = load_golden("scores_table0_k64.npz")
+    o = gscene["objects"][int(g["obj"])]
+    poses = np.ascontiguousarray(g["poses"], np.float32)
+    out = np.zeros(len(poses), np.float32)
+    rc = dropin.rsd_alignment_scores(o["pos"].ctypes.data, o["nor"].ctypes.data, len(o["pos"]),
+                                     gscene["points"].ctypes.data, gscene["normals"].ctypes.data, len(gscene["points"]),
+                                     poses.ctypes.data, len(poses), C.c_float(0.1), 64, out.ctypes.data)
+    assert rc == 0 and np.abs(out.astype(np.float64) - g["scores"]).max() < 2e-6
