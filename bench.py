@@ -42,7 +42,7 @@ def build_workload(n_points, seed, knn):
     from rescan_amd import capi, synth
     s0 = synth.scene_for_point_count(int(n_points * 0.84), seed=seed, timestep=0)
     s1 = synth.scene_for_point_count(int(n_points * 0.84), seed=seed, timestep=1)
-    cell = 0.1 if knn == "hash" else 0.0
+    cell = float(os.environ.get("RS_BENCH_CELL", "-1")) if knn == "hash" else 0.0
     w = {}
     w["s0"], w["s1"] = s0, s1
     w["scan0"] = capi.Cloud(s0["points"], s0["normals"], cell_size=cell)      # ICP target
@@ -52,7 +52,7 @@ def build_workload(n_points, seed, knn):
     # score object: a table model resampled to ~10k points
     op, on = synth.make_object("table", seed * 13 + 1, density=3800.0)
     w["obj_score_np"] = (op, on)
-    w["obj_score"] = capi.Cloud(op, on, cell_size=0.1)
+    w["obj_score"] = capi.Cloud(op, on, cell_size=cell if cell != 0 else -1.0)
     tbl = [o for o in s1["objects"] if o["kind"] == "table"][0]
     w["score_poses"] = np.stack([synth.perturbed_pose(tbl["pose"], rng, 0.6, 0.25) for _ in range(N_POSES)])
     # label placements: 8 scene objects with dense (~50k-point) model clouds, slightly mis-posed
@@ -60,7 +60,7 @@ def build_workload(n_points, seed, knn):
     for k, o in enumerate(s1["objects"][:N_PLACEMENTS]):
         dens = 50000.0 / max(1, len(o["pos"])) * synth.DENSITY
         lp, ln = synth.make_object(o["kind"], seed * 7919 + k, density=dens)
-        plc.append(dict(cloud=capi.Cloud(lp, ln, cell_size=0.1), np=(lp, ln),
+        plc.append(dict(cloud=capi.Cloud(lp, ln, cell_size=cell if cell != 0 else -1.0), np=(lp, ln),
                         pose=synth.perturbed_pose(o["pose"], rng, 0.01, 0.005), cls=o["class_idx"]))
     w["plc"] = plc
     w["n_scan0"], w["n_scan1"], w["n_obj"] = len(s0["points"]), len(s1["points"]), len(op)

@@ -54,7 +54,9 @@ int         rs_hip_profile_read( const char* name, int64_t* launches, double* to
  * (lib/rs/rs_pointcloud.h:77-97,849-863; lib/msh/msh_hash_grid.h:248-269,388-541).
  * cell_size > 0 : grid cell edge in metres (msh_hash_grid uses 2*radius; any value gives the
  *                 same search results, it only changes speed).
- * cell_size <= 0: one cell holding everything ("brute-tile" layout). */
+ * cell_size < 0 : chosen from the cloud's sampling density (about two sample spacings) —
+ *                 the fastest choice for the staged search.
+ * cell_size = 0 : one cell holding everything ("brute-tile" layout). */
 typedef struct rs_hip_cloud rs_hip_cloud_t;
 
 rs_hip_cloud_t* rs_hip_cloud_create( const float* pos, const float* nor /* may be NULL */,

@@ -12,7 +12,7 @@ HEADERS = ["rs_device.h", "rs_math.h", "rs_dropin.cpp", os.path.join("..", "..",
            os.path.join("..", "..", "include", "rescan_dropin.h")]
 # -ffp-contract=off: the neighbour-deciding arithmetic must round exactly like the reference's
 # scalar SSE2 code (no FMA); see DESIGN.md.
-FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared",
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
          "-Wall", "-Wno-unused-function"]
 
 

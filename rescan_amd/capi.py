@@ -121,7 +121,8 @@ IDENTITY = np.eye(4, dtype=np.float32).ravel()
 class Cloud:
     """A device-resident cloud level + its grid index (rs_hip_cloud_t)."""
 
-    def __init__(self, pos, nor=None, cell_size=0.1):
+    def __init__(self, pos, nor=None, cell_size=-1.0):
+        """cell_size > 0: explicit grid cell; < 0 (default): from the sampling density; 0: brute-tile layout."""
         lib = load()
         pos = _f32(pos).reshape(-1, 3)
         self.n = len(pos)

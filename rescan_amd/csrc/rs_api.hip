@@ -83,7 +83,7 @@ struct PinBuf
 
 struct Workspace
 {
-  DevBuf T1, active, slot, d2, dot, corr_part, stats, mom_part, moments, wexp;   // ICP
+  DevBuf T1, active, slot, d2, dot, corr_part, stats, mom_part, moments, wexp, queue, queue_count;   // ICP
   DevBuf poses, score_part, scores;                                             // score
   DevBuf plc, labels, mind;                                                     // labels
   DevBuf q4, rd2, ridx, rnn, rows;                                              // rows / misc
@@ -324,6 +324,33 @@ rs_hip_cloud_t* rs_hip_cloud_create( const float* pos, const float* nor, int32_t
     for( int a = 0; a < 3; ++a ) { float v = pos[3*i+a]; if( v < mn[a] ) mn[a] = v; if( v > mx[a] ) mx[a] = v; }
   for( int a = 0; a < 3; ++a ) { if( !( mx[a] >= mn[a] ) || !std::isfinite( mn[a] ) || !std::isfinite( mx[a] ) ) { mn[a] = 0; mx[a] = 0; } }
 
+  // cell_size < 0: pick the cell from the cloud's own sampling density (about two sample
+  // spacings: a surface patch then holds ~4 points per cell, the first search shell ~100-300).
+  if( cell_size < 0.0f )
+  {
+    cell_size = 0.1f;
+    if( n > 0 )
+    {
+      float ext = std::max( mx[0] - mn[0], std::max( mx[1] - mn[1], mx[2] - mn[2] ) );
+      float c0 = std::min( 0.1f, std::max( ext / 64.0f, 1e-4f ) );
+      for( int attempt = 0; attempt < 8; ++attempt, c0 *= 2.0f )
+      {
+        std::vector<uint64_t> ids( (size_t)n );
+        const float inv = 1.0f / c0;
+        for( int32_t i = 0; i < n; ++i )
+        {
+          uint64_t a = (uint64_t)std::max( 0.0f, floorf( ( pos[3*i] - mn[0] ) * inv ) ), b = (uint64_t)std::max( 0.0f, floorf( ( pos[3*i+1] - mn[1] ) * inv ) ),
+                   c = (uint64_t)std::max( 0.0f, floorf( ( pos[3*i+2] - mn[2] ) * inv ) );
+          ids[i] = ( a << 42 ) | ( b << 21 ) | c;
+        }
+        std::sort( ids.begin(), ids.end() );
+        size_t occ = std::unique( ids.begin(), ids.end() ) - ids.begin();
+        float per_cell = (float)n / (float)occ;
+        if( per_cell >= 4.0f || attempt == 7 ) { cell_size = 2.0f * c0 / std::sqrt( std::max( per_cell, 1.0f ) ); break; }
+      }
+      cell_size = std::min( std::max( cell_size, 0.005f ), 2.0f );
+    }
+  }
   int dims[3] = { 1, 1, 1 };
   float inv_cell = 0.0f, cell = cell_size;
   if( cell_size > 0.0f && n > 0 )
@@ -379,7 +406,7 @@ rs_hip_cloud_t* rs_hip_cloud_create( const float* pos, const float* nor, int32_t
 
   GridView& v = c->view;
   v.pos = c->d_pos; v.nor = c->d_nor; v.cell_start = c->d_cell_start;
-  v.minx = mn[0]; v.miny = mn[1]; v.minz = mn[2]; v.inv_cell = inv_cell;
+  v.minx = mn[0]; v.miny = mn[1]; v.minz = mn[2]; v.inv_cell = inv_cell; v.cell = inv_cell > 0.0f ? cell : 0.0f;
   v.w = dims[0]; v.h = dims[1]; v.d = dims[2]; v.n = n;
 
   // query layout (Hilbert order + tiles)
@@ -442,6 +469,20 @@ void rs_hip_mat4_mul( const float* a_, const float* b_, float* out ) { Mat4 a, b
 // ------------------------------------------------------------------------------------------
 
 namespace {
+
+// Hand-off policy of the two-phase search.  A lone wave that is still unsettled after streaming
+// this many candidates sits in a cluttered neighbourhood and would need ~0.5 ms for the rest of
+// its box; it is queued for the cooperative kernel instead.  That only pays when the launch has
+// too few tiles to hide such stragglers behind other work (measured on MI355X: 1 M-query ICP,
+// 15.6 k tiles: 0.60 -> 0.47 ms per search with hand-off; 256-pose score batch, 40 k tiles:
+// 1.5 -> 3.0 ms, i.e. worse), so big launches keep everything in phase A.
+inline int handoff_threshold( long long total_tiles )
+{
+  static int forced = -2;
+  if( forced == -2 ) { const char* e = getenv( "RS_HIP_SOLO_STAGES" ); forced = e ? atoi( e ) : -1; }
+  if( forced > 0 ) return forced;
+  return total_tiles <= 24000 ? 256 : 0x7fffffff;
+}
 
 inline float radius_sq_of( float r ) { return (float)( (double)r * (double)r ); }   // msh_hash_grid.h:1104,1111 + :828
 
@@ -528,8 +569,11 @@ int icp_prepare( IcpCtx& cx, const rs_hip_cloud_t* src, const rs_hip_cloud_t* tg
       ( rc = g_ws.slot.ensure( np * nq * 4 ) ) || ( rc = g_ws.d2.ensure( np * nq * 4 ) ) || ( rc = g_ws.dot.ensure( np * nq * 4 ) ) ||
       ( rc = g_ws.corr_part.ensure( np * std::max( 1, cx.n_waves ) * 3 * 8 ) ) || ( rc = g_ws.stats.ensure( np * 4 * 8 ) ) ||
       ( rc = g_ws.mom_part.ensure( np * L.n_mom_blocks * ICP_NMOM * 8 ) ) || ( rc = g_ws.moments.ensure( np * ICP_NMOM * 8 ) ) ||
-      ( rc = g_ws.h_a.ensure( np * ( ICP_NMOM + 4 ) * 8 ) ) || ( rc = g_ws.h_b.ensure( np * 64 + np * 4 ) ) )
+      ( rc = g_ws.h_a.ensure( np * ( ICP_NMOM + 4 ) * 8 ) ) || ( rc = g_ws.h_b.ensure( np * 64 + np * 4 ) ) ||
+      ( rc = g_ws.queue.ensure( np * std::max( 1, cx.n_waves ) * 4 ) ) || ( rc = g_ws.queue_count.ensure( np * 4 ) ) )
     return rc;
+  L.queue = g_ws.queue.as<int>(); L.queue_count = g_ws.queue_count.as<int>();
+  L.solo_stages = handoff_threshold( (long long)cx.n_waves * n_prob );
   L.T1 = g_ws.T1.as<float>(); L.active = g_ws.active.as<int>();
   L.m_slot = g_ws.slot.as<int>(); L.m_d2 = g_ws.d2.as<float>(); L.m_dot = g_ws.dot.as<float>();
   L.corr_part = g_ws.corr_part.as<double>(); L.stats = g_ws.stats.as<double>();
@@ -580,7 +624,21 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
   {
     if( ( rc = icp_upload_state( cx, T, active ) ) ) return rc;
     icp_set_radius( cx, max_dist, tmin );
+    static DevBuf dbgbuf;
+    if( getenv( "RS_HIP_DEBUG_CYCLES" ) && n == 1 ) { dbgbuf.ensure( (size_t)cx.n_waves * 16 ); cx.L.dbg = dbgbuf.as<unsigned long long>(); }
     { ProfScope ps( "nn_icp" ); launch_icp_corr( cx.L, g_stream ); }
+    if( cx.L.dbg )
+    {
+      std::vector<unsigned long long> h( (size_t)cx.n_waves * 2 );
+      (void)hipMemcpy( h.data(), cx.L.dbg, h.size() * 8, hipMemcpyDeviceToHost );
+      std::vector<unsigned long long> t; unsigned long long sum = 0, ho = 0;
+      unsigned long long tiles_uns = 0;
+      for( int k = 0; k < cx.n_waves; ++k ) { t.push_back( h[2*k] ); sum += h[2*k]; ho += h[2*k+1]; tiles_uns += h[2*k+1] ? 1 : 0; }
+      std::sort( t.begin(), t.end() );
+      fprintf( stderr, "[rs_hip dbg] unsettled lanes after shell 1: %llu of %d queries, in %llu tiles\n", ho, source->n, tiles_uns );
+      fprintf( stderr, "[rs_hip dbg] it %d tiles %d handoff %llu  wall-ticks(100MHz): mean %.0f p50 %llu p90 %llu p99 %llu max %llu\n", i, cx.n_waves, ho,
+               (double)sum / cx.n_waves, t[t.size()/2], t[t.size()*9/10], t[t.size()*99/100], t.back() );
+    }
     launch_icp_stats( cx.L, g_stream );
     { ProfScope ps( "icp_moments" ); launch_icp_moments( cx.L, g_stream ); }
     HIP_TRY( hipMemcpyAsync( hM, g_ws.moments.p, (size_t)n * ICP_NMOM * 8, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
@@ -750,13 +808,16 @@ int rs_hip_alignment_scores( const rs_hip_cloud_t* object, const rs_hip_cloud_t*
   if( object->n == 0 ) { for( int p = 0; p < n_poses; ++p ) scores[p] = NAN; return RS_HIP_OK; }   // 0/0, pose_proposal.cpp:156
   const int n_tiles = object->qview.n_tiles;
   if( ( rc = g_ws.poses.ensure( (size_t)n_poses * 64 ) ) || ( rc = g_ws.score_part.ensure( (size_t)n_poses * n_tiles * 8 ) ) ||
-      ( rc = g_ws.scores.ensure( (size_t)n_poses * 4 ) ) )
+      ( rc = g_ws.scores.ensure( (size_t)n_poses * 4 ) ) ||
+      ( rc = g_ws.queue.ensure( (size_t)std::min( n_poses, 65535 ) * n_tiles * 4 ) ) || ( rc = g_ws.queue_count.ensure( 4 ) ) )
     return rc;
   HIP_TRY( hipMemcpyAsync( g_ws.poses.p, poses, (size_t)n_poses * 64, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
   ScoreLaunch L{};
   L.scene = scene->view; L.obj = object->qview;
   L.poses = g_ws.poses.as<float>(); L.radius_sq = radius_sq_of( radius ); L.gate_tmin = score_gate_threshold();
   L.K = max_n_neigh; L.sigma = (double)radius; L.part = g_ws.score_part.as<double>(); L.scores = g_ws.scores.as<float>();
+  L.queue = g_ws.queue.as<int>(); L.queue_count = g_ws.queue_count.as<int>();
+  L.solo_stages = handoff_threshold( (long long)n_tiles * n_poses );
   // the launch grid's y dimension is limited to 65535 poses per launch
   for( int p0 = 0; p0 < n_poses; p0 += 65535 )
   {

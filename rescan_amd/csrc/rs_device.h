@@ -15,7 +15,8 @@ struct GridView
   const float4*   nor;          // may be null
   const uint32_t* cell_start;   // w*h*d + 1 entries
   float minx, miny, minz;       // grid origin
-  float inv_cell;               // 1 / cell edge
+  float inv_cell;               // 1 / cell edge (0 for the one-cell brute layout)
+  float cell;                   // cell edge
   int   w, h, d;
   int   n;
 };
@@ -66,6 +67,10 @@ struct IcpLaunch
   double* mom_part;   // n_prob x n_mom_blocks x ICP_NMOM
   double* moments;    // n_prob x ICP_NMOM
   int     n_mom_blocks;
+  int*    queue;        // n_prob x n_tiles : tiles handed to the cooperative kernel
+  int*    queue_count;  // n_prob
+  int     solo_stages;  // candidates a lone wave streams before handing an unsettled tile off
+  unsigned long long* dbg;   // diagnostic builds only: per-tile {cycles, candidates} of phase A (null otherwise)
   const float* w_explicit;   // if non-null: weights given per query (estimate-only entry point)
 };
 void launch_icp_corr( const IcpLaunch& L, hipStream_t st );
@@ -83,6 +88,9 @@ struct ScoreLaunch
   double       sigma;      // (double)radius
   double*      part;       // n_poses x n_tiles
   float*       scores;     // n_poses
+  int*         queue;      // n_poses x n_tiles items (pose*n_tiles + tile) for the cooperative kernel
+  int*         queue_count;
+  int          solo_stages;
 };
 void launch_score( const ScoreLaunch& L, hipStream_t st );
 

@@ -118,9 +118,11 @@ size_t msh_hash_grid_radius_search( const rsd_hash_grid_t* hg, rsd_search_desc_t
 float icp_align( rsd_vec3_t* pts1, rsd_vec3_t* nor1, int32_t n_pts1, rsd_vec3_t* pts2, rsd_vec3_t* nor2, int32_t n_pts2,
                  rsd_mat4_t* T1, rsd_mat4_t T2, float max_dist, float max_angle, bool verbose )
 {
-  // the reference builds its grids with radius = max_dist (icp.h:436-437) -> cell 2*max_dist
-  rs_hip_cloud_t* src = cached_cloud( pts1, nor1, n_pts1, 2.0f * max_dist );
-  rs_hip_cloud_t* tgt = cached_cloud( pts2, nor2, n_pts2, 2.0f * max_dist );
+  // the reference builds its grids with radius = max_dist (icp.h:436-437); the cell size does not
+  // change results here, so the clouds use the density-derived cell (fastest, and shared with the
+  // score / label entry points through the cache)
+  rs_hip_cloud_t* src = cached_cloud( pts1, nor1, n_pts1, -1.0f );
+  rs_hip_cloud_t* tgt = cached_cloud( pts2, nor2, n_pts2, -1.0f );
   float err = 1e6f; int32_t iters = 0;
   if( !src || !tgt ) return err;
   rsd_mat4_t t = *T1;
@@ -160,9 +162,9 @@ void icp_find_corrs( rsd_vec3_t* pts1, rsd_vec3_t* nor1, int32_t n_pts1, rsd_has
   *corr_nor2 = (rsd_vec3_t*)malloc( cap * sizeof(rsd_vec3_t) );
   *weights   = (float*)malloc( cap * sizeof(float) );
   *n_corrs = 0;
-  float cell = ( idx2 && idx2->cell_size > 0.0 ) ? (float)idx2->cell_size : 2.0f * max_dist;
-  rs_hip_cloud_t* src = cached_cloud( pts1, nor1, n_pts1, cell );
-  rs_hip_cloud_t* tgt = cached_cloud( pts2, nor2, n_pts2, cell );
+  (void)idx2;
+  rs_hip_cloud_t* src = cached_cloud( pts1, nor1, n_pts1, -1.0f );
+  rs_hip_cloud_t* tgt = cached_cloud( pts2, nor2, n_pts2, -1.0f );
   if( !src || !tgt ) return;
   if( rs_hip_icp_find_corrs( src, tgt, T1.data, T2.data, max_dist, max_angle, (float*)*corr_pts1, (float*)*corr_nor1,
                              (float*)*corr_pts2, (float*)*corr_nor2, *weights, n_corrs ) )
@@ -175,9 +177,9 @@ int rsd_alignment_scores( const rsd_vec3_t* obj_pos, const rsd_vec3_t* obj_nor, 
                           const rsd_vec3_t* scn_pos, const rsd_vec3_t* scn_nor, int32_t n_scn,
                           const rsd_mat4_t* xforms, int32_t n_poses, float search_radius, int32_t max_n_neigh, float* scores )
 {
-  // scene level grids use radius 0.05 -> cell 0.10 (lib/rs/rs_pointcloud.h:862)
-  rs_hip_cloud_t* obj = cached_cloud( obj_pos, obj_nor, n_obj, 0.1f );
-  rs_hip_cloud_t* scn = cached_cloud( scn_pos, scn_nor, n_scn, 0.1f );
+  // (the reference's level grids use radius 0.05 -> cell 0.10, lib/rs/rs_pointcloud.h:862)
+  rs_hip_cloud_t* obj = cached_cloud( obj_pos, obj_nor, n_obj, -1.0f );
+  rs_hip_cloud_t* scn = cached_cloud( scn_pos, scn_nor, n_scn, -1.0f );
   if( !obj || !scn ) return RS_HIP_E_RUNTIME;
   int rc = rs_hip_alignment_scores( obj, scn, (const float*)xforms, n_poses, search_radius, max_n_neigh, scores );
   if( rc ) complain( "alignment_scores" );
@@ -198,12 +200,12 @@ int rsd_arrangement_to_labels( const rsd_vec3_t* scn_pos, const rsd_vec3_t* scn_
                                const rsd_mat4_t* poses, const int32_t* is_static, const int32_t* class_idx, int32_t n_plc,
                                float radius, bool prioritize_static, int8_t* labels, int32_t* sorted_order )
 {
-  rs_hip_cloud_t* scn = cached_cloud( scn_pos, scn_nor, n_scn, 0.1f );
+  rs_hip_cloud_t* scn = cached_cloud( scn_pos, scn_nor, n_scn, -1.0f );
   if( !scn ) return RS_HIP_E_RUNTIME;
   std::vector<const rs_hip_cloud_t*> objs( (size_t)( n_plc > 0 ? n_plc : 0 ) );
   for( int i = 0; i < n_plc; ++i )
   {
-    objs[i] = cached_cloud( obj_pos[i], obj_nor[i], obj_n[i], 0.1f );
+    objs[i] = cached_cloud( obj_pos[i], obj_nor[i], obj_n[i], -1.0f );
     if( !objs[i] ) return RS_HIP_E_RUNTIME;
   }
   std::vector<float> min_dists( (size_t)( n_scn > 0 ? n_scn : 0 ) );

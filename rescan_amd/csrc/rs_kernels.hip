@@ -1,15 +1,24 @@
 // librescan_hip device code — written for gfx950 (MI355X, wave64) only.
 //
 // One primitive underlies all three consumers of the reference's
-// msh_hash_grid_radius_search (lib/msh/msh_hash_grid.h:1090-1259): a WAVE of 64 spatially
-// adjacent query points sweeps the grid cells overlapping its bounding box (+radius).
-// Candidate points of those cells stream HBM/L2 -> LDS in 64-record chunks (one coalesced
-// 1 KiB global load per wave), and every lane tests the same candidate at the same time
-// through an LDS broadcast read (ds_read_b128, all lanes one address: conflict-free).
-// The four waves of a workgroup share ONE tile of 64 queries and split its candidate chunks
-// round-robin, so the time of the heaviest tile (cluttered corners hold ~6x the average
-// candidate count) is cut by four; they meet once, at the end, to merge their per-lane
-// results through LDS.  Inside the sweep waves never synchronise with each other.
+// msh_hash_grid_radius_search (lib/msh/msh_hash_grid.h:1090-1259): a WAVE owns a tile of up to
+// 64 spatially adjacent query points (Hilbert order, rs_api.hip) and searches the grid cells
+// around the tile's bounding box in EXPANDING SHELLS:
+//
+//   stage 1 sweeps the cells overlapping the box grown by one cell, stage 2 the shell out to
+//   two cells, then four, ... up to the box grown by the search radius.  After a stage a lane
+//   is finished when its best match lies closer than the nearest face of the swept box that
+//   can still grow (nothing unseen can precede it), and the wave stops when all its lanes
+//   are.  For nearly aligned clouds almost every tile stops after the first stage, i.e. it
+//   tests a few hundred candidates instead of everything within the radius.
+//
+// The row pieces of a shell (one or two x-intervals per (y,z) row of cells, each a contiguous
+// span of the cell-sorted cloud) are gathered by the lanes in parallel, prefix-summed, and
+// consumed as ONE flattened stream: every lane fetches "candidate number j" of the stream
+// (binary search over the piece offsets), so each 64-record chunk staged in LDS is full.
+// All lanes then test the same candidate at the same time through an LDS broadcast read
+// (ds_read_b128, one address for the whole wave: conflict-free).  Waves never synchronise with
+// each other; there is no workgroup barrier on the search path.
 //
 // Arithmetic that decides *which* neighbour wins is kept in the reference's own order and
 // precision (the file is compiled with -ffp-contract=off):
@@ -17,7 +26,7 @@
 //   in-range test dist² < (float)((double)r*(double)r)          (msh_hash_grid.h:857,1111)
 //   transforms m0*x + m4*y + m8*z + w*m12                       (msh_vec_math.h:1554-1561)
 // Neighbour order is (dist², original index) — the reference's order among exactly equal
-// distances is an accident of its quicksort/heap and is not reproduced (DESIGN.md §ties).
+// distances is an accident of its quicksort/heap and is not reproduced (DESIGN.md §4).
 //
 // The reference keeps the K nearest in a heap and lets each consumer walk them in
 // ascending order until a normal gate passes.  That is restated as: c = the nearest
@@ -33,7 +42,6 @@ namespace rs {
 #define WAVE 64
 #define BLOCK 256
 #define WAVES_PER_BLOCK (BLOCK / WAVE)
-#define TW WAVES_PER_BLOCK   // waves cooperating on one tile
 
 // ------------------------------------------------------------------------------------------
 // helpers
@@ -65,6 +73,12 @@ __device__ __forceinline__ double wave_sum( double v ) {
   for( int o = 32; o > 0; o >>= 1 ) v += __shfl_xor( v, o );
   return v;
 }
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ uint32_t wave_scan( uint32_t v, int lane ) {
+#pragma unroll
+  for( int o = 1; o < WAVE; o <<= 1 ) { uint32_t t = __shfl_up( v, o ); if( lane >= o ) v += t; }
+  return v;
+}
 
 // msh_mat4_vec3_mul (msh_vec_math.h:1554-1561); w = 1 for points, 0 for directions.
 __device__ __forceinline__ void xform3( const Xform& M, float x, float y, float z, float w,
@@ -75,9 +89,26 @@ __device__ __forceinline__ void xform3( const Xform& M, float x, float y, float 
   oz = M.m[2] * x + M.m[6] * y + M.m[10] * z + w * M.m[14];
 }
 
+// (dist², index) lexicographic "a before b"
+__device__ __forceinline__ bool lex_less( float d2a, int ia, float d2b, int ib )
+{
+  return ( d2a < d2b ) | ( ( d2a == d2b ) & ( ia < ib ) );
+}
+
+// ------------------------------------------------------------------------------------------
+// cell boxes
+// ------------------------------------------------------------------------------------------
+
+struct CellBox { int x0, x1, y0, y1, z0, z1; };
+
+__device__ __forceinline__ bool box_empty( const CellBox& b ) { return ( b.x1 < b.x0 ) | ( b.y1 < b.y0 ) | ( b.z1 < b.z0 ); }
+__device__ __forceinline__ bool box_same( const CellBox& a, const CellBox& b )
+{ return a.x0 == b.x0 && a.x1 == b.x1 && a.y0 == b.y0 && a.y1 == b.y1 && a.z0 == b.z0 && a.z1 == b.z1; }
+
 // Cells of one axis that can hold a point within `r` of the interval [lo,hi].  Binning of
-// the stored points (host, rs_api.hip) and this range use the same float expression; the
-// 0.01-cell margin is far above the rounding error of either, so the range is a superset.
+// the stored points (host, rs_api.hip: cell_of) and this range use the same float
+// expression; the 0.01-cell margin is far above the rounding error of either, so the range
+// is a superset.
 __device__ __forceinline__ void axis_range( float lo, float hi, float r, float gmin, float inv_cell, int dim,
                                             int& c0, int& c1 )
 {
@@ -89,165 +120,335 @@ __device__ __forceinline__ void axis_range( float lo, float hi, float r, float g
   c1 = ( b >= a ) ? (int)b : -1;      // empty -> c1 < c0
 }
 
-struct CellBox { int x0, x1, y0, y1, z0, z1; bool empty; };
+struct TileBounds { float lx, hx, ly, hy, lz, hz; bool any; };
 
-// Bounding box of the wave's (active) queries -> cell box of grid g, wave-uniform.
-__device__ __forceinline__ CellBox wave_cell_box( const GridView& g, bool active, float qx, float qy, float qz, float r )
+__device__ __forceinline__ TileBounds wave_bounds( bool active, float qx, float qy, float qz )
 {
   const float big = FLT_MAX;
-  float lx = wave_min( active ? qx : big ),  hx = wave_max( active ? qx : -big );
-  float ly = wave_min( active ? qy : big ),  hy = wave_max( active ? qy : -big );
-  float lz = wave_min( active ? qz : big ),  hz = wave_max( active ? qz : -big );
+  TileBounds t;
+  t.lx = wave_min( active ? qx : big );  t.hx = wave_max( active ? qx : -big );
+  t.ly = wave_min( active ? qy : big );  t.hy = wave_max( active ? qy : -big );
+  t.lz = wave_min( active ? qz : big );  t.hz = wave_max( active ? qz : -big );
+  t.any = t.hx >= t.lx;
+  return t;
+}
+
+__device__ __forceinline__ CellBox cell_box( const GridView& g, const TileBounds& t, float r )
+{
   CellBox b;
-  axis_range( lx, hx, r, g.minx, g.inv_cell, g.w, b.x0, b.x1 );
-  axis_range( ly, hy, r, g.miny, g.inv_cell, g.h, b.y0, b.y1 );
-  axis_range( lz, hz, r, g.minz, g.inv_cell, g.d, b.z0, b.z1 );
+  axis_range( t.lx, t.hx, r, g.minx, g.inv_cell, g.w, b.x0, b.x1 );
+  axis_range( t.ly, t.hy, r, g.miny, g.inv_cell, g.h, b.y0, b.y1 );
+  axis_range( t.lz, t.hz, r, g.minz, g.inv_cell, g.d, b.z0, b.z1 );
   b.x0 = uni( b.x0 ); b.x1 = uni( b.x1 ); b.y0 = uni( b.y0 ); b.y1 = uni( b.y1 ); b.z0 = uni( b.z0 ); b.z1 = uni( b.z1 );
-  b.empty = ( b.x1 < b.x0 ) || ( b.y1 < b.y0 ) || ( b.z1 < b.z0 ) || !( hx >= lx );
   return b;
 }
 
-// Stream every candidate of the cell box through this wave's LDS slice and call
-// f( P, j, slot ) for each: P = {x,y,z,bitcast(index)}, j = position inside the chunk (so
-// the matching normal is sn[j]), slot = position in the sorted cloud.  j and slot are
-// wave-uniform.  A chunk is always processed as 64 slots rounded up to a multiple of 4:
-// lanes beyond the span store a sentinel at +FLT_MAX whose dist² is +inf, so it can never be
-// "within the radius" and the inner loop needs no remainder handling (f may be called with
-// such sentinels; slot is then >= the span end and must only be used when P qualified).
-// Of the chunks met in sweep order, a wave takes those with (chunk number % n_share) == share.
-template <bool WITH_NOR, class F>
-__device__ __forceinline__ void sweep_box( const GridView& g, const CellBox& b, float4* sp, float4* sn, int lane,
-                                           int share, int n_share, F&& f )
+// core grown by k cells on every side, clipped to full
+__device__ __forceinline__ CellBox box_grow( const CellBox& core, int k, const CellBox& full )
 {
-  int chunk = 0;
-  for( int z = b.z0; z <= b.z1; ++z )
-  {
-    for( int y = b.y0; y <= b.y1; ++y )
-    {
-      const int row = ( z * g.h + y ) * g.w;
-      const uint32_t s = (uint32_t)uni( (int)g.cell_start[row + b.x0] );
-      const uint32_t e = (uint32_t)uni( (int)g.cell_start[row + b.x1 + 1] );
-      for( uint32_t c0 = s; c0 < e; c0 += WAVE )
-      {
-        if( ( chunk++ % n_share ) != share ) continue;
-        const uint32_t cnt = ( e - c0 < WAVE ) ? ( e - c0 ) : WAVE;
-        float4 P = make_float4( FLT_MAX, FLT_MAX, FLT_MAX, 0.0f ), N = make_float4( 0.0f, 0.0f, 0.0f, 0.0f );
-        if( (uint32_t)lane < cnt )
-        {
-          P = g.pos[c0 + lane];
-          if( WITH_NOR ) N = g.nor[c0 + lane];
-        }
-        sp[lane] = P;
-        if( WITH_NOR ) sn[lane] = N;
-        wave_lds_fence();
-        const uint32_t cnt4 = ( cnt + 3u ) & ~3u;
-        for( uint32_t j = 0; j < cnt4; j += 4 )
-        {
-          const float4 P0 = sp[j], P1 = sp[j + 1], P2 = sp[j + 2], P3 = sp[j + 3];
-          f( P0, (int)j, (int)( c0 + j ) );
-          f( P1, (int)j + 1, (int)( c0 + j + 1 ) );
-          f( P2, (int)j + 2, (int)( c0 + j + 2 ) );
-          f( P3, (int)j + 3, (int)( c0 + j + 3 ) );
-        }
-        wave_lds_fence();
-      }
-    }
-  }
+  CellBox b;
+  b.x0 = max( core.x0 - k, full.x0 ); b.x1 = min( core.x1 + k, full.x1 );
+  b.y0 = max( core.y0 - k, full.y0 ); b.y1 = min( core.y1 + k, full.y1 );
+  b.z0 = max( core.z0 - k, full.z0 ); b.z1 = min( core.z1 + k, full.z1 );
+  return b;
 }
 
-// (dist², index) lexicographic "a before b"
-__device__ __forceinline__ bool lex_less( float d2a, int ia, float d2b, int ib )
+// Distance from q to the nearest face of `cur` that can still move outward (a face already at
+// `full` never hides a point within the radius).  Made conservative by a margin far above the
+// rounding of the face coordinates and of the binning.
+__device__ __forceinline__ float box_cover( const GridView& g, const CellBox& cur, const CellBox& full,
+                                            float qx, float qy, float qz )
 {
-  return ( d2a < d2b ) || ( d2a == d2b && ia < ib );
+  float c = FLT_MAX;
+  if( cur.x0 > full.x0 ) c = fminf( c, qx - ( g.minx + (float)cur.x0 * g.cell ) );
+  if( cur.x1 < full.x1 ) c = fminf( c, ( g.minx + (float)( cur.x1 + 1 ) * g.cell ) - qx );
+  if( cur.y0 > full.y0 ) c = fminf( c, qy - ( g.miny + (float)cur.y0 * g.cell ) );
+  if( cur.y1 < full.y1 ) c = fminf( c, ( g.miny + (float)( cur.y1 + 1 ) * g.cell ) - qy );
+  if( cur.z0 > full.z0 ) c = fminf( c, qz - ( g.minz + (float)cur.z0 * g.cell ) );
+  if( cur.z1 < full.z1 ) c = fminf( c, ( g.minz + (float)( cur.z1 + 1 ) * g.cell ) - qz );
+  return c - ( 1e-4f * g.cell + 2e-5f );
 }
 
-// Result of a gated search for one query.
-struct Match { float d2; int idx; float dot; int slot; bool found; };
+// ------------------------------------------------------------------------------------------
+// shell sweep
+// ------------------------------------------------------------------------------------------
 
-// Per-workgroup LDS: candidate staging of each wave + the per-lane merge slots.
-struct TileLds
+// Per-wave LDS.
+struct WaveLds
 {
-  float4 pos[TW][WAVE];
-  float4 nor[TW][WAVE];
-  float  m_d2[TW][WAVE];
-  int    m_idx[TW][WAVE];
-  float  m_dot[TW][WAVE];
-  int    m_slot[TW][WAVE];
-  int    m_cnt[TW][WAVE];
+  float4   pos[WAVE];      // staged candidates {x,y,z,bitcast(orig index)}
+  float4   nor[WAVE];      // their normals {nx,ny,nz,-}
+  uint32_t slot[WAVE];     // their positions in the cell-sorted cloud
+  uint32_t seg_a[WAVE], len_a[WAVE], seg_b[WAVE], pre[WAVE];   // row pieces of the current batch
 };
 
-// Nearest candidate within the radius whose normal passes  tmin <= max(dot,0) <= 1, accepted
-// only if fewer than K candidates (of any normal) precede it in (dist², index) order.
-// That is the reference's "first normal-compatible entry of the K-nearest list"
+// Stream every point of (out \ in) through the wave's LDS and call f( P, j ) for each;
+// `in` (if in_valid) must be a sub-box of `out`.  P = {x,y,z,bitcast(index)}, j = position in
+// the staged chunk (L.nor[j] / L.slot[j] belong to it); j is wave-uniform.  Chunks are padded
+// to a multiple of 4 with sentinels at +FLT_MAX whose dist² is +inf: they can never be
+// "within the radius", so f needs no validity test.
+// When several waves sweep the same shell together, wave `share` of `n_share` takes the chunks
+// whose running number is congruent to it.
+template <bool WITH_NOR, class F>
+__device__ __forceinline__ uint32_t sweep_shell( const GridView& g, const CellBox& out, const CellBox& in, bool in_valid,
+                                                 WaveLds& L, int lane, int share, int n_share, F&& f )
+{
+  const int ny = out.y1 - out.y0 + 1, nz = out.z1 - out.z0 + 1;
+  const int n_rows = ny * nz;
+  uint32_t streamed = 0;
+  for( int r0 = 0; r0 < n_rows; r0 += WAVE )
+  {
+    // each lane describes one (y,z) row of cells: up to two x-pieces
+    const int r = r0 + lane;
+    uint32_t sa = 0, la = 0, sb = 0, lb = 0;
+    if( r < n_rows )
+    {
+      const int y = out.y0 + r % ny, z = out.z0 + r / ny;
+      const uint32_t* cs = g.cell_start + (size_t)( z * g.h + y ) * g.w;
+      const bool inside = in_valid && y >= in.y0 && y <= in.y1 && z >= in.z0 && z <= in.z1;
+      if( !inside ) { sa = cs[out.x0]; la = cs[out.x1 + 1] - sa; }
+      else
+      {
+        if( in.x0 > out.x0 ) { sa = cs[out.x0]; la = cs[in.x0] - sa; }
+        if( out.x1 > in.x1 ) { sb = cs[in.x1 + 1]; lb = cs[out.x1 + 1] - sb; }
+      }
+    }
+    const uint32_t incl = wave_scan( la + lb, lane );
+    const uint32_t total = (uint32_t)uni( (int)__shfl( incl, WAVE - 1 ) );
+    L.seg_a[lane] = sa; L.len_a[lane] = la; L.seg_b[lane] = sb; L.pre[lane] = incl - ( la + lb );
+    streamed += total;
+    wave_lds_fence();
+
+    // This wave's chunks of the batch: share, share + n_share, ...  The global loads of chunk
+    // c+1 are issued before chunk c is evaluated, so their latency hides under the evaluation.
+    auto fetch = [&]( uint32_t c0, float4& P, float4& N, uint32_t& src )
+    {
+      const uint32_t j = c0 + lane;
+      P = make_float4( FLT_MAX, FLT_MAX, FLT_MAX, 0.0f ); N = make_float4( 0.0f, 0.0f, 0.0f, 0.0f ); src = 0;
+      if( j < total )
+      {
+        int row = 0;                                   // last row whose first candidate number is <= j
+#pragma unroll
+        for( int step = WAVE / 2; step > 0; step >>= 1 ) { if( L.pre[row + step] <= j ) row += step; }
+        const uint32_t off = j - L.pre[row];
+        const uint32_t la_r = L.len_a[row];
+        src = ( off < la_r ) ? ( L.seg_a[row] + off ) : ( L.seg_b[row] + ( off - la_r ) );
+        P = g.pos[src];
+        if( WITH_NOR ) N = g.nor[src];
+      }
+    };
+    const uint32_t stride = (uint32_t)n_share * WAVE;
+    uint32_t c0 = (uint32_t)share * WAVE;
+    float4 P, N; uint32_t src;
+    if( c0 < total ) fetch( c0, P, N, src );
+    while( c0 < total )
+    {
+      L.pos[lane] = P;
+      if( WITH_NOR ) L.nor[lane] = N;
+      L.slot[lane] = src;
+      wave_lds_fence();
+      const uint32_t cn = c0 + stride;
+      if( cn < total ) fetch( cn, P, N, src );         // in flight during the loop below
+      const uint32_t cnt = ( total - c0 < WAVE ) ? ( total - c0 ) : WAVE;
+      const uint32_t cnt4 = ( cnt + 3u ) & ~3u;
+#pragma unroll 1
+      for( uint32_t k = 0; k < cnt4; k += 4 )
+      {
+        const float4 P0 = L.pos[k], P1 = L.pos[k + 1], P2 = L.pos[k + 2], P3 = L.pos[k + 3];
+        f( P0, (int)k ); f( P1, (int)k + 1 ); f( P2, (int)k + 2 ); f( P3, (int)k + 3 );
+      }
+      wave_lds_fence();
+      c0 = cn;
+    }
+    wave_lds_fence();
+  }
+  return streamed;
+}
+
+// Result of a search for one query.
+struct Match { float d2; int idx; float dot; int slot; bool found; };
+
+// The per-candidate step shared by all searches: update the best match `m` of this lane.
+// Returns through seen_closer the count of candidates that were no farther than the best so far.
+template <bool GATED>
+__device__ __forceinline__ void consider( float4 P, int j, const WaveLds& L, bool active,
+                                          float qx, float qy, float qz, float nx, float ny, float nz,
+                                          float radius_sq, float tmin, Match& m, int& seen_closer )
+{
+  float vx = P.x - qx, vy = P.y - qy, vz = P.z - qz;
+  float d2 = vx * vx + vy * vy + vz * vz;
+  // cheap superset of "precedes the best so far": ties are settled inside the rare branch
+  const bool maybe = active & ( d2 < radius_sq ) & ( d2 <= m.d2 );
+  seen_closer += maybe ? 1 : 0;
+  if( __any( maybe ) )
+  {
+    const int idx = __float_as_int( P.w );
+    bool take = maybe & lex_less( d2, idx, m.d2, m.idx );
+    float dc = 0.0f;
+    if( GATED )
+    {
+      float4 N = L.nor[j];
+      float dot = N.x * nx + N.y * ny + N.z * nz;       // msh_vec3_dot( m, n )
+      dc = dot > 0.0f ? dot : 0.0f;                     // msh_max( dot, 0.0f )
+      take = take & ( dc >= tmin ) & ( dc <= 1.0f );
+    }
+    if( take ) { m.d2 = d2; m.idx = idx; m.dot = dc; m.slot = (int)L.slot[j]; m.found = true; }
+  }
+}
+
+// Nearest candidate within the radius [whose normal passes tmin <= max(dot,0) <= 1, if GATED],
+// accepted only if fewer than K candidates (of any normal) precede it in (dist², index) order.
+// GATED: the reference's "first normal-compatible entry of the K-nearest list"
 // (lib/rs/icp.h:361-380, apps/pose_proposal/pose_proposal.cpp:127-147).
-// All TW waves of the workgroup call this with the SAME queries; each sweeps its share of the
-// candidate chunks and all return the same merged result.
-__device__ __forceinline__ Match gated_search( const GridView& g, bool active,
-                                               float qx, float qy, float qz, float nx, float ny, float nz,
-                                               float radius, float radius_sq, float tmin, int K,
-                                               TileLds& lds, int wib, int lane )
+// !GATED (K = 1): the plain nearest neighbour of rs_pointcloud_filters.cpp:758.
+//
+// `max_stages` (historical name) is the hand-off threshold: a tile that is still unsettled
+// after its lone wave has streamed that many candidates sits in a populated neighbourhood, so
+// the rest of its box is heavy; *handoff is set, the result is meaningless, and the caller
+// queues the tile for the cooperative kernel, which sweeps the whole box with several waves
+// (a lone wave needs ~0.7 ms for the ~10^4 candidates of a cluttered corner; the bulk of the
+// tiles settle in the first shell with a few hundred).
+template <bool GATED>
+__device__ __forceinline__ Match tile_search( const GridView& g, bool active,
+                                              float qx, float qy, float qz, float nx, float ny, float nz,
+                                              float radius, float radius_sq, float tmin, int K,
+                                              WaveLds& L, int lane, int max_stages, bool* handoff, int* dbg_unsettled = nullptr )
 {
   Match m; m.d2 = INFINITY; m.idx = INT_MAX; m.dot = 0.0f; m.slot = -1; m.found = false;
-  CellBox box = wave_cell_box( g, active, qx, qy, qz, radius );
-  if( box.empty ) return m;                       // identical in every wave of the workgroup
+  if( handoff ) *handoff = false;
+  const TileBounds tb = wave_bounds( active, qx, qy, qz );
+  if( !tb.any ) return m;
+  const CellBox full = cell_box( g, tb, radius );
+  if( box_empty( full ) ) return m;
+  CellBox core = cell_box( g, tb, 0.0f );
+  core = box_grow( core, 0, full );
+  if( box_empty( core ) ) core = full;             // the tile lies outside the grid but within reach of it
 
-  int seen_closer = 0;   // candidates that were no farther than this wave's best-so-far when met
-  sweep_box<true>( g, box, lds.pos[wib], lds.nor[wib], lane, wib, TW, [&]( float4 P, int j, int slot )
+  int seen_closer = 0;   // candidates that were no farther than the best-so-far when they were met
+  CellBox cur = core, prev = core;
+  bool have_prev = false;
+  uint32_t streamed = 0;
+  for( int k = 1; ; k *= 2 )
   {
-    float vx = P.x - qx, vy = P.y - qy, vz = P.z - qz;
-    float d2 = vx * vx + vy * vy + vz * vz;
-    // cheap superset of "precedes the best so far": ties are settled inside the rare branch
-    const bool maybe = active & ( d2 < radius_sq ) & ( d2 <= m.d2 );
-    seen_closer += maybe ? 1 : 0;
-    if( __any( maybe ) )
+    cur = ( g.inv_cell > 0.0f ) ? box_grow( core, k, full ) : full;
+    streamed += sweep_shell<GATED>( g, cur, prev, have_prev, L, lane, 0, 1, [&]( float4 P, int j )
+    { consider<GATED>( P, j, L, active, qx, qy, qz, nx, ny, nz, radius_sq, tmin, m, seen_closer ); } );
+    if( box_same( cur, full ) ) break;
+    // a lane is settled when nothing outside `cur` can precede its match (or reach it at all)
+    const float cov = box_cover( g, cur, full, qx, qy, qz );
+    const bool settled = !active | ( cov >= radius ) | ( m.found & ( cov > 0.0f ) & ( m.d2 < cov * cov ) );
+    if( dbg_unsettled && k == 1 ) *dbg_unsettled = __popcll( __ballot( !settled ) );
+    if( !__any( !settled ) ) break;
+    // Unsettled in a populated neighbourhood: the rest of the box is heavy, let a whole workgroup do it.
+    if( handoff && streamed >= (uint32_t)max_stages ) { *handoff = true; return m; }
+    prev = cur; have_prev = true;
+  }
+
+  if( K > 1 || GATED )
+  {
+    // Every candidate that precedes the final match was counted in seen_closer (it was no
+    // farther than the then-best, which the final match precedes or equals), and so was the
+    // match itself: seen_closer - 1 >= rank.  Only when that bound does not settle rank < K,
+    // count exactly (every such candidate lies inside `cur`: it is closer than the match).
+    bool need_rank = m.found && ( seen_closer - 1 >= K );
+    if( __any( need_rank ) )
     {
-      const int idx = __float_as_int( P.w );
-      float4 N = lds.nor[wib][j];
-      float dot = N.x * nx + N.y * ny + N.z * nz;         // msh_vec3_dot( m, n )
-      float dc = dot > 0.0f ? dot : 0.0f;                 // msh_max( dot, 0.0f )
-      if( maybe && lex_less( d2, idx, m.d2, m.idx ) && dc >= tmin && dc <= 1.0f )
-      { m.d2 = d2; m.idx = idx; m.dot = dc; m.slot = slot; m.found = true; }
+      int rank = 0;
+      sweep_shell<false>( g, cur, cur, false, L, lane, 0, 1, [&]( float4 P, int )
+      {
+        float vx = P.x - qx, vy = P.y - qy, vz = P.z - qz;
+        float d2 = vx * vx + vy * vy + vz * vz;
+        int idx = __float_as_int( P.w );
+        rank += ( need_rank & ( d2 < radius_sq ) & lex_less( d2, idx, m.d2, m.idx ) ) ? 1 : 0;
+      } );
+      if( need_rank && rank >= K ) { m.found = false; m.slot = -1; }
     }
-  } );
-
-  // merge the TW partial results of each lane
-  lds.m_d2[wib][lane] = m.d2; lds.m_idx[wib][lane] = m.idx; lds.m_dot[wib][lane] = m.dot;
-  lds.m_slot[wib][lane] = m.found ? m.slot : -1; lds.m_cnt[wib][lane] = seen_closer;
-  __syncthreads();
-  int seen_total = 0;
-  m.d2 = INFINITY; m.idx = INT_MAX; m.dot = 0.0f; m.slot = -1; m.found = false;
-#pragma unroll
-  for( int w = 0; w < TW; ++w )
-  {
-    seen_total += lds.m_cnt[w][lane];
-    const float d = lds.m_d2[w][lane]; const int ix = lds.m_idx[w][lane]; const int sl = lds.m_slot[w][lane];
-    if( sl >= 0 && lex_less( d, ix, m.d2, m.idx ) ) { m.d2 = d; m.idx = ix; m.dot = lds.m_dot[w][lane]; m.slot = sl; m.found = true; }
   }
+  return m;
+}
 
-  // Every candidate that precedes the final match was counted by the wave that met it (it was
-  // no farther than that wave's then-best, which the final match precedes or equals), and so
-  // was the match itself: seen_total - 1 >= rank.  Only when that bound does not settle
-  // rank < K, count exactly.
-  bool need_rank = m.found && ( seen_total - 1 >= K );
-  if( __any( need_rank ) )                         // same decision in every wave (same data)
+// Merge slots of the cooperative search.
+struct CoopLds
+{
+  float m_d2[WAVES_PER_BLOCK][WAVE];
+  int   m_idx[WAVES_PER_BLOCK][WAVE];
+  float m_dot[WAVES_PER_BLOCK][WAVE];
+  int   m_slot[WAVES_PER_BLOCK][WAVE];
+  int   m_cnt[WAVES_PER_BLOCK][WAVE];
+};
+
+// The same staged search, done by all WAVES_PER_BLOCK waves of a workgroup for ONE tile: every
+// wave holds the same queries and sweeps its share of each shell's chunks; after every shell the
+// per-lane bests are merged through LDS, so all waves take the same continue/stop decision and
+// carry the tightest bound into the next shell.
+template <bool GATED>
+__device__ __forceinline__ Match coop_search( const GridView& g, bool active,
+                                              float qx, float qy, float qz, float nx, float ny, float nz,
+                                              float radius, float radius_sq, float tmin, int K,
+                                              WaveLds& L, CoopLds& C, int wib, int lane )
+{
+  Match m; m.d2 = INFINITY; m.idx = INT_MAX; m.dot = 0.0f; m.slot = -1; m.found = false;
+  const TileBounds tb = wave_bounds( active, qx, qy, qz );
+  if( !tb.any ) return m;                          // identical in every wave of the workgroup
+  const CellBox full = cell_box( g, tb, radius );
+  if( box_empty( full ) ) return m;
+  CellBox core = cell_box( g, tb, 0.0f );
+  core = box_grow( core, 0, full );
+  if( box_empty( core ) ) core = full;
+
+  int seen_closer = 0;
+  CellBox cur = core, prev = core;
+  bool have_prev = false;
+  for( int k = 1; ; k *= 2 )
   {
-    int rank = 0;
-    sweep_box<false>( g, box, lds.pos[wib], lds.nor[wib], lane, wib, TW, [&]( float4 P, int, int )
-    {
-      float vx = P.x - qx, vy = P.y - qy, vz = P.z - qz;
-      float d2 = vx * vx + vy * vy + vz * vz;
-      int idx = __float_as_int( P.w );
-      rank += ( need_rank & ( d2 < radius_sq ) & ( ( d2 < m.d2 ) | ( ( d2 == m.d2 ) & ( idx < m.idx ) ) ) ) ? 1 : 0;
-    } );
-    __syncthreads();                               // everyone is done reading the first merge
-    lds.m_cnt[wib][lane] = rank;
+    cur = ( g.inv_cell > 0.0f ) ? box_grow( core, k, full ) : full;
+    sweep_shell<GATED>( g, cur, prev, have_prev, L, lane, wib, WAVES_PER_BLOCK, [&]( float4 P, int j )
+    { consider<GATED>( P, j, L, active, qx, qy, qz, nx, ny, nz, radius_sq, tmin, m, seen_closer ); } );
+    // merge the per-lane bests of the waves; every wave continues with the merged best
+    C.m_d2[wib][lane] = m.d2; C.m_idx[wib][lane] = m.idx; C.m_dot[wib][lane] = m.dot; C.m_slot[wib][lane] = m.found ? m.slot : -1;
     __syncthreads();
-    rank = 0;
 #pragma unroll
-    for( int w = 0; w < TW; ++w ) rank += lds.m_cnt[w][lane];
-    if( need_rank && rank >= K ) { m.found = false; m.slot = -1; }
+    for( int w = 0; w < WAVES_PER_BLOCK; ++w )
+    {
+      const float d = C.m_d2[w][lane]; const int ix = C.m_idx[w][lane]; const int sl = C.m_slot[w][lane];
+      if( sl >= 0 && lex_less( d, ix, m.d2, m.idx ) ) { m.d2 = d; m.idx = ix; m.dot = C.m_dot[w][lane]; m.slot = sl; m.found = true; }
+    }
+    __syncthreads();
+    if( box_same( cur, full ) ) break;
+    const float cov = box_cover( g, cur, full, qx, qy, qz );
+    const bool settled = !active | ( cov >= radius ) | ( m.found & ( cov > 0.0f ) & ( m.d2 < cov * cov ) );
+    if( !__any( !settled ) ) break;                // same decision in every wave (same merged data)
+    prev = cur; have_prev = true;
   }
-  __syncthreads();                                 // merge slots may be reused by the caller's next search
+
+  if( K > 1 || GATED )
+  {
+    // each wave's count bounds the rank contribution of its own share (see tile_search)
+    C.m_cnt[wib][lane] = seen_closer;
+    __syncthreads();
+    int seen_total = 0;
+#pragma unroll
+    for( int w = 0; w < WAVES_PER_BLOCK; ++w ) seen_total += C.m_cnt[w][lane];
+    bool need_rank = m.found && ( seen_total - 1 >= K );
+    if( __any( need_rank ) )
+    {
+      int rank = 0;
+      sweep_shell<false>( g, cur, cur, false, L, lane, wib, WAVES_PER_BLOCK, [&]( float4 P, int )
+      {
+        float vx = P.x - qx, vy = P.y - qy, vz = P.z - qz;
+        float d2 = vx * vx + vy * vy + vz * vz;
+        int idx = __float_as_int( P.w );
+        rank += ( need_rank & ( d2 < radius_sq ) & lex_less( d2, idx, m.d2, m.idx ) ) ? 1 : 0;
+      } );
+      __syncthreads();                             // everyone is done reading the counts
+      C.m_cnt[wib][lane] = rank;
+      __syncthreads();
+      rank = 0;
+#pragma unroll
+      for( int w = 0; w < WAVES_PER_BLOCK; ++w ) rank += C.m_cnt[w][lane];
+      if( need_rank && rank >= K ) { m.found = false; m.slot = -1; }
+    }
+  }
   return m;
 }
 
@@ -255,23 +456,11 @@ __device__ __forceinline__ Match gated_search( const GridView& g, bool active,
 // ICP: correspondence search  (lib/rs/icp.h:339-391)
 // ------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__( BLOCK ) void k_icp_corr( IcpLaunch L )
+// Source point i of problem `prob` in the target's frame (icp.h:339-347).
+__device__ __forceinline__ void icp_query( const IcpLaunch& L, const Xform& T1, int i, bool active,
+                                           float& qx, float& qy, float& qz, float& nx, float& ny, float& nz )
 {
-  __shared__ TileLds lds;
-  const int prob = blockIdx.y;
-  if( L.active[prob] == 0 ) return;
-  const int lane = threadIdx.x & ( WAVE - 1 );
-  const int wib = threadIdx.x / WAVE;
-  const int tile = blockIdx.x;                           // one workgroup per tile
-  const int i = (int)L.src.tiles[tile] + lane;
-  const bool active = i < (int)L.src.tiles[tile + 1];
-  const int nq = L.src.n;
-
-  Xform T1;
-#pragma unroll
-  for( int k = 0; k < 16; ++k ) T1.m[k] = L.T1[prob * 16 + k];
-
-  float qx = 0, qy = 0, qz = 0, nx = 0, ny = 0, nz = 0;
+  qx = qy = qz = nx = ny = nz = 0.0f;
   if( active )
   {
     float4 p = L.src.pos[i], n = L.src.nor[i];
@@ -279,12 +468,12 @@ __global__ __launch_bounds__( BLOCK ) void k_icp_corr( IcpLaunch L )
     xform3( T1, p.x, p.y, p.z, 1.0f, tx, ty, tz );   xform3( L.T2i, tx, ty, tz, 1.0f, qx, qy, qz );
     xform3( T1, n.x, n.y, n.z, 0.0f, tx, ty, tz );   xform3( L.T2i, tx, ty, tz, 0.0f, nx, ny, nz );
   }
-  Match m = gated_search( L.tgt, active, qx, qy, qz, nx, ny, nz, L.radius, L.radius_sq, L.gate_tmin, L.K,
-                          lds, wib, lane );
-  if( wib != 0 ) return;                                 // every wave holds the merged result; wave 0 writes it
-  const size_t o = (size_t)prob * nq + i;
-  if( active ) { L.m_slot[o] = m.found ? m.slot : -1; L.m_d2[o] = m.d2; L.m_dot[o] = m.dot; }
+}
 
+__device__ __forceinline__ void icp_emit( const IcpLaunch& L, int prob, int tile, int i, bool active, int lane, const Match& m )
+{
+  const size_t o = (size_t)prob * L.src.n + i;
+  if( active ) { L.m_slot[o] = m.found ? m.slot : -1; L.m_d2[o] = m.d2; L.m_dot[o] = m.dot; }
   // statistics of dist² over correspondences (msh_compute_mean/stddev, msh_std.h:1800-1825)
   double c = ( active && m.found ) ? 1.0 : 0.0;
   double s1 = ( active && m.found ) ? (double)m.d2 : 0.0;
@@ -297,16 +486,75 @@ __global__ __launch_bounds__( BLOCK ) void k_icp_corr( IcpLaunch L )
   }
 }
 
-// One block per problem: fixed-order sum of the per-wave partials -> n_corr, mean, stddev.
+// Phase A: one wave per tile, first shell(s) only; unsettled tiles are queued.
+__global__ __launch_bounds__( BLOCK, 8 ) void k_icp_corr( IcpLaunch L )
+{
+  __shared__ WaveLds lds[WAVES_PER_BLOCK];
+  const int prob = blockIdx.y;
+  if( L.active[prob] == 0 ) return;
+  const int lane = threadIdx.x & ( WAVE - 1 );
+  const int wib = threadIdx.x / WAVE;
+  const int tile = blockIdx.x * WAVES_PER_BLOCK + wib;
+  if( tile >= L.src.n_tiles ) return;
+  const int i = (int)L.src.tiles[tile] + lane;
+  const bool active = i < (int)L.src.tiles[tile + 1];
+
+  Xform T1;
+#pragma unroll
+  for( int k = 0; k < 16; ++k ) T1.m[k] = __int_as_float( uni( __float_as_int( L.T1[prob * 16 + k] ) ) );
+  float qx, qy, qz, nx, ny, nz;
+  const unsigned long long t_begin = L.dbg ? wall_clock64() : 0ull;
+  icp_query( L, T1, i, active, qx, qy, qz, nx, ny, nz );
+  bool handoff;
+  int unsettled = 0;
+  Match m = tile_search<true>( L.tgt, active, qx, qy, qz, nx, ny, nz, L.radius, L.radius_sq, L.gate_tmin, L.K,
+                               lds[wib], lane, L.solo_stages, &handoff, L.dbg ? &unsettled : nullptr );
+  if( L.dbg && lane == 0 ) { L.dbg[2 * tile] = wall_clock64() - t_begin; L.dbg[2 * tile + 1] = (unsigned long long)unsettled; }
+  if( handoff )
+  {
+    if( lane == 0 ) { int q = atomicAdd( L.queue_count + prob, 1 ); L.queue[(size_t)prob * L.src.n_tiles + q] = tile; }
+    return;
+  }
+  icp_emit( L, prob, tile, i, active, lane, m );
+}
+
+// Phase B: one workgroup per queued tile, whole box, chunks shared by its waves.
+__global__ __launch_bounds__( BLOCK ) void k_icp_corr_coop( IcpLaunch L )
+{
+  __shared__ WaveLds lds[WAVES_PER_BLOCK];
+  __shared__ CoopLds coop;
+  const int prob = blockIdx.y;
+  if( L.active[prob] == 0 ) return;
+  const int lane = threadIdx.x & ( WAVE - 1 );
+  const int wib = threadIdx.x / WAVE;
+  const int n_queued = L.queue_count[prob];
+  Xform T1;
+#pragma unroll
+  for( int k = 0; k < 16; ++k ) T1.m[k] = L.T1[prob * 16 + k];
+  for( int b = blockIdx.x; b < n_queued; b += gridDim.x )
+  {
+    const int tile = L.queue[(size_t)prob * L.src.n_tiles + b];
+    const int i = (int)L.src.tiles[tile] + lane;
+    const bool active = i < (int)L.src.tiles[tile + 1];
+    float qx, qy, qz, nx, ny, nz;
+    icp_query( L, T1, i, active, qx, qy, qz, nx, ny, nz );
+    Match m = coop_search<true>( L.tgt, active, qx, qy, qz, nx, ny, nz, L.radius, L.radius_sq, L.gate_tmin, L.K,
+                                 lds[wib], coop, wib, lane );
+    if( wib == 0 ) icp_emit( L, prob, tile, i, active, lane, m );
+    __syncthreads();                               // merge slots are reused by the next queued tile
+  }
+}
+
+// One block per problem: fixed-order sum of the per-tile partials -> n_corr, mean, stddev.
 __global__ __launch_bounds__( BLOCK ) void k_icp_stats( IcpLaunch L )
 {
   __shared__ double red[3][BLOCK];
   const int prob = blockIdx.x;
   if( L.active[prob] == 0 ) return;
-  const int n_waves = L.src.n_tiles;
-  const double* in = L.corr_part + (size_t)prob * n_waves * 3;
+  const int n_tiles = L.src.n_tiles;
+  const double* in = L.corr_part + (size_t)prob * n_tiles * 3;
   double a = 0, b = 0, c = 0;
-  for( int w = threadIdx.x; w < n_waves; w += BLOCK ) { a += in[3*w]; b += in[3*w+1]; c += in[3*w+2]; }
+  for( int w = threadIdx.x; w < n_tiles; w += BLOCK ) { a += in[3*w]; b += in[3*w+1]; c += in[3*w+2]; }
   red[0][threadIdx.x] = a; red[1][threadIdx.x] = b; red[2][threadIdx.x] = c;
   __syncthreads();
   for( int s = BLOCK / 2; s > 0; s >>= 1 )
@@ -419,8 +667,12 @@ __global__ __launch_bounds__( BLOCK ) void k_icp_moments_final( IcpLaunch L )
 
 void launch_icp_corr( const IcpLaunch& L, hipStream_t st )
 {
-  dim3 grid( L.src.n_tiles, L.n_prob );
+  (void)hipMemsetAsync( L.queue_count, 0, (size_t)L.n_prob * sizeof(int), st );
+  dim3 grid( ( L.src.n_tiles + WAVES_PER_BLOCK - 1 ) / WAVES_PER_BLOCK, L.n_prob );
   hipLaunchKernelGGL( k_icp_corr, grid, dim3( BLOCK ), 0, st, L );
+  // the queue length is only known on the device: a fixed grid strides over it
+  int coop_blocks = L.src.n_tiles < 2048 ? L.src.n_tiles : 2048;
+  hipLaunchKernelGGL( k_icp_corr_coop, dim3( coop_blocks > 0 ? coop_blocks : 1, L.n_prob ), dim3( BLOCK ), 0, st, L );
 }
 void launch_icp_stats( const IcpLaunch& L, hipStream_t st )
 {
@@ -436,31 +688,20 @@ void launch_icp_moments( const IcpLaunch& L, hipStream_t st )
 // Alignment score  (apps/pose_proposal/pose_proposal.cpp:93-158), all poses in one launch
 // ------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__( BLOCK ) void k_score( ScoreLaunch L )
+__device__ __forceinline__ void score_query( const ScoreLaunch& L, const Xform& X, int i, bool active,
+                                             float& qx, float& qy, float& qz, float& nx, float& ny, float& nz )
 {
-  __shared__ TileLds lds;
-  const int pose = blockIdx.y;
-  const int lane = threadIdx.x & ( WAVE - 1 );
-  const int wib = threadIdx.x / WAVE;
-  const int tile = blockIdx.x;
-  const int n_tiles = L.obj.n_tiles;
-  const int i = (int)L.obj.tiles[tile] + lane;
-  const bool active = i < (int)L.obj.tiles[tile + 1];
-
-  Xform X;
-#pragma unroll
-  for( int k = 0; k < 16; ++k ) X.m[k] = L.poses[pose * 16 + k];
-  float qx = 0, qy = 0, qz = 0, nx = 0, ny = 0, nz = 0;
+  qx = qy = qz = nx = ny = nz = 0.0f;
   if( active )
   {
     float4 p = L.obj.pos[i], n = L.obj.nor[i];
     xform3( X, p.x, p.y, p.z, 1.0f, qx, qy, qz );      // :110
     xform3( X, n.x, n.y, n.z, 0.0f, nx, ny, nz );      // :111
   }
-  const float radius = (float)L.sigma;
-  Match m = gated_search( L.scene, active, qx, qy, qz, nx, ny, nz, radius, L.radius_sq, L.gate_tmin, L.K,
-                          lds, wib, lane );
-  if( wib != 0 ) return;
+}
+
+__device__ __forceinline__ void score_emit( const ScoreLaunch& L, int pose, int tile, bool active, int lane, const Match& m )
+{
   double s = 0.0;
   if( active && m.found )
   {
@@ -470,7 +711,58 @@ __global__ __launch_bounds__( BLOCK ) void k_score( ScoreLaunch L )
     s = 0.05 * normals_compat + ( 1.0 - 0.05 ) * dist_compat;                      // :102-103,151
   }
   s = wave_sum( s );
-  if( lane == 0 ) L.part[(size_t)pose * n_tiles + tile] = s;
+  if( lane == 0 ) L.part[(size_t)pose * L.obj.n_tiles + tile] = s;
+}
+
+__global__ __launch_bounds__( BLOCK, 8 ) void k_score( ScoreLaunch L )
+{
+  __shared__ WaveLds lds[WAVES_PER_BLOCK];
+  const int pose = blockIdx.y;
+  const int lane = threadIdx.x & ( WAVE - 1 );
+  const int wib = threadIdx.x / WAVE;
+  const int tile = blockIdx.x * WAVES_PER_BLOCK + wib;
+  if( tile >= L.obj.n_tiles ) return;
+  const int i = (int)L.obj.tiles[tile] + lane;
+  const bool active = i < (int)L.obj.tiles[tile + 1];
+  Xform X;
+#pragma unroll
+  for( int k = 0; k < 16; ++k ) X.m[k] = __int_as_float( uni( __float_as_int( L.poses[pose * 16 + k] ) ) );
+  float qx, qy, qz, nx, ny, nz;
+  score_query( L, X, i, active, qx, qy, qz, nx, ny, nz );
+  bool handoff;
+  Match m = tile_search<true>( L.scene, active, qx, qy, qz, nx, ny, nz, (float)L.sigma, L.radius_sq, L.gate_tmin, L.K,
+                               lds[wib], lane, L.solo_stages, &handoff );
+  if( handoff )
+  {
+    if( lane == 0 ) { int q = atomicAdd( L.queue_count, 1 ); L.queue[q] = pose * L.obj.n_tiles + tile; }
+    return;
+  }
+  score_emit( L, pose, tile, active, lane, m );
+}
+
+__global__ __launch_bounds__( BLOCK ) void k_score_coop( ScoreLaunch L )
+{
+  __shared__ WaveLds lds[WAVES_PER_BLOCK];
+  __shared__ CoopLds coop;
+  const int lane = threadIdx.x & ( WAVE - 1 );
+  const int wib = threadIdx.x / WAVE;
+  const int n_queued = *L.queue_count;
+  for( int b = blockIdx.x; b < n_queued; b += gridDim.x )
+  {
+    const int item = L.queue[b];
+    const int pose = item / L.obj.n_tiles, tile = item % L.obj.n_tiles;
+    const int i = (int)L.obj.tiles[tile] + lane;
+    const bool active = i < (int)L.obj.tiles[tile + 1];
+    Xform X;
+#pragma unroll
+    for( int k = 0; k < 16; ++k ) X.m[k] = L.poses[pose * 16 + k];
+    float qx, qy, qz, nx, ny, nz;
+    score_query( L, X, i, active, qx, qy, qz, nx, ny, nz );
+    Match m = coop_search<true>( L.scene, active, qx, qy, qz, nx, ny, nz, (float)L.sigma, L.radius_sq, L.gate_tmin, L.K,
+                                 lds[wib], coop, wib, lane );
+    if( wib == 0 ) score_emit( L, pose, tile, active, lane, m );
+    __syncthreads();
+  }
 }
 
 // fixed-order sum over tiles, / n, narrowed to float (:156-157)
@@ -490,8 +782,11 @@ __global__ __launch_bounds__( BLOCK ) void k_score_final( ScoreLaunch L )
 
 void launch_score( const ScoreLaunch& L, hipStream_t st )
 {
-  dim3 grid( L.obj.n_tiles, L.n_poses );
+  (void)hipMemsetAsync( L.queue_count, 0, sizeof(int), st );
+  dim3 grid( ( L.obj.n_tiles + WAVES_PER_BLOCK - 1 ) / WAVES_PER_BLOCK, L.n_poses );
   hipLaunchKernelGGL( k_score, grid, dim3( BLOCK ), 0, st, L );
+  long long items = (long long)L.obj.n_tiles * L.n_poses;
+  hipLaunchKernelGGL( k_score_coop, dim3( items < 4096 ? (int)( items > 0 ? items : 1 ) : 4096 ), dim3( BLOCK ), 0, st, L );
   hipLaunchKernelGGL( k_score_final, dim3( L.n_poses ), dim3( BLOCK ), 0, st, L );
 }
 
@@ -509,12 +804,13 @@ __device__ __forceinline__ void unit3( float& x, float& y, float& z )
   x = x * inv; y = y * inv; z = z * inv;
 }
 
-__global__ __launch_bounds__( BLOCK ) void k_label( LabelLaunch L )
+__global__ __launch_bounds__( BLOCK, 8 ) void k_label( LabelLaunch L )
 {
-  __shared__ TileLds lds;
+  __shared__ WaveLds lds[WAVES_PER_BLOCK];
   const int lane = threadIdx.x & ( WAVE - 1 );
   const int wib = threadIdx.x / WAVE;
-  const int tile = blockIdx.x;
+  const int tile = blockIdx.x * WAVES_PER_BLOCK + wib;
+  if( tile >= L.scene.n_tiles ) return;
   const int i = (int)L.scene.tiles[tile] + lane;
   const bool active = i < (int)L.scene.tiles[tile + 1];
   float4 p = make_float4( 0, 0, 0, 0 ), n = make_float4( 0, 0, 0, 0 );
@@ -530,50 +826,29 @@ __global__ __launch_bounds__( BLOCK ) void k_label( LabelLaunch L )
     const PlacementDev& pl = L.pl[k];
     float qx, qy, qz;
     xform3( pl.inv, p.x, p.y, p.z, 1.0f, qx, qy, qz );                         // :755
-    CellBox box = wave_cell_box( pl.g, active, qx, qy, qz, pl.radius );        // same in all TW waves
-    float bd2 = INFINITY; int bidx = INT_MAX, bslot = -1;
-    if( !box.empty )
-    {
-      const float r2 = pl.radius_sq;
-      sweep_box<false>( pl.g, box, lds.pos[wib], nullptr, lane, wib, TW, [&]( float4 P, int, int slot )
-      {
-        float vx = P.x - qx, vy = P.y - qy, vz = P.z - qz;
-        float d2 = vx * vx + vy * vy + vz * vz;
-        int idx = __float_as_int( P.w );
-        if( active & ( d2 < r2 ) & ( ( d2 < bd2 ) | ( ( d2 == bd2 ) & ( idx < bidx ) ) ) ) { bd2 = d2; bidx = idx; bslot = slot; }
-      } );
-      lds.m_d2[wib][lane] = bd2; lds.m_idx[wib][lane] = bidx; lds.m_slot[wib][lane] = bslot;
-      __syncthreads();
-      bd2 = INFINITY; bidx = INT_MAX; bslot = -1;
-#pragma unroll
-      for( int w = 0; w < TW; ++w )
-      {
-        const float d = lds.m_d2[w][lane]; const int ix = lds.m_idx[w][lane]; const int sl = lds.m_slot[w][lane];
-        if( sl >= 0 && lex_less( d, ix, bd2, bidx ) ) { bd2 = d; bidx = ix; bslot = sl; }
-      }
-      __syncthreads();
-    }
+    Match m = tile_search<false>( pl.g, active, qx, qy, qz, 0.0f, 0.0f, 0.0f, pl.radius, pl.radius_sq, 0.0f, 1,
+                                  lds[wib], lane, 0, nullptr );                // :758 (K = 1)
     // :762-775 — found, strictly closer than the running minimum, and within 70° (either sign)
     bool ok = false;
-    if( active && bslot >= 0 && ( L.rows != nullptr || bd2 < best_min ) )
+    if( active && m.found && ( L.rows != nullptr || m.d2 < best_min ) )
     {
       float n1x, n1y, n1z;
       xform3( pl.nmat, n.x, n.y, n.z, 0.0f, n1x, n1y, n1z );                   // :766
-      float4 m4 = pl.g.nor[bslot];
+      float4 m4 = pl.g.nor[m.slot];
       float n2x = m4.x, n2y = m4.y, n2z = m4.z;
       unit3( n1x, n1y, n1z ); unit3( n2x, n2y, n2z );
       float dot = fabsf( n1x * n2x + n1y * n2y + n1z * n2z );                  // :769
       ok = ( dot >= L.gate_tmin ) && ( dot <= 1.0f );
     }
-    if( L.rows ) { if( active && wib == 0 ) L.rows[(size_t)k * L.scene.n + orig] = ok ? bd2 : INFINITY; }
-    else if( ok ) { best_min = bd2; label = L.label_base + k + 1; }
+    if( L.rows ) { if( active ) L.rows[(size_t)k * L.scene.n + orig] = ok ? m.d2 : INFINITY; }
+    else if( ok ) { best_min = m.d2; label = L.label_base + k + 1; }
   }
-  if( active && wib == 0 && L.min_d ) { L.min_d[orig] = best_min; L.labels[orig] = (int8_t)label; }
+  if( active && L.min_d ) { L.min_d[orig] = best_min; L.labels[orig] = (int8_t)label; }
 }
 
 void launch_label( const LabelLaunch& L, hipStream_t st )
 {
-  hipLaunchKernelGGL( k_label, dim3( L.scene.n_tiles ), dim3( BLOCK ), 0, st, L );
+  hipLaunchKernelGGL( k_label, dim3( ( L.scene.n_tiles + WAVES_PER_BLOCK - 1 ) / WAVES_PER_BLOCK ), dim3( BLOCK ), 0, st, L );
 }
 
 // ------------------------------------------------------------------------------------------
@@ -585,34 +860,33 @@ void launch_label( const LabelLaunch& L, hipStream_t st )
 
 __global__ __launch_bounds__( BLOCK ) void k_rows( RowsLaunch L )
 {
-  __shared__ float4 s_pos[WAVES_PER_BLOCK][WAVE];
+  __shared__ WaveLds lds[WAVES_PER_BLOCK];
   const int lane = threadIdx.x & ( WAVE - 1 );
   const int wib = threadIdx.x / WAVE;
-  const int wave = blockIdx.x * WAVES_PER_BLOCK + wib;
-  const int n_waves = L.q.n_tiles;
-  if( wave >= n_waves ) return;
-  const int i = (int)L.q.tiles[wave] + lane;
-  const bool active = i < (int)L.q.tiles[wave + 1];
+  const int tile = blockIdx.x * WAVES_PER_BLOCK + wib;
+  if( tile >= L.q.n_tiles ) return;
+  const int i = (int)L.q.tiles[tile] + lane;
+  const bool active = i < (int)L.q.tiles[tile + 1];
   float4 q = make_float4( 0, 0, 0, 0 );
   if( active ) q = L.q.pos[i];
   const int orig = __float_as_int( q.w );
-  CellBox box = wave_cell_box( L.tgt, active, q.x, q.y, q.z, L.radius );
+  const TileBounds tb = wave_bounds( active, q.x, q.y, q.z );
+  CellBox box = cell_box( L.tgt, tb, L.radius );
+  const bool searchable = tb.any && !box_empty( box );
 
   float pd2 = -1.0f; int pidx = -1;      // previous pick; dist² >= 0 so (-1,-1) precedes everything
   int count = 0;
-  bool more = active && !box.empty;
+  bool more = active && searchable;
   for( int t = 0; t < L.K; ++t )
   {
     if( !__any( more ) ) break;
     float bd2 = INFINITY; int bidx = INT_MAX;
-    sweep_box<false>( L.tgt, box, s_pos[wib], nullptr, lane, 0, 1, [&]( float4 P, int, int )
+    sweep_shell<false>( L.tgt, box, box, false, lds[wib], lane, 0, 1, [&]( float4 P, int )
     {
       float vx = P.x - q.x, vy = P.y - q.y, vz = P.z - q.z;
       float d2 = vx * vx + vy * vy + vz * vz;
       int idx = __float_as_int( P.w );
-      const bool after_prev = ( pd2 < d2 ) | ( ( pd2 == d2 ) & ( pidx < idx ) );
-      const bool before_best = ( d2 < bd2 ) | ( ( d2 == bd2 ) & ( idx < bidx ) );
-      if( more & ( d2 < L.radius_sq ) & after_prev & before_best ) { bd2 = d2; bidx = idx; }
+      if( (int)more & (int)( d2 < L.radius_sq ) & (int)lex_less( pd2, pidx, d2, idx ) & (int)lex_less( d2, idx, bd2, bidx ) ) { bd2 = d2; bidx = idx; }
     } );
     if( more )
     {
@@ -625,9 +899,7 @@ __global__ __launch_bounds__( BLOCK ) void k_rows( RowsLaunch L )
 
 void launch_rows( const RowsLaunch& L, hipStream_t st )
 {
-  const int n_waves = L.q.n_tiles;
-  dim3 grid( ( n_waves + WAVES_PER_BLOCK - 1 ) / WAVES_PER_BLOCK );
-  hipLaunchKernelGGL( k_rows, grid, dim3( BLOCK ), 0, st, L );
+  hipLaunchKernelGGL( k_rows, dim3( ( L.q.n_tiles + WAVES_PER_BLOCK - 1 ) / WAVES_PER_BLOCK ), dim3( BLOCK ), 0, st, L );
 }
 
 } // namespace rs

@@ -69,8 +69,15 @@ def dropin():
     lib.icp_align.restype = C.c_float
     lib.icp_align.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                               C.POINTER(Mat4), Mat4, C.c_float, C.c_float, C.c_bool]
+    lib.msh_hash_grid_init_3d.restype = None
+    lib.msh_hash_grid_init_3d.argtypes = [C.POINTER(HashGrid), C.c_void_p, C.c_int32, C.c_float]
+    lib.msh_hash_grid_term.restype = None
+    lib.msh_hash_grid_term.argtypes = [C.POINTER(HashGrid)]
     lib.msh_hash_grid_radius_search.restype = C.c_size_t
+    lib.msh_hash_grid_radius_search.argtypes = [C.POINTER(HashGrid), C.POINTER(SearchDesc)]
     lib.rsd_alignment_scores.restype = C.c_int
+    lib.rsd_alignment_scores.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                                         C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_void_p]
     return lib
 
 
@@ -96,7 +103,7 @@ def test_hash_grid_by_reference_name(dropin, gscene):
     g = load_golden("rows_k16_r010.npz")
     hg = HashGrid()
     pts = gscene["points"]
-    dropin.msh_hash_grid_init_3d(C.byref(hg), pts.ctypes.data, len(pts), C.c_float(float(g["grid_radius"])))
+    dropin.msh_hash_grid_init_3d(C.byref(hg), pts.ctypes.data, len(pts), float(g["grid_radius"]))
     assert hg.data_buffer and hg._n_pts == len(pts)
     q = g["query"]; k = int(g["k"])
     d = np.zeros((len(q), k), np.float32); i = np.zeros((len(q), k), np.int32); nn = np.zeros(len(q), np.uint64)
@@ -117,5 +124,5 @@ def test_scores_by_flat_entry(dropin, gscene):
     out = np.zeros(len(poses), np.float32)
     rc = dropin.rsd_alignment_scores(o["pos"].ctypes.data, o["nor"].ctypes.data, len(o["pos"]),
                                      gscene["points"].ctypes.data, gscene["normals"].ctypes.data, len(gscene["points"]),
-                                     poses.ctypes.data, len(poses), C.c_float(0.1), 64, out.ctypes.data)
+                                     poses.ctypes.data, len(poses), 0.1, 64, out.ctypes.data)
     assert rc == 0 and np.abs(out.astype(np.float64) - g["scores"]).max() < 2e-6
