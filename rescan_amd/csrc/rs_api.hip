@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -32,8 +33,12 @@ namespace {
 char g_err[512] = "";
 int g_device = -1;
 bool g_ready = false;
-hipStream_t g_own_stream = nullptr;
-hipStream_t g_stream = nullptr;
+// Every host thread that calls the library gets its own HIP stream and its own workspaces, so
+// independent operators (an ICP chain, a score batch, a label transfer) issued from different
+// threads overlap on the GPU: the tail of one kernel is filled by the others.  Clouds are
+// immutable after creation and may be shared between threads.
+thread_local hipStream_t g_own_stream = nullptr;
+thread_local hipStream_t g_stream = nullptr;
 
 void set_err( const char* fmt, ... )
 {
@@ -47,8 +52,14 @@ void set_err( const char* fmt, ... )
 
 int ensure_ready()
 {
-  if( g_ready ) return RS_HIP_OK;
-  return rs_hip_init( g_device >= 0 ? g_device : 0 );
+  if( !g_ready ) { int rc = rs_hip_init( g_device >= 0 ? g_device : 0 ); if( rc ) return rc; }
+  if( !g_own_stream )       // first call from this host thread
+  {
+    HIP_TRY( hipSetDevice( g_device ), RS_HIP_E_NODEVICE );
+    HIP_TRY( hipStreamCreateWithFlags( &g_own_stream, hipStreamNonBlocking ), RS_HIP_E_NODEVICE );
+  }
+  if( !g_stream ) g_stream = g_own_stream;
+  return RS_HIP_OK;
 }
 
 // growable device / pinned-host buffers, kept for the life of the process
@@ -83,16 +94,18 @@ struct PinBuf
 
 struct Workspace
 {
-  DevBuf T1, active, slot, d2, dot, corr_part, stats, mom_part, moments, wexp, queue, queue_count;   // ICP
+  DevBuf state, slot, d2, dot, corr_part, mom_part, res, wexp, queue, queue_count;   // ICP
   DevBuf poses, score_part, scores;                                             // score
   DevBuf plc, labels, mind;                                                     // labels
   DevBuf q4, rd2, ridx, rnn, rows;                                              // rows / misc
   DevBuf tmp_pos, tmp_pos2, tmp_nor2;                                           // estimate-only
   PinBuf h_a, h_b, h_c;
-} g_ws;
+};
+thread_local Workspace g_ws;
 
 // ---- profiling ---------------------------------------------------------------------------
 bool g_prof = false;
+std::mutex g_prof_mutex;
 struct ProfEntry { std::vector<hipEvent_t> ev; int64_t launches = 0; double ms = 0.0; size_t pending = 0; };
 std::map<std::string, ProfEntry> g_profmap;
 
@@ -102,21 +115,24 @@ struct ProfScope
   ProfScope( const char* name )
   {
     if( !g_prof ) return;
+    std::lock_guard<std::mutex> lock( g_prof_mutex );
     e = &g_profmap[name];
     at = e->pending;
+    e->pending = at + 2;                 // reserve the pair now: other threads may open scopes meanwhile
     while( e->ev.size() < at + 2 ) { hipEvent_t x; if( hipEventCreate( &x ) != hipSuccess ) { e = nullptr; return; } e->ev.push_back( x ); }
     (void)hipEventRecord( e->ev[at], g_stream );
   }
   ~ProfScope()
   {
     if( !e ) return;
+    std::lock_guard<std::mutex> lock( g_prof_mutex );
     (void)hipEventRecord( e->ev[at + 1], g_stream );
-    e->pending = at + 2;
   }
 };
 
 void prof_collect()
 {
+  std::lock_guard<std::mutex> lock( g_prof_mutex );
   for( auto& kv : g_profmap )
   {
     ProfEntry& e = kv.second;
@@ -268,8 +284,6 @@ int rs_hip_init( int device )
   }
   if( device < 0 || device >= count ) { set_err( "rs_hip_init: device %d out of range (%d devices)", device, count ); return RS_HIP_E_ARG; }
   HIP_TRY( hipSetDevice( device ), RS_HIP_E_NODEVICE );
-  if( !g_own_stream ) HIP_TRY( hipStreamCreateWithFlags( &g_own_stream, hipStreamNonBlocking ), RS_HIP_E_NODEVICE );
-  if( !g_stream ) g_stream = g_own_stream;
   g_device = device;
   g_ready = true;
   return RS_HIP_OK;
@@ -293,12 +307,14 @@ int rs_hip_profile_enable( int on ) { g_prof = on != 0; return RS_HIP_OK; }
 int rs_hip_profile_reset( void )
 {
   prof_collect();
+  std::lock_guard<std::mutex> lock( g_prof_mutex );
   for( auto& kv : g_profmap ) { kv.second.launches = 0; kv.second.ms = 0.0; }
   return RS_HIP_OK;
 }
 int rs_hip_profile_read( const char* name, int64_t* launches, double* total_ms )
 {
   prof_collect();
+  std::lock_guard<std::mutex> lock( g_prof_mutex );
   auto it = g_profmap.find( name ? name : "" );
   if( it == g_profmap.end() ) { if( launches ) *launches = 0; if( total_ms ) *total_ms = 0.0; return RS_HIP_OK; }
   if( launches ) *launches = it->second.launches;
@@ -565,20 +581,22 @@ int icp_prepare( IcpCtx& cx, const rs_hip_cloud_t* src, const rs_hip_cloud_t* tg
   L.n_mom_blocks = std::max( 1, std::min( 256, ( src->n + 255 ) / 256 ) );
   const size_t nq = std::max<size_t>( 1, (size_t)src->n ), np = (size_t)n_prob;
   int rc;
-  if( ( rc = g_ws.T1.ensure( np * 64 ) ) || ( rc = g_ws.active.ensure( np * 4 ) ) ||
+  if( ( rc = g_ws.state.ensure( np * 68 ) ) ||
       ( rc = g_ws.slot.ensure( np * nq * 4 ) ) || ( rc = g_ws.d2.ensure( np * nq * 4 ) ) || ( rc = g_ws.dot.ensure( np * nq * 4 ) ) ||
-      ( rc = g_ws.corr_part.ensure( np * std::max( 1, cx.n_waves ) * 3 * 8 ) ) || ( rc = g_ws.stats.ensure( np * 4 * 8 ) ) ||
-      ( rc = g_ws.mom_part.ensure( np * L.n_mom_blocks * ICP_NMOM * 8 ) ) || ( rc = g_ws.moments.ensure( np * ICP_NMOM * 8 ) ) ||
-      ( rc = g_ws.h_a.ensure( np * ( ICP_NMOM + 4 ) * 8 ) ) || ( rc = g_ws.h_b.ensure( np * 64 + np * 4 ) ) ||
+      ( rc = g_ws.corr_part.ensure( np * std::max( 1, cx.n_waves ) * 3 * 8 ) ) ||
+      ( rc = g_ws.mom_part.ensure( np * L.n_mom_blocks * ICP_NMOM * 8 ) ) || ( rc = g_ws.res.ensure( np * ICP_NRES * 8 ) ) ||
+      ( rc = g_ws.h_a.ensure( np * ICP_NRES * 8 ) ) || ( rc = g_ws.h_b.ensure( np * 68 ) ) ||
       ( rc = g_ws.queue.ensure( np * std::max( 1, cx.n_waves ) * 4 ) ) || ( rc = g_ws.queue_count.ensure( np * 4 ) ) )
     return rc;
   L.queue = g_ws.queue.as<int>(); L.queue_count = g_ws.queue_count.as<int>();
   L.solo_stages = handoff_threshold( (long long)cx.n_waves * n_prob );
-  L.T1 = g_ws.T1.as<float>(); L.active = g_ws.active.as<int>();
+  // one upload per iteration: [n_prob x 16 floats of T1][n_prob active flags]
+  L.T1 = g_ws.state.as<float>(); L.active = (const int*)( g_ws.state.as<float>() + np * 16 );
   L.m_slot = g_ws.slot.as<int>(); L.m_d2 = g_ws.d2.as<float>(); L.m_dot = g_ws.dot.as<float>();
-  L.corr_part = g_ws.corr_part.as<double>(); L.stats = g_ws.stats.as<double>();
-  L.mom_part = g_ws.mom_part.as<double>(); L.moments = g_ws.moments.as<double>();
+  L.corr_part = g_ws.corr_part.as<double>();
+  L.mom_part = g_ws.mom_part.as<double>(); L.res = g_ws.res.as<double>();
   L.w_explicit = nullptr;
+  HIP_TRY( hipMemsetAsync( g_ws.queue_count.p, 0, np * 4, g_stream ), RS_HIP_E_RUNTIME );
   return RS_HIP_OK;
 }
 
@@ -588,8 +606,7 @@ int icp_upload_state( IcpCtx& cx, const std::vector<Mat4>& T, const std::vector<
   float* hT = g_ws.h_b.as<float>();
   int* hA = (int*)( hT + np * 16 );
   for( size_t p = 0; p < np; ++p ) { std::memcpy( hT + 16 * p, T[p].m, 64 ); hA[p] = active[p]; }
-  HIP_TRY( hipMemcpyAsync( g_ws.T1.p, hT, np * 64, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
-  HIP_TRY( hipMemcpyAsync( g_ws.active.p, hA, np * 4, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipMemcpyAsync( g_ws.state.p, hT, np * 68, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
   return RS_HIP_OK;
 }
 
@@ -618,8 +635,7 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
   for( int p = 0; p < n; ++p ) std::memcpy( T[p].m, T1s + 16 * p, 64 );
   if( source->n == 0 ) { for( int p = 0; p < n; ++p ) { errs[p] = 1e6f; if( iters ) iters[p] = 1; } return RS_HIP_OK; }   // n_corrs == 0 on the first search
 
-  double* hM = g_ws.h_a.as<double>();
-  double* hS = hM + (size_t)n * ICP_NMOM;
+  double* hR = g_ws.h_a.as<double>();               // n x ICP_NRES: moments, then stats
   for( int i = 0; i < max_iter; ++i )                                  // icp.h:444
   {
     if( ( rc = icp_upload_state( cx, T, active ) ) ) return rc;
@@ -641,8 +657,7 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
     }
     launch_icp_stats( cx.L, g_stream );
     { ProfScope ps( "icp_moments" ); launch_icp_moments( cx.L, g_stream ); }
-    HIP_TRY( hipMemcpyAsync( hM, g_ws.moments.p, (size_t)n * ICP_NMOM * 8, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
-    HIP_TRY( hipMemcpyAsync( hS, g_ws.stats.p, (size_t)n * 4 * 8, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+    HIP_TRY( hipMemcpyAsync( hR, g_ws.res.p, (size_t)n * ICP_NRES * 8, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
     HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
 
     int n_active = 0;
@@ -651,13 +666,15 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
       if( !active[p] ) continue;
       prev[p] = err[p];
       it_count[p]++;
-      if( hS[4 * p] == 0.0 ) { active[p] = 0; continue; }             // icp.h:455-459 no correspondences
+      const double* hM = hR + (size_t)p * ICP_NRES;
+      const double* hS = hM + ICP_NMOM;
+      if( hS[0] == 0.0 ) { active[p] = 0; continue; }                 // icp.h:455-459 no correspondences
       float e;
-      if( !icp_solve( hM + (size_t)p * ICP_NMOM, T[p], e ) ) { active[p] = 0; continue; }   // icp.h:466-470
+      if( !icp_solve( hM, T[p], e ) ) { active[p] = 0; continue; }    // icp.h:466-470
       err[p] = e;
       if( getenv( "RS_HIP_DEBUG" ) )
-        fprintf( stderr, "[rs_hip icp] it %d prob %d n_corr %.0f mean %g sd %g W %.9g err %.9g max_dist %g T12 %g %g %g\n", i, p, hS[4*p], hS[4*p+1], hS[4*p+2],
-                 hM[(size_t)p * ICP_NMOM], (double)e, (double)max_dist, T[p].m[12], T[p].m[13], T[p].m[14] );
+        fprintf( stderr, "[rs_hip icp] it %d prob %d n_corr %.0f mean %g sd %g W %.9g err %.9g max_dist %g T12 %g %g %g\n", i, p, hS[0], hS[1], hS[2],
+                 hM[0], (double)e, (double)max_dist, T[p].m[12], T[p].m[13], T[p].m[14] );
       float delta = fabsf( prev[p] - err[p] );
       if( !fixed_iters && i > 5 && delta < 1e-5 ) { active[p] = 0; continue; }               // icp.h:489
       n_active++;
@@ -753,8 +770,8 @@ int rs_hip_icp_estimate_pt2pl( const float* pts1, const float* pts2, const float
   const size_t nn = (size_t)n;
   if( ( rc = g_ws.tmp_pos.ensure( nn * 16 ) ) || ( rc = g_ws.tmp_pos2.ensure( nn * 16 ) ) || ( rc = g_ws.tmp_nor2.ensure( nn * 16 ) ) ||
       ( rc = g_ws.wexp.ensure( nn * 4 ) ) || ( rc = g_ws.slot.ensure( nn * 4 ) ) || ( rc = g_ws.d2.ensure( nn * 4 ) ) || ( rc = g_ws.dot.ensure( nn * 4 ) ) ||
-      ( rc = g_ws.T1.ensure( 64 ) ) || ( rc = g_ws.active.ensure( 4 ) ) || ( rc = g_ws.stats.ensure( 32 ) ) ||
-      ( rc = g_ws.mom_part.ensure( 256 * ICP_NMOM * 8 ) ) || ( rc = g_ws.moments.ensure( ICP_NMOM * 8 ) ) || ( rc = g_ws.h_a.ensure( ( ICP_NMOM + 4 ) * 8 ) ) )
+      ( rc = g_ws.state.ensure( 68 ) ) ||
+      ( rc = g_ws.mom_part.ensure( 256 * ICP_NMOM * 8 ) ) || ( rc = g_ws.res.ensure( ICP_NRES * 8 ) ) || ( rc = g_ws.h_a.ensure( ICP_NRES * 8 ) ) )
     return rc;
   std::vector<float4> a( nn ), b( nn ), c( nn ); std::vector<int> sl( nn );
   for( size_t i = 0; i < nn; ++i )
@@ -764,26 +781,26 @@ int rs_hip_icp_estimate_pt2pl( const float* pts1, const float* pts2, const float
     c[i] = make_float4( nor2[3*i], nor2[3*i+1], nor2[3*i+2], 0 );
     sl[i] = (int)i;
   }
-  Mat4 I = mat4_identity(); int one = 1; double zeros[4] = { 0, 0, 0, 0 };
+  Mat4 I = mat4_identity(); double zeros[ICP_NRES]; std::memset( zeros, 0, sizeof(zeros) );
+  float st_host[17]; std::memcpy( st_host, I.m, 64 ); { int one = 1; std::memcpy( st_host + 16, &one, 4 ); }
   HIP_TRY( hipMemcpyAsync( g_ws.tmp_pos.p, a.data(), nn * 16, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
   HIP_TRY( hipMemcpyAsync( g_ws.tmp_pos2.p, b.data(), nn * 16, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
   HIP_TRY( hipMemcpyAsync( g_ws.tmp_nor2.p, c.data(), nn * 16, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
   HIP_TRY( hipMemcpyAsync( g_ws.wexp.p, weights, nn * 4, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
   HIP_TRY( hipMemcpyAsync( g_ws.slot.p, sl.data(), nn * 4, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
-  HIP_TRY( hipMemcpyAsync( g_ws.T1.p, I.m, 64, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
-  HIP_TRY( hipMemcpyAsync( g_ws.active.p, &one, 4, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
-  HIP_TRY( hipMemcpyAsync( g_ws.stats.p, zeros, 32, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipMemcpyAsync( g_ws.state.p, st_host, 68, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipMemcpyAsync( g_ws.res.p, zeros, ICP_NRES * 8, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
   HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );     // host staging vectors go out of scope below
   IcpLaunch L{};
   L.tgt.pos = g_ws.tmp_pos2.as<float4>(); L.tgt.nor = g_ws.tmp_nor2.as<float4>(); L.tgt.n = n;
   L.src.pos = g_ws.tmp_pos.as<float4>(); L.src.nor = nullptr; L.src.tiles = nullptr; L.src.n = n; L.src.n_tiles = 0; L.n_prob = 1;
-  L.T1 = g_ws.T1.as<float>(); L.active = g_ws.active.as<int>(); std::memcpy( L.T2i.m, I.m, 64 );
+  L.T1 = g_ws.state.as<float>(); L.active = (const int*)( g_ws.state.as<float>() + 16 ); std::memcpy( L.T2i.m, I.m, 64 );
   L.radius = 1.0f; L.m_slot = g_ws.slot.as<int>(); L.m_d2 = g_ws.d2.as<float>(); L.m_dot = g_ws.dot.as<float>();
-  L.stats = g_ws.stats.as<double>(); L.mom_part = g_ws.mom_part.as<double>(); L.moments = g_ws.moments.as<double>();
+  L.mom_part = g_ws.mom_part.as<double>(); L.res = g_ws.res.as<double>();
   L.n_mom_blocks = std::max( 1, std::min( 256, ( n + 255 ) / 256 ) ); L.w_explicit = g_ws.wexp.as<float>();
   { ProfScope ps( "icp_moments" ); launch_icp_moments( L, g_stream ); }
   double* hM = g_ws.h_a.as<double>();
-  HIP_TRY( hipMemcpyAsync( hM, g_ws.moments.p, ICP_NMOM * 8, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipMemcpyAsync( hM, g_ws.res.p, ICP_NMOM * 8, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
   HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
   Mat4 T; std::memcpy( T.m, T1, 64 );
   float e = 0.0f;

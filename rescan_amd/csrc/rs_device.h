@@ -45,7 +45,8 @@ struct PlacementDev
   float    radius_sq; // (float)((double)radius*(double)radius)
 };
 
-enum { ICP_NMOM = 35 };   // raw moments reduced per ICP iteration (see k_icp_moments)
+enum { ICP_NMOM = 35,     // raw moments reduced per ICP iteration (see k_icp_moments)
+       ICP_NRES = 39 };   // per problem result record: 35 moments + {n_corr, mean, stddev, -}
 
 // ---- launchers (rs_kernels.hip) ----------------------------------------------------------
 struct IcpLaunch
@@ -63,9 +64,8 @@ struct IcpLaunch
   float*  m_d2;     // n_prob x nq
   float*  m_dot;    // n_prob x nq
   double* corr_part;  // n_prob x n_tiles x 3
-  double* stats;      // n_prob x 4 : n_corr, mean, stddev, (unused)
   double* mom_part;   // n_prob x n_mom_blocks x ICP_NMOM
-  double* moments;    // n_prob x ICP_NMOM
+  double* res;        // n_prob x ICP_NRES : moments [0,35), then n_corr, mean, stddev, (unused)
   int     n_mom_blocks;
   int*    queue;        // n_prob x n_tiles : tiles handed to the cooperative kernel
   int*    queue_count;  // n_prob

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <list>
+#include <mutex>
 #include <vector>
 
 static_assert( sizeof(rsd_vec3_t) == 12, "msh_vec3_t is 12 bytes" );
@@ -40,6 +41,7 @@ struct Entry
   rs_hip_cloud_t* cloud;
 };
 std::list<Entry> g_cache;
+std::mutex g_cache_mutex;
 const size_t kMaxEntries = 64;
 
 uint64_t content_hash( const void* a, const void* b, size_t bytes )
@@ -59,6 +61,7 @@ uint64_t content_hash( const void* a, const void* b, size_t bytes )
 rs_hip_cloud_t* cached_cloud( const rsd_vec3_t* pos, const rsd_vec3_t* nor, int32_t n, float cell )
 {
   const uint64_t h = content_hash( pos, nor, (size_t)( n > 0 ? n : 0 ) * 12 );
+  std::lock_guard<std::mutex> lock( g_cache_mutex );
   for( auto it = g_cache.begin(); it != g_cache.end(); ++it )
     if( it->pos == pos && it->nor == nor && it->n == n && it->cell == cell && it->hash == h )
     {
@@ -78,6 +81,7 @@ extern "C" {
 
 void rsd_cache_clear( void )
 {
+  std::lock_guard<std::mutex> lock( g_cache_mutex );
   for( auto& e : g_cache ) rs_hip_cloud_destroy( e.cloud );
   g_cache.clear();
 }

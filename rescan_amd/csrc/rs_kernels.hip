@@ -269,16 +269,18 @@ __device__ __forceinline__ uint32_t sweep_shell( const GridView& g, const CellBo
 struct Match { float d2; int idx; float dot; int slot; bool found; };
 
 // The per-candidate step shared by all searches: update the best match `m` of this lane.
-// Returns through seen_closer the count of candidates that were no farther than the best so far.
+// `bound` folds three tests into one compare: a candidate can only matter if
+// dist² < bound, where bound = radius² until a match exists and then the float just above the
+// match's dist² (so "<= best" including ties, which the rare branch settles by index);
+// inactive lanes carry bound = -1.  seen_closer counts the candidates that passed it.
 template <bool GATED>
-__device__ __forceinline__ void consider( float4 P, int j, const WaveLds& L, bool active,
+__device__ __forceinline__ void consider( float4 P, int j, const WaveLds& L,
                                           float qx, float qy, float qz, float nx, float ny, float nz,
-                                          float radius_sq, float tmin, Match& m, int& seen_closer )
+                                          float tmin, float& bound, Match& m, int& seen_closer )
 {
   float vx = P.x - qx, vy = P.y - qy, vz = P.z - qz;
   float d2 = vx * vx + vy * vy + vz * vz;
-  // cheap superset of "precedes the best so far": ties are settled inside the rare branch
-  const bool maybe = active & ( d2 < radius_sq ) & ( d2 <= m.d2 );
+  const bool maybe = d2 < bound;
   seen_closer += maybe ? 1 : 0;
   if( __any( maybe ) )
   {
@@ -292,8 +294,19 @@ __device__ __forceinline__ void consider( float4 P, int j, const WaveLds& L, boo
       dc = dot > 0.0f ? dot : 0.0f;                     // msh_max( dot, 0.0f )
       take = take & ( dc >= tmin ) & ( dc <= 1.0f );
     }
-    if( take ) { m.d2 = d2; m.idx = idx; m.dot = dc; m.slot = (int)L.slot[j]; m.found = true; }
+    if( take )
+    {
+      m.d2 = d2; m.idx = idx; m.dot = dc; m.slot = (int)L.slot[j]; m.found = true;
+      bound = __int_as_float( __float_as_int( d2 ) + 1 );   // next float above d2 (d2 >= 0, finite, < radius²)
+    }
   }
+}
+
+// bound for a lane before / after a merge
+__device__ __forceinline__ float bound_of( bool active, float radius_sq, const Match& m )
+{
+  if( !active ) return -1.0f;
+  return m.found ? __int_as_float( __float_as_int( m.d2 ) + 1 ) : radius_sq;
 }
 
 // Nearest candidate within the radius [whose normal passes tmin <= max(dot,0) <= 1, if GATED],
@@ -325,6 +338,7 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
   if( box_empty( core ) ) core = full;             // the tile lies outside the grid but within reach of it
 
   int seen_closer = 0;   // candidates that were no farther than the best-so-far when they were met
+  float bound = bound_of( active, radius_sq, m );
   CellBox cur = core, prev = core;
   bool have_prev = false;
   uint32_t streamed = 0;
@@ -332,7 +346,7 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
   {
     cur = ( g.inv_cell > 0.0f ) ? box_grow( core, k, full ) : full;
     streamed += sweep_shell<GATED>( g, cur, prev, have_prev, L, lane, 0, 1, [&]( float4 P, int j )
-    { consider<GATED>( P, j, L, active, qx, qy, qz, nx, ny, nz, radius_sq, tmin, m, seen_closer ); } );
+    { consider<GATED>( P, j, L, qx, qy, qz, nx, ny, nz, tmin, bound, m, seen_closer ); } );
     if( box_same( cur, full ) ) break;
     // a lane is settled when nothing outside `cur` can precede its match (or reach it at all)
     const float cov = box_cover( g, cur, full, qx, qy, qz );
@@ -397,13 +411,14 @@ __device__ __forceinline__ Match coop_search( const GridView& g, bool active,
   if( box_empty( core ) ) core = full;
 
   int seen_closer = 0;
+  float bound = bound_of( active, radius_sq, m );
   CellBox cur = core, prev = core;
   bool have_prev = false;
   for( int k = 1; ; k *= 2 )
   {
     cur = ( g.inv_cell > 0.0f ) ? box_grow( core, k, full ) : full;
     sweep_shell<GATED>( g, cur, prev, have_prev, L, lane, wib, WAVES_PER_BLOCK, [&]( float4 P, int j )
-    { consider<GATED>( P, j, L, active, qx, qy, qz, nx, ny, nz, radius_sq, tmin, m, seen_closer ); } );
+    { consider<GATED>( P, j, L, qx, qy, qz, nx, ny, nz, tmin, bound, m, seen_closer ); } );
     // merge the per-lane bests of the waves; every wave continues with the merged best
     C.m_d2[wib][lane] = m.d2; C.m_idx[wib][lane] = m.idx; C.m_dot[wib][lane] = m.dot; C.m_slot[wib][lane] = m.found ? m.slot : -1;
     __syncthreads();
@@ -413,6 +428,7 @@ __device__ __forceinline__ Match coop_search( const GridView& g, bool active,
       const float d = C.m_d2[w][lane]; const int ix = C.m_idx[w][lane]; const int sl = C.m_slot[w][lane];
       if( sl >= 0 && lex_less( d, ix, m.d2, m.idx ) ) { m.d2 = d; m.idx = ix; m.dot = C.m_dot[w][lane]; m.slot = sl; m.found = true; }
     }
+    bound = bound_of( active, radius_sq, m );
     __syncthreads();
     if( box_same( cur, full ) ) break;
     const float cov = box_cover( g, cur, full, qx, qy, qz );
@@ -569,8 +585,9 @@ __global__ __launch_bounds__( BLOCK ) void k_icp_stats( IcpLaunch L )
     float sqm = (float)( red[2][0] / n );                  // sq_sum / (float)n
     float var = sqm - mean * mean;
     float sd = (float)sqrt( (double)var );                 // (float)sqrt( ... ), msh_std.h:1824
-    double* st = L.stats + (size_t)prob * 4;
+    double* st = L.res + (size_t)prob * ICP_NRES + ICP_NMOM;
     st[0] = n; st[1] = mean; st[2] = sd; st[3] = 0.0;
+    if( L.queue_count ) L.queue_count[prob] = 0;         // ready for the next iteration's phase A
   }
 }
 
@@ -594,7 +611,7 @@ __global__ __launch_bounds__( BLOCK ) void k_icp_moments( IcpLaunch L )
   Xform T1;
 #pragma unroll
   for( int k = 0; k < 16; ++k ) T1.m[k] = L.T1[prob * 16 + k];
-  const float sd = (float)L.stats[(size_t)prob * 4 + 2];
+  const float sd = (float)L.res[(size_t)prob * ICP_NRES + ICP_NMOM + 2];
   const bool use_sd = sd > 0.000001;
   const float cut = 2.5f * sd;
 
@@ -662,12 +679,12 @@ __global__ __launch_bounds__( BLOCK ) void k_icp_moments_final( IcpLaunch L )
   red[threadIdx.x] = v;
   __syncthreads();
   for( int s = BLOCK / 2; s > 0; s >>= 1 ) { if( threadIdx.x < s ) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
-  if( threadIdx.x == 0 ) L.moments[(size_t)prob * ICP_NMOM + k] = red[0];
+  if( threadIdx.x == 0 ) L.res[(size_t)prob * ICP_NRES + k] = red[0];
 }
 
 void launch_icp_corr( const IcpLaunch& L, hipStream_t st )
 {
-  (void)hipMemsetAsync( L.queue_count, 0, (size_t)L.n_prob * sizeof(int), st );
+  // queue_count is zero on entry: cleared once by the host, then by k_icp_stats after every use
   dim3 grid( ( L.src.n_tiles + WAVES_PER_BLOCK - 1 ) / WAVES_PER_BLOCK, L.n_prob );
   hipLaunchKernelGGL( k_icp_corr, grid, dim3( BLOCK ), 0, st, L );
   // the queue length is only known on the device: a fixed grid strides over it
