@@ -176,17 +176,18 @@ __device__ __forceinline__ float box_cover( const GridView& g, const CellBox& cu
 // Per-wave LDS.
 struct WaveLds
 {
-  float4   pos[WAVE];      // staged candidates {x,y,z,bitcast(orig index)}
+  float    px[WAVE], py[WAVE], pz[WAVE];   // staged candidates, one array per coordinate so that four
+  int      pidx[WAVE];                     // consecutive candidates load as one ds_read_b128 per coordinate
   float4   nor[WAVE];      // their normals {nx,ny,nz,-}
   uint32_t slot[WAVE];     // their positions in the cell-sorted cloud
   uint32_t seg_a[WAVE], len_a[WAVE], seg_b[WAVE], pre[WAVE];   // row pieces of the current batch
 };
 
-// Stream every point of (out \ in) through the wave's LDS and call f( P, j ) for each;
-// `in` (if in_valid) must be a sub-box of `out`.  P = {x,y,z,bitcast(index)}, j = position in
-// the staged chunk (L.nor[j] / L.slot[j] belong to it); j is wave-uniform.  Chunks are padded
-// to a multiple of 4 with sentinels at +FLT_MAX whose dist² is +inf: they can never be
-// "within the radius", so f needs no validity test.
+// Stream every point of (out \ in) through the wave's LDS and call f( X, Y, Z, k ) for every
+// group of four staged candidates k..k+3 (X = their four x coordinates, ...; L.pidx[k+i],
+// L.nor[k+i], L.slot[k+i] belong to them); k is wave-uniform.  `in` (if in_valid) must be a
+// sub-box of `out`.  Chunks are padded to a multiple of 4 with sentinels at +FLT_MAX whose
+// dist² is +inf: they can never be "within the radius", so f needs no validity test.
 // When several waves sweep the same shell together, wave `share` of `n_share` takes the chunks
 // whose running number is congruent to it.
 template <bool WITH_NOR, class F>
@@ -243,7 +244,7 @@ __device__ __forceinline__ uint32_t sweep_shell( const GridView& g, const CellBo
     if( c0 < total ) fetch( c0, P, N, src );
     while( c0 < total )
     {
-      L.pos[lane] = P;
+      L.px[lane] = P.x; L.py[lane] = P.y; L.pz[lane] = P.z; L.pidx[lane] = __float_as_int( P.w );
       if( WITH_NOR ) L.nor[lane] = N;
       L.slot[lane] = src;
       wave_lds_fence();
@@ -254,8 +255,10 @@ __device__ __forceinline__ uint32_t sweep_shell( const GridView& g, const CellBo
 #pragma unroll 1
       for( uint32_t k = 0; k < cnt4; k += 4 )
       {
-        const float4 P0 = L.pos[k], P1 = L.pos[k + 1], P2 = L.pos[k + 2], P3 = L.pos[k + 3];
-        f( P0, (int)k ); f( P1, (int)k + 1 ); f( P2, (int)k + 2 ); f( P3, (int)k + 3 );
+        const float4 X = *reinterpret_cast<const float4*>( &L.px[k] );
+        const float4 Y = *reinterpret_cast<const float4*>( &L.py[k] );
+        const float4 Z = *reinterpret_cast<const float4*>( &L.pz[k] );
+        f( X, Y, Z, (int)k );
       }
       wave_lds_fence();
       c0 = cn;
@@ -268,38 +271,78 @@ __device__ __forceinline__ uint32_t sweep_shell( const GridView& g, const CellBo
 // Result of a search for one query.
 struct Match { float d2; int idx; float dot; int slot; bool found; };
 
-// The per-candidate step shared by all searches: update the best match `m` of this lane.
+typedef float f32x2 __attribute__(( ext_vector_type( 2 ) ));
+
+// dist² of four candidates to one query, two at a time in packed fp32: each v_pk_add/v_pk_mul
+// rounds its two halves exactly like the scalar instruction, and the order is the reference's
+// (vx*vx + vy*vy) + vz*vz (msh_hash_grid.h:852-855).  No fused multiply-add is formed
+// (-ffp-contract=off).
+__device__ __forceinline__ void dist2x4( const float4& X, const float4& Y, const float4& Z, float qx, float qy, float qz,
+                                         float& d0, float& d1, float& d2, float& d3 )
+{
+  const f32x2 q_x = { qx, qx }, q_y = { qy, qy }, q_z = { qz, qz };
+  f32x2 ax = f32x2{ X.x, X.y } - q_x, ay = f32x2{ Y.x, Y.y } - q_y, az = f32x2{ Z.x, Z.y } - q_z;
+  f32x2 bx = f32x2{ X.z, X.w } - q_x, by = f32x2{ Y.z, Y.w } - q_y, bz = f32x2{ Z.z, Z.w } - q_z;
+  f32x2 a = ax * ax + ay * ay + az * az;
+  f32x2 b = bx * bx + by * by + bz * bz;
+  d0 = a.x; d1 = a.y; d2 = b.x; d3 = b.y;
+}
+
+// The candidate step shared by all searches, four staged candidates at a time: update the best
+// match `m` of this lane.
 // `bound` folds three tests into one compare: a candidate can only matter if
 // dist² < bound, where bound = radius² until a match exists and then the float just above the
 // match's dist² (so "<= best" including ties, which the rare branch settles by index);
 // inactive lanes carry bound = -1.  seen_closer counts the candidates that passed it.
 template <bool GATED>
-__device__ __forceinline__ void consider( float4 P, int j, const WaveLds& L,
-                                          float qx, float qy, float qz, float nx, float ny, float nz,
-                                          float tmin, float& bound, Match& m, int& seen_closer )
+__device__ __forceinline__ void consider4( const float4& X, const float4& Y, const float4& Z, int k, const WaveLds& L,
+                                           float qx, float qy, float qz, float nx, float ny, float nz,
+                                           float tmin, float& bound, Match& m, int& seen_closer )
 {
-  float vx = P.x - qx, vy = P.y - qy, vz = P.z - qz;
-  float d2 = vx * vx + vy * vy + vz * vz;
-  const bool maybe = d2 < bound;
-  seen_closer += maybe ? 1 : 0;
-  if( __any( maybe ) )
+  float d[4];
+  dist2x4( X, Y, Z, qx, qy, qz, d[0], d[1], d[2], d[3] );
+  const bool m0 = d[0] < bound, m1 = d[1] < bound, m2 = d[2] < bound, m3 = d[3] < bound;
+  if( __any( m0 | m1 | m2 | m3 ) )
   {
-    const int idx = __float_as_int( P.w );
-    bool take = maybe & lex_less( d2, idx, m.d2, m.idx );
-    float dc = 0.0f;
-    if( GATED )
+    // rare: look at the four one by one (the bound may tighten on the way; candidates tested
+    // against the looser, earlier bound only make seen_closer a looser upper bound)
+#pragma unroll
+    for( int i = 0; i < 4; ++i )
     {
-      float4 N = L.nor[j];
-      float dot = N.x * nx + N.y * ny + N.z * nz;       // msh_vec3_dot( m, n )
-      dc = dot > 0.0f ? dot : 0.0f;                     // msh_max( dot, 0.0f )
-      take = take & ( dc >= tmin ) & ( dc <= 1.0f );
-    }
-    if( take )
-    {
-      m.d2 = d2; m.idx = idx; m.dot = dc; m.slot = (int)L.slot[j]; m.found = true;
-      bound = __int_as_float( __float_as_int( d2 ) + 1 );   // next float above d2 (d2 >= 0, finite, < radius²)
+      const bool maybe = d[i] < bound;
+      seen_closer += maybe ? 1 : 0;
+      if( __any( maybe ) )
+      {
+        const int idx = L.pidx[k + i];
+        bool take = maybe & lex_less( d[i], idx, m.d2, m.idx );
+        float dc = 0.0f;
+        if( GATED )
+        {
+          float4 N = L.nor[k + i];
+          float dot = N.x * nx + N.y * ny + N.z * nz;       // msh_vec3_dot( m, n )
+          dc = dot > 0.0f ? dot : 0.0f;                     // msh_max( dot, 0.0f )
+          take = take & ( dc >= tmin ) & ( dc <= 1.0f );
+        }
+        if( take )
+        {
+          m.d2 = d[i]; m.idx = idx; m.dot = dc; m.slot = (int)L.slot[k + i]; m.found = true;
+          bound = __int_as_float( __float_as_int( d[i] ) + 1 );   // next float above d2 (d2 >= 0, finite, < radius²)
+        }
+      }
     }
   }
+}
+
+// count, among four candidates, those that precede (bd2, bidx) within the radius
+__device__ __forceinline__ int precede4( const float4& X, const float4& Y, const float4& Z, int k, const WaveLds& L,
+                                         float qx, float qy, float qz, float radius_sq, float bd2, int bidx )
+{
+  float d[4];
+  dist2x4( X, Y, Z, qx, qy, qz, d[0], d[1], d[2], d[3] );
+  int c = 0;
+#pragma unroll
+  for( int i = 0; i < 4; ++i ) c += ( ( d[i] < radius_sq ) & lex_less( d[i], L.pidx[k + i], bd2, bidx ) ) ? 1 : 0;
+  return c;
 }
 
 // bound for a lane before / after a merge
@@ -345,8 +388,8 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
   for( int k = 1; ; k *= 2 )
   {
     cur = ( g.inv_cell > 0.0f ) ? box_grow( core, k, full ) : full;
-    streamed += sweep_shell<GATED>( g, cur, prev, have_prev, L, lane, 0, 1, [&]( float4 P, int j )
-    { consider<GATED>( P, j, L, qx, qy, qz, nx, ny, nz, tmin, bound, m, seen_closer ); } );
+    streamed += sweep_shell<GATED>( g, cur, prev, have_prev, L, lane, 0, 1, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
+    { consider4<GATED>( X, Y, Z, k4, L, qx, qy, qz, nx, ny, nz, tmin, bound, m, seen_closer ); } );
     if( box_same( cur, full ) ) break;
     // a lane is settled when nothing outside `cur` can precede its match (or reach it at all)
     const float cov = box_cover( g, cur, full, qx, qy, qz );
@@ -368,13 +411,8 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
     if( __any( need_rank ) )
     {
       int rank = 0;
-      sweep_shell<false>( g, cur, cur, false, L, lane, 0, 1, [&]( float4 P, int )
-      {
-        float vx = P.x - qx, vy = P.y - qy, vz = P.z - qz;
-        float d2 = vx * vx + vy * vy + vz * vz;
-        int idx = __float_as_int( P.w );
-        rank += ( need_rank & ( d2 < radius_sq ) & lex_less( d2, idx, m.d2, m.idx ) ) ? 1 : 0;
-      } );
+      sweep_shell<false>( g, cur, cur, false, L, lane, 0, 1, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
+      { rank += need_rank ? precede4( X, Y, Z, k4, L, qx, qy, qz, radius_sq, m.d2, m.idx ) : 0; } );
       if( need_rank && rank >= K ) { m.found = false; m.slot = -1; }
     }
   }
@@ -417,8 +455,8 @@ __device__ __forceinline__ Match coop_search( const GridView& g, bool active,
   for( int k = 1; ; k *= 2 )
   {
     cur = ( g.inv_cell > 0.0f ) ? box_grow( core, k, full ) : full;
-    sweep_shell<GATED>( g, cur, prev, have_prev, L, lane, wib, WAVES_PER_BLOCK, [&]( float4 P, int j )
-    { consider<GATED>( P, j, L, qx, qy, qz, nx, ny, nz, tmin, bound, m, seen_closer ); } );
+    sweep_shell<GATED>( g, cur, prev, have_prev, L, lane, wib, WAVES_PER_BLOCK, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
+    { consider4<GATED>( X, Y, Z, k4, L, qx, qy, qz, nx, ny, nz, tmin, bound, m, seen_closer ); } );
     // merge the per-lane bests of the waves; every wave continues with the merged best
     C.m_d2[wib][lane] = m.d2; C.m_idx[wib][lane] = m.idx; C.m_dot[wib][lane] = m.dot; C.m_slot[wib][lane] = m.found ? m.slot : -1;
     __syncthreads();
@@ -449,13 +487,8 @@ __device__ __forceinline__ Match coop_search( const GridView& g, bool active,
     if( __any( need_rank ) )
     {
       int rank = 0;
-      sweep_shell<false>( g, cur, cur, false, L, lane, wib, WAVES_PER_BLOCK, [&]( float4 P, int )
-      {
-        float vx = P.x - qx, vy = P.y - qy, vz = P.z - qz;
-        float d2 = vx * vx + vy * vy + vz * vz;
-        int idx = __float_as_int( P.w );
-        rank += ( need_rank & ( d2 < radius_sq ) & lex_less( d2, idx, m.d2, m.idx ) ) ? 1 : 0;
-      } );
+      sweep_shell<false>( g, cur, cur, false, L, lane, wib, WAVES_PER_BLOCK, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
+      { rank += need_rank ? precede4( X, Y, Z, k4, L, qx, qy, qz, radius_sq, m.d2, m.idx ) : 0; } );
       __syncthreads();                             // everyone is done reading the counts
       C.m_cnt[wib][lane] = rank;
       __syncthreads();
@@ -898,12 +931,16 @@ __global__ __launch_bounds__( BLOCK ) void k_rows( RowsLaunch L )
   {
     if( !__any( more ) ) break;
     float bd2 = INFINITY; int bidx = INT_MAX;
-    sweep_shell<false>( L.tgt, box, box, false, lds[wib], lane, 0, 1, [&]( float4 P, int )
+    sweep_shell<false>( L.tgt, box, box, false, lds[wib], lane, 0, 1, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
     {
-      float vx = P.x - q.x, vy = P.y - q.y, vz = P.z - q.z;
-      float d2 = vx * vx + vy * vy + vz * vz;
-      int idx = __float_as_int( P.w );
-      if( (int)more & (int)( d2 < L.radius_sq ) & (int)lex_less( pd2, pidx, d2, idx ) & (int)lex_less( d2, idx, bd2, bidx ) ) { bd2 = d2; bidx = idx; }
+      float d[4];
+      dist2x4( X, Y, Z, q.x, q.y, q.z, d[0], d[1], d[2], d[3] );
+#pragma unroll
+      for( int c = 0; c < 4; ++c )
+      {
+        const int idx = lds[wib].pidx[k4 + c];
+        if( (int)more & (int)( d[c] < L.radius_sq ) & (int)lex_less( pd2, pidx, d[c], idx ) & (int)lex_less( d[c], idx, bd2, bidx ) ) { bd2 = d[c]; bidx = idx; }
+      }
     } );
     if( more )
     {
