@@ -640,6 +640,7 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
   {
     if( ( rc = icp_upload_state( cx, T, active ) ) ) return rc;
     icp_set_radius( cx, max_dist, tmin );
+    cx.L.warm = ( i > 0 && !getenv( "RS_HIP_NO_WARM" ) ) ? 1 : 0;   // every active problem wrote m_slot in iteration i-1
     static DevBuf dbgbuf;
     if( getenv( "RS_HIP_DEBUG_CYCLES" ) && n == 1 ) { dbgbuf.ensure( (size_t)cx.n_waves * 16 ); cx.L.dbg = dbgbuf.as<unsigned long long>(); }
     { ProfScope ps( "nn_icp" ); launch_icp_corr( cx.L, g_stream ); }

@@ -70,6 +70,7 @@ struct IcpLaunch
   int*    queue;        // n_prob x n_tiles : tiles handed to the cooperative kernel
   int*    queue_count;  // n_prob
   int     solo_stages;  // candidates a lone wave streams before handing an unsettled tile off
+  int     warm;         // m_slot holds last iteration's matches: use them as starting candidates
   unsigned long long* dbg;   // diagnostic builds only: per-tile {cycles, candidates} of phase A (null otherwise)
   const float* w_explicit;   // if non-null: weights given per query (estimate-only entry point)
 };

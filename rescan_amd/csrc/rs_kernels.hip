@@ -368,9 +368,11 @@ template <bool GATED>
 __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
                                               float qx, float qy, float qz, float nx, float ny, float nz,
                                               float radius, float radius_sq, float tmin, int K,
-                                              WaveLds& L, int lane, int max_stages, bool* handoff, int* dbg_unsettled = nullptr )
+                                              WaveLds& L, int lane, int max_stages, bool* handoff, int* dbg_unsettled = nullptr,
+                                              const Match* init = nullptr )
 {
   Match m; m.d2 = INFINITY; m.idx = INT_MAX; m.dot = 0.0f; m.slot = -1; m.found = false;
+  if( init ) m = *init;     // a genuine candidate (within radius, gate passed): it only tightens the bounds
   if( handoff ) *handoff = false;
   const TileBounds tb = wave_bounds( active, qx, qy, qz );
   if( !tb.any ) return m;
@@ -385,7 +387,9 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
   CellBox cur = core, prev = core;
   bool have_prev = false;
   uint32_t streamed = 0;
-  for( int k = 1; ; k *= 2 )
+  // shells: the tile's own cells first (they hold the nearest candidates, so the per-lane bounds are
+  // tight before the bulk arrives), then grown by 1, 2, 4, ... cells
+  for( int k = 0; ; k = k ? 2 * k : 1 )
   {
     cur = ( g.inv_cell > 0.0f ) ? box_grow( core, k, full ) : full;
     streamed += sweep_shell<GATED>( g, cur, prev, have_prev, L, lane, 0, 1, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
@@ -437,9 +441,10 @@ template <bool GATED>
 __device__ __forceinline__ Match coop_search( const GridView& g, bool active,
                                               float qx, float qy, float qz, float nx, float ny, float nz,
                                               float radius, float radius_sq, float tmin, int K,
-                                              WaveLds& L, CoopLds& C, int wib, int lane )
+                                              WaveLds& L, CoopLds& C, int wib, int lane, const Match* init = nullptr )
 {
   Match m; m.d2 = INFINITY; m.idx = INT_MAX; m.dot = 0.0f; m.slot = -1; m.found = false;
+  if( init ) m = *init;
   const TileBounds tb = wave_bounds( active, qx, qy, qz );
   if( !tb.any ) return m;                          // identical in every wave of the workgroup
   const CellBox full = cell_box( g, tb, radius );
@@ -452,7 +457,9 @@ __device__ __forceinline__ Match coop_search( const GridView& g, bool active,
   float bound = bound_of( active, radius_sq, m );
   CellBox cur = core, prev = core;
   bool have_prev = false;
-  for( int k = 1; ; k *= 2 )
+  // shells: the tile's own cells first (they hold the nearest candidates, so the per-lane bounds are
+  // tight before the bulk arrives), then grown by 1, 2, 4, ... cells
+  for( int k = 0; ; k = k ? 2 * k : 1 )
   {
     cur = ( g.inv_cell > 0.0f ) ? box_grow( core, k, full ) : full;
     sweep_shell<GATED>( g, cur, prev, have_prev, L, lane, wib, WAVES_PER_BLOCK, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
@@ -519,6 +526,26 @@ __device__ __forceinline__ void icp_query( const IcpLaunch& L, const Xform& T1, 
   }
 }
 
+// Warm start (iterations >= 2): last iteration's match of this source point, re-evaluated under
+// the current pose.  If it is still within the radius and passes the gate it is a legitimate
+// candidate, so starting the search from it changes nothing in the result and lets most
+// candidates fail the very first compare.
+__device__ __forceinline__ Match icp_warm_start( const IcpLaunch& L, int prob, int i, bool active,
+                                                 float qx, float qy, float qz, float nx, float ny, float nz )
+{
+  Match m; m.d2 = INFINITY; m.idx = INT_MAX; m.dot = 0.0f; m.slot = -1; m.found = false;
+  if( !L.warm || !active ) return m;
+  const int s = L.m_slot[(size_t)prob * L.src.n + i];
+  if( s < 0 ) return m;
+  const float4 P = L.tgt.pos[s], N = L.tgt.nor[s];
+  float vx = P.x - qx, vy = P.y - qy, vz = P.z - qz;
+  float d2 = vx * vx + vy * vy + vz * vz;
+  float dot = N.x * nx + N.y * ny + N.z * nz;
+  float dc = dot > 0.0f ? dot : 0.0f;
+  if( d2 < L.radius_sq && dc >= L.gate_tmin && dc <= 1.0f ) { m.d2 = d2; m.idx = __float_as_int( P.w ); m.dot = dc; m.slot = s; m.found = true; }
+  return m;
+}
+
 __device__ __forceinline__ void icp_emit( const IcpLaunch& L, int prob, int tile, int i, bool active, int lane, const Match& m )
 {
   const size_t o = (size_t)prob * L.src.n + i;
@@ -556,8 +583,9 @@ __global__ __launch_bounds__( BLOCK, 8 ) void k_icp_corr( IcpLaunch L )
   icp_query( L, T1, i, active, qx, qy, qz, nx, ny, nz );
   bool handoff;
   int unsettled = 0;
+  const Match init = icp_warm_start( L, prob, i, active, qx, qy, qz, nx, ny, nz );
   Match m = tile_search<true>( L.tgt, active, qx, qy, qz, nx, ny, nz, L.radius, L.radius_sq, L.gate_tmin, L.K,
-                               lds[wib], lane, L.solo_stages, &handoff, L.dbg ? &unsettled : nullptr );
+                               lds[wib], lane, L.solo_stages, &handoff, L.dbg ? &unsettled : nullptr, &init );
   if( L.dbg && lane == 0 ) { L.dbg[2 * tile] = wall_clock64() - t_begin; L.dbg[2 * tile + 1] = (unsigned long long)unsettled; }
   if( handoff )
   {
@@ -587,8 +615,9 @@ __global__ __launch_bounds__( BLOCK ) void k_icp_corr_coop( IcpLaunch L )
     const bool active = i < (int)L.src.tiles[tile + 1];
     float qx, qy, qz, nx, ny, nz;
     icp_query( L, T1, i, active, qx, qy, qz, nx, ny, nz );
+    const Match init = icp_warm_start( L, prob, i, active, qx, qy, qz, nx, ny, nz );
     Match m = coop_search<true>( L.tgt, active, qx, qy, qz, nx, ny, nz, L.radius, L.radius_sq, L.gate_tmin, L.K,
-                                 lds[wib], coop, wib, lane );
+                                 lds[wib], coop, wib, lane, &init );
     if( wib == 0 ) icp_emit( L, prob, tile, i, active, lane, m );
     __syncthreads();                               // merge slots are reused by the next queued tile
   }
