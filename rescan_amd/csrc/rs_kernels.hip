@@ -42,6 +42,8 @@ namespace rs {
 #define WAVE 64
 #define BLOCK 256
 #define WAVES_PER_BLOCK (BLOCK / WAVE)
+#define COOP_WAVES 4                 // waves that share one queued (cluttered) tile
+#define COOP_BLOCK (COOP_WAVES * WAVE)
 
 // ------------------------------------------------------------------------------------------
 // helpers
@@ -197,6 +199,9 @@ __device__ __forceinline__ uint32_t sweep_shell( const GridView& g, const CellBo
   const int ny = out.y1 - out.y0 + 1, nz = out.z1 - out.z0 + 1;
   const int n_rows = ny * nz;
   uint32_t streamed = 0;
+  // (Cooperating waves all enumerate the same rows and split the chunks; giving each wave whole
+  //  row batches instead balanced worse and measured slower.)
+  const int c_share = share, c_nshare = n_share;
   for( int r0 = 0; r0 < n_rows; r0 += WAVE )
   {
     // each lane describes one (y,z) row of cells: up to two x-pieces
@@ -238,8 +243,8 @@ __device__ __forceinline__ uint32_t sweep_shell( const GridView& g, const CellBo
         if( WITH_NOR ) N = g.nor[src];
       }
     };
-    const uint32_t stride = (uint32_t)n_share * WAVE;
-    uint32_t c0 = (uint32_t)share * WAVE;
+    const uint32_t stride = (uint32_t)c_nshare * WAVE;
+    uint32_t c0 = (uint32_t)c_share * WAVE;
     float4 P, N; uint32_t src;
     if( c0 < total ) fetch( c0, P, N, src );
     while( c0 < total )
@@ -400,8 +405,15 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
     const bool settled = !active | ( cov >= radius ) | ( m.found & ( cov > 0.0f ) & ( m.d2 < cov * cov ) );
     if( dbg_unsettled && k == 1 ) *dbg_unsettled = __popcll( __ballot( !settled ) );
     if( !__any( !settled ) ) break;
-    // Unsettled in a populated neighbourhood: the rest of the box is heavy, let a whole workgroup do it.
-    if( handoff && streamed >= (uint32_t)max_stages ) { *handoff = true; return m; }
+    // Unsettled in a populated neighbourhood, or facing a shell of many cell rows: the rest of the
+    // box is heavy (or latency-bound for one wave), let a whole workgroup do it.
+    if( handoff && max_stages != 0x7fffffff )
+    {
+      const int kn = k ? 2 * k : 1;
+      const CellBox nxt = box_grow( core, kn, full );
+      const int next_rows = ( nxt.y1 - nxt.y0 + 1 ) * ( nxt.z1 - nxt.z0 + 1 );
+      if( streamed >= (uint32_t)max_stages || next_rows > 2 * WAVE ) { *handoff = true; return m; }
+    }
     prev = cur; have_prev = true;
   }
 
@@ -426,14 +438,14 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
 // Merge slots of the cooperative search.
 struct CoopLds
 {
-  float m_d2[WAVES_PER_BLOCK][WAVE];
-  int   m_idx[WAVES_PER_BLOCK][WAVE];
-  float m_dot[WAVES_PER_BLOCK][WAVE];
-  int   m_slot[WAVES_PER_BLOCK][WAVE];
-  int   m_cnt[WAVES_PER_BLOCK][WAVE];
+  float m_d2[COOP_WAVES][WAVE];
+  int   m_idx[COOP_WAVES][WAVE];
+  float m_dot[COOP_WAVES][WAVE];
+  int   m_slot[COOP_WAVES][WAVE];
+  int   m_cnt[COOP_WAVES][WAVE];
 };
 
-// The same staged search, done by all WAVES_PER_BLOCK waves of a workgroup for ONE tile: every
+// The same staged search, done by all COOP_WAVES waves of a workgroup for ONE tile: every
 // wave holds the same queries and sweeps its share of each shell's chunks; after every shell the
 // per-lane bests are merged through LDS, so all waves take the same continue/stop decision and
 // carry the tightest bound into the next shell.
@@ -462,13 +474,13 @@ __device__ __forceinline__ Match coop_search( const GridView& g, bool active,
   for( int k = 0; ; k = k ? 2 * k : 1 )
   {
     cur = ( g.inv_cell > 0.0f ) ? box_grow( core, k, full ) : full;
-    sweep_shell<GATED>( g, cur, prev, have_prev, L, lane, wib, WAVES_PER_BLOCK, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
+    sweep_shell<GATED>( g, cur, prev, have_prev, L, lane, wib, COOP_WAVES, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
     { consider4<GATED>( X, Y, Z, k4, L, qx, qy, qz, nx, ny, nz, tmin, bound, m, seen_closer ); } );
     // merge the per-lane bests of the waves; every wave continues with the merged best
     C.m_d2[wib][lane] = m.d2; C.m_idx[wib][lane] = m.idx; C.m_dot[wib][lane] = m.dot; C.m_slot[wib][lane] = m.found ? m.slot : -1;
     __syncthreads();
 #pragma unroll
-    for( int w = 0; w < WAVES_PER_BLOCK; ++w )
+    for( int w = 0; w < COOP_WAVES; ++w )
     {
       const float d = C.m_d2[w][lane]; const int ix = C.m_idx[w][lane]; const int sl = C.m_slot[w][lane];
       if( sl >= 0 && lex_less( d, ix, m.d2, m.idx ) ) { m.d2 = d; m.idx = ix; m.dot = C.m_dot[w][lane]; m.slot = sl; m.found = true; }
@@ -489,19 +501,19 @@ __device__ __forceinline__ Match coop_search( const GridView& g, bool active,
     __syncthreads();
     int seen_total = 0;
 #pragma unroll
-    for( int w = 0; w < WAVES_PER_BLOCK; ++w ) seen_total += C.m_cnt[w][lane];
+    for( int w = 0; w < COOP_WAVES; ++w ) seen_total += C.m_cnt[w][lane];
     bool need_rank = m.found && ( seen_total - 1 >= K );
     if( __any( need_rank ) )
     {
       int rank = 0;
-      sweep_shell<false>( g, cur, cur, false, L, lane, wib, WAVES_PER_BLOCK, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
+      sweep_shell<false>( g, cur, cur, false, L, lane, wib, COOP_WAVES, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
       { rank += need_rank ? precede4( X, Y, Z, k4, L, qx, qy, qz, radius_sq, m.d2, m.idx ) : 0; } );
       __syncthreads();                             // everyone is done reading the counts
       C.m_cnt[wib][lane] = rank;
       __syncthreads();
       rank = 0;
 #pragma unroll
-      for( int w = 0; w < WAVES_PER_BLOCK; ++w ) rank += C.m_cnt[w][lane];
+      for( int w = 0; w < COOP_WAVES; ++w ) rank += C.m_cnt[w][lane];
       if( need_rank && rank >= K ) { m.found = false; m.slot = -1; }
     }
   }
@@ -596,9 +608,9 @@ __global__ __launch_bounds__( BLOCK, 8 ) void k_icp_corr( IcpLaunch L )
 }
 
 // Phase B: one workgroup per queued tile, whole box, chunks shared by its waves.
-__global__ __launch_bounds__( BLOCK ) void k_icp_corr_coop( IcpLaunch L )
+__global__ __launch_bounds__( COOP_BLOCK ) void k_icp_corr_coop( IcpLaunch L )
 {
-  __shared__ WaveLds lds[WAVES_PER_BLOCK];
+  __shared__ WaveLds lds[COOP_WAVES];
   __shared__ CoopLds coop;
   const int prob = blockIdx.y;
   if( L.active[prob] == 0 ) return;
@@ -751,7 +763,7 @@ void launch_icp_corr( const IcpLaunch& L, hipStream_t st )
   hipLaunchKernelGGL( k_icp_corr, grid, dim3( BLOCK ), 0, st, L );
   // the queue length is only known on the device: a fixed grid strides over it
   int coop_blocks = L.src.n_tiles < 2048 ? L.src.n_tiles : 2048;
-  hipLaunchKernelGGL( k_icp_corr_coop, dim3( coop_blocks > 0 ? coop_blocks : 1, L.n_prob ), dim3( BLOCK ), 0, st, L );
+  hipLaunchKernelGGL( k_icp_corr_coop, dim3( coop_blocks > 0 ? coop_blocks : 1, L.n_prob ), dim3( COOP_BLOCK ), 0, st, L );
 }
 void launch_icp_stats( const IcpLaunch& L, hipStream_t st )
 {
@@ -819,9 +831,9 @@ __global__ __launch_bounds__( BLOCK, 8 ) void k_score( ScoreLaunch L )
   score_emit( L, pose, tile, active, lane, m );
 }
 
-__global__ __launch_bounds__( BLOCK ) void k_score_coop( ScoreLaunch L )
+__global__ __launch_bounds__( COOP_BLOCK ) void k_score_coop( ScoreLaunch L )
 {
-  __shared__ WaveLds lds[WAVES_PER_BLOCK];
+  __shared__ WaveLds lds[COOP_WAVES];
   __shared__ CoopLds coop;
   const int lane = threadIdx.x & ( WAVE - 1 );
   const int wib = threadIdx.x / WAVE;
@@ -865,7 +877,7 @@ void launch_score( const ScoreLaunch& L, hipStream_t st )
   dim3 grid( ( L.obj.n_tiles + WAVES_PER_BLOCK - 1 ) / WAVES_PER_BLOCK, L.n_poses );
   hipLaunchKernelGGL( k_score, grid, dim3( BLOCK ), 0, st, L );
   long long items = (long long)L.obj.n_tiles * L.n_poses;
-  hipLaunchKernelGGL( k_score_coop, dim3( items < 4096 ? (int)( items > 0 ? items : 1 ) : 4096 ), dim3( BLOCK ), 0, st, L );
+  hipLaunchKernelGGL( k_score_coop, dim3( items < 4096 ? (int)( items > 0 ? items : 1 ) : 4096 ), dim3( COOP_BLOCK ), 0, st, L );
   hipLaunchKernelGGL( k_score_final, dim3( L.n_poses ), dim3( BLOCK ), 0, st, L );
 }
 
