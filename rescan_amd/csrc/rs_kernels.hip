@@ -275,6 +275,7 @@ __device__ __forceinline__ uint32_t sweep_shell( const GridView& g, const CellBo
 
 // Result of a search for one query.
 struct Match { float d2; int idx; float dot; int slot; bool found; };
+__device__ __forceinline__ Match no_match() { Match m; m.d2 = INFINITY; m.idx = INT_MAX; m.dot = 0.0f; m.slot = -1; m.found = false; return m; }
 
 typedef float f32x2 __attribute__(( ext_vector_type( 2 ) ));
 
@@ -373,11 +374,9 @@ template <bool GATED>
 __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
                                               float qx, float qy, float qz, float nx, float ny, float nz,
                                               float radius, float radius_sq, float tmin, int K,
-                                              WaveLds& L, int lane, int max_stages, bool* handoff, int* dbg_unsettled = nullptr,
-                                              const Match* init = nullptr )
+                                              WaveLds& L, int lane, int max_stages, bool* handoff, int* dbg_unsettled,
+                                              Match m /* starting candidate: empty, or a genuine one (within radius, gate passed) that only tightens the bounds */ )
 {
-  Match m; m.d2 = INFINITY; m.idx = INT_MAX; m.dot = 0.0f; m.slot = -1; m.found = false;
-  if( init ) m = *init;     // a genuine candidate (within radius, gate passed): it only tightens the bounds
   if( handoff ) *handoff = false;
   const TileBounds tb = wave_bounds( active, qx, qy, qz );
   if( !tb.any ) return m;
@@ -453,10 +452,8 @@ template <bool GATED>
 __device__ __forceinline__ Match coop_search( const GridView& g, bool active,
                                               float qx, float qy, float qz, float nx, float ny, float nz,
                                               float radius, float radius_sq, float tmin, int K,
-                                              WaveLds& L, CoopLds& C, int wib, int lane, const Match* init = nullptr )
+                                              WaveLds& L, CoopLds& C, int wib, int lane, Match m /* starting candidate, see tile_search */ )
 {
-  Match m; m.d2 = INFINITY; m.idx = INT_MAX; m.dot = 0.0f; m.slot = -1; m.found = false;
-  if( init ) m = *init;
   const TileBounds tb = wave_bounds( active, qx, qy, qz );
   if( !tb.any ) return m;                          // identical in every wave of the workgroup
   const CellBox full = cell_box( g, tb, radius );
@@ -545,7 +542,7 @@ __device__ __forceinline__ void icp_query( const IcpLaunch& L, const Xform& T1, 
 __device__ __forceinline__ Match icp_warm_start( const IcpLaunch& L, int prob, int i, bool active,
                                                  float qx, float qy, float qz, float nx, float ny, float nz )
 {
-  Match m; m.d2 = INFINITY; m.idx = INT_MAX; m.dot = 0.0f; m.slot = -1; m.found = false;
+  Match m = no_match();
   if( !L.warm || !active ) return m;
   const int s = L.m_slot[(size_t)prob * L.src.n + i];
   if( s < 0 ) return m;
@@ -575,7 +572,7 @@ __device__ __forceinline__ void icp_emit( const IcpLaunch& L, int prob, int tile
 }
 
 // Phase A: one wave per tile, first shell(s) only; unsettled tiles are queued.
-__global__ __launch_bounds__( BLOCK, 8 ) void k_icp_corr( IcpLaunch L )
+__global__ __launch_bounds__( BLOCK, 6 ) void k_icp_corr( IcpLaunch L )
 {
   __shared__ WaveLds lds[WAVES_PER_BLOCK];
   const int prob = blockIdx.y;
@@ -597,7 +594,7 @@ __global__ __launch_bounds__( BLOCK, 8 ) void k_icp_corr( IcpLaunch L )
   int unsettled = 0;
   const Match init = icp_warm_start( L, prob, i, active, qx, qy, qz, nx, ny, nz );
   Match m = tile_search<true>( L.tgt, active, qx, qy, qz, nx, ny, nz, L.radius, L.radius_sq, L.gate_tmin, L.K,
-                               lds[wib], lane, L.solo_stages, &handoff, L.dbg ? &unsettled : nullptr, &init );
+                               lds[wib], lane, L.solo_stages, &handoff, L.dbg ? &unsettled : nullptr, init );
   if( L.dbg && lane == 0 ) { L.dbg[2 * tile] = wall_clock64() - t_begin; L.dbg[2 * tile + 1] = (unsigned long long)unsettled; }
   if( handoff )
   {
@@ -629,7 +626,7 @@ __global__ __launch_bounds__( COOP_BLOCK ) void k_icp_corr_coop( IcpLaunch L )
     icp_query( L, T1, i, active, qx, qy, qz, nx, ny, nz );
     const Match init = icp_warm_start( L, prob, i, active, qx, qy, qz, nx, ny, nz );
     Match m = coop_search<true>( L.tgt, active, qx, qy, qz, nx, ny, nz, L.radius, L.radius_sq, L.gate_tmin, L.K,
-                                 lds[wib], coop, wib, lane, &init );
+                                 lds[wib], coop, wib, lane, init );
     if( wib == 0 ) icp_emit( L, prob, tile, i, active, lane, m );
     __syncthreads();                               // merge slots are reused by the next queued tile
   }
@@ -805,7 +802,7 @@ __device__ __forceinline__ void score_emit( const ScoreLaunch& L, int pose, int 
   if( lane == 0 ) L.part[(size_t)pose * L.obj.n_tiles + tile] = s;
 }
 
-__global__ __launch_bounds__( BLOCK, 8 ) void k_score( ScoreLaunch L )
+__global__ __launch_bounds__( BLOCK, 6 ) void k_score( ScoreLaunch L )
 {
   __shared__ WaveLds lds[WAVES_PER_BLOCK];
   const int pose = blockIdx.y;
@@ -822,7 +819,7 @@ __global__ __launch_bounds__( BLOCK, 8 ) void k_score( ScoreLaunch L )
   score_query( L, X, i, active, qx, qy, qz, nx, ny, nz );
   bool handoff;
   Match m = tile_search<true>( L.scene, active, qx, qy, qz, nx, ny, nz, (float)L.sigma, L.radius_sq, L.gate_tmin, L.K,
-                               lds[wib], lane, L.solo_stages, &handoff );
+                               lds[wib], lane, L.solo_stages, &handoff, nullptr, no_match() );
   if( handoff )
   {
     if( lane == 0 ) { int q = atomicAdd( L.queue_count, 1 ); L.queue[q] = pose * L.obj.n_tiles + tile; }
@@ -850,7 +847,7 @@ __global__ __launch_bounds__( COOP_BLOCK ) void k_score_coop( ScoreLaunch L )
     float qx, qy, qz, nx, ny, nz;
     score_query( L, X, i, active, qx, qy, qz, nx, ny, nz );
     Match m = coop_search<true>( L.scene, active, qx, qy, qz, nx, ny, nz, (float)L.sigma, L.radius_sq, L.gate_tmin, L.K,
-                                 lds[wib], coop, wib, lane );
+                                 lds[wib], coop, wib, lane, no_match() );
     if( wib == 0 ) score_emit( L, pose, tile, active, lane, m );
     __syncthreads();
   }
@@ -895,7 +892,7 @@ __device__ __forceinline__ void unit3( float& x, float& y, float& z )
   x = x * inv; y = y * inv; z = z * inv;
 }
 
-__global__ __launch_bounds__( BLOCK, 8 ) void k_label( LabelLaunch L )
+__global__ __launch_bounds__( BLOCK, 6 ) void k_label( LabelLaunch L )
 {
   __shared__ WaveLds lds[WAVES_PER_BLOCK];
   const int lane = threadIdx.x & ( WAVE - 1 );
@@ -918,7 +915,7 @@ __global__ __launch_bounds__( BLOCK, 8 ) void k_label( LabelLaunch L )
     float qx, qy, qz;
     xform3( pl.inv, p.x, p.y, p.z, 1.0f, qx, qy, qz );                         // :755
     Match m = tile_search<false>( pl.g, active, qx, qy, qz, 0.0f, 0.0f, 0.0f, pl.radius, pl.radius_sq, 0.0f, 1,
-                                  lds[wib], lane, 0, nullptr );                // :758 (K = 1)
+                                  lds[wib], lane, 0, nullptr, nullptr, no_match() );   // :758 (K = 1)
     // :762-775 — found, strictly closer than the running minimum, and within 70° (either sign)
     bool ok = false;
     if( active && m.found && ( L.rows != nullptr || m.d2 < best_min ) )
