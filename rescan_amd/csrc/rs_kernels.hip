@@ -468,7 +468,10 @@ __device__ __forceinline__ Match coop_search( const GridView& g, bool active,
   bool have_prev = false;
   // shells: the tile's own cells first (they hold the nearest candidates, so the per-lane bounds are
   // tight before the bulk arrives), then grown by 1, 2, 4, ... cells
-  for( int k = 0; ; k = k ? 2 * k : 1 )
+  // Queued tiles were unsettled after the first shells in a populated neighbourhood; most of them
+  // have no match at all, so the ladder of small shells only adds row enumerations and barriers:
+  // one shell of two cells, then the whole box.
+  for( int k = 2; ; k = 1 << 20 )
   {
     cur = ( g.inv_cell > 0.0f ) ? box_grow( core, k, full ) : full;
     sweep_shell<GATED>( g, cur, prev, have_prev, L, lane, wib, COOP_WAVES, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
