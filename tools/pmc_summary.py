@@ -1,0 +1,32 @@
+"""Summaries of rocprofv3 --pmc CSVs (per kernel, averaged over launches)."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def per_kernel(path):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    cnt = collections.defaultdict(collections.Counter)
+    for r in csv.DictReader(open(path)):
+        k = r["Kernel_Name"].split("(")[0]
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        cnt[k][r["Counter_Name"]] += 1
+    return {k: {c: (v / cnt[k][c], cnt[k][c]) for c, v in d.items()} for k, d in agg.items()}
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--traffic":
+        out = {}
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            f = glob.glob(f"gpurun_out/pmc_{c}/*/*counter_collection.csv")[0]
+            out[c] = {k: v[c] for k, v in per_kernel(f).items() if c in v}
+        json.dump(out, open("gpurun_out/pmc_traffic_raw.json", "w"), indent=1)
+        for k in sorted(out["FETCH_SIZE"]):
+            print(k, "FETCH_SIZE avg KB", round(out["FETCH_SIZE"][k][0], 1),
+                  "WRITE_SIZE avg KB", round(out["WRITE_SIZE"].get(k, (0, 0))[0], 1))
+    else:
+        for k, d in per_kernel(sys.argv[1]).items():
+            if k.startswith("rs::"):
+                print(k, {c: round(v[0] / 1e6, 2) for c, v in d.items()}, "(millions per launch)")

@@ -1,0 +1,25 @@
+#!/bin/bash
+# Profiling recipes used for profiles/ (run on the GPU box through gpurun):
+#   bash tools/profile.sh stats     -> rocprofv3 --kernel-trace --stats of the bench command
+#   bash tools/profile.sh pmc       -> SQ instruction / wait counters per kernel
+#   bash tools/profile.sh traffic   -> FETCH_SIZE and WRITE_SIZE in separate passes -> gpurun_out/pmc_traffic_raw.json
+# rocprofv3 is given the program itself after `--` (python ...), never a shell or env wrapper.
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+mkdir -p gpurun_out
+case "$1" in
+stats)
+  rm -rf gpurun_out/prof_stats
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/prof_stats_bench.json 2> gpurun_out/prof_stats.err
+  head -14 "$(find gpurun_out/prof_stats -name '*kernel_stats.csv' | head -1)" | cut -c1-150 ;;
+pmc)
+  rm -rf gpurun_out/prof_pmc
+  rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d gpurun_out/prof_pmc -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --serial > /dev/null 2> gpurun_out/prof_pmc.err
+  python tools/pmc_summary.py "$(find gpurun_out/prof_pmc -name '*counter_collection.csv' | head -1)" ;;
+traffic)
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf gpurun_out/pmc_$c
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc_$c -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --serial > /dev/null 2> gpurun_out/pmc_$c.err
+  done
+  python tools/pmc_summary.py --traffic ;;
+*) echo "usage: $0 stats|pmc|traffic" ;;
+esac
