@@ -1,0 +1,93 @@
+"""The drop-in claim at application level: the reference's own apps/pose_proposal, compiled
+UNMODIFIED from /root/reference with shadow/icp first on the include path and linked against
+librescan_dropin.so (oracle/Makefile: _ref/pose_proposal_hip), against the same sources built
+the reference's way (_ref/pose_proposal), on a synthetic 2-timestep scene (BASELINE.json
+configs[0]).  The binaries are built in the container that has /root/reference and travel to
+the GPU box as prebuilt files; the test skips where they are absent."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+REF = os.path.join(ROOT, "oracle", "_ref")
+BINS = [os.path.join(REF, b) for b in ("seg2rsdb", "pose_proposal", "pose_proposal_hip")]
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not all(os.path.exists(b) for b in BINS), reason="oracle/_ref apps not built")]
+
+
+def write_ply(path, s):
+    n = len(s["points"])
+    hdr = ("ply\nformat binary_little_endian 1.0\nelement vertex %d\n"
+           "property float x\nproperty float y\nproperty float z\nproperty float nx\nproperty float ny\nproperty float nz\n"
+           "property uchar red\nproperty uchar green\nproperty uchar blue\nproperty float radius\n"
+           "property int class_idx\nproperty int instance_idx\nend_header\n") % n
+    dt = np.dtype([("p", "<f4", 3), ("n", "<f4", 3), ("c", "u1", 3), ("r", "<f4"), ("cls", "<i4"), ("inst", "<i4")])
+    a = np.zeros(n, dt)
+    a["p"] = s["points"]; a["n"] = s["normals"]; a["c"] = 128; a["r"] = 0.01
+    a["cls"] = s["class_idx"]; a["inst"] = s["instance_idx"]
+    with open(path, "wb") as f:
+        f.write(hdr.encode()); f.write(a.tobytes())
+
+
+def read_pose_bin(path):
+    """apps/pose_proposal/main.cpp:61-89: int32 n_obj; int32 count[n_obj]; {float[16] pose; float score} x sum(count)."""
+    b = open(path, "rb").read()
+    n = struct.unpack("<i", b[:4])[0]
+    counts = struct.unpack("<%di" % n, b[4:4 + 4 * n])
+    off = 4 + 4 * n
+    out = []
+    for c in counts:
+        rec = np.frombuffer(b[off:off + 68 * c], np.float32).reshape(c, 17)
+        off += 68 * c
+        out.append(rec)
+    return out
+
+
+def test_pose_proposal_app_links_against_the_shim(tmp_path):
+    from rescan_amd import synth
+    seq = tmp_path / "seq"
+    seq.mkdir()
+    for t in (0, 1):
+        write_ply(str(seq / f"t{t}.ply"), synth.make_scene(seed=7, density=2000.0, timestep=t))
+    with open(tmp_path / "classes.rsdb", "w") as f:
+        f.write("rsdb 0.1\n")
+        for k, v in synth.CLASS_IDX.items():
+            f.write(f"class {k} {v}\n")
+    run = lambda *a: subprocess.run(list(a), cwd=str(tmp_path), capture_output=True, text=True, timeout=900)  # noqa: E731
+    r = run(BINS[0], "seq/t0.ply", "classes.rsdb", "seq/t0.rsdb", "-v")
+    assert os.path.exists(seq / "t0.rsdb"), r.stdout[-500:] + r.stderr[-500:]      # (its exit code is unreliable)
+    cpu = run(BINS[1], "seq/t0.rsdb", "seq/t1.ply", "seq/t1_cpu.rsdb", "-v")
+    assert cpu.returncode == 0, cpu.stdout[-800:]
+    hip = run(BINS[2], "seq/t0.rsdb", "seq/t1.ply", "seq/t1_hip.rsdb", "-v")
+    assert hip.returncode == 0, hip.stdout[-800:] + hip.stderr[-800:]
+    assert "[rescan_hip]" not in hip.stderr, hip.stderr[-800:]                      # the shim reported no failure
+    a = read_pose_bin(str(seq / "t1_cpu" / "t1_cpu.bin"))
+    b = read_pose_bin(str(seq / "t1_hip" / "t1_hip.bin"))
+    assert len(a) == len(b)
+    n_dyn = 0
+    worst = []
+    for pa, pb in zip(a, b):
+        assert len(pa) == len(pb), "different number of surviving proposals"
+        # Proposals are sorted by score; compare pose by pose.  The app refines on level-2 clouds (2 cm
+        # voxels, a few hundred points per chair) and stops on |d err| < 1e-5 (icp.h:489): where the fp64
+        # reduction and the reference's fp32 accumulators put that test on different sides, the two runs
+        # stop one iteration apart and the poses differ by a few 1e-4.  Proposals that explain the scan
+        # (score > 0.9) must stay within 1e-3 with a median under 1e-4 (the north-star tolerance, which
+        # the dense-cloud fixtures meet case by case); weak proposals are ICP runs from wrong start poses
+        # that end in poorly constrained minima and get 1e-2.
+        for ra, rb in zip(pa, pb):
+            dpose = np.linalg.norm(ra[:16].astype(np.float64) - rb[:16])
+            worst.append((float(ra[16]), dpose))
+            assert dpose < (1e-3 if ra[16] > 0.9 else 1e-2), (ra[16], dpose)
+            assert abs(float(ra[16]) - float(rb[16])) < (1e-3 if ra[16] > 0.9 else 1e-2)
+        n_dyn += len(pa) > 1
+    assert n_dyn >= 3                                   # table + two chairs were refined by icp_align
+    good = [d for sc, d in worst if 0.9 < sc < 9.0]
+    assert len(good) >= 3 and np.median(good) < 1e-4
+    print("pose deltas: good proposals median %.2e max %.2e, all max %.2e over %d proposals"
+          % (np.median(good), max(good), max(d for _, d in worst), len(worst)))
