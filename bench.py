@@ -101,23 +101,33 @@ def run_step(w, dist_ctx=None, concurrent=True):
     else:
         (err, T, it), scores, res = icp(), score(), label()
     if dist_ctx is not None:
-        # exchange step: every rank receives every rank's poses / scores / label partials
-        import torch
-        dist, dev = dist_ctx
-        small = torch.from_numpy(np.concatenate([T, [err], scores]).astype(np.float32)).to(dev)
-        out = [torch.empty_like(small) for _ in range(dist.get_world_size())]
-        dist.all_gather(out, small)
-        lab = torch.from_numpy(res["labels"]).to(dev)
-        mind = torch.from_numpy(res["min_dists"]).to(dev)
-        # scenes differ slightly in size across ranks: pad to a common length
-        n = torch.tensor([lab.numel()], device=dev)
-        dist.all_reduce(n, op=dist.ReduceOp.MAX)
-        padl = torch.zeros(int(n.item()), dtype=lab.dtype, device=dev); padl[: lab.numel()] = lab
-        padm = torch.zeros(int(n.item()), dtype=mind.dtype, device=dev); padm[: mind.numel()] = mind
-        gl = [torch.empty_like(padl) for _ in range(dist.get_world_size())]
-        gm = [torch.empty_like(padm) for _ in range(dist.get_world_size())]
-        dist.all_gather(gl, padl); dist.all_gather(gm, padm)
+        exchange_results(dist_ctx[0], dist_ctx[1], T, err, scores, res)
     return err, T, scores, res
+
+
+def exchange_results(dist, dev, T, err, scores, res):
+    """The exchange step of the multi-GPU path (north_star: 'RCCL all-gather of the resulting 4x4
+    poses / unary cost rows'): every rank receives every rank's pose + error + scores and label
+    partials (labels int8 + min_dists f32).  Scene sizes differ slightly across ranks, so the label
+    arrays are padded to the common maximum.  Returns what rank-local code would consume."""
+    import torch
+    world = dist.get_world_size()
+    small = torch.from_numpy(np.concatenate([np.asarray(T, np.float32).ravel(), [np.float32(err)],
+                                             np.asarray(scores, np.float32)]).astype(np.float32)).to(dev)
+    out = [torch.empty_like(small) for _ in range(world)]
+    dist.all_gather(out, small)
+    lab = torch.from_numpy(np.ascontiguousarray(res["labels"])).to(dev)
+    mind = torch.from_numpy(np.ascontiguousarray(res["min_dists"])).to(dev)
+    n = torch.tensor([lab.numel()], device=dev, dtype=torch.int64)
+    dist.all_reduce(n, op=dist.ReduceOp.MAX)
+    nmax = int(n.item())
+    padl = torch.zeros(nmax, dtype=lab.dtype, device=dev); padl[: lab.numel()] = lab
+    padm = torch.full((nmax,), 1e9, dtype=mind.dtype, device=dev); padm[: mind.numel()] = mind
+    gl = [torch.empty_like(padl) for _ in range(world)]
+    gm = [torch.empty_like(padm) for _ in range(world)]
+    dist.all_gather(gl, padl)
+    dist.all_gather(gm, padm)
+    return out, gl, gm
 
 
 def cpu_baseline(w, budget_s=20.0):
