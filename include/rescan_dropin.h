@@ -92,6 +92,13 @@ int   rsd_arrangement_to_labels( const rsd_vec3_t* scn_pos, const rsd_vec3_t* sc
                                  const rsd_mat4_t* poses, const int32_t* is_static, const int32_t* class_idx, int32_t n_plc,
                                  float radius, bool prioritize_static, int8_t* labels, int32_t* sorted_order );
 
+/* rspf_compute_neighborhood (lib/rs/rs_pointcloud_filters.cpp:674-722) on pc->positions/normals[lvl]:
+ * fills the caller's edge arrays (capacity >= n*max_nn; the reference's hashtable would hold as many),
+ * idx1/idx2/weight being the fields of its edge_t (:664-669).  Returns the edge count (< 0: error). */
+int64_t rsd_compute_neighborhood( const rsd_vec3_t* pos, const rsd_vec3_t* nor, int32_t n,
+                                  int32_t max_nn, float radius_sq, float dist_exp, float angle_exp,
+                                  int32_t* idx1, int32_t* idx2, float* weight );
+
 /* Drop every cached device cloud (the shim caches uploads by host pointer + content hash). */
 void  rsd_cache_clear( void );
 

@@ -155,6 +155,19 @@ int rs_hip_arrangement_to_labels( const rs_hip_cloud_t* scene,
                                   float radius, int prioritize_static,
                                   int8_t* labels, float* min_dists, int32_t* sorted_order );
 
+/* ---- neighbourhood graph ------------------------------------------ */
+
+/* rspf_compute_neighborhood (lib/rs/rs_pointcloud_filters.cpp:674-722): K = max_nn self-search
+ * within sqrt(radius_sq) over `cloud` (needs normals), one weighted edge per (point, neighbour),
+ * de-duplicated so that every undirected pair appears once, oriented as the reference's insertion
+ * order leaves it ({i,j}, i<j, is (i,j) when j is among i's neighbours, (j,i) otherwise); self pairs
+ * (i,i) are included, as in the reference.  weight = (1 - pow(d²/(4 r²), dist_exp)) *
+ * powf(clamp(n·m,0,1), angle_exp) (the reference calls it with 8, 0.05², 15, 16).
+ * Edges are written ordered by idx1, then by (dist², idx2); capacity must be >= n*max_nn. */
+int rs_hip_compute_neighborhood( const rs_hip_cloud_t* cloud, int32_t max_nn, float radius_sq,
+                                 float dist_exp, float angle_exp,
+                                 int32_t* idx1, int32_t* idx2, float* weight, int64_t capacity, int64_t* n_edges );
+
 /* ---- host-side helpers shared by the drop-in shim (exact reference arithmetic) ------- */
 
 /* msh_mat4_inverse / msh_mat4_mul (lib/msh/msh_vec_math.h:1818-1905, 1441-1476) */

@@ -14,8 +14,12 @@ Each fixture holds the inputs and the reference's outputs for one hot-path funct
   labels_*.npz   rspf_arrangement_to_labels — produced by the C restatement (oracle/rs_oracle.c),
                  NOT by the reference: lib/rs/rs_pointcloud_filters.cpp needs the un-vendored gco
                  header and cannot be built here.  Its primitives are pinned by the files above.
+  edge_cost.npz  the neighbourhood edge weight (rs_pointcloud_filters.cpp:706-708) from the
+                 reference-toolchain TU oracle/ref_label_gate.cpp
+  neighborhood_*.npz  rspf_compute_neighborhood (:674-722) — by the C restatement, as for labels_*
 
-Usage:  python oracle/gen_golden.py
+Usage:  python oracle/gen_golden.py                       (everything)
+        python oracle/gen_golden.py --neighborhood-only   (adds the last two without rewriting the rest)
 """
 import os
 import sys
@@ -24,7 +28,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle.pyoracle import Oracle, Ref, build  # noqa: E402
+from oracle.pyoracle import Oracle, Ref, build, edge_digest  # noqa: E402
 from rescan_amd import synth  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
@@ -142,9 +146,40 @@ def main():
             labels=res["labels"], min_dists=res["min_dists"], order=res["order"],
             class_ids=res["class_ids"], instance_ids=res["instance_ids"])
 
+    gen_neighborhood(O, R, s)
+
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print(f"wrote {len(os.listdir(OUT))} fixtures, {total/1e6:.2f} MB")
 
 
+def gen_neighborhood(O, R, s):
+    """edge_cost.npz: rs_pointcloud_filters.cpp:706-708 evaluated by the reference-toolchain TU
+    (ref_label_gate.cpp: same math.h preamble).  neighborhood_*.npz: rspf_compute_neighborhood by the
+    C restatement (the TU itself needs gco-v3.0), full edge lists for the object clouds and a digest
+    for the scan."""
+    rng = np.random.default_rng(77)
+    d2 = np.concatenate([rng.uniform(0, 0.0025, 4000), [0.0, 0.0025, 0.0024999, 1e-12, 0.01]]).astype(np.float32)
+    dot = np.concatenate([rng.uniform(-0.2, 1.1, 4000), [1.0, 0.0, -1.0, 0.5, 0.999999]]).astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "edge_cost.npz"), d2=d2, dot=dot,
+                        cost=np.array([R.edge_cost(a, b) for a, b in zip(d2, dot)], np.float32))
+    for oi, o in enumerate(s["objects"]):
+        a, b, w = O.compute_neighborhood(o["pos"], o["nor"])
+        np.savez_compressed(os.path.join(OUT, f"neighborhood_obj{oi}.npz"), obj=oi, idx1=a, idx2=b, weight=w)
+    a, b, w = O.compute_neighborhood(s["points"], s["normals"])
+    np.savez_compressed(os.path.join(OUT, "neighborhood_scene.npz"), digest=edge_digest(a, b, w))
+
+
+def main_neighborhood_only():
+    """Adds the neighbourhood fixtures without rewriting the others (zip timestamps would churn them)."""
+    from oracle.pyoracle import Oracle, Ref
+    d = dict(np.load(os.path.join(OUT, "scene.npz")))
+    s = dict(points=d["points"], normals=d["normals"],
+             objects=[dict(pos=d[f"obj{i}_pos"], nor=d[f"obj{i}_nor"]) for i in range(int(d["n_obj"]))])
+    gen_neighborhood(Oracle(), Ref(), s)
+
+
 if __name__ == "__main__":
-    main()
+    if "--neighborhood-only" in sys.argv:
+        main_neighborhood_only()
+    else:
+        main()

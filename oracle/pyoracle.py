@@ -200,6 +200,25 @@ class Oracle(_Base):
             self.grid_destroy(g)
         return dict(labels=labels, min_dists=mind, order=order[:len(placements)], class_ids=cls, instance_ids=inst)
 
+    def compute_neighborhood(self, pos, nor, max_nn=8, radius_sq=0.0025, dist_exp=15.0, angle_exp=16.0):
+        """rspf_compute_neighborhood on a level-1 style cloud (grid radius 0.05).  Returns (idx1, idx2, weight)."""
+        pos, nor = _f32(pos), _f32(nor)
+        n = len(pos)
+        g = self.grid_create(pos, 0.05)
+        a = np.zeros(n * max_nn, np.int32); b = np.zeros(n * max_nn, np.int32); w = np.zeros(n * max_nn, np.float32)
+        f = self.lib.orc_compute_neighborhood
+        f.restype = C.c_int64
+        f.argtypes = [C.c_void_p, f32p, f32p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, i32p, i32p, f32p]
+        m = f(g, pos, nor, n, int(max_nn), float(radius_sq), float(dist_exp), float(angle_exp), a, b, w)
+        self.grid_destroy(g)
+        return a[:m].copy(), b[:m].copy(), w[:m].copy()
+
+    def edge_cost(self, d2, dot, radius_sq=0.0025, dist_exp=15.0, angle_exp=16.0):
+        f = self.lib.orc_edge_cost
+        f.restype = C.c_float
+        f.argtypes = [C.c_float] * 5
+        return f(float(d2), float(dot), float(radius_sq), float(dist_exp), float(angle_exp))
+
     def icp_gate(self, dot, max_angle):
         return self._icp_gate(float(dot), float(max_angle))
 
@@ -283,3 +302,16 @@ class Ref(_Base):
 
     def label_gate_dot(self, dot):
         return self._label_gate_dot(float(dot))
+
+    def edge_cost(self, d2, dot, radius_sq=0.0025, dist_exp=15.0, angle_exp=16.0):
+        f = self.lib.ref_edge_cost
+        f.restype = C.c_float
+        f.argtypes = [C.c_float] * 5
+        return f(float(d2), float(dot), float(radius_sq), float(dist_exp), float(angle_exp))
+
+
+def edge_digest(a, b, w):
+    """Order-independent digest of an edge list: count, sum of pair keys, sum of weight bit patterns."""
+    hi, lo = np.maximum(a, b).astype(np.int64), np.minimum(a, b).astype(np.int64)
+    return np.array([len(a), int((hi * 1000003 + lo).sum() % (1 << 61)), int(np.sort(w.view(np.uint32)).astype(np.int64).sum())],
+                    np.int64)

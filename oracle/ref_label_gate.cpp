@@ -41,3 +41,14 @@ extern "C" int ref_label_gate_dot( float dot )
   float angle = acos( fabs( dot ) );
   return ( angle < msh_deg2rad(70.0) ) ? 1 : 0;
 }
+
+// The edge weight of rspf_compute_neighborhood (lib/rs/rs_pointcloud_filters.cpp:706-708), spelled
+// as the reference spells it and compiled under the same preamble, so pow() resolves to the same
+// overloads (double pow for the distance term, powf for the float/float normal term).
+extern "C" float ref_edge_cost( float nn_dist, float dot_nm, float radius_sq, float dist_exp, float angle_exp )
+{
+  float dist_cost  = 1.0f - pow(nn_dist/(4.0*radius_sq), dist_exp);
+  float norm_cost  = pow( msh_clamp(dot_nm, 0.0f, 1.0f), angle_exp);
+  float cost = dist_cost * norm_cost;
+  return cost;
+}

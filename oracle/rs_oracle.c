@@ -987,3 +987,69 @@ void orc_arrangement_to_labels( const float* scene_pos, const float* scene_nor, 
   }
   free( sorted ); free( rec );
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Neighbourhood graph  (lib/rs/rs_pointcloud_filters.cpp:674-722)
+ * ---------------------------------------------------------------------------------------- */
+
+/* :706-708 — in that TU pow(double, float) is the double pow and pow(float, float) is powf
+ * (checked in oracle/_ref: ref_edge_cost calls pow then powf). */
+float orc_edge_cost( float nn_dist, float dot_nm, float radius_sq, float dist_exp, float angle_exp )
+{
+  float dist_cost = (float)( 1.0f - pow( nn_dist / ( 4.0 * radius_sq ), dist_exp ) );
+  float c = dot_nm > 0.0f ? dot_nm : 0.0f;          /* msh_clamp( x, 0, 1 ) = min( max( x, 0 ), 1 ) */
+  c = c < 1.0f ? c : 1.0f;
+  float norm_cost = powf( c, angle_exp );
+  return dist_cost * norm_cost;
+}
+
+typedef struct { int32_t key; int64_t order; int32_t a, b; float w; } edge_rec;
+
+static int edge_rec_cmp( const void* x, const void* y )
+{
+  const edge_rec* p = (const edge_rec*)x; const edge_rec* q = (const edge_rec*)y;
+  if( p->key != q->key ) { return p->key < q->key ? -1 : 1; }
+  return ( p->order > q->order ) - ( p->order < q->order );
+}
+
+int64_t orc_compute_neighborhood( const orc_grid_t* grid, const float* pos, const float* nor, int32_t n,
+                                  int32_t max_nn, float radius_sq, float dist_exp, float angle_exp,
+                                  int32_t* idx1, int32_t* idx2, float* weight )
+{
+  size_t cap = (size_t)( n > 0 ? n : 1 ) * (size_t)max_nn;
+  float* d2 = (float*)malloc( cap * 4 );
+  int32_t* ix = (int32_t*)malloc( cap * 4 );
+  int64_t* nn = (int64_t*)malloc( (size_t)( n > 0 ? n : 1 ) * 8 );
+  /* :685-693 — radius = sqrt(radius_sq) (double sqrt narrowed to the float field), sort = 0 */
+  orc_radius_search( grid, pos, n, (float)sqrt( radius_sq ), max_nn, 0, d2, ix, nn );
+
+  edge_rec* rec = (edge_rec*)malloc( cap * sizeof(edge_rec) );
+  int64_t m = 0;
+  for( int32_t i = 0; i < n; ++i )                                             /* :696-714 */
+  {
+    v3 ni = v3_load( nor, i );
+    for( int64_t j = 0; j < nn[i]; ++j )
+    {
+      size_t at = (size_t)i * (size_t)max_nn + (size_t)j;
+      if( ix[at] < 0 || ix[at] > n ) { break; }                               /* :703 */
+      v3 mj = v3_load( nor, ix[at] );
+      edge_rec e;
+      e.a = i; e.b = ix[at];
+      e.w = orc_edge_cost( d2[at], v3_dot( ni, mj ), radius_sq, dist_exp, angle_exp );
+      int32_t hi = e.a > e.b ? e.a : e.b, lo = e.a < e.b ? e.a : e.b;
+      e.key = (int32_t)( (uint32_t)hi * (uint32_t)n + (uint32_t)lo );       /* :73-78, int32 wrap-around */
+      e.order = m;
+      rec[m++] = e;
+    }
+  }
+  /* :711-712 first insertion per key wins */
+  qsort( rec, (size_t)m, sizeof(edge_rec), edge_rec_cmp );
+  int64_t out = 0;
+  for( int64_t k = 0; k < m; ++k )
+  {
+    if( k > 0 && rec[k].key == rec[k-1].key ) { continue; }
+    idx1[out] = rec[k].a; idx2[out] = rec[k].b; weight[out] = rec[k].w; out++;
+  }
+  free( rec ); free( d2 ); free( ix ); free( nn );
+  return out;
+}

@@ -96,6 +96,17 @@ void orc_assign_labels( const float* scene_pos, const float* scene_nor, int32_t 
                         const orc_object_t* objects, const orc_placement_t* placements,
                         int32_t start, int32_t end, float radius, int8_t* labels, float* min_dists );
 
+/* rspf_compute_neighborhood (lib/rs/rs_pointcloud_filters.cpp:674-722): K = max_nn unsorted self-search
+ * over the cloud, one candidate edge per (point, neighbour) with weight
+ * (1 - pow(d²/(4 r²), dist_exp)) * powf(clamp(n·m, 0, 1), angle_exp); edges are de-duplicated by the
+ * int32 key max(i,j)*n + min(i,j) — first insertion wins, the key wraps for n > 46340 exactly as the
+ * reference's int arithmetic does.  Output: edges sorted by (key, then insertion order); returns the
+ * count.  idx1/idx2/weight have capacity n*max_nn. */
+int64_t orc_compute_neighborhood( const orc_grid_t* grid, const float* pos, const float* nor, int32_t n,
+                                  int32_t max_nn, float radius_sq, float dist_exp, float angle_exp,
+                                  int32_t* idx1, int32_t* idx2, float* weight );
+float orc_edge_cost( float nn_dist, float dot_nm, float radius_sq, float dist_exp, float angle_exp );   /* :706-708 */
+
 /* The three normal gates, on a raw dot value (for threshold pinning). */
 int orc_icp_gate( float dot, float max_angle );    /* lib/rs/icp.h:372-374 */
 int orc_score_gate( float dot );                   /* pose_proposal.cpp:138-141 */

@@ -45,6 +45,8 @@ SIGNATURES = {
     "rs_hip_combine_label_rows": (None, [f32p, C.c_int32, C.c_int64, C.c_int32, i8p, f32p]),
     "rs_hip_arrangement_to_labels": (C.c_int, [C.c_void_p, f32p, C.c_void_p, i32p, i32p, C.c_int32, C.c_float,
                                                C.c_int, i8p, f32p, i32p]),
+    "rs_hip_compute_neighborhood": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float, i32p, i32p, f32p,
+                                              C.c_int64, C.POINTER(C.c_int64)]),
     "rs_hip_mat4_inverse": (None, [f32p, f32p]),
     "rs_hip_mat4_mul": (None, [f32p, f32p, f32p]),
     "rs_hip_icp_estimate_pt2pl": (C.c_int, [f32p, f32p, f32p, f32p, C.c_int32, f32p, C.POINTER(C.c_float)]),
@@ -261,3 +263,13 @@ def mat4_inverse(m):
 
 def mat4_mul(a, b):
     o = np.empty(16, np.float32); load().rs_hip_mat4_mul(_f32(a).ravel(), _f32(b).ravel(), o); return o
+
+
+def compute_neighborhood(cloud, max_nn=8, radius_sq=0.05 * 0.05, dist_exp=15.0, angle_exp=16.0):
+    """rspf_compute_neighborhood: unique weighted edges (idx1, idx2, weight) of the K-nearest self-search."""
+    cap = max(1, cloud.n * max_nn)
+    a = np.zeros(cap, np.int32); b = np.zeros(cap, np.int32); w = np.zeros(cap, np.float32)
+    m = C.c_int64()
+    _check(load().rs_hip_compute_neighborhood(cloud.handle, int(max_nn), float(np.float32(radius_sq)), float(dist_exp),
+                                              float(angle_exp), a, b, w, cap, C.byref(m)))
+    return a[:m.value].copy(), b[:m.value].copy(), w[:m.value].copy()

@@ -98,6 +98,7 @@ struct Workspace
   DevBuf poses, score_part, scores;                                             // score
   DevBuf plc, labels, mind;                                                     // labels
   DevBuf q4, rd2, ridx, rnn, rows;                                              // rows / misc
+  DevBuf enor, ecount, eoffset, e1, e2, ew;                                     // neighbourhood edges
   DevBuf tmp_pos, tmp_pos2, tmp_nor2;                                           // estimate-only
   PinBuf h_a, h_b, h_c;
 };
@@ -999,3 +1000,50 @@ int rs_hip_radius_search( const rs_hip_cloud_t* target, const float* query, int6
 }
 
 } // extern "C"
+
+// ------------------------------------------------------------------------------------------
+// neighbourhood graph
+// ------------------------------------------------------------------------------------------
+
+extern "C" int rs_hip_compute_neighborhood( const rs_hip_cloud_t* cloud, int32_t max_nn, float radius_sq,
+                                            float dist_exp, float angle_exp,
+                                            int32_t* idx1, int32_t* idx2, float* weight, int64_t capacity, int64_t* n_edges )
+{
+  int rc = ensure_ready(); if( rc ) return rc;
+  if( !cloud || !cloud->has_nor || max_nn <= 0 || !( radius_sq > 0.0f ) || !idx1 || !idx2 || !weight || !n_edges )
+  { set_err( "compute_neighborhood: bad arguments" ); return RS_HIP_E_ARG; }
+  *n_edges = 0;
+  const int n = cloud->n, K = max_nn;
+  if( n == 0 ) return RS_HIP_OK;
+  if( capacity < (int64_t)n * K ) { set_err( "compute_neighborhood: capacity must be >= n*max_nn" ); return RS_HIP_E_ARG; }
+  const size_t nk = (size_t)n * K;
+  if( ( rc = g_ws.rd2.ensure( nk * 4 ) ) || ( rc = g_ws.ridx.ensure( nk * 4 ) ) || ( rc = g_ws.rnn.ensure( (size_t)n * 4 ) ) ||
+      ( rc = g_ws.enor.ensure( (size_t)n * 12 ) ) || ( rc = g_ws.ecount.ensure( (size_t)n * 4 ) ) || ( rc = g_ws.eoffset.ensure( ( (size_t)n + 1 ) * 4 ) ) ||
+      ( rc = g_ws.e1.ensure( nk * 4 ) ) || ( rc = g_ws.e2.ensure( nk * 4 ) ) || ( rc = g_ws.ew.ensure( nk * 4 ) ) )
+    return rc;
+  // 1. self-search rows (rs_pointcloud_filters.cpp:685-693): radius = (float)sqrt(radius_sq), K = max_nn
+  const float radius = (float)std::sqrt( (double)radius_sq );
+  RowsLaunch R{};
+  R.tgt = cloud->view; R.q = cloud->qview; R.K = K; R.radius = radius; R.radius_sq = radius_sq_of( radius );
+  R.d2 = g_ws.rd2.as<float>(); R.idx = g_ws.ridx.as<int>(); R.nn = g_ws.rnn.as<int>();
+  { ProfScope ps( "nn_rows" ); launch_rows( R, g_stream ); }
+  // 2. rows -> unique weighted edges
+  HIP_TRY( hipMemcpyAsync( g_ws.enor.p, cloud->h_nor.data(), (size_t)n * 12, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+  EdgeLaunch E{};
+  E.n = n; E.K = K; E.row_d2 = R.d2; E.row_idx = R.idx; E.row_nn = R.nn; E.nor = g_ws.enor.as<float>();
+  E.radius_sq = radius_sq; E.dist_exp = dist_exp; E.angle_exp = angle_exp;
+  auto small_int = []( float e ) { return ( e >= 0.0f && e <= 64.0f && e == std::floor( e ) ) ? (int)e : -1; };
+  E.dist_int = small_int( dist_exp ); E.angle_int = small_int( angle_exp );
+  E.count = g_ws.ecount.as<int>(); E.offset = g_ws.eoffset.as<unsigned>();
+  E.e1 = g_ws.e1.as<int>(); E.e2 = g_ws.e2.as<int>(); E.ew = g_ws.ew.as<float>();
+  { ProfScope ps( "edges" ); launch_edge_count( E, g_stream ); launch_edge_scan( E, g_stream ); launch_edge_write( E, g_stream ); }
+  unsigned total = 0;
+  HIP_TRY( hipMemcpyAsync( &total, E.offset + n, 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipMemcpyAsync( idx1, E.e1, (size_t)total * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipMemcpyAsync( idx2, E.e2, (size_t)total * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipMemcpyAsync( weight, E.ew, (size_t)total * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
+  *n_edges = (int64_t)total;
+  return RS_HIP_OK;
+}

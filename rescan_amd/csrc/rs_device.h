@@ -119,4 +119,22 @@ struct RowsLaunch
 };
 void launch_rows( const RowsLaunch& L, hipStream_t st );
 
+// Neighbourhood graph (rspf_compute_neighborhood): from self-search rows to unique weighted edges.
+struct EdgeLaunch
+{
+  int          n, K;
+  const float* row_d2;    // n x K  (original order, ascending)
+  const int*   row_idx;   // n x K
+  const int*   row_nn;    // n
+  const float* nor;       // original-order AoS normals, 3*n floats (device)
+  float        radius_sq, dist_exp, angle_exp;
+  int          dist_int, angle_int;   // exponents as small non-negative integers, or -1 (use pow/powf)
+  int*         count;     // n       : kept edges of row i
+  unsigned*    offset;    // n + 1   : exclusive scan of count
+  int*         e1; int* e2; float* ew;   // outputs
+};
+void launch_edge_count( const EdgeLaunch& L, hipStream_t st );   // fills count
+void launch_edge_scan( const EdgeLaunch& L, hipStream_t st );    // count -> offset (single workgroup, fixed order)
+void launch_edge_write( const EdgeLaunch& L, hipStream_t st );   // fills e1/e2/ew
+
 } // namespace rs

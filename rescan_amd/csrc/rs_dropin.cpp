@@ -219,4 +219,17 @@ int rsd_arrangement_to_labels( const rsd_vec3_t* scn_pos, const rsd_vec3_t* scn_
   return rc;
 }
 
+int64_t rsd_compute_neighborhood( const rsd_vec3_t* pos, const rsd_vec3_t* nor, int32_t n,
+                                  int32_t max_nn, float radius_sq, float dist_exp, float angle_exp,
+                                  int32_t* idx1, int32_t* idx2, float* weight )
+{
+  rs_hip_cloud_t* c = cached_cloud( pos, nor, n, -1.0f );
+  if( !c ) return RS_HIP_E_RUNTIME;
+  int64_t n_edges = 0;
+  int rc = rs_hip_compute_neighborhood( c, max_nn, radius_sq, dist_exp, angle_exp, idx1, idx2, weight,
+                                        (int64_t)n * max_nn, &n_edges );
+  if( rc ) { complain( "compute_neighborhood" ); return rc; }
+  return n_edges;
+}
+
 } // extern "C"

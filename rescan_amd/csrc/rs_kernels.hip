@@ -997,4 +997,121 @@ void launch_rows( const RowsLaunch& L, hipStream_t st )
   hipLaunchKernelGGL( k_rows, dim3( ( L.q.n_tiles + WAVES_PER_BLOCK - 1 ) / WAVES_PER_BLOCK ), dim3( BLOCK ), 0, st, L );
 }
 
+// ------------------------------------------------------------------------------------------
+// Neighbourhood graph  (lib/rs/rs_pointcloud_filters.cpp:674-722)
+// The K = 8 self-search is k_rows; these kernels turn its rows into the de-duplicated edge list.
+// Reference order: rows i ascending, first insertion of an undirected pair wins, so {i,j} (i<j)
+// is stored as (i,j) when j is in row i and as (j,i) otherwise.  Equivalent rule per directed
+// entry i -> j:  keep it iff  i <= j  or  i is not in row j.
+// (The reference's int32 key max*n+min wraps for n > 46340 and then drops whichever edges
+// collide; that accident is not reproduced — see DESIGN.md §4.)
+// ------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ bool edge_kept( const EdgeLaunch& L, int i, int j )
+{
+  if( i <= j ) return true;
+  const int nj = L.row_nn[j];
+  for( int t = 0; t < nj; ++t ) if( L.row_idx[(size_t)j * L.K + t] == i ) return false;
+  return true;
+}
+
+// x^e for a small integer e >= 0 in double-double arithmetic (error-free products via fma), rounded
+// once to double: agrees with a correctly rounded pow() for these arguments.
+__device__ __forceinline__ double powi_dd( double x, int e )
+{
+  double rh = 1.0, rl = 0.0, bh = x, bl = 0.0;
+  while( e > 0 )
+  {
+    if( e & 1 )
+    {
+      double ph = rh * bh, pl = fma( rh, bh, -ph ) + ( rh * bl + rl * bh );
+      double sh = ph + pl; rl = pl - ( sh - ph ); rh = sh;
+    }
+    e >>= 1;
+    if( e )
+    {
+      double ph = bh * bh, pl = fma( bh, bh, -ph ) + 2.0 * ( bh * bl );
+      double sh = ph + pl; bl = pl - ( sh - ph ); bh = sh;
+    }
+  }
+  return rh + rl;
+}
+
+// rs_pointcloud_filters.cpp:706-708: (float)(1.0f - pow( d2/(4.0*r2), dist_exp )) * powf( clamp(dot,0,1), angle_exp )
+__device__ __forceinline__ float edge_weight( const EdgeLaunch& L, float d2, float dot )
+{
+  const double y = (double)d2 / ( 4.0 * (double)L.radius_sq );
+  const double p = L.dist_int >= 0 ? powi_dd( y, L.dist_int ) : pow( y, (double)L.dist_exp );
+  const float dist_cost = (float)( 1.0 - p );
+  float c = dot > 0.0f ? dot : 0.0f;
+  c = c < 1.0f ? c : 1.0f;
+  float norm_cost;
+  if( L.angle_int >= 0 )
+  {
+    double b = c, r = 1.0; int e = L.angle_int;          // powf computes in double and rounds once
+    while( e > 0 ) { if( e & 1 ) r *= b; e >>= 1; if( e ) b *= b; }
+    norm_cost = (float)r;
+  }
+  else norm_cost = powf( c, L.angle_exp );
+  return dist_cost * norm_cost;
+}
+
+__global__ __launch_bounds__( BLOCK ) void k_edge_count( EdgeLaunch L )
+{
+  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  if( i >= L.n ) return;
+  int c = 0;
+  const int ni = L.row_nn[i];
+  for( int t = 0; t < ni; ++t ) c += edge_kept( L, i, L.row_idx[(size_t)i * L.K + t] ) ? 1 : 0;
+  L.count[i] = c;
+}
+
+// exclusive scan of count[0..n) by one workgroup: each thread sums a contiguous slice, the slice
+// totals are scanned through LDS, then each thread writes its slice.  Fixed order, no atomics.
+__global__ __launch_bounds__( 1024 ) void k_edge_scan( EdgeLaunch L )
+{
+  __shared__ unsigned part[1024];
+  const int T = 1024, t = threadIdx.x;
+  const int per = ( L.n + T - 1 ) / T;
+  const int lo = min( t * per, L.n ), hi = min( lo + per, L.n );
+  unsigned s = 0;
+  for( int i = lo; i < hi; ++i ) s += (unsigned)L.count[i];
+  part[t] = s;
+  __syncthreads();
+  for( int o = 1; o < T; o <<= 1 )
+  {
+    unsigned v = ( t >= o ) ? part[t - o] : 0u;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  unsigned run = part[t] - s;
+  for( int i = lo; i < hi; ++i ) { L.offset[i] = run; run += (unsigned)L.count[i]; }
+  if( t == T - 1 ) L.offset[L.n] = part[T - 1];
+}
+
+__global__ __launch_bounds__( BLOCK ) void k_edge_write( EdgeLaunch L )
+{
+  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  if( i >= L.n ) return;
+  unsigned at = L.offset[i];
+  const int ni = L.row_nn[i];
+  const float nx = L.nor[3*i], ny = L.nor[3*i+1], nz = L.nor[3*i+2];
+  for( int t = 0; t < ni; ++t )
+  {
+    const int j = L.row_idx[(size_t)i * L.K + t];
+    if( !edge_kept( L, i, j ) ) continue;
+    const float dot = nx * L.nor[3*j] + ny * L.nor[3*j+1] + nz * L.nor[3*j+2];     // msh_vec3_dot( n, m )
+    L.e1[at] = i; L.e2[at] = j; L.ew[at] = edge_weight( L, L.row_d2[(size_t)i * L.K + t], dot );
+    ++at;
+  }
+}
+
+void launch_edge_count( const EdgeLaunch& L, hipStream_t st )
+{ hipLaunchKernelGGL( k_edge_count, dim3( ( L.n + BLOCK - 1 ) / BLOCK ), dim3( BLOCK ), 0, st, L ); }
+void launch_edge_scan( const EdgeLaunch& L, hipStream_t st )
+{ hipLaunchKernelGGL( k_edge_scan, dim3( 1 ), dim3( 1024 ), 0, st, L ); }
+void launch_edge_write( const EdgeLaunch& L, hipStream_t st )
+{ hipLaunchKernelGGL( k_edge_write, dim3( ( L.n + BLOCK - 1 ) / BLOCK ), dim3( BLOCK ), 0, st, L ); }
+
 } // namespace rs

@@ -126,3 +126,19 @@ def test_scores_by_flat_entry(dropin, gscene):
                                      gscene["points"].ctypes.data, gscene["normals"].ctypes.data, len(gscene["points"]),
                                      poses.ctypes.data, len(poses), 0.1, 64, out.ctypes.data)
     assert rc == 0 and np.abs(out.astype(np.float64) - g["scores"]).max() < 2e-6
+
+
+@pytest.mark.gpu
+def test_neighborhood_by_flat_entry(dropin, gscene):
+    d = load_golden("neighborhood_obj1.npz")
+    o = gscene["objects"][int(d["obj"])]
+    n = len(o["pos"])
+    a = np.zeros(n * 8, np.int32); b = np.zeros(n * 8, np.int32); w = np.zeros(n * 8, np.float32)
+    dropin.rsd_compute_neighborhood.restype = C.c_int64
+    dropin.rsd_compute_neighborhood.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float,
+                                                C.c_void_p, C.c_void_p, C.c_void_p]
+    m = dropin.rsd_compute_neighborhood(o["pos"].ctypes.data, o["nor"].ctypes.data, n, 8, 0.05 * 0.05, 15.0, 16.0,
+                                        a.ctypes.data, b.ctypes.data, w.ctypes.data)
+    assert m == len(d["idx1"])
+    key = lambda x, y: np.sort(np.maximum(x, y).astype(np.int64) * n + np.minimum(x, y))
+    assert (key(a[:m], b[:m]) == key(d["idx1"], d["idx2"])).all()

@@ -181,6 +181,80 @@ def test_labels_prioritize_static_vs_oracle(capi, oracle, gscene, scene_clouds):
     assert (res["labels"] == want["labels"]).all() and (res["min_dists"] == want["min_dists"]).all()
 
 
+# ---- neighbourhood graph -------------------------------------------------
+
+def _edges_sorted(a, b, w, n):
+    key = np.maximum(a, b).astype(np.int64) * n + np.minimum(a, b)
+    o = np.argsort(key, kind="stable")
+    return key[o], a[o], b[o], w[o]
+
+
+def _weights_match(got, want):
+    """Edge weights: the reference's value is (1 - pow(..)) * powf(..) from the host libm, and glibc's
+    powf is only good to 0.82 ulp, so the float weight is defined up to its last bit.  The GPU
+    evaluates both powers correctly rounded; bar: never more than 1 float ulp apart, and bit-identical
+    on all but a sliver of the edges."""
+    du = np.abs(got.view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64))
+    assert du.max() <= 1
+    assert (du == 0).mean() > 0.998
+    return int((du != 0).sum())
+
+
+def test_neighborhood_vs_golden(capi, gscene):
+    from oracle.pyoracle import edge_digest
+    for fname in golden_files("neighborhood_obj"):
+        d = load_golden(fname)
+        o = gscene["objects"][int(d["obj"])]
+        n = len(o["pos"])
+        a, b, w = capi.compute_neighborhood(capi.Cloud(o["pos"], o["nor"]))
+        kg, ag, bg, wg = _edges_sorted(a, b, w, n)
+        kw, aw, bw, ww = _edges_sorted(d["idx1"], d["idx2"], d["weight"], n)
+        assert (kg == kw).all() and (ag == aw).all() and (bg == bw).all()       # same pairs, same orientation
+        _weights_match(wg, ww)
+    a, b, w = capi.compute_neighborhood(capi.Cloud(gscene["points"], gscene["normals"]))
+    want = load_golden("neighborhood_scene.npz")["digest"]       # [count, sum of pair keys, sum of weight bit patterns]
+    got = edge_digest(a, b, w)
+    assert got[0] == want[0] and got[1] == want[1]
+    assert abs(int(got[2]) - int(want[2])) <= 0.002 * got[0]       # at most that many last-bit differences
+
+
+def test_neighborhood_exponents_and_large(capi, oracle):
+    from rescan_amd import synth
+    s = synth.make_scene(seed=5, density=1500, timestep=0)
+    pts, nor = s["points"][:40000].copy(), s["normals"][:40000].copy()
+    c = capi.Cloud(pts, nor)
+    n = len(pts)
+    # integer exponents are evaluated exactly-then-rounded; fractional ones go through the device pow/powf
+    for de, ae, exact in ((2.0, 3.0, True), (15.0, 16.0, True), (1.5, 0.5, False)):
+        a, b, w = capi.compute_neighborhood(c, 8, 0.0025, de, ae)
+        wa, wb, ww = oracle.compute_neighborhood(pts, nor, 8, 0.0025, de, ae)
+        kg, ag, bg, wg = _edges_sorted(a, b, w, n)
+        kw, aw, bw, wwt = _edges_sorted(wa, wb, ww, n)
+        assert (kg == kw).all() and (ag == aw).all() and (bg == bw).all()
+        if exact:
+            _weights_match(wg, wwt)
+        else:
+            assert np.abs(wg - wwt).max() < 1e-6
+    # other K / radius
+    a, b, w = capi.compute_neighborhood(c, 4, 0.03 * 0.03)
+    wa, wb, ww = oracle.compute_neighborhood(pts, nor, 4, 0.03 * 0.03)
+    assert (_edges_sorted(a, b, w, n)[0] == _edges_sorted(wa, wb, ww, n)[0]).all()
+    # n > 46340: the reference's int32 key max*n+min wraps and drops colliding pairs; the GPU keeps
+    # every pair, so its edge set contains the reference's (same weights on the common pairs)
+    big = synth.make_scene(seed=6, density=3000, timestep=0)
+    bp, bn = big["points"], big["normals"]
+    nb = len(bp)
+    assert nb > 46340
+    a, b, w = capi.compute_neighborhood(capi.Cloud(bp, bn))
+    wa, wb, ww = oracle.compute_neighborhood(bp, bn)
+    kg, _, _, wg = _edges_sorted(a, b, w, nb)
+    kw, _, _, wwt = _edges_sorted(wa, wb, ww, nb)
+    assert len(np.unique(kg)) == len(kg) and (np.bincount(a, minlength=nb) <= 8).all()
+    pos = np.searchsorted(kg, kw)
+    assert (pos < len(kg)).all() and (kg[pos] == kw).all()
+    _weights_match(wg[pos], wwt)
+
+
 # ---- fresh seeded inputs against the oracle (sizes the oracle finishes in seconds) --------
 
 def test_seeded_scene_vs_oracle(capi, oracle):

@@ -90,3 +90,36 @@ def test_labels_semantics(oracle, gscene):
     # empty arrangement
     none = oracle.arrangement_to_labels(pts, nor, objs, [], 0.05, 0, 0)
     assert (none["labels"] == 0).all() and (none["instance_ids"] == 1024).all()
+
+
+def test_edge_cost(oracle):
+    """rs_pointcloud_filters.cpp:706-708 — restatement vs the reference-toolchain values."""
+    d = load_golden("edge_cost.npz")
+    got = np.array([oracle.edge_cost(a, b) for a, b in zip(d["d2"], d["dot"])], np.float32)
+    assert (got.view(np.uint32) == d["cost"].view(np.uint32)).all()
+
+
+def test_neighborhood_reproducible(oracle, gscene):
+    from oracle.pyoracle import edge_digest
+    for fname in golden_files("neighborhood_obj"):
+        d = load_golden(fname)
+        o = gscene["objects"][int(d["obj"])]
+        a, b, w = oracle.compute_neighborhood(o["pos"], o["nor"])
+        assert (a == d["idx1"]).all() and (b == d["idx2"]).all() and (w.view(np.uint32) == d["weight"].view(np.uint32)).all()
+    a, b, w = oracle.compute_neighborhood(gscene["points"], gscene["normals"])
+    assert (edge_digest(a, b, w) == load_golden("neighborhood_scene.npz")["digest"]).all()
+
+
+def test_neighborhood_semantics(oracle, gscene):
+    """every point has its self edge; pairs are unique; each edge joins points within the radius;
+    at most max_nn directed entries per point."""
+    o = gscene["objects"][0]
+    n = len(o["pos"])
+    a, b, w = oracle.compute_neighborhood(o["pos"], o["nor"])
+    assert ((a == b).sum() == n)
+    key = np.maximum(a, b).astype(np.int64) * n + np.minimum(a, b)
+    assert len(np.unique(key)) == len(key)
+    d2 = ((o["pos"][a] - o["pos"][b]) ** 2).sum(1)
+    assert (d2 < 0.0025 * 1.0001).all()
+    assert (w >= 0).all() and (w <= 1).all()
+    assert np.bincount(a, minlength=n).max() <= 8

@@ -117,3 +117,44 @@ def test_label_gate_matches_reference_tu(oracle, ref):
         u1, u2 = oracle.normalize(nm[None])[0], oracle.normalize(n2[None])[0]
         dot = np.float32(np.float32(np.float32(u1[0] * u2[0]) + np.float32(u1[1] * u2[1])) + np.float32(u1[2] * u2[2]))
         assert oracle.label_gate(dot) == ref.label_gate(pose, n1, n2)
+
+
+def test_neighborhood_composition(oracle, ref, scene):
+    """rspf_compute_neighborhood (rs_pointcloud_filters.cpp:674-722) cannot be compiled here (gco), so
+    the restatement is pinned against the reference's own pieces composed in Python: the unsorted
+    K=8 search of msh_hash_grid.h, the edge weight from the reference-toolchain TU, and the
+    first-insertion-wins de-duplication on max*n+min."""
+    pts, nor = scene["points"][::3].copy(), scene["normals"][::3].copy()
+    n = len(pts)
+    assert n < 46340          # no int32 key wrap in this case
+    gr = ref.grid_create(pts, 0.05)
+    radius = np.float32(np.sqrt(np.float64(np.float32(0.05 * 0.05))))
+    d, idx, nn, _ = ref.radius_search(gr, pts, float(radius), 8, 0)
+    ref.grid_destroy(gr)
+    seen, e1, e2, ew = set(), [], [], []
+    for i in range(n):
+        for t in range(int(nn[i])):
+            j = int(idx[i, t])
+            key = max(i, j) * n + min(i, j)
+            if key in seen:
+                continue
+            seen.add(key)
+            dot = np.float32(np.float32(nor[i, 0] * nor[j, 0]) + np.float32(nor[i, 1] * nor[j, 1])) + np.float32(nor[i, 2] * nor[j, 2])
+            e1.append(i); e2.append(j); ew.append(ref.edge_cost(d[i, t], dot))
+    key = np.array([max(a, b) * n + min(a, b) for a, b in zip(e1, e2)], np.int64)
+    o = np.argsort(key, kind="stable")
+    a, b, w = oracle.compute_neighborhood(pts, nor)
+    assert len(a) == len(o)
+    assert (a == np.array(e1, np.int32)[o]).all() and (b == np.array(e2, np.int32)[o]).all()
+    assert (w.view(np.uint32) == np.array(ew, np.float32)[o].view(np.uint32)).all()
+
+
+def test_edge_cost(oracle, ref):
+    rng = np.random.default_rng(9)
+    for _ in range(5000):
+        d2, dot = np.float32(rng.uniform(0, 0.0026)), np.float32(rng.uniform(-0.1, 1.05))
+        assert oracle.edge_cost(d2, dot) == ref.edge_cost(d2, dot)
+    for de, ae in ((2.0, 3.0), (1.5, 0.5), (15.0, 16.0)):
+        for _ in range(300):
+            d2, dot = np.float32(rng.uniform(0, 0.0026)), np.float32(rng.uniform(0, 1))
+            assert oracle.edge_cost(d2, dot, 0.0025, de, ae) == ref.edge_cost(d2, dot, 0.0025, de, ae)
