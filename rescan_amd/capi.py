@@ -69,11 +69,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("RS_HIP_LIB", LIB_PATH)       # kernel A/B experiments (tools/variant.sh)
+    if not os.path.exists(path):
         raise RescanHipError(
-            f"{LIB_PATH} is missing: build it with `python -m rescan_amd.build` "
+            f"{path} is missing: build it with `python -m rescan_amd.build` "
             "(there is no CPU fallback for the hot path)")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = res

@@ -21,6 +21,7 @@
 #include <mutex>
 #include <string>
 #include <vector>
+#include <array>
 
 using namespace rs;
 
@@ -99,6 +100,7 @@ struct Workspace
   DevBuf plc, labels, mind;                                                     // labels
   DevBuf q4, rd2, ridx, rnn, rows;                                              // rows / misc
   DevBuf enor, ecount, eoffset, e1, e2, ew;                                     // neighbourhood edges
+  DevBuf cert_r, cert_dot;                                                      // ICP certificates
   DevBuf tmp_pos, tmp_pos2, tmp_nor2;                                           // estimate-only
   PinBuf h_a, h_b, h_c;
 };
@@ -169,6 +171,7 @@ struct rs_hip_cloud
   std::vector<int32_t> qorder;    // query slot -> original index
   std::vector<int32_t> order;     // sorted slot -> original index
   std::vector<float> h_pos, h_nor;  // original-order host copies (AoS)
+  float nor_max = 1.0f;             // max |normal| (bounds how fast a gate value can change with the query normal)
   float cell = 0.0f;
   int64_t bytes = 0;
 };
@@ -333,7 +336,13 @@ rs_hip_cloud_t* rs_hip_cloud_create( const float* pos, const float* nor, int32_t
   rs_hip_cloud* c = new rs_hip_cloud();
   c->n = n; c->has_nor = nor != nullptr;
   c->h_pos.assign( pos, pos + (size_t)3 * n );
-  if( nor ) c->h_nor.assign( nor, nor + (size_t)3 * n );
+  if( nor )
+  {
+    c->h_nor.assign( nor, nor + (size_t)3 * n );
+    double mx = 0.0;
+    for( int i = 0; i < n; ++i ) { double l = (double)nor[3*i] * nor[3*i] + (double)nor[3*i+1] * nor[3*i+1] + (double)nor[3*i+2] * nor[3*i+2]; if( l > mx ) mx = l; }
+    c->nor_max = std::isfinite( mx ) ? (float)( std::sqrt( mx ) * 1.000001 ) : INFINITY;
+  }
 
   float mn[3] = { 0, 0, 0 }, mx[3] = { 0, 0, 0 };
   if( n > 0 ) { for( int a = 0; a < 3; ++a ) { mn[a] = FLT_MAX; mx[a] = -FLT_MAX; } }
@@ -582,17 +591,19 @@ int icp_prepare( IcpCtx& cx, const rs_hip_cloud_t* src, const rs_hip_cloud_t* tg
   L.n_mom_blocks = std::max( 1, std::min( 256, ( src->n + 255 ) / 256 ) );
   const size_t nq = std::max<size_t>( 1, (size_t)src->n ), np = (size_t)n_prob;
   int rc;
-  if( ( rc = g_ws.state.ensure( np * 68 ) ) ||
+  if( ( rc = g_ws.state.ensure( np * 132 ) ) ||
       ( rc = g_ws.slot.ensure( np * nq * 4 ) ) || ( rc = g_ws.d2.ensure( np * nq * 4 ) ) || ( rc = g_ws.dot.ensure( np * nq * 4 ) ) ||
       ( rc = g_ws.corr_part.ensure( np * std::max( 1, cx.n_waves ) * 3 * 8 ) ) ||
       ( rc = g_ws.mom_part.ensure( np * L.n_mom_blocks * ICP_NMOM * 8 ) ) || ( rc = g_ws.res.ensure( np * ICP_NRES * 8 ) ) ||
-      ( rc = g_ws.h_a.ensure( np * ICP_NRES * 8 ) ) || ( rc = g_ws.h_b.ensure( np * 68 ) ) ||
+      ( rc = g_ws.h_a.ensure( np * ICP_NRES * 8 ) ) || ( rc = g_ws.h_b.ensure( np * 132 ) ) ||
       ( rc = g_ws.queue.ensure( np * std::max( 1, cx.n_waves ) * 4 ) ) || ( rc = g_ws.queue_count.ensure( np * 4 ) ) )
     return rc;
   L.queue = g_ws.queue.as<int>(); L.queue_count = g_ws.queue_count.as<int>();
   L.solo_stages = handoff_threshold( (long long)cx.n_waves * n_prob );
-  // one upload per iteration: [n_prob x 16 floats of T1][n_prob active flags]
+  // one upload per iteration: [n_prob x 16 floats of T1][n_prob active flags][n_prob x 16 floats: T1 of the previous iteration]
   L.T1 = g_ws.state.as<float>(); L.active = (const int*)( g_ws.state.as<float>() + np * 16 );
+  L.T1_prev = g_ws.state.as<float>() + np * 17;
+  L.cert_r = nullptr; L.cert_dot = nullptr; L.cert_mu = 0.0f; L.tgt_nor_max = tgt->nor_max;
   L.m_slot = g_ws.slot.as<int>(); L.m_d2 = g_ws.d2.as<float>(); L.m_dot = g_ws.dot.as<float>();
   L.corr_part = g_ws.corr_part.as<double>();
   L.mom_part = g_ws.mom_part.as<double>(); L.res = g_ws.res.as<double>();
@@ -601,13 +612,31 @@ int icp_prepare( IcpCtx& cx, const rs_hip_cloud_t* src, const rs_hip_cloud_t* tg
   return RS_HIP_OK;
 }
 
-int icp_upload_state( IcpCtx& cx, const std::vector<Mat4>& T, const std::vector<int>& active )
+int icp_upload_state( IcpCtx& cx, const std::vector<Mat4>& T, const std::vector<int>& active, const std::vector<Mat4>* T_prev = nullptr )
 {
   const size_t np = T.size();
   float* hT = g_ws.h_b.as<float>();
   int* hA = (int*)( hT + np * 16 );
-  for( size_t p = 0; p < np; ++p ) { std::memcpy( hT + 16 * p, T[p].m, 64 ); hA[p] = active[p]; }
-  HIP_TRY( hipMemcpyAsync( g_ws.state.p, hT, np * 68, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+  float* hP = hT + np * 17;
+  for( size_t p = 0; p < np; ++p )
+  {
+    std::memcpy( hT + 16 * p, T[p].m, 64 ); hA[p] = active[p];
+    std::memcpy( hP + 16 * p, ( T_prev ? *T_prev : T )[p].m, 64 );
+  }
+  HIP_TRY( hipMemcpyAsync( g_ws.state.p, hT, np * 132, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+  return RS_HIP_OK;
+}
+
+// Certificates on: margin mu on the gate value (cos of the angle).  0.05 is ~3.3 degrees at a 60-degree gate:
+// wide enough to survive the pose changes of the later iterations, narrow enough that few unmatched
+// points have a candidate inside the band.
+int icp_enable_certificates( IcpCtx& cx, size_t np, size_t nq )
+{
+  int rc;
+  if( getenv( "RS_HIP_NO_CERT" ) || !std::isfinite( cx.L.tgt_nor_max ) ) return RS_HIP_OK;
+  if( ( rc = g_ws.cert_r.ensure( np * nq * 4 ) ) || ( rc = g_ws.cert_dot.ensure( np * nq * 4 ) ) ) return rc;
+  HIP_TRY( hipMemsetAsync( g_ws.cert_r.p, 0xFF, np * nq * 4, g_stream ), RS_HIP_E_RUNTIME );      // NaN: no certificate
+  cx.L.cert_r = g_ws.cert_r.as<float>(); cx.L.cert_dot = g_ws.cert_dot.as<float>(); cx.L.cert_mu = 0.05f;
   return RS_HIP_OK;
 }
 
@@ -630,7 +659,8 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
   if( ( rc = icp_prepare( cx, source, target, n, T2 ) ) ) return rc;
   const float tmin = icp_gate_threshold( max_angle );
 
-  std::vector<Mat4> T( n );
+  if( ( rc = icp_enable_certificates( cx, (size_t)n, std::max<size_t>( 1, (size_t)source->n ) ) ) ) return rc;
+  std::vector<Mat4> T( n ), T_prev( n );
   std::vector<int> active( n, 1 ), it_count( n, 0 );
   std::vector<float> err( n, 1e6f ), prev( n, 1e6f );                 // icp.h:441-442
   for( int p = 0; p < n; ++p ) std::memcpy( T[p].m, T1s + 16 * p, 64 );
@@ -639,11 +669,12 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
   double* hR = g_ws.h_a.as<double>();               // n x ICP_NRES: moments, then stats
   for( int i = 0; i < max_iter; ++i )                                  // icp.h:444
   {
-    if( ( rc = icp_upload_state( cx, T, active ) ) ) return rc;
+    if( ( rc = icp_upload_state( cx, T, active, i > 0 ? &T_prev : nullptr ) ) ) return rc;
+    T_prev = T;                                                         // the poses this iteration searches with
     icp_set_radius( cx, max_dist, tmin );
     cx.L.warm = ( i > 0 && !getenv( "RS_HIP_NO_WARM" ) ) ? 1 : 0;   // every active problem wrote m_slot in iteration i-1
     static DevBuf dbgbuf;
-    if( getenv( "RS_HIP_DEBUG_CYCLES" ) && n == 1 ) { dbgbuf.ensure( (size_t)cx.n_waves * 16 ); cx.L.dbg = dbgbuf.as<unsigned long long>(); }
+    if( getenv( "RS_HIP_DEBUG_CYCLES" ) && n == 1 ) { dbgbuf.ensure( (size_t)cx.n_waves * 48 + 64 ); (void)hipMemsetAsync( (char*)dbgbuf.p + (size_t)cx.n_waves * 48, 0, 64, g_stream ); cx.L.dbg = dbgbuf.as<unsigned long long>(); }
     { ProfScope ps( "nn_icp" ); launch_icp_corr( cx.L, g_stream ); }
     if( cx.L.dbg )
     {
@@ -653,9 +684,35 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
       unsigned long long tiles_uns = 0;
       for( int k = 0; k < cx.n_waves; ++k ) { t.push_back( h[2*k] ); sum += h[2*k]; ho += h[2*k+1]; tiles_uns += h[2*k+1] ? 1 : 0; }
       std::sort( t.begin(), t.end() );
+      {
+        std::vector<int> qc( 1 ); (void)hipMemcpy( qc.data(), cx.L.queue_count, 4, hipMemcpyDeviceToHost );
+        std::vector<unsigned long long> c( (size_t)qc[0] * 4 );
+        (void)hipMemcpy( c.data(), cx.L.dbg + 2 * (size_t)cx.n_waves, c.size() * 8, hipMemcpyDeviceToHost );
+        std::vector<std::array<unsigned long long, 4>> rows;
+        for( int b = 0; b < qc[0]; ++b ) rows.push_back( { c[4*b], c[4*b+1], c[4*b+2], c[4*b+3] } );
+        std::sort( rows.begin(), rows.end() );
+        auto pr = [&]( const char* tag, size_t k ) { if( rows.empty() ) return; k = std::min( k, rows.size() - 1 );
+          fprintf( stderr, "[rs_hip dbg]   coop %s: %.1f us, wave-0 streamed %llu cand, searching lanes %llu, unmatched %llu\n", tag, rows[k][0] / 100.0, rows[k][1], rows[k][2], rows[k][3] ); };
+        unsigned long long cat[4]; (void)hipMemcpy( cat, cx.L.dbg + 6 * (size_t)cx.n_waves, 32, hipMemcpyDeviceToHost );
+        fprintf( stderr, "[rs_hip dbg] it %d unmatched lanes: skipped by certificate %llu, freshly certified %llu, rank-rejected %llu, loose-band only %llu\n", i, cat[0], cat[1], cat[2], cat[3] );
+        fprintf( stderr, "[rs_hip dbg] coop tiles %d\n", qc[0] );
+        pr( "p10", rows.size() / 10 ); pr( "p50", rows.size() / 2 ); pr( "p90", rows.size() * 9 / 10 ); pr( "p99", rows.size() * 99 / 100 ); pr( "max", rows.size() - 1 );
+      }
       fprintf( stderr, "[rs_hip dbg] unsettled lanes after shell 1: %llu of %d queries, in %llu tiles\n", ho, source->n, tiles_uns );
       fprintf( stderr, "[rs_hip dbg] it %d tiles %d handoff %llu  wall-ticks(100MHz): mean %.0f p50 %llu p90 %llu p99 %llu max %llu\n", i, cx.n_waves, ho,
                (double)sum / cx.n_waves, t[t.size()/2], t[t.size()*9/10], t[t.size()*99/100], t.back() );
+    }
+    if( getenv( "RS_HIP_DEBUG" ) )
+    {
+      std::vector<int> qc( n ), ms( (size_t)source->n ); std::vector<float> cr( cx.L.cert_r ? (size_t)source->n : 0 );
+      (void)hipStreamSynchronize( g_stream );
+      (void)hipMemcpy( qc.data(), cx.L.queue_count, (size_t)n * 4, hipMemcpyDeviceToHost );
+      (void)hipMemcpy( ms.data(), cx.L.m_slot, ms.size() * 4, hipMemcpyDeviceToHost );
+      if( cx.L.cert_r ) (void)hipMemcpy( cr.data(), cx.L.cert_r, cr.size() * 4, hipMemcpyDeviceToHost );
+      size_t unm = 0, cert = 0;
+      for( int v : ms ) unm += v < 0;
+      for( float v : cr ) cert += v > 0.0f;
+      fprintf( stderr, "[rs_hip icp] it %d: prob 0 queued tiles %d of %d, unmatched %zu of %d, certificates %zu\n", i, qc[0], cx.n_waves, unm, source->n, cert );
     }
     launch_icp_stats( cx.L, g_stream );
     { ProfScope ps( "icp_moments" ); launch_icp_moments( cx.L, g_stream ); }

@@ -71,6 +71,12 @@ struct IcpLaunch
   int*    queue_count;  // n_prob
   int     solo_stages;  // candidates a lone wave streams before handing an unsettled tile off
   int     warm;         // m_slot holds last iteration's matches: use them as starting candidates
+  // "no correspondence" certificates carried across iterations (rs_kernels.hip: icp_certificate); null = off
+  float*  cert_r;       // n_prob x nq
+  float*  cert_dot;     // n_prob x nq
+  const float* T1_prev; // device, n_prob x 16: the poses of the previous iteration
+  float   cert_mu;      // margin by which the gate is loosened when a certificate is issued
+  float   tgt_nor_max;  // max |normal| over the target cloud
   unsigned long long* dbg;   // diagnostic builds only: per-tile {cycles, candidates} of phase A (null otherwise)
   const float* w_explicit;   // if non-null: weights given per query (estimate-only entry point)
 };

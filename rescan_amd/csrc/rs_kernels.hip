@@ -180,14 +180,14 @@ struct WaveLds
 {
   float    px[WAVE], py[WAVE], pz[WAVE];   // staged candidates, one array per coordinate so that four
   int      pidx[WAVE];                     // consecutive candidates load as one ds_read_b128 per coordinate
-  float4   nor[WAVE];      // their normals {nx,ny,nz,-}
+  float    nx[WAVE], ny[WAVE], nz[WAVE];   // their normals, same layout
   uint32_t slot[WAVE];     // their positions in the cell-sorted cloud
   uint32_t seg_a[WAVE], len_a[WAVE], seg_b[WAVE], pre[WAVE];   // row pieces of the current batch
 };
 
 // Stream every point of (out \ in) through the wave's LDS and call f( X, Y, Z, k ) for every
 // group of four staged candidates k..k+3 (X = their four x coordinates, ...; L.pidx[k+i],
-// L.nor[k+i], L.slot[k+i] belong to them); k is wave-uniform.  `in` (if in_valid) must be a
+// L.nx/ny/nz[k+i], L.slot[k+i] belong to them); k is wave-uniform.  `in` (if in_valid) must be a
 // sub-box of `out`.  Chunks are padded to a multiple of 4 with sentinels at +FLT_MAX whose
 // dist² is +inf: they can never be "within the radius", so f needs no validity test.
 // When several waves sweep the same shell together, wave `share` of `n_share` takes the chunks
@@ -250,7 +250,7 @@ __device__ __forceinline__ uint32_t sweep_shell( const GridView& g, const CellBo
     while( c0 < total )
     {
       L.px[lane] = P.x; L.py[lane] = P.y; L.pz[lane] = P.z; L.pidx[lane] = __float_as_int( P.w );
-      if( WITH_NOR ) L.nor[lane] = N;
+      if( WITH_NOR ) { L.nx[lane] = N.x; L.ny[lane] = N.y; L.nz[lane] = N.z; }
       L.slot[lane] = src;
       wave_lds_fence();
       const uint32_t cn = c0 + stride;
@@ -274,8 +274,10 @@ __device__ __forceinline__ uint32_t sweep_shell( const GridView& g, const CellBo
 }
 
 // Result of a search for one query.
-struct Match { float d2; int idx; float dot; int slot; bool found; };
-__device__ __forceinline__ Match no_match() { Match m; m.d2 = INFINITY; m.idx = INT_MAX; m.dot = 0.0f; m.slot = -1; m.found = false; return m; }
+// `loose`: some candidate within the radius had max(dot,0) >= tmin_loose (a gate loosened by a margin;
+// only the ICP certificate below reads it).
+struct Match { float d2; int idx; float dot; int slot; bool found; bool loose; };
+__device__ __forceinline__ Match no_match() { Match m; m.d2 = INFINITY; m.idx = INT_MAX; m.dot = 0.0f; m.slot = -1; m.found = false; m.loose = false; return m; }
 
 typedef float f32x2 __attribute__(( ext_vector_type( 2 ) ));
 
@@ -298,40 +300,51 @@ __device__ __forceinline__ void dist2x4( const float4& X, const float4& Y, const
 // match `m` of this lane.
 // `bound` folds three tests into one compare: a candidate can only matter if
 // dist² < bound, where bound = radius² until a match exists and then the float just above the
-// match's dist² (so "<= best" including ties, which the rare branch settles by index);
-// inactive lanes carry bound = -1.  seen_closer counts the candidates that passed it.
+// match's dist² (so "<= best" including ties, which the last branch settles by index);
+// inactive lanes carry bound = -1.  seen_closer counts the candidates that passed it (against the
+// bound at the start of the group: looser than one by one, still an upper bound of the rank).
+// Three levels: (1) distances only — most groups end here; (2) some lane has a candidate inside its
+// bound (lanes without a match see that for everything within the radius): the gate of all four,
+// packed like the distances; (3) a candidate passed both: settle it one by one.
 template <bool GATED>
 __device__ __forceinline__ void consider4( const float4& X, const float4& Y, const float4& Z, int k, const WaveLds& L,
                                            float qx, float qy, float qz, float nx, float ny, float nz,
-                                           float tmin, float& bound, Match& m, int& seen_closer )
+                                           float tmin, float tmin_loose, float& bound, Match& m, int& seen_closer )
 {
   float d[4];
   dist2x4( X, Y, Z, qx, qy, qz, d[0], d[1], d[2], d[3] );
-  const bool m0 = d[0] < bound, m1 = d[1] < bound, m2 = d[2] < bound, m3 = d[3] < bound;
-  if( __any( m0 | m1 | m2 | m3 ) )
+  const bool in0 = d[0] < bound, in1 = d[1] < bound, in2 = d[2] < bound, in3 = d[3] < bound;
+  if( !__any( in0 | in1 | in2 | in3 ) ) return;
+  seen_closer += ( in0 ? 1 : 0 ) + ( in1 ? 1 : 0 ) + ( in2 ? 1 : 0 ) + ( in3 ? 1 : 0 );
+  float dc[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+  bool p0 = in0, p1 = in1, p2 = in2, p3 = in3;
+  if( GATED )
   {
-    // rare: look at the four one by one (the bound may tighten on the way; candidates tested
-    // against the looser, earlier bound only make seen_closer a looser upper bound)
+    const float4 NX = *reinterpret_cast<const float4*>( &L.nx[k] );
+    const float4 NY = *reinterpret_cast<const float4*>( &L.ny[k] );
+    const float4 NZ = *reinterpret_cast<const float4*>( &L.nz[k] );
+    const f32x2 n_x = { nx, nx }, n_y = { ny, ny }, n_z = { nz, nz };
+    const f32x2 a = f32x2{ NX.x, NX.y } * n_x + f32x2{ NY.x, NY.y } * n_y + f32x2{ NZ.x, NZ.y } * n_z;   // msh_vec3_dot( m, n )
+    const f32x2 b = f32x2{ NX.z, NX.w } * n_x + f32x2{ NY.z, NY.w } * n_y + f32x2{ NZ.z, NZ.w } * n_z;
+    dc[0] = a.x > 0.0f ? a.x : 0.0f; dc[1] = a.y > 0.0f ? a.y : 0.0f;                                    // msh_max( dot, 0.0f )
+    dc[2] = b.x > 0.0f ? b.x : 0.0f; dc[3] = b.y > 0.0f ? b.y : 0.0f;
+    m.loose |= ( in0 & ( dc[0] >= tmin_loose ) ) | ( in1 & ( dc[1] >= tmin_loose ) ) | ( in2 & ( dc[2] >= tmin_loose ) ) | ( in3 & ( dc[3] >= tmin_loose ) );
+    p0 &= ( dc[0] >= tmin ) & ( dc[0] <= 1.0f ); p1 &= ( dc[1] >= tmin ) & ( dc[1] <= 1.0f );
+    p2 &= ( dc[2] >= tmin ) & ( dc[2] <= 1.0f ); p3 &= ( dc[3] >= tmin ) & ( dc[3] <= 1.0f );
+  }
+  if( __any( p0 | p1 | p2 | p3 ) )
+  {
+    const bool pass[4] = { p0, p1, p2, p3 };
 #pragma unroll
     for( int i = 0; i < 4; ++i )
     {
-      const bool maybe = d[i] < bound;
-      seen_closer += maybe ? 1 : 0;
-      if( __any( maybe ) )
+      if( __any( pass[i] ) )
       {
         const int idx = L.pidx[k + i];
-        bool take = maybe & lex_less( d[i], idx, m.d2, m.idx );
-        float dc = 0.0f;
-        if( GATED )
-        {
-          float4 N = L.nor[k + i];
-          float dot = N.x * nx + N.y * ny + N.z * nz;       // msh_vec3_dot( m, n )
-          dc = dot > 0.0f ? dot : 0.0f;                     // msh_max( dot, 0.0f )
-          take = take & ( dc >= tmin ) & ( dc <= 1.0f );
-        }
+        const bool take = pass[i] & ( d[i] < bound ) & lex_less( d[i], idx, m.d2, m.idx );   // the bound may have tightened within the group
         if( take )
         {
-          m.d2 = d[i]; m.idx = idx; m.dot = dc; m.slot = (int)L.slot[k + i]; m.found = true;
+          m.d2 = d[i]; m.idx = idx; m.dot = dc[i]; m.slot = (int)L.slot[k + i]; m.found = true;
           bound = __int_as_float( __float_as_int( d[i] ) + 1 );   // next float above d2 (d2 >= 0, finite, < radius²)
         }
       }
@@ -373,7 +386,7 @@ __device__ __forceinline__ float bound_of( bool active, float radius_sq, const M
 template <bool GATED>
 __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
                                               float qx, float qy, float qz, float nx, float ny, float nz,
-                                              float radius, float radius_sq, float tmin, int K,
+                                              float radius, float radius_sq, float tmin, float tmin_loose, int K,
                                               WaveLds& L, int lane, int max_stages, bool* handoff, int* dbg_unsettled,
                                               Match m /* starting candidate: empty, or a genuine one (within radius, gate passed) that only tightens the bounds */ )
 {
@@ -397,7 +410,7 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
   {
     cur = ( g.inv_cell > 0.0f ) ? box_grow( core, k, full ) : full;
     streamed += sweep_shell<GATED>( g, cur, prev, have_prev, L, lane, 0, 1, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
-    { consider4<GATED>( X, Y, Z, k4, L, qx, qy, qz, nx, ny, nz, tmin, bound, m, seen_closer ); } );
+    { consider4<GATED>( X, Y, Z, k4, L, qx, qy, qz, nx, ny, nz, tmin, tmin_loose, bound, m, seen_closer ); } );
     if( box_same( cur, full ) ) break;
     // a lane is settled when nothing outside `cur` can precede its match (or reach it at all)
     const float cov = box_cover( g, cur, full, qx, qy, qz );
@@ -442,6 +455,7 @@ struct CoopLds
   float m_dot[COOP_WAVES][WAVE];
   int   m_slot[COOP_WAVES][WAVE];
   int   m_cnt[COOP_WAVES][WAVE];
+  int   m_loose[COOP_WAVES][WAVE];
 };
 
 // The same staged search, done by all COOP_WAVES waves of a workgroup for ONE tile: every
@@ -451,9 +465,11 @@ struct CoopLds
 template <bool GATED>
 __device__ __forceinline__ Match coop_search( const GridView& g, bool active,
                                               float qx, float qy, float qz, float nx, float ny, float nz,
-                                              float radius, float radius_sq, float tmin, int K,
-                                              WaveLds& L, CoopLds& C, int wib, int lane, Match m /* starting candidate, see tile_search */ )
+                                              float radius, float radius_sq, float tmin, float tmin_loose, int K,
+                                              WaveLds& L, CoopLds& C, int wib, int lane, Match m /* starting candidate, see tile_search */,
+                                              uint32_t* dbg_streamed = nullptr )
 {
+  uint32_t streamed = 0;
   const TileBounds tb = wave_bounds( active, qx, qy, qz );
   if( !tb.any ) return m;                          // identical in every wave of the workgroup
   const CellBox full = cell_box( g, tb, radius );
@@ -474,8 +490,8 @@ __device__ __forceinline__ Match coop_search( const GridView& g, bool active,
   for( int k = 2; ; k = 1 << 20 )
   {
     cur = ( g.inv_cell > 0.0f ) ? box_grow( core, k, full ) : full;
-    sweep_shell<GATED>( g, cur, prev, have_prev, L, lane, wib, COOP_WAVES, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
-    { consider4<GATED>( X, Y, Z, k4, L, qx, qy, qz, nx, ny, nz, tmin, bound, m, seen_closer ); } );
+    streamed += sweep_shell<GATED>( g, cur, prev, have_prev, L, lane, wib, COOP_WAVES, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
+    { consider4<GATED>( X, Y, Z, k4, L, qx, qy, qz, nx, ny, nz, tmin, tmin_loose, bound, m, seen_closer ); } );
     // merge the per-lane bests of the waves; every wave continues with the merged best
     C.m_d2[wib][lane] = m.d2; C.m_idx[wib][lane] = m.idx; C.m_dot[wib][lane] = m.dot; C.m_slot[wib][lane] = m.found ? m.slot : -1;
     __syncthreads();
@@ -497,11 +513,11 @@ __device__ __forceinline__ Match coop_search( const GridView& g, bool active,
   if( K > 1 || GATED )
   {
     // each wave's count bounds the rank contribution of its own share (see tile_search)
-    C.m_cnt[wib][lane] = seen_closer;
+    C.m_cnt[wib][lane] = seen_closer; C.m_loose[wib][lane] = m.loose ? 1 : 0;
     __syncthreads();
     int seen_total = 0;
 #pragma unroll
-    for( int w = 0; w < COOP_WAVES; ++w ) seen_total += C.m_cnt[w][lane];
+    for( int w = 0; w < COOP_WAVES; ++w ) { seen_total += C.m_cnt[w][lane]; m.loose |= C.m_loose[w][lane] != 0; }
     bool need_rank = m.found && ( seen_total - 1 >= K );
     if( __any( need_rank ) )
     {
@@ -517,6 +533,7 @@ __device__ __forceinline__ Match coop_search( const GridView& g, bool active,
       if( need_rank && rank >= K ) { m.found = false; m.slot = -1; }
     }
   }
+  if( dbg_streamed ) *dbg_streamed = streamed;
   return m;
 }
 
@@ -554,14 +571,64 @@ __device__ __forceinline__ Match icp_warm_start( const IcpLaunch& L, int prob, i
   float d2 = vx * vx + vy * vy + vz * vz;
   float dot = N.x * nx + N.y * ny + N.z * nz;
   float dc = dot > 0.0f ? dot : 0.0f;
-  if( d2 < L.radius_sq && dc >= L.gate_tmin && dc <= 1.0f ) { m.d2 = d2; m.idx = __float_as_int( P.w ); m.dot = dc; m.slot = s; m.found = true; }
+  if( d2 < L.radius_sq && dc >= L.gate_tmin && dc <= 1.0f ) { m.d2 = d2; m.idx = __float_as_int( P.w ); m.dot = dc; m.slot = s; m.found = true; m.loose = true; }
   return m;
 }
 
-__device__ __forceinline__ void icp_emit( const IcpLaunch& L, int prob, int tile, int i, bool active, int lane, const Match& m )
+// "No correspondence" certificates.  A query that ended an iteration unmatched after all candidates
+// within radius r_i were examined, none of them with max(dot,0) >= tmin - mu, carries
+//   cert_r   = r_i - margin  : every candidate within this distance of the query AS IT WAS THEN is known to fail the
+//                              loosened gate; each later iteration subtracts how far the query has moved since;
+//   cert_dot = mu - margin   : how much the gate value of any candidate may still rise; each later iteration
+//                              subtracts |delta n| * max|m| (dot(m, n') - dot(m, n) <= |m| |n' - n|).
+// While radius <= cert_r and cert_dot >= 0 the search is skipped: by the triangle inequality every candidate within
+// the current radius was examined then, and none can pass the gate now — the result (unmatched) is exactly what the
+// full sweep would return.  The margins (1e-4 m, 1e-5) are orders of magnitude above the fp32 rounding of dist²,
+// dot and the displacement itself.  This removes the one case a search cannot bound: the full-radius sweep of
+// a source point with nothing to match, repeated every iteration (icp.h:444-493 shrinks the radius only 5 % a time).
+//
+// Returns whether the search of this query may be skipped, and writes the aged certificate back at once
+// (keeping it in registers across the search costs a wave of occupancy).  A tile that phase A hands off
+// is aged a second time by the cooperative kernel: that only makes the certificate more conservative.
+__device__ __forceinline__ bool icp_certificate( const IcpLaunch& L, int prob, int i, bool active,
+                                                 float qx, float qy, float qz, float nx, float ny, float nz )
+{
+  if( !L.cert_r || !L.warm || !active ) return false;
+  const size_t o = (size_t)prob * L.src.n + i;
+  const float r = L.cert_r[o];
+  if( !( r > 0.0f ) ) return false;
+  // the same query under the previous iteration's pose (identical float operations as then)
+  Xform Tp;
+#pragma unroll
+  for( int k = 0; k < 16; ++k ) Tp.m[k] = L.T1_prev[prob * 16 + k];
+  float4 p = L.src.pos[i], n = L.src.nor[i];
+  float tx, ty, tz, px, py, pz, mx, my, mz;
+  xform3( Tp, p.x, p.y, p.z, 1.0f, tx, ty, tz );   xform3( L.T2i, tx, ty, tz, 1.0f, px, py, pz );
+  xform3( Tp, n.x, n.y, n.z, 0.0f, tx, ty, tz );   xform3( L.T2i, tx, ty, tz, 0.0f, mx, my, mz );
+  const float dq = sqrtf( ( qx - px ) * ( qx - px ) + ( qy - py ) * ( qy - py ) + ( qz - pz ) * ( qz - pz ) );
+  const float dn = sqrtf( ( nx - mx ) * ( nx - mx ) + ( ny - my ) * ( ny - my ) + ( nz - mz ) * ( nz - mz ) );
+  const float r_now = r - ( dq * 1.0001f + 1e-5f );
+  const float dot_now = L.cert_dot[o] - ( dn * L.tgt_nor_max * 1.0001f + 1e-6f );
+  const bool skip = ( L.radius <= r_now ) & ( dot_now >= 0.0f );
+  L.cert_r[o] = skip ? r_now : -1.0f;
+  L.cert_dot[o] = dot_now;
+  return skip;
+}
+
+__device__ __forceinline__ void icp_emit( const IcpLaunch& L, int prob, int tile, int i, bool active, int lane, const Match& m,
+                                          bool skipped )
 {
   const size_t o = (size_t)prob * L.src.n + i;
   if( active ) { L.m_slot[o] = m.found ? m.slot : -1; L.m_d2[o] = m.d2; L.m_dot[o] = m.dot; }
+  if( active && L.cert_r && !skipped && !m.found && !m.loose ) { L.cert_r[o] = L.radius - 1e-4f; L.cert_dot[o] = L.cert_mu - 1e-5f; }   // fresh certificate
+  if( L.dbg )
+  {
+    unsigned long long* cat = L.dbg + 6 * (size_t)L.src.n_tiles;
+    const int c_skip = __popcll( __ballot( skipped ) ), c_fresh = __popcll( __ballot( active && !skipped && !m.found && !m.loose ) );
+    const int c_rank = __popcll( __ballot( active && !skipped && !m.found && m.loose && m.idx != INT_MAX ) );
+    const int c_loose = __popcll( __ballot( active && !skipped && !m.found && m.loose && m.idx == INT_MAX ) );
+    if( lane == 0 ) { atomicAdd( cat + 0, (unsigned long long)c_skip ); atomicAdd( cat + 1, (unsigned long long)c_fresh ); atomicAdd( cat + 2, (unsigned long long)c_rank ); atomicAdd( cat + 3, (unsigned long long)c_loose ); }
+  }
   // statistics of dist² over correspondences (msh_compute_mean/stddev, msh_std.h:1800-1825)
   double c = ( active && m.found ) ? 1.0 : 0.0;
   double s1 = ( active && m.found ) ? (double)m.d2 : 0.0;
@@ -575,7 +642,10 @@ __device__ __forceinline__ void icp_emit( const IcpLaunch& L, int prob, int tile
 }
 
 // Phase A: one wave per tile, first shell(s) only; unsettled tiles are queued.
-__global__ __launch_bounds__( BLOCK, 6 ) void k_icp_corr( IcpLaunch L )
+#ifndef RS_ICP_OCC
+#define RS_ICP_OCC 7      // workgroups of 4 waves per CU the register allocation aims at (x4 SIMDs: waves per SIMD)
+#endif
+__global__ __launch_bounds__( BLOCK, RS_ICP_OCC ) void k_icp_corr( IcpLaunch L )
 {
   __shared__ WaveLds lds[WAVES_PER_BLOCK];
   const int prob = blockIdx.y;
@@ -595,8 +665,9 @@ __global__ __launch_bounds__( BLOCK, 6 ) void k_icp_corr( IcpLaunch L )
   icp_query( L, T1, i, active, qx, qy, qz, nx, ny, nz );
   bool handoff;
   int unsettled = 0;
-  const Match init = icp_warm_start( L, prob, i, active, qx, qy, qz, nx, ny, nz );
-  Match m = tile_search<true>( L.tgt, active, qx, qy, qz, nx, ny, nz, L.radius, L.radius_sq, L.gate_tmin, L.K,
+  const bool search = active & !icp_certificate( L, prob, i, active, qx, qy, qz, nx, ny, nz );
+  const Match init = icp_warm_start( L, prob, i, search, qx, qy, qz, nx, ny, nz );
+  Match m = tile_search<true>( L.tgt, search, qx, qy, qz, nx, ny, nz, L.radius, L.radius_sq, L.gate_tmin, L.gate_tmin - L.cert_mu, L.K,
                                lds[wib], lane, L.solo_stages, &handoff, L.dbg ? &unsettled : nullptr, init );
   if( L.dbg && lane == 0 ) { L.dbg[2 * tile] = wall_clock64() - t_begin; L.dbg[2 * tile + 1] = (unsigned long long)unsettled; }
   if( handoff )
@@ -604,7 +675,7 @@ __global__ __launch_bounds__( BLOCK, 6 ) void k_icp_corr( IcpLaunch L )
     if( lane == 0 ) { int q = atomicAdd( L.queue_count + prob, 1 ); L.queue[(size_t)prob * L.src.n_tiles + q] = tile; }
     return;
   }
-  icp_emit( L, prob, tile, i, active, lane, m );
+  icp_emit( L, prob, tile, i, active, lane, m, active & !search );
 }
 
 // Phase B: one workgroup per queued tile, whole box, chunks shared by its waves.
@@ -627,10 +698,22 @@ __global__ __launch_bounds__( COOP_BLOCK ) void k_icp_corr_coop( IcpLaunch L )
     const bool active = i < (int)L.src.tiles[tile + 1];
     float qx, qy, qz, nx, ny, nz;
     icp_query( L, T1, i, active, qx, qy, qz, nx, ny, nz );
-    const Match init = icp_warm_start( L, prob, i, active, qx, qy, qz, nx, ny, nz );
-    Match m = coop_search<true>( L.tgt, active, qx, qy, qz, nx, ny, nz, L.radius, L.radius_sq, L.gate_tmin, L.K,
-                                 lds[wib], coop, wib, lane, init );
-    if( wib == 0 ) icp_emit( L, prob, tile, i, active, lane, m );
+    const unsigned long long t_begin = L.dbg ? wall_clock64() : 0ull;
+    const bool search = active & !icp_certificate( L, prob, i, active, qx, qy, qz, nx, ny, nz );
+    const Match init = icp_warm_start( L, prob, i, search, qx, qy, qz, nx, ny, nz );
+    uint32_t streamed = 0;
+    Match m = coop_search<true>( L.tgt, search, qx, qy, qz, nx, ny, nz, L.radius, L.radius_sq, L.gate_tmin, L.gate_tmin - L.cert_mu, L.K,
+                                 lds[wib], coop, wib, lane, init, L.dbg ? &streamed : nullptr );
+    if( L.dbg && wib == 0 )
+    {
+      const int n_search = __popcll( __ballot( search ) ), n_unm = __popcll( __ballot( search & !m.found ) );
+      if( lane == 0 )
+      {
+        unsigned long long* d = L.dbg + 2 * (size_t)L.src.n_tiles + 4 * (size_t)b;
+        d[0] = wall_clock64() - t_begin; d[1] = streamed; d[2] = (unsigned long long)n_search; d[3] = (unsigned long long)n_unm;
+      }
+    }
+    if( wib == 0 ) icp_emit( L, prob, tile, i, active, lane, m, active & !search );
     __syncthreads();                               // merge slots are reused by the next queued tile
   }
 }
@@ -821,7 +904,7 @@ __global__ __launch_bounds__( BLOCK, 6 ) void k_score( ScoreLaunch L )
   float qx, qy, qz, nx, ny, nz;
   score_query( L, X, i, active, qx, qy, qz, nx, ny, nz );
   bool handoff;
-  Match m = tile_search<true>( L.scene, active, qx, qy, qz, nx, ny, nz, (float)L.sigma, L.radius_sq, L.gate_tmin, L.K,
+  Match m = tile_search<true>( L.scene, active, qx, qy, qz, nx, ny, nz, (float)L.sigma, L.radius_sq, L.gate_tmin, L.gate_tmin, L.K,
                                lds[wib], lane, L.solo_stages, &handoff, nullptr, no_match() );
   if( handoff )
   {
@@ -849,7 +932,7 @@ __global__ __launch_bounds__( COOP_BLOCK ) void k_score_coop( ScoreLaunch L )
     for( int k = 0; k < 16; ++k ) X.m[k] = L.poses[pose * 16 + k];
     float qx, qy, qz, nx, ny, nz;
     score_query( L, X, i, active, qx, qy, qz, nx, ny, nz );
-    Match m = coop_search<true>( L.scene, active, qx, qy, qz, nx, ny, nz, (float)L.sigma, L.radius_sq, L.gate_tmin, L.K,
+    Match m = coop_search<true>( L.scene, active, qx, qy, qz, nx, ny, nz, (float)L.sigma, L.radius_sq, L.gate_tmin, L.gate_tmin, L.K,
                                  lds[wib], coop, wib, lane, no_match() );
     if( wib == 0 ) score_emit( L, pose, tile, active, lane, m );
     __syncthreads();
@@ -917,7 +1000,7 @@ __global__ __launch_bounds__( BLOCK, 6 ) void k_label( LabelLaunch L )
     const PlacementDev& pl = L.pl[k];
     float qx, qy, qz;
     xform3( pl.inv, p.x, p.y, p.z, 1.0f, qx, qy, qz );                         // :755
-    Match m = tile_search<false>( pl.g, active, qx, qy, qz, 0.0f, 0.0f, 0.0f, pl.radius, pl.radius_sq, 0.0f, 1,
+    Match m = tile_search<false>( pl.g, active, qx, qy, qz, 0.0f, 0.0f, 0.0f, pl.radius, pl.radius_sq, 0.0f, 0.0f, 1,
                                   lds[wib], lane, 0, nullptr, nullptr, no_match() );   // :758 (K = 1)
     // :762-775 — found, strictly closer than the running minimum, and within 70° (either sign)
     bool ok = false;

@@ -2,6 +2,7 @@
 # Profiling recipes used for profiles/ (run on the GPU box through gpurun):
 #   bash tools/profile.sh stats     -> rocprofv3 --kernel-trace --stats of the bench command
 #   bash tools/profile.sh pmc       -> SQ instruction / wait counters per kernel
+#   bash tools/profile.sh trace     -> per-dispatch durations of one serial step, in launch order
 #   bash tools/profile.sh traffic   -> FETCH_SIZE and WRITE_SIZE in separate passes -> gpurun_out/pmc_traffic_raw.json
 # rocprofv3 is given the program itself after `--` (python ...), never a shell or env wrapper.
 cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
@@ -21,5 +22,9 @@ traffic)
     rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc_$c -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --serial > /dev/null 2> gpurun_out/pmc_$c.err
   done
   python tools/pmc_summary.py --traffic ;;
-*) echo "usage: $0 stats|pmc|traffic" ;;
+trace)   # per-dispatch timeline of one serial step: which ICP iteration costs what
+  rm -rf gpurun_out/prof_trace
+  rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_trace -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --serial > /dev/null 2> gpurun_out/prof_trace.err
+  python tools/pmc_summary.py --trace "$(find gpurun_out/prof_trace -name '*kernel_trace.csv' | head -1)" ;;
+*) echo "usage: $0 stats|pmc|traffic|trace" ;;
 esac
