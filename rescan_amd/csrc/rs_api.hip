@@ -667,12 +667,14 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
   if( source->n == 0 ) { for( int p = 0; p < n; ++p ) { errs[p] = 1e6f; if( iters ) iters[p] = 1; } return RS_HIP_OK; }   // n_corrs == 0 on the first search
 
   double* hR = g_ws.h_a.as<double>();               // n x ICP_NRES: moments, then stats
+  int coop_waves = 4;                               // chosen from the previous iteration's queue length
   for( int i = 0; i < max_iter; ++i )                                  // icp.h:444
   {
     if( ( rc = icp_upload_state( cx, T, active, i > 0 ? &T_prev : nullptr ) ) ) return rc;
     T_prev = T;                                                         // the poses this iteration searches with
     icp_set_radius( cx, max_dist, tmin );
     cx.L.warm = ( i > 0 && !getenv( "RS_HIP_NO_WARM" ) ) ? 1 : 0;   // every active problem wrote m_slot in iteration i-1
+    cx.L.coop_waves = coop_waves;
     static DevBuf dbgbuf;
     if( getenv( "RS_HIP_DEBUG_CYCLES" ) && n == 1 ) { dbgbuf.ensure( (size_t)cx.n_waves * 48 + 64 ); (void)hipMemsetAsync( (char*)dbgbuf.p + (size_t)cx.n_waves * 48, 0, 64, g_stream ); cx.L.dbg = dbgbuf.as<unsigned long long>(); }
     { ProfScope ps( "nn_icp" ); launch_icp_corr( cx.L, g_stream ); }
@@ -692,7 +694,9 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
         for( int b = 0; b < qc[0]; ++b ) rows.push_back( { c[4*b], c[4*b+1], c[4*b+2], c[4*b+3] } );
         std::sort( rows.begin(), rows.end() );
         auto pr = [&]( const char* tag, size_t k ) { if( rows.empty() ) return; k = std::min( k, rows.size() - 1 );
-          fprintf( stderr, "[rs_hip dbg]   coop %s: %.1f us, wave-0 streamed %llu cand, searching lanes %llu, unmatched %llu\n", tag, rows[k][0] / 100.0, rows[k][1], rows[k][2], rows[k][3] ); };
+          fprintf( stderr, "[rs_hip dbg]   coop %s: %.1f us (setup %.1f, shell k=2 %.1f, full shell %.1f, rest %.1f), wave-0 streamed %llu cand, searching lanes %llu, unmatched %llu\n", tag, rows[k][0] / 100.0,
+                   ( rows[k][3] & 0xffff ) / 100.0, ( ( rows[k][3] >> 16 ) & 0xffff ) / 100.0, ( ( rows[k][3] >> 32 ) & 0xffff ) / 100.0, ( rows[k][3] >> 48 ) / 100.0,
+                   rows[k][1], rows[k][2] & 0xff, rows[k][2] >> 8 ); };
         unsigned long long cat[4]; (void)hipMemcpy( cat, cx.L.dbg + 6 * (size_t)cx.n_waves, 32, hipMemcpyDeviceToHost );
         fprintf( stderr, "[rs_hip dbg] it %d unmatched lanes: skipped by certificate %llu, freshly certified %llu, rank-rejected %llu, loose-band only %llu\n", i, cat[0], cat[1], cat[2], cat[3] );
         fprintf( stderr, "[rs_hip dbg] coop tiles %d\n", qc[0] );
@@ -720,6 +724,9 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
     HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
 
     int n_active = 0;
+    double queued = 0.0;
+    for( int p = 0; p < n; ++p ) if( active[p] ) queued += hR[(size_t)p * ICP_NRES + ICP_NMOM + 3];
+    { static const char* e = getenv( "RS_HIP_COOP8_BELOW" ); const double lim = e ? atof( e ) : 1200.0; coop_waves = queued < lim ? 8 : 4; }
     for( int p = 0; p < n; ++p )
     {
       if( !active[p] ) continue;

@@ -65,11 +65,12 @@ struct IcpLaunch
   float*  m_dot;    // n_prob x nq
   double* corr_part;  // n_prob x n_tiles x 3
   double* mom_part;   // n_prob x n_mom_blocks x ICP_NMOM
-  double* res;        // n_prob x ICP_NRES : moments [0,35), then n_corr, mean, stddev, (unused)
+  double* res;        // n_prob x ICP_NRES : moments [0,35), then n_corr, mean, stddev, queued tiles
   int     n_mom_blocks;
   int*    queue;        // n_prob x n_tiles : tiles handed to the cooperative kernel
   int*    queue_count;  // n_prob
   int     solo_stages;  // candidates a lone wave streams before handing an unsettled tile off
+  int     coop_waves;   // waves per queued tile in the cooperative kernel (4 or 8)
   int     warm;         // m_slot holds last iteration's matches: use them as starting candidates
   // "no correspondence" certificates carried across iterations (rs_kernels.hip: icp_certificate); null = off
   float*  cert_r;       // n_prob x nq

@@ -371,6 +371,26 @@ __device__ __forceinline__ float bound_of( bool active, float radius_sq, const M
   return m.found ? __int_as_float( __float_as_int( m.d2 ) + 1 ) : radius_sq;
 }
 
+// Cells that can hold a candidate preceding the match of a lane that needs its exact rank: such a
+// candidate is no farther than the match, so it lies within sqrt(m.d2) of the query (the factor and
+// the offset are far above the fp32 rounding of dist² and of the square root).  Wave-uniform.
+__device__ __forceinline__ CellBox rank_box( const GridView& g, const CellBox& cur, bool need_rank, const Match& m,
+                                             float qx, float qy, float qz )
+{
+  const float rr = need_rank ? sqrtf( m.d2 ) * 1.0001f + 1e-5f : 0.0f;
+  const float big = FLT_MAX;
+  TileBounds t;
+  t.lx = wave_min( need_rank ? qx - rr : big );  t.hx = wave_max( need_rank ? qx + rr : -big );
+  t.ly = wave_min( need_rank ? qy - rr : big );  t.hy = wave_max( need_rank ? qy + rr : -big );
+  t.lz = wave_min( need_rank ? qz - rr : big );  t.hz = wave_max( need_rank ? qz + rr : -big );
+  t.any = true;
+  CellBox b = cell_box( g, t, 0.0f );
+  b.x0 = max( b.x0, cur.x0 ); b.x1 = min( b.x1, cur.x1 );
+  b.y0 = max( b.y0, cur.y0 ); b.y1 = min( b.y1, cur.y1 );
+  b.z0 = max( b.z0, cur.z0 ); b.z1 = min( b.z1, cur.z1 );
+  return b;
+}
+
 // Nearest candidate within the radius [whose normal passes tmin <= max(dot,0) <= 1, if GATED],
 // accepted only if fewer than K candidates (of any normal) precede it in (dist², index) order.
 // GATED: the reference's "first normal-compatible entry of the K-nearest list"
@@ -439,7 +459,9 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
     if( __any( need_rank ) )
     {
       int rank = 0;
-      sweep_shell<false>( g, cur, cur, false, L, lane, 0, 1, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
+      const CellBox rb = rank_box( g, cur, need_rank, m, qx, qy, qz );
+      if( !box_empty( rb ) )
+      sweep_shell<false>( g, rb, rb, false, L, lane, 0, 1, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
       { rank += need_rank ? precede4( X, Y, Z, k4, L, qx, qy, qz, radius_sq, m.d2, m.idx ) : 0; } );
       if( need_rank && rank >= K ) { m.found = false; m.slot = -1; }
     }
@@ -448,28 +470,31 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
 }
 
 // Merge slots of the cooperative search.
+template <int NW>
 struct CoopLds
 {
-  float m_d2[COOP_WAVES][WAVE];
-  int   m_idx[COOP_WAVES][WAVE];
-  float m_dot[COOP_WAVES][WAVE];
-  int   m_slot[COOP_WAVES][WAVE];
-  int   m_cnt[COOP_WAVES][WAVE];
-  int   m_loose[COOP_WAVES][WAVE];
+  float m_d2[NW][WAVE];
+  int   m_idx[NW][WAVE];
+  float m_dot[NW][WAVE];
+  int   m_slot[NW][WAVE];
+  int   m_cnt[NW][WAVE];
+  int   m_loose[NW][WAVE];
 };
 
-// The same staged search, done by all COOP_WAVES waves of a workgroup for ONE tile: every
+// The same staged search, done by all NW waves of a workgroup for ONE tile: every
 // wave holds the same queries and sweeps its share of each shell's chunks; after every shell the
 // per-lane bests are merged through LDS, so all waves take the same continue/stop decision and
 // carry the tightest bound into the next shell.
-template <bool GATED>
+template <bool GATED, int NW>
 __device__ __forceinline__ Match coop_search( const GridView& g, bool active,
                                               float qx, float qy, float qz, float nx, float ny, float nz,
                                               float radius, float radius_sq, float tmin, float tmin_loose, int K,
-                                              WaveLds& L, CoopLds& C, int wib, int lane, Match m /* starting candidate, see tile_search */,
-                                              uint32_t* dbg_streamed = nullptr )
+                                              WaveLds& L, CoopLds<NW>& C, int wib, int lane, Match m /* starting candidate, see tile_search */,
+                                              uint32_t* dbg_streamed = nullptr, unsigned long long* dbg_t = nullptr )
 {
   uint32_t streamed = 0;
+  int dbg_k = 0;
+  if( dbg_t ) dbg_t[dbg_k++] = wall_clock64();
   const TileBounds tb = wave_bounds( active, qx, qy, qz );
   if( !tb.any ) return m;                          // identical in every wave of the workgroup
   const CellBox full = cell_box( g, tb, radius );
@@ -490,13 +515,14 @@ __device__ __forceinline__ Match coop_search( const GridView& g, bool active,
   for( int k = 2; ; k = 1 << 20 )
   {
     cur = ( g.inv_cell > 0.0f ) ? box_grow( core, k, full ) : full;
-    streamed += sweep_shell<GATED>( g, cur, prev, have_prev, L, lane, wib, COOP_WAVES, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
+    streamed += sweep_shell<GATED>( g, cur, prev, have_prev, L, lane, wib, NW, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
     { consider4<GATED>( X, Y, Z, k4, L, qx, qy, qz, nx, ny, nz, tmin, tmin_loose, bound, m, seen_closer ); } );
+    if( dbg_t && dbg_k < 7 ) dbg_t[dbg_k++] = wall_clock64();
     // merge the per-lane bests of the waves; every wave continues with the merged best
     C.m_d2[wib][lane] = m.d2; C.m_idx[wib][lane] = m.idx; C.m_dot[wib][lane] = m.dot; C.m_slot[wib][lane] = m.found ? m.slot : -1;
     __syncthreads();
 #pragma unroll
-    for( int w = 0; w < COOP_WAVES; ++w )
+    for( int w = 0; w < NW; ++w )
     {
       const float d = C.m_d2[w][lane]; const int ix = C.m_idx[w][lane]; const int sl = C.m_slot[w][lane];
       if( sl >= 0 && lex_less( d, ix, m.d2, m.idx ) ) { m.d2 = d; m.idx = ix; m.dot = C.m_dot[w][lane]; m.slot = sl; m.found = true; }
@@ -517,23 +543,26 @@ __device__ __forceinline__ Match coop_search( const GridView& g, bool active,
     __syncthreads();
     int seen_total = 0;
 #pragma unroll
-    for( int w = 0; w < COOP_WAVES; ++w ) { seen_total += C.m_cnt[w][lane]; m.loose |= C.m_loose[w][lane] != 0; }
+    for( int w = 0; w < NW; ++w ) { seen_total += C.m_cnt[w][lane]; m.loose |= C.m_loose[w][lane] != 0; }
     bool need_rank = m.found && ( seen_total - 1 >= K );
     if( __any( need_rank ) )
     {
       int rank = 0;
-      sweep_shell<false>( g, cur, cur, false, L, lane, wib, COOP_WAVES, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
+      const CellBox rb = rank_box( g, cur, need_rank, m, qx, qy, qz );
+      if( !box_empty( rb ) )
+      sweep_shell<false>( g, rb, rb, false, L, lane, wib, NW, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
       { rank += need_rank ? precede4( X, Y, Z, k4, L, qx, qy, qz, radius_sq, m.d2, m.idx ) : 0; } );
       __syncthreads();                             // everyone is done reading the counts
       C.m_cnt[wib][lane] = rank;
       __syncthreads();
       rank = 0;
 #pragma unroll
-      for( int w = 0; w < COOP_WAVES; ++w ) rank += C.m_cnt[w][lane];
+      for( int w = 0; w < NW; ++w ) rank += C.m_cnt[w][lane];
       if( need_rank && rank >= K ) { m.found = false; m.slot = -1; }
     }
   }
   if( dbg_streamed ) *dbg_streamed = streamed;
+  if( dbg_t ) { while( dbg_k < 7 ) dbg_t[dbg_k++] = wall_clock64(); }
   return m;
 }
 
@@ -679,10 +708,11 @@ __global__ __launch_bounds__( BLOCK, RS_ICP_OCC ) void k_icp_corr( IcpLaunch L )
 }
 
 // Phase B: one workgroup per queued tile, whole box, chunks shared by its waves.
-__global__ __launch_bounds__( COOP_BLOCK ) void k_icp_corr_coop( IcpLaunch L )
+template <int NW>
+__global__ __launch_bounds__( NW * WAVE ) void k_icp_corr_coop( IcpLaunch L )
 {
-  __shared__ WaveLds lds[COOP_WAVES];
-  __shared__ CoopLds coop;
+  __shared__ WaveLds lds[NW];
+  __shared__ CoopLds<NW> coop;
   const int prob = blockIdx.y;
   if( L.active[prob] == 0 ) return;
   const int lane = threadIdx.x & ( WAVE - 1 );
@@ -699,18 +729,23 @@ __global__ __launch_bounds__( COOP_BLOCK ) void k_icp_corr_coop( IcpLaunch L )
     float qx, qy, qz, nx, ny, nz;
     icp_query( L, T1, i, active, qx, qy, qz, nx, ny, nz );
     const unsigned long long t_begin = L.dbg ? wall_clock64() : 0ull;
+    unsigned long long stamps[8];
     const bool search = active & !icp_certificate( L, prob, i, active, qx, qy, qz, nx, ny, nz );
     const Match init = icp_warm_start( L, prob, i, search, qx, qy, qz, nx, ny, nz );
     uint32_t streamed = 0;
-    Match m = coop_search<true>( L.tgt, search, qx, qy, qz, nx, ny, nz, L.radius, L.radius_sq, L.gate_tmin, L.gate_tmin - L.cert_mu, L.K,
-                                 lds[wib], coop, wib, lane, init, L.dbg ? &streamed : nullptr );
+    Match m = coop_search<true, NW>( L.tgt, search, qx, qy, qz, nx, ny, nz, L.radius, L.radius_sq, L.gate_tmin, L.gate_tmin - L.cert_mu, L.K,
+                                 lds[wib], coop, wib, lane, init, L.dbg ? &streamed : nullptr, L.dbg ? stamps : nullptr );
     if( L.dbg && wib == 0 )
     {
       const int n_search = __popcll( __ballot( search ) ), n_unm = __popcll( __ballot( search & !m.found ) );
       if( lane == 0 )
       {
         unsigned long long* d = L.dbg + 2 * (size_t)L.src.n_tiles + 4 * (size_t)b;
-        d[0] = wall_clock64() - t_begin; d[1] = streamed; d[2] = (unsigned long long)n_search; d[3] = (unsigned long long)n_unm;
+        const unsigned long long t_end = wall_clock64();
+        // [0] total | [1] streamed | lanes | phases packed: setup, shell 1, shell 2, rest (each 16 bits, ticks of 10 ns)
+        auto clip = []( unsigned long long v ) { return v > 0xffffull ? 0xffffull : v; };
+        d[0] = t_end - t_begin; d[1] = streamed; d[2] = (unsigned long long)n_search | ( (unsigned long long)n_unm << 8 );
+        d[3] = clip( stamps[0] - t_begin ) | ( clip( stamps[1] - stamps[0] ) << 16 ) | ( clip( stamps[2] - stamps[1] ) << 32 ) | ( clip( t_end - stamps[2] ) << 48 );
       }
     }
     if( wib == 0 ) icp_emit( L, prob, tile, i, active, lane, m, active & !search );
@@ -743,7 +778,7 @@ __global__ __launch_bounds__( BLOCK ) void k_icp_stats( IcpLaunch L )
     float var = sqm - mean * mean;
     float sd = (float)sqrt( (double)var );                 // (float)sqrt( ... ), msh_std.h:1824
     double* st = L.res + (size_t)prob * ICP_NRES + ICP_NMOM;
-    st[0] = n; st[1] = mean; st[2] = sd; st[3] = 0.0;
+    st[0] = n; st[1] = mean; st[2] = sd; st[3] = L.queue_count ? (double)L.queue_count[prob] : 0.0;   // [3]: tiles phase A handed off
     if( L.queue_count ) L.queue_count[prob] = 0;         // ready for the next iteration's phase A
   }
 }
@@ -846,7 +881,10 @@ void launch_icp_corr( const IcpLaunch& L, hipStream_t st )
   hipLaunchKernelGGL( k_icp_corr, grid, dim3( BLOCK ), 0, st, L );
   // the queue length is only known on the device: a fixed grid strides over it
   int coop_blocks = L.src.n_tiles < 2048 ? L.src.n_tiles : 2048;
-  hipLaunchKernelGGL( k_icp_corr_coop, dim3( coop_blocks > 0 ? coop_blocks : 1, L.n_prob ), dim3( COOP_BLOCK ), 0, st, L );
+  const dim3 cgrid( coop_blocks > 0 ? coop_blocks : 1, L.n_prob );
+  // a short queue is latency-bound by its heaviest tile: give every tile more waves
+  if( L.coop_waves >= 8 ) hipLaunchKernelGGL( k_icp_corr_coop<8>, cgrid, dim3( 8 * WAVE ), 0, st, L );
+  else                    hipLaunchKernelGGL( k_icp_corr_coop<COOP_WAVES>, cgrid, dim3( COOP_BLOCK ), 0, st, L );
 }
 void launch_icp_stats( const IcpLaunch& L, hipStream_t st )
 {
@@ -917,7 +955,7 @@ __global__ __launch_bounds__( BLOCK, 6 ) void k_score( ScoreLaunch L )
 __global__ __launch_bounds__( COOP_BLOCK ) void k_score_coop( ScoreLaunch L )
 {
   __shared__ WaveLds lds[COOP_WAVES];
-  __shared__ CoopLds coop;
+  __shared__ CoopLds<COOP_WAVES> coop;
   const int lane = threadIdx.x & ( WAVE - 1 );
   const int wib = threadIdx.x / WAVE;
   const int n_queued = *L.queue_count;
@@ -932,7 +970,7 @@ __global__ __launch_bounds__( COOP_BLOCK ) void k_score_coop( ScoreLaunch L )
     for( int k = 0; k < 16; ++k ) X.m[k] = L.poses[pose * 16 + k];
     float qx, qy, qz, nx, ny, nz;
     score_query( L, X, i, active, qx, qy, qz, nx, ny, nz );
-    Match m = coop_search<true>( L.scene, active, qx, qy, qz, nx, ny, nz, (float)L.sigma, L.radius_sq, L.gate_tmin, L.gate_tmin, L.K,
+    Match m = coop_search<true, COOP_WAVES>( L.scene, active, qx, qy, qz, nx, ny, nz, (float)L.sigma, L.radius_sq, L.gate_tmin, L.gate_tmin, L.K,
                                  lds[wib], coop, wib, lane, no_match() );
     if( wib == 0 ) score_emit( L, pose, tile, active, lane, m );
     __syncthreads();
