@@ -512,71 +512,15 @@ inline int handoff_threshold( long long total_tiles )
 
 inline float radius_sq_of( float r ) { return (float)( (double)r * (double)r ); }   // msh_hash_grid.h:1104,1111 + :828
 
-// Finish lib/rs/icp.h:210-298 from the 35 uncentred fp64 moments (layout: k_icp_moments).
-// Returns false when the reference would have stopped before estimating (Σw <= 1e-7, icp.h:466).
-bool icp_solve( const double* M, Mat4& T1, float& err )
-{
-  const double W = M[0];
-  if( (float)W <= 1e-7 ) return false;
-  const float c1f[3] = { (float)( M[1] / W ), (float)( M[2] / W ), (float)( M[3] / W ) };
-  const float c2f[3] = { (float)( M[4] / W ), (float)( M[5] / W ), (float)( M[6] / W ) };
-  const double c1[3] = { c1f[0], c1f[1], c1f[2] }, dl[3] = { (double)c1f[0] - c2f[0], (double)c1f[1] - c2f[1], (double)c1f[2] - c2f[2] };
-  const double Maa[3][3] = { { M[7], M[8], M[9] }, { M[8], M[10], M[11] }, { M[9], M[11], M[12] } };
-  double Man[3][3];
-  for( int r = 0; r < 3; ++r ) for( int c = 0; c < 3; ++c ) Man[r][c] = M[13 + 3*r + c];
-  const double Mnn[3][3] = { { M[22], M[23], M[24] }, { M[23], M[25], M[26] }, { M[24], M[26], M[27] } };
-  const double vae[3] = { M[28], M[29], M[30] }, vne[3] = { M[31], M[32], M[33] };
-  const double see = M[34];
-  // X v = c1 × v
-  const double X[3][3] = { { 0, -c1[2], c1[1] }, { c1[2], 0, -c1[0] }, { -c1[1], c1[0], 0 } };
-
-  auto mul = []( const double A[3][3], const double B[3][3], double O[3][3], bool tb ) {
-    for( int r = 0; r < 3; ++r ) for( int c = 0; c < 3; ++c ) { double s = 0; for( int k = 0; k < 3; ++k ) s += A[r][k] * ( tb ? B[c][k] : B[k][c] ); O[r][c] = s; } };
-  double XMnn[3][3], ManXt[3][3], XMnnXt[3][3];
-  mul( X, Mnn, XMnn, false );        // X·Mnn
-  mul( Man, X, ManXt, true );        // Man·Xᵀ
-  mul( XMnn, X, XMnnXt, true );      // X·Mnn·Xᵀ
-  double TL[3][3], TR[3][3];
-  for( int r = 0; r < 3; ++r ) for( int c = 0; c < 3; ++c )
-  {
-    TL[r][c] = Maa[r][c] - ManXt[r][c] - ManXt[c][r] + XMnnXt[r][c];   // Σw·c cᵀ, c = a - X n
-    TR[r][c] = Man[r][c] - XMnn[r][c];                                   // Σw·c nᵀ
-  }
-  double bc[3], bn[3], Mnn_d[3], Man_d[3], sum;
-  for( int r = 0; r < 3; ++r ) { Mnn_d[r] = 0; Man_d[r] = 0; for( int k = 0; k < 3; ++k ) { Mnn_d[r] += Mnn[r][k] * dl[k]; Man_d[r] += Man[r][k] * dl[k]; } }
-  for( int r = 0; r < 3; ++r )
-  {
-    double xv = 0, xm = 0;
-    for( int k = 0; k < 3; ++k ) { xv += X[r][k] * vne[k]; xm += X[r][k] * Mnn_d[k]; }
-    bc[r] = vae[r] - Man_d[r] - xv + xm;       // Σw·c·s,  s = e - δ·n
-    bn[r] = vne[r] - Mnn_d[r];                 // Σw·n·s
-  }
-  sum = see - 2.0 * ( dl[0] * vne[0] + dl[1] * vne[1] + dl[2] * vne[2] ) + ( dl[0] * Mnn_d[0] + dl[1] * Mnn_d[1] + dl[2] * Mnn_d[2] );
-  if( sum < 0.0 ) sum = 0.0;
-  err = (float)std::sqrt( sum / W );           // icp.h:253
-
-  double C[6][6], b[6], x[6] = { 0, 0, 0, 0, 0, 0 };    // icp.h:267-277
-  for( int r = 0; r < 3; ++r ) for( int c = 0; c < 3; ++c )
-  { C[r][c] = TL[r][c]; C[r][3+c] = TR[r][c]; C[3+r][c] = TR[c][r]; C[3+r][3+c] = Mnn[r][c]; }
-  for( int r = 0; r < 3; ++r ) { b[r] = -bc[r]; b[3+r] = -bn[r]; }
-  ldlt6_solve( C, b, x );
-
-  Mat4 T = mat4_identity();                    // icp.h:280-295
-  T = mat4_translate( T, c1f[0], c1f[1], c1f[2] );
-  T = mat4_translate( T, (float)x[3], (float)x[4], (float)x[5] );
-  T = mat4_rotate_axis( T, (float)x[0], 0 );
-  T = mat4_rotate_axis( T, (float)x[1], 1 );
-  T = mat4_rotate_axis( T, (float)x[2], 2 );
-  T = mat4_translate( T, -c1f[0], -c1f[1], -c1f[2] );
-  T1 = mat4_mul( T, T1 );
-  return true;
-}
-
 struct IcpCtx
 {
   IcpLaunch L{};
   int n_waves = 0;
 };
+
+// Device-resident loop state, one 4-byte word array after the other (n = n_prob):
+//   T1 16n | active n | T1_prev 16n | iters n | err n | prev_err n | queued n | ticket 2n
+constexpr size_t ICP_STATE_WORDS = 16 + 1 + 16 + 1 + 1 + 1 + 1 + 2;
 
 int icp_prepare( IcpCtx& cx, const rs_hip_cloud_t* src, const rs_hip_cloud_t* tgt, int n_prob, const float* T2 )
 {
@@ -591,18 +535,19 @@ int icp_prepare( IcpCtx& cx, const rs_hip_cloud_t* src, const rs_hip_cloud_t* tg
   L.n_mom_blocks = std::max( 1, std::min( 256, ( src->n + 255 ) / 256 ) );
   const size_t nq = std::max<size_t>( 1, (size_t)src->n ), np = (size_t)n_prob;
   int rc;
-  if( ( rc = g_ws.state.ensure( np * 132 ) ) ||
+  if( ( rc = g_ws.state.ensure( np * ICP_STATE_WORDS * 4 ) ) ||
       ( rc = g_ws.slot.ensure( np * nq * 4 ) ) || ( rc = g_ws.d2.ensure( np * nq * 4 ) ) || ( rc = g_ws.dot.ensure( np * nq * 4 ) ) ||
       ( rc = g_ws.corr_part.ensure( np * std::max( 1, cx.n_waves ) * 3 * 8 ) ) ||
       ( rc = g_ws.mom_part.ensure( np * L.n_mom_blocks * ICP_NMOM * 8 ) ) || ( rc = g_ws.res.ensure( np * ICP_NRES * 8 ) ) ||
-      ( rc = g_ws.h_a.ensure( np * ICP_NRES * 8 ) ) || ( rc = g_ws.h_b.ensure( np * 132 ) ) ||
+      ( rc = g_ws.h_a.ensure( np * ICP_NRES * 8 ) ) || ( rc = g_ws.h_b.ensure( np * ICP_STATE_WORDS * 4 ) ) ||
       ( rc = g_ws.queue.ensure( np * std::max( 1, cx.n_waves ) * 4 ) ) || ( rc = g_ws.queue_count.ensure( np * 4 ) ) )
     return rc;
   L.queue = g_ws.queue.as<int>(); L.queue_count = g_ws.queue_count.as<int>();
   L.solo_stages = handoff_threshold( (long long)cx.n_waves * n_prob );
-  // one upload per iteration: [n_prob x 16 floats of T1][n_prob active flags][n_prob x 16 floats: T1 of the previous iteration]
-  L.T1 = g_ws.state.as<float>(); L.active = (const int*)( g_ws.state.as<float>() + np * 16 );
-  L.T1_prev = g_ws.state.as<float>() + np * 17;
+  float* w = g_ws.state.as<float>();
+  L.T1 = w; L.active = (int*)( w + np * 16 ); L.T1_prev = w + np * 17;
+  L.iters = (int*)( w + np * 33 ); L.err = w + np * 34; L.prev_err = w + np * 35; L.queued = (int*)( w + np * 36 ); L.ticket = (int*)( w + np * 37 );
+  L.solve = 0; L.iter_index = 0; L.fixed_iters = 0;
   L.cert_r = nullptr; L.cert_dot = nullptr; L.cert_mu = 0.0f; L.tgt_nor_max = tgt->nor_max;
   L.m_slot = g_ws.slot.as<int>(); L.m_d2 = g_ws.d2.as<float>(); L.m_dot = g_ws.dot.as<float>();
   L.corr_part = g_ws.corr_part.as<double>();
@@ -612,18 +557,19 @@ int icp_prepare( IcpCtx& cx, const rs_hip_cloud_t* src, const rs_hip_cloud_t* tg
   return RS_HIP_OK;
 }
 
-int icp_upload_state( IcpCtx& cx, const std::vector<Mat4>& T, const std::vector<int>& active, const std::vector<Mat4>* T_prev = nullptr )
+// initial loop state (icp.h:441-442: errors start at 1e6)
+int icp_upload_state( IcpCtx& cx, const float* T1s, size_t np )
 {
-  const size_t np = T.size();
-  float* hT = g_ws.h_b.as<float>();
-  int* hA = (int*)( hT + np * 16 );
-  float* hP = hT + np * 17;
+  float* h = g_ws.h_b.as<float>();
+  std::memset( h, 0, np * ICP_STATE_WORDS * 4 );
+  int* hi = (int*)h;
   for( size_t p = 0; p < np; ++p )
   {
-    std::memcpy( hT + 16 * p, T[p].m, 64 ); hA[p] = active[p];
-    std::memcpy( hP + 16 * p, ( T_prev ? *T_prev : T )[p].m, 64 );
+    std::memcpy( h + 16 * p, T1s + 16 * p, 64 ); hi[np * 16 + p] = 1;
+    std::memcpy( h + np * 17 + 16 * p, T1s + 16 * p, 64 );
+    h[np * 34 + p] = 1e6f; h[np * 35 + p] = 1e6f;
   }
-  HIP_TRY( hipMemcpyAsync( g_ws.state.p, hT, np * 132, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipMemcpyAsync( g_ws.state.p, h, np * ICP_STATE_WORDS * 4, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
   return RS_HIP_OK;
 }
 
@@ -638,6 +584,52 @@ int icp_enable_certificates( IcpCtx& cx, size_t np, size_t nq )
   HIP_TRY( hipMemsetAsync( g_ws.cert_r.p, 0xFF, np * nq * 4, g_stream ), RS_HIP_E_RUNTIME );      // NaN: no certificate
   cx.L.cert_r = g_ws.cert_r.as<float>(); cx.L.cert_dot = g_ws.cert_dot.as<float>(); cx.L.cert_mu = 0.05f;
   return RS_HIP_OK;
+}
+
+// ---- diagnostics (RS_HIP_DEBUG / RS_HIP_DEBUG_CYCLES): one iteration per chunk, device timers per tile ----
+void icp_debug_before( IcpCtx& cx, int n )
+{
+  static DevBuf dbgbuf;
+  if( getenv( "RS_HIP_DEBUG_CYCLES" ) && n == 1 )
+  {
+    if( dbgbuf.ensure( (size_t)cx.n_waves * 48 + 64 ) ) return;
+    (void)hipMemsetAsync( (char*)dbgbuf.p + (size_t)cx.n_waves * 48, 0, 64, g_stream );
+    cx.L.dbg = dbgbuf.as<unsigned long long>();
+  }
+}
+
+void icp_debug_after( IcpCtx& cx, int n_src, int n, int i, float max_dist )
+{
+  (void)hipStreamSynchronize( g_stream );
+  std::vector<int> qc( n ), ms( (size_t)n_src ); std::vector<float> cr( cx.L.cert_r ? (size_t)n_src : 0 );
+  (void)hipMemcpy( qc.data(), cx.L.queued, (size_t)n * 4, hipMemcpyDeviceToHost );
+  (void)hipMemcpy( ms.data(), cx.L.m_slot, ms.size() * 4, hipMemcpyDeviceToHost );
+  if( cx.L.cert_r ) (void)hipMemcpy( cr.data(), cx.L.cert_r, cr.size() * 4, hipMemcpyDeviceToHost );
+  size_t unm = 0, cert = 0;
+  for( int v : ms ) unm += v < 0;
+  for( float v : cr ) cert += v > 0.0f;
+  fprintf( stderr, "[rs_hip icp] it %d (max_dist %g, coop waves %d): prob 0 queued tiles %d of %d, unmatched %zu of %d, certificates %zu\n",
+           i, (double)max_dist, cx.L.coop_waves, qc[0], cx.n_waves, unm, n_src, cert );
+  if( !cx.L.dbg ) return;
+  std::vector<unsigned long long> h( (size_t)cx.n_waves * 2 );
+  (void)hipMemcpy( h.data(), cx.L.dbg, h.size() * 8, hipMemcpyDeviceToHost );
+  std::vector<unsigned long long> t; unsigned long long sum = 0, ho = 0, tiles_uns = 0;
+  for( int k = 0; k < cx.n_waves; ++k ) { t.push_back( h[2*k] ); sum += h[2*k]; ho += h[2*k+1]; tiles_uns += h[2*k+1] ? 1 : 0; }
+  std::sort( t.begin(), t.end() );
+  fprintf( stderr, "[rs_hip dbg] phase A: unsettled lanes after shell 1: %llu in %llu tiles; wall-ticks(100MHz) per tile: mean %.0f p50 %llu p90 %llu p99 %llu max %llu\n",
+           ho, tiles_uns, (double)sum / cx.n_waves, t[t.size()/2], t[t.size()*9/10], t[t.size()*99/100], t.back() );
+  std::vector<unsigned long long> c( (size_t)qc[0] * 4 );
+  (void)hipMemcpy( c.data(), cx.L.dbg + 2 * (size_t)cx.n_waves, c.size() * 8, hipMemcpyDeviceToHost );
+  std::vector<std::array<unsigned long long, 4>> rows;
+  for( int b = 0; b < qc[0]; ++b ) rows.push_back( { c[4*b], c[4*b+1], c[4*b+2], c[4*b+3] } );
+  std::sort( rows.begin(), rows.end() );
+  auto pr = [&]( const char* tag, size_t k ) { if( rows.empty() ) return; k = std::min( k, rows.size() - 1 );
+    fprintf( stderr, "[rs_hip dbg]   coop %s: %.1f us (setup %.1f, shell k=2 %.1f, full shell %.1f, rest %.1f), wave-0 streamed %llu cand, searching lanes %llu, unmatched %llu\n", tag, rows[k][0] / 100.0,
+             ( rows[k][3] & 0xffff ) / 100.0, ( ( rows[k][3] >> 16 ) & 0xffff ) / 100.0, ( ( rows[k][3] >> 32 ) & 0xffff ) / 100.0, ( rows[k][3] >> 48 ) / 100.0,
+             rows[k][1], rows[k][2] & 0xff, rows[k][2] >> 8 ); };
+  unsigned long long cat[4]; (void)hipMemcpy( cat, cx.L.dbg + 6 * (size_t)cx.n_waves, 32, hipMemcpyDeviceToHost );
+  fprintf( stderr, "[rs_hip dbg]   unmatched lanes: skipped by certificate %llu, freshly certified %llu, rank-rejected %llu, loose-band only %llu\n", cat[0], cat[1], cat[2], cat[3] );
+  pr( "p10", rows.size() / 10 ); pr( "p50", rows.size() / 2 ); pr( "p90", rows.size() * 9 / 10 ); pr( "p99", rows.size() * 99 / 100 ); pr( "max", rows.size() - 1 );
 }
 
 void icp_set_radius( IcpCtx& cx, float max_dist, float tmin )
@@ -658,98 +650,47 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
   IcpCtx cx;
   if( ( rc = icp_prepare( cx, source, target, n, T2 ) ) ) return rc;
   const float tmin = icp_gate_threshold( max_angle );
-
-  if( ( rc = icp_enable_certificates( cx, (size_t)n, std::max<size_t>( 1, (size_t)source->n ) ) ) ) return rc;
-  std::vector<Mat4> T( n ), T_prev( n );
-  std::vector<int> active( n, 1 ), it_count( n, 0 );
-  std::vector<float> err( n, 1e6f ), prev( n, 1e6f );                 // icp.h:441-442
-  for( int p = 0; p < n; ++p ) std::memcpy( T[p].m, T1s + 16 * p, 64 );
   if( source->n == 0 ) { for( int p = 0; p < n; ++p ) { errs[p] = 1e6f; if( iters ) iters[p] = 1; } return RS_HIP_OK; }   // n_corrs == 0 on the first search
+  if( ( rc = icp_enable_certificates( cx, (size_t)n, (size_t)source->n ) ) ) return rc;
+  if( ( rc = icp_upload_state( cx, T1s, (size_t)n ) ) ) return rc;
 
-  double* hR = g_ws.h_a.as<double>();               // n x ICP_NRES: moments, then stats
-  int coop_waves = 4;                               // chosen from the previous iteration's queue length
-  for( int i = 0; i < max_iter; ++i )                                  // icp.h:444
+  // The whole iteration runs on the device (search, statistics, moments, solve, pose update, stop
+  // tests), so iterations are enqueued back to back and the host looks at the state only once per
+  // chunk; problems that stopped inside a chunk turn the rest of its launches into no-ops
+  // (every kernel returns at once for an inactive problem).
+  const bool debug = getenv( "RS_HIP_DEBUG" ) || getenv( "RS_HIP_DEBUG_CYCLES" );
+  static const int chunk_env = getenv( "RS_HIP_ICP_CHUNK" ) ? atoi( getenv( "RS_HIP_ICP_CHUNK" ) ) : 4;
+  const size_t np = (size_t)n, state_bytes = np * ICP_STATE_WORDS * 4;
+  float* hS = g_ws.h_b.as<float>();
+  const int* hActive = (const int*)( hS + np * 16 );
+  const bool small = (long long)cx.n_waves * n < 2400;      // the cooperative queue is short from the start
+  cx.L.solve = 1; cx.L.fixed_iters = fixed_iters ? 1 : 0;
+  for( int i = 0; i < max_iter; )                                       // icp.h:444
   {
-    if( ( rc = icp_upload_state( cx, T, active, i > 0 ? &T_prev : nullptr ) ) ) return rc;
-    T_prev = T;                                                         // the poses this iteration searches with
-    icp_set_radius( cx, max_dist, tmin );
-    cx.L.warm = ( i > 0 && !getenv( "RS_HIP_NO_WARM" ) ) ? 1 : 0;   // every active problem wrote m_slot in iteration i-1
-    cx.L.coop_waves = coop_waves;
-    static DevBuf dbgbuf;
-    if( getenv( "RS_HIP_DEBUG_CYCLES" ) && n == 1 ) { dbgbuf.ensure( (size_t)cx.n_waves * 48 + 64 ); (void)hipMemsetAsync( (char*)dbgbuf.p + (size_t)cx.n_waves * 48, 0, 64, g_stream ); cx.L.dbg = dbgbuf.as<unsigned long long>(); }
-    { ProfScope ps( "nn_icp" ); launch_icp_corr( cx.L, g_stream ); }
-    if( cx.L.dbg )
+    const int chunk = debug ? 1 : ( fixed_iters ? max_iter - i : std::min( std::max( 1, chunk_env ), max_iter - i ) );
+    for( int c = 0; c < chunk; ++c, ++i )
     {
-      std::vector<unsigned long long> h( (size_t)cx.n_waves * 2 );
-      (void)hipMemcpy( h.data(), cx.L.dbg, h.size() * 8, hipMemcpyDeviceToHost );
-      std::vector<unsigned long long> t; unsigned long long sum = 0, ho = 0;
-      unsigned long long tiles_uns = 0;
-      for( int k = 0; k < cx.n_waves; ++k ) { t.push_back( h[2*k] ); sum += h[2*k]; ho += h[2*k+1]; tiles_uns += h[2*k+1] ? 1 : 0; }
-      std::sort( t.begin(), t.end() );
-      {
-        std::vector<int> qc( 1 ); (void)hipMemcpy( qc.data(), cx.L.queue_count, 4, hipMemcpyDeviceToHost );
-        std::vector<unsigned long long> c( (size_t)qc[0] * 4 );
-        (void)hipMemcpy( c.data(), cx.L.dbg + 2 * (size_t)cx.n_waves, c.size() * 8, hipMemcpyDeviceToHost );
-        std::vector<std::array<unsigned long long, 4>> rows;
-        for( int b = 0; b < qc[0]; ++b ) rows.push_back( { c[4*b], c[4*b+1], c[4*b+2], c[4*b+3] } );
-        std::sort( rows.begin(), rows.end() );
-        auto pr = [&]( const char* tag, size_t k ) { if( rows.empty() ) return; k = std::min( k, rows.size() - 1 );
-          fprintf( stderr, "[rs_hip dbg]   coop %s: %.1f us (setup %.1f, shell k=2 %.1f, full shell %.1f, rest %.1f), wave-0 streamed %llu cand, searching lanes %llu, unmatched %llu\n", tag, rows[k][0] / 100.0,
-                   ( rows[k][3] & 0xffff ) / 100.0, ( ( rows[k][3] >> 16 ) & 0xffff ) / 100.0, ( ( rows[k][3] >> 32 ) & 0xffff ) / 100.0, ( rows[k][3] >> 48 ) / 100.0,
-                   rows[k][1], rows[k][2] & 0xff, rows[k][2] >> 8 ); };
-        unsigned long long cat[4]; (void)hipMemcpy( cat, cx.L.dbg + 6 * (size_t)cx.n_waves, 32, hipMemcpyDeviceToHost );
-        fprintf( stderr, "[rs_hip dbg] it %d unmatched lanes: skipped by certificate %llu, freshly certified %llu, rank-rejected %llu, loose-band only %llu\n", i, cat[0], cat[1], cat[2], cat[3] );
-        fprintf( stderr, "[rs_hip dbg] coop tiles %d\n", qc[0] );
-        pr( "p10", rows.size() / 10 ); pr( "p50", rows.size() / 2 ); pr( "p90", rows.size() * 9 / 10 ); pr( "p99", rows.size() * 99 / 100 ); pr( "max", rows.size() - 1 );
-      }
-      fprintf( stderr, "[rs_hip dbg] unsettled lanes after shell 1: %llu of %d queries, in %llu tiles\n", ho, source->n, tiles_uns );
-      fprintf( stderr, "[rs_hip dbg] it %d tiles %d handoff %llu  wall-ticks(100MHz): mean %.0f p50 %llu p90 %llu p99 %llu max %llu\n", i, cx.n_waves, ho,
-               (double)sum / cx.n_waves, t[t.size()/2], t[t.size()*9/10], t[t.size()*99/100], t.back() );
+      icp_set_radius( cx, max_dist, tmin );
+      cx.L.iter_index = i;
+      cx.L.warm = ( i > 0 && !getenv( "RS_HIP_NO_WARM" ) ) ? 1 : 0;   // every active problem wrote m_slot in iteration i-1
+      // a short queue is bound by its heaviest tile: from the third iteration on the certificates have
+      // emptied it (small batches: always)
+      cx.L.coop_waves = ( small || ( i >= 2 && cx.L.cert_r ) ) ? 8 : 4;
+      if( debug ) icp_debug_before( cx, n );
+      { ProfScope ps( "nn_icp" ); launch_icp_corr( cx.L, g_stream ); }
+      if( debug ) icp_debug_after( cx, source->n, n, i, max_dist );
+      { ProfScope ps( "icp_moments" ); launch_icp_moments( cx.L, g_stream ); }
+      double nd = max_dist * 0.95;                                      // icp.h:493
+      max_dist = (float)( nd > 0.05 ? nd : 0.05 );
     }
-    if( getenv( "RS_HIP_DEBUG" ) )
-    {
-      std::vector<int> qc( n ), ms( (size_t)source->n ); std::vector<float> cr( cx.L.cert_r ? (size_t)source->n : 0 );
-      (void)hipStreamSynchronize( g_stream );
-      (void)hipMemcpy( qc.data(), cx.L.queue_count, (size_t)n * 4, hipMemcpyDeviceToHost );
-      (void)hipMemcpy( ms.data(), cx.L.m_slot, ms.size() * 4, hipMemcpyDeviceToHost );
-      if( cx.L.cert_r ) (void)hipMemcpy( cr.data(), cx.L.cert_r, cr.size() * 4, hipMemcpyDeviceToHost );
-      size_t unm = 0, cert = 0;
-      for( int v : ms ) unm += v < 0;
-      for( float v : cr ) cert += v > 0.0f;
-      fprintf( stderr, "[rs_hip icp] it %d: prob 0 queued tiles %d of %d, unmatched %zu of %d, certificates %zu\n", i, qc[0], cx.n_waves, unm, source->n, cert );
-    }
-    launch_icp_stats( cx.L, g_stream );
-    { ProfScope ps( "icp_moments" ); launch_icp_moments( cx.L, g_stream ); }
-    HIP_TRY( hipMemcpyAsync( hR, g_ws.res.p, (size_t)n * ICP_NRES * 8, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+    HIP_TRY( hipMemcpyAsync( hS, g_ws.state.p, state_bytes, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
     HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
-
     int n_active = 0;
-    double queued = 0.0;
-    for( int p = 0; p < n; ++p ) if( active[p] ) queued += hR[(size_t)p * ICP_NRES + ICP_NMOM + 3];
-    { static const char* e = getenv( "RS_HIP_COOP8_BELOW" ); const double lim = e ? atof( e ) : 1200.0; coop_waves = queued < lim ? 8 : 4; }
-    for( int p = 0; p < n; ++p )
-    {
-      if( !active[p] ) continue;
-      prev[p] = err[p];
-      it_count[p]++;
-      const double* hM = hR + (size_t)p * ICP_NRES;
-      const double* hS = hM + ICP_NMOM;
-      if( hS[0] == 0.0 ) { active[p] = 0; continue; }                 // icp.h:455-459 no correspondences
-      float e;
-      if( !icp_solve( hM, T[p], e ) ) { active[p] = 0; continue; }    // icp.h:466-470
-      err[p] = e;
-      if( getenv( "RS_HIP_DEBUG" ) )
-        fprintf( stderr, "[rs_hip icp] it %d prob %d n_corr %.0f mean %g sd %g W %.9g err %.9g max_dist %g T12 %g %g %g\n", i, p, hS[0], hS[1], hS[2],
-                 hM[0], (double)e, (double)max_dist, T[p].m[12], T[p].m[13], T[p].m[14] );
-      float delta = fabsf( prev[p] - err[p] );
-      if( !fixed_iters && i > 5 && delta < 1e-5 ) { active[p] = 0; continue; }               // icp.h:489
-      n_active++;
-    }
+    for( int p = 0; p < n; ++p ) n_active += hActive[p] ? 1 : 0;
     if( n_active == 0 ) break;
-    double nd = max_dist * 0.95;                                        // icp.h:493
-    max_dist = (float)( nd > 0.05 ? nd : 0.05 );
   }
-  for( int p = 0; p < n; ++p ) { std::memcpy( T1s + 16 * p, T[p].m, 64 ); errs[p] = err[p]; if( iters ) iters[p] = it_count[p]; }
+  const int* hIters = (const int*)( hS + np * 33 );
+  for( int p = 0; p < n; ++p ) { std::memcpy( T1s + 16 * p, hS + 16 * p, 64 ); errs[p] = hS[np * 34 + p]; if( iters ) iters[p] = hIters[p]; }
   return RS_HIP_OK;
 }
 
@@ -777,8 +718,7 @@ int rs_hip_icp_find_corrs( const rs_hip_cloud_t* source, const rs_hip_cloud_t* t
   const int nq = source->n;
   if( nq == 0 ) return RS_HIP_OK;
   std::vector<Mat4> T( 1 ); std::memcpy( T[0].m, T1, 64 );
-  std::vector<int> active( 1, 1 );
-  if( ( rc = icp_upload_state( cx, T, active ) ) ) return rc;
+  if( ( rc = icp_upload_state( cx, T1, 1 ) ) ) return rc;
   icp_set_radius( cx, max_dist, icp_gate_threshold( max_angle ) );
   { ProfScope ps( "nn_icp" ); launch_icp_corr( cx.L, g_stream ); }
   std::vector<int> slot( nq ); std::vector<float> d2( nq ), dot( nq );
@@ -836,7 +776,7 @@ int rs_hip_icp_estimate_pt2pl( const float* pts1, const float* pts2, const float
   const size_t nn = (size_t)n;
   if( ( rc = g_ws.tmp_pos.ensure( nn * 16 ) ) || ( rc = g_ws.tmp_pos2.ensure( nn * 16 ) ) || ( rc = g_ws.tmp_nor2.ensure( nn * 16 ) ) ||
       ( rc = g_ws.wexp.ensure( nn * 4 ) ) || ( rc = g_ws.slot.ensure( nn * 4 ) ) || ( rc = g_ws.d2.ensure( nn * 4 ) ) || ( rc = g_ws.dot.ensure( nn * 4 ) ) ||
-      ( rc = g_ws.state.ensure( 68 ) ) ||
+      ( rc = g_ws.state.ensure( ICP_STATE_WORDS * 4 ) ) ||
       ( rc = g_ws.mom_part.ensure( 256 * ICP_NMOM * 8 ) ) || ( rc = g_ws.res.ensure( ICP_NRES * 8 ) ) || ( rc = g_ws.h_a.ensure( ICP_NRES * 8 ) ) )
     return rc;
   std::vector<float4> a( nn ), b( nn ), c( nn ); std::vector<int> sl( nn );
@@ -848,19 +788,21 @@ int rs_hip_icp_estimate_pt2pl( const float* pts1, const float* pts2, const float
     sl[i] = (int)i;
   }
   Mat4 I = mat4_identity(); double zeros[ICP_NRES]; std::memset( zeros, 0, sizeof(zeros) );
-  float st_host[17]; std::memcpy( st_host, I.m, 64 ); { int one = 1; std::memcpy( st_host + 16, &one, 4 ); }
+  float st_host[ICP_STATE_WORDS]; std::memset( st_host, 0, sizeof( st_host ) );       // identity pose, active, tickets zero
+  std::memcpy( st_host, I.m, 64 ); { int one = 1; std::memcpy( st_host + 16, &one, 4 ); }
   HIP_TRY( hipMemcpyAsync( g_ws.tmp_pos.p, a.data(), nn * 16, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
   HIP_TRY( hipMemcpyAsync( g_ws.tmp_pos2.p, b.data(), nn * 16, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
   HIP_TRY( hipMemcpyAsync( g_ws.tmp_nor2.p, c.data(), nn * 16, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
   HIP_TRY( hipMemcpyAsync( g_ws.wexp.p, weights, nn * 4, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
   HIP_TRY( hipMemcpyAsync( g_ws.slot.p, sl.data(), nn * 4, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
-  HIP_TRY( hipMemcpyAsync( g_ws.state.p, st_host, 68, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipMemcpyAsync( g_ws.state.p, st_host, sizeof( st_host ), hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
   HIP_TRY( hipMemcpyAsync( g_ws.res.p, zeros, ICP_NRES * 8, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
   HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );     // host staging vectors go out of scope below
   IcpLaunch L{};
   L.tgt.pos = g_ws.tmp_pos2.as<float4>(); L.tgt.nor = g_ws.tmp_nor2.as<float4>(); L.tgt.n = n;
   L.src.pos = g_ws.tmp_pos.as<float4>(); L.src.nor = nullptr; L.src.tiles = nullptr; L.src.n = n; L.src.n_tiles = 0; L.n_prob = 1;
-  L.T1 = g_ws.state.as<float>(); L.active = (const int*)( g_ws.state.as<float>() + 16 ); std::memcpy( L.T2i.m, I.m, 64 );
+  L.T1 = g_ws.state.as<float>(); L.active = (int*)( g_ws.state.as<float>() + 16 ); std::memcpy( L.T2i.m, I.m, 64 );
+  L.ticket = (int*)( g_ws.state.as<float>() + 37 ); L.solve = 0;       // reductions only: the solve below runs on the host
   L.radius = 1.0f; L.m_slot = g_ws.slot.as<int>(); L.m_d2 = g_ws.d2.as<float>(); L.m_dot = g_ws.dot.as<float>();
   L.mom_part = g_ws.mom_part.as<double>(); L.res = g_ws.res.as<double>();
   L.n_mom_blocks = std::max( 1, std::min( 256, ( n + 255 ) / 256 ) ); L.w_explicit = g_ws.wexp.as<float>();

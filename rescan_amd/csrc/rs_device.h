@@ -54,8 +54,8 @@ struct IcpLaunch
   GridView     tgt;
   QueryView    src;            // source cloud (query order)
   int          n_prob;         // batch size
-  const float* T1;             // device, n_prob x 16
-  const int*   active;         // device, n_prob flags (0 = skip)
+  float*       T1;             // device, n_prob x 16: current poses (updated on the device by every iteration)
+  int*         active;         // device, n_prob flags (0 = skip; cleared on the device when a problem stops)
   Xform        T2i;
   float        radius, radius_sq, gate_tmin;
   int          K;
@@ -71,19 +71,27 @@ struct IcpLaunch
   int*    queue_count;  // n_prob
   int     solo_stages;  // candidates a lone wave streams before handing an unsettled tile off
   int     coop_waves;   // waves per queued tile in the cooperative kernel (4 or 8)
+  // loop state kept on the device (lib/rs/icp.h:441-493): k_icp_update solves and updates it
+  int     solve;        // 0: reductions only (estimate-only / find_corrs entry points), 1: also solve + update the state
+  int     iter_index;   // i of icp.h:444
+  int     fixed_iters;  // benchmark mode: no convergence test
+  int*    iters;        // n_prob: find_corrs calls made
+  float*  err;          // n_prob: last RMS error (icp.h:253)
+  float*  prev_err;     // n_prob
+  int*    queued;       // n_prob: tiles phase A handed off in the last iteration (host heuristics, diagnostics)
+  int*    ticket;       // (unused, kept zero)
   int     warm;         // m_slot holds last iteration's matches: use them as starting candidates
   // "no correspondence" certificates carried across iterations (rs_kernels.hip: icp_certificate); null = off
   float*  cert_r;       // n_prob x nq
   float*  cert_dot;     // n_prob x nq
-  const float* T1_prev; // device, n_prob x 16: the poses of the previous iteration
+  float*  T1_prev;      // device, n_prob x 16: the poses the previous iteration searched with
   float   cert_mu;      // margin by which the gate is loosened when a certificate is issued
   float   tgt_nor_max;  // max |normal| over the target cloud
   unsigned long long* dbg;   // diagnostic builds only: per-tile {cycles, candidates} of phase A (null otherwise)
   const float* w_explicit;   // if non-null: weights given per query (estimate-only entry point)
 };
-void launch_icp_corr( const IcpLaunch& L, hipStream_t st );
-void launch_icp_stats( const IcpLaunch& L, hipStream_t st );
-void launch_icp_moments( const IcpLaunch& L, hipStream_t st );
+void launch_icp_corr( const IcpLaunch& L, hipStream_t st );     // phase A, phase B (+ statistics of dist² over the correspondences)
+void launch_icp_moments( const IcpLaunch& L, hipStream_t st );  // weights + moments (+ solve and loop-state update if L.solve)
 
 struct ScoreLaunch
 {

@@ -34,6 +34,7 @@
 // It needs no per-lane heap, does not diverge, and costs the same for K = 16, 32 or 64.
 
 #include "rs_device.h"
+#include "rs_math.h"
 #include <cfloat>
 #include <climits>
 
@@ -707,6 +708,52 @@ __global__ __launch_bounds__( BLOCK, RS_ICP_OCC ) void k_icp_corr( IcpLaunch L )
   icp_emit( L, prob, tile, i, active, lane, m, active & !search );
 }
 
+// Fixed-order sum of the per-tile partials -> n_corr, mean, stddev (msh_std.h:1800-1825) by a workgroup of
+// STATS_BLOCK threads (the loads are latency-bound: many threads, few rounds).  `red`: 3*STATS_BLOCK doubles.
+#define STATS_BLOCK 1024
+__device__ __forceinline__ void icp_stats_block( const IcpLaunch& L, int prob, double* red )
+{
+  const int T = STATS_BLOCK, t = threadIdx.x;
+  const int n_tiles = L.src.n_tiles;
+  const double* in = L.corr_part + (size_t)prob * n_tiles * 3;
+  __syncthreads();                                 // the scratch may alias LDS the tile loop used
+  if( t < T )
+  {
+    double a = 0, b = 0, c = 0;
+    for( int w = t; w < n_tiles; w += T ) { a += in[3*w]; b += in[3*w+1]; c += in[3*w+2]; }
+    red[t] = a; red[T + t] = b; red[2 * T + t] = c;
+  }
+  __syncthreads();
+  for( int s = T / 2; s > 0; s >>= 1 )
+  {
+    if( t < s ) { red[t] += red[t + s]; red[T + t] += red[T + t + s]; red[2 * T + t] += red[2 * T + t + s]; }
+    __syncthreads();
+  }
+  if( t == 0 )
+  {
+    double n = red[0];
+    float mean = (float)( red[T] / n );                    // sum / (float)n
+    float sqm = (float)( red[2 * T] / n );                 // sq_sum / (float)n
+    float var = sqm - mean * mean;
+    float sd = (float)sqrt( (double)var );                 // (float)sqrt( ... ), msh_std.h:1824
+    double* st = L.res + (size_t)prob * ICP_NRES + ICP_NMOM;
+    st[0] = n; st[1] = mean; st[2] = sd; st[3] = (double)L.queue_count[prob];   // [3]: tiles phase A handed off
+    if( L.queued ) L.queued[prob] = L.queue_count[prob];
+    L.queue_count[prob] = 0;                               // ready for the next iteration's phase A
+  }
+}
+
+// One workgroup per problem.
+// (A "last workgroup done" ticket inside the search kernels would save this launch, but a device-scope
+// fence per workgroup writes back the XCD's L2 on this part: measured 4x slower than the launch.)
+__global__ __launch_bounds__( STATS_BLOCK ) void k_icp_stats( IcpLaunch L )
+{
+  __shared__ double red[3 * STATS_BLOCK];
+  const int prob = blockIdx.x;
+  if( L.active[prob] == 0 ) return;
+  icp_stats_block( L, prob, red );
+}
+
 // Phase B: one workgroup per queued tile, whole box, chunks shared by its waves.
 template <int NW>
 __global__ __launch_bounds__( NW * WAVE ) void k_icp_corr_coop( IcpLaunch L )
@@ -750,36 +797,6 @@ __global__ __launch_bounds__( NW * WAVE ) void k_icp_corr_coop( IcpLaunch L )
     }
     if( wib == 0 ) icp_emit( L, prob, tile, i, active, lane, m, active & !search );
     __syncthreads();                               // merge slots are reused by the next queued tile
-  }
-}
-
-// One block per problem: fixed-order sum of the per-tile partials -> n_corr, mean, stddev.
-__global__ __launch_bounds__( BLOCK ) void k_icp_stats( IcpLaunch L )
-{
-  __shared__ double red[3][BLOCK];
-  const int prob = blockIdx.x;
-  if( L.active[prob] == 0 ) return;
-  const int n_tiles = L.src.n_tiles;
-  const double* in = L.corr_part + (size_t)prob * n_tiles * 3;
-  double a = 0, b = 0, c = 0;
-  for( int w = threadIdx.x; w < n_tiles; w += BLOCK ) { a += in[3*w]; b += in[3*w+1]; c += in[3*w+2]; }
-  red[0][threadIdx.x] = a; red[1][threadIdx.x] = b; red[2][threadIdx.x] = c;
-  __syncthreads();
-  for( int s = BLOCK / 2; s > 0; s >>= 1 )
-  {
-    if( threadIdx.x < s ) { red[0][threadIdx.x] += red[0][threadIdx.x + s]; red[1][threadIdx.x] += red[1][threadIdx.x + s]; red[2][threadIdx.x] += red[2][threadIdx.x + s]; }
-    __syncthreads();
-  }
-  if( threadIdx.x == 0 )
-  {
-    double n = red[0][0];
-    float mean = (float)( red[1][0] / n );                 // sum / (float)n
-    float sqm = (float)( red[2][0] / n );                  // sq_sum / (float)n
-    float var = sqm - mean * mean;
-    float sd = (float)sqrt( (double)var );                 // (float)sqrt( ... ), msh_std.h:1824
-    double* st = L.res + (size_t)prob * ICP_NRES + ICP_NMOM;
-    st[0] = n; st[1] = mean; st[2] = sd; st[3] = L.queue_count ? (double)L.queue_count[prob] : 0.0;   // [3]: tiles phase A handed off
-    if( L.queue_count ) L.queue_count[prob] = 0;         // ready for the next iteration's phase A
   }
 }
 
@@ -857,26 +874,46 @@ __global__ __launch_bounds__( BLOCK ) void k_icp_moments( IcpLaunch L )
     for( int w = 0; w < WAVES_PER_BLOCK; ++w ) v += red[w][threadIdx.x];
     L.mom_part[( (size_t)prob * L.n_mom_blocks + blockIdx.x ) * ICP_NMOM + threadIdx.x] = v;
   }
+
 }
 
-// fixed-order tree over the per-block partials: one workgroup per (moment, problem)
-__global__ __launch_bounds__( BLOCK ) void k_icp_moments_final( IcpLaunch L )
+// One workgroup per problem: fixed-order sum of the per-workgroup partials (moment k by wave k mod 4;
+// lane l adds partials l, l+64, l+128, l+192, then the wave tree) and — inside the ICP loop — the
+// rest of the iteration (icp.h:455-493), which the reference runs on the CPU: 6x6 solve, pose
+// update, stop tests.  Nothing goes back to the host between two searches.
+__global__ __launch_bounds__( BLOCK ) void k_icp_update( IcpLaunch L )
 {
-  __shared__ double red[BLOCK];
-  const int prob = blockIdx.y, k = blockIdx.x;
+  const int prob = blockIdx.x;
   if( L.active[prob] == 0 ) return;
+  const int lane = threadIdx.x & ( WAVE - 1 ), wib = threadIdx.x / WAVE;
   const double* in = L.mom_part + (size_t)prob * L.n_mom_blocks * ICP_NMOM;
-  double v = 0.0;
-  for( int b = threadIdx.x; b < L.n_mom_blocks; b += BLOCK ) v += in[(size_t)b * ICP_NMOM + k];
-  red[threadIdx.x] = v;
+  double* res = L.res + (size_t)prob * ICP_NRES;
+  for( int k = wib; k < ICP_NMOM; k += WAVES_PER_BLOCK )
+  {
+    double v = 0.0;
+    for( int b = lane; b < L.n_mom_blocks; b += WAVE ) v += in[(size_t)b * ICP_NMOM + k];
+    v = wave_sum( v );
+    if( lane == 0 ) res[k] = v;
+  }
   __syncthreads();
-  for( int s = BLOCK / 2; s > 0; s >>= 1 ) { if( threadIdx.x < s ) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
-  if( threadIdx.x == 0 ) L.res[(size_t)prob * ICP_NRES + k] = red[0];
+  if( threadIdx.x != 0 || !L.solve ) return;
+  // ---- icp.h:455-493 for this problem ----
+  L.prev_err[prob] = L.err[prob];
+  L.iters[prob] += 1;
+  if( res[ICP_NMOM] == 0.0 ) { L.active[prob] = 0; return; }            // icp.h:455-459: no correspondences
+  Mat4 T;
+  for( int k = 0; k < 16; ++k ) { T.m[k] = L.T1[prob * 16 + k]; L.T1_prev[prob * 16 + k] = T.m[k]; }
+  float e;
+  if( !icp_solve( res, T, e ) ) { L.active[prob] = 0; return; }         // icp.h:466-470: weights vanished
+  for( int k = 0; k < 16; ++k ) L.T1[prob * 16 + k] = T.m[k];           // icp.h:295
+  L.err[prob] = e;
+  const float delta = fabsf( L.prev_err[prob] - e );
+  if( !L.fixed_iters && L.iter_index > 5 && delta < 1e-5 ) L.active[prob] = 0;   // icp.h:489
 }
 
 void launch_icp_corr( const IcpLaunch& L, hipStream_t st )
 {
-  // queue_count is zero on entry: cleared once by the host, then by k_icp_stats after every use
+  // queue_count is zero on entry: cleared once by the host, then by the cooperative kernel's last workgroup after every use
   dim3 grid( ( L.src.n_tiles + WAVES_PER_BLOCK - 1 ) / WAVES_PER_BLOCK, L.n_prob );
   hipLaunchKernelGGL( k_icp_corr, grid, dim3( BLOCK ), 0, st, L );
   // the queue length is only known on the device: a fixed grid strides over it
@@ -885,15 +922,12 @@ void launch_icp_corr( const IcpLaunch& L, hipStream_t st )
   // a short queue is latency-bound by its heaviest tile: give every tile more waves
   if( L.coop_waves >= 8 ) hipLaunchKernelGGL( k_icp_corr_coop<8>, cgrid, dim3( 8 * WAVE ), 0, st, L );
   else                    hipLaunchKernelGGL( k_icp_corr_coop<COOP_WAVES>, cgrid, dim3( COOP_BLOCK ), 0, st, L );
-}
-void launch_icp_stats( const IcpLaunch& L, hipStream_t st )
-{
-  hipLaunchKernelGGL( k_icp_stats, dim3( L.n_prob ), dim3( BLOCK ), 0, st, L );
+  hipLaunchKernelGGL( k_icp_stats, dim3( L.n_prob ), dim3( STATS_BLOCK ), 0, st, L );
 }
 void launch_icp_moments( const IcpLaunch& L, hipStream_t st )
 {
   hipLaunchKernelGGL( k_icp_moments, dim3( L.n_mom_blocks, L.n_prob ), dim3( BLOCK ), 0, st, L );
-  hipLaunchKernelGGL( k_icp_moments_final, dim3( ICP_NMOM, L.n_prob ), dim3( BLOCK ), 0, st, L );
+  hipLaunchKernelGGL( k_icp_update, dim3( L.n_prob ), dim3( BLOCK ), 0, st, L );
 }
 
 // ------------------------------------------------------------------------------------------

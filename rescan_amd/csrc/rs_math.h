@@ -1,20 +1,38 @@
-// Host-side small linear algebra with the reference's float arithmetic, operation for
-// operation (column-major float[16], lib/msh/msh_vec_math.h).  These run on the CPU side of
-// the ICP loop (pose composition, 6x6 solve) exactly as the reference does (lib/rs/icp.h:267-295);
-// the GPU does the searches and the reductions.
+// Small linear algebra with the reference's float arithmetic, operation for operation
+// (column-major float[16], lib/msh/msh_vec_math.h): pose composition and the 6x6 solve of
+// lib/rs/icp.h:267-295.  Compiled for the host (drop-in shim, estimate-only entry point) and, under
+// hipcc, for the device as well: the ICP loop finishes every iteration on the GPU (rs_kernels.hip:
+// k_icp_update), so no host round trip sits between two searches.
 #pragma once
 #include <cmath>
 #include <cstring>
 #include <cstdint>
 
+#if defined( __HIPCC__ )
+#define RS_HD __host__ __device__
+#else
+#define RS_HD
+#endif
+
 namespace rs {
 
 struct Mat4 { float m[16]; };
 
-inline Mat4 mat4_identity() { Mat4 r; std::memset( r.m, 0, sizeof(r.m) ); r.m[0] = r.m[5] = r.m[10] = r.m[15] = 1.0f; return r; }
+RS_HD inline Mat4 mat4_identity() { Mat4 r; for( int i = 0; i < 16; ++i ) r.m[i] = 0.0f; r.m[0] = r.m[5] = r.m[10] = r.m[15] = 1.0f; return r; }
+
+// cosf/sinf of the host libm; on the device the double-precision functions rounded once to float
+// (correctly rounded for all practical purposes, as glibc's are to within its 0.56-ulp bound).
+RS_HD inline void rs_sincosf( float a, float& s, float& c )
+{
+#if defined( __HIP_DEVICE_COMPILE__ )
+  s = (float)sin( (double)a ); c = (float)cos( (double)a );
+#else
+  c = cosf( a ); s = sinf( a );
+#endif
+}
 
 // msh_mat4_mul (msh_vec_math.h:1441-1476): element (row r, col c) = Σ_k b[k,c]·a[r,k], k ascending.
-inline Mat4 mat4_mul( const Mat4& a, const Mat4& b )
+RS_HD inline Mat4 mat4_mul( const Mat4& a, const Mat4& b )
 {
   Mat4 o;
   for( int c = 0; c < 4; ++c )
@@ -23,7 +41,7 @@ inline Mat4 mat4_mul( const Mat4& a, const Mat4& b )
   return o;
 }
 
-inline Mat4 mat4_transpose( const Mat4& a )
+RS_HD inline Mat4 mat4_transpose( const Mat4& a )
 {
   Mat4 o;
   for( int c = 0; c < 4; ++c ) for( int r = 0; r < 4; ++r ) o.m[4*c+r] = a.m[4*r+c];
@@ -74,7 +92,7 @@ inline Mat4 mat4_inverse( const Mat4& A )
 }
 
 // msh_translate (msh_vec_math.h:2064-2074): col3 = (col0·tx + col1·ty) + (col2·tz + col3)
-inline Mat4 mat4_translate( const Mat4& a, float tx, float ty, float tz )
+RS_HD inline Mat4 mat4_translate( const Mat4& a, float tx, float ty, float tz )
 {
   Mat4 o = a;
   for( int r = 0; r < 4; ++r )
@@ -84,9 +102,10 @@ inline Mat4 mat4_translate( const Mat4& a, float tx, float ty, float tz )
 
 // msh_rotate (msh_vec_math.h:2089-2132) about a coordinate axis (0 = x, 1 = y, 2 = z); the
 // reference normalises the unit axis first, which is exact for these three.
-inline Mat4 mat4_rotate_axis( const Mat4& a, float angle, int axis )
+RS_HD inline Mat4 mat4_rotate_axis( const Mat4& a, float angle, int axis )
 {
-  float c = cosf( angle ), s = sinf( angle ), t = 1.0f - c;
+  float c, s; rs_sincosf( angle, s, c );
+  float t = 1.0f - c;
   float ax[3] = { 0.0f, 0.0f, 0.0f }; ax[axis] = 1.0f;
   float R[9];   // R[3*col + row]
   R[0] = c + ax[0] * ax[0] * t;  R[4] = c + ax[1] * ax[1] * t;  R[8] = c + ax[2] * ax[2] * t;
@@ -104,33 +123,106 @@ inline Mat4 mat4_rotate_axis( const Mat4& a, float angle, int axis )
 // trimesh's ldltdc/ldltsl instantiated at <double,6> (lib/rs/lineqn.h:153-218).  A zero pivot
 // stops the factorisation; like the reference's caller (icp.h:276) we solve with whatever was
 // produced.
-inline void ldlt6_solve( double A[6][6], const double b[6], double x[6] )
+RS_HD inline void ldlt6_solve( double A[6][6], const double b[6], double x[6] )
 {
-  double rd[6] = { 0, 0, 0, 0, 0, 0 }, v[5];
+  // fully unrolled (fixed trip counts, no early exits from the loops) so that on the device every
+  // array stays in registers; `ok` turns the remaining steps into no-ops after a zero pivot
+  double rd[6] = { 0, 0, 0, 0, 0, 0 }, v[6] = { 0, 0, 0, 0, 0, 0 };
   bool ok = true;
-  for( int i = 0; i < 6 && ok; ++i )
+#pragma unroll
+  for( int i = 0; i < 6; ++i )
   {
-    for( int k = 0; k < i; ++k ) v[k] = A[i][k] * rd[k];
-    for( int j = i; j < 6; ++j )
+#pragma unroll
+    for( int k = 0; k < 6; ++k ) if( k < i ) v[k] = A[i][k] * rd[k];
+#pragma unroll
+    for( int j = 0; j < 6; ++j )
     {
+      if( j < i || !ok ) continue;
       double sum = A[i][j];
-      for( int k = 0; k < i; ++k ) sum -= v[k] * A[j][k];
-      if( i == j ) { if( sum == 0 ) { ok = false; break; } rd[i] = 1 / sum; }
+#pragma unroll
+      for( int k = 0; k < 6; ++k ) if( k < i ) sum -= v[k] * A[j][k];
+      if( i == j ) { if( sum == 0 ) ok = false; else rd[i] = 1 / sum; }
       else A[j][i] = sum;
     }
   }
+#pragma unroll
   for( int i = 0; i < 6; ++i )
   {
     double sum = b[i];
-    for( int k = 0; k < i; ++k ) sum -= A[i][k] * x[k];
+#pragma unroll
+    for( int k = 0; k < 6; ++k ) if( k < i ) sum -= A[i][k] * x[k];
     x[i] = sum * rd[i];
   }
+#pragma unroll
   for( int i = 5; i >= 0; --i )
   {
     double sum = 0;
-    for( int k = i + 1; k < 6; ++k ) sum += A[k][i] * x[k];
+#pragma unroll
+    for( int k = 0; k < 6; ++k ) if( k > i ) sum += A[k][i] * x[k];
     x[i] -= sum * rd[i];
   }
+}
+
+// Finish lib/rs/icp.h:210-298 from the 35 uncentred fp64 moments (layout: rs_kernels.hip, k_icp_moments).
+// Returns false when the reference would have stopped before estimating (Σw <= 1e-7, icp.h:466).
+RS_HD inline bool icp_solve( const double* M, Mat4& T1, float& err )
+{
+  const double W = M[0];
+  if( (float)W <= 1e-7 ) return false;
+  const float c1f[3] = { (float)( M[1] / W ), (float)( M[2] / W ), (float)( M[3] / W ) };
+  const float c2f[3] = { (float)( M[4] / W ), (float)( M[5] / W ), (float)( M[6] / W ) };
+  const double c1[3] = { c1f[0], c1f[1], c1f[2] }, dl[3] = { (double)c1f[0] - c2f[0], (double)c1f[1] - c2f[1], (double)c1f[2] - c2f[2] };
+  const double Maa[3][3] = { { M[7], M[8], M[9] }, { M[8], M[10], M[11] }, { M[9], M[11], M[12] } };
+  double Man[3][3];
+  for( int r = 0; r < 3; ++r ) for( int c = 0; c < 3; ++c ) Man[r][c] = M[13 + 3*r + c];
+  const double Mnn[3][3] = { { M[22], M[23], M[24] }, { M[23], M[25], M[26] }, { M[24], M[26], M[27] } };
+  const double vae[3] = { M[28], M[29], M[30] }, vne[3] = { M[31], M[32], M[33] };
+  const double see = M[34];
+  // X v = c1 × v
+  const double X[3][3] = { { 0, -c1[2], c1[1] }, { c1[2], 0, -c1[0] }, { -c1[1], c1[0], 0 } };
+
+  double XMnn[3][3], ManXt[3][3], XMnnXt[3][3];
+  for( int r = 0; r < 3; ++r ) for( int c = 0; c < 3; ++c )
+  {
+    double s = 0; for( int k = 0; k < 3; ++k ) s += X[r][k] * Mnn[k][c];     XMnn[r][c] = s;       // X·Mnn
+    s = 0;        for( int k = 0; k < 3; ++k ) s += Man[r][k] * X[c][k];     ManXt[r][c] = s;      // Man·Xᵀ
+  }
+  for( int r = 0; r < 3; ++r ) for( int c = 0; c < 3; ++c )
+  { double s = 0; for( int k = 0; k < 3; ++k ) s += XMnn[r][k] * X[c][k]; XMnnXt[r][c] = s; }       // X·Mnn·Xᵀ
+  double TL[3][3], TR[3][3];
+  for( int r = 0; r < 3; ++r ) for( int c = 0; c < 3; ++c )
+  {
+    TL[r][c] = Maa[r][c] - ManXt[r][c] - ManXt[c][r] + XMnnXt[r][c];   // Σw·c cᵀ, c = a - X n
+    TR[r][c] = Man[r][c] - XMnn[r][c];                                   // Σw·c nᵀ
+  }
+  double bc[3], bn[3], Mnn_d[3], Man_d[3], sum;
+  for( int r = 0; r < 3; ++r ) { Mnn_d[r] = 0; Man_d[r] = 0; for( int k = 0; k < 3; ++k ) { Mnn_d[r] += Mnn[r][k] * dl[k]; Man_d[r] += Man[r][k] * dl[k]; } }
+  for( int r = 0; r < 3; ++r )
+  {
+    double xv = 0, xm = 0;
+    for( int k = 0; k < 3; ++k ) { xv += X[r][k] * vne[k]; xm += X[r][k] * Mnn_d[k]; }
+    bc[r] = vae[r] - Man_d[r] - xv + xm;       // Σw·c·s,  s = e - δ·n
+    bn[r] = vne[r] - Mnn_d[r];                 // Σw·n·s
+  }
+  sum = see - 2.0 * ( dl[0] * vne[0] + dl[1] * vne[1] + dl[2] * vne[2] ) + ( dl[0] * Mnn_d[0] + dl[1] * Mnn_d[1] + dl[2] * Mnn_d[2] );
+  if( sum < 0.0 ) sum = 0.0;
+  err = (float)sqrt( sum / W );                // icp.h:253
+
+  double C[6][6], b[6], x[6] = { 0, 0, 0, 0, 0, 0 };    // icp.h:267-277
+  for( int r = 0; r < 3; ++r ) for( int c = 0; c < 3; ++c )
+  { C[r][c] = TL[r][c]; C[r][3+c] = TR[r][c]; C[3+r][c] = TR[c][r]; C[3+r][3+c] = Mnn[r][c]; }
+  for( int r = 0; r < 3; ++r ) { b[r] = -bc[r]; b[3+r] = -bn[r]; }
+  ldlt6_solve( C, b, x );
+
+  Mat4 T = mat4_identity();                    // icp.h:280-295
+  T = mat4_translate( T, c1f[0], c1f[1], c1f[2] );
+  T = mat4_translate( T, (float)x[3], (float)x[4], (float)x[5] );
+  T = mat4_rotate_axis( T, (float)x[0], 0 );
+  T = mat4_rotate_axis( T, (float)x[1], 1 );
+  T = mat4_rotate_axis( T, (float)x[2], 2 );
+  T = mat4_translate( T, -c1f[0], -c1f[1], -c1f[2] );
+  T1 = mat4_mul( T, T1 );
+  return true;
 }
 
 // ---- normal gates as thresholds on the (clamped) dot product ---------------------------

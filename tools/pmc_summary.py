@@ -28,7 +28,7 @@ if __name__ == "__main__":
                   "WRITE_SIZE avg KB", round(out["WRITE_SIZE"].get(k, (0, 0))[0], 1))
     elif len(sys.argv) > 2 and sys.argv[1] == "--trace":
         rows = sorted(csv.DictReader(open(sys.argv[2])), key=lambda r: int(r["Start_Timestamp"]))
-        rows = [r for r in rows if r["Kernel_Name"].startswith("rs::")]
+        rows = [r for r in rows if "rs::" in r["Kernel_Name"]]
         t0 = int(rows[0]["Start_Timestamp"])
         # the last step only: everything after the largest gap
         gaps = [(int(b["Start_Timestamp"]) - int(a["End_Timestamp"]), i + 1) for i, (a, b) in enumerate(zip(rows, rows[1:]))]
@@ -36,7 +36,7 @@ if __name__ == "__main__":
         lines = []
         for r in rows[start:]:
             s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-            lines.append(f'{(s - int(rows[start]["Start_Timestamp"])) / 1e3:9.1f} us  +{(e - s) / 1e3:8.1f} us  {r["Kernel_Name"].split("(")[0]}')
+            lines.append(f'{(s - int(rows[start]["Start_Timestamp"])) / 1e3:9.1f} us  +{(e - s) / 1e3:8.1f} us  {r["Kernel_Name"].split("(")[0].replace("void ", "")}')
         open("gpurun_out/trace_last_step.txt", "w").write("\n".join(lines) + "\n")
         print("\n".join(lines[:80]))
     else:
