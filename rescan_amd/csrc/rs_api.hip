@@ -590,7 +590,12 @@ int icp_enable_certificates( IcpCtx& cx, size_t np, size_t nq )
 void icp_debug_before( IcpCtx& cx, int n )
 {
   static DevBuf dbgbuf;
-  if( getenv( "RS_HIP_DEBUG_CYCLES" ) && n == 1 )
+#ifndef RS_DBG
+#define RS_DBG 0
+#endif
+  if( getenv( "RS_HIP_DEBUG_CYCLES" ) && !RS_DBG )
+  { static bool told = false; if( !told ) fprintf( stderr, "[rs_hip] RS_HIP_DEBUG_CYCLES needs the diagnostic build: tools/variant.sh dbg -DRS_DBG=1, then RS_HIP_LIB=.../librescan_hip_dbg.so\n" ); told = true; }
+  if( RS_DBG && getenv( "RS_HIP_DEBUG_CYCLES" ) && n == 1 )
   {
     if( dbgbuf.ensure( (size_t)cx.n_waves * 48 + 64 ) ) return;
     (void)hipMemsetAsync( (char*)dbgbuf.p + (size_t)cx.n_waves * 48, 0, 64, g_stream );
@@ -613,11 +618,22 @@ void icp_debug_after( IcpCtx& cx, int n_src, int n, int i, float max_dist )
   if( !cx.L.dbg ) return;
   std::vector<unsigned long long> h( (size_t)cx.n_waves * 2 );
   (void)hipMemcpy( h.data(), cx.L.dbg, h.size() * 8, hipMemcpyDeviceToHost );
-  std::vector<unsigned long long> t; unsigned long long sum = 0, ho = 0, tiles_uns = 0;
-  for( int k = 0; k < cx.n_waves; ++k ) { t.push_back( h[2*k] ); sum += h[2*k]; ho += h[2*k+1]; tiles_uns += h[2*k+1] ? 1 : 0; }
-  std::sort( t.begin(), t.end() );
-  fprintf( stderr, "[rs_hip dbg] phase A: unsettled lanes after shell 1: %llu in %llu tiles; wall-ticks(100MHz) per tile: mean %.0f p50 %llu p90 %llu p99 %llu max %llu\n",
-           ho, tiles_uns, (double)sum / cx.n_waves, t[t.size()/2], t[t.size()*9/10], t[t.size()*99/100], t.back() );
+  struct Row { unsigned long long ticks; unsigned uns, handoff, stages, streamed, rank_streamed; };
+  std::vector<Row> t;
+  unsigned long long sum = 0, ho = 0, tiles_uns = 0, n_rank = 0;
+  for( int k = 0; k < cx.n_waves; ++k )
+  {
+    const unsigned long long v = h[2*k+1];
+    Row r{ h[2*k], (unsigned)( v & 0xff ), (unsigned)( ( v >> 8 ) & 1 ), (unsigned)( ( v >> 9 ) & 0x7f ), (unsigned)( ( v >> 16 ) & 0xffffff ), (unsigned)( v >> 40 ) };
+    t.push_back( r ); sum += r.ticks; ho += r.uns; tiles_uns += r.uns ? 1 : 0; n_rank += r.rank_streamed ? 1 : 0;
+  }
+  std::sort( t.begin(), t.end(), []( const Row& a, const Row& b ) { return a.ticks < b.ticks; } );
+  fprintf( stderr, "[rs_hip dbg] phase A: unsettled lanes after shell 1: %llu in %llu tiles; rank pass in %llu tiles; mean tile %.1f us\n", ho, tiles_uns, n_rank, (double)sum / cx.n_waves / 100.0 );
+  for( double q : { 0.5, 0.9, 0.99, 0.999, 1.0 } )
+  {
+    const Row& r = t[std::min( t.size() - 1, (size_t)( q * t.size() ) )];
+    fprintf( stderr, "[rs_hip dbg]   phase A p%g: %.1f us, shells %u, streamed %u, rank-pass streamed %u, handoff %u\n", q * 100, r.ticks / 100.0, r.stages, r.streamed, r.rank_streamed, r.handoff );
+  }
   std::vector<unsigned long long> c( (size_t)qc[0] * 4 );
   (void)hipMemcpy( c.data(), cx.L.dbg + 2 * (size_t)cx.n_waves, c.size() * 8, hipMemcpyDeviceToHost );
   std::vector<std::array<unsigned long long, 4>> rows;

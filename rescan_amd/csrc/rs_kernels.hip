@@ -38,6 +38,14 @@
 #include <cfloat>
 #include <climits>
 
+// Per-tile timers and counters (RS_HIP_DEBUG_CYCLES) exist only in the diagnostic build
+// (tools/variant.sh dbg -DRS_DBG=1): in the production build DBG() is a constant null pointer and
+// every diagnostic statement, array and argument folds away.
+#ifndef RS_DBG
+#define RS_DBG 0
+#endif
+#define DBG( L ) ( RS_DBG ? ( L ).dbg : (unsigned long long*)nullptr )
+
 namespace rs {
 
 #define WAVE 64
@@ -188,8 +196,7 @@ struct WaveLds
 
 // Stream every point of (out \ in) through the wave's LDS and call f( X, Y, Z, k ) for every
 // group of four staged candidates k..k+3 (X = their four x coordinates, ...; L.pidx[k+i],
-// L.nx/ny/nz[k+i], L.slot[k+i] belong to them); k is wave-uniform.  `in` (if in_valid) must be a
-// sub-box of `out`.  Chunks are padded to a multiple of 4 with sentinels at +FLT_MAX whose
+// L.nx/ny/nz[k+i], L.slot[k+i] belong to them); k is wave-uniform.  `in` (if in_valid) is any box.  Chunks are padded to a multiple of 4 with sentinels at +FLT_MAX whose
 // dist² is +inf: they can never be "within the radius", so f needs no validity test.
 // When several waves sweep the same shell together, wave `share` of `n_share` takes the chunks
 // whose running number is congruent to it.
@@ -216,8 +223,10 @@ __device__ __forceinline__ uint32_t sweep_shell( const GridView& g, const CellBo
       if( !inside ) { sa = cs[out.x0]; la = cs[out.x1 + 1] - sa; }
       else
       {
-        if( in.x0 > out.x0 ) { sa = cs[out.x0]; la = cs[in.x0] - sa; }
-        if( out.x1 > in.x1 ) { sb = cs[in.x1 + 1]; lb = cs[out.x1 + 1] - sb; }
+        // the row minus in's x-range (which may stick out of, or miss, out's)
+        const int a1 = min( in.x0 - 1, out.x1 ), b0 = max( in.x1 + 1, out.x0 );
+        if( a1 >= out.x0 ) { sa = cs[out.x0]; la = cs[a1 + 1] - sa; }
+        if( b0 <= out.x1 ) { sb = cs[b0]; lb = cs[out.x1 + 1] - sb; }
       }
     }
     const uint32_t incl = wave_scan( la + lb, lane );
@@ -372,23 +381,37 @@ __device__ __forceinline__ float bound_of( bool active, float radius_sq, const M
   return m.found ? __int_as_float( __float_as_int( m.d2 ) + 1 ) : radius_sq;
 }
 
-// Cells that can hold a candidate preceding the match of a lane that needs its exact rank: such a
-// candidate is no farther than the match, so it lies within sqrt(m.d2) of the query (the factor and
-// the offset are far above the fp32 rounding of dist² and of the square root).  Wave-uniform.
-__device__ __forceinline__ CellBox rank_box( const GridView& g, const CellBox& cur, bool need_rank, const Match& m,
-                                             float qx, float qy, float qz )
+// How far from its query a lane still has to look: to its match (a candidate that precedes the match,
+// or ties with it, is no farther; the factor and the offset are far above the fp32 rounding of dist²
+// and of the square root), or the whole radius while it has none.
+__device__ __forceinline__ float reach_of( const Match& m, float radius )
 {
-  const float rr = need_rank ? sqrtf( m.d2 ) * 1.0001f + 1e-5f : 0.0f;
+  return m.found ? sqrtf( m.d2 ) * 1.0001f + 1e-5f : radius;
+}
+
+// Cells overlapping the boxes [q - reach, q + reach] of the lanes in `mask`, clipped to `clip`.  Wave-uniform.
+__device__ __forceinline__ CellBox reach_box( const GridView& g, const CellBox& clip, bool mask, float reach,
+                                              float qx, float qy, float qz )
+{
   const float big = FLT_MAX;
   TileBounds t;
-  t.lx = wave_min( need_rank ? qx - rr : big );  t.hx = wave_max( need_rank ? qx + rr : -big );
-  t.ly = wave_min( need_rank ? qy - rr : big );  t.hy = wave_max( need_rank ? qy + rr : -big );
-  t.lz = wave_min( need_rank ? qz - rr : big );  t.hz = wave_max( need_rank ? qz + rr : -big );
+  t.lx = wave_min( mask ? qx - reach : big );  t.hx = wave_max( mask ? qx + reach : -big );
+  t.ly = wave_min( mask ? qy - reach : big );  t.hy = wave_max( mask ? qy + reach : -big );
+  t.lz = wave_min( mask ? qz - reach : big );  t.hz = wave_max( mask ? qz + reach : -big );
   t.any = true;
   CellBox b = cell_box( g, t, 0.0f );
-  b.x0 = max( b.x0, cur.x0 ); b.x1 = min( b.x1, cur.x1 );
-  b.y0 = max( b.y0, cur.y0 ); b.y1 = min( b.y1, cur.y1 );
-  b.z0 = max( b.z0, cur.z0 ); b.z1 = min( b.z1, cur.z1 );
+  b.x0 = max( b.x0, clip.x0 ); b.x1 = min( b.x1, clip.x1 );
+  b.y0 = max( b.y0, clip.y0 ); b.y1 = min( b.y1, clip.y1 );
+  b.z0 = max( b.z0, clip.z0 ); b.z1 = min( b.z1, clip.z1 );
+  return b;
+}
+
+__device__ __forceinline__ CellBox box_clip( const CellBox& a, const CellBox& c )
+{
+  CellBox b;
+  b.x0 = max( a.x0, c.x0 ); b.x1 = min( a.x1, c.x1 );
+  b.y0 = max( a.y0, c.y0 ); b.y1 = min( a.y1, c.y1 );
+  b.z0 = max( a.z0, c.z0 ); b.z1 = min( a.z1, c.z1 );
   return b;
 }
 
@@ -425,18 +448,40 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
   CellBox cur = core, prev = core;
   bool have_prev = false;
   uint32_t streamed = 0;
+  const bool grid = g.inv_cell > 0.0f;
+  if( grid && !__any( active & !m.found ) )
+  {
+    // Every lane starts from a genuine candidate (ICP iterations >= 2): whatever can beat or precede it
+    // lies within its distance, so ONE sweep of the cells those small boxes touch settles the tile —
+    // no shells, no cover test.
+    cur = reach_box( g, full, active, reach_of( m, radius ), qx, qy, qz );
+    if( !box_empty( cur ) )
+      streamed += sweep_shell<GATED>( g, cur, cur, false, L, lane, 0, 1, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
+      { consider4<GATED>( X, Y, Z, k4, L, qx, qy, qz, nx, ny, nz, tmin, tmin_loose, bound, m, seen_closer ); } );
+    if( dbg_unsettled ) { dbg_unsettled[1] = (int)streamed; dbg_unsettled[3] = 1; }
+  }
+  else
+  {
   // shells: the tile's own cells first (they hold the nearest candidates, so the per-lane bounds are
-  // tight before the bulk arrives), then grown by 1, 2, 4, ... cells
+  // tight before the bulk arrives), then grown by 1, 2, 4, ... cells.  Of each shell only the part within
+  // reach of a lane that is still unsettled is swept: for such a lane every cell of grow(core,k) that its
+  // own box [q - reach, q + reach] touches has then been examined (its reach only shrinks), which is all the
+  // cover test below relies on.
+  bool unsettled = active;
   for( int k = 0; ; k = k ? 2 * k : 1 )
   {
-    cur = ( g.inv_cell > 0.0f ) ? box_grow( core, k, full ) : full;
-    streamed += sweep_shell<GATED>( g, cur, prev, have_prev, L, lane, 0, 1, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
-    { consider4<GATED>( X, Y, Z, k4, L, qx, qy, qz, nx, ny, nz, tmin, tmin_loose, bound, m, seen_closer ); } );
+    cur = grid ? box_grow( core, k, full ) : full;
+    const CellBox out = grid ? reach_box( g, cur, unsettled, reach_of( m, radius ), qx, qy, qz ) : full;
+    if( !box_empty( out ) )
+      streamed += sweep_shell<GATED>( g, out, prev, have_prev, L, lane, 0, 1, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
+      { consider4<GATED>( X, Y, Z, k4, L, qx, qy, qz, nx, ny, nz, tmin, tmin_loose, bound, m, seen_closer ); } );
+    if( dbg_unsettled ) dbg_unsettled[1] = (int)streamed;
     if( box_same( cur, full ) ) break;
     // a lane is settled when nothing outside `cur` can precede its match (or reach it at all)
     const float cov = box_cover( g, cur, full, qx, qy, qz );
     const bool settled = !active | ( cov >= radius ) | ( m.found & ( cov > 0.0f ) & ( m.d2 < cov * cov ) );
-    if( dbg_unsettled && k == 1 ) *dbg_unsettled = __popcll( __ballot( !settled ) );
+    unsettled = !settled;
+    if( dbg_unsettled ) { if( k == 1 ) dbg_unsettled[0] = __popcll( __ballot( !settled ) ); dbg_unsettled[1] = (int)streamed; dbg_unsettled[3] += 1; }
     if( !__any( !settled ) ) break;
     // Unsettled in a populated neighbourhood, or facing a shell of many cell rows: the rest of the
     // box is heavy (or latency-bound for one wave), let a whole workgroup do it.
@@ -449,6 +494,7 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
     }
     prev = cur; have_prev = true;
   }
+  }
 
   if( K > 1 || GATED )
   {
@@ -460,10 +506,12 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
     if( __any( need_rank ) )
     {
       int rank = 0;
-      const CellBox rb = rank_box( g, cur, need_rank, m, qx, qy, qz );
+      const CellBox rb = reach_box( g, cur, need_rank, reach_of( m, radius ), qx, qy, qz );
+      uint32_t rs = 0;
       if( !box_empty( rb ) )
-      sweep_shell<false>( g, rb, rb, false, L, lane, 0, 1, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
+      rs = sweep_shell<false>( g, rb, rb, false, L, lane, 0, 1, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
       { rank += need_rank ? precede4( X, Y, Z, k4, L, qx, qy, qz, radius_sq, m.d2, m.idx ) : 0; } );
+      if( dbg_unsettled ) dbg_unsettled[2] = (int)rs;
       if( need_rank && rank >= K ) { m.found = false; m.slot = -1; }
     }
   }
@@ -513,10 +561,14 @@ __device__ __forceinline__ Match coop_search( const GridView& g, bool active,
   // Queued tiles were unsettled after the first shells in a populated neighbourhood; most of them
   // have no match at all, so the ladder of small shells only adds row enumerations and barriers:
   // one shell of two cells, then the whole box.
+  bool unsettled = active;
   for( int k = 2; ; k = 1 << 20 )
   {
     cur = ( g.inv_cell > 0.0f ) ? box_grow( core, k, full ) : full;
-    streamed += sweep_shell<GATED>( g, cur, prev, have_prev, L, lane, wib, NW, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
+    // only the part of the shell within reach of a still-unsettled lane (see tile_search); identical in every wave
+    const CellBox out = ( g.inv_cell > 0.0f ) ? reach_box( g, cur, unsettled, reach_of( m, radius ), qx, qy, qz ) : full;
+    if( !box_empty( out ) )
+    streamed += sweep_shell<GATED>( g, out, prev, have_prev, L, lane, wib, NW, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
     { consider4<GATED>( X, Y, Z, k4, L, qx, qy, qz, nx, ny, nz, tmin, tmin_loose, bound, m, seen_closer ); } );
     if( dbg_t && dbg_k < 7 ) dbg_t[dbg_k++] = wall_clock64();
     // merge the per-lane bests of the waves; every wave continues with the merged best
@@ -533,6 +585,7 @@ __device__ __forceinline__ Match coop_search( const GridView& g, bool active,
     if( box_same( cur, full ) ) break;
     const float cov = box_cover( g, cur, full, qx, qy, qz );
     const bool settled = !active | ( cov >= radius ) | ( m.found & ( cov > 0.0f ) & ( m.d2 < cov * cov ) );
+    unsettled = !settled;
     if( !__any( !settled ) ) break;                // same decision in every wave (same merged data)
     prev = cur; have_prev = true;
   }
@@ -549,7 +602,7 @@ __device__ __forceinline__ Match coop_search( const GridView& g, bool active,
     if( __any( need_rank ) )
     {
       int rank = 0;
-      const CellBox rb = rank_box( g, cur, need_rank, m, qx, qy, qz );
+      const CellBox rb = reach_box( g, cur, need_rank, reach_of( m, radius ), qx, qy, qz );
       if( !box_empty( rb ) )
       sweep_shell<false>( g, rb, rb, false, L, lane, wib, NW, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
       { rank += need_rank ? precede4( X, Y, Z, k4, L, qx, qy, qz, radius_sq, m.d2, m.idx ) : 0; } );
@@ -651,9 +704,9 @@ __device__ __forceinline__ void icp_emit( const IcpLaunch& L, int prob, int tile
   const size_t o = (size_t)prob * L.src.n + i;
   if( active ) { L.m_slot[o] = m.found ? m.slot : -1; L.m_d2[o] = m.d2; L.m_dot[o] = m.dot; }
   if( active && L.cert_r && !skipped && !m.found && !m.loose ) { L.cert_r[o] = L.radius - 1e-4f; L.cert_dot[o] = L.cert_mu - 1e-5f; }   // fresh certificate
-  if( L.dbg )
+  if( DBG( L ) )
   {
-    unsigned long long* cat = L.dbg + 6 * (size_t)L.src.n_tiles;
+    unsigned long long* cat = DBG( L ) + 6 * (size_t)L.src.n_tiles;
     const int c_skip = __popcll( __ballot( skipped ) ), c_fresh = __popcll( __ballot( active && !skipped && !m.found && !m.loose ) );
     const int c_rank = __popcll( __ballot( active && !skipped && !m.found && m.loose && m.idx != INT_MAX ) );
     const int c_loose = __popcll( __ballot( active && !skipped && !m.found && m.loose && m.idx == INT_MAX ) );
@@ -691,15 +744,20 @@ __global__ __launch_bounds__( BLOCK, RS_ICP_OCC ) void k_icp_corr( IcpLaunch L )
 #pragma unroll
   for( int k = 0; k < 16; ++k ) T1.m[k] = __int_as_float( uni( __float_as_int( L.T1[prob * 16 + k] ) ) );
   float qx, qy, qz, nx, ny, nz;
-  const unsigned long long t_begin = L.dbg ? wall_clock64() : 0ull;
+  const unsigned long long t_begin = DBG( L ) ? wall_clock64() : 0ull;
   icp_query( L, T1, i, active, qx, qy, qz, nx, ny, nz );
   bool handoff;
-  int unsettled = 0;
+  int unsettled[4] = { 0, 0, 0, 0 };
   const bool search = active & !icp_certificate( L, prob, i, active, qx, qy, qz, nx, ny, nz );
   const Match init = icp_warm_start( L, prob, i, search, qx, qy, qz, nx, ny, nz );
   Match m = tile_search<true>( L.tgt, search, qx, qy, qz, nx, ny, nz, L.radius, L.radius_sq, L.gate_tmin, L.gate_tmin - L.cert_mu, L.K,
-                               lds[wib], lane, L.solo_stages, &handoff, L.dbg ? &unsettled : nullptr, init );
-  if( L.dbg && lane == 0 ) { L.dbg[2 * tile] = wall_clock64() - t_begin; L.dbg[2 * tile + 1] = (unsigned long long)unsettled; }
+                               lds[wib], lane, L.solo_stages, &handoff, DBG( L ) ? unsettled : nullptr, init );
+  if( DBG( L ) && lane == 0 )
+  {
+    DBG( L )[2 * tile] = wall_clock64() - t_begin;       // [1]: unsettled lanes 8 bits | handoff 1 | stages 7 | streamed 24 | rank-pass streamed 24
+    DBG( L )[2 * tile + 1] = (unsigned long long)( unsettled[0] & 0xff ) | ( (unsigned long long)( handoff ? 1 : 0 ) << 8 ) | ( (unsigned long long)( unsettled[3] & 0x7f ) << 9 ) |
+                          ( (unsigned long long)( unsettled[1] & 0xffffff ) << 16 ) | ( (unsigned long long)( unsettled[2] & 0xffffff ) << 40 );
+  }
   if( handoff )
   {
     if( lane == 0 ) { int q = atomicAdd( L.queue_count + prob, 1 ); L.queue[(size_t)prob * L.src.n_tiles + q] = tile; }
@@ -775,19 +833,19 @@ __global__ __launch_bounds__( NW * WAVE ) void k_icp_corr_coop( IcpLaunch L )
     const bool active = i < (int)L.src.tiles[tile + 1];
     float qx, qy, qz, nx, ny, nz;
     icp_query( L, T1, i, active, qx, qy, qz, nx, ny, nz );
-    const unsigned long long t_begin = L.dbg ? wall_clock64() : 0ull;
+    const unsigned long long t_begin = DBG( L ) ? wall_clock64() : 0ull;
     unsigned long long stamps[8];
     const bool search = active & !icp_certificate( L, prob, i, active, qx, qy, qz, nx, ny, nz );
     const Match init = icp_warm_start( L, prob, i, search, qx, qy, qz, nx, ny, nz );
     uint32_t streamed = 0;
     Match m = coop_search<true, NW>( L.tgt, search, qx, qy, qz, nx, ny, nz, L.radius, L.radius_sq, L.gate_tmin, L.gate_tmin - L.cert_mu, L.K,
-                                 lds[wib], coop, wib, lane, init, L.dbg ? &streamed : nullptr, L.dbg ? stamps : nullptr );
-    if( L.dbg && wib == 0 )
+                                 lds[wib], coop, wib, lane, init, DBG( L ) ? &streamed : nullptr, DBG( L ) ? stamps : nullptr );
+    if( DBG( L ) && wib == 0 )
     {
       const int n_search = __popcll( __ballot( search ) ), n_unm = __popcll( __ballot( search & !m.found ) );
       if( lane == 0 )
       {
-        unsigned long long* d = L.dbg + 2 * (size_t)L.src.n_tiles + 4 * (size_t)b;
+        unsigned long long* d = DBG( L ) + 2 * (size_t)L.src.n_tiles + 4 * (size_t)b;
         const unsigned long long t_end = wall_clock64();
         // [0] total | [1] streamed | lanes | phases packed: setup, shell 1, shell 2, rest (each 16 bits, ticks of 10 ns)
         auto clip = []( unsigned long long v ) { return v > 0xffffull ? 0xffffull : v; };
@@ -960,7 +1018,10 @@ __device__ __forceinline__ void score_emit( const ScoreLaunch& L, int pose, int 
   if( lane == 0 ) L.part[(size_t)pose * L.obj.n_tiles + tile] = s;
 }
 
-__global__ __launch_bounds__( BLOCK, 6 ) void k_score( ScoreLaunch L )
+#ifndef RS_SCORE_OCC
+#define RS_SCORE_OCC 6
+#endif
+__global__ __launch_bounds__( BLOCK, RS_SCORE_OCC ) void k_score( ScoreLaunch L )
 {
   __shared__ WaveLds lds[WAVES_PER_BLOCK];
   const int pose = blockIdx.y;
