@@ -101,6 +101,7 @@ struct Workspace
   DevBuf q4, rd2, ridx, rnn, rows;                                              // rows / misc
   DevBuf enor, ecount, eoffset, e1, e2, ew;                                     // neighbourhood edges
   DevBuf cert_r, cert_dot;                                                      // ICP certificates
+  DevBuf order_a, order_b;                                                      // ICP phase A slow-tile lists (ping-pong)
   DevBuf tmp_pos, tmp_pos2, tmp_nor2;                                           // estimate-only
   PinBuf h_a, h_b, h_c;
 };
@@ -506,8 +507,9 @@ inline int handoff_threshold( long long total_tiles )
 {
   static int forced = -2;
   if( forced == -2 ) { const char* e = getenv( "RS_HIP_SOLO_STAGES" ); forced = e ? atoi( e ) : -1; }
-  if( forced > 0 ) return forced;
-  return total_tiles <= 24000 ? 256 : 0x7fffffff;
+  static const int k_always = getenv( "RS_HIP_HANDOFF_K" ) ? atoi( getenv( "RS_HIP_HANDOFF_K" ) ) : 0;
+  if( forced > 0 ) return forced | ( k_always << 16 );
+  return total_tiles <= 24000 ? ( 192 | ( k_always << 16 ) ) : 0x7fffffff;
 }
 
 inline float radius_sq_of( float r ) { return (float)( (double)r * (double)r ); }   // msh_hash_grid.h:1104,1111 + :828
@@ -618,17 +620,30 @@ void icp_debug_after( IcpCtx& cx, int n_src, int n, int i, float max_dist )
   if( !cx.L.dbg ) return;
   std::vector<unsigned long long> h( (size_t)cx.n_waves * 2 );
   (void)hipMemcpy( h.data(), cx.L.dbg, h.size() * 8, hipMemcpyDeviceToHost );
-  struct Row { unsigned long long ticks; unsigned uns, handoff, stages, streamed, rank_streamed; };
+  struct Row { unsigned long long start, ticks; unsigned uns, handoff, stages, streamed, rank_streamed; };
   std::vector<Row> t;
-  unsigned long long sum = 0, ho = 0, tiles_uns = 0, n_rank = 0;
+  unsigned long long sum = 0, ho = 0, tiles_uns = 0, n_rank = 0, t0 = ~0ull, t1 = 0;
   for( int k = 0; k < cx.n_waves; ++k )
   {
     const unsigned long long v = h[2*k+1];
-    Row r{ h[2*k], (unsigned)( v & 0xff ), (unsigned)( ( v >> 8 ) & 1 ), (unsigned)( ( v >> 9 ) & 0x7f ), (unsigned)( ( v >> 16 ) & 0xffffff ), (unsigned)( v >> 40 ) };
+    Row r{ h[2*k], v & 0xfffff, (unsigned)( v >> 57 ), (unsigned)( ( v >> 20 ) & 1 ), (unsigned)( ( v >> 21 ) & 15 ), (unsigned)( ( v >> 25 ) & 0xffff ), (unsigned)( ( v >> 41 ) & 0xffff ) };
     t.push_back( r ); sum += r.ticks; ho += r.uns; tiles_uns += r.uns ? 1 : 0; n_rank += r.rank_streamed ? 1 : 0;
+    t0 = std::min( t0, r.start ); t1 = std::max( t1, r.start + r.ticks );
+  }
+  fprintf( stderr, "[rs_hip dbg] phase A: %.1f us from first wave start to last wave end; unsettled lanes after shell 1: %llu in %llu tiles; rank pass in %llu tiles; mean tile %.1f us\n",
+           ( t1 - t0 ) / 100.0, ho, tiles_uns, n_rank, (double)sum / cx.n_waves / 100.0 );
+  {
+    // waves in flight over time (10 slices) and the tiles that end last
+    const double span = (double)( t1 - t0 );
+    int live[10] = { 0 };
+    for( const Row& r : t ) for( int b = 0; b < 10; ++b ) { const double at = t0 + span * ( b + 0.5 ) / 10; if( r.start <= at && at < r.start + r.ticks ) live[b]++; }
+    fprintf( stderr, "[rs_hip dbg]   waves in flight at 5%%,15%%,..95%% of the span:" ); for( int b = 0; b < 10; ++b ) fprintf( stderr, " %d", live[b] ); fprintf( stderr, "\n" );
+    std::vector<Row> byend = t; std::sort( byend.begin(), byend.end(), []( const Row& a, const Row& b ) { return a.start + a.ticks > b.start + b.ticks; } );
+    for( int k = 0; k < 5 && k < (int)byend.size(); ++k )
+      fprintf( stderr, "[rs_hip dbg]   late finisher: starts at %.1f us, runs %.1f us, shells %u, streamed %u, rank-pass %u, handoff %u\n",
+               ( byend[k].start - t0 ) / 100.0, byend[k].ticks / 100.0, byend[k].stages, byend[k].streamed, byend[k].rank_streamed, byend[k].handoff );
   }
   std::sort( t.begin(), t.end(), []( const Row& a, const Row& b ) { return a.ticks < b.ticks; } );
-  fprintf( stderr, "[rs_hip dbg] phase A: unsettled lanes after shell 1: %llu in %llu tiles; rank pass in %llu tiles; mean tile %.1f us\n", ho, tiles_uns, n_rank, (double)sum / cx.n_waves / 100.0 );
   for( double q : { 0.5, 0.9, 0.99, 0.999, 1.0 } )
   {
     const Row& r = t[std::min( t.size() - 1, (size_t)( q * t.size() ) )];
@@ -644,7 +659,7 @@ void icp_debug_after( IcpCtx& cx, int n_src, int n, int i, float max_dist )
              ( rows[k][3] & 0xffff ) / 100.0, ( ( rows[k][3] >> 16 ) & 0xffff ) / 100.0, ( ( rows[k][3] >> 32 ) & 0xffff ) / 100.0, ( rows[k][3] >> 48 ) / 100.0,
              rows[k][1], rows[k][2] & 0xff, rows[k][2] >> 8 ); };
   unsigned long long cat[4]; (void)hipMemcpy( cat, cx.L.dbg + 6 * (size_t)cx.n_waves, 32, hipMemcpyDeviceToHost );
-  fprintf( stderr, "[rs_hip dbg]   unmatched lanes: skipped by certificate %llu, freshly certified %llu, rank-rejected %llu, loose-band only %llu\n", cat[0], cat[1], cat[2], cat[3] );
+  if( RS_DBG >= 2 ) fprintf( stderr, "[rs_hip dbg]   unmatched lanes: skipped by certificate %llu, freshly certified %llu, rank-rejected %llu, loose-band only %llu\n", cat[0], cat[1], cat[2], cat[3] );
   pr( "p10", rows.size() / 10 ); pr( "p50", rows.size() / 2 ); pr( "p90", rows.size() * 9 / 10 ); pr( "p99", rows.size() * 99 / 100 ); pr( "max", rows.size() - 1 );
 }
 
@@ -669,6 +684,14 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
   if( source->n == 0 ) { for( int p = 0; p < n; ++p ) { errs[p] = 1e6f; if( iters ) iters[p] = 1; } return RS_HIP_OK; }   // n_corrs == 0 on the first search
   if( ( rc = icp_enable_certificates( cx, (size_t)n, (size_t)source->n ) ) ) return rc;
   if( ( rc = icp_upload_state( cx, T1s, (size_t)n ) ) ) return rc;
+  const size_t heavy_words = (size_t)n * ( (size_t)cx.n_waves + HEAVY_SLOTS + 1 );
+  const bool reorder = !getenv( "RS_HIP_NO_LPT" );
+  if( reorder )
+  {
+    if( ( rc = g_ws.order_a.ensure( heavy_words * 4 ) ) || ( rc = g_ws.order_b.ensure( heavy_words * 4 ) ) ) return rc;
+    HIP_TRY( hipMemsetAsync( g_ws.order_a.p, 0, heavy_words * 4, g_stream ), RS_HIP_E_RUNTIME );
+    HIP_TRY( hipMemsetAsync( g_ws.order_b.p, 0, heavy_words * 4, g_stream ), RS_HIP_E_RUNTIME );
+  }
 
   // The whole iteration runs on the device (search, statistics, moments, solve, pose update, stop
   // tests), so iterations are enqueued back to back and the host looks at the state only once per
@@ -692,6 +715,11 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
       // a short queue is bound by its heaviest tile: from the third iteration on the certificates have
       // emptied it (small batches: always)
       cx.L.coop_waves = ( small || ( i >= 2 && cx.L.cert_r ) ) ? 8 : 4;
+      if( reorder )
+      {
+        cx.L.heavy_in = i == 0 ? nullptr : ( ( i & 1 ) ? g_ws.order_a.as<int>() : g_ws.order_b.as<int>() );
+        cx.L.heavy_out = ( i & 1 ) ? g_ws.order_b.as<int>() : g_ws.order_a.as<int>();
+      }
       if( debug ) icp_debug_before( cx, n );
       { ProfScope ps( "nn_icp" ); launch_icp_corr( cx.L, g_stream ); }
       if( debug ) icp_debug_after( cx, source->n, n, i, max_dist );

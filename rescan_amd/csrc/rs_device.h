@@ -49,6 +49,8 @@ enum { ICP_NMOM = 35,     // raw moments reduced per ICP iteration (see k_icp_mo
        ICP_NRES = 39 };   // per problem result record: 35 moments + {n_corr, mean, stddev, -}
 
 // ---- launchers (rs_kernels.hip) ----------------------------------------------------------
+constexpr int HEAVY_SLOTS = 2048;   // wave slots at the front of phase A's grid reserved for the previous iteration's slow tiles
+
 struct IcpLaunch
 {
   GridView     tgt;
@@ -89,6 +91,10 @@ struct IcpLaunch
   float   tgt_nor_max;  // max |normal| over the target cloud
   unsigned long long* dbg;   // diagnostic builds only: per-tile {cycles, candidates} of phase A (null otherwise)
   const float* w_explicit;   // if non-null: weights given per query (estimate-only entry point)
+  // slowest-first start of phase A's tiles: every iteration lists its slow tiles for the next one (null: off)
+  //   per problem: [0] count | HEAVY_SLOTS tile ids | n_tiles x (position in the list + 1, or 0)
+  const int* heavy_in;
+  int*    heavy_out;
 };
 void launch_icp_corr( const IcpLaunch& L, hipStream_t st );     // phase A, phase B (+ statistics of dist² over the correspondences)
 void launch_icp_moments( const IcpLaunch& L, hipStream_t st );  // weights + moments (+ solve and loop-state update if L.solve)

@@ -432,9 +432,11 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
                                               float qx, float qy, float qz, float nx, float ny, float nz,
                                               float radius, float radius_sq, float tmin, float tmin_loose, int K,
                                               WaveLds& L, int lane, int max_stages, bool* handoff, int* dbg_unsettled,
-                                              Match m /* starting candidate: empty, or a genuine one (within radius, gate passed) that only tightens the bounds */ )
+                                              Match m /* starting candidate: empty, or a genuine one (within radius, gate passed) that only tightens the bounds */,
+                                              int* n_sweeps = nullptr /* out: shells swept + rank pass: the tile's cost class */ )
 {
   if( handoff ) *handoff = false;
+  int sweeps = 0;
   const TileBounds tb = wave_bounds( active, qx, qy, qz );
   if( !tb.any ) return m;
   const CellBox full = cell_box( g, tb, radius );
@@ -459,6 +461,7 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
       streamed += sweep_shell<GATED>( g, cur, cur, false, L, lane, 0, 1, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
       { consider4<GATED>( X, Y, Z, k4, L, qx, qy, qz, nx, ny, nz, tmin, tmin_loose, bound, m, seen_closer ); } );
     if( dbg_unsettled ) { dbg_unsettled[1] = (int)streamed; dbg_unsettled[3] = 1; }
+    sweeps = 1;
   }
   else
   {
@@ -476,6 +479,8 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
       streamed += sweep_shell<GATED>( g, out, prev, have_prev, L, lane, 0, 1, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
       { consider4<GATED>( X, Y, Z, k4, L, qx, qy, qz, nx, ny, nz, tmin, tmin_loose, bound, m, seen_closer ); } );
     if( dbg_unsettled ) dbg_unsettled[1] = (int)streamed;
+    ++sweeps;
+    if( n_sweeps ) *n_sweeps = sweeps;
     if( box_same( cur, full ) ) break;
     // a lane is settled when nothing outside `cur` can precede its match (or reach it at all)
     const float cov = box_cover( g, cur, full, qx, qy, qz );
@@ -490,7 +495,8 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
       const int kn = k ? 2 * k : 1;
       const CellBox nxt = box_grow( core, kn, full );
       const int next_rows = ( nxt.y1 - nxt.y0 + 1 ) * ( nxt.z1 - nxt.z0 + 1 );
-      if( streamed >= (uint32_t)max_stages || next_rows > 2 * WAVE ) { *handoff = true; return m; }
+      const int thr = max_stages & 0xffff, k_always = max_stages >> 16;     // k_always: hand off whenever still unsettled after shell k >= that (0: never)
+      if( streamed >= (uint32_t)thr || next_rows > 2 * WAVE || ( k_always && k >= k_always ) ) { *handoff = true; return m; }
     }
     prev = cur; have_prev = true;
   }
@@ -513,8 +519,10 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
       { rank += need_rank ? precede4( X, Y, Z, k4, L, qx, qy, qz, radius_sq, m.d2, m.idx ) : 0; } );
       if( dbg_unsettled ) dbg_unsettled[2] = (int)rs;
       if( need_rank && rank >= K ) { m.found = false; m.slot = -1; }
+      ++sweeps;
     }
   }
+  if( n_sweeps ) *n_sweeps = sweeps;
   return m;
 }
 
@@ -704,7 +712,7 @@ __device__ __forceinline__ void icp_emit( const IcpLaunch& L, int prob, int tile
   const size_t o = (size_t)prob * L.src.n + i;
   if( active ) { L.m_slot[o] = m.found ? m.slot : -1; L.m_d2[o] = m.d2; L.m_dot[o] = m.dot; }
   if( active && L.cert_r && !skipped && !m.found && !m.loose ) { L.cert_r[o] = L.radius - 1e-4f; L.cert_dot[o] = L.cert_mu - 1e-5f; }   // fresh certificate
-  if( DBG( L ) )
+  if( RS_DBG >= 2 && DBG( L ) )
   {
     unsigned long long* cat = DBG( L ) + 6 * (size_t)L.src.n_tiles;
     const int c_skip = __popcll( __ballot( skipped ) ), c_fresh = __popcll( __ballot( active && !skipped && !m.found && !m.loose ) );
@@ -735,8 +743,25 @@ __global__ __launch_bounds__( BLOCK, RS_ICP_OCC ) void k_icp_corr( IcpLaunch L )
   if( L.active[prob] == 0 ) return;
   const int lane = threadIdx.x & ( WAVE - 1 );
   const int wib = threadIdx.x / WAVE;
-  const int tile = blockIdx.x * WAVES_PER_BLOCK + wib;
-  if( tile >= L.src.n_tiles ) return;
+  // Slowest first: the kernel ends when its slowest tile does, and the slow tiles (several shells, a rank
+  // pass) are the same from one iteration to the next.  The previous iteration listed them; the first
+  // HEAVY_SLOTS wave slots of the grid take that list, the rest walk the tiles in their natural (Hilbert)
+  // order — which the caches depend on — and skip the listed ones.
+  int slot = blockIdx.x * WAVES_PER_BLOCK + wib;
+  int tile;
+  if( L.heavy_in )
+  {
+    const int* hv = L.heavy_in + (size_t)prob * ( L.src.n_tiles + HEAVY_SLOTS + 1 );     // [0] count | list HEAVY_SLOTS | per-tile position+1 or 0
+    if( slot < HEAVY_SLOTS ) { if( slot >= min( uni( hv[0] ), HEAVY_SLOTS ) ) return; tile = uni( hv[1 + slot] ); }
+    else
+    {
+      tile = slot - HEAVY_SLOTS;
+      if( tile >= L.src.n_tiles ) return;
+      const int listed = uni( hv[1 + HEAVY_SLOTS + tile] );
+      if( listed > 0 && listed <= HEAVY_SLOTS ) return;       // a front slot has it
+    }
+  }
+  else { tile = slot; if( tile >= L.src.n_tiles ) return; }
   const int i = (int)L.src.tiles[tile] + lane;
   const bool active = i < (int)L.src.tiles[tile + 1];
 
@@ -747,16 +772,26 @@ __global__ __launch_bounds__( BLOCK, RS_ICP_OCC ) void k_icp_corr( IcpLaunch L )
   const unsigned long long t_begin = DBG( L ) ? wall_clock64() : 0ull;
   icp_query( L, T1, i, active, qx, qy, qz, nx, ny, nz );
   bool handoff;
+  int sweeps = 0;
   int unsettled[4] = { 0, 0, 0, 0 };
   const bool search = active & !icp_certificate( L, prob, i, active, qx, qy, qz, nx, ny, nz );
   const Match init = icp_warm_start( L, prob, i, search, qx, qy, qz, nx, ny, nz );
   Match m = tile_search<true>( L.tgt, search, qx, qy, qz, nx, ny, nz, L.radius, L.radius_sq, L.gate_tmin, L.gate_tmin - L.cert_mu, L.K,
-                               lds[wib], lane, L.solo_stages, &handoff, DBG( L ) ? unsettled : nullptr, init );
+                               lds[wib], lane, L.solo_stages, &handoff, DBG( L ) ? unsettled : nullptr, init, &sweeps );
+  if( L.heavy_out && lane == 0 )
+  {
+    int* hv = L.heavy_out + (size_t)prob * ( L.src.n_tiles + HEAVY_SLOTS + 1 );
+    int listed = 0;
+    if( handoff || sweeps >= 2 ) { const int pos = atomicAdd( hv, 1 ); listed = pos + 1; if( pos < HEAVY_SLOTS ) hv[1 + pos] = tile; }
+    hv[1 + HEAVY_SLOTS + tile] = listed;
+  }
   if( DBG( L ) && lane == 0 )
   {
-    DBG( L )[2 * tile] = wall_clock64() - t_begin;       // [1]: unsettled lanes 8 bits | handoff 1 | stages 7 | streamed 24 | rank-pass streamed 24
-    DBG( L )[2 * tile + 1] = (unsigned long long)( unsettled[0] & 0xff ) | ( (unsigned long long)( handoff ? 1 : 0 ) << 8 ) | ( (unsigned long long)( unsettled[3] & 0x7f ) << 9 ) |
-                          ( (unsigned long long)( unsettled[1] & 0xffffff ) << 16 ) | ( (unsigned long long)( unsettled[2] & 0xffffff ) << 40 );
+    // [0] start (absolute, 10 ns ticks) | [1] duration 20 bits | handoff 1 | shells 4 | streamed 16 | rank-pass streamed 16 | unsettled lanes after shell 1: 7
+    auto clipv = []( unsigned long long v, unsigned long long mx ) { return v > mx ? mx : v; };
+    DBG( L )[2 * tile] = t_begin;
+    DBG( L )[2 * tile + 1] = clipv( wall_clock64() - t_begin, 0xfffff ) | ( (unsigned long long)( handoff ? 1 : 0 ) << 20 ) | ( clipv( unsettled[3], 15 ) << 21 ) |
+                             ( clipv( unsettled[1], 0xffff ) << 25 ) | ( clipv( unsettled[2], 0xffff ) << 41 ) | ( clipv( unsettled[0], 127 ) << 57 );
   }
   if( handoff )
   {
@@ -798,6 +833,7 @@ __device__ __forceinline__ void icp_stats_block( const IcpLaunch& L, int prob, d
     st[0] = n; st[1] = mean; st[2] = sd; st[3] = (double)L.queue_count[prob];   // [3]: tiles phase A handed off
     if( L.queued ) L.queued[prob] = L.queue_count[prob];
     L.queue_count[prob] = 0;                               // ready for the next iteration's phase A
+    if( L.heavy_in ) const_cast<int*>( L.heavy_in )[(size_t)prob * ( L.src.n_tiles + HEAVY_SLOTS + 1 )] = 0;   // consumed: it is the next iteration's output buffer
   }
 }
 
@@ -972,7 +1008,7 @@ __global__ __launch_bounds__( BLOCK ) void k_icp_update( IcpLaunch L )
 void launch_icp_corr( const IcpLaunch& L, hipStream_t st )
 {
   // queue_count is zero on entry: cleared once by the host, then by the cooperative kernel's last workgroup after every use
-  dim3 grid( ( L.src.n_tiles + WAVES_PER_BLOCK - 1 ) / WAVES_PER_BLOCK, L.n_prob );
+  dim3 grid( ( L.src.n_tiles + ( L.heavy_in ? HEAVY_SLOTS : 0 ) + WAVES_PER_BLOCK - 1 ) / WAVES_PER_BLOCK, L.n_prob );
   hipLaunchKernelGGL( k_icp_corr, grid, dim3( BLOCK ), 0, st, L );
   // the queue length is only known on the device: a fixed grid strides over it
   int coop_blocks = L.src.n_tiles < 2048 ? L.src.n_tiles : 2048;
@@ -1111,7 +1147,10 @@ __device__ __forceinline__ void unit3( float& x, float& y, float& z )
   x = x * inv; y = y * inv; z = z * inv;
 }
 
-__global__ __launch_bounds__( BLOCK, 6 ) void k_label( LabelLaunch L )
+#ifndef RS_LABEL_OCC
+#define RS_LABEL_OCC 6
+#endif
+__global__ __launch_bounds__( BLOCK, RS_LABEL_OCC ) void k_label( LabelLaunch L )
 {
   __shared__ WaveLds lds[WAVES_PER_BLOCK];
   const int lane = threadIdx.x & ( WAVE - 1 );
