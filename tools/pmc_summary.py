@@ -29,10 +29,8 @@ if __name__ == "__main__":
     elif len(sys.argv) > 2 and sys.argv[1] == "--trace":
         rows = sorted(csv.DictReader(open(sys.argv[2])), key=lambda r: int(r["Start_Timestamp"]))
         rows = [r for r in rows if "rs::" in r["Kernel_Name"]]
-        t0 = int(rows[0]["Start_Timestamp"])
-        # the last step only: everything after the largest gap
-        gaps = [(int(b["Start_Timestamp"]) - int(a["End_Timestamp"]), i + 1) for i, (a, b) in enumerate(zip(rows, rows[1:]))]
-        start = max(gaps)[1] if gaps else 0
+        # bench.py --steps 1 --warmup 1 --serial: two identical steps; show the second
+        start = len(rows) // 2
         lines = []
         for r in rows[start:]:
             s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
