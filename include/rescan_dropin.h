@@ -99,6 +99,17 @@ int64_t rsd_compute_neighborhood( const rsd_vec3_t* pos, const rsd_vec3_t* nor, 
                                   int32_t max_nn, float radius_sq, float dist_exp, float angle_exp,
                                   int32_t* idx1, int32_t* idx2, float* weight );
 
+/* Scene-coverage term of the arrangement optimiser (apps/segment_transfer/arrangement_optimization.cpp:344-373).
+ * rsd_coverage_create replaces isect_grid3d_init + rsao_rasterize_scene_to_grid for opts->scn_grd
+ * (apps/segment_transfer/main.cpp:323-339); rsd_coverage_score replaces the body of
+ * rsao__compute_scene_coverage_score: obj_* = rsdb->objects[arrangement[i].object_idx].shape level 2,
+ * is_static[i] = rsdb_is_object_static(...).  Returns the score; < 0 on a device error. */
+void* rsd_coverage_create( const rsd_vec3_t* bbox_min, const rsd_vec3_t* bbox_max, float voxel_size,
+                           const rsd_vec3_t* scene_pos, const float* scene_quality, int32_t n_scene, float quality_threshold );
+float rsd_coverage_score( void* coverage, const rsd_vec3_t* const* obj_pos, const int32_t* obj_n,
+                          const rsd_mat4_t* poses, const int32_t* is_static, int32_t n_plc );
+void  rsd_coverage_destroy( void* coverage );
+
 /* Drop every cached device cloud (the shim caches uploads by host pointer + content hash). */
 void  rsd_cache_clear( void );
 

@@ -168,6 +168,31 @@ int rs_hip_compute_neighborhood( const rs_hip_cloud_t* cloud, int32_t max_nn, fl
                                  float dist_exp, float angle_exp,
                                  int32_t* idx1, int32_t* idx2, float* weight, int64_t capacity, int64_t* n_edges );
 
+/* ---- scene-coverage term of the arrangement optimiser ---------------- */
+
+/* The voxel grid of lib/rs/intersect.h:59-109 over a scene's bounding box (isect_grid3d_init: fattened by
+ * 0.3, ceilf(extent/voxel)+1 cells per axis) with the scene's level-2 points rasterised into it
+ * (rsao_rasterize_scene_to_grid, apps/segment_transfer/arrangement_optimization.cpp:1064-1079: points
+ * with quality < threshold are skipped; quality may be NULL).  One bit per voxel on the device. */
+typedef struct rs_hip_coverage rs_hip_coverage_t;
+rs_hip_coverage_t* rs_hip_coverage_create( const float bbox_min[3], const float bbox_max[3], float voxel_size,
+                                           const float* scene_pos, const float* scene_quality, int64_t n_scene,
+                                           float quality_threshold );
+void rs_hip_coverage_destroy( rs_hip_coverage_t* c );
+int  rs_hip_coverage_info( const rs_hip_coverage_t* c, int32_t res[3], float origin[3], int64_t* n_cells, int64_t* valid_cells );
+/* Copies the scene grid out as the reference's byte array (1 = RSAO_CELL_ACTIVE), n_cells bytes. */
+int  rs_hip_coverage_scene_grid( const rs_hip_coverage_t* c, uint8_t* data );
+
+/* rsao__compute_scene_coverage_score (:344-373) for a batch of arrangements in one launch: arrangement a
+ * consists of the placements [first_placement[a], first_placement[a+1]); placement k puts objects[k] (its
+ * level-2 cloud) at poses[16k..] and is skipped when is_static[k] (rsdb_is_object_static, :1095-1096).
+ * scores[a] = agreeing / valid scene voxels (0 when the scene grid is empty); agree (optional) receives
+ * the integer numerators.  The simulated-annealing loop evaluates one arrangement per iteration
+ * (:388); candidate moves can be scored together. */
+int  rs_hip_coverage_scores( rs_hip_coverage_t* c, const rs_hip_cloud_t* const* objects, const float* poses,
+                             const int32_t* is_static, const int32_t* first_placement, int32_t n_arrangements,
+                             float* scores, int32_t* agree );
+
 /* ---- host-side helpers shared by the drop-in shim (exact reference arithmetic) ------- */
 
 /* msh_mat4_inverse / msh_mat4_mul (lib/msh/msh_vec_math.h:1818-1905, 1441-1476) */

@@ -17,9 +17,12 @@ Each fixture holds the inputs and the reference's outputs for one hot-path funct
   edge_cost.npz  the neighbourhood edge weight (rs_pointcloud_filters.cpp:706-708) from the
                  reference-toolchain TU oracle/ref_label_gate.cpp
   neighborhood_*.npz  rspf_compute_neighborhood (:674-722) — by the C restatement, as for labels_*
+  coverage.npz   rsao__compute_scene_coverage_score + grids (arrangement_optimization.cpp:344-373,1064-1106) from the
+                 reference TU compiled in place (oracle/_ref/libref_ao.so)
 
 Usage:  python oracle/gen_golden.py                       (everything)
-        python oracle/gen_golden.py --neighborhood-only   (adds the last two without rewriting the rest)
+        python oracle/gen_golden.py --neighborhood-only   (adds those two without rewriting the rest)
+        python oracle/gen_golden.py --coverage-only       (likewise)
 """
 import os
 import sys
@@ -147,6 +150,7 @@ def main():
             class_ids=res["class_ids"], instance_ids=res["instance_ids"])
 
     gen_neighborhood(O, R, s)
+    gen_coverage(s)
 
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print(f"wrote {len(os.listdir(OUT))} fixtures, {total/1e6:.2f} MB")
@@ -169,6 +173,40 @@ def gen_neighborhood(O, R, s):
     np.savez_compressed(os.path.join(OUT, "neighborhood_scene.npz"), digest=edge_digest(a, b, w))
 
 
+def gen_coverage(s):
+    """coverage.npz: the scene-coverage term by the REFERENCE itself (oracle/_ref/libref_ao.so =
+    arrangement_optimization.cpp compiled in place): grid geometry, the rasterised scene grid and the
+    scores of 24 arrangements (perturbed object poses, subsets, one static placement)."""
+    from oracle.pyoracle import RefAO
+    pts = s["points"]
+    bmin, bmax = pts.min(0), pts.max(0)
+    rng = np.random.default_rng(99)
+    quality = rng.uniform(0.3, 1.0, len(pts)).astype(np.float32)        # some points fall below the 0.5 threshold
+    R = RefAO(synth.CLASS_IDX, pts, bmin, bmax, quality=quality)
+    objs = s["objects"]
+    idx = [R.add_object(o["pos"], o["class_idx"], o["uidx"]) for o in objs]
+    wall = pts[s["instance_idx"] == 1][::3].copy()
+    idx.append(R.add_object(wall, synth.CLASS_IDX["wall"], 1))          # a static object: must be skipped
+    arr_obj, arr_pose, arr_first, scores = [], [], [0], []
+    for a in range(24):
+        members = [k for k in range(len(idx)) if rng.uniform() < 0.7] or [0]
+        poses = [synth.perturbed_pose(objs[k]["pose"], rng, 0.02 * (a % 5), 0.01 * (a % 3)) if k < len(objs) else I4 for k in members]
+        scores.append(R.coverage([idx[k] for k in members], poses))
+        arr_obj += members; arr_pose += poses; arr_first.append(len(arr_obj))
+    np.savez_compressed(os.path.join(OUT, "coverage.npz"), bbox_min=bmin, bbox_max=bmax, quality=quality, wall=wall,
+                        res=R.res, origin=R.origin, n_cells=R.n_cells, scene_grid=np.packbits(R.scene_grid()),
+                        arr_obj=np.array(arr_obj, np.int32), arr_pose=np.array(arr_pose, np.float32).reshape(-1, 16),
+                        arr_first=np.array(arr_first, np.int32), scores=np.array(scores, np.float32))
+
+
+def main_coverage_only():
+    d = dict(np.load(os.path.join(OUT, "scene.npz")))
+    s = dict(points=d["points"], normals=d["normals"], instance_idx=d["instance_idx"],
+             objects=[dict(pos=d[f"obj{i}_pos"], nor=d[f"obj{i}_nor"], pose=d["obj_pose"][i], class_idx=int(d["obj_class"][i]),
+                           uidx=int(d["obj_uidx"][i])) for i in range(int(d["n_obj"]))])
+    gen_coverage(s)
+
+
 def main_neighborhood_only():
     """Adds the neighbourhood fixtures without rewriting the others (zip timestamps would churn them)."""
     from oracle.pyoracle import Oracle, Ref
@@ -181,5 +219,7 @@ def main_neighborhood_only():
 if __name__ == "__main__":
     if "--neighborhood-only" in sys.argv:
         main_neighborhood_only()
+    elif "--coverage-only" in sys.argv:
+        main_coverage_only()
     else:
         main()

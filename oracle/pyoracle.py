@@ -5,6 +5,7 @@ ctypes bindings for the two CPU checkers:
 * ``Oracle``  -> oracle/librs_oracle.so   (plain-C restatement, rs_oracle.c)
 * ``Ref``     -> oracle/_ref/libref.so    (the real reference compiled in place; only
                  buildable where /root/reference exists, the .so travels to the GPU box)
+* ``RefAO``   -> oracle/_ref/libref_ao.so (the reference's arrangement_optimization.cpp: scene-coverage term)
 
 Both expose the same method names so tests can run one function against the other.
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
@@ -219,6 +220,50 @@ class Oracle(_Base):
         f.argtypes = [C.c_float] * 5
         return f(float(d2), float(dot), float(radius_sq), float(dist_exp), float(angle_exp))
 
+    # ---- scene-coverage term ----
+    class VoxGrid(C.Structure):
+        _fields_ = [("x_res", C.c_int32), ("y_res", C.c_int32), ("z_res", C.c_int32), ("n_cells", C.c_int32),
+                    ("voxel_size", C.c_float), ("origin", C.c_float * 3)]
+
+    def voxgrid(self, bbox_min, bbox_max, voxel_size=0.05):
+        g = self.VoxGrid()
+        f = self.lib.orc_voxgrid_init
+        f.restype = None
+        f.argtypes = [C.POINTER(self.VoxGrid), f32p, f32p, C.c_float]
+        f(C.byref(g), _f32(bbox_min), _f32(bbox_max), float(voxel_size))
+        return g
+
+    def rasterize_scene(self, g, pos, quality=None, threshold=0.5):
+        pos = _f32(pos)
+        data = np.zeros(g.n_cells, np.uint8)
+        f = self.lib.orc_rasterize_scene
+        f.restype = None
+        f.argtypes = [C.POINTER(self.VoxGrid), f32p, C.c_void_p, C.c_int64, C.c_float, np.ctypeslib.ndpointer(np.uint8)]
+        q = None if quality is None else _f32(quality)
+        f(C.byref(g), pos, None if q is None else q.ctypes.data, len(pos), float(threshold), data)
+        return data
+
+    def rasterize_arrangement(self, g, obj_pos, poses, is_static):
+        n = len(obj_pos)
+        keep = [_f32(p) for p in obj_pos]
+        ptrs = (C.c_void_p * n)(*[p.ctypes.data for p in keep])
+        ns = np.array([len(p) for p in keep], np.int64)
+        data = np.zeros(g.n_cells, np.uint8)
+        f = self.lib.orc_rasterize_arrangement
+        f.restype = None
+        f.argtypes = [C.POINTER(self.VoxGrid), C.c_void_p, i64p, f32p, i32p, C.c_int32, np.ctypeslib.ndpointer(np.uint8)]
+        f(C.byref(g), C.addressof(ptrs), ns, _f32(np.asarray(poses).reshape(-1, 16)), np.asarray(is_static, np.int32), n, data)
+        return data
+
+    def coverage_score(self, scene_data, arr_data):
+        f = self.lib.orc_coverage_score
+        f.restype = C.c_float
+        u8 = np.ctypeslib.ndpointer(np.uint8)
+        f.argtypes = [u8, u8, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        a, v = C.c_int32(), C.c_int32()
+        s = f(scene_data, arr_data, len(scene_data), C.byref(a), C.byref(v))
+        return np.float32(s), a.value, v.value
+
     def icp_gate(self, dot, max_angle):
         return self._icp_gate(float(dot), float(max_angle))
 
@@ -315,3 +360,59 @@ def edge_digest(a, b, w):
     hi, lo = np.maximum(a, b).astype(np.int64), np.minimum(a, b).astype(np.int64)
     return np.array([len(a), int((hi * 1000003 + lo).sum() % (1 << 61)), int(np.sort(w.view(np.uint32)).astype(np.int64).sum())],
                     np.int64)
+
+
+class RefAO:
+    """The reference's scene-coverage term (apps/segment_transfer/arrangement_optimization.cpp) behind
+    oracle/ref_ao_driver.cpp.  One class table per process (the reference caches class ids in statics)."""
+    PATH = os.path.join(HERE, "_ref", "libref_ao.so")
+
+    @staticmethod
+    def available():
+        return os.path.exists(RefAO.PATH)
+
+    def __init__(self, class_table, scene_pos, bbox_min, bbox_max, quality=None, voxel_size=0.05, threshold=0.5):
+        self.lib = C.CDLL(self.PATH)
+        names = list(class_table)
+        arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+        ids = np.array([class_table[n] for n in names], np.int32)
+        self._pos = _f32(scene_pos)
+        self._q = _f32(np.ones(len(self._pos)) if quality is None else quality)
+        self._objs = []
+        f = self.lib.ref_ao_create
+        f.restype = C.c_void_p
+        f.argtypes = [C.c_void_p, i32p, C.c_int32, f32p, f32p, C.c_int64, f32p, f32p, C.c_float, C.c_float]
+        self.h = f(C.addressof(arr), ids, len(names), self._pos, self._q, len(self._pos), _f32(bbox_min), _f32(bbox_max),
+                   float(voxel_size), float(threshold))
+        res = np.zeros(3, np.int32); org = np.zeros(3, np.float32); n = C.c_int64()
+        g = self.lib.ref_ao_info
+        g.restype = None
+        g.argtypes = [C.c_void_p, i32p, f32p, C.POINTER(C.c_int64)]
+        g(self.h, res, org, C.byref(n))
+        self.res, self.origin, self.n_cells = res, org, n.value
+
+    def add_object(self, pos, class_idx, uidx):
+        p = _f32(pos)
+        self._objs.append(p)
+        f = self.lib.ref_ao_add_object
+        f.restype = C.c_int32
+        f.argtypes = [C.c_void_p, f32p, C.c_int64, C.c_int32, C.c_int32]
+        return f(self.h, p, len(p), int(class_idx), int(uidx))
+
+    def coverage(self, object_idx, poses):
+        f = self.lib.ref_ao_coverage
+        f.restype = C.c_float
+        f.argtypes = [C.c_void_p, i32p, f32p, C.c_int32]
+        return np.float32(f(self.h, np.asarray(object_idx, np.int32), _f32(np.asarray(poses).reshape(-1, 16)), len(object_idx)))
+
+    def _grid(self, name):
+        f = getattr(self.lib, name)
+        f.restype = C.POINTER(C.c_uint8)
+        f.argtypes = [C.c_void_p]
+        return np.ctypeslib.as_array(f(self.h), shape=(self.n_cells,)).copy()
+
+    def scene_grid(self):
+        return self._grid("ref_ao_scene_grid")
+
+    def arrangement_grid(self):
+        return self._grid("ref_ao_arrangement_grid")

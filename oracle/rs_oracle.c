@@ -1053,3 +1053,78 @@ int64_t orc_compute_neighborhood( const orc_grid_t* grid, const float* pos, cons
   free( rec ); free( d2 ); free( ix ); free( nn );
   return out;
 }
+
+
+/* ------------------------------------------------------------------------------------------
+ * Scene-coverage term  (lib/rs/intersect.h:59-109, apps/segment_transfer/arrangement_optimization.cpp:344-373,1064-1106)
+ * ------------------------------------------------------------------------------------------ */
+
+void orc_voxgrid_init( orc_voxgrid_t* g, const float bbox_min[3], const float bbox_max[3], float voxel_size )
+{
+  const float fat = 0.3f;                                         /* intersect.h:61 */
+  float mn[3], mx[3];
+  for( int a = 0; a < 3; ++a ) { mn[a] = bbox_min[a] - fat; mx[a] = bbox_max[a] + fat; }     /* :64-65 */
+  g->x_res = (int32_t)ceilf( ( mx[0] - mn[0] ) / voxel_size ) + 1;     /* :67-69 */
+  g->y_res = (int32_t)ceilf( ( mx[1] - mn[1] ) / voxel_size ) + 1;
+  g->z_res = (int32_t)ceilf( ( mx[2] - mn[2] ) / voxel_size ) + 1;
+  g->voxel_size = voxel_size;
+  g->n_cells = g->x_res * g->y_res * g->z_res;
+  for( int a = 0; a < 3; ++a ) g->origin[a] = mn[a];
+}
+
+int64_t orc_voxgrid_cell( const orc_voxgrid_t* g, const float p[3] )
+{
+  float inv = 1.0f / g->voxel_size;                               /* :100 */
+  int32_t x = (int32_t)floorf( ( p[0] - g->origin[0] ) * inv );
+  int32_t y = (int32_t)floorf( ( p[1] - g->origin[1] ) * inv );
+  int32_t z = (int32_t)floorf( ( p[2] - g->origin[2] ) * inv );
+  if( x < 0 || x >= g->x_res || y < 0 || y >= g->y_res || z < 0 || z >= g->z_res ) return -1;
+  return (int64_t)( y * g->x_res * g->z_res + z * g->x_res + x );   /* :108 (int arithmetic, as there) */
+}
+
+void orc_rasterize_scene( const orc_voxgrid_t* g, const float* pos, const float* quality, int64_t n, float quality_threshold, uint8_t* data )
+{
+  memset( data, 0, (size_t)g->n_cells );
+  for( int64_t i = 0; i < n; ++i )
+  {
+    if( quality && quality[i] < quality_threshold ) continue;     /* :1073-1074 */
+    int64_t c = orc_voxgrid_cell( g, pos + 3 * i );
+    if( c >= 0 ) data[c] = 1;
+  }
+}
+
+void orc_rasterize_arrangement( const orc_voxgrid_t* g, const float* const* obj_pos, const int64_t* obj_n, const float* poses,
+                                const int32_t* is_static, int32_t n_plc, uint8_t* data )
+{
+  memset( data, 0, (size_t)g->n_cells );
+  for( int32_t k = 0; k < n_plc; ++k )
+  {
+    if( is_static[k] ) continue;                                  /* :1095-1096 */
+    const float* m = poses + 16 * k;
+    for( int64_t i = 0; i < obj_n[k]; ++i )
+    {
+      const float* v = obj_pos[k] + 3 * i;
+      float w[3];                                                 /* msh_mat4_vec3_mul( pose, p, 1 ), msh_vec_math.h:1554-1561 */
+      w[0] = m[0] * v[0] + m[4] * v[1] + m[8] * v[2] + 1.0f * m[12];
+      w[1] = m[1] * v[0] + m[5] * v[1] + m[9] * v[2] + 1.0f * m[13];
+      w[2] = m[2] * v[0] + m[6] * v[1] + m[10] * v[2] + 1.0f * m[14];
+      int64_t c = orc_voxgrid_cell( g, w );
+      if( c >= 0 ) data[c] = 1;
+    }
+  }
+}
+
+float orc_coverage_score( const uint8_t* scene_data, const uint8_t* arr_data, int64_t n_cells, int32_t* agree, int32_t* valid )
+{
+  int32_t a = 0, v = 0;
+  for( int64_t i = 0; i < n_cells; ++i )
+  {
+    if( scene_data[i] > 0 ) v++;
+    if( scene_data[i] > 0 && arr_data[i] > 0 ) a++;
+  }
+  if( agree ) *agree = a;
+  if( valid ) *valid = v;
+  float score = (float)a / (float)v;                              /* :366 */
+  if( v == 0 ) score = 0.0f;
+  return score;
+}

@@ -107,6 +107,20 @@ int64_t orc_compute_neighborhood( const orc_grid_t* grid, const float* pos, cons
                                   int32_t* idx1, int32_t* idx2, float* weight );
 float orc_edge_cost( float nn_dist, float dot_nm, float radius_sq, float dist_exp, float angle_exp );   /* :706-708 */
 
+/* Scene-coverage term of the arrangement optimiser.
+ * isect_grid3d_init (lib/rs/intersect.h:59-75): bbox fattened by 0.3 on every side, resolution
+ * ceilf(extent / voxel) + 1 per axis; cell (x,y,z) lives at y*x_res*z_res + z*x_res + x (:91-109). */
+typedef struct orc_voxgrid { int32_t x_res, y_res, z_res, n_cells; float voxel_size; float origin[3]; } orc_voxgrid_t;
+void    orc_voxgrid_init( orc_voxgrid_t* g, const float bbox_min[3], const float bbox_max[3], float voxel_size );
+int64_t orc_voxgrid_cell( const orc_voxgrid_t* g, const float p[3] );          /* -1 = outside (:97-109) */
+/* rsao_rasterize_scene_to_grid (apps/segment_transfer/arrangement_optimization.cpp:1064-1079); quality may be NULL (= all pass) */
+void    orc_rasterize_scene( const orc_voxgrid_t* g, const float* pos, const float* quality, int64_t n, float quality_threshold, uint8_t* data );
+/* rsao__rasterize_arrangement_to_grid (:1082-1106): data zeroed, then every point of every non-static placement, transformed by its pose */
+void    orc_rasterize_arrangement( const orc_voxgrid_t* g, const float* const* obj_pos, const int64_t* obj_n, const float* poses,
+                                   const int32_t* is_static, int32_t n_plc, uint8_t* data );
+/* rsao__compute_scene_coverage_score (:344-373): agreeing / valid scene cells (0 if no valid cell) */
+float   orc_coverage_score( const uint8_t* scene_data, const uint8_t* arr_data, int64_t n_cells, int32_t* agree, int32_t* valid );
+
 /* The three normal gates, on a raw dot value (for threshold pinning). */
 int orc_icp_gate( float dot, float max_angle );    /* lib/rs/icp.h:372-374 */
 int orc_score_gate( float dot );                   /* pose_proposal.cpp:138-141 */

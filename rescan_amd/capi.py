@@ -47,6 +47,11 @@ SIGNATURES = {
                                                C.c_int, i8p, f32p, i32p]),
     "rs_hip_compute_neighborhood": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float, i32p, i32p, f32p,
                                               C.c_int64, C.POINTER(C.c_int64)]),
+    "rs_hip_coverage_create": (C.c_void_p, [f32p, f32p, C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_float]),
+    "rs_hip_coverage_destroy": (None, [C.c_void_p]),
+    "rs_hip_coverage_info": (C.c_int, [C.c_void_p, i32p, f32p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "rs_hip_coverage_scene_grid": (C.c_int, [C.c_void_p, np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")]),
+    "rs_hip_coverage_scores": (C.c_int, [C.c_void_p, C.c_void_p, f32p, i32p, i32p, C.c_int32, f32p, C.c_void_p]),
     "rs_hip_mat4_inverse": (None, [f32p, f32p]),
     "rs_hip_mat4_mul": (None, [f32p, f32p, f32p]),
     "rs_hip_icp_estimate_pt2pl": (C.c_int, [f32p, f32p, f32p, f32p, C.c_int32, f32p, C.POINTER(C.c_float)]),
@@ -274,3 +279,45 @@ def compute_neighborhood(cloud, max_nn=8, radius_sq=0.05 * 0.05, dist_exp=15.0, 
     _check(load().rs_hip_compute_neighborhood(cloud.handle, int(max_nn), float(np.float32(radius_sq)), float(dist_exp),
                                               float(angle_exp), a, b, w, cap, C.byref(m)))
     return a[:m.value].copy(), b[:m.value].copy(), w[:m.value].copy()
+
+
+class Coverage:
+    """Scene voxel grid + coverage scores (rsao__compute_scene_coverage_score)."""
+
+    def __init__(self, bbox_min, bbox_max, scene_pos, quality=None, voxel_size=0.05, threshold=0.5):
+        pos = np.ascontiguousarray(scene_pos, np.float32)
+        q = None if quality is None else np.ascontiguousarray(quality, np.float32)
+        self.handle = load().rs_hip_coverage_create(np.ascontiguousarray(bbox_min, np.float32), np.ascontiguousarray(bbox_max, np.float32),
+                                                    float(voxel_size), pos.ctypes.data if len(pos) else None,
+                                                    None if q is None else q.ctypes.data, len(pos), float(threshold))
+        if not self.handle:
+            raise RescanHipError(f"coverage_create failed: {load().rs_hip_last_error().decode()}")
+        res = np.zeros(3, np.int32); org = np.zeros(3, np.float32); n = C.c_int64(); v = C.c_int64()
+        _check(load().rs_hip_coverage_info(self.handle, res, org, C.byref(n), C.byref(v)))
+        self.res, self.origin, self.n_cells, self.valid_cells = res, org, n.value, v.value
+
+    def scene_grid(self):
+        data = np.zeros(self.n_cells, np.uint8)
+        _check(load().rs_hip_coverage_scene_grid(self.handle, data))
+        return data
+
+    def scores(self, arrangements):
+        """arrangements: list of lists of (Cloud, pose16, is_static).  Returns (scores f32, agree i32)."""
+        flat = [p for a in arrangements for p in a]
+        first = np.zeros(len(arrangements) + 1, np.int32)
+        first[1:] = np.cumsum([len(a) for a in arrangements])
+        n = len(flat)
+        objs = (C.c_void_p * max(1, n))(*[p[0].handle for p in flat])
+        poses = np.ascontiguousarray(np.array([np.asarray(p[1], np.float32).ravel() for p in flat], np.float32).reshape(-1, 16)) if n else np.zeros((1, 16), np.float32)
+        stat = np.array([int(p[2]) for p in flat] or [0], np.int32)
+        sc = np.zeros(len(arrangements), np.float32); ag = np.zeros(len(arrangements), np.int32)
+        _check(load().rs_hip_coverage_scores(self.handle, C.addressof(objs), poses, stat, first, len(arrangements), sc, ag.ctypes.data))
+        return sc, ag
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                load().rs_hip_coverage_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass

@@ -101,6 +101,7 @@ struct Workspace
   DevBuf q4, rd2, ridx, rnn, rows;                                              // rows / misc
   DevBuf enor, ecount, eoffset, e1, e2, ew;                                     // neighbourhood edges
   DevBuf cert_r, cert_dot;                                                      // ICP certificates
+  DevBuf cov_bits, cov_plc, cov_agree;                                          // coverage scores
   DevBuf order_a, order_b;                                                      // ICP phase A slow-tile lists (ping-pong)
   DevBuf tmp_pos, tmp_pos2, tmp_nor2;                                           // estimate-only
   PinBuf h_a, h_b, h_c;
@@ -1095,5 +1096,144 @@ extern "C" int rs_hip_compute_neighborhood( const rs_hip_cloud_t* cloud, int32_t
   HIP_TRY( hipMemcpyAsync( weight, E.ew, (size_t)total * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
   HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
   *n_edges = (int64_t)total;
+  return RS_HIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// scene-coverage term
+// ------------------------------------------------------------------------------------------
+
+struct rs_hip_coverage
+{
+  VoxGrid grid{};
+  float voxel_size = 0.0f, origin[3] = { 0, 0, 0 };
+  int n_words = 0;
+  long long valid = 0;
+  uint32_t* d_bits = nullptr;
+};
+
+extern "C" rs_hip_coverage_t* rs_hip_coverage_create( const float bbox_min[3], const float bbox_max[3], float voxel_size,
+                                                      const float* scene_pos, const float* scene_quality, int64_t n_scene,
+                                                      float quality_threshold )
+{
+  if( ensure_ready() ) return nullptr;
+  if( !bbox_min || !bbox_max || !( voxel_size > 0.0f ) || n_scene < 0 || ( n_scene > 0 && !scene_pos ) ) { set_err( "coverage_create: bad arguments" ); return nullptr; }
+  rs_hip_coverage_t* c = new rs_hip_coverage_t();
+  // isect_grid3d_init (lib/rs/intersect.h:59-75), same float operations
+  const float fat = 0.3f;
+  float mn[3], mx[3];
+  for( int a = 0; a < 3; ++a ) { mn[a] = bbox_min[a] - fat; mx[a] = bbox_max[a] + fat; }
+  const double cells = ( (double)std::ceil( ( mx[0] - mn[0] ) / voxel_size ) + 1 ) * ( (double)std::ceil( ( mx[1] - mn[1] ) / voxel_size ) + 1 ) *
+                       ( (double)std::ceil( ( mx[2] - mn[2] ) / voxel_size ) + 1 );
+  if( !( cells > 0 ) || cells > 2.0e9 ) { set_err( "coverage_create: %g voxels do not fit the reference's int32 cell index", cells ); delete c; return nullptr; }
+  c->grid.x_res = (int)std::ceil( ( mx[0] - mn[0] ) / voxel_size ) + 1;
+  c->grid.y_res = (int)std::ceil( ( mx[1] - mn[1] ) / voxel_size ) + 1;
+  c->grid.z_res = (int)std::ceil( ( mx[2] - mn[2] ) / voxel_size ) + 1;
+  c->grid.n_cells = c->grid.x_res * c->grid.y_res * c->grid.z_res;
+  c->grid.ox = mn[0]; c->grid.oy = mn[1]; c->grid.oz = mn[2];
+  c->grid.inv_voxel = 1.0f / voxel_size;                      // :100
+  c->voxel_size = voxel_size; for( int a = 0; a < 3; ++a ) c->origin[a] = mn[a];
+  c->n_words = ( c->grid.n_cells + 31 ) / 32;
+  auto fail = [&]( const char* what ) { set_err( "coverage_create: %s", what ); if( c->d_bits ) (void)hipFree( c->d_bits ); delete c; return (rs_hip_coverage_t*)nullptr; };
+  if( hipMalloc( &c->d_bits, (size_t)c->n_words * 4 ) != hipSuccess ) return fail( "hipMalloc failed" );
+  if( hipMemsetAsync( c->d_bits, 0, (size_t)c->n_words * 4, g_stream ) != hipSuccess ) return fail( "memset failed" );
+  float *d_pos = nullptr, *d_q = nullptr; int* d_cnt = nullptr;
+  bool ok = hipMalloc( &d_cnt, 4 ) == hipSuccess && hipMemsetAsync( d_cnt, 0, 4, g_stream ) == hipSuccess;
+  if( ok && n_scene > 0 )
+  {
+    ok = hipMalloc( &d_pos, (size_t)n_scene * 12 ) == hipSuccess &&
+         hipMemcpyAsync( d_pos, scene_pos, (size_t)n_scene * 12, hipMemcpyHostToDevice, g_stream ) == hipSuccess;
+    if( ok && scene_quality )
+      ok = hipMalloc( &d_q, (size_t)n_scene * 4 ) == hipSuccess &&
+           hipMemcpyAsync( d_q, scene_quality, (size_t)n_scene * 4, hipMemcpyHostToDevice, g_stream ) == hipSuccess;
+    if( ok ) launch_voxel_mark( c->grid, d_pos, d_q, quality_threshold, n_scene, c->d_bits, g_stream );
+  }
+  int valid = 0;
+  if( ok ) { launch_popcount( c->d_bits, c->n_words, d_cnt, g_stream ); ok = hipMemcpyAsync( &valid, d_cnt, 4, hipMemcpyDeviceToHost, g_stream ) == hipSuccess; }
+  ok = ok && hipStreamSynchronize( g_stream ) == hipSuccess;
+  if( d_pos ) (void)hipFree( d_pos );
+  if( d_q ) (void)hipFree( d_q );
+  if( d_cnt ) (void)hipFree( d_cnt );
+  if( !ok ) return fail( "device step failed" );
+  c->valid = valid;
+  return c;
+}
+
+extern "C" void rs_hip_coverage_destroy( rs_hip_coverage_t* c )
+{
+  if( !c ) return;
+  if( c->d_bits ) (void)hipFree( c->d_bits );
+  delete c;
+}
+
+extern "C" int rs_hip_coverage_info( const rs_hip_coverage_t* c, int32_t res[3], float origin[3], int64_t* n_cells, int64_t* valid_cells )
+{
+  if( !c ) { set_err( "coverage_info: null handle" ); return RS_HIP_E_ARG; }
+  if( res ) { res[0] = c->grid.x_res; res[1] = c->grid.y_res; res[2] = c->grid.z_res; }
+  if( origin ) { origin[0] = c->origin[0]; origin[1] = c->origin[1]; origin[2] = c->origin[2]; }
+  if( n_cells ) *n_cells = c->grid.n_cells;
+  if( valid_cells ) *valid_cells = c->valid;
+  return RS_HIP_OK;
+}
+
+extern "C" int rs_hip_coverage_scene_grid( const rs_hip_coverage_t* c, uint8_t* data )
+{
+  int rc = ensure_ready(); if( rc ) return rc;
+  if( !c || !data ) { set_err( "coverage_scene_grid: bad arguments" ); return RS_HIP_E_ARG; }
+  std::vector<uint32_t> bits( (size_t)c->n_words );
+  HIP_TRY( hipMemcpyAsync( bits.data(), c->d_bits, bits.size() * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
+  for( int i = 0; i < c->grid.n_cells; ++i ) data[i] = ( bits[(size_t)i >> 5] >> ( i & 31 ) ) & 1u;
+  return RS_HIP_OK;
+}
+
+extern "C" int rs_hip_coverage_scores( rs_hip_coverage_t* c, const rs_hip_cloud_t* const* objects, const float* poses,
+                                       const int32_t* is_static, const int32_t* first_placement, int32_t n_arr,
+                                       float* scores, int32_t* agree )
+{
+  int rc = ensure_ready(); if( rc ) return rc;
+  if( !c || n_arr < 0 || !scores || ( n_arr > 0 && !first_placement ) ) { set_err( "coverage_scores: bad arguments" ); return RS_HIP_E_ARG; }
+  if( n_arr == 0 ) return RS_HIP_OK;
+  const int n_plc_all = first_placement[n_arr];
+  if( n_plc_all < 0 || ( n_plc_all > 0 && ( !objects || !poses || !is_static ) ) ) { set_err( "coverage_scores: bad placement lists" ); return RS_HIP_E_ARG; }
+  if( (double)n_arr * c->n_words * 4 > 8.0e9 ) { set_err( "coverage_scores: batch of %d arrangements needs more than 8 GB of voxel bitmaps", n_arr ); return RS_HIP_E_CAPACITY; }
+  std::vector<CoveragePlacement> h;
+  int max_pts = 0;
+  for( int a = 0; a < n_arr; ++a )
+  {
+    if( first_placement[a] > first_placement[a + 1] ) { set_err( "coverage_scores: first_placement must be non-decreasing" ); return RS_HIP_E_ARG; }
+    for( int k = first_placement[a]; k < first_placement[a + 1]; ++k )
+    {
+      if( is_static[k] ) continue;                              // :1095-1096
+      if( !objects[k] ) { set_err( "coverage_scores: placement %d has no object cloud", k ); return RS_HIP_E_ARG; }
+      CoveragePlacement p{};
+      p.pos = objects[k]->view.pos; p.n = objects[k]->n; p.arrangement = a;
+      std::memcpy( p.pose.m, poses + 16 * (size_t)k, 64 );
+      if( p.n > 0 ) { h.push_back( p ); max_pts = std::max( max_pts, p.n ); }
+    }
+  }
+  const size_t bits_bytes = (size_t)n_arr * c->n_words * 4;
+  if( ( rc = g_ws.cov_bits.ensure( bits_bytes ) ) || ( rc = g_ws.cov_agree.ensure( (size_t)n_arr * 4 ) ) ||
+      ( rc = g_ws.cov_plc.ensure( std::max<size_t>( 1, h.size() ) * sizeof(CoveragePlacement) ) ) ) return rc;
+  HIP_TRY( hipMemsetAsync( g_ws.cov_bits.p, 0, bits_bytes, g_stream ), RS_HIP_E_RUNTIME );      // :1090 memset
+  HIP_TRY( hipMemsetAsync( g_ws.cov_agree.p, 0, (size_t)n_arr * 4, g_stream ), RS_HIP_E_RUNTIME );
+  if( !h.empty() )
+  {
+    HIP_TRY( hipMemcpyAsync( g_ws.cov_plc.p, h.data(), h.size() * sizeof(CoveragePlacement), hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+    CoverageLaunch L{};
+    L.grid = c->grid; L.scene_bits = c->d_bits; L.arr_bits = g_ws.cov_bits.as<uint32_t>(); L.n_words = c->n_words;
+    L.plc = g_ws.cov_plc.as<CoveragePlacement>(); L.n_plc = (int)h.size(); L.max_pts = max_pts; L.agree = g_ws.cov_agree.as<int>();
+    { ProfScope ps( "coverage" ); launch_coverage( L, g_stream ); }
+  }
+  std::vector<int> cnt( (size_t)n_arr );
+  HIP_TRY( hipMemcpyAsync( cnt.data(), g_ws.cov_agree.p, (size_t)n_arr * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );      // also keeps `h` alive until the upload is done
+  for( int a = 0; a < n_arr; ++a )
+  {
+    float s = (float)cnt[a] / (float)c->valid;                   // :366
+    if( c->valid == 0 ) s = 0.0f;                                // :367
+    scores[a] = s;
+    if( agree ) agree[a] = cnt[a];
+  }
   return RS_HIP_OK;
 }

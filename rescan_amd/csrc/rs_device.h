@@ -140,6 +140,31 @@ struct RowsLaunch
 };
 void launch_rows( const RowsLaunch& L, hipStream_t st );
 
+// Scene-coverage term of the arrangement optimiser (apps/segment_transfer/arrangement_optimization.cpp:344-373,
+// 1064-1106 on the voxel grid of lib/rs/intersect.h:59-109): bitmaps instead of byte grids.
+struct VoxGrid { int x_res, y_res, z_res, n_cells; float ox, oy, oz, inv_voxel; };
+struct CoveragePlacement
+{
+  const float4* pos;     // object level cloud (any order)
+  int           n;
+  int           arrangement;
+  Xform         pose;
+};
+struct CoverageLaunch
+{
+  VoxGrid      grid;
+  const uint32_t* scene_bits;     // n_words
+  uint32_t*    arr_bits;          // n_arr x n_words, zero on entry
+  int          n_words;
+  const CoveragePlacement* plc;   // device array, non-static placements only
+  int          n_plc, max_pts;
+  int*         agree;             // n_arr, zero on entry
+};
+void launch_voxel_mark( const VoxGrid& g, const float* pos /* AoS xyz */, const float* quality /* or null */, float threshold,
+                        long long n, uint32_t* bits, hipStream_t st );
+void launch_popcount( const uint32_t* bits, int n_words, int* out /* zero on entry */, hipStream_t st );
+void launch_coverage( const CoverageLaunch& L, hipStream_t st );
+
 // Neighbourhood graph (rspf_compute_neighborhood): from self-search rows to unique weighted edges.
 struct EdgeLaunch
 {

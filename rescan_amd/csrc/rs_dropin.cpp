@@ -232,4 +232,31 @@ int64_t rsd_compute_neighborhood( const rsd_vec3_t* pos, const rsd_vec3_t* nor, 
   return n_edges;
 }
 
+void* rsd_coverage_create( const rsd_vec3_t* bbox_min, const rsd_vec3_t* bbox_max, float voxel_size,
+                           const rsd_vec3_t* scene_pos, const float* scene_quality, int32_t n_scene, float quality_threshold )
+{
+  rs_hip_coverage_t* c = rs_hip_coverage_create( (const float*)bbox_min, (const float*)bbox_max, voxel_size, (const float*)scene_pos,
+                                                 scene_quality, n_scene, quality_threshold );
+  if( !c ) complain( "coverage_create" );
+  return c;
+}
+
+float rsd_coverage_score( void* coverage, const rsd_vec3_t* const* obj_pos, const int32_t* obj_n,
+                          const rsd_mat4_t* poses, const int32_t* is_static, int32_t n_plc )
+{
+  std::vector<const rs_hip_cloud_t*> objs( (size_t)( n_plc > 0 ? n_plc : 0 ) );
+  for( int i = 0; i < n_plc; ++i )
+  {
+    objs[i] = is_static[i] ? nullptr : cached_cloud( obj_pos[i], nullptr, obj_n[i], -1.0f );
+    if( !is_static[i] && !objs[i] ) return -1.0f;
+  }
+  const int32_t first[2] = { 0, n_plc };
+  float score = 0.0f;
+  int rc = rs_hip_coverage_scores( (rs_hip_coverage_t*)coverage, objs.data(), (const float*)poses, is_static, first, 1, &score, nullptr );
+  if( rc ) { complain( "coverage_score" ); return -1.0f; }
+  return score;
+}
+
+void rsd_coverage_destroy( void* coverage ) { rs_hip_coverage_destroy( (rs_hip_coverage_t*)coverage ); }
+
 } // extern "C"

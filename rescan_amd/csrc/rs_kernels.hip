@@ -37,6 +37,7 @@
 #include "rs_math.h"
 #include <cfloat>
 #include <climits>
+#include <algorithm>
 
 // Per-tile timers and counters (RS_HIP_DEBUG_CYCLES) exist only in the diagnostic build
 // (tools/variant.sh dbg -DRS_DBG=1): in the production build DBG() is a constant null pointer and
@@ -1368,5 +1369,74 @@ void launch_edge_scan( const EdgeLaunch& L, hipStream_t st )
 { hipLaunchKernelGGL( k_edge_scan, dim3( 1 ), dim3( 1024 ), 0, st, L ); }
 void launch_edge_write( const EdgeLaunch& L, hipStream_t st )
 { hipLaunchKernelGGL( k_edge_write, dim3( ( L.n + BLOCK - 1 ) / BLOCK ), dim3( BLOCK ), 0, st, L ); }
+
+// ------------------------------------------------------------------------------------------
+// Scene-coverage term  (arrangement_optimization.cpp:344-373, 1064-1106; intersect.h:97-109)
+// One bit per voxel.  The scene bitmap is built once; an arrangement's score only needs the
+// scene-active voxels its points hit, so a point whose voxel is not scene-active is dropped at
+// once and the others race on atomicOr — the first to set a bit counts it.
+// ------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ int voxel_of( const VoxGrid& g, float x, float y, float z )
+{
+  const int cx = (int)floorf( ( x - g.ox ) * g.inv_voxel );     // intersect.h:101-103
+  const int cy = (int)floorf( ( y - g.oy ) * g.inv_voxel );
+  const int cz = (int)floorf( ( z - g.oz ) * g.inv_voxel );
+  if( cx < 0 || cx >= g.x_res || cy < 0 || cy >= g.y_res || cz < 0 || cz >= g.z_res ) return -1;
+  return cy * g.x_res * g.z_res + cz * g.x_res + cx;            // :108
+}
+
+__global__ __launch_bounds__( BLOCK ) void k_voxel_mark( VoxGrid g, const float* pos, const float* quality, float threshold, long long n, uint32_t* bits )
+{
+  const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if( i >= n ) return;
+  if( quality && quality[i] < threshold ) return;               // arrangement_optimization.cpp:1073-1074
+  const int c = voxel_of( g, pos[3*i], pos[3*i+1], pos[3*i+2] );
+  if( c >= 0 ) atomicOr( bits + ( c >> 5 ), 1u << ( c & 31 ) );
+}
+
+__global__ __launch_bounds__( BLOCK ) void k_popcount( const uint32_t* bits, int n_words, int* out )
+{
+  int c = 0;
+  for( int w = blockIdx.x * BLOCK + threadIdx.x; w < n_words; w += gridDim.x * BLOCK ) c += __popc( bits[w] );
+  for( int o = WAVE / 2; o > 0; o >>= 1 ) c += __shfl_down( c, o );
+  if( ( threadIdx.x & ( WAVE - 1 ) ) == 0 && c ) atomicAdd( out, c );
+}
+
+__global__ __launch_bounds__( BLOCK ) void k_coverage( CoverageLaunch L )
+{
+  const CoveragePlacement& P = L.plc[blockIdx.y];
+  int hit = 0;
+  const uint32_t* scene = L.scene_bits;
+  uint32_t* mine = L.arr_bits + (size_t)P.arrangement * L.n_words;
+  for( int i = blockIdx.x * BLOCK + threadIdx.x; i < P.n; i += gridDim.x * BLOCK )
+  {
+    const float4 p = P.pos[i];
+    float x, y, z;
+    xform3( P.pose, p.x, p.y, p.z, 1.0f, x, y, z );            // msh_mat4_vec3_mul( pose, p, 1 ), :1101
+    const int c = voxel_of( L.grid, x, y, z );
+    if( c < 0 ) continue;
+    const uint32_t m = 1u << ( c & 31 );
+    if( !( scene[c >> 5] & m ) ) continue;                      // only cells with scn_cell > 0 can agree (:363)
+    if( !( atomicOr( mine + ( c >> 5 ), m ) & m ) ) ++hit;
+  }
+  for( int o = WAVE / 2; o > 0; o >>= 1 ) hit += __shfl_down( hit, o );
+  if( ( threadIdx.x & ( WAVE - 1 ) ) == 0 && hit ) atomicAdd( L.agree + P.arrangement, hit );
+}
+
+void launch_voxel_mark( const VoxGrid& g, const float* pos, const float* quality, float threshold, long long n, uint32_t* bits, hipStream_t st )
+{
+  if( n > 0 ) hipLaunchKernelGGL( k_voxel_mark, dim3( (unsigned)( ( n + BLOCK - 1 ) / BLOCK ) ), dim3( BLOCK ), 0, st, g, pos, quality, threshold, n, bits );
+}
+void launch_popcount( const uint32_t* bits, int n_words, int* out, hipStream_t st )
+{
+  hipLaunchKernelGGL( k_popcount, dim3( std::max( 1, std::min( 256, ( n_words + BLOCK - 1 ) / BLOCK ) ) ), dim3( BLOCK ), 0, st, bits, n_words, out );
+}
+void launch_coverage( const CoverageLaunch& L, hipStream_t st )
+{
+  if( L.n_plc <= 0 || L.max_pts <= 0 ) return;
+  const int bx = std::max( 1, std::min( 64, ( L.max_pts + BLOCK - 1 ) / BLOCK ) );
+  hipLaunchKernelGGL( k_coverage, dim3( bx, L.n_plc ), dim3( BLOCK ), 0, st, L );
+}
 
 } // namespace rs

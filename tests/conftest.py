@@ -72,3 +72,15 @@ def rows_equal_up_to_ties(d_a, i_a, nn_a, d_b, i_b, nn_b):
                 tie = (c > 0 and d_a[r, c] == d_a[r, c - 1]) or (c + 1 < n and d_a[r, c] == d_a[r, c + 1])
                 assert tie, f"row {r} col {c}: index differs without a distance tie"
     return int(diff.sum())
+
+
+def coverage_case(gscene):
+    """Inputs of tests/golden/coverage.npz: (fixture dict, object point lists incl. the static wall, class ids, per-arrangement placements)."""
+    d = load_golden("coverage.npz")
+    objs = [o["pos"] for o in gscene["objects"]] + [d["wall"]]
+    static = [0] * len(gscene["objects"]) + [1]
+    arrangements = []
+    for a in range(len(d["arr_first"]) - 1):
+        ks = range(int(d["arr_first"][a]), int(d["arr_first"][a + 1]))
+        arrangements.append([(int(d["arr_obj"][k]), d["arr_pose"][k]) for k in ks])
+    return d, objs, static, arrangements

@@ -142,3 +142,28 @@ def test_neighborhood_by_flat_entry(dropin, gscene):
     assert m == len(d["idx1"])
     key = lambda x, y: np.sort(np.maximum(x, y).astype(np.int64) * n + np.minimum(x, y))
     assert (key(a[:m], b[:m]) == key(d["idx1"], d["idx2"])).all()
+
+
+@pytest.mark.gpu
+def test_coverage_by_flat_entry(dropin, gscene):
+    from conftest import coverage_case
+    d, objs, static, arrangements = coverage_case(gscene)
+    dropin.rsd_coverage_create.restype = C.c_void_p
+    dropin.rsd_coverage_create.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int32, C.c_float]
+    dropin.rsd_coverage_score.restype = C.c_float
+    dropin.rsd_coverage_score.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+    dropin.rsd_coverage_destroy.argtypes = [C.c_void_p]
+    bmin, bmax = np.ascontiguousarray(d["bbox_min"], np.float32), np.ascontiguousarray(d["bbox_max"], np.float32)
+    pts, q = gscene["points"], np.ascontiguousarray(d["quality"], np.float32)
+    h = dropin.rsd_coverage_create(bmin.ctypes.data, bmax.ctypes.data, 0.05, pts.ctypes.data, q.ctypes.data, len(pts), 0.5)
+    assert h
+    keep = [np.ascontiguousarray(o, np.float32) for o in objs]
+    for a in (0, 7, 23):
+        plc = arrangements[a]
+        ptrs = (C.c_void_p * len(plc))(*[keep[k].ctypes.data for k, _ in plc])
+        ns = np.array([len(keep[k]) for k, _ in plc], np.int32)
+        poses = np.ascontiguousarray(np.array([p for _, p in plc], np.float32))
+        st = np.array([static[k] for k, _ in plc], np.int32)
+        s = dropin.rsd_coverage_score(h, C.addressof(ptrs), ns.ctypes.data, poses.ctypes.data, st.ctypes.data, len(plc))
+        assert np.float32(s) == d["scores"][a]
+    dropin.rsd_coverage_destroy(h)

@@ -255,6 +255,49 @@ def test_neighborhood_exponents_and_large(capi, oracle):
     _weights_match(wg[pos], wwt)
 
 
+# ---- scene-coverage term --------------------------------------------------
+
+def test_coverage_vs_golden(capi, gscene):
+    from conftest import coverage_case
+    d, objs, static, arrangements = coverage_case(gscene)
+    cov = capi.Coverage(d["bbox_min"], d["bbox_max"], gscene["points"], d["quality"], 0.05, 0.5)
+    assert tuple(cov.res) == tuple(d["res"]) and cov.n_cells == int(d["n_cells"]) and (cov.origin == d["origin"]).all()
+    want_grid = np.unpackbits(d["scene_grid"])[:cov.n_cells]
+    assert (cov.scene_grid() == want_grid).all() and cov.valid_cells == int(want_grid.sum())
+    clouds = [capi.Cloud(p, np.zeros_like(p)) for p in objs]
+    batch = [[(clouds[k], pose, static[k]) for k, pose in plc] for plc in arrangements]
+    sc, agree = cov.scores(batch)                      # all 24 arrangements in one launch
+    assert (sc == d["scores"]).all()
+    one, _ = cov.scores(batch[5:6])                    # and one at a time, as the SA loop calls it
+    assert one[0] == d["scores"][5]
+
+
+def test_coverage_edge_cases(capi, oracle):
+    from rescan_amd import synth
+    s = synth.make_scene(seed=31, density=900, timestep=0)
+    pts = s["points"]
+    bmin, bmax = pts.min(0), pts.max(0)
+    rng = np.random.default_rng(2)
+    cov = capi.Coverage(bmin, bmax, pts, None, 0.07)
+    g = oracle.voxgrid(bmin, bmax, 0.07)
+    sd = oracle.rasterize_scene(g, pts)
+    assert (cov.scene_grid() == sd).all()
+    clouds = [capi.Cloud(o["pos"], o["nor"]) for o in s["objects"]]
+    arrs, want = [], []
+    for a in range(10):
+        poses = [synth.perturbed_pose(o["pose"], rng, 1.5 if a % 2 else 0.1, 0.3) for o in s["objects"]]     # far moves push points out of the grid
+        stat = [int(rng.uniform() < 0.3) for _ in s["objects"]]
+        arrs.append([(clouds[k], poses[k], stat[k]) for k in range(len(clouds))])
+        ad = oracle.rasterize_arrangement(g, [o["pos"] for o in s["objects"]], poses, stat)
+        want.append(oracle.coverage_score(sd, ad))
+    arrs.append([]); want.append((np.float32(0), 0, int(sd.sum())))                                           # empty arrangement
+    sc, agree = cov.scores(arrs)
+    assert (sc == np.array([w[0] for w in want], np.float32)).all() and (agree == [w[1] for w in want]).all()
+    # a scene with no point above the quality threshold: empty grid, score 0 (not NaN)
+    empty = capi.Coverage(bmin, bmax, pts, np.zeros(len(pts), np.float32), 0.07)
+    assert empty.valid_cells == 0 and (empty.scores(arrs[:2])[0] == 0).all()
+
+
 # ---- fresh seeded inputs against the oracle (sizes the oracle finishes in seconds) --------
 
 def test_seeded_scene_vs_oracle(capi, oracle):

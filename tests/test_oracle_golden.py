@@ -3,7 +3,7 @@ compiled reference (oracle/gen_golden.py -> tests/golden/).  Everything here is 
 import numpy as np
 import pytest
 
-from conftest import golden_files, label_case, load_golden
+from conftest import coverage_case, golden_files, label_case, load_golden
 
 I4 = np.eye(4, dtype=np.float32).ravel()
 
@@ -123,3 +123,21 @@ def test_neighborhood_semantics(oracle, gscene):
     assert (d2 < 0.0025 * 1.0001).all()
     assert (w >= 0).all() and (w <= 1).all()
     assert np.bincount(a, minlength=n).max() <= 8
+
+
+def test_coverage(oracle, gscene):
+    """Scene-coverage term: restatement vs the values the reference TU produced (coverage.npz)."""
+    from conftest import coverage_case
+    d, objs, static, arrangements = coverage_case(gscene)
+    g = oracle.voxgrid(d["bbox_min"], d["bbox_max"])
+    assert (g.x_res, g.y_res, g.z_res) == tuple(d["res"]) and g.n_cells == int(d["n_cells"])
+    assert (np.array(list(g.origin), np.float32) == d["origin"]).all()
+    sd = oracle.rasterize_scene(g, gscene["points"], d["quality"], 0.5)
+    assert (sd == np.unpackbits(d["scene_grid"])[:g.n_cells]).all()
+    for a, plc in enumerate(arrangements):
+        ad = oracle.rasterize_arrangement(g, [objs[k] for k, _ in plc], [p for _, p in plc], [static[k] for k, _ in plc])
+        s, agree, valid = oracle.coverage_score(sd, ad)
+        assert s == d["scores"][a]
+    # empty scene grid -> score 0, no NaN (:367)
+    s, agree, valid = oracle.coverage_score(np.zeros(g.n_cells, np.uint8), ad)
+    assert s == 0 and valid == 0

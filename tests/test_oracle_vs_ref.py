@@ -158,3 +158,27 @@ def test_edge_cost(oracle, ref):
         for _ in range(300):
             d2, dot = np.float32(rng.uniform(0, 0.0026)), np.float32(rng.uniform(0, 1))
             assert oracle.edge_cost(d2, dot, 0.0025, de, ae) == ref.edge_cost(d2, dot, 0.0025, de, ae)
+
+
+def test_coverage_vs_reference(oracle, scene):
+    """Fresh inputs through the reference's arrangement_optimization.cpp (oracle/_ref/libref_ao.so)."""
+    from oracle.pyoracle import RefAO
+    from rescan_amd import synth
+    if not RefAO.available():
+        pytest.skip("oracle/_ref/libref_ao.so not built")
+    pts = scene["points"]
+    rng = np.random.default_rng(4)
+    bmin, bmax = pts.min(0), pts.max(0)
+    for voxel in (0.05, 0.08):
+        R = RefAO(synth.CLASS_IDX, pts, bmin, bmax, voxel_size=voxel)
+        g = oracle.voxgrid(bmin, bmax, voxel)
+        assert (g.x_res, g.y_res, g.z_res) == tuple(R.res) and (np.array(list(g.origin), np.float32) == R.origin).all()
+        sd = oracle.rasterize_scene(g, pts)
+        assert (sd == R.scene_grid()).all()
+        idx = [R.add_object(o["pos"], o["class_idx"], o["uidx"]) for o in scene["objects"]]
+        for _ in range(6):
+            poses = [synth.perturbed_pose(o["pose"], rng, 0.3, 0.2) for o in scene["objects"]]     # some points leave the grid
+            want = R.coverage(idx, poses)
+            ad = oracle.rasterize_arrangement(g, [o["pos"] for o in scene["objects"]], poses, [0] * len(idx))
+            assert (ad == R.arrangement_grid()).all()
+            assert oracle.coverage_score(sd, ad)[0] == want
