@@ -110,6 +110,23 @@ float rsd_coverage_score( void* coverage, const rsd_vec3_t* const* obj_pos, cons
                           const rsd_mat4_t* poses, const int32_t* is_static, int32_t n_plc );
 void  rsd_coverage_destroy( void* coverage );
 
+/* ---- the on-disk formats either side of the path ---------------------------------
+ * Pose-proposal blob (writer apps/pose_proposal/main.cpp:61-89, reader apps/segment_transfer/main.cpp:143-193):
+ * int32 n_arrays; int32 count[n_arrays]; then per proposal 16 floats (column-major pose) + 1 float score,
+ * arrays back to back, host byte order.  `records` holds sum(count) x 17 floats.  The reader allocates
+ * *counts and *records with malloc (caller frees); like the reference's, it accepts a truncated file only
+ * up to the last complete array and reports the failure (RSD_FORMAT_ERR). */
+#define RSD_FORMAT_ERR (-20)
+int rsd_pose_bin_write( const char* path, int32_t n_arrays, const int32_t* counts, const float* records );
+int rsd_pose_bin_read( const char* path, int32_t* n_arrays, int32_t** counts, float** records );
+/* One `pose` line of an .rsdb database (lib/rs/rs_database.h:379-401 parser, :597-606 writer): the 4x4 pose
+ * is printed row by row with "%f", i.e. rounded to 6 decimals — poses lose precision between pose_proposal and
+ * segment_transfer, and that is reference behaviour.  format returns the length written (no newline). */
+int rsd_rsdb_format_pose_line( char* out, size_t capacity, int32_t uidx, int32_t arrangement_idx, int32_t object_idx,
+                               float score, const rsd_mat4_t* pose );
+int rsd_rsdb_parse_pose_line( const char* line, int32_t* uidx, int32_t* arrangement_idx, int32_t* object_idx,
+                              float* score, rsd_mat4_t* pose );
+
 /* Drop every cached device cloud (the shim caches uploads by host pointer + content hash). */
 void  rsd_cache_clear( void );
 

@@ -259,4 +259,67 @@ float rsd_coverage_score( void* coverage, const rsd_vec3_t* const* obj_pos, cons
 
 void rsd_coverage_destroy( void* coverage ) { rs_hip_coverage_destroy( (rs_hip_coverage_t*)coverage ); }
 
+// ---- on-disk formats -------------------------------------------------------------------------
+
+int rsd_pose_bin_write( const char* path, int32_t n_arrays, const int32_t* counts, const float* records )
+{
+  if( !path || n_arrays < 0 || ( n_arrays > 0 && !counts ) ) return RS_HIP_E_ARG;
+  FILE* fp = fopen( path, "wb" );
+  if( !fp ) { fprintf( stderr, "[rescan_hip] could not open %s\n", path ); return RSD_FORMAT_ERR; }
+  size_t total = 0;
+  bool ok = fwrite( &n_arrays, sizeof(int32_t), 1, fp ) == 1;                         // main.cpp:69-70
+  for( int32_t i = 0; ok && i < n_arrays; ++i ) { ok = counts[i] >= 0 && fwrite( &counts[i], sizeof(int32_t), 1, fp ) == 1; total += (size_t)counts[i]; }   // :71-75
+  if( ok && total ) ok = records && fwrite( records, 17 * sizeof(float), total, fp ) == total;   // :77-87: 16 floats + score, arrays in order
+  fclose( fp );
+  return ok ? 0 : RSD_FORMAT_ERR;
+}
+
+int rsd_pose_bin_read( const char* path, int32_t* n_arrays, int32_t** counts, float** records )
+{
+  if( !path || !n_arrays || !counts || !records ) return RS_HIP_E_ARG;
+  *n_arrays = 0; *counts = nullptr; *records = nullptr;
+  FILE* fp = fopen( path, "rb" );
+  if( !fp ) return RSD_FORMAT_ERR;
+  int32_t n = -1;
+  if( fread( &n, sizeof(int32_t), 1, fp ) != 1 || n < 0 ) { fclose( fp ); return RSD_FORMAT_ERR; }     // segment_transfer/main.cpp:154-155
+  int32_t* cnt = (int32_t*)malloc( (size_t)( n > 0 ? n : 1 ) * sizeof(int32_t) );
+  size_t total = 0;
+  for( int32_t i = 0; i < n; ++i )
+  {
+    if( fread( &cnt[i], sizeof(int32_t), 1, fp ) != 1 || cnt[i] < 0 ) { free( cnt ); fclose( fp ); return RSD_FORMAT_ERR; }   // :157-163
+    total += (size_t)cnt[i];
+  }
+  float* rec = (float*)malloc( ( total ? total : 1 ) * 17 * sizeof(float) );
+  const size_t got = total ? fread( rec, 17 * sizeof(float), total, fp ) : 0;                             // :175-176
+  fclose( fp );
+  if( got != total ) { free( cnt ); free( rec ); return RSD_FORMAT_ERR; }
+  *n_arrays = n; *counts = cnt; *records = rec;
+  return 0;
+}
+
+int rsd_rsdb_format_pose_line( char* out, size_t capacity, int32_t uidx, int32_t arrangement_idx, int32_t object_idx,
+                               float score, const rsd_mat4_t* pose )
+{
+  if( !out || !pose ) return RS_HIP_E_ARG;
+  const float* m = pose->data;   // column-major: col[c].{x,y,z,w} = m[4c + {0,1,2,3}]; printed row by row (rs_database.h:599-605)
+  int len = snprintf( out, capacity, "pose %d %d %d %f   %f %f %f %f  %f %f %f %f  %f %f %f %f  %f %f %f %f",
+                      uidx, arrangement_idx, object_idx, score,
+                      m[0], m[4], m[8], m[12],  m[1], m[5], m[9], m[13],  m[2], m[6], m[10], m[14],  m[3], m[7], m[11], m[15] );
+  return ( len < 0 || (size_t)len >= capacity ) ? RSD_FORMAT_ERR : len;
+}
+
+int rsd_rsdb_parse_pose_line( const char* line, int32_t* uidx, int32_t* arrangement_idx, int32_t* object_idx,
+                              float* score, rsd_mat4_t* pose )
+{
+  if( !line || !uidx || !arrangement_idx || !object_idx || !score || !pose ) return RS_HIP_E_ARG;
+  char cmd[128] = { 0 };
+  float* m = pose->data;
+  for( int i = 0; i < 16; ++i ) m[i] = ( i % 5 == 0 ) ? 1.0f : 0.0f;       // msh_mat4_identity(), rs_database.h:386
+  *uidx = *arrangement_idx = *object_idx = -1; *score = 0.0f;
+  const int got = sscanf( line, "%127s  %d %d %d %f  %f %f %f %f  %f %f %f %f  %f %f %f %f  %f %f %f %f",   // :387-393
+                          cmd, uidx, arrangement_idx, object_idx, score,
+                          &m[0], &m[4], &m[8], &m[12],  &m[1], &m[5], &m[9], &m[13],  &m[2], &m[6], &m[10], &m[14],  &m[3], &m[7], &m[11], &m[15] );
+  return got == 21 ? 0 : RSD_FORMAT_ERR;
+}
+
 } // extern "C"
