@@ -313,19 +313,31 @@ __device__ __forceinline__ void dist2x4( const float4& X, const float4& Y, const
 // dist² < bound, where bound = radius² until a match exists and then the float just above the
 // match's dist² (so "<= best" including ties, which the last branch settles by index);
 // inactive lanes carry bound = -1.  seen_closer counts the candidates that passed it (against the
-// bound at the start of the group: looser than one by one, still an upper bound of the rank).
+// bound at the start of the group: looser than one by one, still an upper bound of the rank); with SELF
+// the lane's current match is not counted when it meets itself (whatever precedes the final match
+// preceded every earlier best too, so the count still bounds the rank from above).
 // Three levels: (1) distances only — most groups end here; (2) some lane has a candidate inside its
 // bound (lanes without a match see that for everything within the radius): the gate of all four,
 // packed like the distances; (3) a candidate passed both: settle it one by one.
-template <bool GATED>
+template <bool GATED, bool SELF>
 __device__ __forceinline__ void consider4( const float4& X, const float4& Y, const float4& Z, int k, const WaveLds& L,
                                            float qx, float qy, float qz, float nx, float ny, float nz,
                                            float tmin, float tmin_loose, float& bound, Match& m, int& seen_closer )
 {
   float d[4];
   dist2x4( X, Y, Z, qx, qy, qz, d[0], d[1], d[2], d[3] );
-  const bool in0 = d[0] < bound, in1 = d[1] < bound, in2 = d[2] < bound, in3 = d[3] < bound;
+  bool in0 = d[0] < bound, in1 = d[1] < bound, in2 = d[2] < bound, in3 = d[3] < bound;
   if( !__any( in0 | in1 | in2 | in3 ) ) return;
+  int4 I = make_int4( 0, 0, 0, 0 );
+  if( SELF )
+  {
+    // searches seeded with a starting candidate (ICP iterations >= 2): a lane's match meets itself in the
+    // stream exactly once (d == its dist² < bound) — that is most of what gets here once the bounds are
+    // tight, and it is no news
+    I = *reinterpret_cast<const int4*>( &L.pidx[k] );
+    in0 &= I.x != m.idx; in1 &= I.y != m.idx; in2 &= I.z != m.idx; in3 &= I.w != m.idx;
+    if( !__any( in0 | in1 | in2 | in3 ) ) return;
+  }
   seen_closer += ( in0 ? 1 : 0 ) + ( in1 ? 1 : 0 ) + ( in2 ? 1 : 0 ) + ( in3 ? 1 : 0 );
   float dc[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
   bool p0 = in0, p1 = in1, p2 = in2, p3 = in3;
@@ -351,7 +363,7 @@ __device__ __forceinline__ void consider4( const float4& X, const float4& Y, con
     {
       if( __any( pass[i] ) )
       {
-        const int idx = L.pidx[k + i];
+        const int idx = SELF ? ( i == 0 ? I.x : i == 1 ? I.y : i == 2 ? I.z : I.w ) : L.pidx[k + i];
         const bool take = pass[i] & ( d[i] < bound ) & lex_less( d[i], idx, m.d2, m.idx );   // the bound may have tightened within the group
         if( take )
         {
@@ -428,7 +440,7 @@ __device__ __forceinline__ CellBox box_clip( const CellBox& a, const CellBox& c 
 // queues the tile for the cooperative kernel, which sweeps the whole box with several waves
 // (a lone wave needs ~0.7 ms for the ~10^4 candidates of a cluttered corner; the bulk of the
 // tiles settle in the first shell with a few hundred).
-template <bool GATED>
+template <bool GATED, bool WARM = false>
 __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
                                               float qx, float qy, float qz, float nx, float ny, float nz,
                                               float radius, float radius_sq, float tmin, float tmin_loose, int K,
@@ -452,7 +464,7 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
   bool have_prev = false;
   uint32_t streamed = 0;
   const bool grid = g.inv_cell > 0.0f;
-  if( grid && !__any( active & !m.found ) )
+  if( WARM && grid && !__any( active & !m.found ) )
   {
     // Every lane starts from a genuine candidate (ICP iterations >= 2): whatever can beat or precede it
     // lies within its distance, so ONE sweep of the cells those small boxes touch settles the tile —
@@ -460,7 +472,7 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
     cur = reach_box( g, full, active, reach_of( m, radius ), qx, qy, qz );
     if( !box_empty( cur ) )
       streamed += sweep_shell<GATED>( g, cur, cur, false, L, lane, 0, 1, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
-      { consider4<GATED>( X, Y, Z, k4, L, qx, qy, qz, nx, ny, nz, tmin, tmin_loose, bound, m, seen_closer ); } );
+      { consider4<GATED, WARM>( X, Y, Z, k4, L, qx, qy, qz, nx, ny, nz, tmin, tmin_loose, bound, m, seen_closer ); } );
     if( dbg_unsettled ) { dbg_unsettled[1] = (int)streamed; dbg_unsettled[3] = 1; }
     sweeps = 1;
   }
@@ -478,7 +490,7 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
     const CellBox out = grid ? reach_box( g, cur, unsettled, reach_of( m, radius ), qx, qy, qz ) : full;
     if( !box_empty( out ) )
       streamed += sweep_shell<GATED>( g, out, prev, have_prev, L, lane, 0, 1, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
-      { consider4<GATED>( X, Y, Z, k4, L, qx, qy, qz, nx, ny, nz, tmin, tmin_loose, bound, m, seen_closer ); } );
+      { consider4<GATED, WARM>( X, Y, Z, k4, L, qx, qy, qz, nx, ny, nz, tmin, tmin_loose, bound, m, seen_closer ); } );
     if( dbg_unsettled ) dbg_unsettled[1] = (int)streamed;
     ++sweeps;
     if( n_sweeps ) *n_sweeps = sweeps;
@@ -507,9 +519,10 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
   {
     // Every candidate that precedes the final match was counted in seen_closer (it was no
     // farther than the then-best, which the final match precedes or equals), and so was the
-    // match itself: seen_closer - 1 >= rank.  Only when that bound does not settle rank < K,
+    // match itself: seen_closer - 1 >= rank (WARM: a starting candidate does not count itself, so
+    // only seen_closer >= rank holds).  Only when that bound does not settle rank < K,
     // count exactly (every such candidate lies inside `cur`: it is closer than the match).
-    bool need_rank = m.found && ( seen_closer - 1 >= K );
+    bool need_rank = m.found && ( seen_closer - ( WARM ? 0 : 1 ) >= K );
     if( __any( need_rank ) )
     {
       int rank = 0;
@@ -543,7 +556,7 @@ struct CoopLds
 // wave holds the same queries and sweeps its share of each shell's chunks; after every shell the
 // per-lane bests are merged through LDS, so all waves take the same continue/stop decision and
 // carry the tightest bound into the next shell.
-template <bool GATED, int NW>
+template <bool GATED, int NW, bool WARM = false>
 __device__ __forceinline__ Match coop_search( const GridView& g, bool active,
                                               float qx, float qy, float qz, float nx, float ny, float nz,
                                               float radius, float radius_sq, float tmin, float tmin_loose, int K,
@@ -578,7 +591,7 @@ __device__ __forceinline__ Match coop_search( const GridView& g, bool active,
     const CellBox out = ( g.inv_cell > 0.0f ) ? reach_box( g, cur, unsettled, reach_of( m, radius ), qx, qy, qz ) : full;
     if( !box_empty( out ) )
     streamed += sweep_shell<GATED>( g, out, prev, have_prev, L, lane, wib, NW, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
-    { consider4<GATED>( X, Y, Z, k4, L, qx, qy, qz, nx, ny, nz, tmin, tmin_loose, bound, m, seen_closer ); } );
+    { consider4<GATED, WARM>( X, Y, Z, k4, L, qx, qy, qz, nx, ny, nz, tmin, tmin_loose, bound, m, seen_closer ); } );
     if( dbg_t && dbg_k < 7 ) dbg_t[dbg_k++] = wall_clock64();
     // merge the per-lane bests of the waves; every wave continues with the merged best
     C.m_d2[wib][lane] = m.d2; C.m_idx[wib][lane] = m.idx; C.m_dot[wib][lane] = m.dot; C.m_slot[wib][lane] = m.found ? m.slot : -1;
@@ -607,7 +620,7 @@ __device__ __forceinline__ Match coop_search( const GridView& g, bool active,
     int seen_total = 0;
 #pragma unroll
     for( int w = 0; w < NW; ++w ) { seen_total += C.m_cnt[w][lane]; m.loose |= C.m_loose[w][lane] != 0; }
-    bool need_rank = m.found && ( seen_total - 1 >= K );
+    bool need_rank = m.found && ( seen_total - ( WARM ? 0 : 1 ) >= K );
     if( __any( need_rank ) )
     {
       int rank = 0;
@@ -777,7 +790,7 @@ __global__ __launch_bounds__( BLOCK, RS_ICP_OCC ) void k_icp_corr( IcpLaunch L )
   int unsettled[4] = { 0, 0, 0, 0 };
   const bool search = active & !icp_certificate( L, prob, i, active, qx, qy, qz, nx, ny, nz );
   const Match init = icp_warm_start( L, prob, i, search, qx, qy, qz, nx, ny, nz );
-  Match m = tile_search<true>( L.tgt, search, qx, qy, qz, nx, ny, nz, L.radius, L.radius_sq, L.gate_tmin, L.gate_tmin - L.cert_mu, L.K,
+  Match m = tile_search<true, true>( L.tgt, search, qx, qy, qz, nx, ny, nz, L.radius, L.radius_sq, L.gate_tmin, L.gate_tmin - L.cert_mu, L.K,
                                lds[wib], lane, L.solo_stages, &handoff, DBG( L ) ? unsettled : nullptr, init, &sweeps );
   if( L.heavy_out && lane == 0 )
   {
@@ -875,7 +888,7 @@ __global__ __launch_bounds__( NW * WAVE ) void k_icp_corr_coop( IcpLaunch L )
     const bool search = active & !icp_certificate( L, prob, i, active, qx, qy, qz, nx, ny, nz );
     const Match init = icp_warm_start( L, prob, i, search, qx, qy, qz, nx, ny, nz );
     uint32_t streamed = 0;
-    Match m = coop_search<true, NW>( L.tgt, search, qx, qy, qz, nx, ny, nz, L.radius, L.radius_sq, L.gate_tmin, L.gate_tmin - L.cert_mu, L.K,
+    Match m = coop_search<true, NW, true>( L.tgt, search, qx, qy, qz, nx, ny, nz, L.radius, L.radius_sq, L.gate_tmin, L.gate_tmin - L.cert_mu, L.K,
                                  lds[wib], coop, wib, lane, init, DBG( L ) ? &streamed : nullptr, DBG( L ) ? stamps : nullptr );
     if( DBG( L ) && wib == 0 )
     {
