@@ -111,28 +111,51 @@ thread_local Workspace g_ws;
 // ---- profiling ---------------------------------------------------------------------------
 bool g_prof = false;
 std::mutex g_prof_mutex;
-struct ProfEntry { std::vector<hipEvent_t> ev; int64_t launches = 0; double ms = 0.0; size_t pending = 0; };
+struct ProfEntry { std::vector<std::pair<hipEvent_t, hipEvent_t>> spans; int64_t launches = 0; double ms = 0.0; };
 std::map<std::string, ProfEntry> g_profmap;
+std::vector<hipEvent_t> g_evpool;      // events are handed out in order and recycled by prof_collect
+size_t g_evnext = 0;
+
+// one event recorded on the calling thread's stream (null if profiling is off or events ran out)
+hipEvent_t prof_event()
+{
+  hipEvent_t ev = nullptr;
+  {
+    std::lock_guard<std::mutex> lock( g_prof_mutex );
+    if( g_evnext == g_evpool.size() ) { hipEvent_t x; if( hipEventCreate( &x ) != hipSuccess ) return nullptr; g_evpool.push_back( x ); }
+    ev = g_evpool[g_evnext++];
+  }
+  (void)hipEventRecord( ev, g_stream );
+  return ev;
+}
+void prof_span( const char* name, hipEvent_t a, hipEvent_t b )
+{
+  if( !a || !b ) return;
+  std::lock_guard<std::mutex> lock( g_prof_mutex );
+  g_profmap[name].spans.emplace_back( a, b );
+}
 
 struct ProfScope
 {
-  ProfEntry* e = nullptr; size_t at = 0;
-  ProfScope( const char* name )
+  const char* name; hipEvent_t start = nullptr;
+  ProfScope( const char* n ) : name( n ) { if( g_prof ) start = prof_event(); }
+  ~ProfScope() { if( start ) prof_span( name, start, prof_event() ); }
+};
+
+// Consecutive segments of one stream sharing their boundary events: one event per boundary instead of
+// two (an event between two dependent launches costs a few microseconds of their back-to-back dispatch,
+// which matters for the ICP loop's chain of short kernels).
+struct ProfChain
+{
+  const char* cur = nullptr; hipEvent_t at = nullptr;
+  void mark( const char* name )
   {
     if( !g_prof ) return;
-    std::lock_guard<std::mutex> lock( g_prof_mutex );
-    e = &g_profmap[name];
-    at = e->pending;
-    e->pending = at + 2;                 // reserve the pair now: other threads may open scopes meanwhile
-    while( e->ev.size() < at + 2 ) { hipEvent_t x; if( hipEventCreate( &x ) != hipSuccess ) { e = nullptr; return; } e->ev.push_back( x ); }
-    (void)hipEventRecord( e->ev[at], g_stream );
+    hipEvent_t ev = prof_event();
+    if( cur ) prof_span( cur, at, ev );
+    cur = name; at = ev;
   }
-  ~ProfScope()
-  {
-    if( !e ) return;
-    std::lock_guard<std::mutex> lock( g_prof_mutex );
-    (void)hipEventRecord( e->ev[at + 1], g_stream );
-  }
+  ~ProfChain() { if( cur ) mark( nullptr ); }
 };
 
 void prof_collect()
@@ -141,14 +164,15 @@ void prof_collect()
   for( auto& kv : g_profmap )
   {
     ProfEntry& e = kv.second;
-    for( size_t i = 0; i + 1 < e.pending; i += 2 )
+    for( auto& sp : e.spans )
     {
       float ms = 0.0f;
-      (void)hipEventSynchronize( e.ev[i + 1] );
-      if( hipEventElapsedTime( &ms, e.ev[i], e.ev[i + 1] ) == hipSuccess ) { e.ms += ms; e.launches++; }
+      (void)hipEventSynchronize( sp.second );
+      if( hipEventElapsedTime( &ms, sp.first, sp.second ) == hipSuccess ) { e.ms += ms; e.launches++; }
     }
-    e.pending = 0;
+    e.spans.clear();
   }
+  g_evnext = 0;
 }
 
 } // namespace
@@ -705,6 +729,7 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
   const int* hActive = (const int*)( hS + np * 16 );
   const bool small = (long long)cx.n_waves * n < 2400;      // the cooperative queue is short from the start
   cx.L.solve = 1; cx.L.fixed_iters = fixed_iters ? 1 : 0;
+  ProfChain prof;
   for( int i = 0; i < max_iter; )                                       // icp.h:444
   {
     const int chunk = debug ? 1 : ( fixed_iters ? max_iter - i : std::min( std::max( 1, chunk_env ), max_iter - i ) );
@@ -722,12 +747,13 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
         cx.L.heavy_out = ( i & 1 ) ? g_ws.order_b.as<int>() : g_ws.order_a.as<int>();
       }
       if( debug ) icp_debug_before( cx, n );
-      { ProfScope ps( "nn_icp" ); launch_icp_corr( cx.L, g_stream ); }
+      prof.mark( "nn_icp" ); launch_icp_corr( cx.L, g_stream );
       if( debug ) icp_debug_after( cx, source->n, n, i, max_dist );
-      { ProfScope ps( "icp_moments" ); launch_icp_moments( cx.L, g_stream ); }
+      prof.mark( "icp_moments" ); launch_icp_moments( cx.L, g_stream );
       double nd = max_dist * 0.95;                                      // icp.h:493
       max_dist = (float)( nd > 0.05 ? nd : 0.05 );
     }
+    prof.mark( nullptr );
     HIP_TRY( hipMemcpyAsync( hS, g_ws.state.p, state_bytes, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
     HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
     int n_active = 0;
