@@ -575,7 +575,7 @@ int icp_prepare( IcpCtx& cx, const rs_hip_cloud_t* src, const rs_hip_cloud_t* tg
   L.T1 = w; L.active = (int*)( w + np * 16 ); L.T1_prev = w + np * 17;
   L.iters = (int*)( w + np * 33 ); L.err = w + np * 34; L.prev_err = w + np * 35; L.queued = (int*)( w + np * 36 ); L.ticket = (int*)( w + np * 37 );
   L.solve = 0; L.iter_index = 0; L.fixed_iters = 0;
-  L.cert_r = nullptr; L.cert_dot = nullptr; L.cert_mu = 0.0f; L.tgt_nor_max = tgt->nor_max;
+  L.cert_r = nullptr; L.cert_dot = nullptr; L.tgt_nor_max = tgt->nor_max;
   L.m_slot = g_ws.slot.as<int>(); L.m_d2 = g_ws.d2.as<float>(); L.m_dot = g_ws.dot.as<float>();
   L.corr_part = g_ws.corr_part.as<double>();
   L.mom_part = g_ws.mom_part.as<double>(); L.res = g_ws.res.as<double>();
@@ -600,16 +600,14 @@ int icp_upload_state( IcpCtx& cx, const float* T1s, size_t np )
   return RS_HIP_OK;
 }
 
-// Certificates on: margin mu on the gate value (cos of the angle).  0.05 is ~3.3 degrees at a 60-degree gate:
-// wide enough to survive the pose changes of the later iterations, narrow enough that few unmatched
-// points have a candidate inside the band.
+// Certificates on (rs_kernels.hip: icp_certificate): two floats per (problem, source point).
 int icp_enable_certificates( IcpCtx& cx, size_t np, size_t nq )
 {
   int rc;
   if( getenv( "RS_HIP_NO_CERT" ) || !std::isfinite( cx.L.tgt_nor_max ) ) return RS_HIP_OK;
   if( ( rc = g_ws.cert_r.ensure( np * nq * 4 ) ) || ( rc = g_ws.cert_dot.ensure( np * nq * 4 ) ) ) return rc;
   HIP_TRY( hipMemsetAsync( g_ws.cert_r.p, 0xFF, np * nq * 4, g_stream ), RS_HIP_E_RUNTIME );      // NaN: no certificate
-  cx.L.cert_r = g_ws.cert_r.as<float>(); cx.L.cert_dot = g_ws.cert_dot.as<float>(); cx.L.cert_mu = 0.05f;
+  cx.L.cert_r = g_ws.cert_r.as<float>(); cx.L.cert_dot = g_ws.cert_dot.as<float>();
   return RS_HIP_OK;
 }
 

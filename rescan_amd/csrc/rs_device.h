@@ -83,11 +83,10 @@ struct IcpLaunch
   int*    queued;       // n_prob: tiles phase A handed off in the last iteration (host heuristics, diagnostics)
   int*    ticket;       // (unused, kept zero)
   int     warm;         // m_slot holds last iteration's matches: use them as starting candidates
-  // "no correspondence" certificates carried across iterations (rs_kernels.hip: icp_certificate); null = off
+  // certificates issued by every search and consulted when a point has no usable previous match (rs_kernels.hip: icp_certificate); null = off
   float*  cert_r;       // n_prob x nq
   float*  cert_dot;     // n_prob x nq
   float*  T1_prev;      // device, n_prob x 16: the poses the previous iteration searched with
-  float   cert_mu;      // margin by which the gate is loosened when a certificate is issued
   float   tgt_nor_max;  // max |normal| over the target cloud
   unsigned long long* dbg;   // diagnostic builds only: per-tile {cycles, candidates} of phase A (null otherwise)
   const float* w_explicit;   // if non-null: weights given per query (estimate-only entry point)

@@ -285,10 +285,11 @@ __device__ __forceinline__ uint32_t sweep_shell( const GridView& g, const CellBo
 }
 
 // Result of a search for one query.
-// `loose`: some candidate within the radius had max(dot,0) >= tmin_loose (a gate loosened by a margin;
-// only the ICP certificate below reads it).
-struct Match { float d2; int idx; float dot; int slot; bool found; bool loose; };
-__device__ __forceinline__ Match no_match() { Match m; m.d2 = INFINITY; m.idx = INT_MAX; m.dot = 0.0f; m.slot = -1; m.found = false; m.loose = false; return m; }
+// `fail_max`: the largest gate value max(dot,0) among the candidates that were inside the lane's bound when
+// met and failed the gate — every candidate closer than the final match (or, without one, within the
+// radius) is among them.  Only the ICP certificates below read it.
+struct Match { float d2; int idx; float dot; int slot; bool found; float fail_max; };
+__device__ __forceinline__ Match no_match() { Match m; m.d2 = INFINITY; m.idx = INT_MAX; m.dot = 0.0f; m.slot = -1; m.found = false; m.fail_max = 0.0f; return m; }
 
 typedef float f32x2 __attribute__(( ext_vector_type( 2 ) ));
 
@@ -322,7 +323,7 @@ __device__ __forceinline__ void dist2x4( const float4& X, const float4& Y, const
 template <bool GATED, bool SELF>
 __device__ __forceinline__ void consider4( const float4& X, const float4& Y, const float4& Z, int k, const WaveLds& L,
                                            float qx, float qy, float qz, float nx, float ny, float nz,
-                                           float tmin, float tmin_loose, float& bound, Match& m, int& seen_closer )
+                                           float tmin, float& bound, Match& m, int& seen_closer )
 {
   float d[4];
   dist2x4( X, Y, Z, qx, qy, qz, d[0], d[1], d[2], d[3] );
@@ -351,9 +352,10 @@ __device__ __forceinline__ void consider4( const float4& X, const float4& Y, con
     const f32x2 b = f32x2{ NX.z, NX.w } * n_x + f32x2{ NY.z, NY.w } * n_y + f32x2{ NZ.z, NZ.w } * n_z;
     dc[0] = a.x > 0.0f ? a.x : 0.0f; dc[1] = a.y > 0.0f ? a.y : 0.0f;                                    // msh_max( dot, 0.0f )
     dc[2] = b.x > 0.0f ? b.x : 0.0f; dc[3] = b.y > 0.0f ? b.y : 0.0f;
-    m.loose |= ( in0 & ( dc[0] >= tmin_loose ) ) | ( in1 & ( dc[1] >= tmin_loose ) ) | ( in2 & ( dc[2] >= tmin_loose ) ) | ( in3 & ( dc[3] >= tmin_loose ) );
     p0 &= ( dc[0] >= tmin ) & ( dc[0] <= 1.0f ); p1 &= ( dc[1] >= tmin ) & ( dc[1] <= 1.0f );
     p2 &= ( dc[2] >= tmin ) & ( dc[2] <= 1.0f ); p3 &= ( dc[3] >= tmin ) & ( dc[3] <= 1.0f );
+    m.fail_max = fmaxf( fmaxf( m.fail_max, ( in0 & !p0 ) ? dc[0] : 0.0f ), ( in1 & !p1 ) ? dc[1] : 0.0f );
+    m.fail_max = fmaxf( fmaxf( m.fail_max, ( in2 & !p2 ) ? dc[2] : 0.0f ), ( in3 & !p3 ) ? dc[3] : 0.0f );
   }
   if( __any( p0 | p1 | p2 | p3 ) )
   {
@@ -443,7 +445,7 @@ __device__ __forceinline__ CellBox box_clip( const CellBox& a, const CellBox& c 
 template <bool GATED, bool WARM = false>
 __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
                                               float qx, float qy, float qz, float nx, float ny, float nz,
-                                              float radius, float radius_sq, float tmin, float tmin_loose, int K,
+                                              float radius, float radius_sq, float tmin, int K,
                                               WaveLds& L, int lane, int max_stages, bool* handoff, int* dbg_unsettled,
                                               Match m /* starting candidate: empty, or a genuine one (within radius, gate passed) that only tightens the bounds */,
                                               int* n_sweeps = nullptr /* out: shells swept + rank pass: the tile's cost class */ )
@@ -472,7 +474,7 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
     cur = reach_box( g, full, active, reach_of( m, radius ), qx, qy, qz );
     if( !box_empty( cur ) )
       streamed += sweep_shell<GATED>( g, cur, cur, false, L, lane, 0, 1, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
-      { consider4<GATED, WARM>( X, Y, Z, k4, L, qx, qy, qz, nx, ny, nz, tmin, tmin_loose, bound, m, seen_closer ); } );
+      { consider4<GATED, WARM>( X, Y, Z, k4, L, qx, qy, qz, nx, ny, nz, tmin, bound, m, seen_closer ); } );
     if( dbg_unsettled ) { dbg_unsettled[1] = (int)streamed; dbg_unsettled[3] = 1; }
     sweeps = 1;
   }
@@ -490,7 +492,7 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
     const CellBox out = grid ? reach_box( g, cur, unsettled, reach_of( m, radius ), qx, qy, qz ) : full;
     if( !box_empty( out ) )
       streamed += sweep_shell<GATED>( g, out, prev, have_prev, L, lane, 0, 1, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
-      { consider4<GATED, WARM>( X, Y, Z, k4, L, qx, qy, qz, nx, ny, nz, tmin, tmin_loose, bound, m, seen_closer ); } );
+      { consider4<GATED, WARM>( X, Y, Z, k4, L, qx, qy, qz, nx, ny, nz, tmin, bound, m, seen_closer ); } );
     if( dbg_unsettled ) dbg_unsettled[1] = (int)streamed;
     ++sweeps;
     if( n_sweeps ) *n_sweeps = sweeps;
@@ -549,7 +551,7 @@ struct CoopLds
   float m_dot[NW][WAVE];
   int   m_slot[NW][WAVE];
   int   m_cnt[NW][WAVE];
-  int   m_loose[NW][WAVE];
+  float m_fail[NW][WAVE];
 };
 
 // The same staged search, done by all NW waves of a workgroup for ONE tile: every
@@ -559,7 +561,7 @@ struct CoopLds
 template <bool GATED, int NW, bool WARM = false>
 __device__ __forceinline__ Match coop_search( const GridView& g, bool active,
                                               float qx, float qy, float qz, float nx, float ny, float nz,
-                                              float radius, float radius_sq, float tmin, float tmin_loose, int K,
+                                              float radius, float radius_sq, float tmin, int K,
                                               WaveLds& L, CoopLds<NW>& C, int wib, int lane, Match m /* starting candidate, see tile_search */,
                                               uint32_t* dbg_streamed = nullptr, unsigned long long* dbg_t = nullptr )
 {
@@ -591,7 +593,7 @@ __device__ __forceinline__ Match coop_search( const GridView& g, bool active,
     const CellBox out = ( g.inv_cell > 0.0f ) ? reach_box( g, cur, unsettled, reach_of( m, radius ), qx, qy, qz ) : full;
     if( !box_empty( out ) )
     streamed += sweep_shell<GATED>( g, out, prev, have_prev, L, lane, wib, NW, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
-    { consider4<GATED, WARM>( X, Y, Z, k4, L, qx, qy, qz, nx, ny, nz, tmin, tmin_loose, bound, m, seen_closer ); } );
+    { consider4<GATED, WARM>( X, Y, Z, k4, L, qx, qy, qz, nx, ny, nz, tmin, bound, m, seen_closer ); } );
     if( dbg_t && dbg_k < 7 ) dbg_t[dbg_k++] = wall_clock64();
     // merge the per-lane bests of the waves; every wave continues with the merged best
     C.m_d2[wib][lane] = m.d2; C.m_idx[wib][lane] = m.idx; C.m_dot[wib][lane] = m.dot; C.m_slot[wib][lane] = m.found ? m.slot : -1;
@@ -615,11 +617,11 @@ __device__ __forceinline__ Match coop_search( const GridView& g, bool active,
   if( K > 1 || GATED )
   {
     // each wave's count bounds the rank contribution of its own share (see tile_search)
-    C.m_cnt[wib][lane] = seen_closer; C.m_loose[wib][lane] = m.loose ? 1 : 0;
+    C.m_cnt[wib][lane] = seen_closer; C.m_fail[wib][lane] = m.fail_max;
     __syncthreads();
     int seen_total = 0;
 #pragma unroll
-    for( int w = 0; w < NW; ++w ) { seen_total += C.m_cnt[w][lane]; m.loose |= C.m_loose[w][lane] != 0; }
+    for( int w = 0; w < NW; ++w ) { seen_total += C.m_cnt[w][lane]; m.fail_max = fmaxf( m.fail_max, C.m_fail[w][lane] ); }
     bool need_rank = m.found && ( seen_total - ( WARM ? 0 : 1 ) >= K );
     if( __any( need_rank ) )
     {
@@ -676,21 +678,23 @@ __device__ __forceinline__ Match icp_warm_start( const IcpLaunch& L, int prob, i
   float d2 = vx * vx + vy * vy + vz * vz;
   float dot = N.x * nx + N.y * ny + N.z * nz;
   float dc = dot > 0.0f ? dot : 0.0f;
-  if( d2 < L.radius_sq && dc >= L.gate_tmin && dc <= 1.0f ) { m.d2 = d2; m.idx = __float_as_int( P.w ); m.dot = dc; m.slot = s; m.found = true; m.loose = true; }
+  if( d2 < L.radius_sq && dc >= L.gate_tmin && dc <= 1.0f ) { m.d2 = d2; m.idx = __float_as_int( P.w ); m.dot = dc; m.slot = s; m.found = true; }
   return m;
 }
 
-// "No correspondence" certificates.  A query that ended an iteration unmatched after all candidates
-// within radius r_i were examined, none of them with max(dot,0) >= tmin - mu, carries
-//   cert_r   = r_i - margin  : every candidate within this distance of the query AS IT WAS THEN is known to fail the
-//                              loosened gate; each later iteration subtracts how far the query has moved since;
-//   cert_dot = mu - margin   : how much the gate value of any candidate may still rise; each later iteration
-//                              subtracts |delta n| * max|m| (dot(m, n') - dot(m, n) <= |m| |n' - n|).
-// While radius <= cert_r and cert_dot >= 0 the search is skipped: by the triangle inequality every candidate within
-// the current radius was examined then, and none can pass the gate now — the result (unmatched) is exactly what the
-// full sweep would return.  The margins (1e-4 m, 1e-5) are orders of magnitude above the fp32 rounding of dist²,
-// dot and the displacement itself.  This removes the one case a search cannot bound: the full-radius sweep of
-// a source point with nothing to match, repeated every iteration (icp.h:444-493 shrinks the radius only 5 % a time).
+// Certificates.  Every search ends knowing, for its query, a distance within which EVERY candidate failed the
+// gate, and by how much:
+//   cert_r   = (distance to the nearest gated candidate — the match, or one rejected for its rank — or the radius
+//              when there is none) - margin.  Each later iteration subtracts how far the query has moved since;
+//   cert_dot = tmin - fail_max - margin: how much the gate value of any of those candidates may still rise.  Each
+//              later iteration subtracts |delta n| * max|m|  (dot(m, n') - dot(m, n) <= |m| |n' - n|).
+// A query whose previous match is no longer usable (there was none, or it left the shrinking radius —
+// icp.h:493 — or its gate) consults the certificate: while radius <= cert_r and cert_dot >= 0 the triangle
+// inequality proves that every candidate within the current radius was examined then and cannot pass the gate
+// now, so the result (unmatched) is exactly what the full sweep would return, and the sweep is skipped.  The
+// margins (1e-4 m, 1e-5) are orders of magnitude above the fp32 rounding of dist², dot and the displacement.
+// This removes the one case a search cannot bound — the full-radius sweep of a source point with nothing to
+// match, repeated every iteration — including the points that become unmatched because the radius shrinks.
 //
 // Returns whether the search of this query may be skipped, and writes the aged certificate back at once
 // (keeping it in registers across the search costs a wave of occupancy).  A tile that phase A hands off
@@ -725,13 +729,20 @@ __device__ __forceinline__ void icp_emit( const IcpLaunch& L, int prob, int tile
 {
   const size_t o = (size_t)prob * L.src.n + i;
   if( active ) { L.m_slot[o] = m.found ? m.slot : -1; L.m_d2[o] = m.d2; L.m_dot[o] = m.dot; }
-  if( active && L.cert_r && !skipped && !m.found && !m.loose ) { L.cert_r[o] = L.radius - 1e-4f; L.cert_dot[o] = L.cert_mu - 1e-5f; }   // fresh certificate
+  if( active && L.cert_r && !skipped )
+  {
+    // fresh certificate (m.idx != INT_MAX: a gated candidate exists at dist² m.d2, even if its rank rejected it)
+    const float r = ( m.idx != INT_MAX ? sqrtf( m.d2 ) : L.radius ) - 1e-4f;
+    const float d = L.gate_tmin - m.fail_max - 1e-5f;
+    L.cert_r[o] = ( d >= 0.0f ) ? r : -1.0f; L.cert_dot[o] = d;
+  }
   if( RS_DBG >= 2 && DBG( L ) )
   {
     unsigned long long* cat = DBG( L ) + 6 * (size_t)L.src.n_tiles;
-    const int c_skip = __popcll( __ballot( skipped ) ), c_fresh = __popcll( __ballot( active && !skipped && !m.found && !m.loose ) );
-    const int c_rank = __popcll( __ballot( active && !skipped && !m.found && m.loose && m.idx != INT_MAX ) );
-    const int c_loose = __popcll( __ballot( active && !skipped && !m.found && m.loose && m.idx == INT_MAX ) );
+    const bool margin = L.gate_tmin - m.fail_max - 1e-5f >= 0.0f;
+    const int c_skip = __popcll( __ballot( skipped ) ), c_fresh = __popcll( __ballot( active && !skipped && !m.found && margin ) );
+    const int c_rank = __popcll( __ballot( active && !skipped && !m.found && m.idx != INT_MAX ) );
+    const int c_loose = __popcll( __ballot( active && !skipped && !m.found && !margin && m.idx == INT_MAX ) );
     if( lane == 0 ) { atomicAdd( cat + 0, (unsigned long long)c_skip ); atomicAdd( cat + 1, (unsigned long long)c_fresh ); atomicAdd( cat + 2, (unsigned long long)c_rank ); atomicAdd( cat + 3, (unsigned long long)c_loose ); }
   }
   // statistics of dist² over correspondences (msh_compute_mean/stddev, msh_std.h:1800-1825)
@@ -788,9 +799,9 @@ __global__ __launch_bounds__( BLOCK, RS_ICP_OCC ) void k_icp_corr( IcpLaunch L )
   bool handoff;
   int sweeps = 0;
   int unsettled[4] = { 0, 0, 0, 0 };
-  const bool search = active & !icp_certificate( L, prob, i, active, qx, qy, qz, nx, ny, nz );
-  const Match init = icp_warm_start( L, prob, i, search, qx, qy, qz, nx, ny, nz );
-  Match m = tile_search<true, true>( L.tgt, search, qx, qy, qz, nx, ny, nz, L.radius, L.radius_sq, L.gate_tmin, L.gate_tmin - L.cert_mu, L.K,
+  const Match init = icp_warm_start( L, prob, i, active, qx, qy, qz, nx, ny, nz );
+  const bool search = active & !icp_certificate( L, prob, i, active & !init.found, qx, qy, qz, nx, ny, nz );
+  Match m = tile_search<true, true>( L.tgt, search, qx, qy, qz, nx, ny, nz, L.radius, L.radius_sq, L.gate_tmin, L.K,
                                lds[wib], lane, L.solo_stages, &handoff, DBG( L ) ? unsettled : nullptr, init, &sweeps );
   if( L.heavy_out && lane == 0 )
   {
@@ -885,10 +896,10 @@ __global__ __launch_bounds__( NW * WAVE ) void k_icp_corr_coop( IcpLaunch L )
     icp_query( L, T1, i, active, qx, qy, qz, nx, ny, nz );
     const unsigned long long t_begin = DBG( L ) ? wall_clock64() : 0ull;
     unsigned long long stamps[8];
-    const bool search = active & !icp_certificate( L, prob, i, active, qx, qy, qz, nx, ny, nz );
-    const Match init = icp_warm_start( L, prob, i, search, qx, qy, qz, nx, ny, nz );
+    const Match init = icp_warm_start( L, prob, i, active, qx, qy, qz, nx, ny, nz );
+    const bool search = active & !icp_certificate( L, prob, i, active & !init.found, qx, qy, qz, nx, ny, nz );
     uint32_t streamed = 0;
-    Match m = coop_search<true, NW, true>( L.tgt, search, qx, qy, qz, nx, ny, nz, L.radius, L.radius_sq, L.gate_tmin, L.gate_tmin - L.cert_mu, L.K,
+    Match m = coop_search<true, NW, true>( L.tgt, search, qx, qy, qz, nx, ny, nz, L.radius, L.radius_sq, L.gate_tmin, L.K,
                                  lds[wib], coop, wib, lane, init, DBG( L ) ? &streamed : nullptr, DBG( L ) ? stamps : nullptr );
     if( DBG( L ) && wib == 0 )
     {
@@ -1087,7 +1098,7 @@ __global__ __launch_bounds__( BLOCK, RS_SCORE_OCC ) void k_score( ScoreLaunch L 
   float qx, qy, qz, nx, ny, nz;
   score_query( L, X, i, active, qx, qy, qz, nx, ny, nz );
   bool handoff;
-  Match m = tile_search<true>( L.scene, active, qx, qy, qz, nx, ny, nz, (float)L.sigma, L.radius_sq, L.gate_tmin, L.gate_tmin, L.K,
+  Match m = tile_search<true>( L.scene, active, qx, qy, qz, nx, ny, nz, (float)L.sigma, L.radius_sq, L.gate_tmin, L.K,
                                lds[wib], lane, L.solo_stages, &handoff, nullptr, no_match() );
   if( handoff )
   {
@@ -1115,7 +1126,7 @@ __global__ __launch_bounds__( COOP_BLOCK ) void k_score_coop( ScoreLaunch L )
     for( int k = 0; k < 16; ++k ) X.m[k] = L.poses[pose * 16 + k];
     float qx, qy, qz, nx, ny, nz;
     score_query( L, X, i, active, qx, qy, qz, nx, ny, nz );
-    Match m = coop_search<true, COOP_WAVES>( L.scene, active, qx, qy, qz, nx, ny, nz, (float)L.sigma, L.radius_sq, L.gate_tmin, L.gate_tmin, L.K,
+    Match m = coop_search<true, COOP_WAVES>( L.scene, active, qx, qy, qz, nx, ny, nz, (float)L.sigma, L.radius_sq, L.gate_tmin, L.K,
                                  lds[wib], coop, wib, lane, no_match() );
     if( wib == 0 ) score_emit( L, pose, tile, active, lane, m );
     __syncthreads();
@@ -1186,7 +1197,7 @@ __global__ __launch_bounds__( BLOCK, RS_LABEL_OCC ) void k_label( LabelLaunch L 
     const PlacementDev& pl = L.pl[k];
     float qx, qy, qz;
     xform3( pl.inv, p.x, p.y, p.z, 1.0f, qx, qy, qz );                         // :755
-    Match m = tile_search<false>( pl.g, active, qx, qy, qz, 0.0f, 0.0f, 0.0f, pl.radius, pl.radius_sq, 0.0f, 0.0f, 1,
+    Match m = tile_search<false>( pl.g, active, qx, qy, qz, 0.0f, 0.0f, 0.0f, pl.radius, pl.radius_sq, 0.0f, 1,
                                   lds[wib], lane, 0, nullptr, nullptr, no_match() );   // :758 (K = 1)
     // :762-775 — found, strictly closer than the running minimum, and within 70° (either sign)
     bool ok = false;
