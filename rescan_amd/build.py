@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librescan_hip.so")
 DROPIN = os.path.join(HERE, "librescan_dropin.so")
-SOURCES = ["rs_kernels.hip", "rs_api.hip"]
+SOURCES = ["rs_kernels.hip", "rs_build.hip", "rs_api.hip"]
 HEADERS = ["rs_device.h", "rs_math.h", "rs_dropin.cpp", os.path.join("..", "..", "include", "rescan_hip.h"),
            os.path.join("..", "..", "include", "rescan_dropin.h")]
 # -ffp-contract=off: the neighbour-deciding arithmetic must round exactly like the reference's
@@ -29,13 +29,17 @@ def build(force=False, verbose=False):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS if h.endswith(".h")] + [os.path.abspath(__file__)]
     for s in SOURCES:
         o = os.path.join(CSRC, s.replace(".hip", ".o"))
+        objs.append(o)
+        deps = [os.path.join(CSRC, s)] + hdrs
+        if not force and os.path.exists(o) and all(os.path.getmtime(d) <= os.path.getmtime(o) for d in deps):
+            continue                    # this object is current (rs_build.hip pulls in hipCUB: ~20 s)
         cmd = [hipcc] + [f for f in FLAGS if f != "-shared"] + ["-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
-        objs.append(o)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

@@ -102,6 +102,7 @@ struct Workspace
   DevBuf enor, ecount, eoffset, e1, e2, ew;                                     // neighbourhood edges
   DevBuf cert_r, cert_dot;                                                      // ICP certificates
   DevBuf cov_bits, cov_plc, cov_agree;                                          // coverage scores
+  DevBuf bld_pos, bld_nor, bld_k0, bld_k1, bld_v0, bld_v1, bld_v2, bld_small, bld_bits, bld_tmp;   // cloud construction
   DevBuf order_a, order_b;                                                      // ICP phase A slow-tile lists (ping-pong)
   DevBuf tmp_pos, tmp_pos2, tmp_nor2;                                           // estimate-only
   PinBuf h_a, h_b, h_c;
@@ -353,8 +354,11 @@ int rs_hip_profile_read( const char* name, int64_t* launches, double* total_ms )
 }
 
 // ---- cloud build -------------------------------------------------------------------------
-// Host counting sort by cell (stable: input order inside a cell, like msh_hash_grid.h:511-532),
-// then one upload.  The index is built once per cloud level and reused by every search.
+// The caller's raw arrays are uploaded once and everything else happens on the device (rs_build.hip):
+// bounds, the density-derived cell size, a stable sort by cell (input order inside a cell, like
+// msh_hash_grid.h:511-532) with a dense offset table, and the Hilbert-ordered, tiled query layout.
+// The host only takes the few decisions in between (cell size, table size, number of tiles).
+// The index is built once per cloud level and reused by every search.
 rs_hip_cloud_t* rs_hip_cloud_create( const float* pos, const float* nor, int32_t n, float cell_size )
 {
   if( ensure_ready() != RS_HIP_OK ) return nullptr;
@@ -362,19 +366,43 @@ rs_hip_cloud_t* rs_hip_cloud_create( const float* pos, const float* nor, int32_t
   rs_hip_cloud* c = new rs_hip_cloud();
   c->n = n; c->has_nor = nor != nullptr;
   c->h_pos.assign( pos, pos + (size_t)3 * n );
-  if( nor )
+  if( nor ) c->h_nor.assign( nor, nor + (size_t)3 * n );
+  auto fail = [&]( hipError_t e ) { set_err( "rs_hip_cloud_create: %s", hipGetErrorString( e ) ); rs_hip_cloud_destroy( c ); return (rs_hip_cloud_t*)nullptr; };
+  auto failrc = [&]( const char* what ) { set_err( "rs_hip_cloud_create: %s", what ); rs_hip_cloud_destroy( c ); return (rs_hip_cloud_t*)nullptr; };
+#define CC( expr ) do { hipError_t e_ = ( expr ); if( e_ != hipSuccess ) return fail( e_ ); } while( 0 )
+  const size_t nn = (size_t)std::max( 1, n );
+  Workspace& W = g_ws;
+  if( W.bld_pos.ensure( nn * 12 ) || ( nor && W.bld_nor.ensure( nn * 12 ) ) || W.bld_k0.ensure( ( nn + 1 ) * 4 ) || W.bld_k1.ensure( ( nn + 1 ) * 4 ) ||
+      W.bld_v0.ensure( nn * 4 ) || W.bld_v1.ensure( nn * 4 ) || W.bld_v2.ensure( nn * 4 ) || W.bld_small.ensure( 64 ) )
+    return failrc( "workspace allocation failed" );
+  float* d_raw = W.bld_pos.as<float>(); float* d_rawn = nor ? W.bld_nor.as<float>() : nullptr;
+  uint32_t *k0 = W.bld_k0.as<uint32_t>(), *k1 = W.bld_k1.as<uint32_t>(), *v0 = W.bld_v0.as<uint32_t>(), *v1 = W.bld_v1.as<uint32_t>(), *v2 = W.bld_v2.as<uint32_t>();
+  unsigned* d_small = W.bld_small.as<unsigned>();
+  if( n > 0 )
   {
-    c->h_nor.assign( nor, nor + (size_t)3 * n );
-    double mx = 0.0;
-    for( int i = 0; i < n; ++i ) { double l = (double)nor[3*i] * nor[3*i] + (double)nor[3*i+1] * nor[3*i+1] + (double)nor[3*i+2] * nor[3*i+2]; if( l > mx ) mx = l; }
-    c->nor_max = std::isfinite( mx ) ? (float)( std::sqrt( mx ) * 1.000001 ) : INFINITY;
+    CC( hipMemcpyAsync( d_raw, pos, (size_t)n * 12, hipMemcpyHostToDevice, g_stream ) );
+    if( nor ) CC( hipMemcpyAsync( d_rawn, nor, (size_t)n * 12, hipMemcpyHostToDevice, g_stream ) );
   }
 
+  // bounds (+ the largest normal, which bounds how fast a gate value can change with the query normal)
   float mn[3] = { 0, 0, 0 }, mx[3] = { 0, 0, 0 };
-  if( n > 0 ) { for( int a = 0; a < 3; ++a ) { mn[a] = FLT_MAX; mx[a] = -FLT_MAX; } }
-  for( int32_t i = 0; i < n; ++i )
-    for( int a = 0; a < 3; ++a ) { float v = pos[3*i+a]; if( v < mn[a] ) mn[a] = v; if( v > mx[a] ) mx[a] = v; }
-  for( int a = 0; a < 3; ++a ) { if( !( mx[a] >= mn[a] ) || !std::isfinite( mn[a] ) || !std::isfinite( mx[a] ) ) { mn[a] = 0; mx[a] = 0; } }
+  if( n > 0 )
+  {
+    const unsigned init[8] = { ~0u, ~0u, ~0u, 0u, 0u, 0u, 0u, 0u };
+    unsigned got[8];
+    CC( hipMemcpyAsync( d_small, init, 32, hipMemcpyHostToDevice, g_stream ) );
+    launch_build_bounds( d_raw, d_rawn, n, d_small, g_stream );
+    CC( hipMemcpyAsync( got, d_small, 32, hipMemcpyDeviceToHost, g_stream ) );
+    CC( hipStreamSynchronize( g_stream ) );
+    auto dec = []( unsigned u ) { unsigned b = ( u & 0x80000000u ) ? ( u ^ 0x80000000u ) : ~u; float f; std::memcpy( &f, &b, 4 ); return f; };
+    for( int a = 0; a < 3; ++a ) { mn[a] = dec( got[a] ); mx[a] = dec( got[3 + a] ); }
+    for( int a = 0; a < 3; ++a ) { if( !( mx[a] >= mn[a] ) || !std::isfinite( mn[a] ) || !std::isfinite( mx[a] ) ) { mn[a] = 0; mx[a] = 0; } }
+    if( nor )
+    {
+      float n2; std::memcpy( &n2, &got[6], 4 );
+      c->nor_max = ( got[7] || !std::isfinite( n2 ) ) ? INFINITY : std::sqrt( n2 ) * 1.00001f;
+    }
+  }
 
   // cell_size < 0: pick the cell from the cloud's own sampling density (about two sample
   // spacings: a surface patch then holds ~4 points per cell, the first search shell ~100-300).
@@ -387,17 +415,24 @@ rs_hip_cloud_t* rs_hip_cloud_create( const float* pos, const float* nor, int32_t
       float c0 = std::min( 0.1f, std::max( ext / 64.0f, 1e-4f ) );
       for( int attempt = 0; attempt < 8; ++attempt, c0 *= 2.0f )
       {
-        std::vector<uint64_t> ids( (size_t)n );
         const float inv = 1.0f / c0;
-        for( int32_t i = 0; i < n; ++i )
+        unsigned long long td[3]; double cells = 1.0;
+        for( int a = 0; a < 3; ++a ) { td[a] = (unsigned long long)std::max( 0.0f, floorf( ( mx[a] - mn[a] ) * inv ) ) + 2ull; cells *= (double)td[a]; }
+        if( cells > 1073741824.0 && attempt < 7 ) continue;          // trial grid too fine to count (huge, sparse extent): coarsen
+        float per_cell = 4.0f;
+        if( cells <= 1073741824.0 )
         {
-          uint64_t a = (uint64_t)std::max( 0.0f, floorf( ( pos[3*i] - mn[0] ) * inv ) ), b = (uint64_t)std::max( 0.0f, floorf( ( pos[3*i+1] - mn[1] ) * inv ) ),
-                   c = (uint64_t)std::max( 0.0f, floorf( ( pos[3*i+2] - mn[2] ) * inv ) );
-          ids[i] = ( a << 42 ) | ( b << 21 ) | c;
+          const size_t words = (size_t)( cells / 32.0 ) + 2;
+          if( W.bld_bits.ensure( words * 4 ) ) return failrc( "workspace allocation failed" );
+          CC( hipMemsetAsync( W.bld_bits.p, 0, words * 4, g_stream ) );
+          CC( hipMemsetAsync( d_small, 0, 4, g_stream ) );
+          launch_build_mark( d_raw, n, mn, inv, td[1], td[2], W.bld_bits.as<uint32_t>(), g_stream );
+          launch_popcount( W.bld_bits.as<uint32_t>(), (int)words, (int*)d_small, g_stream );
+          int occ = 0;
+          CC( hipMemcpyAsync( &occ, d_small, 4, hipMemcpyDeviceToHost, g_stream ) );
+          CC( hipStreamSynchronize( g_stream ) );
+          per_cell = (float)n / (float)std::max( 1, occ );
         }
-        std::sort( ids.begin(), ids.end() );
-        size_t occ = std::unique( ids.begin(), ids.end() ) - ids.begin();
-        float per_cell = (float)n / (float)occ;
         if( per_cell >= 4.0f || attempt == 7 ) { cell_size = 2.0f * c0 / std::sqrt( std::max( per_cell, 1.0f ) ); break; }
       }
       cell_size = std::min( std::max( cell_size, 0.005f ), 2.0f );
@@ -419,41 +454,31 @@ rs_hip_cloud_t* rs_hip_cloud_create( const float* pos, const float* nor, int32_t
   c->cell = ( cell_size > 0.0f ) ? cell : 0.0f;
   const size_t n_cells = (size_t)dims[0] * dims[1] * dims[2];
 
-  std::vector<uint32_t> start( n_cells + 1, 0u );
-  std::vector<uint32_t> cid( (size_t)n );
-  for( int32_t i = 0; i < n; ++i )
-  {
-    int cx = cell_of( pos[3*i],   mn[0], inv_cell, dims[0] );
-    int cy = cell_of( pos[3*i+1], mn[1], inv_cell, dims[1] );
-    int cz = cell_of( pos[3*i+2], mn[2], inv_cell, dims[2] );
-    uint32_t id = (uint32_t)( ( (size_t)cz * dims[1] + cy ) * dims[0] + cx );
-    cid[i] = id; start[id + 1]++;
-  }
-  for( size_t k = 0; k < n_cells; ++k ) start[k + 1] += start[k];
-  std::vector<uint32_t> fill( start.begin(), start.end() - 1 );
-  c->order.resize( (size_t)n );
-  std::vector<float4> spos( (size_t)n ), snor( nor ? (size_t)n : 0 );
-  for( int32_t i = 0; i < n; ++i )
-  {
-    uint32_t s = fill[cid[i]]++;
-    c->order[s] = i;
-    float w; std::memcpy( &w, &i, 4 );
-    spos[s] = make_float4( pos[3*i], pos[3*i+1], pos[3*i+2], w );
-    if( nor ) snor[s] = make_float4( nor[3*i], nor[3*i+1], nor[3*i+2], 0.0f );
-  }
-
-  auto fail = [&]( hipError_t e ) { set_err( "rs_hip_cloud_create: %s", hipGetErrorString( e ) ); rs_hip_cloud_destroy( c ); return (rs_hip_cloud_t*)nullptr; };
-  hipError_t e;
-  size_t pb = std::max<size_t>( 1, (size_t)n ) * sizeof(float4);
-  if( ( e = hipMalloc( (void**)&c->d_pos, pb ) ) != hipSuccess ) return fail( e );
-  if( nor && ( e = hipMalloc( (void**)&c->d_nor, pb ) ) != hipSuccess ) return fail( e );
-  if( ( e = hipMalloc( (void**)&c->d_cell_start, ( n_cells + 1 ) * 4 ) ) != hipSuccess ) return fail( e );
+  const size_t pb = nn * sizeof(float4);
+  CC( hipMalloc( (void**)&c->d_pos, pb ) );
+  if( nor ) CC( hipMalloc( (void**)&c->d_nor, pb ) );
+  CC( hipMalloc( (void**)&c->d_cell_start, ( n_cells + 1 ) * 4 ) );
+  CC( hipMemsetAsync( c->d_cell_start, 0, ( n_cells + 1 ) * 4, g_stream ) );
+  size_t occupied = 0;
+  int key_bits = 1; while( ( 1ull << key_bits ) < n_cells && key_bits < 32 ) ++key_bits;
+  const size_t tmp_bytes = std::max( std::max( build_sort_temp_bytes( (int)nn, 32 ), build_scan_temp_bytes( n_cells + 1 ) ), build_scan_temp_bytes( nn + 1 ) );
+  if( W.bld_tmp.ensure( tmp_bytes + 256 ) ) return failrc( "workspace allocation failed" );
   if( n > 0 )
   {
-    if( ( e = hipMemcpy( c->d_pos, spos.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice ) ) != hipSuccess ) return fail( e );
-    if( nor && ( e = hipMemcpy( c->d_nor, snor.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice ) ) != hipSuccess ) return fail( e );
+    // cell ids + per-cell counts -> offsets; stable sort of the point indices by cell
+    launch_build_cellids( d_raw, n, mn, inv_cell, dims, k0, v0, c->d_cell_start, g_stream );
+    if( build_exclusive_scan( W.bld_tmp.p, tmp_bytes, c->d_cell_start, c->d_cell_start, n_cells + 1, g_stream ) ) return failrc( "device scan failed" );
+    if( build_sort_pairs( W.bld_tmp.p, tmp_bytes, k0, k1, v0, v1, n, key_bits, g_stream ) ) return failrc( "device sort failed" );
+    launch_build_gather( d_raw, d_rawn, v1, n, c->d_pos, c->d_nor, g_stream );
+    CC( hipMemsetAsync( d_small, 0, 4, g_stream ) );
+    launch_build_count_runs( k1, n, (int*)d_small, g_stream );
+    int occ = 0;
+    CC( hipMemcpyAsync( &occ, d_small, 4, hipMemcpyDeviceToHost, g_stream ) );
+    c->order.resize( (size_t)n );
+    CC( hipMemcpyAsync( c->order.data(), v1, (size_t)n * 4, hipMemcpyDeviceToHost, g_stream ) );
+    CC( hipStreamSynchronize( g_stream ) );
+    occupied = (size_t)occ;
   }
-  if( ( e = hipMemcpy( c->d_cell_start, start.data(), ( n_cells + 1 ) * 4, hipMemcpyHostToDevice ) ) != hipSuccess ) return fail( e );
   c->bytes = (int64_t)( pb * ( nor ? 2 : 1 ) + ( n_cells + 1 ) * 4 );
 
   GridView& v = c->view;
@@ -461,9 +486,7 @@ rs_hip_cloud_t* rs_hip_cloud_create( const float* pos, const float* nor, int32_t
   v.minx = mn[0]; v.miny = mn[1]; v.minz = mn[2]; v.inv_cell = inv_cell; v.cell = inv_cell > 0.0f ? cell : 0.0f;
   v.w = dims[0]; v.h = dims[1]; v.d = dims[2]; v.n = n;
 
-  // query layout (Hilbert order + tiles)
-  size_t occupied = 0;
-  for( size_t k = 0; k < n_cells; ++k ) occupied += ( start[k + 1] > start[k] ) ? 1 : 0;
+  // query layout: Hilbert order (10 bits per axis over the largest extent), tiles of <= 64 points
   float lim_cell = cell_size > 0.0f ? cell : 0.1f;
   if( !( cell_size > 0.0f ) )
   {
@@ -471,28 +494,44 @@ rs_hip_cloud_t* rs_hip_cloud_create( const float* pos, const float* nor, int32_t
     double vol_cells = 1.0; for( int a = 0; a < 3; ++a ) vol_cells *= std::floor( ( (double)mx[a] - mn[a] ) / 0.1 ) + 1.0;
     occupied = (size_t)std::max( 1.0, std::min( (double)n, std::pow( vol_cells, 2.0 / 3.0 ) ) );
   }
-  std::vector<uint32_t> tiles;
-  build_query_layout( pos, n, query_extent_limit( n, occupied, lim_cell ), c->qorder, tiles );
-  std::vector<float4> qpos( (size_t)n ), qnor( nor ? (size_t)n : 0 );
-  for( int32_t s = 0; s < n; ++s )
-  {
-    int32_t i = c->qorder[s];
-    float w; std::memcpy( &w, &i, 4 );
-    qpos[s] = make_float4( pos[3*i], pos[3*i+1], pos[3*i+2], w );
-    if( nor ) qnor[s] = make_float4( nor[3*i], nor[3*i+1], nor[3*i+2], 0.0f );
-  }
-  if( ( e = hipMalloc( (void**)&c->d_qpos, pb ) ) != hipSuccess ) return fail( e );
-  if( nor && ( e = hipMalloc( (void**)&c->d_qnor, pb ) ) != hipSuccess ) return fail( e );
-  if( ( e = hipMalloc( (void**)&c->d_tiles, tiles.size() * 4 ) ) != hipSuccess ) return fail( e );
+  CC( hipMalloc( (void**)&c->d_qpos, pb ) );
+  if( nor ) CC( hipMalloc( (void**)&c->d_qnor, pb ) );
+  int n_tiles = 0;
   if( n > 0 )
   {
-    if( ( e = hipMemcpy( c->d_qpos, qpos.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice ) ) != hipSuccess ) return fail( e );
-    if( nor && ( e = hipMemcpy( c->d_qnor, qnor.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice ) ) != hipSuccess ) return fail( e );
+    float ext = 0.0f;
+    for( int a = 0; a < 3; ++a ) { float e = mx[a] - mn[a]; if( std::isfinite( e ) && e > ext ) ext = e; }
+    const float scale = ext > 0.0f ? 1024.0f / ext : 0.0f;
+    launch_build_hilbert( d_raw, n, mn, scale, k0, v0, g_stream );
+    if( build_sort_pairs( W.bld_tmp.p, tmp_bytes, k0, k1, v0, v2, n, 30, g_stream ) ) return failrc( "device sort failed" );
+    launch_build_gather( d_raw, d_rawn, v2, n, c->d_qpos, c->d_qnor, g_stream );
+    // tile starts: flags -> exclusive scan -> scatter
+    uint32_t* flags = k0; uint32_t* scanned = k1;
+    CC( hipMemsetAsync( flags + n, 0, 4, g_stream ) );
+    launch_build_tile_flags( c->d_qpos, n, query_extent_limit( n, occupied, lim_cell ), flags, v0, v1, g_stream );   // (order / v1 is on the host by now)
+    if( build_exclusive_scan( W.bld_tmp.p, tmp_bytes, flags, scanned, (size_t)n + 1, g_stream ) ) return failrc( "device scan failed" );
+    unsigned total = 0;
+    CC( hipMemcpyAsync( &total, scanned + n, 4, hipMemcpyDeviceToHost, g_stream ) );
+    c->qorder.resize( (size_t)n );
+    CC( hipMemcpyAsync( c->qorder.data(), v2, (size_t)n * 4, hipMemcpyDeviceToHost, g_stream ) );
+    CC( hipStreamSynchronize( g_stream ) );
+    n_tiles = (int)total;
+    CC( hipMalloc( (void**)&c->d_tiles, ( (size_t)n_tiles + 1 ) * 4 ) );
+    launch_build_tile_scatter( flags, scanned, n, c->d_tiles, g_stream );
+    const uint32_t last = (uint32_t)n;
+    CC( hipMemcpyAsync( c->d_tiles + n_tiles, &last, 4, hipMemcpyHostToDevice, g_stream ) );
+    CC( hipStreamSynchronize( g_stream ) );
   }
-  if( ( e = hipMemcpy( c->d_tiles, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice ) ) != hipSuccess ) return fail( e );
-  c->bytes += (int64_t)( pb * ( nor ? 2 : 1 ) + tiles.size() * 4 );
+  else
+  {
+    CC( hipMalloc( (void**)&c->d_tiles, 4 ) );
+    CC( hipMemsetAsync( c->d_tiles, 0, 4, g_stream ) );
+    CC( hipStreamSynchronize( g_stream ) );
+  }
+  c->bytes += (int64_t)( pb * ( nor ? 2 : 1 ) + ( (size_t)n_tiles + 1 ) * 4 );
   c->qview.pos = c->d_qpos; c->qview.nor = c->d_qnor; c->qview.tiles = c->d_tiles;
-  c->qview.n = n; c->qview.n_tiles = (int)tiles.size() - 1;
+  c->qview.n = n; c->qview.n_tiles = n_tiles;
+#undef CC
   return c;
 }
 

@@ -164,6 +164,20 @@ void launch_voxel_mark( const VoxGrid& g, const float* pos /* AoS xyz */, const 
 void launch_popcount( const uint32_t* bits, int n_words, int* out /* zero on entry */, hipStream_t st );
 void launch_coverage( const CoverageLaunch& L, hipStream_t st );
 
+// Device-side cloud construction (rs_build.hip)
+void   launch_build_bounds( const float* pos3, const float* nor3, int n, unsigned* out8, hipStream_t st );
+void   launch_build_mark( const float* pos3, int n, const float mn[3], float inv, unsigned long long db, unsigned long long dc, uint32_t* bits, hipStream_t st );
+void   launch_build_cellids( const float* pos3, int n, const float mn[3], float inv_cell, const int dims[3], uint32_t* cid, uint32_t* iota, uint32_t* counts, hipStream_t st );
+void   launch_build_gather( const float* pos3, const float* nor3, const uint32_t* order, int n, float4* spos, float4* snor, hipStream_t st );
+void   launch_build_count_runs( const uint32_t* sorted, int n, int* out, hipStream_t st );
+void   launch_build_hilbert( const float* pos3, int n, const float mn[3], float scale, uint32_t* key, uint32_t* iota, hipStream_t st );
+void   launch_build_tile_flags( const float4* qpos, int n, float max_extent, uint32_t* flags, uint32_t* jump_a, uint32_t* jump_b, hipStream_t st );
+void   launch_build_tile_scatter( const uint32_t* flags, const uint32_t* scanned, int n, uint32_t* tiles, hipStream_t st );
+size_t build_sort_temp_bytes( int n, int bits );
+int    build_sort_pairs( void* tmp, size_t bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout, int n, int bits, hipStream_t st );
+size_t build_scan_temp_bytes( size_t n );
+int    build_exclusive_scan( void* tmp, size_t bytes, const uint32_t* in, uint32_t* out, size_t n, hipStream_t st );
+
 // Neighbourhood graph (rspf_compute_neighborhood): from self-search rows to unique weighted edges.
 struct EdgeLaunch
 {
