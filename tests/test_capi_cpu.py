@@ -38,13 +38,13 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_code_object_is_gfx950_only():
+    """Every device code object bundled in the library targets gfx950 (the .hip_fatbin entries are named
+    `hipv4-amdgcn-amd-amdhsa--<arch>`; rocPRIM's host-side tuning tables mention other arch names as plain
+    strings, which is not code)."""
     from rescan_amd import capi
-    out = subprocess.run(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--list", "--type=o",
-                          f"--input={capi.LIB_PATH}"], capture_output=True, text=True).stdout
-    if out.strip():
-        assert "gfx950" in out and "gfx9" in out
     blob = open(capi.LIB_PATH, "rb").read()
-    assert b"gfx950" in blob and b"gfx90a" not in blob and b"gfx942" not in blob
+    targets = set(re.findall(rb"hipv4-amdgcn-amd-amdhsa--([a-z0-9:+-]+)", blob))
+    assert targets == {b"gfx950"}, targets
 
 
 def test_product_does_not_touch_the_oracle():
