@@ -879,6 +879,7 @@ __global__ __launch_bounds__( NW * WAVE ) void k_icp_corr_coop( IcpLaunch L )
 {
   __shared__ WaveLds lds[NW];
   __shared__ CoopLds<NW> coop;
+  __shared__ unsigned long long s_skip;
   const int prob = blockIdx.y;
   if( L.active[prob] == 0 ) return;
   const int lane = threadIdx.x & ( WAVE - 1 );
@@ -897,7 +898,15 @@ __global__ __launch_bounds__( NW * WAVE ) void k_icp_corr_coop( IcpLaunch L )
     const unsigned long long t_begin = DBG( L ) ? wall_clock64() : 0ull;
     unsigned long long stamps[8];
     const Match init = icp_warm_start( L, prob, i, active, qx, qy, qz, nx, ny, nz );
-    const bool search = active & !icp_certificate( L, prob, i, active & !init.found, qx, qy, qz, nx, ny, nz );
+    // the certificate check ages the certificate in place: ONE wave does it and tells the others (each wave
+    // re-reading what another has just aged would decide differently, and the waves must agree on who searches)
+    if( wib == 0 )
+    {
+      const unsigned long long skip_mask = __ballot( icp_certificate( L, prob, i, active & !init.found, qx, qy, qz, nx, ny, nz ) );
+      if( lane == 0 ) s_skip = skip_mask;
+    }
+    __syncthreads();
+    const bool search = active & !( ( s_skip >> lane ) & 1ull );
     uint32_t streamed = 0;
     Match m = coop_search<true, NW, true>( L.tgt, search, qx, qy, qz, nx, ny, nz, L.radius, L.radius_sq, L.gate_tmin, L.K,
                                  lds[wib], coop, wib, lane, init, DBG( L ) ? &streamed : nullptr, DBG( L ) ? stamps : nullptr );

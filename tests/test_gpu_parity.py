@@ -369,3 +369,24 @@ def test_full_size_properties(capi):
     assert np.abs(T1 - o["pose"]).max() < 5e-3
     e2, T2, _ = capi.icp_align(oc, scn, T1, I4, 0.1, np.deg2rad(60.0))
     assert np.linalg.norm(T2 - T1) < 2e-3 and abs(e2 - e1) < 1e-4
+
+
+# ---- determinism ------------------------------------------------------------------------------
+
+def test_icp_is_bit_reproducible_and_thread_safe(capi):
+    """Run to run, and issued from several host threads at once, an ICP run returns the same bits (the
+    cooperative kernel's waves must agree on which lanes a certificate lets them skip: a regression here
+    showed up as 1-ulp pose differences between runs)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from rescan_amd import synth
+    s0 = synth.scene_for_point_count(300_000, seed=11, timestep=0)
+    s1 = synth.scene_for_point_count(300_000, seed=11, timestep=1)
+    a, b = capi.Cloud(s0["points"], s0["normals"]), capi.Cloud(s1["points"], s1["normals"])
+    T0 = synth.perturbed_pose(I4, np.random.default_rng(16), 0.01, 0.01)
+    run = lambda: capi.icp_align(b, a, T0, I4, 0.10, np.deg2rad(60.0), max_iter=10, fixed_iters=True)   # noqa: E731
+    key = lambda r: (np.float32(r[0]).tobytes(), np.asarray(r[1], np.float32).tobytes())                  # noqa: E731
+    ref = key(run())
+    assert all(key(run()) == ref for _ in range(8))
+    with ThreadPoolExecutor(max_workers=3) as pool:
+        for _ in range(3):
+            assert all(key(f.result()) == ref for f in [pool.submit(run) for _ in range(3)])
