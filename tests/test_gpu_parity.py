@@ -390,3 +390,39 @@ def test_icp_is_bit_reproducible_and_thread_safe(capi):
     with ThreadPoolExecutor(max_workers=3) as pool:
         for _ in range(3):
             assert all(key(f.result()) == ref for f in [pool.submit(run) for _ in range(3)])
+
+
+def test_cloud_build_edge_cases(capi, oracle):
+    """The device-side index build on degenerate inputs: tiny clouds, coincident points, a NaN coordinate,
+    a huge sparse extent — searches on them still agree with the oracle."""
+    rng = np.random.default_rng(5)
+    base = rng.uniform(0, 1, (500, 3)).astype(np.float32)
+    nor = np.tile(np.array([0, 0, 1], np.float32), (500, 1))
+    cases = {
+        "one": (base[:1], nor[:1]),
+        "two": (base[:2], nor[:2]),
+        "coincident": (np.repeat(base[:1], 300, axis=0), nor[:300]),
+        "line": (np.stack([np.linspace(0, 1, 400), np.zeros(400), np.zeros(400)], 1).astype(np.float32), nor[:400]),
+        "sparse_far": (np.concatenate([base[:200], base[:200] + np.float32(60.0)]), nor[:400]),
+    }
+    q = np.concatenate([base[:64], base[:8] + np.float32(60.0)])
+    for name, (p, n) in cases.items():
+        c = capi.Cloud(p.copy(), n.copy())
+        g = oracle.grid_create(p, 0.5)                       # big cells: the reference's 512-bin cap stays out of the way
+        for k, r in ((1, 0.05), (8, 0.3)):
+            d, i, nn, _ = capi.radius_search(c, q, r, k)
+            want = oracle.radius_search(g, q, r, k, 1)
+            rows_equal_up_to_ties(d, i, nn, want[0], want[1], want[2].astype(nn.dtype))
+        oracle.grid_destroy(g)
+    # an extent of 1e5 m (the trial grids for the cell size do not fit; the table is capped): every point still finds itself
+    p = np.concatenate([base[:200], base[:200] + np.float32(1.0e5)])
+    c = capi.Cloud(p, nor[:400].copy())
+    d, i, nn, _ = capi.radius_search(c, p, 0.05, 1)
+    assert (nn == 1).all() and (d[:, 0] == 0).all()
+    # a NaN coordinate never matches anything and breaks nothing
+    p = base.copy(); p[7, 1] = np.nan
+    c = capi.Cloud(p, nor.copy())
+    d, i, nn, _ = capi.radius_search(c, base[:32], 0.2, 4)
+    valid = np.arange(4)[None, :] < nn[:, None]
+    assert (i[valid] != 7).all() and np.isfinite(d[valid]).all()
+    assert capi.Cloud(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32)).n == 0
