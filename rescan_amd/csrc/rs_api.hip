@@ -598,7 +598,7 @@ int icp_prepare( IcpCtx& cx, const rs_hip_cloud_t* src, const rs_hip_cloud_t* tg
   Mat4 t2i = mat4_inverse( t2 );                                                                             // icp.h:329
   std::memcpy( L.T2i.m, t2i.m, 64 );
   cx.n_waves = src->qview.n_tiles;
-  L.n_mom_blocks = std::max( 1, std::min( 256, ( src->n + 255 ) / 256 ) );
+  L.n_mom_blocks = std::max( 1, std::min( 512, ( src->n + 255 ) / 256 ) );    // 512: gathers want more waves in flight than 256 give, the final tree fewer partials than 1024
   const size_t nq = std::max<size_t>( 1, (size_t)src->n ), np = (size_t)n_prob;
   int rc;
   if( ( rc = g_ws.state.ensure( np * ICP_STATE_WORDS * 4 ) ) ||

@@ -1005,18 +1005,19 @@ __global__ __launch_bounds__( BLOCK ) void k_icp_moments( IcpLaunch L )
 
 }
 
-// One workgroup per problem: fixed-order sum of the per-workgroup partials (moment k by wave k mod 4;
-// lane l adds partials l, l+64, l+128, l+192, then the wave tree) and — inside the ICP loop — the
+// One workgroup per problem: fixed-order sum of the per-workgroup partials (moment k by wave k mod 16;
+// lane l adds partials l, l+64, l+128, ..., then the wave tree) and — inside the ICP loop — the
 // rest of the iteration (icp.h:455-493), which the reference runs on the CPU: 6x6 solve, pose
 // update, stop tests.  Nothing goes back to the host between two searches.
-__global__ __launch_bounds__( BLOCK ) void k_icp_update( IcpLaunch L )
+#define UPDATE_WAVES 16
+__global__ __launch_bounds__( UPDATE_WAVES * WAVE ) void k_icp_update( IcpLaunch L )
 {
   const int prob = blockIdx.x;
   if( L.active[prob] == 0 ) return;
   const int lane = threadIdx.x & ( WAVE - 1 ), wib = threadIdx.x / WAVE;
   const double* in = L.mom_part + (size_t)prob * L.n_mom_blocks * ICP_NMOM;
   double* res = L.res + (size_t)prob * ICP_NRES;
-  for( int k = wib; k < ICP_NMOM; k += WAVES_PER_BLOCK )
+  for( int k = wib; k < ICP_NMOM; k += UPDATE_WAVES )
   {
     double v = 0.0;
     for( int b = lane; b < L.n_mom_blocks; b += WAVE ) v += in[(size_t)b * ICP_NMOM + k];
@@ -1055,7 +1056,7 @@ void launch_icp_corr( const IcpLaunch& L, hipStream_t st )
 void launch_icp_moments( const IcpLaunch& L, hipStream_t st )
 {
   hipLaunchKernelGGL( k_icp_moments, dim3( L.n_mom_blocks, L.n_prob ), dim3( BLOCK ), 0, st, L );
-  hipLaunchKernelGGL( k_icp_update, dim3( L.n_prob ), dim3( BLOCK ), 0, st, L );
+  hipLaunchKernelGGL( k_icp_update, dim3( L.n_prob ), dim3( UPDATE_WAVES * WAVE ), 0, st, L );
 }
 
 // ------------------------------------------------------------------------------------------
