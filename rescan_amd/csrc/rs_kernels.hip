@@ -666,11 +666,41 @@ __device__ __forceinline__ void icp_query( const IcpLaunch& L, const Xform& T1, 
 // the current pose.  If it is still within the radius and passes the gate it is a legitimate
 // candidate, so starting the search from it changes nothing in the result and lets most
 // candidates fail the very first compare.
+// First iteration: no previous match to start from.  The first few points of the query's OWN cell serve the
+// same purpose: whichever of them lies within the radius and passes the gate is a legitimate candidate, and
+// starting from it turns the cold search (every candidate within the radius passes the bound test of a lane
+// without a match) into the bounded one the later iterations run.
+__device__ __forceinline__ Match icp_cell_seed( const IcpLaunch& L, bool active, float qx, float qy, float qz, float nx, float ny, float nz )
+{
+  Match m = no_match();
+  const GridView& g = L.tgt;
+  if( !active || !( g.inv_cell > 0.0f ) ) return m;
+  const float fx = floorf( ( qx - g.minx ) * g.inv_cell ), fy = floorf( ( qy - g.miny ) * g.inv_cell ), fz = floorf( ( qz - g.minz ) * g.inv_cell );
+  if( !( fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx < (float)g.w && fy < (float)g.h && fz < (float)g.d ) ) return m;     // outside the grid (or NaN)
+  const size_t id = ( (size_t)(int)fz * g.h + (int)fy ) * g.w + (int)fx;
+  const uint32_t s0 = g.cell_start[id], s1 = g.cell_start[id + 1];
+  const uint32_t n = min( s1 - s0, 4u );
+  for( uint32_t t = 0; t < n; ++t )
+  {
+    const uint32_t s = s0 + t;
+    const float4 P = g.pos[s], N = g.nor[s];
+    const float vx = P.x - qx, vy = P.y - qy, vz = P.z - qz;
+    const float d2 = vx * vx + vy * vy + vz * vz;
+    const float dot = N.x * nx + N.y * ny + N.z * nz;
+    const float dc = dot > 0.0f ? dot : 0.0f;
+    const int idx = __float_as_int( P.w );
+    if( d2 < L.radius_sq && dc >= L.gate_tmin && dc <= 1.0f && lex_less( d2, idx, m.d2, m.idx ) )
+    { m.d2 = d2; m.idx = idx; m.dot = dc; m.slot = (int)s; m.found = true; }
+  }
+  return m;
+}
+
 __device__ __forceinline__ Match icp_warm_start( const IcpLaunch& L, int prob, int i, bool active,
                                                  float qx, float qy, float qz, float nx, float ny, float nz )
 {
   Match m = no_match();
-  if( !L.warm || !active ) return m;
+  if( !active ) return m;
+  if( !L.warm ) return L.seed ? icp_cell_seed( L, active, qx, qy, qz, nx, ny, nz ) : m;
   const int s = L.m_slot[(size_t)prob * L.src.n + i];
   if( s < 0 ) return m;
   const float4 P = L.tgt.pos[s], N = L.tgt.nor[s];
