@@ -670,10 +670,11 @@ __device__ __forceinline__ void icp_query( const IcpLaunch& L, const Xform& T1, 
 // same purpose: whichever of them lies within the radius and passes the gate is a legitimate candidate, and
 // starting from it turns the cold search (every candidate within the radius passes the bound test of a lane
 // without a match) into the bounded one the later iterations run.
-__device__ __forceinline__ Match icp_cell_seed( const IcpLaunch& L, bool active, float qx, float qy, float qz, float nx, float ny, float nz )
+template <bool GATED>
+__device__ __forceinline__ Match cell_seed( const GridView& g, bool active, float qx, float qy, float qz, float nx, float ny, float nz,
+                                            float radius_sq, float tmin )
 {
   Match m = no_match();
-  const GridView& g = L.tgt;
   if( !active || !( g.inv_cell > 0.0f ) ) return m;
   const float fx = floorf( ( qx - g.minx ) * g.inv_cell ), fy = floorf( ( qy - g.miny ) * g.inv_cell ), fz = floorf( ( qz - g.minz ) * g.inv_cell );
   if( !( fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx < (float)g.w && fy < (float)g.h && fz < (float)g.d ) ) return m;     // outside the grid (or NaN)
@@ -683,17 +684,25 @@ __device__ __forceinline__ Match icp_cell_seed( const IcpLaunch& L, bool active,
   for( uint32_t t = 0; t < n; ++t )
   {
     const uint32_t s = s0 + t;
-    const float4 P = g.pos[s], N = g.nor[s];
+    const float4 P = g.pos[s];
     const float vx = P.x - qx, vy = P.y - qy, vz = P.z - qz;
     const float d2 = vx * vx + vy * vy + vz * vz;
-    const float dot = N.x * nx + N.y * ny + N.z * nz;
-    const float dc = dot > 0.0f ? dot : 0.0f;
+    float dc = 0.0f;
+    bool ok = d2 < radius_sq;
+    if( GATED )
+    {
+      const float4 N = g.nor[s];
+      const float dot = N.x * nx + N.y * ny + N.z * nz;
+      dc = dot > 0.0f ? dot : 0.0f;
+      ok = ok && dc >= tmin && dc <= 1.0f;
+    }
     const int idx = __float_as_int( P.w );
-    if( d2 < L.radius_sq && dc >= L.gate_tmin && dc <= 1.0f && lex_less( d2, idx, m.d2, m.idx ) )
-    { m.d2 = d2; m.idx = idx; m.dot = dc; m.slot = (int)s; m.found = true; }
+    if( ok && lex_less( d2, idx, m.d2, m.idx ) ) { m.d2 = d2; m.idx = idx; m.dot = dc; m.slot = (int)s; m.found = true; }
   }
   return m;
 }
+__device__ __forceinline__ Match icp_cell_seed( const IcpLaunch& L, bool active, float qx, float qy, float qz, float nx, float ny, float nz )
+{ return cell_seed<true>( L.tgt, active, qx, qy, qz, nx, ny, nz, L.radius_sq, L.gate_tmin ); }
 
 __device__ __forceinline__ Match icp_warm_start( const IcpLaunch& L, int prob, int i, bool active,
                                                  float qx, float qy, float qz, float nx, float ny, float nz )
@@ -1138,6 +1147,8 @@ __global__ __launch_bounds__( BLOCK, RS_SCORE_OCC ) void k_score( ScoreLaunch L 
   float qx, qy, qz, nx, ny, nz;
   score_query( L, X, i, active, qx, qy, qz, nx, ny, nz );
   bool handoff;
+  // (starting from the query's own cell, as the cold ICP search does, measured 10 % slower here: bad poses leave
+  //  most lanes without a usable point in their cell, and the mixed tiles pay for the seed without skipping the shells)
   Match m = tile_search<true>( L.scene, active, qx, qy, qz, nx, ny, nz, (float)L.sigma, L.radius_sq, L.gate_tmin, L.K,
                                lds[wib], lane, L.solo_stages, &handoff, nullptr, no_match() );
   if( handoff )
