@@ -326,6 +326,41 @@ def test_seeded_scene_vs_oracle(capi, oracle):
         assert all(a.shape == b.shape and (a == b).all() for a, b in zip(w_b, g_b))
 
 
+def test_quarter_million_points_vs_oracle(capi, oracle):
+    """Scan-to-scan ICP on ~280 k points each: large enough for every mechanism of the search to engage
+    (hand-off to the cooperative kernel, certificates, slow-tile lists, chunked device-side loop), small
+    enough for the oracle (~15 s).  Correspondences bit-exact, pose within the north-star tolerance,
+    same number of iterations."""
+    from rescan_amd import synth
+    s0 = synth.scene_for_point_count(250_000, seed=23, timestep=0)
+    s1 = synth.scene_for_point_count(250_000, seed=23, timestep=1)
+    a, b = capi.Cloud(s0["points"], s0["normals"]), capi.Cloud(s1["points"], s1["normals"])
+    T0 = synth.perturbed_pose(I4, np.random.default_rng(3), 0.02, 0.02)
+    ang = np.float32(np.deg2rad(60.0))
+    want = oracle.icp_find_corrs(s1["points"], s1["normals"], s0["points"], s0["normals"], T0, I4, 0.1, ang)
+    got = capi.icp_find_corrs(b, a, T0, I4, 0.1, np.deg2rad(60.0))
+    assert all(x.shape == y.shape and (x == y).all() for x, y in zip(want, got))
+    e_o, T_o, it_o = oracle.icp_align(s1["points"], s1["normals"], s0["points"], s0["normals"], T0, I4, 0.1, ang)
+    e_g, T_g, it_g = capi.icp_align(b, a, T0, I4, 0.1, np.deg2rad(60.0))
+    assert it_o == it_g and np.linalg.norm(T_o.astype(np.float64) - T_g) < POSE_TOL and abs(float(e_o) - float(e_g)) < 1e-6
+    # scores (good and bad poses of a 10 k-point table) and the label transfer of 8 placements, same scene
+    rng = np.random.default_rng(8)
+    op, on = synth.make_object("table", 77, density=3800.0)
+    tbl = [o for o in s1["objects"] if o["kind"] == "table"][0]
+    poses = np.stack([synth.perturbed_pose(tbl["pose"], rng, 0.02 if k < 4 else 0.5, 0.02 if k < 4 else 0.25) for k in range(16)])
+    sc_o = oracle.alignment_scores(s1["points"], s1["normals"], op, on, poses, 64)
+    sc_g = capi.alignment_scores(capi.Cloud(op, on), b, poses, 0.1, 64)
+    assert np.abs(sc_o.astype(np.float64) - sc_g).max() < SCORE_TOL
+    objs, plcs = [], []
+    for k, o in enumerate(s1["objects"][:8]):
+        objs.append(dict(pos=o["pos"], nor=o["nor"], class_idx=o["class_idx"], is_static=int(k % 3 == 0)))
+        plcs.append(dict(pose=synth.perturbed_pose(o["pose"], rng, 0.01, 0.005), object_idx=k, uidx=o["uidx"]))
+    want = oracle.arrangement_to_labels(s1["points"], s1["normals"], objs, plcs, 0.05, 0, 0)
+    res = capi.arrangement_to_labels(b, np.stack([p["pose"] for p in plcs]), [capi.Cloud(o["pos"], o["nor"]) for o in objs],
+                                     [o["is_static"] for o in objs], [o["class_idx"] for o in objs], 0.05, False)
+    assert (res["labels"] == want["labels"]).all() and (res["min_dists"] == want["min_dists"]).all() and (res["order"] == want["order"]).all()
+
+
 # ---- size-independent properties at BASELINE.json's full size (~1M-point clouds) -----------
 
 def test_full_size_properties(capi):
