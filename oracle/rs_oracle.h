@@ -12,7 +12,13 @@
  * the *composition* of the label loop (lib/rs/rs_pointcloud_filters.cpp:738-879)
  * is restated but not run against the reference, because that TU needs the
  * un-vendored gco-v3.0 header; all primitives it calls (K=1 radius search,
- * mat4 inverse/transpose/mat·vec, normalise, the acosf gate) are pinned.
+ * mat4 inverse/transpose/mat·vec, normalise, the acosf gate) are pinned.  The
+ * same holds for rspf_compute_neighborhood (:674-722, same TU): its pieces are
+ * pinned (unsorted K=8 search; the edge weight compiled in a TU with that file's
+ * include preamble) and the composition is checked against those pieces.
+ * The scene-coverage term (orc_voxgrid_*, orc_rasterize_*, orc_coverage_score)
+ * is pinned against the reference TU itself: apps/segment_transfer/
+ * arrangement_optimization.cpp compiles from its own sources (oracle/_ref/libref_ao.so).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use
  * this library.  The product (rescan_amd/, include/) never links or loads it.
