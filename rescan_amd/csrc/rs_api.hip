@@ -567,13 +567,19 @@ namespace {
 // too few tiles to hide such stragglers behind other work (measured on MI355X: 1 M-query ICP,
 // 15.6 k tiles: 0.60 -> 0.47 ms per search with hand-off; 256-pose score batch, 40 k tiles:
 // 1.5 -> 3.0 ms, i.e. worse), so big launches keep everything in phase A.
+// Hand-off rule of a search launch (rs_kernels.hip: tile_search): low 16 bits = candidates a lone wave may
+// stream while a lane is unsettled, high bits = the shell after which an unsettled tile is handed off whatever it
+// streamed.  A wave that runs almost alone on its SIMD (few tiles in flight) is latency-bound, so the fewer tiles a
+// launch has, the earlier the cooperative kernel takes over; launches with > 24 k tiles (score batches) keep
+// everything in phase A — there the stragglers hide behind other tiles and the hand-off measured slower.
 inline int handoff_threshold( long long total_tiles )
 {
-  static int forced = -2;
-  if( forced == -2 ) { const char* e = getenv( "RS_HIP_SOLO_STAGES" ); forced = e ? atoi( e ) : -1; }
-  static const int k_always = getenv( "RS_HIP_HANDOFF_K" ) ? atoi( getenv( "RS_HIP_HANDOFF_K" ) ) : 0;
-  if( forced > 0 ) return forced | ( k_always << 16 );
-  return total_tiles <= 24000 ? ( 192 | ( k_always << 16 ) ) : 0x7fffffff;
+  static const int forced = getenv( "RS_HIP_SOLO_STAGES" ) ? atoi( getenv( "RS_HIP_SOLO_STAGES" ) ) : -1;
+  static const int forced_k = getenv( "RS_HIP_HANDOFF_K" ) ? atoi( getenv( "RS_HIP_HANDOFF_K" ) ) : -1;
+  if( forced > 0 ) return forced | ( std::max( 0, forced_k ) << 16 );
+  if( total_tiles > 24000 ) return 0x7fffffff;
+  const int k_always = forced_k >= 0 ? forced_k : 1;
+  return ( total_tiles <= 12000 ? 128 : 192 ) | ( k_always << 16 );
 }
 
 inline float radius_sq_of( float r ) { return (float)( (double)r * (double)r ); }   // msh_hash_grid.h:1104,1111 + :828
