@@ -785,6 +785,7 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
       // a short queue is bound by its heaviest tile: from the third iteration on the certificates have
       // emptied it (small batches: always)
       cx.L.coop_waves = ( small || ( i >= 2 && cx.L.cert_r ) ) ? 8 : 4;
+      { static const int force = getenv( "RS_HIP_COOP_WAVES" ) ? atoi( getenv( "RS_HIP_COOP_WAVES" ) ) : 0; if( force ) cx.L.coop_waves = force; }
       if( reorder )
       {
         cx.L.heavy_in = i == 0 ? nullptr : ( ( i & 1 ) ? g_ws.order_a.as<int>() : g_ws.order_b.as<int>() );

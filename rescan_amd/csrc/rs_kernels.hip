@@ -207,6 +207,7 @@ __device__ __forceinline__ uint32_t sweep_shell( const GridView& g, const CellBo
 {
   const int ny = out.y1 - out.y0 + 1, nz = out.z1 - out.z0 + 1;
   const int n_rows = ny * nz;
+  const float inv_ny = 1.0f / (float)ny;
   uint32_t streamed = 0;
   // (Cooperating waves all enumerate the same rows and split the chunks; giving each wave whole
   //  row batches instead balanced worse and measured slower.)
@@ -218,7 +219,11 @@ __device__ __forceinline__ uint32_t sweep_shell( const GridView& g, const CellBo
     uint32_t sa = 0, la = 0, sb = 0, lb = 0;
     if( r < n_rows )
     {
-      const int y = out.y0 + r % ny, z = out.z0 + r / ny;
+      // r / ny, r % ny without the integer-division sequence: r < 2^20, so the float quotient is off by at most one
+      int rz = (int)( (float)r * inv_ny );
+      rz -= ( rz * ny > r ) ? 1 : 0;
+      rz += ( ( rz + 1 ) * ny <= r ) ? 1 : 0;
+      const int y = out.y0 + ( r - rz * ny ), z = out.z0 + rz;
       const uint32_t* cs = g.cell_start + (size_t)( z * g.h + y ) * g.w;
       const bool inside = in_valid && y >= in.y0 && y <= in.y1 && z >= in.z0 && z <= in.z1;
       if( !inside ) { sa = cs[out.x0]; la = cs[out.x1 + 1] - sa; }
@@ -785,10 +790,10 @@ __device__ __forceinline__ void icp_emit( const IcpLaunch& L, int prob, int tile
     if( lane == 0 ) { atomicAdd( cat + 0, (unsigned long long)c_skip ); atomicAdd( cat + 1, (unsigned long long)c_fresh ); atomicAdd( cat + 2, (unsigned long long)c_rank ); atomicAdd( cat + 3, (unsigned long long)c_loose ); }
   }
   // statistics of dist² over correspondences (msh_compute_mean/stddev, msh_std.h:1800-1825)
-  double c = ( active && m.found ) ? 1.0 : 0.0;
+  const double c = (double)__popcll( __ballot( active && m.found ) );
   double s1 = ( active && m.found ) ? (double)m.d2 : 0.0;
   double s2 = ( active && m.found ) ? (double)( m.d2 * m.d2 ) : 0.0;
-  c = wave_sum( c ); s1 = wave_sum( s1 ); s2 = wave_sum( s2 );
+  s1 = wave_sum( s1 ); s2 = wave_sum( s2 );
   if( lane == 0 )
   {
     double* out = L.corr_part + ( (size_t)prob * L.src.n_tiles + tile ) * 3;
