@@ -457,21 +457,26 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
 {
   if( handoff ) *handoff = false;
   int sweeps = 0;
-  const TileBounds tb = wave_bounds( active, qx, qy, qz );
-  if( !tb.any ) return m;
-  const CellBox full = cell_box( g, tb, radius );
-  if( box_empty( full ) ) return m;
-  CellBox core = cell_box( g, tb, 0.0f );
-  core = box_grow( core, 0, full );
-  if( box_empty( core ) ) core = full;             // the tile lies outside the grid but within reach of it
-
+  if( !__any( active ) ) return m;
   int seen_closer = 0;   // candidates that were no farther than the best-so-far when they were met
   float bound = bound_of( active, radius_sq, m );
-  CellBox cur = core, prev = core;
-  bool have_prev = false;
   uint32_t streamed = 0;
   const bool grid = g.inv_cell > 0.0f;
-  if( WARM && grid && !__any( active & !m.found ) )
+  const bool all_bounded = WARM && grid && !__any( active & !m.found );
+  CellBox full, core, cur, prev;
+  if( all_bounded ) { full.x0 = full.y0 = full.z0 = 0; full.x1 = g.w - 1; full.y1 = g.h - 1; full.z1 = g.d - 1; core = full; }   // only clips reach_box below
+  else
+  {
+    const TileBounds tb = wave_bounds( active, qx, qy, qz );
+    full = cell_box( g, tb, radius );
+    if( box_empty( full ) ) return m;
+    core = cell_box( g, tb, 0.0f );
+    core = box_grow( core, 0, full );
+    if( box_empty( core ) ) core = full;           // the tile lies outside the grid but within reach of it
+  }
+  cur = core; prev = core;
+  bool have_prev = false;
+  if( all_bounded )
   {
     // Every lane starts from a genuine candidate (ICP iterations >= 2): whatever can beat or precede it
     // lies within its distance, so ONE sweep of the cells those small boxes touch settles the tile —
