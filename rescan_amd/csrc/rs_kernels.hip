@@ -923,8 +923,11 @@ __global__ __launch_bounds__( STATS_BLOCK ) void k_icp_stats( IcpLaunch L )
 }
 
 // Phase B: one workgroup per queued tile, whole box, chunks shared by its waves.
+#ifndef RS_COOP_OCC
+#define RS_COOP_OCC 6      // waves per SIMD the cooperative kernel's register allocation aims at
+#endif
 template <int NW>
-__global__ __launch_bounds__( NW * WAVE ) void k_icp_corr_coop( IcpLaunch L )
+__global__ __launch_bounds__( NW * WAVE, RS_COOP_OCC ) void k_icp_corr_coop( IcpLaunch L )
 {
   __shared__ WaveLds lds[NW];
   __shared__ CoopLds<NW> coop;
