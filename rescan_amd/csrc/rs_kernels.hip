@@ -5,20 +5,24 @@
 // 64 spatially adjacent query points (Hilbert order, rs_api.hip) and searches the grid cells
 // around the tile's bounding box in EXPANDING SHELLS:
 //
-//   stage 1 sweeps the cells overlapping the box grown by one cell, stage 2 the shell out to
-//   two cells, then four, ... up to the box grown by the search radius.  After a stage a lane
-//   is finished when its best match lies closer than the nearest face of the swept box that
-//   can still grow (nothing unseen can precede it), and the wave stops when all its lanes
-//   are.  For nearly aligned clouds almost every tile stops after the first stage, i.e. it
-//   tests a few hundred candidates instead of everything within the radius.
+//   the tile's own cells first, then the box grown by one cell, two, four, ... up to the box grown
+//   by the search radius; of each shell only the part within reach of a lane that is still unsettled.
+//   After a shell a lane is settled when its best match lies closer than the nearest face of the
+//   swept box that can still grow (nothing unseen can precede it), and the wave stops when all its
+//   lanes are.  A tile whose lanes all start from a genuine candidate (ICP: last iteration's match,
+//   or a point of the query's own cell) needs no shells at all: one sweep of the cells within those
+//   candidates' distances settles it — a hundred or two candidates instead of everything within the
+//   radius.  Tiles that stay unsettled are handed to a second kernel that gives each of them a whole
+//   workgroup (coop_search); what cannot be bounded at all — a point with nothing to match — is
+//   remembered from one ICP iteration to the next (icp_certificate).
 //
 // The row pieces of a shell (one or two x-intervals per (y,z) row of cells, each a contiguous
 // span of the cell-sorted cloud) are gathered by the lanes in parallel, prefix-summed, and
 // consumed as ONE flattened stream: every lane fetches "candidate number j" of the stream
 // (binary search over the piece offsets), so each 64-record chunk staged in LDS is full.
 // All lanes then test the same candidate at the same time through an LDS broadcast read
-// (ds_read_b128, one address for the whole wave: conflict-free).  Waves never synchronise with
-// each other; there is no workgroup barrier on the search path.
+// (ds_read_b128, one address for the whole wave: conflict-free).  In phase A waves never synchronise
+// with each other; the cooperative kernel merges its waves' results through LDS after every shell.
 //
 // Arithmetic that decides *which* neighbour wins is kept in the reference's own order and
 // precision (the file is compiled with -ffp-contract=off):
