@@ -205,87 +205,8 @@ struct rs_hip_cloud
 
 namespace {
 
-// Cell coordinate of a stored point along one axis; the kernels' axis_range() covers this
-// expression with a 0.01-cell margin.
-inline int cell_of( float v, float gmin, float inv_cell, int dim )
-{
-  float c = floorf( ( v - gmin ) * inv_cell );
-  if( !( c >= 0.0f ) ) c = 0.0f;
-  if( c > (float)( dim - 1 ) ) c = (float)( dim - 1 );
-  return (int)c;
-}
-
-
 // ---- query layout ---------------------------------------------------------------------------
-// Index of a cell on a 3-D Hilbert curve with `bits` bits per axis (Skilling's transpose form).
-// Consecutive cells of the curve are face neighbours, so consecutive points are spatially close
-// wherever the surface is continuous.
-inline uint32_t hilbert3( uint32_t x, uint32_t y, uint32_t z, int bits )
-{
-  uint32_t X[3] = { x, y, z };
-  const uint32_t M = 1u << ( bits - 1 );
-  for( uint32_t Q = M; Q > 1; Q >>= 1 )
-  {
-    const uint32_t P = Q - 1;
-    for( int i = 0; i < 3; ++i )
-    {
-      if( X[i] & Q ) X[0] ^= P;
-      else { uint32_t t = ( X[0] ^ X[i] ) & P; X[0] ^= t; X[i] ^= t; }
-    }
-  }
-  X[1] ^= X[0]; X[2] ^= X[1];
-  uint32_t t = 0;
-  for( uint32_t Q = M; Q > 1; Q >>= 1 ) if( X[2] & Q ) t ^= Q - 1;
-  X[0] ^= t; X[1] ^= t; X[2] ^= t;
-  uint32_t h = 0;
-  for( int b = bits - 1; b >= 0; --b )
-    for( int i = 0; i < 3; ++i ) h = ( h << 1 ) | ( ( X[i] >> b ) & 1u );
-  return h;
-}
-
-// Hilbert order of the points + greedy tiling: a tile ends after 64 points or when adding the
-// next point would stretch its bounding box beyond `max_extent` on any axis (the curve crosses
-// empty space there).  Any tiling is correct — tiles only decide which candidates a wave
-// stages — so this is purely a load-balance / locality choice.
-void build_query_layout( const float* pos, int32_t n, float max_extent, std::vector<int32_t>& order, std::vector<uint32_t>& tiles )
-{
-  order.resize( (size_t)n ); tiles.clear(); tiles.push_back( 0u );
-  if( n == 0 ) return;
-  float mn[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, mx[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
-  for( int32_t i = 0; i < n; ++i ) for( int a = 0; a < 3; ++a ) { float v = pos[3*i+a]; if( v < mn[a] ) mn[a] = v; if( v > mx[a] ) mx[a] = v; }
-  float ext = 0.0f;
-  for( int a = 0; a < 3; ++a ) { float e = mx[a] - mn[a]; if( std::isfinite( e ) && e > ext ) ext = e; }
-  const int bits = 10;
-  const float scale = ext > 0.0f ? (float)( 1 << bits ) / ext : 0.0f;
-  std::vector<uint64_t> key( (size_t)n );
-  for( int32_t i = 0; i < n; ++i )
-  {
-    uint32_t c[3];
-    for( int a = 0; a < 3; ++a )
-    {
-      float f = ( pos[3*i+a] - mn[a] ) * scale;
-      if( !( f >= 0.0f ) ) f = 0.0f;
-      if( f > (float)( ( 1 << bits ) - 1 ) ) f = (float)( ( 1 << bits ) - 1 );
-      c[a] = (uint32_t)f;
-    }
-    key[i] = ( (uint64_t)hilbert3( c[0], c[1], c[2], bits ) << 32 ) | (uint32_t)i;
-  }
-  std::sort( key.begin(), key.end() );
-  for( int32_t s = 0; s < n; ++s ) order[s] = (int32_t)( key[s] & 0xffffffffu );
-  float lo[3], hi[3]; int count = 0;
-  for( int32_t s = 0; s < n; ++s )
-  {
-    const float* p = pos + 3 * (size_t)order[s];
-    bool cut = count == 64;
-    if( !cut && count > 0 )
-      for( int a = 0; a < 3; ++a ) { float l = std::min( lo[a], p[a] ), h = std::max( hi[a], p[a] ); if( h - l > max_extent ) cut = true; }
-    if( cut ) { tiles.push_back( (uint32_t)s ); count = 0; }
-    if( count == 0 ) { for( int a = 0; a < 3; ++a ) { lo[a] = hi[a] = p[a]; } }
-    else for( int a = 0; a < 3; ++a ) { lo[a] = std::min( lo[a], p[a] ); hi[a] = std::max( hi[a], p[a] ); }
-    count++;
-  }
-  tiles.push_back( (uint32_t)n );
-}
+// (Hilbert order + greedy tiling are computed on the device: rs_build.hip.)
 
 // Tile extent limit from the cloud's own sampling density: a full tile of 64 surface samples
 // spans about 8 sample spacings; allow half as much again, and never less than 0.25 m.
@@ -1094,29 +1015,59 @@ int rs_hip_radius_search( const rs_hip_cloud_t* target, const float* query, int6
   if( n_query == 0 ) return RS_HIP_OK;
   const int nq = (int)n_query;
   const GridView& g = target->view;
-  // order the queries along a Hilbert curve and tile them, exactly like a cloud's query layout
-  std::vector<int32_t> qorder; std::vector<uint32_t> tiles;
-  build_query_layout( query, nq, std::max( 0.25f, 4.0f * radius ), qorder, tiles );
-  std::vector<float4> q4( nq );
-  for( int s = 0; s < nq; ++s ) { int i = qorder[s]; float w; std::memcpy( &w, &i, 4 ); q4[s] = make_float4( query[3*i], query[3*i+1], query[3*i+2], w ); }
-  const size_t nk = (size_t)nq * k;
-  if( ( rc = g_ws.q4.ensure( (size_t)nq * 16 ) ) || ( rc = g_ws.tmp_pos.ensure( tiles.size() * 4 ) ) || ( rc = g_ws.rd2.ensure( nk * 4 ) ) || ( rc = g_ws.ridx.ensure( nk * 4 ) ) || ( rc = g_ws.rnn.ensure( (size_t)nq * 4 ) ) ) return rc;
-  HIP_TRY( hipMemcpyAsync( g_ws.q4.p, q4.data(), (size_t)nq * 16, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
-  HIP_TRY( hipMemcpyAsync( g_ws.tmp_pos.p, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+  // order the queries along a Hilbert curve and tile them on the device, exactly like a cloud's query layout
+  Workspace& W = g_ws;
+  const size_t nn = (size_t)nq, nk = nn * k;
+  const size_t tmp_bytes = std::max( build_sort_temp_bytes( nq, 32 ), build_scan_temp_bytes( nn + 1 ) );
+  if( ( rc = W.bld_pos.ensure( nn * 12 ) ) || ( rc = W.bld_k0.ensure( ( nn + 1 ) * 4 ) ) || ( rc = W.bld_k1.ensure( ( nn + 1 ) * 4 ) ) || ( rc = W.bld_v0.ensure( nn * 4 ) ) ||
+      ( rc = W.bld_v1.ensure( nn * 4 ) ) || ( rc = W.bld_v2.ensure( nn * 4 ) ) || ( rc = W.bld_small.ensure( 64 ) ) || ( rc = W.bld_tmp.ensure( tmp_bytes + 256 ) ) ||
+      ( rc = W.q4.ensure( nn * 16 ) ) || ( rc = W.tmp_pos.ensure( ( nn + 2 ) * 4 ) ) || ( rc = W.rd2.ensure( nk * 4 ) ) || ( rc = W.ridx.ensure( nk * 4 ) ) || ( rc = W.rnn.ensure( nn * 4 ) ) ) return rc;
+  float* d_raw = W.bld_pos.as<float>();
+  uint32_t *k0 = W.bld_k0.as<uint32_t>(), *k1 = W.bld_k1.as<uint32_t>(), *v0 = W.bld_v0.as<uint32_t>(), *v1 = W.bld_v1.as<uint32_t>(), *v2 = W.bld_v2.as<uint32_t>();
+  unsigned* d_small = W.bld_small.as<unsigned>();
+  HIP_TRY( hipMemcpyAsync( d_raw, query, nn * 12, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+  const unsigned init[8] = { ~0u, ~0u, ~0u, 0u, 0u, 0u, 0u, 0u };
+  unsigned got[8];
+  HIP_TRY( hipMemcpyAsync( d_small, init, 32, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+  launch_build_bounds( d_raw, nullptr, nq, d_small, g_stream );
+  HIP_TRY( hipMemcpyAsync( got, d_small, 32, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
+  auto dec = []( unsigned u ) { unsigned b = ( u & 0x80000000u ) ? ( u ^ 0x80000000u ) : ~u; float f; std::memcpy( &f, &b, 4 ); return f; };
+  float mn[3], ext = 0.0f;
+  for( int a = 0; a < 3; ++a )
+  {
+    mn[a] = dec( got[a] ); const float hi = dec( got[3 + a] );
+    if( !( hi >= mn[a] ) || !std::isfinite( mn[a] ) || !std::isfinite( hi ) ) mn[a] = 0.0f;
+    else if( hi - mn[a] > ext ) ext = hi - mn[a];
+  }
+  launch_build_hilbert( d_raw, nq, mn, ext > 0.0f ? 1024.0f / ext : 0.0f, k0, v0, g_stream );
+  if( build_sort_pairs( W.bld_tmp.p, tmp_bytes, k0, k1, v0, v2, nq, 30, g_stream ) ) { set_err( "radius_search: device sort failed" ); return RS_HIP_E_RUNTIME; }
+  launch_build_gather( d_raw, nullptr, v2, nq, W.q4.as<float4>(), nullptr, g_stream );          // {x, y, z, bitcast(original query index)}
+  uint32_t* flags = k0; uint32_t* scanned = k1;
+  HIP_TRY( hipMemsetAsync( flags + nq, 0, 4, g_stream ), RS_HIP_E_RUNTIME );
+  launch_build_tile_flags( W.q4.as<float4>(), nq, std::max( 0.25f, 4.0f * radius ), flags, v0, v1, g_stream );
+  if( build_exclusive_scan( W.bld_tmp.p, tmp_bytes, flags, scanned, nn + 1, g_stream ) ) { set_err( "radius_search: device scan failed" ); return RS_HIP_E_RUNTIME; }
+  unsigned n_tiles_u = 0;
+  HIP_TRY( hipMemcpyAsync( &n_tiles_u, scanned + nq, 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
+  const int n_tiles = (int)n_tiles_u;
+  launch_build_tile_scatter( flags, scanned, nq, W.tmp_pos.as<uint32_t>(), g_stream );
+  const uint32_t last = (uint32_t)nq;
+  HIP_TRY( hipMemcpyAsync( W.tmp_pos.as<uint32_t>() + n_tiles, &last, 4, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
   HIP_TRY( hipMemsetAsync( g_ws.rd2.p, 0, nk * 4, g_stream ), RS_HIP_E_RUNTIME );
   HIP_TRY( hipMemsetAsync( g_ws.ridx.p, 0, nk * 4, g_stream ), RS_HIP_E_RUNTIME );
   RowsLaunch L{};
-  L.tgt = g; L.q.pos = g_ws.q4.as<float4>(); L.q.nor = nullptr; L.q.tiles = g_ws.tmp_pos.as<uint32_t>(); L.q.n = nq; L.q.n_tiles = (int)tiles.size() - 1;
+  L.tgt = g; L.q.pos = g_ws.q4.as<float4>(); L.q.nor = nullptr; L.q.tiles = g_ws.tmp_pos.as<uint32_t>(); L.q.n = nq; L.q.n_tiles = n_tiles;
   L.K = k; L.radius = radius; L.radius_sq = radius_sq_of( radius );
   L.d2 = g_ws.rd2.as<float>(); L.idx = g_ws.ridx.as<int>(); L.nn = g_ws.rnn.as<int>();
   { ProfScope ps( "nn_rows" ); launch_rows( L, g_stream ); }
-  std::vector<int> nn( nq );
+  std::vector<int> counts( nq );
   HIP_TRY( hipMemcpyAsync( distances_sq, L.d2, nk * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
   HIP_TRY( hipMemcpyAsync( indices, L.idx, nk * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
-  HIP_TRY( hipMemcpyAsync( nn.data(), L.nn, (size_t)nq * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipMemcpyAsync( counts.data(), L.nn, (size_t)nq * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
   HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
   uint64_t tot = 0;
-  for( int i = 0; i < nq; ++i ) { tot += (uint64_t)nn[i]; if( n_neighbors ) n_neighbors[i] = (size_t)nn[i]; }
+  for( int i = 0; i < nq; ++i ) { tot += (uint64_t)counts[i]; if( n_neighbors ) n_neighbors[i] = (size_t)counts[i]; }
   if( total ) *total = tot;
   return RS_HIP_OK;
 }
