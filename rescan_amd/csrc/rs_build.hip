@@ -55,7 +55,7 @@ __global__ __launch_bounds__( B_BLOCK ) void k_build_mark( const float* pos, int
   atomicOr( bits + ( id >> 5 ), 1u << ( id & 31 ) );
 }
 
-// cell coordinate of a stored point along one axis (identical to the host's cell_of, rs_api.hip)
+// cell coordinate of a stored point along one axis (the search kernels' axis_range covers this expression with a 0.01-cell margin)
 __device__ __forceinline__ int cell_of_dev( float v, float gmin, float inv_cell, int dim )
 {
   float c = floorf( ( v - gmin ) * inv_cell );
