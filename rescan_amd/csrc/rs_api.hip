@@ -692,7 +692,9 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
   const size_t np = (size_t)n, state_bytes = np * ICP_STATE_WORDS * 4;
   float* hS = g_ws.h_b.as<float>();
   const int* hActive = (const int*)( hS + np * 16 );
-  const bool small = (long long)cx.n_waves * n < 2400;      // the cooperative queue is short from the start
+  const long long total_tiles = (long long)cx.n_waves * n;
+  static const long long coop_all_below = getenv( "RS_HIP_COOP_ALL_BELOW" ) ? atoll( getenv( "RS_HIP_COOP_ALL_BELOW" ) ) : 4096;
+  static const int coop_waves_forced = getenv( "RS_HIP_COOP_WAVES" ) ? atoi( getenv( "RS_HIP_COOP_WAVES" ) ) : 0;
   cx.L.solve = 1; cx.L.fixed_iters = fixed_iters ? 1 : 0;
   ProfChain prof;
   for( int i = 0; i < max_iter; )                                       // icp.h:444
@@ -705,8 +707,11 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
       cx.L.warm = ( i > 0 && !getenv( "RS_HIP_NO_WARM" ) ) ? 1 : 0;   // every active problem wrote m_slot in iteration i-1
       // a short queue is bound by its heaviest tile: from the third iteration on the certificates have
       // emptied it (small batches: always)
-      cx.L.coop_waves = ( small || ( i >= 2 && cx.L.cert_r ) ) ? 8 : 4;
-      { static const int force = getenv( "RS_HIP_COOP_WAVES" ) ? atoi( getenv( "RS_HIP_COOP_WAVES" ) ) : 0; if( force ) cx.L.coop_waves = force; }
+      // launches of a few thousand tiles go straight to the cooperative kernel (launch_icp_corr); it is bound by its
+      // heaviest tile while the list is short (8 waves per tile), by throughput beyond (4)
+      cx.L.coop_all = total_tiles <= coop_all_below ? 1 : 0;
+      cx.L.coop_waves = cx.L.coop_all ? ( total_tiles <= 1536 ? 8 : 4 ) : ( ( i >= 2 && cx.L.cert_r ) ? 8 : 4 );
+      if( coop_waves_forced ) cx.L.coop_waves = coop_waves_forced;
       if( reorder )
       {
         cx.L.heavy_in = i == 0 ? nullptr : ( ( i & 1 ) ? g_ws.order_a.as<int>() : g_ws.order_b.as<int>() );

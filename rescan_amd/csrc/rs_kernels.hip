@@ -940,13 +940,13 @@ __global__ __launch_bounds__( NW * WAVE, RS_COOP_OCC ) void k_icp_corr_coop( Icp
   if( L.active[prob] == 0 ) return;
   const int lane = threadIdx.x & ( WAVE - 1 );
   const int wib = threadIdx.x / WAVE;
-  const int n_queued = L.queue_count[prob];
+  const int n_queued = L.coop_all ? L.src.n_tiles : L.queue_count[prob];     // coop_all: phase A was not launched, every tile is searched here
   Xform T1;
 #pragma unroll
   for( int k = 0; k < 16; ++k ) T1.m[k] = L.T1[prob * 16 + k];
   for( int b = blockIdx.x; b < n_queued; b += gridDim.x )
   {
-    const int tile = L.queue[(size_t)prob * L.src.n_tiles + b];
+    const int tile = L.coop_all ? b : L.queue[(size_t)prob * L.src.n_tiles + b];
     const int i = (int)L.src.tiles[tile] + lane;
     const bool active = i < (int)L.src.tiles[tile + 1];
     float qx, qy, qz, nx, ny, nz;
@@ -1099,8 +1099,10 @@ __global__ __launch_bounds__( UPDATE_WAVES * WAVE ) void k_icp_update( IcpLaunch
 void launch_icp_corr( const IcpLaunch& L, hipStream_t st )
 {
   // queue_count is zero on entry: cleared once by the host, then by the cooperative kernel's last workgroup after every use
+  // A launch of a few hundred tiles leaves every wave alone on its SIMD, i.e. latency-bound, and phase A's slowest tile
+  // sets its time: such launches skip phase A and give every tile a workgroup straight away (coop_all).
   dim3 grid( ( L.src.n_tiles + ( L.heavy_in ? HEAVY_SLOTS : 0 ) + WAVES_PER_BLOCK - 1 ) / WAVES_PER_BLOCK, L.n_prob );
-  hipLaunchKernelGGL( k_icp_corr, grid, dim3( BLOCK ), 0, st, L );
+  if( !L.coop_all ) hipLaunchKernelGGL( k_icp_corr, grid, dim3( BLOCK ), 0, st, L );
   // the queue length is only known on the device: a fixed grid strides over it
   int coop_blocks = L.src.n_tiles < 2048 ? L.src.n_tiles : 2048;
   const dim3 cgrid( coop_blocks > 0 ? coop_blocks : 1, L.n_prob );
