@@ -304,6 +304,12 @@ def main():
                          "avg_launch_ms": ms / max(1, n_l), "launches": n_l, "alg_bytes_per_launch": bytes_launch},
             "kernel_ms_per_step": {k: v[1] / args.steps for k, v in prof.items()},
         }
+        # "the real limiter is candidate evaluation ... so also report candidate-evals/s"
+        # (candidates staged in LDS x the 64 query lanes that test each of them)
+        cand = capi.profile_read("candidates")[0]
+        line["candidate_evals"] = {"per_step": cand * 64 / args.steps, "per_s": cand * 64 / elapsed,
+                                   "candidates_staged_per_step": cand / args.steps,
+                                   "per_point_pair": cand * 64 / args.steps / max(1, sum(w["pairs"].values()))}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 cb = cpu_baseline(w)

@@ -41,7 +41,9 @@ const char* rs_hip_version( void );
 /* Per-kernel timing with HIP events recorded on the launch stream.  While enabled, each
  * launch of a hot kernel is bracketed by an event pair; rs_hip_profile_read() synchronises
  * and returns launch count and summed milliseconds for kernel `name`
- * ("nn_icp", "icp_moments", "nn_score", "nn_label", "nn_rows"). */
+ * ("nn_icp", "icp_moments", "nn_score", "nn_label", "nn_rows", "edges", "coverage").  The name "candidates" is
+ * not a kernel: its launch count is the number of candidates the search kernels staged and evaluated
+ * since the last reset (each of them by the 64 query lanes of its wave) — SURVEY.md §8d's second figure. */
 int         rs_hip_profile_enable( int on );
 int         rs_hip_profile_reset( void );
 int         rs_hip_profile_read( const char* name, int64_t* launches, double* total_ms );

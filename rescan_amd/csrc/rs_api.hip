@@ -114,6 +114,7 @@ bool g_prof = false;
 std::mutex g_prof_mutex;
 struct ProfEntry { std::vector<std::pair<hipEvent_t, hipEvent_t>> spans; int64_t launches = 0; double ms = 0.0; };
 std::map<std::string, ProfEntry> g_profmap;
+unsigned long long* g_evals = nullptr;  // device counter of staged-and-evaluated candidates (all threads, all kernels) while profiling
 std::vector<hipEvent_t> g_evpool;      // events are handed out in order and recycled by prof_collect
 size_t g_evnext = 0;
 
@@ -255,17 +256,42 @@ int rs_hip_synchronize( void )
   return RS_HIP_OK;
 }
 
-int rs_hip_profile_enable( int on ) { g_prof = on != 0; return RS_HIP_OK; }
+int rs_hip_profile_enable( int on )
+{
+  if( on && !g_evals )
+  {
+    int rc = ensure_ready(); if( rc ) return rc;
+    HIP_TRY( hipMalloc( (void**)&g_evals, EVAL_SHARDS * 64 ), RS_HIP_E_RUNTIME );
+    HIP_TRY( hipMemset( g_evals, 0, EVAL_SHARDS * 64 ), RS_HIP_E_RUNTIME );
+  }
+  g_prof = on != 0;
+  return RS_HIP_OK;
+}
 int rs_hip_profile_reset( void )
 {
   prof_collect();
   std::lock_guard<std::mutex> lock( g_prof_mutex );
   for( auto& kv : g_profmap ) { kv.second.launches = 0; kv.second.ms = 0.0; }
+  if( g_evals ) (void)hipMemset( g_evals, 0, EVAL_SHARDS * 64 );
   return RS_HIP_OK;
 }
 int rs_hip_profile_read( const char* name, int64_t* launches, double* total_ms )
 {
   prof_collect();
+  if( name && !std::strcmp( name, "candidates" ) )
+  {
+    // not a kernel: the number of candidates staged and evaluated since the last reset (each by the 64 lanes of its wave)
+    unsigned long long v = 0;
+    if( g_evals )
+    {
+      std::vector<unsigned long long> h( (size_t)EVAL_SHARDS * 8 );
+      (void)hipMemcpy( h.data(), g_evals, h.size() * 8, hipMemcpyDeviceToHost );
+      for( int k = 0; k < EVAL_SHARDS; ++k ) v += h[(size_t)k * 8];
+    }
+    if( launches ) *launches = (int64_t)v;
+    if( total_ms ) *total_ms = 0.0;
+    return RS_HIP_OK;
+  }
   std::lock_guard<std::mutex> lock( g_prof_mutex );
   auto it = g_profmap.find( name ? name : "" );
   if( it == g_profmap.end() ) { if( launches ) *launches = 0; if( total_ms ) *total_ms = 0.0; return RS_HIP_OK; }
@@ -520,7 +546,7 @@ int icp_prepare( IcpCtx& cx, const rs_hip_cloud_t* src, const rs_hip_cloud_t* tg
   if( !src || !tgt || !src->has_nor || !tgt->has_nor ) { set_err( "icp: source and target clouds need normals" ); return RS_HIP_E_ARG; }
   if( n_prob <= 0 ) { set_err( "icp: empty batch" ); return RS_HIP_E_ARG; }
   IcpLaunch& L = cx.L;
-  L.tgt = tgt->view; L.src = src->qview; L.n_prob = n_prob; L.K = 16;   // icp.h:330
+  L.tgt = tgt->view; L.tgt.evals = g_prof ? g_evals : nullptr; L.src = src->qview; L.n_prob = n_prob; L.K = 16;   // icp.h:330
   Mat4 t2; std::memcpy( t2.m, T2, 64 );
   Mat4 t2i = mat4_inverse( t2 );                                                                             // icp.h:329
   std::memcpy( L.T2i.m, t2i.m, 64 );
@@ -880,7 +906,7 @@ int rs_hip_alignment_scores( const rs_hip_cloud_t* object, const rs_hip_cloud_t*
     return rc;
   HIP_TRY( hipMemcpyAsync( g_ws.poses.p, poses, (size_t)n_poses * 64, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
   ScoreLaunch L{};
-  L.scene = scene->view; L.obj = object->qview;
+  L.scene = scene->view; L.scene.evals = g_prof ? g_evals : nullptr; L.obj = object->qview;
   L.poses = g_ws.poses.as<float>(); L.radius_sq = radius_sq_of( radius ); L.gate_tmin = score_gate_threshold();
   L.K = max_n_neigh; L.sigma = (double)radius; L.part = g_ws.score_part.as<double>(); L.scores = g_ws.scores.as<float>();
   L.queue = g_ws.queue.as<int>(); L.queue_count = g_ws.queue_count.as<int>();
@@ -913,7 +939,7 @@ static int label_upload_placements( const rs_hip_placement_t* pl, int32_t n )
     if( !pl[i].object || !pl[i].object->has_nor ) { set_err( "labels: placement %d has no object cloud with normals", i ); return RS_HIP_E_ARG; }
     Mat4 pose; std::memcpy( pose.m, pl[i].pose, 64 );
     Mat4 inv = mat4_inverse( pose ), nm = mat4_transpose( pose );       // rs_pointcloud_filters.cpp:750-751
-    h[i].g = pl[i].object->view;
+    h[i].g = pl[i].object->view; h[i].g.evals = g_prof ? g_evals : nullptr;
     std::memcpy( h[i].inv.m, inv.m, 64 ); std::memcpy( h[i].nmat.m, nm.m, 64 );
     h[i].radius = pl[i].radius; h[i].radius_sq = radius_sq_of( pl[i].radius );
   }

@@ -9,6 +9,8 @@ namespace rs {
 // pos[s] = {x, y, z, bitcast(original index)};  nor[s] = {nx, ny, nz, 0}.
 // cell id = (z*h + y)*w + x, so the cells of one (y,z) row are contiguous in x and a row's
 // x-interval [x0,x1] is the single span cell_start[row+x0] .. cell_start[row+x1+1].
+constexpr int EVAL_SHARDS = 1024;
+
 struct GridView
 {
   const float4*   pos;
@@ -19,6 +21,7 @@ struct GridView
   float cell;                   // cell edge
   int   w, h, d;
   int   n;
+  unsigned long long* evals;    // profiling only (null otherwise): EVAL_SHARDS counters, 64 B apart, of candidates staged and evaluated
 };
 
 struct Xform { float m[16]; };  // column-major, passed by value (lands in SGPRs)

@@ -212,7 +212,7 @@ __device__ __forceinline__ uint32_t sweep_shell( const GridView& g, const CellBo
   const int ny = out.y1 - out.y0 + 1, nz = out.z1 - out.z0 + 1;
   const int n_rows = ny * nz;
   const float inv_ny = 1.0f / (float)ny;
-  uint32_t streamed = 0;
+  uint32_t streamed = 0, evaluated = 0;
   // (Cooperating waves all enumerate the same rows and split the chunks; giving each wave whole
   //  row batches instead balanced worse and measured slower.)
   const int c_share = share, c_nshare = n_share;
@@ -277,6 +277,7 @@ __device__ __forceinline__ uint32_t sweep_shell( const GridView& g, const CellBo
       if( cn < total ) fetch( cn, P, N, src );         // in flight during the loop below
       const uint32_t cnt = ( total - c0 < WAVE ) ? ( total - c0 ) : WAVE;
       const uint32_t cnt4 = ( cnt + 3u ) & ~3u;
+      evaluated += cnt;
 #pragma unroll 1
       for( uint32_t k = 0; k < cnt4; k += 4 )
       {
@@ -290,6 +291,7 @@ __device__ __forceinline__ uint32_t sweep_shell( const GridView& g, const CellBo
     }
     wave_lds_fence();
   }
+  if( g.evals && lane == 0 && evaluated ) atomicAdd( g.evals + 8 * ( ( blockIdx.x + 37 * blockIdx.y ) & ( EVAL_SHARDS - 1 ) ), (unsigned long long)evaluated );   // sharded, one cache line each
   return streamed;
 }
 
