@@ -1,0 +1,41 @@
+"""Seed sweep: GPU vs the oracle on fresh scenes (correspondences bit-exact, ICP pose / iterations, scores, labels).
+A wider net than the committed fixtures for rare events (distance ties, certificate and hand-off edge cases)."""
+import os, sys, numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from rescan_amd import capi, synth
+from oracle.pyoracle import Oracle
+capi.init(0)
+O = Oracle()
+I4 = np.eye(4, dtype=np.float32).ravel()
+ang = np.float32(np.deg2rad(60.0))
+bad = 0
+seeds = range(int(sys.argv[1]) if len(sys.argv) > 1 else 1, int(sys.argv[2]) if len(sys.argv) > 2 else 13)
+for seed in seeds:
+    rng = np.random.default_rng(seed)
+    dens = float(rng.choice([600, 1500, 3000, 5000]))
+    s0 = synth.make_scene(seed=seed, density=dens, timestep=0); s1 = synth.make_scene(seed=seed, density=dens, timestep=1)
+    a, b = capi.Cloud(s0["points"], s0["normals"]), capi.Cloud(s1["points"], s1["normals"])
+    msgs = []
+    for trial in range(2):
+        r = float(rng.choice([0.05, 0.075, 0.1])); T0 = synth.perturbed_pose(I4, rng, rng.choice([0.005, 0.03, 0.1]), rng.choice([0.005, 0.03, 0.1]))
+        want = O.icp_find_corrs(s1["points"], s1["normals"], s0["points"], s0["normals"], T0, I4, r, ang)
+        got = capi.icp_find_corrs(b, a, T0, I4, r, float(ang))
+        if not all(x.shape == y.shape and (x == y).all() for x, y in zip(want, got)): msgs.append(f"corrs(r={r})")
+        e_o, T_o, it_o = O.icp_align(s1["points"], s1["normals"], s0["points"], s0["normals"], T0, I4, r, ang)
+        e_g, T_g, it_g = capi.icp_align(b, a, T0, I4, r, float(ang))
+        if it_o != it_g or np.linalg.norm(T_o.astype(np.float64) - T_g) > 1e-4: msgs.append(f"icp(r={r}: it {it_o} vs {it_g}, dT {np.linalg.norm(T_o.astype(np.float64) - T_g):.2e})")
+    o = s1["objects"][seed % len(s1["objects"])]
+    oc = capi.Cloud(o["pos"], o["nor"])
+    poses = np.stack([synth.perturbed_pose(o["pose"], rng, 0.3, 0.2) for _ in range(12)])
+    sc_o = O.alignment_scores(s1["points"], s1["normals"], o["pos"], o["nor"], poses, 64); sc_g = capi.alignment_scores(oc, b, poses, 0.1, 64)
+    if np.abs(sc_o.astype(np.float64) - sc_g).max() > 2e-6: msgs.append("scores")
+    objs = [dict(pos=q["pos"], nor=q["nor"], class_idx=q["class_idx"], is_static=int(k % 2)) for k, q in enumerate(s1["objects"])]
+    plcs = [dict(pose=synth.perturbed_pose(q["pose"], rng, 0.02, 0.01), object_idx=k, uidx=q["uidx"]) for k, q in enumerate(s1["objects"])]
+    want = O.arrangement_to_labels(s1["points"], s1["normals"], objs, plcs, 0.05, 0, 0)
+    res = capi.arrangement_to_labels(b, np.stack([p["pose"] for p in plcs]), [capi.Cloud(q["pos"], q["nor"]) for q in objs], [q["is_static"] for q in objs], [q["class_idx"] for q in objs], 0.05, False)
+    if not ((res["labels"] == want["labels"]).all() and (res["min_dists"] == want["min_dists"]).all()): msgs.append("labels")
+    print(f"seed {seed:3d} density {dens:6.0f} n {len(s1['points']):7d}: {'OK' if not msgs else 'MISMATCH ' + ', '.join(msgs)}", flush=True)
+    bad += len(msgs)
+print("mismatches:", bad)
+sys.exit(1 if bad else 0)
