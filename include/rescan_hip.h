@@ -92,6 +92,15 @@ int rs_hip_icp_align( const rs_hip_cloud_t* source, const rs_hip_cloud_t* target
                       float* T1, const float* T2, float max_dist, float max_angle,
                       int32_t max_iter, int32_t fixed_iters, float* err, int32_t* n_iters );
 
+/* The estimator step (icp.h:136-148,210-298,393-402) has two implementations.  Sources of at most
+ * `n_points` points use the reference's own accumulation order and precisions (one sequential fp32 chain
+ * per accumulator): poses, errors and iteration counts are bit-identical to the reference's.  Larger
+ * sources use a parallel fp64 reduction of the same sums: more accurate than the reference, equal to it
+ * within its own fp32 rounding.  Default 16384 (environment: RS_HIP_REF_ORDER_BELOW);
+ * 0 = always the fp64 reduction; n_points < 0 only reads.  Returns the previous threshold.  Applies to
+ * rs_hip_icp_align, rs_hip_icp_align_batch and rs_hip_icp_estimate_pt2pl. */
+int32_t rs_hip_icp_reference_order_below( int32_t n_points );
+
 /* Many independent icp_align problems of one (source, target) pair, one per start pose
  * (apps/pose_proposal/main.cpp:190-202 runs exactly this loop): T1s is float[16*n], errs
  * float[n], iters int32[n] (may be NULL).  All problems advance in lock-step launches. */
@@ -200,6 +209,10 @@ int  rs_hip_coverage_scores( rs_hip_coverage_t* c, const rs_hip_cloud_t* const* 
 /* msh_mat4_inverse / msh_mat4_mul (lib/msh/msh_vec_math.h:1818-1905, 1441-1476) */
 void rs_hip_mat4_inverse( const float* m, float* out );
 void rs_hip_mat4_mul( const float* a, const float* b, float* out );
+/* The device's sinf/cosf — a restatement of the host libm's algorithm, since the reference's poses carry libm's bits
+ * (msh_rotate, msh_vec_math.h:2091-2092) — evaluated on the host for n arguments, so that a CPU test can hold it
+ * against the libm of the machine (no GPU needed). */
+void rs_hip_sincosf_model( const float* x, int64_t n, float* sin_out, float* cos_out );
 /* icp_estimate_rigid_xform_pt2pl (lib/rs/icp.h:210-298) on host arrays (device reduction) */
 int  rs_hip_icp_estimate_pt2pl( const float* pts1, const float* pts2, const float* nor2,
                                 const float* weights, int32_t n, float* T1, float* err );

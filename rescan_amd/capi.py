@@ -35,6 +35,7 @@ SIGNATURES = {
                                        C.POINTER(C.c_uint64)]),
     "rs_hip_icp_align": (C.c_int, [C.c_void_p, C.c_void_p, f32p, f32p, C.c_float, C.c_float, C.c_int32, C.c_int32,
                                    C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
+    "rs_hip_icp_reference_order_below": (C.c_int32, [C.c_int32]),
     "rs_hip_icp_align_batch": (C.c_int, [C.c_void_p, C.c_void_p, f32p, C.c_int32, f32p, C.c_float, C.c_float,
                                          C.c_int32, C.c_int32, f32p, i32p]),
     "rs_hip_icp_find_corrs": (C.c_int, [C.c_void_p, C.c_void_p, f32p, f32p, C.c_float, C.c_float,
@@ -53,6 +54,7 @@ SIGNATURES = {
     "rs_hip_coverage_scene_grid": (C.c_int, [C.c_void_p, np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")]),
     "rs_hip_coverage_scores": (C.c_int, [C.c_void_p, C.c_void_p, f32p, i32p, i32p, C.c_int32, f32p, C.c_void_p]),
     "rs_hip_mat4_inverse": (None, [f32p, f32p]),
+    "rs_hip_sincosf_model": (None, [f32p, C.c_int64, f32p, f32p]),
     "rs_hip_mat4_mul": (None, [f32p, f32p, f32p]),
     "rs_hip_icp_estimate_pt2pl": (C.c_int, [f32p, f32p, f32p, f32p, C.c_int32, f32p, C.POINTER(C.c_float)]),
 }
@@ -169,6 +171,12 @@ def radius_search(target, query, radius, k):
     return d, i, nn.astype(np.int64), tot.value
 
 
+def icp_reference_order_below(n_points=-1):
+    """Sources of at most n_points points run the estimator in the reference's accumulation order (bit-identical
+    results); -1 only reads.  Returns the previous threshold."""
+    return int(load().rs_hip_icp_reference_order_below(int(n_points)))
+
+
 def icp_align(source, target, T1, T2=IDENTITY, max_dist=0.1, max_angle=np.deg2rad(60.0), max_iter=100,
               fixed_iters=False):
     """icp_align (lib/rs/icp.h:416-500).  Returns (err, T1_new, n_iters)."""
@@ -265,6 +273,14 @@ def arrangement_to_labels(scene, poses, objects, is_static, class_idx, radius=0.
 
 def mat4_inverse(m):
     o = np.empty(16, np.float32); load().rs_hip_mat4_inverse(_f32(m).ravel(), o); return o
+
+
+def sincosf_model(x):
+    """The device's sinf/cosf evaluated on the host (tests: must equal the machine's libm)."""
+    x = np.ascontiguousarray(x, np.float32).ravel()
+    s = np.empty_like(x); c = np.empty_like(x)
+    load().rs_hip_sincosf_model(x, len(x), s, c)
+    return s, c
 
 
 def mat4_mul(a, b):

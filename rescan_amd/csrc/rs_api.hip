@@ -22,6 +22,7 @@
 #include <string>
 #include <vector>
 #include <array>
+#include <atomic>
 
 using namespace rs;
 
@@ -105,12 +106,16 @@ struct Workspace
   DevBuf bld_pos, bld_nor, bld_k0, bld_k1, bld_v0, bld_v1, bld_v2, bld_small, bld_bits, bld_tmp;   // cloud construction
   DevBuf order_a, order_b;                                                      // ICP phase A slow-tile lists (ping-pong)
   DevBuf tmp_pos, tmp_pos2, tmp_nor2;                                           // estimate-only
+  DevBuf faith;                                                                 // reference-order estimator: correspondences in source order
   PinBuf h_a, h_b, h_c;
 };
 thread_local Workspace g_ws;
 
 // ---- profiling ---------------------------------------------------------------------------
 bool g_prof = false;
+// Sources of at most this many points run the ICP estimator in the reference's own accumulation order and precisions
+// (bit-identical poses, errors and iteration counts); larger ones the fp64 moment reduction.
+std::atomic<int> g_ref_order_below{ getenv( "RS_HIP_REF_ORDER_BELOW" ) ? atoi( getenv( "RS_HIP_REF_ORDER_BELOW" ) ) : 16384 };
 std::mutex g_prof_mutex;
 struct ProfEntry { std::vector<std::pair<hipEvent_t, hipEvent_t>> spans; int64_t launches = 0; double ms = 0.0; };
 std::map<std::string, ProfEntry> g_profmap;
@@ -196,6 +201,7 @@ struct rs_hip_cloud
   float4* d_qpos = nullptr;
   float4* d_qnor = nullptr;
   uint32_t* d_tiles = nullptr;
+  int* d_qby_orig = nullptr;      // original index -> query slot (the reference-order estimator walks the source in its own order)
   std::vector<int32_t> qorder;    // query slot -> original index
   std::vector<int32_t> order;     // sorted slot -> original index
   std::vector<float> h_pos, h_nor;  // original-order host copies (AoS)
@@ -216,7 +222,11 @@ float query_extent_limit( int32_t n, size_t occupied_cells, float cell )
   if( n <= 0 || occupied_cells == 0 || !( cell > 0.0f ) ) return FLT_MAX;
   float per_cell = (float)n / (float)occupied_cells;
   float spacing = cell / std::sqrt( std::max( per_cell, 1.0f ) );
-  return std::max( 0.25f, 12.0f * spacing );
+  // ... and never more than 0.3 m: a sparse cloud (a subsampled level, a random subset) searched in a denser one would
+  // otherwise get tiles whose box is mostly the empty space between its points (1000 points against a 200 k scan:
+  // 404 -> 60 us per ICP iteration with the cap)
+  static const float cap = getenv( "RS_HIP_TILE_EXTENT_MAX" ) ? (float)atof( getenv( "RS_HIP_TILE_EXTENT_MAX" ) ) : 0.3f;
+  return std::min( cap, std::max( 0.25f, 12.0f * spacing ) );
 }
 
 } // namespace
@@ -452,6 +462,8 @@ rs_hip_cloud_t* rs_hip_cloud_create( const float* pos, const float* nor, int32_t
     launch_build_hilbert( d_raw, n, mn, scale, k0, v0, g_stream );
     if( build_sort_pairs( W.bld_tmp.p, tmp_bytes, k0, k1, v0, v2, n, 30, g_stream ) ) return failrc( "device sort failed" );
     launch_build_gather( d_raw, d_rawn, v2, n, c->d_qpos, c->d_qnor, g_stream );
+    CC( hipMalloc( (void**)&c->d_qby_orig, (size_t)n * 4 ) );
+    launch_build_inverse( c->d_qpos, n, c->d_qby_orig, g_stream );
     // tile starts: flags -> exclusive scan -> scatter
     uint32_t* flags = k0; uint32_t* scanned = k1;
     CC( hipMemsetAsync( flags + n, 0, 4, g_stream ) );
@@ -475,7 +487,7 @@ rs_hip_cloud_t* rs_hip_cloud_create( const float* pos, const float* nor, int32_t
     CC( hipMemsetAsync( c->d_tiles, 0, 4, g_stream ) );
     CC( hipStreamSynchronize( g_stream ) );
   }
-  c->bytes += (int64_t)( pb * ( nor ? 2 : 1 ) + ( (size_t)n_tiles + 1 ) * 4 );
+  c->bytes += (int64_t)( pb * ( nor ? 2 : 1 ) + ( (size_t)n_tiles + 1 ) * 4 + (size_t)n * 4 );
   c->qview.pos = c->d_qpos; c->qview.nor = c->d_qnor; c->qview.tiles = c->d_tiles;
   c->qview.n = n; c->qview.n_tiles = n_tiles;
 #undef CC
@@ -491,12 +503,17 @@ void rs_hip_cloud_destroy( rs_hip_cloud_t* c )
   if( c->d_qpos ) (void)hipFree( c->d_qpos );
   if( c->d_qnor ) (void)hipFree( c->d_qnor );
   if( c->d_tiles ) (void)hipFree( c->d_tiles );
+  if( c->d_qby_orig ) (void)hipFree( c->d_qby_orig );
   delete c;
 }
 
 int32_t rs_hip_cloud_size( const rs_hip_cloud_t* c ) { return c ? c->n : 0; }
 int64_t rs_hip_cloud_bytes( const rs_hip_cloud_t* c ) { return c ? c->bytes : 0; }
 
+void rs_hip_sincosf_model( const float* x, int64_t n, float* sin_out, float* cos_out )
+{
+  for( int64_t i = 0; i < n; ++i ) rs_sincosf_model( x[i], sin_out[i], cos_out[i] );
+}
 void rs_hip_mat4_inverse( const float* m, float* out ) { Mat4 a; std::memcpy( a.m, m, 64 ); Mat4 r = mat4_inverse( a ); std::memcpy( out, r.m, 64 ); }
 void rs_hip_mat4_mul( const float* a_, const float* b_, float* out ) { Mat4 a, b; std::memcpy( a.m, a_, 64 ); std::memcpy( b.m, b_, 64 ); Mat4 r = mat4_mul( a, b ); std::memcpy( out, r.m, 64 ); }
 
@@ -573,6 +590,7 @@ int icp_prepare( IcpCtx& cx, const rs_hip_cloud_t* src, const rs_hip_cloud_t* tg
   L.corr_part = g_ws.corr_part.as<double>();
   L.mom_part = g_ws.mom_part.as<double>(); L.res = g_ws.res.as<double>();
   L.w_explicit = nullptr;
+  L.by_orig = src->d_qby_orig; L.faith = nullptr;
   HIP_TRY( hipMemsetAsync( g_ws.queue_count.p, 0, np * 4, g_stream ), RS_HIP_E_RUNTIME );
   return RS_HIP_OK;
 }
@@ -700,6 +718,11 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
   if( source->n == 0 ) { for( int p = 0; p < n; ++p ) { errs[p] = 1e6f; if( iters ) iters[p] = 1; } return RS_HIP_OK; }   // n_corrs == 0 on the first search
   if( ( rc = icp_enable_certificates( cx, (size_t)n, (size_t)source->n ) ) ) return rc;
   if( ( rc = icp_upload_state( cx, T1s, (size_t)n ) ) ) return rc;
+  if( source->n <= g_ref_order_below.load() )
+  {
+    if( ( rc = g_ws.faith.ensure( (size_t)n * FAITH_REC * (size_t)source->n * 4 ) ) ) return rc;
+    cx.L.faith = g_ws.faith.as<float>();
+  }
   const size_t heavy_words = (size_t)n * ( (size_t)cx.n_waves + HEAVY_SLOTS + 1 );
   const bool reorder = !getenv( "RS_HIP_NO_LPT" );
   if( reorder )
@@ -746,7 +769,8 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
       if( debug ) icp_debug_before( cx, n );
       prof.mark( "nn_icp" ); launch_icp_corr( cx.L, g_stream );
       if( debug ) icp_debug_after( cx, source->n, n, i, max_dist );
-      prof.mark( "icp_moments" ); launch_icp_moments( cx.L, g_stream );
+      prof.mark( "icp_moments" );
+      if( cx.L.faith ) launch_icp_faithful( cx.L, g_stream ); else launch_icp_moments( cx.L, g_stream );
       double nd = max_dist * 0.95;                                      // icp.h:493
       max_dist = (float)( nd > 0.05 ? nd : 0.05 );
     }
@@ -760,6 +784,13 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
   const int* hIters = (const int*)( hS + np * 33 );
   for( int p = 0; p < n; ++p ) { std::memcpy( T1s + 16 * p, hS + 16 * p, 64 ); errs[p] = hS[np * 34 + p]; if( iters ) iters[p] = hIters[p]; }
   return RS_HIP_OK;
+}
+
+int32_t rs_hip_icp_reference_order_below( int32_t n_points )
+{
+  const int prev = g_ref_order_below.load();
+  if( n_points >= 0 ) g_ref_order_below.store( n_points );
+  return prev;
 }
 
 int rs_hip_icp_align( const rs_hip_cloud_t* source, const rs_hip_cloud_t* target,
@@ -874,6 +905,22 @@ int rs_hip_icp_estimate_pt2pl( const float* pts1, const float* pts2, const float
   L.radius = 1.0f; L.m_slot = g_ws.slot.as<int>(); L.m_d2 = g_ws.d2.as<float>(); L.m_dot = g_ws.dot.as<float>();
   L.mom_part = g_ws.mom_part.as<double>(); L.res = g_ws.res.as<double>();
   L.n_mom_blocks = std::max( 1, std::min( 256, ( n + 255 ) / 256 ) ); L.w_explicit = g_ws.wexp.as<float>();
+  if( n <= g_ref_order_below.load() )
+  {
+    // the reference's own accumulation order (k_icp_faithful): solve and pose update on the device too
+    if( ( rc = g_ws.faith.ensure( nn * FAITH_REC * 4 ) ) ) return rc;
+    L.faith = g_ws.faith.as<float>(); L.by_orig = nullptr; L.err = g_ws.state.as<float>() + 34;
+    // (the points are presented untransformed, so the state's pose stays the identity uploaded above and T1 is multiplied in afterwards)
+    { ProfScope ps( "icp_moments" ); launch_icp_faithful( L, g_stream ); }
+    float out[ICP_STATE_WORDS];
+    HIP_TRY( hipMemcpyAsync( out, g_ws.state.p, sizeof( out ), hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+    HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
+    Mat4 step, T; std::memcpy( step.m, out, 64 ); std::memcpy( T.m, T1, 64 );
+    T = mat4_mul( step, T );                      // icp.h:295: *T1 = T * *T1 (step = T * I, exact)
+    std::memcpy( T1, T.m, 64 );
+    if( err ) *err = out[34];
+    return RS_HIP_OK;
+  }
   { ProfScope ps( "icp_moments" ); launch_icp_moments( L, g_stream ); }
   double* hM = g_ws.h_a.as<double>();
   HIP_TRY( hipMemcpyAsync( hM, g_ws.res.p, ICP_NMOM * 8, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );

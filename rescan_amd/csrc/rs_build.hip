@@ -228,6 +228,17 @@ void launch_build_tile_scatter( const uint32_t* flags, const uint32_t* scanned, 
   hipLaunchKernelGGL( k_build_tile_scatter, dim3( blocks_for( n ) ), dim3( B_BLOCK ), 0, st, flags, scanned, n, tiles );
 }
 
+// by_orig[original index] = query slot (the inverse of the Hilbert permutation kept in qpos[s].w)
+__global__ __launch_bounds__( B_BLOCK ) void k_build_inverse( const float4* qpos, int n, int* by_orig )
+{
+  const int s = blockIdx.x * B_BLOCK + threadIdx.x;
+  if( s < n ) by_orig[__float_as_int( qpos[s].w )] = s;
+}
+void launch_build_inverse( const float4* qpos, int n, int* by_orig, hipStream_t st )
+{
+  hipLaunchKernelGGL( k_build_inverse, dim3( blocks_for( n ) ), dim3( B_BLOCK ), 0, st, qpos, n, by_orig );
+}
+
 size_t build_sort_temp_bytes( int n, int bits )
 {
   size_t b = 0;

@@ -99,9 +99,14 @@ struct IcpLaunch
   //   per problem: [0] count | HEAVY_SLOTS tile ids | n_tiles x (position in the list + 1, or 0)
   const int* heavy_in;
   int*    heavy_out;
+  // reference-order estimator (rs_kernels.hip: k_icp_faithful); faith == null: fp64 moments
+  const int* by_orig;   // original source index -> query slot (null: identity)
+  float*  faith;        // n_prob x FAITH_REC x nq: the correspondences in the source's own order
 };
 void launch_icp_corr( const IcpLaunch& L, hipStream_t st );     // phase A, phase B (+ statistics of dist² over the correspondences)
 void launch_icp_moments( const IcpLaunch& L, hipStream_t st );  // weights + moments (+ solve and loop-state update if L.solve)
+constexpr int FAITH_REC = 11;   // per correspondence: dist² (< 0: none), dot | weight, p, q, n
+void launch_icp_faithful( const IcpLaunch& L, hipStream_t st ); // the same step with the reference's own accumulation order and precisions
 
 struct ScoreLaunch
 {
@@ -178,6 +183,7 @@ void   launch_build_count_runs( const uint32_t* sorted, int n, int* out, hipStre
 void   launch_build_hilbert( const float* pos3, int n, const float mn[3], float scale, uint32_t* key, uint32_t* iota, hipStream_t st );
 void   launch_build_tile_flags( const float4* qpos, int n, float max_extent, uint32_t* flags, uint32_t* jump_a, uint32_t* jump_b, hipStream_t st );
 void   launch_build_tile_scatter( const uint32_t* flags, const uint32_t* scanned, int n, uint32_t* tiles, hipStream_t st );
+void   launch_build_inverse( const float4* qpos, int n, int* by_orig, hipStream_t st );
 size_t build_sort_temp_bytes( int n, int bits );
 int    build_sort_pairs( void* tmp, size_t bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout, int n, int bits, hipStream_t st );
 size_t build_scan_temp_bytes( size_t n );

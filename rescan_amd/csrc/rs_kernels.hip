@@ -1098,6 +1098,277 @@ __global__ __launch_bounds__( UPDATE_WAVES * WAVE ) void k_icp_update( IcpLaunch
   if( !L.fixed_iters && L.iter_index > 5 && delta < 1e-5 ) L.active[prob] = 0;   // icp.h:489
 }
 
+// ------------------------------------------------------------------------------------------
+// ICP estimator in the reference's own order and precisions  (lib/rs/icp.h:136-148,210-298,387-402)
+//
+// The reference sums everything one correspondence after the other in source order, in fp32 (dist²
+// statistics, Σw, the two centroids, the 3x3 blocks, the right-hand side) and in fp64 only Σw·s² and Σw.
+// On clouds of a few thousand points that rounding is part of its result: poses drift from the exact
+// least-squares step in the 5th digit and the stop test (|Δerr| < 1e-5) can fire an iteration earlier
+// or later.  k_icp_moments above is the fast, more accurate step; this one reproduces the reference bit
+// for bit.  fp32 addition does not associate, so each accumulator is ONE sequential chain over the
+// correspondences — but the 35 accumulators are independent chains, and producing the addends is parallel:
+//   k_icp_faith_gather   the correspondences in the source's original order, SoA, all threads
+//   k_icp_faithful       one workgroup per problem, four waves on four SIMDs:
+//                          waves 2,3  turn 128 correspondences at a time into the addends of every accumulator (LDS)
+//                          wave 0     lane a adds row a, entry after entry, to fp32 accumulator a
+//                          wave 1     the same for the two fp64 accumulators
+//                        double-buffered, so the chains never wait for the producers.
+//   Three passes (each needs the previous one's totals): dist² statistics -> weights, centroids -> normal equations,
+//   then thread 0 runs the rest of the iteration exactly as k_icp_update does.
+// Unmatched source points add +0 (no effect on an accumulator that started at +0).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__( BLOCK ) void k_icp_faith_gather( IcpLaunch L )
+{
+  const int prob = blockIdx.y;
+  if( L.active[prob] == 0 ) return;
+  const int i = blockIdx.x * BLOCK + threadIdx.x, n = L.src.n;
+  if( i >= n ) return;
+  const int s = L.by_orig ? L.by_orig[i] : i;
+  const size_t o = (size_t)prob * n + s;
+  float* F = L.faith + (size_t)prob * FAITH_REC * n + i;
+  const int slot = L.m_slot[o];
+  if( slot < 0 ) { F[0] = -1.0f; return; }
+  Xform T1;
+#pragma unroll
+  for( int k = 0; k < 16; ++k ) T1.m[k] = L.T1[prob * 16 + k];
+  const float4 p4 = L.src.pos[s];
+  float tx, ty, tz, px, py, pz;
+  xform3( T1, p4.x, p4.y, p4.z, 1.0f, tx, ty, tz );
+  xform3( L.T2i, tx, ty, tz, 1.0f, px, py, pz );
+  const float4 q4 = L.tgt.pos[slot], n4 = L.tgt.nor[slot];
+  const size_t N = (size_t)n;
+  F[0] = L.w_explicit ? 0.0f : L.m_d2[o];
+  F[N] = L.w_explicit ? L.w_explicit[o] : L.m_dot[o];
+  F[2 * N] = px;   F[3 * N] = py;   F[4 * N] = pz;
+  F[5 * N] = q4.x; F[6 * N] = q4.y; F[7 * N] = q4.z;
+  F[8 * N] = n4.x; F[9 * N] = n4.y; F[10 * N] = n4.z;
+}
+
+#define FAITH_CHUNK 128
+#define FAITH_PITCH ( FAITH_CHUNK + 4 )          // rows stay 16-byte aligned (128-bit LDS reads) and a quarter-wave of them covers all banks once
+#define FAITH_THREADS ( 2 * WAVE + FAITH_CHUNK )   // two chain waves + two producer waves: one wave per SIMD
+
+struct FaithRec { float v[FAITH_REC]; };
+struct FaithPar
+{
+  bool  w_explicit, use_sd;
+  float max_dist, cut;
+  float c1[3], c2[3];
+};
+
+__device__ __forceinline__ void faith_load( const float* F, int n, int i, FaithRec& r )
+{
+  r.v[0] = -1.0f;
+  if( i < n )
+  {
+#pragma unroll
+    for( int k = 0; k < FAITH_REC; ++k ) r.v[k] = F[(size_t)k * n + i];
+  }
+}
+
+__device__ __forceinline__ float faith_weight( const FaithRec& r, const FaithPar& P )
+{
+  if( P.w_explicit ) return r.v[1];
+  float w = ( 1.0f - __fdiv_rn( r.v[0], P.max_dist ) ) * r.v[1];      // icp.h:387
+  if( P.use_sd && r.v[0] > P.cut ) w = 0.0f;                           // icp.h:396-401
+  return w;
+}
+
+// the addends of one correspondence for pass PASS, written to column t of `term`
+template <int PASS>
+__device__ __forceinline__ void faith_terms( const FaithRec& r, const FaithPar& P, float ( *term )[FAITH_PITCH], int t )
+{
+  const bool m = r.v[0] >= 0.0f;
+  if( PASS == 1 )
+  {
+    term[0][t] = m ? r.v[0] : 0.0f;                 // msh_compute_mean
+    term[1][t] = m ? r.v[0] * r.v[0] : 0.0f;        // msh_compute_stddev
+    term[2][t] = m ? 1.0f : 0.0f;                   // n_corrs (exact in fp32 below 2^24)
+  }
+  else if( PASS == 2 )
+  {
+    const float w = m ? faith_weight( r, P ) : 0.0f;
+    term[0][t] = w;                                 // icp.h:141  total += w
+#pragma unroll
+    for( int a = 0; a < 3; ++a )
+    {
+      term[1 + a][t] = m ? r.v[2 + a] * w : 0.0f;   // icp.h:142  c = c + p*w
+      term[4 + a][t] = m ? r.v[5 + a] * w : 0.0f;
+    }
+  }
+  else
+  {
+    if( !m )
+    {
+#pragma unroll
+      for( int a = 0; a < ICP_NMOM; ++a ) term[a][t] = 0.0f;
+      return;
+    }
+    const float wi = faith_weight( r, P );
+    const float p[3] = { r.v[2] - P.c1[0], r.v[3] - P.c1[1], r.v[4] - P.c1[2] };
+    const float q[3] = { r.v[5] - P.c2[0], r.v[6] - P.c2[1], r.v[7] - P.c2[2] };
+    const float nv[3] = { r.v[8], r.v[9], r.v[10] };
+    const float d[3] = { p[0] - q[0], p[1] - q[1], p[2] - q[2] };
+    const float cv[3] = { p[1] * nv[2] - p[2] * nv[1], p[2] * nv[0] - p[0] * nv[2], p[0] * nv[1] - p[1] * nv[0] };
+    const float sd = d[0] * nv[0] + d[1] * nv[1] + d[2] * nv[2];
+#pragma unroll
+    for( int col = 0; col < 3; ++col )
+#pragma unroll
+      for( int row = 0; row < 3; ++row )
+      {
+        term[3 * col + row][t]      = ( cv[row] * cv[col] ) * wi;     // icp.h:239-241, column-major blocks
+        term[9 + 3 * col + row][t]  = ( cv[row] * nv[col] ) * wi;
+        term[18 + 3 * col + row][t] = ( nv[row] * nv[col] ) * wi;
+      }
+#pragma unroll
+    for( int a = 0; a < 3; ++a )
+    {
+      term[27 + a][t] = wi * cv[a] * sd;            // icp.h:242-247
+      term[30 + a][t] = wi * nv[a] * sd;
+    }
+    term[33][t] = wi * sd * sd;                     // icp.h:249 (a float product, summed in fp64)
+    term[34][t] = wi;                               // icp.h:250
+  }
+}
+
+// A chain wave's two steps for one chunk: pull its row into registers (128-bit LDS reads), and later add the
+// entries one after the other.  Columns past the end of the cloud hold +0, so every chunk is a full one.
+struct FaithRow { float4 v[FAITH_CHUNK / 4]; };
+__device__ __forceinline__ void faith_fetch( const float* row, FaithRow& r )
+{
+  const float4* row4 = reinterpret_cast<const float4*>( row );
+#pragma unroll
+  for( int q = 0; q < FAITH_CHUNK / 4; ++q ) r.v[q] = row4[q];
+}
+template <class ACC>
+__device__ __forceinline__ void faith_chain( const FaithRow& r, ACC& acc )
+{
+#pragma unroll
+  for( int q = 0; q < FAITH_CHUNK / 4; ++q ) { acc += (ACC)r.v[q].x; acc += (ACC)r.v[q].y; acc += (ACC)r.v[q].z; acc += (ACC)r.v[q].w; }
+}
+
+// One pass over the correspondences: rows [0,NF) end in accf of wave 0's lanes, rows [NF,NF+ND) in accd of wave 1's.
+// Iteration k: the producers write chunk k (and keep FAITH_AHEAD chunks of loads in flight: a chunk is consumed faster
+// than a load returns); the chain waves fetch chunk k-1 from LDS while they add up chunk k-2 from registers.
+#define FAITH_AHEAD 4
+template <int PASS, int NF, int ND>
+__device__ __forceinline__ void faith_pass( const float* F, int n, const FaithPar& P, float ( *term )[ICP_NMOM][FAITH_PITCH],
+                                            float& accf, double& accd )
+{
+  const int wib = threadIdx.x / WAVE, lane = threadIdx.x & ( WAVE - 1 );
+  const int t = threadIdx.x - 2 * WAVE;            // producer column
+  const int n_chunks = ( n + FAITH_CHUNK - 1 ) / FAITH_CHUNK;
+  const int my_row = wib == 0 ? ( lane < NF ? lane : -1 ) : ( wib == 1 && lane < ND ? NF + lane : -1 );
+  accf = 0.0f; accd = 0.0;
+  FaithRec ring[FAITH_AHEAD];
+  FaithRow rows[2];
+  const bool producer = wib >= 2;
+  if( producer )
+  {
+#pragma unroll
+    for( int u = 0; u < FAITH_AHEAD; ++u ) faith_load( F, n, u * FAITH_CHUNK + t, ring[u] );
+  }
+  for( int k0 = 0; k0 <= n_chunks + 1; k0 += FAITH_AHEAD )
+  {
+#pragma unroll
+    for( int u = 0; u < FAITH_AHEAD; ++u )
+    {
+      const int k = k0 + u;
+      if( wib >= 2 )
+      {
+        if( producer && k < n_chunks )
+        {
+          faith_terms<PASS>( ring[u], P, term[k & 1], t );
+          faith_load( F, n, ( k + FAITH_AHEAD ) * FAITH_CHUNK + t, ring[u] );
+        }
+      }
+      else if( my_row >= 0 )
+      {
+        if( k >= 1 && k <= n_chunks ) faith_fetch( term[( k - 1 ) & 1][my_row], rows[( k - 1 ) & 1] );
+        if( k >= 2 && k <= n_chunks + 1 )
+        {
+          if( wib == 0 ) faith_chain( rows[k & 1], accf ); else faith_chain( rows[k & 1], accd );
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__global__ __launch_bounds__( FAITH_THREADS ) void k_icp_faithful( IcpLaunch L )
+{
+  __shared__ __attribute__( ( aligned( 16 ) ) ) float term[2][ICP_NMOM][FAITH_PITCH];
+  __shared__ float s_f[ICP_NMOM];
+  __shared__ double s_d[2];
+  const int prob = blockIdx.x;
+  if( L.active[prob] == 0 ) return;
+  const int wib = threadIdx.x / WAVE, lane = threadIdx.x & ( WAVE - 1 );
+  const int n = L.src.n;
+  const float* F = L.faith + (size_t)prob * FAITH_REC * n;
+  FaithPar P;
+  P.w_explicit = L.w_explicit != nullptr; P.use_sd = false; P.max_dist = L.radius; P.cut = 0.0f;
+  P.c1[0] = P.c1[1] = P.c1[2] = P.c2[0] = P.c2[1] = P.c2[2] = 0.0f;
+  float accf; double accd;
+
+  // ---- icp.h:393-402: mean and standard deviation of dist² over the correspondences ----
+  if( !P.w_explicit )
+  {
+    faith_pass<1, 3, 0>( F, n, P, term, accf, accd );
+    if( wib == 0 && lane < 3 ) s_f[lane] = accf;
+    __syncthreads();
+    const float cnt = s_f[2];
+    if( cnt == 0.0f )                                                   // icp.h:455-459: no correspondences
+    {
+      if( threadIdx.x == 0 && L.solve ) { L.prev_err[prob] = L.err[prob]; L.iters[prob] += 1; L.active[prob] = 0; }
+      return;
+    }
+    const float mean = __fdiv_rn( s_f[0], cnt );                        // msh_std.h:1800-1825
+    const float var = __fdiv_rn( s_f[1], cnt ) - mean * mean;
+    const float sd = (float)sqrt( (double)var );
+    P.use_sd = sd > 0.000001;
+    P.cut = 2.5f * sd;
+    __syncthreads();                                                    // s_f is rewritten below
+  }
+
+  // ---- icp.h:136-148: Σw and the two weighted centroids ----
+  faith_pass<2, 7, 0>( F, n, P, term, accf, accd );
+  if( wib == 0 && lane < 7 ) s_f[lane] = accf;
+  __syncthreads();
+  const float total = s_f[0];
+  if( total <= 1e-7 )                                                   // icp.h:466-470: the weights vanished
+  {
+    if( threadIdx.x == 0 && L.solve ) { L.prev_err[prob] = L.err[prob]; L.iters[prob] += 1; L.active[prob] = 0; }
+    return;
+  }
+  const float inv = __fdiv_rn( 1.0f, total );
+#pragma unroll
+  for( int a = 0; a < 3; ++a ) { P.c1[a] = s_f[1 + a] * inv; P.c2[a] = s_f[4 + a] * inv; }
+  __syncthreads();
+
+  // ---- icp.h:221-252: the normal equations ----
+  faith_pass<3, 33, 2>( F, n, P, term, accf, accd );
+  if( wib == 0 && lane < 33 ) s_f[lane] = accf;
+  if( wib == 1 && lane < 2 ) s_d[lane] = accd;
+  __syncthreads();
+  if( threadIdx.x != 0 ) return;
+
+  // ---- icp.h:253-295 and the loop's bookkeeping (icp.h:455-493), as in k_icp_update ----
+  float A[33];
+  for( int k = 0; k < 33; ++k ) A[k] = s_f[k];
+  Mat4 T;
+  for( int k = 0; k < 16; ++k ) { T.m[k] = L.T1[prob * 16 + k]; if( L.solve ) L.T1_prev[prob * 16 + k] = T.m[k]; }
+  float e;
+  icp_solve_ref_order( A, s_d[0], s_d[1], P.c1, T, e );
+  for( int k = 0; k < 16; ++k ) L.T1[prob * 16 + k] = T.m[k];
+  if( !L.solve ) { L.err[prob] = e; return; }
+  L.prev_err[prob] = L.err[prob];
+  L.iters[prob] += 1;
+  L.err[prob] = e;
+  const float delta = fabsf( L.prev_err[prob] - e );
+  if( !L.fixed_iters && L.iter_index > 5 && delta < 1e-5 ) L.active[prob] = 0;   // icp.h:489
+}
+
 void launch_icp_corr( const IcpLaunch& L, hipStream_t st )
 {
   // queue_count is zero on entry: cleared once by the host, then by the cooperative kernel's last workgroup after every use
@@ -1112,6 +1383,11 @@ void launch_icp_corr( const IcpLaunch& L, hipStream_t st )
   if( L.coop_waves >= 8 ) hipLaunchKernelGGL( k_icp_corr_coop<8>, cgrid, dim3( 8 * WAVE ), 0, st, L );
   else                    hipLaunchKernelGGL( k_icp_corr_coop<COOP_WAVES>, cgrid, dim3( COOP_BLOCK ), 0, st, L );
   hipLaunchKernelGGL( k_icp_stats, dim3( L.n_prob ), dim3( STATS_BLOCK ), 0, st, L );
+}
+void launch_icp_faithful( const IcpLaunch& L, hipStream_t st )
+{
+  hipLaunchKernelGGL( k_icp_faith_gather, dim3( ( L.src.n + BLOCK - 1 ) / BLOCK, L.n_prob ), dim3( BLOCK ), 0, st, L );
+  hipLaunchKernelGGL( k_icp_faithful, dim3( L.n_prob ), dim3( FAITH_THREADS ), 0, st, L );
 }
 void launch_icp_moments( const IcpLaunch& L, hipStream_t st )
 {

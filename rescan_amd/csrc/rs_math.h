@@ -20,12 +20,60 @@ struct Mat4 { float m[16]; };
 
 RS_HD inline Mat4 mat4_identity() { Mat4 r; for( int i = 0; i < 16; ++i ) r.m[i] = 0.0f; r.m[0] = r.m[5] = r.m[10] = r.m[15] = 1.0f; return r; }
 
-// cosf/sinf of the host libm; on the device the double-precision functions rounded once to float
-// (correctly rounded for all practical purposes, as glibc's are to within its 0.56-ulp bound).
+// sinf/cosf as glibc >= 2.28 computes them (sysdeps/ieee754/flt-32/s_sincosf.h, the algorithm of Arm's optimized
+// routines): a double-precision polynomial of the published coefficients, 0.56 ulp — NOT the correctly rounded value
+// (it differs from (float)sin((double)x) for 0.85 % of the arguments), and the reference's poses carry exactly these
+// bits (msh_rotate, msh_vec_math.h:2091-2092).  The fused steps are the ones of libm's FMA build, which every x86-64
+// host of the last decade selects; pinned against the host's sinf/cosf on 6e8 arguments with zero mismatches
+// (tests/test_capi_cpu.py checks a sample on every run).  |x| >= 120, inf and NaN (never an ICP step) fall back to
+// the double-precision function rounded once.
+RS_HD inline float rs_sincosf_poly( double x, double x2, bool cosine, bool negate_cos )
+{
+  // __sincosf_table[0]; table[1] is the same with c0..c4 negated
+  const double c0 = 0x1p0, c1 = -0x1.ffffffd0c621cp-2, c2 = 0x1.55553e1068f19p-5, c3 = -0x1.6c087e89a359dp-10, c4 = 0x1.99343027bf8c3p-16;
+  const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
+  if( !cosine )
+  {
+    const double x3 = x * x2, t1 = fma( x2, s3, s2 ), x7 = x3 * x2, t = fma( x3, s1, x );
+    return (float)fma( x7, t1, t );
+  }
+  const double g = negate_cos ? -1.0 : 1.0;
+  const double x4 = x2 * x2, t2 = fma( x2, g * c4, g * c3 ), t1 = fma( x2, g * c1, g * c0 ), x6 = x4 * x2, t = fma( x4, g * c2, t1 );
+  return (float)fma( x6, t2, t );
+}
+RS_HD inline void rs_sincosf_model( float a, float& s, float& c )
+{
+  uint32_t u; memcpy( &u, &a, 4 );
+  const uint32_t top12 = ( u >> 20 ) & 0x7ff;
+  const double x = a;
+  if( top12 < 0x3f4 )                              // |a| < 0.75 (abstop12 compare against pi/4)
+  {
+    if( top12 < 0x398 ) { s = a; c = 1.0f; return; }   // |a| < 2^-12
+    const double x2 = x * x;
+    s = rs_sincosf_poly( x, x2, false, false ); c = rs_sincosf_poly( x, x2, true, false );
+    return;
+  }
+  if( top12 < 0x42f )                              // |a| < 120: reduce_fast
+  {
+    const double hpi_inv = 0x1.45F306DC9C883p+23, hpi = 0x1.921FB54442D18p0;
+    const double r = x * hpi_inv;
+    const int n = ( (int32_t)r + 0x800000 ) >> 24;
+    const double xr = fma( -(double)n, hpi, x );
+    const double sign = ( ( n & 3 ) == 1 || ( n & 3 ) == 2 ) ? -1.0 : 1.0;     // { 1, -1, -1, 1 }[n & 3]
+    const double xs = xr * sign, x2 = xr * xr;
+    const bool tab1 = ( n & 2 ) != 0;
+    s = rs_sincosf_poly( xs, x2, ( n & 1 ) != 0, tab1 );
+    c = rs_sincosf_poly( xs, x2, ( ( n ^ 1 ) & 1 ) != 0, tab1 );
+    return;
+  }
+  s = (float)sin( x ); c = (float)cos( x );
+}
+
+// cosf/sinf of the host libm — by definition what the reference calls; on the device the model above.
 RS_HD inline void rs_sincosf( float a, float& s, float& c )
 {
 #if defined( __HIP_DEVICE_COMPILE__ )
-  s = (float)sin( (double)a ); c = (float)cos( (double)a );
+  rs_sincosf_model( a, s, c );
 #else
   c = cosf( a ); s = sinf( a );
 #endif
@@ -223,6 +271,28 @@ RS_HD inline bool icp_solve( const double* M, Mat4& T1, float& err )
   T = mat4_translate( T, -c1f[0], -c1f[1], -c1f[2] );
   T1 = mat4_mul( T, T1 );
   return true;
+}
+
+// The same step from the reference's own accumulators (k_icp_faithful): A = TL[9] TR[9] BR[9] (column-major
+// 3x3 floats, M[3*col+row]) and rhs[6], all fp32; sum = Σw·s² and tw = Σw in fp64; c1 = the fp32 centroid
+// (icp.h:253-295).
+RS_HD inline void icp_solve_ref_order( const float* A, double sum, double tw, const float c1f[3], Mat4& T1, float& err )
+{
+  const float* TL = A; const float* TR = A + 9; const float* BR = A + 18; const float* rhs = A + 27;
+  err = (float)sqrt( sum / tw );
+  double C[6][6], b[6], x[6] = { 0, 0, 0, 0, 0, 0 };    // icp.h:267-277
+  for( int r = 0; r < 3; ++r ) for( int c = 0; c < 3; ++c )
+  { C[r][c] = TL[3*c + r]; C[r][3+c] = TR[3*c + r]; C[3+r][c] = TR[3*r + c]; C[3+r][3+c] = BR[3*c + r]; }
+  for( int i = 0; i < 6; ++i ) b[i] = -rhs[i];
+  ldlt6_solve( C, b, x );
+  Mat4 T = mat4_identity();                    // icp.h:280-295
+  T = mat4_translate( T, c1f[0], c1f[1], c1f[2] );
+  T = mat4_translate( T, (float)x[3], (float)x[4], (float)x[5] );
+  T = mat4_rotate_axis( T, (float)x[0], 0 );
+  T = mat4_rotate_axis( T, (float)x[1], 1 );
+  T = mat4_rotate_axis( T, (float)x[2], 2 );
+  T = mat4_translate( T, -c1f[0], -c1f[1], -c1f[2] );
+  T1 = mat4_mul( T, T1 );
 }
 
 // ---- normal gates as thresholds on the (clamped) dot product ---------------------------

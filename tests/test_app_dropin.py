@@ -73,21 +73,22 @@ def test_pose_proposal_app_links_against_the_shim(tmp_path):
     worst = []
     for pa, pb in zip(a, b):
         assert len(pa) == len(pb), "different number of surviving proposals"
-        # Proposals are sorted by score; compare pose by pose.  The app refines on level-2 clouds (2 cm
-        # voxels, a few hundred points per chair) and stops on |d err| < 1e-5 (icp.h:489): where the fp64
-        # reduction and the reference's fp32 accumulators put that test on different sides, the two runs
-        # stop one iteration apart and the poses differ by a few 1e-4.  Proposals that explain the scan
-        # (score > 0.9) must stay within 1e-3 with a median under 1e-4 (the north-star tolerance, which
-        # the dense-cloud fixtures meet case by case); weak proposals are ICP runs from wrong start poses
-        # that end in poorly constrained minima and get 1e-2.
+        # Proposals are sorted by score; compare pose by pose.  The app refines on level-2 clouds (2 cm voxels, a few
+        # hundred points per chair): object-sized sources, for which the library runs the estimator in the reference's
+        # own accumulation order with libm's sinf/cosf, so the refined poses are the reference's bit for bit (26 of the
+        # 27 proposals of this scene; the 27th, a weak one, is 7e-7 away — an exact distance tie, which the reference
+        # decides by its grid traversal order).  Asserted: good proposals (score > 0.9) at most 1e-4
+        # apart with a median of exactly 0; weak ones within 1e-2.
         for ra, rb in zip(pa, pb):
             dpose = np.linalg.norm(ra[:16].astype(np.float64) - rb[:16])
             worst.append((float(ra[16]), dpose))
-            assert dpose < (1e-3 if ra[16] > 0.9 else 1e-2), (ra[16], dpose)
+            assert dpose < (1e-4 if ra[16] > 0.9 else 1e-2), (ra[16], dpose)
             assert abs(float(ra[16]) - float(rb[16])) < (1e-3 if ra[16] > 0.9 else 1e-2)
         n_dyn += len(pa) > 1
     assert n_dyn >= 3                                   # table + two chairs were refined by icp_align
     good = [d for sc, d in worst if 0.9 < sc < 9.0]
-    assert len(good) >= 3 and np.median(good) < 1e-4
+    assert len(good) >= 3 and np.median(good) == 0.0
+    assert np.mean([d == 0.0 for _, d in worst]) > 0.9
     print("pose deltas: good proposals median %.2e max %.2e, all max %.2e over %d proposals"
           % (np.median(good), max(good), max(d for _, d in worst), len(worst)))
+    print("nonzero:", [(round(sc, 4), "%.2e" % d) for sc, d in worst if d > 0])

@@ -68,6 +68,36 @@ def test_host_math_vs_golden(lib):
         assert (capi.mat4_mul(g["m"][k], g["b"][k]) == g["mul"][k]).all()
 
 
+def test_device_sincosf_model_is_the_host_libm(lib):
+    """The reference composes its poses with libm's sinf/cosf (msh_vec_math.h:2091-2092), which are not correctly
+    rounded (0.85 % of the arguments differ from the rounded double result); the ICP loop runs on the device, so the
+    device carries a restatement of glibc's algorithm.  It must return libm's bits: ICP-step-sized angles, the whole
+    polynomial range, the range-reduced one, and the edges of each."""
+    import ctypes as C
+    from rescan_amd import capi
+    libm = C.CDLL("libm.so.6")
+    libm.sinf.restype = C.c_float; libm.sinf.argtypes = [C.c_float]
+    libm.cosf.restype = C.c_float; libm.cosf.argtypes = [C.c_float]
+    rng = np.random.default_rng(1)
+    x = np.concatenate([
+        rng.uniform(-0.2, 0.2, 60000), rng.uniform(-0.75, 0.75, 40000), rng.uniform(-120, 120, 40000),
+        10.0 ** rng.uniform(-7, -2, 20000) * rng.choice([-1, 1], 20000),
+        np.array([0.0, -0.0, 2.0 ** -12, np.nextafter(np.float32(2.0 ** -12), np.float32(0)), 0.75, np.nextafter(np.float32(0.75), np.float32(0)),
+                  np.pi / 4, np.pi / 2, np.pi, 119.99999, 120.0, 1e5, -1e5]),
+    ]).astype(np.float32)
+    s, c = capi.sincosf_model(x)
+    want_s = np.array([libm.sinf(float(v)) for v in x], np.float32)
+    want_c = np.array([libm.cosf(float(v)) for v in x], np.float32)
+    # (beyond |x| = 120 the model rounds the double-precision function once: equal to libm's third branch
+    #  except in its rare misroundings — not an ICP step, not asserted bit for bit)
+    small = np.abs(x) < 120
+    assert (s[small].view(np.uint32) == want_s[small].view(np.uint32)).all()
+    assert (c[small].view(np.uint32) == want_c[small].view(np.uint32)).all()
+    assert np.abs(s[~small] - want_s[~small]).max() < 1e-6 and np.abs(c[~small] - want_c[~small]).max() < 1e-6
+    # the point of the exercise: libm is NOT the correctly rounded function
+    assert (want_s != np.sin(x.astype(np.float64)).astype(np.float32)).sum() > 100
+
+
 def test_fails_loudly_without_gpu(lib):
     import torch
     if torch.cuda.is_available():

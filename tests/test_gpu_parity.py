@@ -108,6 +108,68 @@ def test_icp_align_vs_golden(capi, gscene, scene_clouds, fname):
     assert iters == int(g["iters"])
 
 
+@pytest.mark.parametrize("fname", golden_files("icp_"))
+def test_icp_align_reference_order_is_bit_identical(capi, gscene, scene_clouds, fname):
+    """Sources below the threshold run the estimator in the reference's own accumulation order: pose, error and
+    iteration count are the reference's bits, not merely within tolerance (icp.h:136-148,210-298,393-402)."""
+    g = load_golden(fname)
+    clouds, objs = scene_clouds
+    md = float(g["max_dist"])
+    src = objs[int(g["obj"])]
+    prev = capi.icp_reference_order_below(max(src.n, 16384))
+    try:
+        err, T, iters = capi.icp_align(src, clouds[round(md, 3)], g["T1"], g["T2"], md, g["max_angle"])
+    finally:
+        capi.icp_reference_order_below(prev)
+    assert T.tobytes() == np.asarray(g["T_out"], np.float32).ravel().tobytes()
+    assert np.float32(err).tobytes() == np.float32(g["err"]).tobytes()
+    assert iters == int(g["iters"])
+
+
+def test_icp_reference_order_vs_oracle_seeded(capi, oracle):
+    """The same on fresh seeded scenes, as a batch (every problem of a batch is its own sequential chain), for
+    whole scans with the threshold lifted, and for the estimator entry point; and the fp64 reduction, which larger
+    sources get, stays within the pose tolerance of the same runs."""
+    from rescan_amd import synth
+    ang = np.float32(np.deg2rad(60.0))
+    s0 = synth.make_scene(seed=21, density=1500, timestep=0)
+    s1 = synth.make_scene(seed=21, density=1500, timestep=1)
+    a = capi.Cloud(s0["points"], s0["normals"])
+    rng = np.random.default_rng(8)
+    prev = capi.icp_reference_order_below(-1)
+    try:
+        o = s1["objects"][1]
+        oc = capi.Cloud(o["pos"], o["nor"])
+        import os
+        if "RS_HIP_REF_ORDER_BELOW" in os.environ:
+            capi.icp_reference_order_below(16384)
+        else:
+            assert oc.n <= prev == 16384                      # the default threshold covers object-sized sources
+        T0s = np.stack([synth.perturbed_pose(o["pose"], rng, 0.05, 0.05) for _ in range(4)])
+        errs, Ts, its = capi.icp_align_batch(oc, a, T0s, I4, 0.075, ang)
+        for k in range(4):
+            e_o, T_o, it_o = oracle.icp_align(o["pos"], o["nor"], s0["points"], s0["normals"], T0s[k], I4, 0.075, ang)
+            assert Ts[k].tobytes() == T_o.tobytes() and np.float32(errs[k]).tobytes() == np.float32(e_o).tobytes() and its[k] == it_o
+        # whole scan, threshold lifted / estimator forced to the fp64 reduction
+        b = capi.Cloud(s1["points"], s1["normals"])
+        T0 = synth.perturbed_pose(I4, rng, 0.03, 0.03)
+        e_o, T_o, it_o = oracle.icp_align(s1["points"], s1["normals"], s0["points"], s0["normals"], T0, I4, 0.1, ang)
+        capi.icp_reference_order_below(1 << 30)
+        e_g, T_g, it_g = capi.icp_align(b, a, T0, I4, 0.1, float(ang))
+        assert T_g.tobytes() == T_o.tobytes() and np.float32(e_g).tobytes() == np.float32(e_o).tobytes() and it_g == it_o
+        c = oracle.icp_find_corrs(s1["points"], s1["normals"], s0["points"], s0["normals"], T0, I4, 0.1, ang)
+        e_o2, T_o2 = oracle.icp_estimate_pt2pl(c[0], c[2], c[3], c[4], T0)
+        e_g2, T_g2 = capi.icp_estimate_pt2pl(c[0], c[2], c[3], c[4], T0)
+        assert T_g2.tobytes() == T_o2.tobytes() and np.float32(e_g2).tobytes() == np.float32(e_o2).tobytes()
+        assert capi.icp_reference_order_below(0) == 1 << 30
+        e_f, T_f, it_f = capi.icp_align(b, a, T0, I4, 0.1, float(ang))
+        assert it_f == it_o and np.linalg.norm(T_f.astype(np.float64) - T_o) < POSE_TOL
+        e_f2, T_f2 = capi.icp_estimate_pt2pl(c[0], c[2], c[3], c[4], T0)
+        assert np.linalg.norm(T_f2.astype(np.float64) - T_o2) < POSE_TOL
+    finally:
+        capi.icp_reference_order_below(prev)
+
+
 def test_icp_batch_matches_single(capi, gscene, scene_clouds):
     clouds, objs = scene_clouds
     rng = np.random.default_rng(3)
