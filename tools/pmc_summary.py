@@ -29,7 +29,9 @@ if __name__ == "__main__":
     elif len(sys.argv) > 2 and sys.argv[1] == "--trace":
         rows = sorted(csv.DictReader(open(sys.argv[2])), key=lambda r: int(r["Start_Timestamp"]))
         rows = [r for r in rows if "rs::" in r["Kernel_Name"]]
-        # bench.py --steps 1 --warmup 1 --serial: two identical steps; show the second
+        # bench.py --steps 1 --warmup 1 --serial: cloud construction, then two identical steps; show the second
+        last_build = max([k for k, r in enumerate(rows) if "k_build_" in r["Kernel_Name"]], default=-1)
+        rows = rows[last_build + 1:]
         start = len(rows) // 2
         lines = []
         for r in rows[start:]:
