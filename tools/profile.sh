@@ -4,6 +4,7 @@
 #   bash tools/profile.sh pmc       -> SQ instruction / wait counters per kernel
 #   bash tools/profile.sh trace     -> per-dispatch durations of one serial step, in launch order
 #   bash tools/profile.sh traffic   -> FETCH_SIZE and WRITE_SIZE in separate passes -> gpurun_out/pmc_traffic_raw.json
+#                                      (BENCH_ARGS="--knn brute --points 100000" for the other layout / size)
 # rocprofv3 is given the program itself after `--` (python ...), never a shell or env wrapper.
 cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 mkdir -p gpurun_out
@@ -19,7 +20,7 @@ pmc)
 traffic)
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf gpurun_out/pmc_$c
-    rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc_$c -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --serial > /dev/null 2> gpurun_out/pmc_$c.err
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc_$c -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --serial $BENCH_ARGS > /dev/null 2> gpurun_out/pmc_$c.err
   done
   python tools/pmc_summary.py --traffic ;;
 trace)   # per-dispatch timeline of one serial step: which ICP iteration costs what
