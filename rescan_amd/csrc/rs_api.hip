@@ -392,7 +392,8 @@ rs_hip_cloud_t* rs_hip_cloud_create( const float* pos, const float* nor, int32_t
         }
         if( per_cell >= 4.0f || attempt == 7 ) { cell_size = 2.0f * c0 / std::sqrt( std::max( per_cell, 1.0f ) ); break; }
       }
-      cell_size = std::min( std::max( cell_size, 0.005f ), 2.0f );
+      static const float scale = getenv( "RS_HIP_AUTO_CELL_SCALE" ) ? (float)atof( getenv( "RS_HIP_AUTO_CELL_SCALE" ) ) : 1.0f;
+      cell_size = std::min( std::max( cell_size * scale, 0.005f ), 2.0f );
     }
   }
   int dims[3] = { 1, 1, 1 };

@@ -1382,7 +1382,8 @@ void launch_icp_corr( const IcpLaunch& L, hipStream_t st )
   // a short queue is latency-bound by its heaviest tile: give every tile more waves
   if( L.coop_waves >= 8 ) hipLaunchKernelGGL( k_icp_corr_coop<8>, cgrid, dim3( 8 * WAVE ), 0, st, L );
   else                    hipLaunchKernelGGL( k_icp_corr_coop<COOP_WAVES>, cgrid, dim3( COOP_BLOCK ), 0, st, L );
-  hipLaunchKernelGGL( k_icp_stats, dim3( L.n_prob ), dim3( STATS_BLOCK ), 0, st, L );
+  // (the reference-order estimator computes its own statistics; with no phase A there is no queue or slow-tile list to reset either)
+  if( !( L.coop_all && L.faith ) ) hipLaunchKernelGGL( k_icp_stats, dim3( L.n_prob ), dim3( STATS_BLOCK ), 0, st, L );
 }
 void launch_icp_faithful( const IcpLaunch& L, hipStream_t st )
 {
