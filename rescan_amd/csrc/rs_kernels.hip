@@ -74,25 +74,79 @@ __device__ __forceinline__ void wave_lds_fence()
   __builtin_amdgcn_wave_barrier();
 }
 
-__device__ __forceinline__ float wave_min( float v ) {
-#pragma unroll
-  for( int o = 32; o > 0; o >>= 1 ) v = fminf( v, __shfl_xor( v, o ) );
-  return v;
+// Wave-wide reductions and the lane prefix sum through DPP lane moves (data-parallel primitives: one VALU instruction
+// per step, no LDS round trip), instead of ds_bpermute shuffles, whose six dependent LDS round trips per reduction
+// were ~15 % of phase A's instructions and a few microseconds of every tile's latency chain.
+//   quad_perm [1,0,3,2] / [2,3,0,1]: lane ^ 1, lane ^ 2;  row_half_mirror / row_mirror: reversed within 8 / 16 lanes
+//   (after the quad steps every lane of a row of 16 holds the row's result);  row_bcast:15 into rows 1 and 3, then
+//   row_bcast:31 into rows 2 and 3: lane 63 ends with the whole wave's result and is read back as a scalar.
+#define RS_DPP_QUAD_XOR1   0xB1
+#define RS_DPP_QUAD_XOR2   0x4E
+#define RS_DPP_ROW_SHR( n ) ( 0x110 + ( n ) )
+#define RS_DPP_ROW_MIRROR  0x140
+#define RS_DPP_HALF_MIRROR 0x141
+#define RS_DPP_BCAST15     0x142
+#define RS_DPP_BCAST31     0x143
+// lanes whose source is outside the row / disabled by ROW_MASK keep `old`
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f( float old, float v )
+{
+  return __int_as_float( __builtin_amdgcn_update_dpp( __float_as_int( old ), __float_as_int( v ), CTRL, ROW_MASK, 0xf, false ) );
 }
-__device__ __forceinline__ float wave_max( float v ) {
-#pragma unroll
-  for( int o = 32; o > 0; o >>= 1 ) v = fmaxf( v, __shfl_xor( v, o ) );
-  return v;
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_u( uint32_t old, uint32_t v )
+{
+  return (uint32_t)__builtin_amdgcn_update_dpp( (int)old, (int)v, CTRL, ROW_MASK, 0xf, false );
 }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_d( double old, double v )
+{
+  const long long o = __double_as_longlong( old ), x = __double_as_longlong( v );
+  const uint32_t lo = dpp_u<CTRL, ROW_MASK>( (uint32_t)o, (uint32_t)x );
+  const uint32_t hi = dpp_u<CTRL, ROW_MASK>( (uint32_t)( (unsigned long long)o >> 32 ), (uint32_t)( (unsigned long long)x >> 32 ) );
+  return __longlong_as_double( (long long)( ( (unsigned long long)hi << 32 ) | lo ) );
+}
+__device__ __forceinline__ float lane63( float v ) { return __int_as_float( __builtin_amdgcn_readlane( __float_as_int( v ), 63 ) ); }
+
+// One instruction per step, in place (v = op(v moved, v); lanes of rows outside row_mask keep v).  The hazard
+// recogniser does not see inside inline assembly, so the wait states are spelled out: 5 after a possible VALU write
+// of EXEC before the first DPP read, 2 between a VALU write of a VGPR and a DPP read of it (CDNA3 ISA §4.5).
+#define RS_DPP_REDUCE( OP, v )                                                              \
+  asm volatile( "s_nop 4\n\t"                                                               \
+                OP " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t" \
+                OP " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t" \
+                OP " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"     \
+                OP " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"          \
+                OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"        \
+                OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"            \
+                : "+v"( v ) )
+__device__ __forceinline__ float wave_min( float v ) { RS_DPP_REDUCE( "v_min_f32_dpp", v ); return lane63( v ); }
+__device__ __forceinline__ float wave_max( float v ) { RS_DPP_REDUCE( "v_max_f32_dpp", v ); return lane63( v ); }
+// fixed association: ((quad) + mirrored quad) + mirrored half-row, then rows 0..3 in order
 __device__ __forceinline__ double wave_sum( double v ) {
-#pragma unroll
-  for( int o = 32; o > 0; o >>= 1 ) v += __shfl_xor( v, o );
-  return v;
+  v += dpp_d<RS_DPP_QUAD_XOR1, 0xf>( 0.0, v );
+  v += dpp_d<RS_DPP_QUAD_XOR2, 0xf>( 0.0, v );
+  v += dpp_d<RS_DPP_HALF_MIRROR, 0xf>( 0.0, v );
+  v += dpp_d<RS_DPP_ROW_MIRROR, 0xf>( 0.0, v );
+  v += dpp_d<RS_DPP_BCAST15, 0xa>( 0.0, v );
+  v += dpp_d<RS_DPP_BCAST31, 0xc>( 0.0, v );
+  const long long r = __double_as_longlong( v );
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane( (int)(uint32_t)r, 63 );
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane( (int)(uint32_t)( (unsigned long long)r >> 32 ), 63 );
+  return __longlong_as_double( (long long)( ( (unsigned long long)hi << 32 ) | lo ) );
 }
-// inclusive prefix sum over the 64 lanes
+// inclusive prefix sum over the 64 lanes: Kogge-Stone within each row of 16 (row_shr 1, 2, 4, 8: lanes without a
+// source add 0), then the totals of the rows before (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3)
 __device__ __forceinline__ uint32_t wave_scan( uint32_t v, int lane ) {
-#pragma unroll
-  for( int o = 1; o < WAVE; o <<= 1 ) { uint32_t t = __shfl_up( v, o ); if( lane >= o ) v += t; }
+  (void)lane;
+  asm volatile( "s_nop 4\n\t"
+                "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+                "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+                : "+v"( v ) );
   return v;
 }
 
@@ -240,7 +294,7 @@ __device__ __forceinline__ uint32_t sweep_shell( const GridView& g, const CellBo
       }
     }
     const uint32_t incl = wave_scan( la + lb, lane );
-    const uint32_t total = (uint32_t)uni( (int)__shfl( incl, WAVE - 1 ) );
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane( (int)incl, WAVE - 1 );
     L.seg_a[lane] = sa; L.len_a[lane] = la; L.seg_b[lane] = sb; L.pre[lane] = incl - ( la + lb );
     streamed += total;
     wave_lds_fence();
