@@ -96,7 +96,7 @@ struct PinBuf
 
 struct Workspace
 {
-  DevBuf state, slot, d2, dot, corr_part, mom_part, res, wexp, queue, queue_count;   // ICP
+  DevBuf state, slot, d2, dot, stat_acc, mom_part, res, wexp, queue, queue_count;   // ICP
   DevBuf poses, score_part, scores;                                             // score
   DevBuf plc, labels, mind;                                                     // labels
   DevBuf q4, rd2, ridx, rnn, rows;                                              // rows / misc
@@ -574,7 +574,7 @@ int icp_prepare( IcpCtx& cx, const rs_hip_cloud_t* src, const rs_hip_cloud_t* tg
   int rc;
   if( ( rc = g_ws.state.ensure( np * ICP_STATE_WORDS * 4 ) ) ||
       ( rc = g_ws.slot.ensure( np * nq * 4 ) ) || ( rc = g_ws.d2.ensure( np * nq * 4 ) ) || ( rc = g_ws.dot.ensure( np * nq * 4 ) ) ||
-      ( rc = g_ws.corr_part.ensure( np * std::max( 1, cx.n_waves ) * 3 * 8 ) ) ||
+      ( rc = g_ws.stat_acc.ensure( np * STAT_SHARDS * 4 * 8 ) ) ||
       ( rc = g_ws.mom_part.ensure( np * L.n_mom_blocks * ICP_NMOM * 8 ) ) || ( rc = g_ws.res.ensure( np * ICP_NRES * 8 ) ) ||
       ( rc = g_ws.h_a.ensure( np * ICP_NRES * 8 ) ) || ( rc = g_ws.h_b.ensure( np * ICP_STATE_WORDS * 4 ) ) ||
       ( rc = g_ws.queue.ensure( np * std::max( 1, cx.n_waves ) * 4 ) ) || ( rc = g_ws.queue_count.ensure( np * 4 ) ) )
@@ -588,7 +588,7 @@ int icp_prepare( IcpCtx& cx, const rs_hip_cloud_t* src, const rs_hip_cloud_t* tg
   L.seed = getenv( "RS_HIP_NO_SEED" ) ? 0 : 1;
   L.cert_r = nullptr; L.cert_dot = nullptr; L.tgt_nor_max = tgt->nor_max;
   L.m_slot = g_ws.slot.as<int>(); L.m_d2 = g_ws.d2.as<float>(); L.m_dot = g_ws.dot.as<float>();
-  L.corr_part = g_ws.corr_part.as<double>();
+  L.stat_acc = nullptr;       // set by the align loop (fp64 estimator only)
   L.mom_part = g_ws.mom_part.as<double>(); L.res = g_ws.res.as<double>();
   L.w_explicit = nullptr;
   L.by_orig = src->d_qby_orig; L.faith = nullptr;
@@ -644,7 +644,7 @@ void icp_debug_after( IcpCtx& cx, int n_src, int n, int i, float max_dist )
 {
   (void)hipStreamSynchronize( g_stream );
   std::vector<int> qc( n ), ms( (size_t)n_src ); std::vector<float> cr( cx.L.cert_r ? (size_t)n_src : 0 );
-  (void)hipMemcpy( qc.data(), cx.L.queued, (size_t)n * 4, hipMemcpyDeviceToHost );
+  (void)hipMemcpy( qc.data(), cx.L.queue_count, (size_t)n * 4, hipMemcpyDeviceToHost );      // (reset when the iteration ends)
   (void)hipMemcpy( ms.data(), cx.L.m_slot, ms.size() * 4, hipMemcpyDeviceToHost );
   if( cx.L.cert_r ) (void)hipMemcpy( cr.data(), cx.L.cert_r, cr.size() * 4, hipMemcpyDeviceToHost );
   size_t unm = 0, cert = 0;
@@ -701,6 +701,14 @@ void icp_debug_after( IcpCtx& cx, int n_src, int n, int i, float max_dist )
 void icp_set_radius( IcpCtx& cx, float max_dist, float tmin )
 {
   cx.L.radius = max_dist; cx.L.radius_sq = radius_sq_of( max_dist ); cx.L.gate_tmin = tmin;
+  // fixed-point scales of the dist² statistics: r²·2^e1 and r⁴·2^e2 just below 2^36, so that a tile's sum (64 terms)
+  // and the sum over 2^22 tiles stay below 2^64, with 36 bits below the radius
+  const double r2 = cx.L.radius_sq;
+  int e1 = 0, e2 = 0;
+  if( r2 > 0.0 && std::isfinite( r2 ) ) { e1 = 35 - std::ilogb( r2 ); e2 = 35 - std::ilogb( r2 * r2 ); }
+  e1 = std::max( -900, std::min( 900, e1 ) ); e2 = std::max( -900, std::min( 900, e2 ) );
+  cx.L.stat_s1 = std::ldexp( 1.0, e1 ); cx.L.stat_i1 = std::ldexp( 1.0, -e1 );
+  cx.L.stat_s2 = std::ldexp( 1.0, e2 ); cx.L.stat_i2 = std::ldexp( 1.0, -e2 );
 }
 
 } // namespace
@@ -723,6 +731,11 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
   {
     if( ( rc = g_ws.faith.ensure( (size_t)n * FAITH_REC * (size_t)source->n * 4 ) ) ) return rc;
     cx.L.faith = g_ws.faith.as<float>();
+  }
+  else
+  {
+    HIP_TRY( hipMemsetAsync( g_ws.stat_acc.p, 0, (size_t)n * STAT_SHARDS * 4 * 8, g_stream ), RS_HIP_E_RUNTIME );
+    cx.L.stat_acc = g_ws.stat_acc.as<unsigned long long>();
   }
   const size_t heavy_words = (size_t)n * ( (size_t)cx.n_waves + HEAVY_SLOTS + 1 );
   const bool reorder = !getenv( "RS_HIP_NO_LPT" );

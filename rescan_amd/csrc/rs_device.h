@@ -10,6 +10,7 @@ namespace rs {
 // cell id = (z*h + y)*w + x, so the cells of one (y,z) row are contiguous in x and a row's
 // x-interval [x0,x1] is the single span cell_start[row+x0] .. cell_start[row+x1+1].
 constexpr int EVAL_SHARDS = 1024;
+constexpr int STAT_SHARDS = 256;    // integer accumulators the tiles of an ICP search add their dist² statistics to
 
 struct GridView
 {
@@ -68,9 +69,12 @@ struct IcpLaunch
   int*    m_slot;   // n_prob x nq : matched target slot or -1
   float*  m_d2;     // n_prob x nq
   float*  m_dot;    // n_prob x nq
-  double* corr_part;  // n_prob x n_tiles x 3
+  // dist² statistics of the correspondences: n_prob x STAT_SHARDS x {Σ1, Σd²·stat_s1, Σd⁴·stat_s2, -} as integers
+  // (null: not wanted — reference-order estimator, find_corrs / estimate-only entry points)
+  unsigned long long* stat_acc;
+  double  stat_s1, stat_s2, stat_i1, stat_i2;   // fixed-point scales (powers of two chosen from the radius) and their inverses
   double* mom_part;   // n_prob x n_mom_blocks x ICP_NMOM
-  double* res;        // n_prob x ICP_NRES : moments [0,35), then n_corr, mean, stddev, queued tiles
+  double* res;        // n_prob x ICP_NRES : moments [0,35), then n_corr, mean, stddev, queued tiles (written by k_icp_moments)
   int     n_mom_blocks;
   int*    queue;        // n_prob x n_tiles : tiles handed to the cooperative kernel
   int*    queue_count;  // n_prob
@@ -103,7 +107,7 @@ struct IcpLaunch
   const int* by_orig;   // original source index -> query slot (null: identity)
   float*  faith;        // n_prob x FAITH_REC x nq: the correspondences in the source's own order
 };
-void launch_icp_corr( const IcpLaunch& L, hipStream_t st );     // phase A, phase B (+ statistics of dist² over the correspondences)
+void launch_icp_corr( const IcpLaunch& L, hipStream_t st );     // phase A, phase B (the tiles add their dist² statistics to L.stat_acc)
 void launch_icp_moments( const IcpLaunch& L, hipStream_t st );  // weights + moments (+ solve and loop-state update if L.solve)
 constexpr int FAITH_REC = 11;   // per correspondence: dist² (< 0: none), dot | weight, p, q, n
 void launch_icp_faithful( const IcpLaunch& L, hipStream_t st ); // the same step with the reference's own accumulation order and precisions

@@ -135,6 +135,23 @@ __device__ __forceinline__ double wave_sum( double v ) {
   const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane( (int)(uint32_t)( (unsigned long long)r >> 32 ), 63 );
   return __longlong_as_double( (long long)( ( (unsigned long long)hi << 32 ) | lo ) );
 }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_u64( unsigned long long v )
+{
+  const uint32_t lo = dpp_u<CTRL, ROW_MASK>( 0u, (uint32_t)v ), hi = dpp_u<CTRL, ROW_MASK>( 0u, (uint32_t)( v >> 32 ) );
+  return ( (unsigned long long)hi << 32 ) | lo;
+}
+__device__ __forceinline__ unsigned long long wave_sum_u64( unsigned long long v ) {
+  v += dpp_u64<RS_DPP_QUAD_XOR1, 0xf>( v );
+  v += dpp_u64<RS_DPP_QUAD_XOR2, 0xf>( v );
+  v += dpp_u64<RS_DPP_HALF_MIRROR, 0xf>( v );
+  v += dpp_u64<RS_DPP_ROW_MIRROR, 0xf>( v );
+  v += dpp_u64<RS_DPP_BCAST15, 0xa>( v );
+  v += dpp_u64<RS_DPP_BCAST31, 0xc>( v );
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane( (int)(uint32_t)v, 63 );
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane( (int)(uint32_t)( v >> 32 ), 63 );
+  return ( (unsigned long long)hi << 32 ) | lo;
+}
 // inclusive prefix sum over the 64 lanes: Kogge-Stone within each row of 16 (row_shr 1, 2, 4, 8: lanes without a
 // source add 0), then the totals of the rows before (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3)
 __device__ __forceinline__ uint32_t wave_scan( uint32_t v, int lane ) {
@@ -854,16 +871,37 @@ __device__ __forceinline__ void icp_emit( const IcpLaunch& L, int prob, int tile
     const int c_loose = __popcll( __ballot( active && !skipped && !m.found && !margin && m.idx == INT_MAX ) );
     if( lane == 0 ) { atomicAdd( cat + 0, (unsigned long long)c_skip ); atomicAdd( cat + 1, (unsigned long long)c_fresh ); atomicAdd( cat + 2, (unsigned long long)c_rank ); atomicAdd( cat + 3, (unsigned long long)c_loose ); }
   }
-  // statistics of dist² over correspondences (msh_compute_mean/stddev, msh_std.h:1800-1825)
-  const double c = (double)__popcll( __ballot( active && m.found ) );
-  double s1 = ( active && m.found ) ? (double)m.d2 : 0.0;
-  double s2 = ( active && m.found ) ? (double)( m.d2 * m.d2 ) : 0.0;
-  s1 = wave_sum( s1 ); s2 = wave_sum( s2 );
-  if( lane == 0 )
+  // statistics of dist² over the correspondences (msh_compute_mean/stddev, msh_std.h:1800-1825): Σ1, Σd², Σd⁴ of the
+  // tile, added as INTEGERS (fixed point, scaled to the radius) to one of STAT_SHARDS accumulators — integer addition
+  // does not care in which order the tiles arrive, so the totals are bit-reproducible without a fixed-order pass
+  // (and without the kernel launch that pass used to be).
+  if( L.stat_acc )
   {
-    double* out = L.corr_part + ( (size_t)prob * L.src.n_tiles + tile ) * 3;
-    out[0] = c; out[1] = s1; out[2] = s2;
+    const unsigned long long c = (unsigned long long)__popcll( __ballot( active && m.found ) );
+    double s1 = ( active && m.found ) ? (double)m.d2 : 0.0;
+    double s2 = ( active && m.found ) ? (double)( m.d2 * m.d2 ) : 0.0;
+    s1 = wave_sum( s1 ); s2 = wave_sum( s2 );
+    if( lane == 0 && c != 0 )
+    {
+      unsigned long long* a = L.stat_acc + ( (size_t)prob * STAT_SHARDS + ( tile & ( STAT_SHARDS - 1 ) ) ) * 4;
+      atomicAdd( a + 0, c );
+      atomicAdd( a + 1, (unsigned long long)( s1 * L.stat_s1 ) );
+      atomicAdd( a + 2, (unsigned long long)( s2 * L.stat_s2 ) );
+    }
   }
+}
+
+// What has to be reset between two searches of a problem (done by the workgroup that ends the iteration).
+__device__ __forceinline__ void icp_iteration_reset( const IcpLaunch& L, int prob )
+{
+  if( threadIdx.x == 0 )
+  {
+    if( L.queued ) L.queued[prob] = L.queue_count[prob];       // tiles phase A handed off (diagnostics)
+    L.queue_count[prob] = 0;                                   // ready for the next iteration's phase A
+    if( L.heavy_in ) const_cast<int*>( L.heavy_in )[(size_t)prob * ( L.src.n_tiles + HEAVY_SLOTS + 1 )] = 0;   // consumed: it is the next iteration's output buffer
+  }
+  if( L.stat_acc )
+    for( int k = threadIdx.x; k < STAT_SHARDS * 4; k += blockDim.x ) L.stat_acc[(size_t)prob * STAT_SHARDS * 4 + k] = 0ull;
 }
 
 // Phase A: one wave per tile, first shell(s) only; unsettled tiles are queued.
@@ -933,53 +971,6 @@ __global__ __launch_bounds__( BLOCK, RS_ICP_OCC ) void k_icp_corr( IcpLaunch L )
     return;
   }
   icp_emit( L, prob, tile, i, active, lane, m, active & !search );
-}
-
-// Fixed-order sum of the per-tile partials -> n_corr, mean, stddev (msh_std.h:1800-1825) by a workgroup of
-// STATS_BLOCK threads (the loads are latency-bound: many threads, few rounds).  `red`: 3*STATS_BLOCK doubles.
-#define STATS_BLOCK 1024
-__device__ __forceinline__ void icp_stats_block( const IcpLaunch& L, int prob, double* red )
-{
-  const int T = STATS_BLOCK, t = threadIdx.x;
-  const int n_tiles = L.src.n_tiles;
-  const double* in = L.corr_part + (size_t)prob * n_tiles * 3;
-  __syncthreads();                                 // the scratch may alias LDS the tile loop used
-  if( t < T )
-  {
-    double a = 0, b = 0, c = 0;
-    for( int w = t; w < n_tiles; w += T ) { a += in[3*w]; b += in[3*w+1]; c += in[3*w+2]; }
-    red[t] = a; red[T + t] = b; red[2 * T + t] = c;
-  }
-  __syncthreads();
-  for( int s = T / 2; s > 0; s >>= 1 )
-  {
-    if( t < s ) { red[t] += red[t + s]; red[T + t] += red[T + t + s]; red[2 * T + t] += red[2 * T + t + s]; }
-    __syncthreads();
-  }
-  if( t == 0 )
-  {
-    double n = red[0];
-    float mean = (float)( red[T] / n );                    // sum / (float)n
-    float sqm = (float)( red[2 * T] / n );                 // sq_sum / (float)n
-    float var = sqm - mean * mean;
-    float sd = (float)sqrt( (double)var );                 // (float)sqrt( ... ), msh_std.h:1824
-    double* st = L.res + (size_t)prob * ICP_NRES + ICP_NMOM;
-    st[0] = n; st[1] = mean; st[2] = sd; st[3] = (double)L.queue_count[prob];   // [3]: tiles phase A handed off
-    if( L.queued ) L.queued[prob] = L.queue_count[prob];
-    L.queue_count[prob] = 0;                               // ready for the next iteration's phase A
-    if( L.heavy_in ) const_cast<int*>( L.heavy_in )[(size_t)prob * ( L.src.n_tiles + HEAVY_SLOTS + 1 )] = 0;   // consumed: it is the next iteration's output buffer
-  }
-}
-
-// One workgroup per problem.
-// (A "last workgroup done" ticket inside the search kernels would save this launch, but a device-scope
-// fence per workgroup writes back the XCD's L2 on this part: measured 4x slower than the launch.)
-__global__ __launch_bounds__( STATS_BLOCK ) void k_icp_stats( IcpLaunch L )
-{
-  __shared__ double red[3 * STATS_BLOCK];
-  const int prob = blockIdx.x;
-  if( L.active[prob] == 0 ) return;
-  icp_stats_block( L, prob, red );
 }
 
 // Phase B: one workgroup per queued tile, whole box, chunks shared by its waves.
@@ -1060,7 +1051,31 @@ __global__ __launch_bounds__( BLOCK ) void k_icp_moments( IcpLaunch L )
   Xform T1;
 #pragma unroll
   for( int k = 0; k < 16; ++k ) T1.m[k] = L.T1[prob * 16 + k];
-  const float sd = (float)L.res[(size_t)prob * ICP_NRES + ICP_NMOM + 2];
+  // n_corr, mean, stddev of dist² (icp.h:393-402) from the integer accumulators: every workgroup adds up the same
+  // STAT_SHARDS integers, so all of them hold the same bits
+  __shared__ unsigned long long s_stat[WAVES_PER_BLOCK][3];
+  float sd = 0.0f;
+  if( L.stat_acc )
+  {
+    static_assert( STAT_SHARDS == BLOCK, "one shard per thread" );
+    const unsigned long long* a = L.stat_acc + ( (size_t)prob * STAT_SHARDS + threadIdx.x ) * 4;
+    const unsigned long long c0 = wave_sum_u64( a[0] ), c1 = wave_sum_u64( a[1] ), c2 = wave_sum_u64( a[2] );
+    if( ( threadIdx.x & ( WAVE - 1 ) ) == 0 ) { unsigned long long* o = s_stat[threadIdx.x / WAVE]; o[0] = c0; o[1] = c1; o[2] = c2; }
+    __syncthreads();
+    unsigned long long t0 = 0, t1 = 0, t2 = 0;
+#pragma unroll
+    for( int w = 0; w < WAVES_PER_BLOCK; ++w ) { t0 += s_stat[w][0]; t1 += s_stat[w][1]; t2 += s_stat[w][2]; }
+    const double n = (double)t0;
+    const float mean = (float)( (double)t1 * L.stat_i1 / n );           // sum / (float)n
+    const float sqm = (float)( (double)t2 * L.stat_i2 / n );            // sq_sum / (float)n
+    const float var = sqm - mean * mean;
+    sd = (float)sqrt( (double)var );                                    // (float)sqrt( ... ), msh_std.h:1824
+    if( blockIdx.x == 0 && threadIdx.x == 0 )
+    {
+      double* st = L.res + (size_t)prob * ICP_NRES + ICP_NMOM;
+      st[0] = n; st[1] = mean; st[2] = sd; st[3] = (double)L.queue_count[prob];
+    }
+  }
   const bool use_sd = sd > 0.000001;
   const float cut = 2.5f * sd;
 
@@ -1137,7 +1152,9 @@ __global__ __launch_bounds__( UPDATE_WAVES * WAVE ) void k_icp_update( IcpLaunch
     if( lane == 0 ) res[k] = v;
   }
   __syncthreads();
-  if( threadIdx.x != 0 || !L.solve ) return;
+  if( !L.solve ) return;
+  icp_iteration_reset( L, prob );
+  if( threadIdx.x != 0 ) return;
   // ---- icp.h:455-493 for this problem ----
   L.prev_err[prob] = L.err[prob];
   L.iters[prob] += 1;
@@ -1357,6 +1374,7 @@ __global__ __launch_bounds__( FAITH_THREADS ) void k_icp_faithful( IcpLaunch L )
   __shared__ double s_d[2];
   const int prob = blockIdx.x;
   if( L.active[prob] == 0 ) return;
+  if( L.solve ) icp_iteration_reset( L, prob );            // (the search of this iteration is over: its queue has been consumed)
   const int wib = threadIdx.x / WAVE, lane = threadIdx.x & ( WAVE - 1 );
   const int n = L.src.n;
   const float* F = L.faith + (size_t)prob * FAITH_REC * n;
@@ -1425,7 +1443,7 @@ __global__ __launch_bounds__( FAITH_THREADS ) void k_icp_faithful( IcpLaunch L )
 
 void launch_icp_corr( const IcpLaunch& L, hipStream_t st )
 {
-  // queue_count is zero on entry: cleared once by the host, then by the cooperative kernel's last workgroup after every use
+  // queue_count is zero on entry: cleared once by the host, then by the workgroup that ends every iteration (icp_iteration_reset)
   // A launch of a few hundred tiles leaves every wave alone on its SIMD, i.e. latency-bound, and phase A's slowest tile
   // sets its time: such launches skip phase A and give every tile a workgroup straight away (coop_all).
   dim3 grid( ( L.src.n_tiles + ( L.heavy_in ? HEAVY_SLOTS : 0 ) + WAVES_PER_BLOCK - 1 ) / WAVES_PER_BLOCK, L.n_prob );
@@ -1436,8 +1454,6 @@ void launch_icp_corr( const IcpLaunch& L, hipStream_t st )
   // a short queue is latency-bound by its heaviest tile: give every tile more waves
   if( L.coop_waves >= 8 ) hipLaunchKernelGGL( k_icp_corr_coop<8>, cgrid, dim3( 8 * WAVE ), 0, st, L );
   else                    hipLaunchKernelGGL( k_icp_corr_coop<COOP_WAVES>, cgrid, dim3( COOP_BLOCK ), 0, st, L );
-  // (the reference-order estimator computes its own statistics; with no phase A there is no queue or slow-tile list to reset either)
-  if( !( L.coop_all && L.faith ) ) hipLaunchKernelGGL( k_icp_stats, dim3( L.n_prob ), dim3( STATS_BLOCK ), 0, st, L );
 }
 void launch_icp_faithful( const IcpLaunch& L, hipStream_t st )
 {
