@@ -436,8 +436,11 @@ __device__ __forceinline__ void consider4( const float4& X, const float4& Y, con
     dc[2] = b.x > 0.0f ? b.x : 0.0f; dc[3] = b.y > 0.0f ? b.y : 0.0f;
     p0 &= ( dc[0] >= tmin ) & ( dc[0] <= 1.0f ); p1 &= ( dc[1] >= tmin ) & ( dc[1] <= 1.0f );
     p2 &= ( dc[2] >= tmin ) & ( dc[2] <= 1.0f ); p3 &= ( dc[3] >= tmin ) & ( dc[3] <= 1.0f );
-    m.fail_max = fmaxf( fmaxf( m.fail_max, ( in0 & !p0 ) ? dc[0] : 0.0f ), ( in1 & !p1 ) ? dc[1] : 0.0f );
-    m.fail_max = fmaxf( fmaxf( m.fail_max, ( in2 & !p2 ) ? dc[2] : 0.0f ), ( in3 & !p3 ) ? dc[3] : 0.0f );
+    if( SELF )     // only the ICP instantiation issues certificates (icp_emit); the score batch has no use for fail_max
+    {
+      m.fail_max = fmaxf( fmaxf( m.fail_max, ( in0 & !p0 ) ? dc[0] : 0.0f ), ( in1 & !p1 ) ? dc[1] : 0.0f );
+      m.fail_max = fmaxf( fmaxf( m.fail_max, ( in2 & !p2 ) ? dc[2] : 0.0f ), ( in3 & !p3 ) ? dc[3] : 0.0f );
+    }
   }
   if( __any( p0 | p1 | p2 | p3 ) )
   {
