@@ -96,7 +96,7 @@ int rs_hip_icp_align( const rs_hip_cloud_t* source, const rs_hip_cloud_t* target
  * `n_points` points use the reference's own accumulation order and precisions (one sequential fp32 chain
  * per accumulator): poses, errors and iteration counts are bit-identical to the reference's.  Larger
  * sources use a parallel fp64 reduction of the same sums: more accurate than the reference, equal to it
- * within its own fp32 rounding.  Default 16384 (environment: RS_HIP_REF_ORDER_BELOW);
+ * within its own fp32 rounding.  Default 65536 — every icp_align call site of the reference — (environment: RS_HIP_REF_ORDER_BELOW);
  * 0 = always the fp64 reduction; n_points < 0 only reads.  Returns the previous threshold.  Applies to
  * rs_hip_icp_align, rs_hip_icp_align_batch and rs_hip_icp_estimate_pt2pl. */
 int32_t rs_hip_icp_reference_order_below( int32_t n_points );

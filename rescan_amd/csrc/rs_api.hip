@@ -114,8 +114,9 @@ thread_local Workspace g_ws;
 // ---- profiling ---------------------------------------------------------------------------
 bool g_prof = false;
 // Sources of at most this many points run the ICP estimator in the reference's own accumulation order and precisions
-// (bit-identical poses, errors and iteration counts); larger ones the fp64 moment reduction.
-std::atomic<int> g_ref_order_below{ getenv( "RS_HIP_REF_ORDER_BELOW" ) ? atoi( getenv( "RS_HIP_REF_ORDER_BELOW" ) ) : 16384 };
+// (bit-identical poses, errors and iteration counts); larger ones the fp64 moment reduction.  65 536 covers
+// every icp_align call site of the reference (level-2 objects, 2-10 k points; scene extracts of up to ~50 k).
+std::atomic<int> g_ref_order_below{ getenv( "RS_HIP_REF_ORDER_BELOW" ) ? atoi( getenv( "RS_HIP_REF_ORDER_BELOW" ) ) : 65536 };
 std::mutex g_prof_mutex;
 struct ProfEntry { std::vector<std::pair<hipEvent_t, hipEvent_t>> spans; int64_t launches = 0; double ms = 0.0; };
 std::map<std::string, ProfEntry> g_profmap;

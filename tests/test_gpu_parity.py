@@ -116,7 +116,7 @@ def test_icp_align_reference_order_is_bit_identical(capi, gscene, scene_clouds, 
     clouds, objs = scene_clouds
     md = float(g["max_dist"])
     src = objs[int(g["obj"])]
-    prev = capi.icp_reference_order_below(max(src.n, 16384))
+    prev = capi.icp_reference_order_below(max(src.n, 65536))
     try:
         err, T, iters = capi.icp_align(src, clouds[round(md, 3)], g["T1"], g["T2"], md, g["max_angle"])
     finally:
@@ -142,9 +142,9 @@ def test_icp_reference_order_vs_oracle_seeded(capi, oracle):
         oc = capi.Cloud(o["pos"], o["nor"])
         import os
         if "RS_HIP_REF_ORDER_BELOW" in os.environ:
-            capi.icp_reference_order_below(16384)
+            capi.icp_reference_order_below(65536)
         else:
-            assert oc.n <= prev == 16384                      # the default threshold covers object-sized sources
+            assert oc.n <= prev == 65536                      # the default threshold covers object-sized sources
         T0s = np.stack([synth.perturbed_pose(o["pose"], rng, 0.05, 0.05) for _ in range(4)])
         errs, Ts, its = capi.icp_align_batch(oc, a, T0s, I4, 0.075, ang)
         for k in range(4):
