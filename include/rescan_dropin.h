@@ -99,6 +99,14 @@ int64_t rsd_compute_neighborhood( const rsd_vec3_t* pos, const rsd_vec3_t* nor, 
                                   int32_t max_nn, float radius_sq, float dist_exp, float angle_exp,
                                   int32_t* idx1, int32_t* idx2, float* weight );
 
+/* rs_pointcloud__compute_level_poisson (lib/rs/rs_pointcloud.h:984-1106) on pc->positions[0]: the indices of the
+ * level's samples, increasing — the caller fills positions/normals/colors/... [level][i] = [0][sample_idx[i]] as the
+ * reference does (:1090-1099).  voxel_size = pc->voxel_size[level]; the reference's cap on a search,
+ * max_n_neigh = 1024 * level / (RSPC_N_LEVELS - 1) or 256 (:995-996), is derived from `level`.  sample_idx has
+ * capacity n.  Returns the number of samples (< 0: error; RS_HIP_E_CAPACITY if a point has more than max_n_neigh
+ * points within voxel_size, where a reference search would be truncated). */
+int32_t rsd_level_poisson( const rsd_vec3_t* pos, int32_t n, float voxel_size, int32_t level, int32_t* sample_idx );
+
 /* Scene-coverage term of the arrangement optimiser (apps/segment_transfer/arrangement_optimization.cpp:344-373).
  * rsd_coverage_create replaces isect_grid3d_init + rsao_rasterize_scene_to_grid for opts->scn_grd
  * (apps/segment_transfer/main.cpp:323-339); rsd_coverage_score replaces the body of

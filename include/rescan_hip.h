@@ -166,6 +166,20 @@ int rs_hip_arrangement_to_labels( const rs_hip_cloud_t* scene,
                                   float radius, int prioritize_static,
                                   int8_t* labels, float* min_dists, int32_t* sorted_order );
 
+/* ---- level builder ---------------------------------------------------- */
+
+/* rs_pointcloud__compute_level_poisson (lib/rs/rs_pointcloud.h:984-1106): Poisson-disk subsample of
+ * `cloud` in INPUT order — the first point no earlier sample has marked becomes a sample and marks
+ * every point within `radius` of it (the reference's searches return at most max_n_neigh points;
+ * for level L it uses radius = voxel_size[L] = 0.005·2^L and max_n_neigh = 1024·L/4, 256 for L = 0,
+ * :995-996,1011).  sample_idx (capacity = cloud size) receives the sample indices in increasing
+ * order — the order in which the reference fills the level's arrays (:1090-1099); n_rounds (may be
+ * NULL) the number of decision rounds the device needed.  If some point has more than max_n_neigh
+ * points within the radius a reference search would be truncated to its max_n_neigh nearest; that
+ * case is not reproduced: the call fails with RS_HIP_E_CAPACITY and writes nothing. */
+int rs_hip_level_samples( const rs_hip_cloud_t* cloud, float radius, int32_t max_n_neigh,
+                          int32_t* sample_idx, int32_t* n_samples, int32_t* n_rounds );
+
 /* ---- neighbourhood graph ------------------------------------------ */
 
 /* rspf_compute_neighborhood (lib/rs/rs_pointcloud_filters.cpp:674-722): K = max_nn self-search

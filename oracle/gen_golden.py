@@ -23,6 +23,7 @@ Each fixture holds the inputs and the reference's outputs for one hot-path funct
 Usage:  python oracle/gen_golden.py                       (everything)
         python oracle/gen_golden.py --neighborhood-only   (adds those two without rewriting the rest)
         python oracle/gen_golden.py --coverage-only       (likewise)
+        python oracle/gen_golden.py --level-only          (likewise: level.npz)
 """
 import os
 import sys
@@ -151,6 +152,7 @@ def main():
 
     gen_neighborhood(O, R, s)
     gen_coverage(s)
+    gen_level(s)
 
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print(f"wrote {len(os.listdir(OUT))} fixtures, {total/1e6:.2f} MB")
@@ -199,6 +201,25 @@ def gen_coverage(s):
                         arr_first=np.array(arr_first, np.int32), scores=np.array(scores, np.float32))
 
 
+def gen_level(s):
+    """level.npz: rs_pointcloud__compute_level_poisson by the REFERENCE itself (oracle/_ref/libref_ao.so carries
+    rs_pointcloud.h, oracle/ref_ao_driver.cpp: ref_level_poisson) on the golden scene's points, levels 1-4, in the
+    scene's own point order and in a raster (z, y, x) order; the fixture stores the permutation and the sample indices."""
+    from oracle.pyoracle import ref_level_poisson
+    pts = s["points"]
+    raster = np.lexsort((pts[:, 0], pts[:, 1], pts[:, 2])).astype(np.int32)
+    out = dict(raster=raster)
+    for level in (1, 2, 3, 4):
+        out[f"own_l{level}"] = ref_level_poisson(pts, level)
+        out[f"raster_l{level}"] = ref_level_poisson(np.ascontiguousarray(pts[raster]), level)
+    np.savez_compressed(os.path.join(OUT, "level.npz"), **out)
+
+
+def main_level_only():
+    d = dict(np.load(os.path.join(OUT, "scene.npz")))
+    gen_level(dict(points=d["points"]))
+
+
 def main_coverage_only():
     d = dict(np.load(os.path.join(OUT, "scene.npz")))
     s = dict(points=d["points"], normals=d["normals"], instance_idx=d["instance_idx"],
@@ -219,6 +240,8 @@ def main_neighborhood_only():
 if __name__ == "__main__":
     if "--neighborhood-only" in sys.argv:
         main_neighborhood_only()
+    elif "--level-only" in sys.argv:
+        main_level_only()
     elif "--coverage-only" in sys.argv:
         main_coverage_only()
     else:

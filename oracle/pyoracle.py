@@ -255,6 +255,16 @@ class Oracle(_Base):
         f(C.byref(g), C.addressof(ptrs), ns, _f32(np.asarray(poses).reshape(-1, 16)), np.asarray(is_static, np.int32), n, data)
         return data
 
+    def level_poisson(self, pos, radius, max_n_neigh):
+        """rs_pointcloud__compute_level_poisson: indices of the samples (increasing)."""
+        pos = _f32(pos)
+        out = np.zeros(max(len(pos), 1), np.int32)
+        f = self.lib.orc_level_poisson
+        f.restype = C.c_int32
+        f.argtypes = [f32p, C.c_int32, C.c_float, C.c_int32, i32p]
+        m = f(pos, len(pos), float(radius), int(max_n_neigh), out)
+        return out[:m].copy()
+
     def coverage_score(self, scene_data, arr_data):
         f = self.lib.orc_coverage_score
         f.restype = C.c_float
@@ -416,3 +426,24 @@ class RefAO:
 
     def arrangement_grid(self):
         return self._grid("ref_ao_arrangement_grid")
+
+
+def ref_level_poisson(pos, level, voxel_size=0.0):
+    """The REAL reference's level builder (oracle/_ref/libref_ao.so: ref_level_poisson) -> sample indices."""
+    lib = C.CDLL(RefAO.PATH)
+    pos = _f32(pos)
+    out = np.zeros(max(len(pos), 1), np.int32)
+    f = lib.ref_level_poisson
+    f.restype = C.c_int32
+    f.argtypes = [f32p, C.c_int32, C.c_int32, C.c_float, i32p]
+    m = f(pos, len(pos), int(level), float(voxel_size), out)
+    return out[:m].copy()
+
+
+LEVEL_VOXEL = (0.005, 0.01, 0.02, 0.04, 0.08)          # rs_pointcloud.h:148
+
+
+def level_max_n_neigh(level):
+    """rs_pointcloud.h:995-996: size_t max_n_neigh = 1024 * (level / (float)(RSPC_N_LEVELS-1)); 256 if that is 0."""
+    m = int(np.float32(1024) * (np.float32(level) / np.float32(4)))
+    return m if m else 256

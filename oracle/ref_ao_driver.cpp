@@ -127,6 +127,27 @@ float ref_ao_coverage( void* hp, const int32_t* object_idx, const float* poses, 
   return s;
 }
 
+// rs_pointcloud__compute_level_poisson (lib/rs/rs_pointcloud.h:984-1106) of the REAL reference on a bare
+// cloud: level 0 holds the given points, its class ids carry the point indices, so the level's class ids come back as
+// the sample indices.  voxel_size > 0 overrides the level's resolution (rs_pointcloud.h:148).
+int32_t ref_level_poisson( const float* pts, int32_t n, int32_t level, float voxel_size, int32_t* out_idx )
+{
+  rs_pointcloud_t* pc = rs_pointcloud_init( 1 );
+  rs_pointcloud__allocate_level( pc, 0, n );
+  memcpy( pc->positions[0], pts, (size_t)n * sizeof(msh_vec3_t) );
+  memset( pc->normals[0], 0, (size_t)n * sizeof(msh_vec3_t) ); memset( pc->colors[0], 0, (size_t)n * sizeof(msh_vec3_t) );
+  memset( pc->radii[0], 0, (size_t)n * 4 ); memset( pc->qualities[0], 0, (size_t)n * 4 ); memset( pc->instance_ids[0], 0, (size_t)n * 4 );
+  for( int32_t i = 0; i < n; ++i ) pc->class_ids[0][i] = i;
+  if( voxel_size > 0.0f ) pc->voxel_size[level] = voxel_size;
+  rs_pointcloud__compute_level_poisson( pc, level );
+  const int32_t n_out = (int32_t)pc->n_pts[level];
+  memcpy( out_idx, pc->class_ids[level], (size_t)n_out * 4 );
+  rs_pointcloud__free_level( pc, level );
+  rs_pointcloud__free_level( pc, 0 );
+  free( pc );
+  return n_out;
+}
+
 const uint8_t* ref_ao_scene_grid( void* hp ) { return ((ref_ao_t*)hp)->scn_grd.data; }
 const uint8_t* ref_ao_arrangement_grid( void* hp ) { return ((ref_ao_t*)hp)->arr_grd.data; }   // as left by the last ref_ao_coverage
 

@@ -1128,3 +1128,37 @@ float orc_coverage_score( const uint8_t* scene_data, const uint8_t* arr_data, in
   if( v == 0 ) score = 0.0f;
   return score;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Level builder: Poisson-disk subsample in input order  (lib/rs/rs_pointcloud.h:984-1106)
+ * The first unmarked point becomes a sample and marks every point the radius search returns for it:
+ * the max_n_neigh nearest points with dist² < radius² (unsorted rows, :1009-1013), itself included.
+ * The search grid is built with 2.5 * radius (:989-990).  Returns the number of samples; sample_idx
+ * (capacity n) receives their indices in increasing order.
+ * ---------------------------------------------------------------------------------------- */
+int32_t orc_level_poisson( const float* pts, int32_t n, float radius, int32_t max_n_neigh, int32_t* sample_idx )
+{
+  if( n <= 0 ) { return 0; }
+  orc_grid_t* grid = orc_grid_create( pts, n, 2.5f * radius );
+  int8_t* unmarked = (int8_t*)malloc( (size_t)n );
+  float* d2 = (float*)malloc( (size_t)max_n_neigh * sizeof(float) );
+  int32_t* ind = (int32_t*)malloc( (size_t)max_n_neigh * sizeof(int32_t) );
+  memset( unmarked, 1, (size_t)n );
+  size_t n_marked = 0;
+  int32_t n_samples = 0, last = 0;
+  while( n_marked < (size_t)n )
+  {
+    int32_t s = last;
+    while( unmarked[s] != 1 ) { s++; }                       /* :1018-1021 first unmarked point */
+    last = s;
+    sample_idx[n_samples++] = s;
+    int64_t nn = 0;
+    orc_radius_search( grid, pts + 3 * (size_t)s, 1, radius, max_n_neigh, 0, d2, ind, &nn );   /* :1026-1028 */
+    size_t valid = 0;
+    for( int64_t i = 0; i < nn; ++i ) { if( unmarked[ind[i]] > 0 ) { valid++; } unmarked[ind[i]] = 0; }   /* :1030-1036 */
+    n_marked += valid;
+  }
+  free( unmarked ); free( d2 ); free( ind );
+  orc_grid_destroy( grid );
+  return n_samples;
+}

@@ -127,6 +127,11 @@ void    orc_rasterize_arrangement( const orc_voxgrid_t* g, const float* const* o
 /* rsao__compute_scene_coverage_score (:344-373): agreeing / valid scene cells (0 if no valid cell) */
 float   orc_coverage_score( const uint8_t* scene_data, const uint8_t* arr_data, int64_t n_cells, int32_t* agree, int32_t* valid );
 
+/* Level builder: rs_pointcloud__compute_level_poisson (lib/rs/rs_pointcloud.h:984-1106) — indices of the
+ * samples, increasing; the caller gathers the level's attribute arrays with them (:1090-1099).  For level L the
+ * reference passes radius = voxel_size[L] and max_n_neigh = 1024*L/4 (256 for L = 0), :995-996. */
+int32_t orc_level_poisson( const float* pts, int32_t n, float radius, int32_t max_n_neigh, int32_t* sample_idx );
+
 /* The three normal gates, on a raw dot value (for threshold pinning). */
 int orc_icp_gate( float dot, float max_angle );    /* lib/rs/icp.h:372-374 */
 int orc_score_gate( float dot );                   /* pose_proposal.cpp:138-141 */

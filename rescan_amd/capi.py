@@ -53,6 +53,7 @@ SIGNATURES = {
     "rs_hip_coverage_info": (C.c_int, [C.c_void_p, i32p, f32p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "rs_hip_coverage_scene_grid": (C.c_int, [C.c_void_p, np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")]),
     "rs_hip_coverage_scores": (C.c_int, [C.c_void_p, C.c_void_p, f32p, i32p, i32p, C.c_int32, f32p, C.c_void_p]),
+    "rs_hip_level_samples": (C.c_int, [C.c_void_p, C.c_float, C.c_int32, i32p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rs_hip_mat4_inverse": (None, [f32p, f32p]),
     "rs_hip_sincosf_model": (None, [f32p, C.c_int64, f32p, f32p]),
     "rs_hip_mat4_mul": (None, [f32p, f32p, f32p]),
@@ -273,6 +274,14 @@ def arrangement_to_labels(scene, poses, objects, is_static, class_idx, radius=0.
 
 def mat4_inverse(m):
     o = np.empty(16, np.float32); load().rs_hip_mat4_inverse(_f32(m).ravel(), o); return o
+
+
+def level_samples(cloud, radius, max_n_neigh):
+    """rs_pointcloud__compute_level_poisson (lib/rs/rs_pointcloud.h:984-1106): (sample indices, rounds)."""
+    out = np.zeros(max(cloud.n, 1), np.int32)
+    n = C.c_int32(); r = C.c_int32()
+    _check(load().rs_hip_level_samples(cloud.handle, float(radius), int(max_n_neigh), out, C.byref(n), C.byref(r)))
+    return out[:n.value].copy(), r.value
 
 
 def sincosf_model(x):

@@ -106,6 +106,7 @@ struct Workspace
   DevBuf bld_pos, bld_nor, bld_k0, bld_k1, bld_v0, bld_v1, bld_v2, bld_small, bld_bits, bld_tmp;   // cloud construction
   DevBuf order_a, order_b;                                                      // ICP phase A slow-tile lists (ping-pong)
   DevBuf tmp_pos, tmp_pos2, tmp_nor2;                                           // estimate-only
+  DevBuf lvl_cnt, lvl_within, lvl_offset, lvl_adj, lvl_state, lvl_misc, lvl_flags, lvl_scan, lvl_samples, lvl_tmp, lvl_cursor, lvl_work_a, lvl_work_b;   // level builder
   DevBuf faith;                                                                 // reference-order estimator: correspondences in source order
   PinBuf h_a, h_b, h_c;
 };
@@ -1211,6 +1212,93 @@ extern "C" int rs_hip_compute_neighborhood( const rs_hip_cloud_t* cloud, int32_t
   HIP_TRY( hipMemcpyAsync( weight, E.ew, (size_t)total * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
   HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
   *n_edges = (int64_t)total;
+  return RS_HIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// level builder (rs_kernels.hip: k_level_*)
+// ------------------------------------------------------------------------------------------
+
+extern "C" int rs_hip_level_samples( const rs_hip_cloud_t* cloud, float radius, int32_t max_n_neigh,
+                                     int32_t* sample_idx, int32_t* n_samples, int32_t* n_rounds )
+{
+  int rc = ensure_ready(); if( rc ) return rc;
+  if( !cloud || !( radius > 0.0f ) || max_n_neigh <= 0 || !sample_idx || !n_samples ) { set_err( "level_samples: bad arguments" ); return RS_HIP_E_ARG; }
+  *n_samples = 0; if( n_rounds ) *n_rounds = 0;
+  const int n = cloud->n;
+  if( n == 0 ) return RS_HIP_OK;
+  const size_t n1 = (size_t)n + 1;
+  const size_t tmp_bytes = build_scan_temp_bytes( n1 );
+  if( ( rc = g_ws.lvl_cnt.ensure( n1 * 4 ) ) || ( rc = g_ws.lvl_within.ensure( n1 * 4 ) ) || ( rc = g_ws.lvl_offset.ensure( n1 * 4 ) ) ||
+      ( rc = g_ws.lvl_state.ensure( n1 * 4 ) ) || ( rc = g_ws.lvl_misc.ensure( 64 ) ) || ( rc = g_ws.lvl_flags.ensure( n1 * 4 ) ) ||
+      ( rc = g_ws.lvl_scan.ensure( n1 * 4 ) ) || ( rc = g_ws.lvl_samples.ensure( n1 * 4 ) ) || ( rc = g_ws.lvl_tmp.ensure( tmp_bytes ) ) ||
+      ( rc = g_ws.lvl_cursor.ensure( n1 * 4 ) ) || ( rc = g_ws.lvl_work_a.ensure( n1 * 4 ) ) || ( rc = g_ws.lvl_work_b.ensure( n1 * 4 ) ) )
+    return rc;
+  LevelLaunch L{};
+  L.tgt = cloud->view; L.q = cloud->qview; L.by_orig = cloud->d_qby_orig; L.n = n;
+  L.radius = radius; L.radius_sq = radius_sq_of( radius ); L.max_n_neigh = max_n_neigh;
+  L.n_earlier = g_ws.lvl_cnt.as<int>(); L.n_later = g_ws.lvl_within.as<int>(); L.offset = g_ws.lvl_offset.as<unsigned>();
+  L.state = g_ws.lvl_state.as<int>(); L.word = g_ws.lvl_cursor.as<int>();
+  L.flags = g_ws.lvl_flags.as<unsigned>(); L.flag_scan = g_ws.lvl_scan.as<unsigned>(); L.samples = g_ws.lvl_samples.as<int>();
+  const int BATCH = 16;
+  int* misc = g_ws.lvl_misc.as<int>();            // [0..BATCH] frontier lengths of a batch of steps (entry r: input of step r), [31] over-cap flag
+  L.over_cap = misc + 31;
+  HIP_TRY( hipMemsetAsync( misc, 0, 128, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipMemsetAsync( L.n_later + n, 0, 4, g_stream ), RS_HIP_E_RUNTIME );
+  // 1. who is within the radius of whom: counts, row offsets, rows of later neighbours
+  { ProfScope ps( "level_neighbours" ); launch_level_neighbours( L, false, g_stream ); }
+  if( build_exclusive_scan( g_ws.lvl_tmp.p, tmp_bytes, (const uint32_t*)L.n_later, g_ws.lvl_offset.as<uint32_t>(), n1, g_stream ) )
+  { set_err( "level_samples: device scan failed" ); return RS_HIP_E_RUNTIME; }
+  unsigned total = 0; int over = 0;
+  HIP_TRY( hipMemcpyAsync( &total, L.offset + n, 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipMemcpyAsync( &over, L.over_cap, 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
+  if( over ) { set_err( "level_samples: a point has more than max_n_neigh = %d points within the radius (a reference search would be truncated)", max_n_neigh ); return RS_HIP_E_CAPACITY; }
+  if( ( rc = g_ws.lvl_adj.ensure( std::max<size_t>( 1, total ) * 4 ) ) ) return rc;
+  L.adj = g_ws.lvl_adj.as<int>();
+  { ProfScope ps( "level_neighbours" ); launch_level_neighbours( L, true, g_stream ); }
+  // 2. propagate: one launch per frontier, the host looks at the frontier lengths once per batch of steps
+  int* front[2] = { g_ws.lvl_work_a.as<int>(), g_ws.lvl_work_b.as<int>() };
+  L.front_out = front[0]; L.front_count_out = misc;           // the first frontier: points without earlier neighbours
+  launch_level_init( L, g_stream );
+  // lanes per frontier item from the average row length
+  const double avg_row = (double)total / (double)n;
+  const int G = avg_row >= 24.0 ? 64 : ( avg_row >= 3.0 ? 8 : 1 );
+  const int per_block = 256 / G;
+  int rounds = 0, blocks = std::min( ( n + per_block - 1 ) / per_block, 16384 ); bool done = false, first = true;
+  while( !done )
+  {
+    if( rounds > n + BATCH ) { set_err( "level_samples: no fixed point after %d steps", rounds ); return RS_HIP_E_RUNTIME; }
+    if( !first ) HIP_TRY( hipMemcpyAsync( misc, misc + BATCH, 4, hipMemcpyDeviceToDevice, g_stream ), RS_HIP_E_RUNTIME );
+    HIP_TRY( hipMemsetAsync( misc + 1, 0, BATCH * 4, g_stream ), RS_HIP_E_RUNTIME );
+    { ProfScope ps( "level_rounds" );
+      for( int b = 0; b < BATCH; ++b )
+      {
+        const int r = rounds + b;
+        L.front_in = front[r & 1]; L.front_count_in = misc + b;
+        L.front_out = front[( r + 1 ) & 1]; L.front_count_out = misc + b + 1;
+        launch_level_frontier( L, G, blocks, g_stream );
+      } }
+    int len[BATCH + 1];
+    HIP_TRY( hipMemcpyAsync( len, misc, ( BATCH + 1 ) * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+    HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
+    int widest = 1;
+    for( int b = 0; b <= BATCH && !done; ++b ) { if( len[b] == 0 ) done = true; else { if( b < BATCH ) rounds++; widest = std::max( widest, len[b] ); } }
+    blocks = std::min( ( n + per_block - 1 ) / per_block, std::max( 256, 2 * ( ( widest + per_block - 1 ) / per_block ) ) );     // the next batch's frontiers are about as wide as this one's
+    first = false;
+  }
+  // 3. the samples in increasing index order
+  launch_level_flags( L, g_stream );
+  if( build_exclusive_scan( g_ws.lvl_tmp.p, tmp_bytes, L.flags, g_ws.lvl_scan.as<uint32_t>(), n1, g_stream ) )
+  { set_err( "level_samples: device scan failed" ); return RS_HIP_E_RUNTIME; }
+  launch_level_scatter( L, g_stream );
+  unsigned count = 0;
+  HIP_TRY( hipMemcpyAsync( &count, L.flag_scan + n, 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipMemcpyAsync( sample_idx, L.samples, (size_t)count * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
+  *n_samples = (int32_t)count;
+  if( n_rounds ) *n_rounds = rounds;
   return RS_HIP_OK;
 }
 

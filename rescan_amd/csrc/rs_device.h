@@ -194,6 +194,37 @@ size_t build_scan_temp_bytes( size_t n );
 int    build_exclusive_scan( void* tmp, size_t bytes, const uint32_t* in, uint32_t* out, size_t n, hipStream_t st );
 
 // Neighbourhood graph (rspf_compute_neighborhood): from self-search rows to unique weighted edges.
+// Level builder (lib/rs/rs_pointcloud.h:984-1106): a self-search of one cloud listing, per point, the LATER points
+// (larger original index) within the radius, then a propagation of decisions along those rows (rs_kernels.hip).
+struct LevelLaunch
+{
+  GridView     tgt;
+  QueryView    q;            // the same cloud's query layout
+  const int*   by_orig;      // original index -> query slot
+  int          n;
+  float        radius, radius_sq;
+  int*         n_earlier;    // n (query slot): earlier points within the radius
+  int*         n_later;      // n + 1 (query slot): later points within the radius (row lengths)
+  const unsigned* offset;    // n + 1: exclusive scan of n_later
+  int*         adj;          // original indices of the later neighbours, rows in query-slot order
+  int*         word;         // n (original index): earlier neighbours not yet known to be covered | LEVEL_COVERED
+  int*         state;        // n (original index): 1 = sample
+  const int*   front_in;     // frontier of this step: (original index << 1) | is_sample
+  const int*   front_count_in;
+  int*         front_out;
+  int*         front_count_out;
+  int*         over_cap;     // device flag: some point has more than max_n_neigh points within the radius
+  int          max_n_neigh;
+  unsigned*    flags;        // n + 1 (original index): 1 = sample (for the final compaction)
+  const unsigned* flag_scan; // n + 1
+  int*         samples;      // output: sample indices, increasing
+};
+void launch_level_neighbours( const LevelLaunch& L, bool write, hipStream_t st );
+void launch_level_init( const LevelLaunch& L, hipStream_t st );
+void launch_level_frontier( const LevelLaunch& L, int lanes_per_item /* 1, 8 or 64 */, int blocks, hipStream_t st );
+void launch_level_flags( const LevelLaunch& L, hipStream_t st );
+void launch_level_scatter( const LevelLaunch& L, hipStream_t st );
+
 struct EdgeLaunch
 {
   int          n, K;

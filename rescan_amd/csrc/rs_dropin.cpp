@@ -244,6 +244,18 @@ int64_t rsd_compute_neighborhood( const rsd_vec3_t* pos, const rsd_vec3_t* nor, 
   return n_edges;
 }
 
+int32_t rsd_level_poisson( const rsd_vec3_t* pos, int32_t n, float voxel_size, int32_t level, int32_t* sample_idx )
+{
+  rs_hip_cloud_t* c = cached_cloud( pos, nullptr, n, -1.0f );
+  if( !c ) return RS_HIP_E_RUNTIME;
+  size_t max_n_neigh = (size_t)( 1024 * ( ( level ) / (float)( 5 - 1 ) ) );      // rs_pointcloud.h:995 (RSPC_N_LEVELS = 5)
+  if( !max_n_neigh ) max_n_neigh = 256;                                           // :996
+  int32_t n_samples = 0;
+  int rc = rs_hip_level_samples( c, voxel_size, (int32_t)max_n_neigh, sample_idx, &n_samples, nullptr );
+  if( rc ) { complain( "level_poisson" ); return rc; }
+  return n_samples;
+}
+
 void* rsd_coverage_create( const rsd_vec3_t* bbox_min, const rsd_vec3_t* bbox_max, float voxel_size,
                            const rsd_vec3_t* scene_pos, const float* scene_quality, int32_t n_scene, float quality_threshold )
 {

@@ -1700,6 +1700,171 @@ void launch_rows( const RowsLaunch& L, hipStream_t st )
 }
 
 // ------------------------------------------------------------------------------------------
+// Level builder: Poisson-disk subsample in input order  (lib/rs/rs_pointcloud.h:984-1106)
+//
+// The reference walks the points in input order: the first unmarked point becomes a sample and marks every point its
+// radius search returns (the max_n_neigh nearest within the radius, itself included).  Equivalent statement, as long
+// as no search is truncated by max_n_neigh (checked: n_within <= max_n_neigh for every point):
+//     point i is a sample  <=>  no EARLIER point within the radius is a sample.
+// That is the lexicographically first maximal independent set of the "within radius" graph, decided here in
+// dependence order instead of index order, every edge touched once:
+//   word[k] = number of earlier neighbours of k not yet known to be covered  (| COVERED once a sample marks k)
+//   a SAMPLE j   ORs COVERED into the word of each later neighbour k; the first one to do so puts k on the frontier
+//   a COVERED j  decrements the word of each later neighbour k; the decrement that makes it 0 (all earlier neighbours
+//                covered, hence none of them a sample: nobody can still set COVERED) makes k a sample, onto the frontier
+// One launch per frontier; the number of launches is the longest dependence chain — a handful for shuffled input, of
+// the order of the cloud's extent in sample spacings for raster-like vertex orders.  The result is the reference's
+// sample set, bit for bit.
+//   k_level_neighbours<false>  counts per point its earlier / later neighbours and all points within the radius
+//   (scan)                     row offsets
+//   k_level_neighbours<true>   writes the later neighbours' original indices
+//   k_level_init               word = number of earlier neighbours; points without any are the first frontier (samples)
+//   k_level_frontier           one step
+//   k_level_flags / scatter    the samples in increasing index order
+// ------------------------------------------------------------------------------------------
+#define LEVEL_COVERED 0x40000000
+template <bool WRITE>
+__global__ __launch_bounds__( BLOCK ) void k_level_neighbours( LevelLaunch L )
+{
+  __shared__ WaveLds lds[WAVES_PER_BLOCK];
+  const int lane = threadIdx.x & ( WAVE - 1 );
+  const int wib = threadIdx.x / WAVE;
+  const int tile = blockIdx.x * WAVES_PER_BLOCK + wib;
+  if( tile >= L.q.n_tiles ) return;
+  const int i = (int)L.q.tiles[tile] + lane;
+  const bool active = i < (int)L.q.tiles[tile + 1];
+  float4 q = make_float4( 0, 0, 0, 0 );
+  if( active ) q = L.q.pos[i];
+  const int orig = __float_as_int( q.w );
+  const TileBounds tb = wave_bounds( active, q.x, q.y, q.z );
+  CellBox box = cell_box( L.tgt, tb, L.radius );
+  int earlier = 0, later = 0, within = 0;
+  int* row = WRITE && active ? L.adj + L.offset[i] : nullptr;
+  if( tb.any && !box_empty( box ) )
+  {
+    sweep_shell<false>( L.tgt, box, box, false, lds[wib], lane, 0, 1, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
+    {
+      float d[4];
+      dist2x4( X, Y, Z, q.x, q.y, q.z, d[0], d[1], d[2], d[3] );       // candidate - query, msh_hash_grid.h:852-855 (the square is the same either way round)
+#pragma unroll
+      for( int c = 0; c < 4; ++c )
+      {
+        if( active & ( d[c] < L.radius_sq ) )                          // strict, :857
+        {
+          const int idx = lds[wib].pidx[k4 + c];
+          within++;
+          if( idx < orig ) earlier++;
+          if( idx > orig ) { if( WRITE ) row[later] = idx; later++; }
+        }
+      }
+    } );
+  }
+  if( !WRITE && active )
+  {
+    L.n_earlier[i] = earlier; L.n_later[i] = later;
+    if( within > L.max_n_neigh ) *L.over_cap = 1;
+  }
+}
+
+__global__ __launch_bounds__( BLOCK ) void k_level_init( LevelLaunch L )
+{
+  const int s = blockIdx.x * BLOCK + threadIdx.x;
+  if( s >= L.n ) return;
+  const int i = __float_as_int( L.q.pos[s].w );
+  const int ne = L.n_earlier[s];
+  L.word[i] = ne;
+  L.state[i] = ne == 0 ? 1 : 0;
+  if( ne == 0 ) L.front_out[atomicAdd( L.front_count_out, 1 )] = ( i << 1 ) | 1;
+}
+
+// frontier items: (original index << 1) | (1 = sample, 0 = covered).  G lanes per item, one lane per later neighbour:
+// the atomics of an item are in flight together (one thread per item would wait for each of its ~100 in turn at
+// level 4; at level 1, with two neighbours per point, a whole wave per item would idle), and a wave's new frontier
+// entries take consecutive slots with one counter update.
+template <int G>
+__global__ __launch_bounds__( BLOCK ) void k_level_frontier( LevelLaunch L )
+{
+  const int m = *L.front_count_in;
+  const int lane = threadIdx.x & ( WAVE - 1 );
+  const int sub = threadIdx.x & ( G - 1 );
+  const int n_groups = gridDim.x * ( BLOCK / G );
+  // (every lane of a wave runs the same number of outer and inner iterations: the ballot below needs them all)
+  const int m_pad = ( m + ( WAVE / G ) - 1 ) / ( WAVE / G ) * ( WAVE / G );
+  for( int t = blockIdx.x * ( BLOCK / G ) + threadIdx.x / G; t < m_pad; t += n_groups )
+  {
+    int j = 0; bool sample = false; unsigned e0 = 0, e1 = 0;
+    if( t < m )
+    {
+      const int item = L.front_in[t];
+      j = item >> 1; sample = item & 1;
+      const int s = L.by_orig[j];
+      e0 = L.offset[s]; e1 = L.offset[s + 1];
+    }
+    // longest row among the items this wave is working on
+    unsigned len = e1 - e0;
+#pragma unroll
+    for( int o = WAVE / 2; o >= G; o >>= 1 ) len = max( len, (unsigned)__shfl_xor( (int)len, o ) );
+    for( unsigned eb = 0; eb < len; eb += G )
+    {
+      const unsigned e = e0 + eb + (unsigned)sub;
+      int push = -1;
+      if( e < e1 )
+      {
+        const int k = L.adj[e];
+        if( sample )
+        {
+          const int old = atomicOr( L.word + k, LEVEL_COVERED );
+          if( !( old & LEVEL_COVERED ) ) push = k << 1;
+        }
+        else
+        {
+          const int now = atomicSub( L.word + k, 1 ) - 1;
+          if( now == 0 ) { L.state[k] = 1; push = ( k << 1 ) | 1; }
+        }
+      }
+      const unsigned long long mask = __ballot( push >= 0 );
+      if( mask )
+      {
+        int base = 0;
+        if( lane == 0 ) base = atomicAdd( L.front_count_out, (int)__popcll( mask ) );
+        base = __builtin_amdgcn_readfirstlane( base );
+        if( push >= 0 ) L.front_out[base + (int)__popcll( mask & ( ( 1ull << lane ) - 1ull ) )] = push;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__( BLOCK ) void k_level_flags( LevelLaunch L )
+{
+  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  if( i <= L.n ) L.flags[i] = ( i < L.n && L.state[i] == 1 ) ? 1u : 0u;
+}
+__global__ __launch_bounds__( BLOCK ) void k_level_scatter( LevelLaunch L )
+{
+  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  if( i < L.n && L.flags[i] ) L.samples[L.flag_scan[i]] = i;
+}
+void launch_level_neighbours( const LevelLaunch& L, bool write, hipStream_t st )
+{
+  const dim3 grid( ( L.q.n_tiles + WAVES_PER_BLOCK - 1 ) / WAVES_PER_BLOCK );
+  if( write ) hipLaunchKernelGGL( k_level_neighbours<true>, grid, dim3( BLOCK ), 0, st, L );
+  else        hipLaunchKernelGGL( k_level_neighbours<false>, grid, dim3( BLOCK ), 0, st, L );
+}
+void launch_level_init( const LevelLaunch& L, hipStream_t st )
+{ hipLaunchKernelGGL( k_level_init, dim3( ( L.n + BLOCK - 1 ) / BLOCK ), dim3( BLOCK ), 0, st, L ); }
+void launch_level_frontier( const LevelLaunch& L, int lanes_per_item, int blocks, hipStream_t st )
+{
+  const dim3 grid( std::max( 1, blocks ) );
+  if( lanes_per_item >= 64 )     hipLaunchKernelGGL( k_level_frontier<64>, grid, dim3( BLOCK ), 0, st, L );
+  else if( lanes_per_item >= 8 ) hipLaunchKernelGGL( k_level_frontier<8>, grid, dim3( BLOCK ), 0, st, L );
+  else                           hipLaunchKernelGGL( k_level_frontier<1>, grid, dim3( BLOCK ), 0, st, L );
+}
+void launch_level_flags( const LevelLaunch& L, hipStream_t st )
+{ hipLaunchKernelGGL( k_level_flags, dim3( ( L.n + BLOCK ) / BLOCK ), dim3( BLOCK ), 0, st, L ); }
+void launch_level_scatter( const LevelLaunch& L, hipStream_t st )
+{ hipLaunchKernelGGL( k_level_scatter, dim3( ( L.n + BLOCK - 1 ) / BLOCK ), dim3( BLOCK ), 0, st, L ); }
+
+// ------------------------------------------------------------------------------------------
 // Neighbourhood graph  (lib/rs/rs_pointcloud_filters.cpp:674-722)
 // The K = 8 self-search is k_rows; these kernels turn its rows into the de-duplicated edge list.
 // Reference order: rows i ascending, first insertion of an undirected pair wins, so {i,j} (i<j)

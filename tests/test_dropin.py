@@ -145,6 +145,18 @@ def test_neighborhood_by_flat_entry(dropin, gscene):
 
 
 @pytest.mark.gpu
+def test_level_poisson_by_flat_entry(dropin, gscene):
+    g = load_golden("level.npz")
+    pts = gscene["points"]
+    out = np.zeros(len(pts), np.int32)
+    dropin.rsd_level_poisson.restype = C.c_int32
+    dropin.rsd_level_poisson.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_void_p]
+    for level, voxel in ((2, 0.02), (4, 0.08)):
+        m = dropin.rsd_level_poisson(pts.ctypes.data, len(pts), voxel, level, out.ctypes.data)
+        assert m == len(g[f"own_l{level}"]) and (out[:m] == g[f"own_l{level}"]).all()
+
+
+@pytest.mark.gpu
 def test_coverage_by_flat_entry(dropin, gscene):
     from conftest import coverage_case
     d, objs, static, arrangements = coverage_case(gscene)

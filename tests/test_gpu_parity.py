@@ -319,6 +319,51 @@ def test_neighborhood_exponents_and_large(capi, oracle):
 
 # ---- scene-coverage term --------------------------------------------------
 
+def test_level_builder_vs_golden(capi, gscene):
+    """rs_pointcloud__compute_level_poisson: the sample indices are the reference's, exactly, for the
+    scene's own point order (a few propagation steps) and a raster order (hundreds)."""
+    from oracle.pyoracle import LEVEL_VOXEL, level_max_n_neigh
+    g = load_golden("level.npz")
+    pts = gscene["points"]
+    for name, p in (("own", pts), ("raster", np.ascontiguousarray(pts[g["raster"]]))):
+        cloud = capi.Cloud(p, None)
+        steps = []
+        for level in (1, 2, 3, 4):
+            got, rounds = capi.level_samples(cloud, LEVEL_VOXEL[level], level_max_n_neigh(level))
+            want = g[f"{name}_l{level}"]
+            assert len(got) == len(want) and (got == want).all(), (name, level)
+            steps.append(rounds)
+        assert max(steps) >= 2
+        cloud.close()
+
+
+def test_level_builder_edge_cases(capi, oracle):
+    from oracle.pyoracle import LEVEL_VOXEL, level_max_n_neigh
+    rng = np.random.default_rng(12)
+    base = rng.uniform(0, 0.5, (4000, 3)).astype(np.float32)
+    cases = {
+        "one": base[:1], "two close": np.array([[0, 0, 0], [0.001, 0, 0]], np.float32), "coincident": np.repeat(base[:4], 50, axis=0),
+        "volume": base, "line": np.stack([np.linspace(0, 1, 3000), np.zeros(3000), np.zeros(3000)], 1).astype(np.float32),
+        "exactly on the radius": np.array([[0, 0, 0], [0.02, 0, 0], [0.04, 0, 0], [0.0400001, 0, 0]], np.float32),
+    }
+    for name, p in cases.items():
+        cloud = capi.Cloud(np.ascontiguousarray(p), None)
+        for level in (2, 3):
+            r, k = LEVEL_VOXEL[level], level_max_n_neigh(level)
+            want = oracle.level_poisson(p, r, k)
+            got, _ = capi.level_samples(cloud, r, k)
+            assert len(got) == len(want) and (got == want).all(), (name, level)
+        cloud.close()
+    # empty cloud
+    e = capi.Cloud(np.zeros((0, 3), np.float32), None)
+    got, _ = capi.level_samples(e, 0.02, 512)
+    assert len(got) == 0
+    # a search the reference would truncate (more than max_n_neigh points within the radius) is refused, not approximated
+    dense = capi.Cloud(rng.uniform(0, 0.01, (600, 3)).astype(np.float32), None)
+    with pytest.raises(RuntimeError):
+        capi.level_samples(dense, 0.02, 512)
+
+
 def test_coverage_vs_golden(capi, gscene):
     from conftest import coverage_case
     d, objs, static, arrangements = coverage_case(gscene)

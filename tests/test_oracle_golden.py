@@ -141,3 +141,20 @@ def test_coverage(oracle, gscene):
     # empty scene grid -> score 0, no NaN (:367)
     s, agree, valid = oracle.coverage_score(np.zeros(g.n_cells, np.uint8), ad)
     assert s == 0 and valid == 0
+
+
+def test_level_poisson(oracle, gscene):
+    """rs_pointcloud__compute_level_poisson: the restatement against the sample indices the REFERENCE
+    itself produced (tests/golden/level.npz, oracle/gen_golden.py: gen_level), for the scene's own point order and
+    a raster order, levels 1-4."""
+    from oracle.pyoracle import LEVEL_VOXEL, level_max_n_neigh
+    g = load_golden("level.npz")
+    pts = gscene["points"]
+    ras = np.ascontiguousarray(pts[g["raster"]])
+    assert [level_max_n_neigh(l) for l in range(5)] == [256, 256, 512, 768, 1024]
+    for level in (1, 2, 3, 4):
+        for name, p in (("own", pts), ("raster", ras)):
+            got = oracle.level_poisson(p, LEVEL_VOXEL[level], level_max_n_neigh(level))
+            want = g[f"{name}_l{level}"]
+            assert len(got) == len(want) and (got == want).all(), (name, level)
+            assert (np.diff(got) > 0).all() and got[0] == 0            # increasing, and the first point is always a sample

@@ -182,3 +182,21 @@ def test_coverage_vs_reference(oracle, scene):
             ad = oracle.rasterize_arrangement(g, [o["pos"] for o in scene["objects"]], poses, [0] * len(idx))
             assert (ad == R.arrangement_grid()).all()
             assert oracle.coverage_score(sd, ad)[0] == want
+
+
+def test_level_poisson_vs_reference(oracle):
+    """The level builder's restatement against the reference's own function on fresh clouds (seeded scene in three
+    point orders, a tiny cloud, coincident points)."""
+    from oracle.pyoracle import RefAO, ref_level_poisson, LEVEL_VOXEL, level_max_n_neigh
+    if not RefAO.available():
+        pytest.skip("oracle/_ref/libref_ao.so not built")
+    from rescan_amd import synth
+    pts = synth.make_scene(seed=5, density=1500.0, timestep=0)["points"]
+    rng = np.random.default_rng(2)
+    clouds = [pts, np.ascontiguousarray(pts[np.lexsort((pts[:, 0], pts[:, 1], pts[:, 2]))]), np.ascontiguousarray(pts[rng.permutation(len(pts))]),
+              np.ascontiguousarray(pts[:7]), np.repeat(pts[:3], 5, axis=0)]
+    for p in clouds:
+        for level in (1, 2, 4):
+            a = oracle.level_poisson(p, LEVEL_VOXEL[level], level_max_n_neigh(level))
+            b = ref_level_poisson(p, level)
+            assert len(a) == len(b) and (a == b).all()
