@@ -19,6 +19,9 @@
  * The scene-coverage term (orc_voxgrid_*, orc_rasterize_*, orc_coverage_score)
  * is pinned against the reference TU itself: apps/segment_transfer/
  * arrangement_optimization.cpp compiles from its own sources (oracle/_ref/libref_ao.so).
+ * The level builder (orc_level_poisson) is pinned against the reference's own
+ * rs_pointcloud__compute_level_poisson, which that same library carries (lib/rs/rs_pointcloud.h is
+ * header-only; oracle/ref_ao_driver.cpp: ref_level_poisson), and against tests/golden/level.npz.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use
  * this library.  The product (rescan_amd/, include/) never links or loads it.
