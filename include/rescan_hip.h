@@ -180,6 +180,13 @@ int rs_hip_arrangement_to_labels( const rs_hip_cloud_t* scene,
 int rs_hip_level_samples( const rs_hip_cloud_t* cloud, float radius, int32_t max_n_neigh,
                           int32_t* sample_idx, int32_t* n_samples, int32_t* n_rounds );
 
+/* The level as a cloud of its own, built without leaving the device: the samples of `base` (as above), the gather of
+ * their positions / normals (rs_pointcloud.h:1090-1099) and the level's search index
+ * (rs_pointcloud_compute_search_grid, :849-863; cell_size as for rs_hip_cloud_create).  sample_idx (may be NULL,
+ * capacity = size of base) and n_samples (may be NULL) receive the samples.  NULL on failure. */
+rs_hip_cloud_t* rs_hip_cloud_create_level( const rs_hip_cloud_t* base, float radius, int32_t max_n_neigh, float cell_size,
+                                           int32_t* sample_idx, int32_t* n_samples );
+
 /* ---- neighbourhood graph ------------------------------------------ */
 
 /* rspf_compute_neighborhood (lib/rs/rs_pointcloud_filters.cpp:674-722): K = max_nn self-search

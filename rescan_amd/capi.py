@@ -53,6 +53,7 @@ SIGNATURES = {
     "rs_hip_coverage_info": (C.c_int, [C.c_void_p, i32p, f32p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "rs_hip_coverage_scene_grid": (C.c_int, [C.c_void_p, np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")]),
     "rs_hip_coverage_scores": (C.c_int, [C.c_void_p, C.c_void_p, f32p, i32p, i32p, C.c_int32, f32p, C.c_void_p]),
+    "rs_hip_cloud_create_level": (C.c_void_p, [C.c_void_p, C.c_float, C.c_int32, C.c_float, i32p, C.POINTER(C.c_int32)]),
     "rs_hip_level_samples": (C.c_int, [C.c_void_p, C.c_float, C.c_int32, i32p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rs_hip_mat4_inverse": (None, [f32p, f32p]),
     "rs_hip_sincosf_model": (None, [f32p, C.c_int64, f32p, f32p]),
@@ -145,6 +146,22 @@ class Cloud:
             self.n, float(cell_size))
         if not self.handle:
             raise RescanHipError("rs_hip_cloud_create failed: " + lib.rs_hip_last_error().decode())
+
+    @classmethod
+    def level_of(cls, base, radius, max_n_neigh, cell_size=-1.0):
+        """The level of `base` as a cloud of its own, built on the device (rs_hip_cloud_create_level).
+        Returns (cloud, sample indices)."""
+        lib = load()
+        idx = np.zeros(max(base.n, 1), np.int32); m = C.c_int32()
+        h = lib.rs_hip_cloud_create_level(base.handle, float(radius), int(max_n_neigh), float(cell_size), idx, C.byref(m))
+        if not h:
+            raise RescanHipError("rs_hip_cloud_create_level failed: " + lib.rs_hip_last_error().decode())
+        self = cls.__new__(cls)
+        self.handle = h; self.n = m.value
+        idx = idx[:m.value].copy()
+        self._pos = base._pos[idx]
+        self._nor = None if base._nor is None else base._nor[idx]
+        return self, idx
 
     @property
     def nbytes(self):

@@ -106,7 +106,7 @@ struct Workspace
   DevBuf bld_pos, bld_nor, bld_k0, bld_k1, bld_v0, bld_v1, bld_v2, bld_small, bld_bits, bld_tmp;   // cloud construction
   DevBuf order_a, order_b;                                                      // ICP phase A slow-tile lists (ping-pong)
   DevBuf tmp_pos, tmp_pos2, tmp_nor2;                                           // estimate-only
-  DevBuf lvl_cnt, lvl_within, lvl_offset, lvl_adj, lvl_state, lvl_misc, lvl_flags, lvl_scan, lvl_samples, lvl_tmp, lvl_cursor, lvl_work_a, lvl_work_b;   // level builder
+  DevBuf lvl_pos, lvl_nor, lvl_cnt, lvl_within, lvl_offset, lvl_adj, lvl_state, lvl_misc, lvl_flags, lvl_scan, lvl_samples, lvl_tmp, lvl_cursor, lvl_work_a, lvl_work_b;   // level builder
   DevBuf faith;                                                                 // reference-order estimator: correspondences in source order
   PinBuf h_a, h_b, h_c;
 };
@@ -318,14 +318,24 @@ int rs_hip_profile_read( const char* name, int64_t* launches, double* total_ms )
 // msh_hash_grid.h:511-532) with a dense offset table, and the Hilbert-ordered, tiled query layout.
 // The host only takes the few decisions in between (cell size, table size, number of tiles).
 // The index is built once per cloud level and reused by every search.
-rs_hip_cloud_t* rs_hip_cloud_create( const float* pos, const float* nor, int32_t n, float cell_size )
+// pos / nor: packed xyz, host pointers — or device pointers when from_device (a level gathered on the device: the
+// host copies the shim and the find_corrs entry point use are then downloaded instead of uploaded)
+static rs_hip_cloud_t* cloud_create_impl( const float* pos, const float* nor, int32_t n, float cell_size, bool from_device )
 {
   if( ensure_ready() != RS_HIP_OK ) return nullptr;
   if( n < 0 || ( n > 0 && !pos ) ) { set_err( "rs_hip_cloud_create: bad arguments" ); return nullptr; }
   rs_hip_cloud* c = new rs_hip_cloud();
   c->n = n; c->has_nor = nor != nullptr;
-  c->h_pos.assign( pos, pos + (size_t)3 * n );
-  if( nor ) c->h_nor.assign( nor, nor + (size_t)3 * n );
+  if( !from_device )
+  {
+    c->h_pos.assign( pos, pos + (size_t)3 * n );
+    if( nor ) c->h_nor.assign( nor, nor + (size_t)3 * n );
+  }
+  else
+  {
+    c->h_pos.resize( (size_t)3 * n );
+    if( nor ) c->h_nor.resize( (size_t)3 * n );
+  }
   auto fail = [&]( hipError_t e ) { set_err( "rs_hip_cloud_create: %s", hipGetErrorString( e ) ); rs_hip_cloud_destroy( c ); return (rs_hip_cloud_t*)nullptr; };
   auto failrc = [&]( const char* what ) { set_err( "rs_hip_cloud_create: %s", what ); rs_hip_cloud_destroy( c ); return (rs_hip_cloud_t*)nullptr; };
 #define CC( expr ) do { hipError_t e_ = ( expr ); if( e_ != hipSuccess ) return fail( e_ ); } while( 0 )
@@ -339,8 +349,13 @@ rs_hip_cloud_t* rs_hip_cloud_create( const float* pos, const float* nor, int32_t
   unsigned* d_small = W.bld_small.as<unsigned>();
   if( n > 0 )
   {
-    CC( hipMemcpyAsync( d_raw, pos, (size_t)n * 12, hipMemcpyHostToDevice, g_stream ) );
-    if( nor ) CC( hipMemcpyAsync( d_rawn, nor, (size_t)n * 12, hipMemcpyHostToDevice, g_stream ) );
+    CC( hipMemcpyAsync( d_raw, pos, (size_t)n * 12, from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, g_stream ) );
+    if( nor ) CC( hipMemcpyAsync( d_rawn, nor, (size_t)n * 12, from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, g_stream ) );
+    if( from_device )
+    {
+      CC( hipMemcpyAsync( c->h_pos.data(), pos, (size_t)n * 12, hipMemcpyDeviceToHost, g_stream ) );
+      if( nor ) CC( hipMemcpyAsync( c->h_nor.data(), nor, (size_t)n * 12, hipMemcpyDeviceToHost, g_stream ) );
+    }
   }
 
   // bounds (+ the largest normal, which bounds how fast a gate value can change with the query normal)
@@ -495,6 +510,11 @@ rs_hip_cloud_t* rs_hip_cloud_create( const float* pos, const float* nor, int32_t
   c->qview.n = n; c->qview.n_tiles = n_tiles;
 #undef CC
   return c;
+}
+
+rs_hip_cloud_t* rs_hip_cloud_create( const float* pos, const float* nor, int32_t n, float cell_size )
+{
+  return cloud_create_impl( pos, nor, n, cell_size, false );
 }
 
 void rs_hip_cloud_destroy( rs_hip_cloud_t* c )
@@ -1219,11 +1239,11 @@ extern "C" int rs_hip_compute_neighborhood( const rs_hip_cloud_t* cloud, int32_t
 // level builder (rs_kernels.hip: k_level_*)
 // ------------------------------------------------------------------------------------------
 
-extern "C" int rs_hip_level_samples( const rs_hip_cloud_t* cloud, float radius, int32_t max_n_neigh,
-                                     int32_t* sample_idx, int32_t* n_samples, int32_t* n_rounds )
+// the samples of a level, left on the device in g_ws.lvl_samples (increasing original indices)
+static int level_samples_device( const rs_hip_cloud_t* cloud, float radius, int32_t max_n_neigh, int32_t* n_samples, int32_t* n_rounds )
 {
   int rc = ensure_ready(); if( rc ) return rc;
-  if( !cloud || !( radius > 0.0f ) || max_n_neigh <= 0 || !sample_idx || !n_samples ) { set_err( "level_samples: bad arguments" ); return RS_HIP_E_ARG; }
+  if( !cloud || !( radius > 0.0f ) || max_n_neigh <= 0 || !n_samples ) { set_err( "level_samples: bad arguments" ); return RS_HIP_E_ARG; }
   *n_samples = 0; if( n_rounds ) *n_rounds = 0;
   const int n = cloud->n;
   if( n == 0 ) return RS_HIP_OK;
@@ -1295,11 +1315,40 @@ extern "C" int rs_hip_level_samples( const rs_hip_cloud_t* cloud, float radius, 
   unsigned count = 0;
   HIP_TRY( hipMemcpyAsync( &count, L.flag_scan + n, 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
   HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
-  HIP_TRY( hipMemcpyAsync( sample_idx, L.samples, (size_t)count * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
-  HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
   *n_samples = (int32_t)count;
   if( n_rounds ) *n_rounds = rounds;
   return RS_HIP_OK;
+}
+
+extern "C" int rs_hip_level_samples( const rs_hip_cloud_t* cloud, float radius, int32_t max_n_neigh,
+                                     int32_t* sample_idx, int32_t* n_samples, int32_t* n_rounds )
+{
+  if( !sample_idx || !n_samples ) { set_err( "level_samples: bad arguments" ); return RS_HIP_E_ARG; }
+  int rc = level_samples_device( cloud, radius, max_n_neigh, n_samples, n_rounds );
+  if( rc || *n_samples == 0 ) return rc;
+  HIP_TRY( hipMemcpyAsync( sample_idx, g_ws.lvl_samples.p, (size_t)*n_samples * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
+  return RS_HIP_OK;
+}
+
+// rs_pointcloud__compute_level_poisson + rs_pointcloud_compute_search_grid (rs_pointcloud.h:984-1106,849-863) without
+// leaving the device: samples -> gather of the level's positions / normals -> index build.
+extern "C" rs_hip_cloud_t* rs_hip_cloud_create_level( const rs_hip_cloud_t* base, float radius, int32_t max_n_neigh, float cell_size,
+                                                      int32_t* sample_idx, int32_t* n_samples )
+{
+  int32_t count = 0;
+  if( level_samples_device( base, radius, max_n_neigh, &count, nullptr ) ) return nullptr;
+  if( n_samples ) *n_samples = count;
+  const size_t nn = (size_t)std::max( 1, count );
+  if( g_ws.lvl_pos.ensure( nn * 12 ) || ( base->has_nor && g_ws.lvl_nor.ensure( nn * 12 ) ) ) return nullptr;
+  if( count > 0 )
+  {
+    launch_level_gather( g_ws.lvl_samples.as<int>(), count, base->d_qby_orig, base->d_qpos, base->has_nor ? base->d_qnor : nullptr,
+                         g_ws.lvl_pos.as<float>(), base->has_nor ? g_ws.lvl_nor.as<float>() : nullptr, g_stream );
+    if( sample_idx && hipMemcpyAsync( sample_idx, g_ws.lvl_samples.p, (size_t)count * 4, hipMemcpyDeviceToHost, g_stream ) != hipSuccess )
+    { set_err( "cloud_create_level: copy of the sample indices failed" ); return nullptr; }
+  }
+  return cloud_create_impl( g_ws.lvl_pos.as<float>(), base->has_nor ? g_ws.lvl_nor.as<float>() : nullptr, count, cell_size, true );
 }
 
 // ------------------------------------------------------------------------------------------

@@ -224,6 +224,9 @@ void launch_level_init( const LevelLaunch& L, hipStream_t st );
 void launch_level_frontier( const LevelLaunch& L, int lanes_per_item /* 1, 8 or 64 */, int blocks, hipStream_t st );
 void launch_level_flags( const LevelLaunch& L, hipStream_t st );
 void launch_level_scatter( const LevelLaunch& L, hipStream_t st );
+// out3[i] = xyz of the base cloud's point samples[i] (query layout + original -> slot map)
+void launch_level_gather( const int* samples, int count, const int* by_orig, const float4* qpos, const float4* qnor,
+                          float* pos3, float* nor3, hipStream_t st );
 
 struct EdgeLaunch
 {

@@ -1844,6 +1844,19 @@ __global__ __launch_bounds__( BLOCK ) void k_level_scatter( LevelLaunch L )
   const int i = blockIdx.x * BLOCK + threadIdx.x;
   if( i < L.n && L.flags[i] ) L.samples[L.flag_scan[i]] = i;
 }
+__global__ __launch_bounds__( BLOCK ) void k_level_gather( const int* samples, int count, const int* by_orig, const float4* qpos, const float4* qnor,
+                                                           float* pos3, float* nor3 )
+{
+  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  if( i >= count ) return;
+  const int s = by_orig[samples[i]];
+  const float4 p = qpos[s];
+  pos3[3 * i] = p.x; pos3[3 * i + 1] = p.y; pos3[3 * i + 2] = p.z;
+  if( nor3 ) { const float4 m = qnor[s]; nor3[3 * i] = m.x; nor3[3 * i + 1] = m.y; nor3[3 * i + 2] = m.z; }
+}
+void launch_level_gather( const int* samples, int count, const int* by_orig, const float4* qpos, const float4* qnor,
+                          float* pos3, float* nor3, hipStream_t st )
+{ hipLaunchKernelGGL( k_level_gather, dim3( ( count + BLOCK - 1 ) / BLOCK ), dim3( BLOCK ), 0, st, samples, count, by_orig, qpos, qnor, pos3, nor3 ); }
 void launch_level_neighbours( const LevelLaunch& L, bool write, hipStream_t st )
 {
   const dim3 grid( ( L.q.n_tiles + WAVES_PER_BLOCK - 1 ) / WAVES_PER_BLOCK );

@@ -337,6 +337,27 @@ def test_level_builder_vs_golden(capi, gscene):
         cloud.close()
 
 
+def test_level_cloud_built_on_the_device(capi, oracle, gscene):
+    """rs_hip_cloud_create_level: samples, gather and index without a host round trip — the level cloud answers searches
+    exactly like a cloud created from the same points on the host, and ICP against it returns the same bits."""
+    from oracle.pyoracle import LEVEL_VOXEL, level_max_n_neigh
+    g = load_golden("level.npz")
+    pts, nor = gscene["points"], gscene["normals"]
+    base = capi.Cloud(pts, nor)
+    lvl, idx = capi.Cloud.level_of(base, LEVEL_VOXEL[2], level_max_n_neigh(2))
+    assert (idx == g["own_l2"]).all() and lvl.n == len(idx)
+    host = capi.Cloud(pts[idx], nor[idx])
+    q = pts[::37] + np.float32(0.003)
+    a = capi.radius_search(lvl, q, 0.05, 8); b = capi.radius_search(host, q, 0.05, 8)
+    assert all((x == y).all() for x, y in zip(a[:3], b[:3])) and a[3] == b[3]
+    o = gscene["objects"][1]
+    oc = capi.Cloud(o["pos"], o["nor"])
+    r1 = capi.icp_align(oc, lvl, o["pose"], I4, 0.1, np.deg2rad(60.0)); r2 = capi.icp_align(oc, host, o["pose"], I4, 0.1, np.deg2rad(60.0))
+    assert r1[1].tobytes() == r2[1].tobytes() and r1[2] == r2[2]
+    c = capi.icp_find_corrs(oc, lvl, o["pose"], I4, 0.1, np.deg2rad(60.0)); d = capi.icp_find_corrs(oc, host, o["pose"], I4, 0.1, np.deg2rad(60.0))
+    assert all(x.shape == y.shape and (x == y).all() for x, y in zip(c, d))          # host copies of the level were downloaded correctly
+
+
 def test_level_builder_edge_cases(capi, oracle):
     from oracle.pyoracle import LEVEL_VOXEL, level_max_n_neigh
     rng = np.random.default_rng(12)

@@ -22,4 +22,12 @@ for name, pts in (("generator order", s["points"]), ("raster order", s["points"]
         bad += 0 if ok else 1
         print(f"{name:16s} level {level} (r {r}): {len(pts)} -> {len(got)} samples, {'IDENTICAL' if ok else 'DIFFERENT (%d vs %d)' % (len(want), len(got))}, "
               f"{rounds} rounds, GPU {1e3*t_gpu:.2f} ms (cloud index {1e3*t_build:.1f} ms), CPU oracle {1e3*t_cpu:.1f} ms", flush=True)
+# the whole pyramid of a scan as device-resident clouds (levels 1-4: samples + gather + index, rs_hip_cloud_create_level)
+pts = np.ascontiguousarray(s["points"]); nor = np.ascontiguousarray(s["normals"])
+base = capi.Cloud(pts, nor)
+for rep in range(2):
+    t = time.perf_counter()
+    lv = [capi.Cloud.level_of(base, LEVEL_VOXEL[l], level_max_n_neigh(l))[0] for l in (1, 2, 3, 4)]
+    dt = time.perf_counter() - t
+print(f"levels 1-4 of {len(pts)} points as device clouds: {1e3*dt:.1f} ms ({', '.join(str(c.n) for c in lv)} points)")
 sys.exit(1 if bad else 0)
