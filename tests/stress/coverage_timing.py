@@ -5,7 +5,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from rescan_amd import capi, synth  # noqa: E402
 from oracle.pyoracle import Oracle, RefAO  # noqa: E402

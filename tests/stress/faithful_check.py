@@ -1,7 +1,7 @@
 """Reference-order estimator vs the oracle, bit for bit: poses, errors, iteration counts of whole ICP runs
 (object-sized sources against a scene, and whole scans with the threshold lifted), and what it costs."""
 import os, sys, time, numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from rescan_amd import capi, synth
 from oracle.pyoracle import Oracle

@@ -1,6 +1,6 @@
-"""How the GPU and the oracle drift apart over ICP iterations on one hard case (seed 7 of tools/stress_parity.py)."""
+"""How the GPU and the oracle drift apart over ICP iterations on one hard case (seed 7 of tests/stress/stress_parity.py)."""
 import os, sys, numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from rescan_amd import capi, synth
 from oracle.pyoracle import Oracle

@@ -1,6 +1,6 @@
 """Pose distance GPU vs oracle after icp_align, by source-cloud size (the reference's fp32 accumulators get noisier with n)."""
 import os, sys, numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from rescan_amd import capi, synth
 from oracle.pyoracle import Oracle

@@ -1,7 +1,7 @@
 """Level builder against the oracle on many small clouds: random densities, radii, point orders (shuffled, raster,
 Hilbert-like by object), duplicated points, lattices (distances exactly on the radius)."""
 import os, sys, numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from rescan_amd import capi, synth
 from oracle.pyoracle import Oracle

@@ -1,7 +1,7 @@
 """Level builder (rs_pointcloud__compute_level_poisson) on the GPU against the oracle: sample sets, rounds, time,
 for the generator's point order and for a raster (z, y, x) vertex order."""
 import os, sys, time, numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from rescan_amd import capi, synth
 from oracle.pyoracle import Oracle, LEVEL_VOXEL, level_max_n_neigh

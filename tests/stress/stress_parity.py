@@ -1,7 +1,7 @@
 """Seed sweep: GPU vs the oracle on fresh scenes (correspondences bit-exact, ICP pose / iterations, scores, labels).
 A wider net than the committed fixtures for rare events (distance ties, certificate and hand-off edge cases)."""
 import os, sys, numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from rescan_amd import capi, synth
 from oracle.pyoracle import Oracle

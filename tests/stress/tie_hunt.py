@@ -2,8 +2,8 @@
 2 cm) of an object against a scan, from good and from bad start poses: correspondences GPU vs oracle, and for every
 mismatch the two candidates' distances (an exact fp32 distance tie is decided by the reference's heap/sort order)."""
 import os, sys, numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from rescan_amd import capi, synth
 from oracle.pyoracle import Oracle
 capi.init(0)
@@ -12,7 +12,7 @@ I4 = np.eye(4, dtype=np.float32).ravel()
 ang = np.float32(np.deg2rad(60.0))
 
 
-from tools.tie_hunt_lib import level
+from tie_hunt_lib import level
 
 n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 runs = bad_runs = corr_mismatch = tie_runs = 0
