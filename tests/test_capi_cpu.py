@@ -48,11 +48,12 @@ def test_code_object_is_gfx950_only():
 
 
 def test_product_does_not_touch_the_oracle():
-    """rescan_amd/ and include/ never import, link or name anything under oracle/."""
-    for base in ("rescan_amd", "include"):
+    """rescan_amd/, include/, shadow/ and tools/ never import, link or name anything under oracle/ (only tests/,
+    __graft_entry__.smoke() and bench.py's CPU-baseline leg do)."""
+    for base in ("rescan_amd", "include", "shadow", "tools"):
         for dp, _, fs in os.walk(os.path.join(ROOT, base)):
             for f in fs:
-                if f.endswith((".py", ".h", ".hip", ".cpp")):
+                if f.endswith((".py", ".h", ".hip", ".cpp", ".sh")):
                     txt = open(os.path.join(dp, f), errors="ignore").read()
                     assert "pyoracle" not in txt and "rs_oracle" not in txt and "libref" not in txt, os.path.join(dp, f)
     from rescan_amd import capi
