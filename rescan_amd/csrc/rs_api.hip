@@ -101,7 +101,7 @@ struct Workspace
   DevBuf plc, labels, mind;                                                     // labels
   DevBuf q4, rd2, ridx, rnn, rows;                                              // rows / misc
   DevBuf enor, ecount, eoffset, e1, e2, ew;                                     // neighbourhood edges
-  DevBuf cert_r, cert_dot;                                                      // ICP certificates
+  DevBuf cert_r, cert_dot, cert_slack;                                                    // ICP certificates
   DevBuf cov_bits, cov_plc, cov_agree;                                          // coverage scores
   DevBuf bld_pos, bld_nor, bld_k0, bld_k1, bld_v0, bld_v1, bld_v2, bld_small, bld_bits, bld_tmp;   // cloud construction
   DevBuf order_a, order_b;                                                      // ICP phase A slow-tile lists (ping-pong)
@@ -608,7 +608,7 @@ int icp_prepare( IcpCtx& cx, const rs_hip_cloud_t* src, const rs_hip_cloud_t* tg
   L.iters = (int*)( w + np * 33 ); L.err = w + np * 34; L.prev_err = w + np * 35; L.queued = (int*)( w + np * 36 ); L.ticket = (int*)( w + np * 37 );
   L.solve = 0; L.iter_index = 0; L.fixed_iters = 0;
   L.seed = getenv( "RS_HIP_NO_SEED" ) ? 0 : 1;
-  L.cert_r = nullptr; L.cert_dot = nullptr; L.tgt_nor_max = tgt->nor_max;
+  L.cert_r = nullptr; L.cert_dot = nullptr; L.cert_slack = nullptr; L.tgt_nor_max = tgt->nor_max;
   L.m_slot = g_ws.slot.as<int>(); L.m_d2 = g_ws.d2.as<float>(); L.m_dot = g_ws.dot.as<float>();
   L.stat_acc = nullptr;       // set by the align loop (fp64 estimator only)
   L.mom_part = g_ws.mom_part.as<double>(); L.res = g_ws.res.as<double>();
@@ -642,6 +642,11 @@ int icp_enable_certificates( IcpCtx& cx, size_t np, size_t nq )
   if( ( rc = g_ws.cert_r.ensure( np * nq * 4 ) ) || ( rc = g_ws.cert_dot.ensure( np * nq * 4 ) ) ) return rc;
   HIP_TRY( hipMemsetAsync( g_ws.cert_r.p, 0xFF, np * nq * 4, g_stream ), RS_HIP_E_RUNTIME );      // NaN: no certificate
   cx.L.cert_r = g_ws.cert_r.as<float>(); cx.L.cert_dot = g_ws.cert_dot.as<float>();
+  if( !getenv( "RS_HIP_NO_RANK_CERT" ) )            // read only next to a valid cert_r, written with every fresh one: no initialisation
+  {
+    if( ( rc = g_ws.cert_slack.ensure( np * nq * 4 ) ) ) return rc;
+    cx.L.cert_slack = g_ws.cert_slack.as<float>();
+  }
   return RS_HIP_OK;
 }
 

@@ -95,6 +95,7 @@ struct IcpLaunch
   // certificates issued by every search and consulted when a point has no usable previous match (rs_kernels.hip: icp_certificate); null = off
   float*  cert_r;       // n_prob x nq
   float*  cert_dot;     // n_prob x nq
+  float*  cert_slack;   // n_prob x nq: rank certificates (null: off) — see icp_certificate
   float*  T1_prev;      // device, n_prob x 16: the poses the previous iteration searched with
   float   tgt_nor_max;  // max |normal| over the target cloud
   unsigned long long* dbg;   // diagnostic builds only: per-tile {cycles, candidates} of phase A (null otherwise)

@@ -370,8 +370,10 @@ __device__ __forceinline__ uint32_t sweep_shell( const GridView& g, const CellBo
 // `fail_max`: the largest gate value max(dot,0) among the candidates that were inside the lane's bound when
 // met and failed the gate — every candidate closer than the final match (or, without one, within the
 // radius) is among them.  Only the ICP certificates below read it.
-struct Match { float d2; int idx; float dot; int slot; bool found; float fail_max; };
-__device__ __forceinline__ Match no_match() { Match m; m.d2 = INFINITY; m.idx = INT_MAX; m.dot = 0.0f; m.slot = -1; m.found = false; m.fail_max = 0.0f; return m; }
+// `rank_slack` (ICP only, > 0 when set): the match was rejected for its rank, and at least K candidates lie closer to
+// the query than (distance of the match - rank_slack) — see icp_certificate.
+struct Match { float d2; int idx; float dot; int slot; bool found; float fail_max; float rank_slack; };
+__device__ __forceinline__ Match no_match() { Match m; m.d2 = INFINITY; m.idx = INT_MAX; m.dot = 0.0f; m.slot = -1; m.found = false; m.fail_max = 0.0f; m.rank_slack = 0.0f; return m; }
 
 typedef float f32x2 __attribute__(( ext_vector_type( 2 ) ));
 
@@ -472,6 +474,38 @@ __device__ __forceinline__ int precede4( const float4& X, const float4& Y, const
 #pragma unroll
   for( int i = 0; i < 4; ++i ) c += ( ( d[i] < radius_sq ) & lex_less( d[i], L.pidx[k + i], bd2, bidx ) ) ? 1 : 0;
   return c;
+}
+
+// The rank pass of a search that issues certificates (ICP): besides the exact rank, how many candidates lie
+// within 0.5, 0.75, 0.9 and 0.97 of the match's distance.
+struct RankBands { float dm, t1, t2, t3, t4; int c1, c2, c3, c4; };
+__device__ __forceinline__ RankBands rank_bands( const Match& m )
+{
+  RankBands b; b.dm = sqrtf( m.d2 ); b.t1 = 0.5f * b.dm; b.t2 = 0.75f * b.dm; b.t3 = 0.9f * b.dm; b.t4 = 0.97f * b.dm; b.c1 = b.c2 = b.c3 = b.c4 = 0;
+  return b;
+}
+__device__ __forceinline__ int precede4_bands( const float4& X, const float4& Y, const float4& Z, int k, const WaveLds& L,
+                                               float qx, float qy, float qz, float radius_sq, float bd2, int bidx, RankBands& b )
+{
+  float d[4];
+  dist2x4( X, Y, Z, qx, qy, qz, d[0], d[1], d[2], d[3] );
+  const float s1 = b.t1 * b.t1, s2 = b.t2 * b.t2, s3 = b.t3 * b.t3, s4 = b.t4 * b.t4;
+  int c = 0;
+#pragma unroll
+  for( int i = 0; i < 4; ++i )
+  {
+    c += ( ( d[i] < radius_sq ) & lex_less( d[i], L.pidx[k + i], bd2, bidx ) ) ? 1 : 0;
+    b.c1 += d[i] < s1 ? 1 : 0; b.c2 += d[i] < s2 ? 1 : 0; b.c3 += d[i] < s3 ? 1 : 0; b.c4 += d[i] < s4 ? 1 : 0;
+  }
+  return c;
+}
+// Widest band that holds K candidates, as a distance margin (0: none).  3e-4 m is far above the fp32 rounding of the
+// distances involved (<= 1e-7 m at these radii) and above the 1e-4 m the gate certificate's radius gives away.
+__device__ __forceinline__ float rank_slack_of( const RankBands& b, int K )
+{
+  const float t = b.c1 >= K ? b.t1 : b.c2 >= K ? b.t2 : b.c3 >= K ? b.t3 : b.c4 >= K ? b.t4 : b.dm;
+  const float s = b.dm - t - 3e-4f;
+  return s > 0.0f ? s : 0.0f;
 }
 
 // bound for a lane before / after a merge
@@ -620,11 +654,15 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
       int rank = 0;
       const CellBox rb = reach_box( g, cur, need_rank, reach_of( m, radius ), qx, qy, qz );
       uint32_t rs = 0;
+      RankBands rbands = rank_bands( m );
       if( !box_empty( rb ) )
       rs = sweep_shell<false>( g, rb, rb, false, L, lane, 0, 1, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
-      { rank += need_rank ? precede4( X, Y, Z, k4, L, qx, qy, qz, radius_sq, m.d2, m.idx ) : 0; } );
+      {
+        if( WARM ) { const int c = precede4_bands( X, Y, Z, k4, L, qx, qy, qz, radius_sq, m.d2, m.idx, rbands ); rank += need_rank ? c : 0; }
+        else rank += need_rank ? precede4( X, Y, Z, k4, L, qx, qy, qz, radius_sq, m.d2, m.idx ) : 0;
+      } );
       if( dbg_unsettled ) dbg_unsettled[2] = (int)rs;
-      if( need_rank && rank >= K ) { m.found = false; m.slot = -1; }
+      if( need_rank && rank >= K ) { m.found = false; m.slot = -1; if( WARM ) m.rank_slack = rank_slack_of( rbands, K ); }
       ++sweeps;
     }
   }
@@ -642,6 +680,7 @@ struct CoopLds
   int   m_slot[NW][WAVE];
   int   m_cnt[NW][WAVE];
   float m_fail[NW][WAVE];
+  int   m_bands[NW][WAVE];   // rank pass: the four band counts of a wave's share, saturated at 31, 8 bits each
 };
 
 // The same staged search, done by all NW waves of a workgroup for ONE tile: every
@@ -717,16 +756,27 @@ __device__ __forceinline__ Match coop_search( const GridView& g, bool active,
     {
       int rank = 0;
       const CellBox rb = reach_box( g, cur, need_rank, reach_of( m, radius ), qx, qy, qz );
+      RankBands rbands = rank_bands( m );
       if( !box_empty( rb ) )
       sweep_shell<false>( g, rb, rb, false, L, lane, wib, NW, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
-      { rank += need_rank ? precede4( X, Y, Z, k4, L, qx, qy, qz, radius_sq, m.d2, m.idx ) : 0; } );
+      {
+        if( WARM ) { const int c = precede4_bands( X, Y, Z, k4, L, qx, qy, qz, radius_sq, m.d2, m.idx, rbands ); rank += need_rank ? c : 0; }
+        else rank += need_rank ? precede4( X, Y, Z, k4, L, qx, qy, qz, radius_sq, m.d2, m.idx ) : 0;
+      } );
       __syncthreads();                             // everyone is done reading the counts
       C.m_cnt[wib][lane] = rank;
+      if( WARM ) C.m_bands[wib][lane] = min( rbands.c1, 31 ) | ( min( rbands.c2, 31 ) << 8 ) | ( min( rbands.c3, 31 ) << 16 ) | ( min( rbands.c4, 31 ) << 24 );
       __syncthreads();
       rank = 0;
+      int bands = 0;
 #pragma unroll
-      for( int w = 0; w < NW; ++w ) rank += C.m_cnt[w][lane];
-      if( need_rank && rank >= K ) { m.found = false; m.slot = -1; }
+      for( int w = 0; w < NW; ++w ) { rank += C.m_cnt[w][lane]; if( WARM ) bands += C.m_bands[w][lane]; }
+      if( need_rank && rank >= K )
+      {
+        m.found = false; m.slot = -1;
+        // (saturated sums decide "at least K" correctly while K <= 31, and NW * 31 fits the 8 bits)
+        if( WARM && K <= 31 && NW <= 8 ) { rbands.c1 = bands & 255; rbands.c2 = ( bands >> 8 ) & 255; rbands.c3 = ( bands >> 16 ) & 255; rbands.c4 = ( bands >> 24 ) & 255; m.rank_slack = rank_slack_of( rbands, K ); }
+      }
     }
   }
   if( dbg_streamed ) *dbg_streamed = streamed;
@@ -845,9 +895,21 @@ __device__ __forceinline__ bool icp_certificate( const IcpLaunch& L, int prob, i
   xform3( Tp, n.x, n.y, n.z, 0.0f, tx, ty, tz );   xform3( L.T2i, tx, ty, tz, 0.0f, mx, my, mz );
   const float dq = sqrtf( ( qx - px ) * ( qx - px ) + ( qy - py ) * ( qy - py ) + ( qz - pz ) * ( qz - pz ) );
   const float dn = sqrtf( ( nx - mx ) * ( nx - mx ) + ( ny - my ) * ( ny - my ) + ( nz - mz ) * ( nz - mz ) );
-  const float r_now = r - ( dq * 1.0001f + 1e-5f );
+  const float moved = dq * 1.0001f + 1e-5f;
+  const float r_now = r - moved;
   const float dot_now = L.cert_dot[o] - ( dn * L.tgt_nor_max * 1.0001f + 1e-6f );
-  const bool skip = ( L.radius <= r_now ) & ( dot_now >= 0.0f );
+  bool skip = ( L.radius <= r_now ) & ( dot_now >= 0.0f );
+  if( L.cert_slack )
+  {
+    // rank certificate: the nearest gated candidate (at cert_r) was rejected because K candidates precede it, and K of
+    // them lie closer than cert_r - slack.  They have come closer to the query by at most `moved`, whatever passes
+    // the gate now lies no closer than r_now = cert_r - moved (everything inside failed it, by the margin above): while
+    // slack - 2 moved > 0 those K still precede every candidate that could be chosen, so the point stays unmatched.
+    const float s = L.cert_slack[o];
+    const float s_now = s > 0.0f ? s - 2.0f * moved : 0.0f;
+    skip |= ( s_now > 0.0f ) & ( dot_now >= 0.0f ) & ( r_now > 0.0f );
+    L.cert_slack[o] = s_now;
+  }
   L.cert_r[o] = skip ? r_now : -1.0f;
   L.cert_dot[o] = dot_now;
   return skip;
@@ -864,6 +926,7 @@ __device__ __forceinline__ void icp_emit( const IcpLaunch& L, int prob, int tile
     const float r = ( m.idx != INT_MAX ? sqrtf( m.d2 ) : L.radius ) - 1e-4f;
     const float d = L.gate_tmin - m.fail_max - 1e-5f;
     L.cert_r[o] = ( d >= 0.0f ) ? r : -1.0f; L.cert_dot[o] = d;
+    if( L.cert_slack ) L.cert_slack[o] = ( !m.found && m.idx != INT_MAX ) ? m.rank_slack : 0.0f;
   }
   if( RS_DBG >= 2 && DBG( L ) )
   {
