@@ -478,10 +478,14 @@ __device__ __forceinline__ int precede4( const float4& X, const float4& Y, const
 
 // The rank pass of a search that issues certificates (ICP): besides the exact rank, how many candidates lie
 // within 0.5, 0.75, 0.9 and 0.97 of the match's distance.
-struct RankBands { float dm, t1, t2, t3, t4; int c1, c2, c3, c4; };
+struct RankBands { float dm; int c1, c2, c3, c4; };
+#define RANK_BAND_1 0.5f
+#define RANK_BAND_2 0.75f
+#define RANK_BAND_3 0.9f
+#define RANK_BAND_4 0.97f
 __device__ __forceinline__ RankBands rank_bands( const Match& m )
 {
-  RankBands b; b.dm = sqrtf( m.d2 ); b.t1 = 0.5f * b.dm; b.t2 = 0.75f * b.dm; b.t3 = 0.9f * b.dm; b.t4 = 0.97f * b.dm; b.c1 = b.c2 = b.c3 = b.c4 = 0;
+  RankBands b; b.dm = sqrtf( m.d2 ); b.c1 = b.c2 = b.c3 = b.c4 = 0;
   return b;
 }
 __device__ __forceinline__ int precede4_bands( const float4& X, const float4& Y, const float4& Z, int k, const WaveLds& L,
@@ -489,7 +493,8 @@ __device__ __forceinline__ int precede4_bands( const float4& X, const float4& Y,
 {
   float d[4];
   dist2x4( X, Y, Z, qx, qy, qz, d[0], d[1], d[2], d[3] );
-  const float s1 = b.t1 * b.t1, s2 = b.t2 * b.t2, s3 = b.t3 * b.t3, s4 = b.t4 * b.t4;
+  const float t1 = RANK_BAND_1 * b.dm, t2 = RANK_BAND_2 * b.dm, t3 = RANK_BAND_3 * b.dm, t4 = RANK_BAND_4 * b.dm;
+  const float s1 = t1 * t1, s2 = t2 * t2, s3 = t3 * t3, s4 = t4 * t4;
   int c = 0;
 #pragma unroll
   for( int i = 0; i < 4; ++i )
@@ -503,7 +508,12 @@ __device__ __forceinline__ int precede4_bands( const float4& X, const float4& Y,
 // distances involved (<= 1e-7 m at these radii) and above the 1e-4 m the gate certificate's radius gives away.
 __device__ __forceinline__ float rank_slack_of( const RankBands& b, int K )
 {
-  const float t = b.c1 >= K ? b.t1 : b.c2 >= K ? b.t2 : b.c3 >= K ? b.t3 : b.c4 >= K ? b.t4 : b.dm;
+  // (the same products as in precede4_bands; a chain of selects on values, so that nothing here needs an address)
+  float t = b.dm;
+  t = b.c4 >= K ? RANK_BAND_4 * b.dm : t;
+  t = b.c3 >= K ? RANK_BAND_3 * b.dm : t;
+  t = b.c2 >= K ? RANK_BAND_2 * b.dm : t;
+  t = b.c1 >= K ? RANK_BAND_1 * b.dm : t;
   const float s = b.dm - t - 3e-4f;
   return s > 0.0f ? s : 0.0f;
 }
@@ -1041,7 +1051,7 @@ __global__ __launch_bounds__( BLOCK, RS_ICP_OCC ) void k_icp_corr( IcpLaunch L )
 
 // Phase B: one workgroup per queued tile, whole box, chunks shared by its waves.
 #ifndef RS_COOP_OCC
-#define RS_COOP_OCC 6      // waves per SIMD the cooperative kernel's register allocation aims at
+#define RS_COOP_OCC 5      // waves per SIMD the cooperative kernel's register allocation aims at (96 VGPRs: no spills; 6 = 80 VGPRs spilt 56 B per lane for no gain in time)
 #endif
 template <int NW>
 __global__ __launch_bounds__( NW * WAVE, RS_COOP_OCC ) void k_icp_corr_coop( IcpLaunch L )
