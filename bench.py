@@ -6,7 +6,7 @@ One "step" = one pass of the three consumers over one synthetic 2-scan scene hel
 
   ICP-NN    whole-scan point-to-plane ICP, scan t1 (~1M pts) -> scan t0 (~1M pts), K=16,
             r = 0.10 with the reference's 0.95 shrink schedule, 60°, 10 fixed iterations
-            (search + weights + normal-equation reduction on the GPU, 6x6 solve on the host)
+            (search, weights, normal-equation reduction, 6x6 solve and pose update all on the GPU)
   score-NN  256 poses x 10k-point object against the 1M-point scan, K=64, r=0.10, 35° gate
   label-NN  8 placements of ~50k-point objects against the 1M scene points, K=1, r=0.05
 
@@ -204,8 +204,8 @@ def cpu_baseline(w, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)        # a step is ~3 ms: 20 of them average out the host-side jitter of a short run
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--points", type=int, default=1_000_000, help="points per scan")
     ap.add_argument("--knn", choices=["hash", "brute"], default="hash",
                     help="candidate layout: LDS spatial-hash cells (default) or one brute tile")
@@ -246,10 +246,13 @@ def main():
     capi.profile_reset()
     barrier()
     t0 = time.perf_counter()
+    marks = []
     for _ in range(args.steps):
         run_step(w, dist_ctx, conc)
+        marks.append(time.perf_counter())       # (a step ends with its results on the host: no extra synchronisation)
     barrier()
     elapsed = time.perf_counter() - t0
+    step_ms = np.diff(np.array([t0] + marks)) * 1e3
     capi.profile_enable(False)
 
     pairs_rank = sum(w["pairs"].values()) * args.steps
@@ -302,6 +305,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": ms / max(1, n_l), "launches": n_l, "alg_bytes_per_launch": bytes_launch},
+            "ms_per_step_spread": {"min": float(step_ms.min()), "median": float(np.median(step_ms)), "max": float(step_ms.max())},
             "kernel_ms_per_step": {k: v[1] / args.steps for k, v in prof.items()},
         }
         # "the real limiter is candidate evaluation ... so also report candidate-evals/s"
