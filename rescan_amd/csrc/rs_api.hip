@@ -608,6 +608,7 @@ int icp_prepare( IcpCtx& cx, const rs_hip_cloud_t* src, const rs_hip_cloud_t* tg
   L.iters = (int*)( w + np * 33 ); L.err = w + np * 34; L.prev_err = w + np * 35; L.queued = (int*)( w + np * 36 ); L.ticket = (int*)( w + np * 37 );
   L.solve = 0; L.iter_index = 0; L.fixed_iters = 0;
   L.seed = getenv( "RS_HIP_NO_SEED" ) ? 0 : 1;
+  L.by_rows = getenv( "RS_HIP_NO_BY_ROWS" ) ? 0 : 1;
   L.cert_r = nullptr; L.cert_dot = nullptr; L.cert_slack = nullptr; L.tgt_nor_max = tgt->nor_max;
   L.m_slot = g_ws.slot.as<int>(); L.m_d2 = g_ws.d2.as<float>(); L.m_dot = g_ws.dot.as<float>();
   L.stat_acc = nullptr;       // set by the align loop (fp64 estimator only)

@@ -92,6 +92,7 @@ struct IcpLaunch
   int*    ticket;       // (unused, kept zero)
   int     warm;         // m_slot holds last iteration's matches: use them as starting candidates
   int     seed;         // (when !warm) start from the best usable point of the query's own cell
+  int     by_rows;      // (when warm) per-row sweep of the tiles whose lanes all start from a candidate (rs_kernels.hip: sweep_by_rows)
   // certificates issued by every search and consulted when a point has no usable previous match (rs_kernels.hip: icp_certificate); null = off
   float*  cert_r;       // n_prob x nq
   float*  cert_dot;     // n_prob x nq

@@ -120,6 +120,27 @@ __device__ __forceinline__ float lane63( float v ) { return __int_as_float( __bu
                 OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"        \
                 OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"            \
                 : "+v"( v ) )
+// the same within every row of 16 lanes: all 16 end with their row's result
+#define RS_DPP_ROW_REDUCE( OP, v )                                                          \
+  asm volatile( "s_nop 4\n\t"                                                               \
+                OP " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t" \
+                OP " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t" \
+                OP " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"     \
+                OP " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1"               \
+                : "+v"( v ) )
+__device__ __forceinline__ float row_min( float v ) { RS_DPP_ROW_REDUCE( "v_min_f32_dpp", v ); return v; }
+__device__ __forceinline__ float row_max( float v ) { RS_DPP_ROW_REDUCE( "v_max_f32_dpp", v ); return v; }
+__device__ __forceinline__ uint32_t row_max_u( uint32_t v ) { RS_DPP_ROW_REDUCE( "v_max_u32_dpp", v ); return v; }
+// inclusive prefix sum within every row of 16 lanes
+__device__ __forceinline__ uint32_t row_scan( uint32_t v ) {
+  asm volatile( "s_nop 4\n\t"
+                "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+                : "+v"( v ) );
+  return v;
+}
 __device__ __forceinline__ float wave_min( float v ) { RS_DPP_REDUCE( "v_min_f32_dpp", v ); return lane63( v ); }
 __device__ __forceinline__ float wave_max( float v ) { RS_DPP_REDUCE( "v_max_f32_dpp", v ); return lane63( v ); }
 // fixed association: ((quad) + mirrored quad) + mirrored half-row, then rows 0..3 in order
@@ -366,6 +387,96 @@ __device__ __forceinline__ uint32_t sweep_shell( const GridView& g, const CellBo
   return streamed;
 }
 
+// The sweep of a tile whose lanes all start from a candidate, done per ROW of 16 lanes (a quarter of the tile: 16
+// Hilbert-consecutive queries, a patch a few centimetres across).  The wave-wide sweep streams the cells of the whole
+// tile's box past all 64 lanes — about 2.3 candidates per query, every one of them tested by every lane; here each row
+// streams only the cells its own lanes reach, 16 candidates per row and round, and a lane tests its row's candidates
+// only: a third of the distance evaluations, which are what phase A's VALU time goes to.  The staged candidates of row r
+// occupy entries [16 r, 16 r + 16) of the wave's LDS arrays; the four rows' ds_read_b128 addresses differ, which the LDS
+// serves at the same rate (it processes 16 lanes of a b128 read at a time anyway).  Candidates that two rows both
+// reach are staged twice — a lane still meets each candidate once.  Returns false (nothing done) when a row's box has
+// more than 16 rows of cells: the caller then sweeps the tile's common box as before.
+template <bool WITH_NOR, class F>
+__device__ __forceinline__ bool sweep_by_rows( const GridView& g, const CellBox& clip, bool mask, float reach,
+                                               float qx, float qy, float qz, WaveLds& L, int lane, F&& f, uint32_t& streamed )
+{
+  const float big = FLT_MAX;
+  const float lx = row_min( mask ? qx - reach : big ), hx = row_max( mask ? qx + reach : -big );
+  const float ly = row_min( mask ? qy - reach : big ), hy = row_max( mask ? qy + reach : -big );
+  const float lz = row_min( mask ? qz - reach : big ), hz = row_max( mask ? qz + reach : -big );
+  int x0, x1, y0, y1, z0, z1;
+  axis_range( lx, hx, 0.0f, g.minx, g.inv_cell, g.w, x0, x1 );
+  axis_range( ly, hy, 0.0f, g.miny, g.inv_cell, g.h, y0, y1 );
+  axis_range( lz, hz, 0.0f, g.minz, g.inv_cell, g.d, z0, z1 );
+  x0 = max( x0, clip.x0 ); x1 = min( x1, clip.x1 ); y0 = max( y0, clip.y0 ); y1 = min( y1, clip.y1 ); z0 = max( z0, clip.z0 ); z1 = min( z1, clip.z1 );
+  const bool empty = ( hx < lx ) | ( x1 < x0 ) | ( y1 < y0 ) | ( z1 < z0 );
+  const int ny = y1 - y0 + 1;
+  const int n_rows = empty ? 0 : ny * ( z1 - z0 + 1 );
+  if( __any( n_rows > 16 ) ) return false;
+  const int l16 = lane & 15, base = lane & 48;
+  uint32_t sa = 0, la = 0;
+  if( l16 < n_rows )
+  {
+    int rz = (int)( (float)l16 / (float)ny );               // l16 < 16, ny <= 16: exact enough to be off by at most one
+    rz -= ( rz * ny > l16 ) ? 1 : 0;
+    rz += ( ( rz + 1 ) * ny <= l16 ) ? 1 : 0;
+    const int y = y0 + ( l16 - rz * ny ), z = z0 + rz;
+    const uint32_t* cs = g.cell_start + (size_t)( z * g.h + y ) * g.w;
+    sa = cs[x0]; la = cs[x1 + 1] - sa;
+  }
+  const uint32_t incl = row_scan( la );
+  const uint32_t total = row_max_u( incl );                 // of this lane's row
+  // entries past a row's last cell row carry pre = total: the binary search below never selects them
+  L.seg_a[lane] = sa; L.pre[lane] = incl - la;
+  wave_lds_fence();
+  const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane( (int)total, 15 ), t1 = (uint32_t)__builtin_amdgcn_readlane( (int)total, 31 );
+  const uint32_t t2 = (uint32_t)__builtin_amdgcn_readlane( (int)total, 47 ), t3 = (uint32_t)__builtin_amdgcn_readlane( (int)total, 63 );
+  const uint32_t longest = max( max( t0, t1 ), max( t2, t3 ) );
+  streamed += t0 + t1 + t2 + t3;
+
+  auto fetch = [&]( uint32_t c0, float4& P, float4& N, uint32_t& src )
+  {
+    const uint32_t j = c0 + (uint32_t)l16;
+    P = make_float4( FLT_MAX, FLT_MAX, FLT_MAX, 0.0f ); N = make_float4( 0.0f, 0.0f, 0.0f, 0.0f ); src = 0;
+    if( j < total )
+    {
+      int row = 0;                                   // last cell row of this lane's row whose first candidate number is <= j
+#pragma unroll
+      for( int step = 8; step > 0; step >>= 1 ) { if( L.pre[base + row + step] <= j ) row += step; }
+      src = L.seg_a[base + row] + ( j - L.pre[base + row] );
+      P = g.pos[src];
+      if( WITH_NOR ) N = g.nor[src];
+    }
+  };
+  float4 P, N; uint32_t src;
+  uint32_t c0 = 0;
+  if( c0 < longest ) fetch( c0, P, N, src );
+  while( c0 < longest )
+  {
+    L.px[lane] = P.x; L.py[lane] = P.y; L.pz[lane] = P.z; L.pidx[lane] = __float_as_int( P.w );
+    if( WITH_NOR ) { L.nx[lane] = N.x; L.ny[lane] = N.y; L.nz[lane] = N.z; }
+    L.slot[lane] = src;
+    wave_lds_fence();
+    const uint32_t cn = c0 + 16u;
+    if( cn < longest ) fetch( cn, P, N, src );       // in flight during the evaluation
+    const uint32_t left = longest - c0;
+    const int n4 = left >= 16u ? 4 : (int)( ( left + 3u ) >> 2 );
+#pragma unroll 1
+    for( int k4 = 0; k4 < n4; ++k4 )
+    {
+      const int k = base + 4 * k4;
+      const float4 X = *reinterpret_cast<const float4*>( &L.px[k] );
+      const float4 Y = *reinterpret_cast<const float4*>( &L.py[k] );
+      const float4 Z = *reinterpret_cast<const float4*>( &L.pz[k] );
+      f( X, Y, Z, k );
+    }
+    wave_lds_fence();
+    c0 = cn;
+  }
+  if( g.evals && lane == 0 && ( t0 + t1 + t2 + t3 ) ) atomicAdd( g.evals + 8 * ( ( blockIdx.x + 37 * blockIdx.y ) & ( EVAL_SHARDS - 1 ) ), (unsigned long long)( ( t0 + t1 + t2 + t3 ) / 4 ) );   // (each candidate is tested by 16 lanes, not 64)
+  return true;
+}
+
 // Result of a search for one query.
 // `fail_max`: the largest gate value max(dot,0) among the candidates that were inside the lane's bound when
 // met and failed the gate — every candidate closer than the final match (or, without one, within the
@@ -577,7 +688,8 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
                                               float radius, float radius_sq, float tmin, int K,
                                               WaveLds& L, int lane, int max_stages, bool* handoff, int* dbg_unsettled,
                                               Match m /* starting candidate: empty, or a genuine one (within radius, gate passed) that only tightens the bounds */,
-                                              int* n_sweeps = nullptr /* out: shells swept + rank pass: the tile's cost class */ )
+                                              int* n_sweeps = nullptr /* out: shells swept + rank pass: the tile's cost class */,
+                                              bool by_rows = false /* WARM: sweep_by_rows for tiles whose lanes all start from a candidate */ )
 {
   if( handoff ) *handoff = false;
   int sweeps = 0;
@@ -605,10 +717,15 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
     // Every lane starts from a genuine candidate (ICP iterations >= 2): whatever can beat or precede it
     // lies within its distance, so ONE sweep of the cells those small boxes touch settles the tile —
     // no shells, no cover test.
-    cur = reach_box( g, full, active, reach_of( m, radius ), qx, qy, qz );
-    if( !box_empty( cur ) )
-      streamed += sweep_shell<GATED>( g, cur, cur, false, L, lane, 0, 1, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
-      { consider4<GATED, WARM>( X, Y, Z, k4, L, qx, qy, qz, nx, ny, nz, tmin, bound, m, seen_closer ); } );
+    auto step = [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
+    { consider4<GATED, WARM>( X, Y, Z, k4, L, qx, qy, qz, nx, ny, nz, tmin, bound, m, seen_closer ); };
+    const float reach = reach_of( m, radius );
+    if( by_rows && sweep_by_rows<GATED>( g, full, active, reach, qx, qy, qz, L, lane, step, streamed ) ) cur = full;   // (cur only clips the rank pass's own box)
+    else
+    {
+      cur = reach_box( g, full, active, reach, qx, qy, qz );
+      if( !box_empty( cur ) ) streamed += sweep_shell<GATED>( g, cur, cur, false, L, lane, 0, 1, step );
+    }
     if( dbg_unsettled ) { dbg_unsettled[1] = (int)streamed; dbg_unsettled[3] = 1; }
     sweeps = 1;
   }
@@ -1025,7 +1142,7 @@ __global__ __launch_bounds__( BLOCK, RS_ICP_OCC ) void k_icp_corr( IcpLaunch L )
   const Match init = icp_warm_start( L, prob, i, active, qx, qy, qz, nx, ny, nz );
   const bool search = active & !icp_certificate( L, prob, i, active & !init.found, qx, qy, qz, nx, ny, nz );
   Match m = tile_search<true, true>( L.tgt, search, qx, qy, qz, nx, ny, nz, L.radius, L.radius_sq, L.gate_tmin, L.K,
-                               lds[wib], lane, L.solo_stages, &handoff, DBG( L ) ? unsettled : nullptr, init, &sweeps );
+                               lds[wib], lane, L.solo_stages, &handoff, DBG( L ) ? unsettled : nullptr, init, &sweeps, L.by_rows != 0 );
   if( L.heavy_out && lane == 0 )
   {
     int* hv = L.heavy_out + (size_t)prob * ( L.src.n_tiles + HEAVY_SLOTS + 1 );

@@ -492,21 +492,22 @@ def test_quarter_million_points_vs_oracle(capi, oracle):
 def test_certificates_change_nothing(capi, monkeypatch):
     """The gate certificates and the rank certificates (rs_kernels.hip: icp_certificate) only decide which source
     points are searched again; the poses and errors must be the same bits with either of them switched off
-    (the fp64 estimator sums in a fixed order, the dist² statistics are integer sums)."""
+    (the fp64 estimator sums in a fixed order, the dist² statistics are integer sums).  The same holds for the per-row
+    sweep of the warm tiles (sweep_by_rows): which lanes test which candidates is no part of the result."""
     from rescan_amd import synth
     s0 = synth.scene_for_point_count(250_000, seed=29, timestep=0)
     s1 = synth.scene_for_point_count(250_000, seed=29, timestep=1)
     a, b = capi.Cloud(s0["points"], s0["normals"]), capi.Cloud(s1["points"], s1["normals"])
     T0 = synth.perturbed_pose(I4, np.random.default_rng(4), 0.01, 0.01)
     runs = []
-    for switch in (None, "RS_HIP_NO_RANK_CERT", "RS_HIP_NO_CERT"):
+    for switch in (None, "RS_HIP_NO_RANK_CERT", "RS_HIP_NO_CERT", "RS_HIP_NO_BY_ROWS"):
         if switch:
             monkeypatch.setenv(switch, "1")
         e, T, it = capi.icp_align(b, a, T0, I4, 0.1, np.deg2rad(60.0), max_iter=12, fixed_iters=True)
         if switch:
             monkeypatch.delenv(switch)
         runs.append((np.float32(e).tobytes(), T.tobytes(), it))
-    assert runs[0] == runs[1] == runs[2]
+    assert runs[0] == runs[1] == runs[2] == runs[3]
 
 
 # ---- size-independent properties at BASELINE.json's full size (~1M-point clouds) -----------
