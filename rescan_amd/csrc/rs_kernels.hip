@@ -1099,7 +1099,7 @@ __device__ __forceinline__ void icp_iteration_reset( const IcpLaunch& L, int pro
 
 // Phase A: one wave per tile, first shell(s) only; unsettled tiles are queued.
 #ifndef RS_ICP_OCC
-#define RS_ICP_OCC 7      // workgroups of 4 waves per CU the register allocation aims at (x4 SIMDs: waves per SIMD)
+#define RS_ICP_OCC 6      // waves per SIMD the register allocation aims at: 80 VGPRs, 36 B of scratch per lane (7: 72 VGPRs, 80 B — slower and 100 MB more HBM-side traffic per search; 5: none, +3 % time)
 #endif
 __global__ __launch_bounds__( BLOCK, RS_ICP_OCC ) void k_icp_corr( IcpLaunch L )
 {
