@@ -40,7 +40,7 @@ if __name__ == "__main__":
                         "--warmup 1 --serial`, tools/profile.sh traffic, folded by tools/pmc_summary.py --fold), FETCH_SIZE doubled as "
                         "MI355X_MICROARCH.md \u00a7HBM prescribes for 16-B-per-lane reads on gfx950; WRITE_SIZE as reported.  nn_icp = "
                         "k_icp_corr + k_icp_corr_coop<4|8> (one search).  Part of the search kernels' writes are register spills to "
-                        "scratch (occupancy-7 / -6 register caps), not results."}
+                        "scratch (phase A and the score / label kernels: occupancy-6 register caps), not results."}
         for d, (names, per) in doms.items():
             out[d] = total(names) / F[per][1]
         out["raw_avg_KB"] = {c: {k: v[0] for k, v in raw[c].items()} for c in ("FETCH_SIZE", "WRITE_SIZE")}
