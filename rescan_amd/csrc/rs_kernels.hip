@@ -12,7 +12,8 @@
 //   lanes are.  A tile whose lanes all start from a genuine candidate (ICP: last iteration's match,
 //   or a point of the query's own cell) needs no shells at all: one sweep of the cells within those
 //   candidates' distances settles it — a hundred or two candidates instead of everything within the
-//   radius.  Tiles that stay unsettled are handed to a second kernel that gives each of them a whole
+//   radius — and that sweep is done per row of 16 lanes, each row streaming only the cells its own lanes
+//   reach (sweep_by_rows).  Tiles that stay unsettled are handed to a second kernel that gives each of them a whole
 //   workgroup (coop_search); what cannot be bounded at all — a point with nothing to match — is
 //   remembered from one ICP iteration to the next (icp_certificate).
 //
