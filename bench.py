@@ -101,32 +101,72 @@ def run_step(w, dist_ctx=None, concurrent=True):
     else:
         (err, T, it), scores, res = icp(), score(), label()
     if dist_ctx is not None:
-        exchange_results(dist_ctx[0], dist_ctx[1], T, err, scores, res)
+        # The exchange of step s overlaps step s + 1 (its consumers are host code downstream — the graph cut — not the next
+        # step's kernels): one exchange in flight, the last one is waited for before the timed region closes (exchange_wait).
+        exchange_wait()
+        _XCH["pending"] = _exchange_pool().submit(exchange_results, dist_ctx[0], dist_ctx[1], T, err, scores, res)
     return err, T, scores, res
+
+
+def _exchange_pool():
+    if "pool" not in _XCH:
+        from concurrent.futures import ThreadPoolExecutor
+        _XCH["pool"] = ThreadPoolExecutor(max_workers=1)
+    return _XCH["pool"]
+
+
+def exchange_wait():
+    f = _XCH.pop("pending", None)
+    return f.result() if f is not None else None
+
+
+_XCH = {}
 
 
 def exchange_results(dist, dev, T, err, scores, res):
     """The exchange step of the multi-GPU path (north_star: 'RCCL all-gather of the resulting 4x4
     poses / unary cost rows'): every rank receives every rank's pose + error + scores and label
-    partials (labels int8 + min_dists f32).  Scene sizes differ slightly across ranks, so the label
-    arrays are padded to the common maximum.  Returns what rank-local code would consume."""
+    partials (labels int8 + min_dists f32) in ONE all-gather per step — the payload (5 MB per rank at
+    1 M points) is far below what xGMI moves in a millisecond, so the step is bound by launches, not bytes
+    (SURVEY.md §8e).  Scene sizes differ slightly across ranks: the label arrays are padded to the common
+    maximum, agreed on once.  Packed per rank: int64 n | f32 pose, err, scores | f32 min_dists[nmax] |
+    int8 labels[nmax].  Returns per-rank views (small, labels, min_dists) of the gathered buffer."""
     import torch
+    if dev.type == "cuda":
+        torch.cuda.set_device(dev)                 # (called from the exchange thread)
     world = dist.get_world_size()
-    small = torch.from_numpy(np.concatenate([np.asarray(T, np.float32).ravel(), [np.float32(err)],
-                                             np.asarray(scores, np.float32)]).astype(np.float32)).to(dev)
-    out = [torch.empty_like(small) for _ in range(world)]
-    dist.all_gather(out, small)
-    lab = torch.from_numpy(np.ascontiguousarray(res["labels"])).to(dev)
-    mind = torch.from_numpy(np.ascontiguousarray(res["min_dists"])).to(dev)
-    n = torch.tensor([lab.numel()], device=dev, dtype=torch.int64)
-    dist.all_reduce(n, op=dist.ReduceOp.MAX)
-    nmax = int(n.item())
-    padl = torch.zeros(nmax, dtype=lab.dtype, device=dev); padl[: lab.numel()] = lab
-    padm = torch.full((nmax,), 1e9, dtype=mind.dtype, device=dev); padm[: mind.numel()] = mind
-    gl = [torch.empty_like(padl) for _ in range(world)]
-    gm = [torch.empty_like(padm) for _ in range(world)]
-    dist.all_gather(gl, padl)
-    dist.all_gather(gm, padm)
+    lab = np.ascontiguousarray(res["labels"], np.int8)
+    mind = np.ascontiguousarray(res["min_dists"], np.float32)
+    small = np.concatenate([np.asarray(T, np.float32).ravel(), [np.float32(err)], np.asarray(scores, np.float32)]).astype(np.float32)
+    st = _XCH.get("st")
+    if st is None or st["n"] != len(lab) or st["n_small"] != len(small) or st["world"] != world:
+        n = torch.tensor([len(lab)], device=dev, dtype=torch.int64)
+        dist.all_reduce(n, op=dist.ReduceOp.MAX)
+        nmax = int(n.item())
+        o_small, o_mind = 8, 8 + 4 * len(small)
+        o_lab = o_mind + 4 * nmax
+        nbytes = (o_lab + nmax + 15) // 16 * 16
+        host = torch.zeros(nbytes, dtype=torch.uint8)
+        if dev.type == "cuda":
+            host = host.pin_memory()
+        st = dict(n=len(lab), n_small=len(small), world=world, nmax=nmax, nbytes=nbytes, off=(o_small, o_mind, o_lab), host=host,
+                  send=torch.empty(nbytes, dtype=torch.uint8, device=dev), recv=torch.empty(world * nbytes, dtype=torch.uint8, device=dev))
+        _XCH["st"] = st
+    o_small, o_mind, o_lab = st["off"]
+    nmax, nbytes = st["nmax"], st["nbytes"]
+    h = st["host"].numpy()
+    h[0:8].view(np.int64)[0] = len(lab)
+    h[o_small:o_mind].view(np.float32)[:] = small
+    hm = h[o_mind:o_lab].view(np.float32); hm[: len(mind)] = mind; hm[len(mind):] = 1e9
+    hl = h[o_lab:o_lab + nmax].view(np.int8); hl[: len(lab)] = lab; hl[len(lab):] = 0
+    st["send"].copy_(st["host"])
+    dist.all_gather_into_tensor(st["recv"], st["send"])
+    out, gl, gm = [], [], []
+    for r in range(world):
+        b = st["recv"][r * nbytes:(r + 1) * nbytes]
+        out.append(b[o_small:o_mind].view(torch.float32))
+        gm.append(b[o_mind:o_lab].view(torch.float32))
+        gl.append(b[o_lab:o_lab + nmax].view(torch.int8))
     return out, gl, gm
 
 
@@ -223,9 +263,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # RS_BENCH_FORCE_DIST=1: rehearse the RCCL exchange step on a one-GPU box (world size 1 under torch.distributed.run)
+    if world > 1 or os.environ.get("RS_BENCH_FORCE_DIST"):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     from rescan_amd import capi
@@ -242,6 +285,7 @@ def main():
     conc = not args.serial
     for _ in range(args.warmup):
         run_step(w, dist_ctx, conc)
+    exchange_wait()
     capi.profile_enable(True)
     capi.profile_reset()
     barrier()
@@ -250,6 +294,7 @@ def main():
     for _ in range(args.steps):
         run_step(w, dist_ctx, conc)
         marks.append(time.perf_counter())       # (a step ends with its results on the host: no extra synchronisation)
+    exchange_wait()                             # the last step's exchange belongs to the timed region
     barrier()
     elapsed = time.perf_counter() - t0
     step_ms = np.diff(np.array([t0] + marks)) * 1e3
@@ -301,7 +346,7 @@ def main():
                        "n_scan0": w["n_scan0"], "n_scan1": w["n_scan1"], "n_obj": w["n_obj"],
                        "pairs_per_step": sum(w["pairs"].values()), "pairs_split": w["pairs"],
                        "issue": "3 host threads / 3 HIP streams (ICP chain | score batch | label pass)" if conc else "serial",
-                       "exchange": "all_gather(poses, scores, label partials)" if world > 1 else "none"},
+                       "exchange": "one fused all_gather(poses, scores, label partials) per step, overlapped with the next step" if dist is not None else "none"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": ms / max(1, n_l), "launches": n_l, "alg_bytes_per_launch": bytes_launch},
