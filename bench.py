@@ -288,6 +288,8 @@ def main():
     exchange_wait()
     capi.profile_enable(True)
     capi.profile_reset()
+    import gc
+    gc.collect(); gc.disable()                  # no collector pauses inside the timed region
     barrier()
     t0 = time.perf_counter()
     marks = []
@@ -297,7 +299,10 @@ def main():
     exchange_wait()                             # the last step's exchange belongs to the timed region
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     step_ms = np.diff(np.array([t0] + marks)) * 1e3
+    if os.environ.get("RS_BENCH_PRINT_STEPS") and rank == 0:
+        print("slow steps (index, ms):", [(int(k), round(float(v), 2)) for k, v in enumerate(step_ms) if v > 1.3 * np.median(step_ms)], file=sys.stderr)
     capi.profile_enable(False)
 
     pairs_rank = sum(w["pairs"].values()) * args.steps

@@ -276,6 +276,12 @@ int rs_hip_profile_enable( int on )
     HIP_TRY( hipMalloc( (void**)&g_evals, EVAL_SHARDS * 64 ), RS_HIP_E_RUNTIME );
     HIP_TRY( hipMemset( g_evals, 0, EVAL_SHARDS * 64 ), RS_HIP_E_RUNTIME );
   }
+  if( on )
+  {
+    // events are created ahead of the timed region (creating them one by one inside it shows up as stalls of a step)
+    std::lock_guard<std::mutex> lock( g_prof_mutex );
+    while( g_evpool.size() < 8192 ) { hipEvent_t x; if( hipEventCreate( &x ) != hipSuccess ) break; g_evpool.push_back( x ); }
+  }
   g_prof = on != 0;
   return RS_HIP_OK;
 }
