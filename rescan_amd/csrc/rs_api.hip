@@ -154,12 +154,21 @@ struct ProfScope
 // Consecutive segments of one stream sharing their boundary events: one event per boundary instead of
 // two (an event between two dependent launches costs a few microseconds of their back-to-back dispatch,
 // which matters for the ICP loop's chain of short kernels).
+// The ICP loop may be sampled: one call in RS_HIP_PROF_EVERY (default 1: every call) carries the events and the averages
+// per launch are taken over those — two events per iteration are ~12 us of a ~180 us iteration, 3-4 % of a bench step.
 struct ProfChain
 {
   const char* cur = nullptr; hipEvent_t at = nullptr;
+  bool on = true;
+  ProfChain()
+  {
+    static const unsigned every = getenv( "RS_HIP_PROF_EVERY" ) ? (unsigned)std::max( 1, atoi( getenv( "RS_HIP_PROF_EVERY" ) ) ) : 1u;
+    thread_local unsigned tick = 0;
+    if( g_prof ) on = ( tick++ % every ) == 0;
+  }
   void mark( const char* name )
   {
-    if( !g_prof ) return;
+    if( !g_prof || !on ) return;
     hipEvent_t ev = prof_event();
     if( cur ) prof_span( cur, at, ev );
     cur = name; at = ev;
