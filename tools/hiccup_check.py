@@ -16,7 +16,9 @@ def loop(tag, conc, prof, n=200):
     gc.enable(); capi.profile_enable(False)
     d = np.diff(t) * 1e3; med = np.median(d)
     print(tag, "median %.3f mean %.3f max %.2f slow:" % (med, d.mean(), d.max()), [(k, round(float(v), 1)) for k, v in enumerate(d) if v > 1.3 * med][:12], flush=True)
-loop("concurrent+profile", True, True)
+loop("concurrent+profile" + (" [" + os.environ["HICCUP_TAG"] + "]" if os.environ.get("HICCUP_TAG") else ""), True, True)
+if os.environ.get("HICCUP_TAG"):
+    sys.exit(0)
 loop("concurrent no-profile", True, False)
 loop("serial+profile", False, True)
 sys.setswitchinterval(1e-4)
