@@ -14,9 +14,15 @@ point-pairs = sum of query points over all searches = 10*n_scan + 256*n_obj + 8*
 Inputs are resident in HBM when the timed region starts; poses / scores / labels return to the
 host inside the timed region (they are the outputs the reference's callers consume).
 
-N > 1 (torchrun, one rank per GPU, RCCL): weak scaling — every rank processes its own scene of
-the same size (independent units) and the ranks all-gather the resulting poses,
-scores and label partials; value = pairs of all ranks / max-over-ranks time.
+N > 1 (torchrun, one rank per GPU, RCCL) — BASELINE.json configs[3], SURVEY.md §8e: ONE scene, replicated on every
+GPU; the units of the three consumers (ICP start poses, score poses, placements of the sorted arrangement) are
+sharded across the ranks with rescan_amd.dist.shard_range; every rank's label kernel writes its per-placement unary
+rows straight into the RCCL send buffer, next to its poses / errors / scores; ONE all-gather per step; every rank
+folds the gathered rows in the arrangement's sorted order on the device (rs_hip_fold_label_rows_device).  Weak
+scaling: the unit lists grow with N (N x {1 ICP problem, 256 poses, 8 placements}), so per-GPU work is fixed;
+value = pairs of all ranks / max-over-ranks time.  `--shard` runs the same route at N = 1 (a world of one: the
+"gather" is the send buffer itself); `--replicas` is the other multi-GPU shape (configs[4]: every rank its own
+scene, results all-gathered).
 
 Prints ONE JSON line (rank 0).
 """
@@ -40,21 +46,21 @@ N_PLACEMENTS = 8
 I4 = np.eye(4, dtype=np.float32).ravel()
 
 
-def build_workload(n_points, seed, knn):
-    from rescan_amd import capi, synth
+def build_inputs(n_points, seed, units=1):
+    """The step's inputs as numpy arrays only (no device): tests/golden/bench_seed11.npz pins the reference's
+    outputs for exactly these (oracle/gen_golden_bench.py imports this function in the build container).
+    units > 1 (sharded multi-GPU route): the unit lists are `units` times as long — further ICP start poses, score
+    poses and placements of the same scene and objects, drawn after the first unit's, which stays what it is."""
+    from rescan_amd import synth
     s0 = synth.scene_for_point_count(int(n_points * 0.84), seed=seed, timestep=0)
     s1 = synth.scene_for_point_count(int(n_points * 0.84), seed=seed, timestep=1)
-    cell = float(os.environ.get("RS_BENCH_CELL", "-1")) if knn == "hash" else 0.0
     w = {}
     w["s0"], w["s1"] = s0, s1
-    w["scan0"] = capi.Cloud(s0["points"], s0["normals"], cell_size=cell)      # ICP target
-    w["scan1"] = capi.Cloud(s1["points"], s1["normals"], cell_size=cell)      # ICP source, score + label scene
     rng = np.random.default_rng(seed + 5)
     w["icp_T0"] = synth.perturbed_pose(I4, rng, 0.01, 0.01)
     # score object: a table model resampled to ~10k points
     op, on = synth.make_object("table", seed * 13 + 1, density=3800.0)
     w["obj_score_np"] = (op, on)
-    w["obj_score"] = capi.Cloud(op, on, cell_size=cell if cell != 0 else -1.0)
     tbl = [o for o in s1["objects"] if o["kind"] == "table"][0]
     w["score_poses"] = np.stack([synth.perturbed_pose(tbl["pose"], rng, 0.6, 0.25) for _ in range(N_POSES)])
     # label placements: 8 scene objects with dense (~50k-point) model clouds, slightly mis-posed
@@ -62,26 +68,56 @@ def build_workload(n_points, seed, knn):
     for k, o in enumerate(s1["objects"][:N_PLACEMENTS]):
         dens = 50000.0 / max(1, len(o["pos"])) * synth.DENSITY
         lp, ln = synth.make_object(o["kind"], seed * 7919 + k, density=dens)
-        plc.append(dict(cloud=capi.Cloud(lp, ln, cell_size=cell if cell != 0 else -1.0), np=(lp, ln),
-                        pose=synth.perturbed_pose(o["pose"], rng, 0.01, 0.005), cls=o["class_idx"]))
+        plc.append(dict(np=(lp, ln), pose=synth.perturbed_pose(o["pose"], rng, 0.01, 0.005), cls=o["class_idx"]))
+    w["icp_T0s"] = [w["icp_T0"]]
+    for u in range(1, units):
+        rng_u = np.random.default_rng(seed + 5 + 1000 * u)
+        w["icp_T0s"].append(synth.perturbed_pose(I4, rng_u, 0.01, 0.01))
+        w["score_poses"] = np.concatenate([w["score_poses"], np.stack([synth.perturbed_pose(tbl["pose"], rng_u, 0.6, 0.25) for _ in range(N_POSES)])])
+        for k in range(N_PLACEMENTS):
+            plc.append(dict(np=plc[k]["np"], same_as=k, pose=synth.perturbed_pose(s1["objects"][k]["pose"], rng_u, 0.01, 0.005), cls=plc[k]["cls"]))
+    w["icp_T0s"] = np.stack(w["icp_T0s"])
     w["plc"] = plc
     w["plc_poses"] = np.stack([p["pose"] for p in plc])
+    w["units"] = units
     w["n_scan0"], w["n_scan1"], w["n_obj"] = len(s0["points"]), len(s1["points"]), len(op)
-    w["pairs"] = dict(icp=ICP_ITERS * w["n_scan1"], score=N_POSES * w["n_obj"], label=len(plc) * w["n_scan1"])
+    w["pairs"] = dict(icp=ICP_ITERS * w["n_scan1"], score=N_POSES * w["n_obj"], label=N_PLACEMENTS * w["n_scan1"])   # per unit
+    return w
+
+
+def build_workload(n_points, seed, knn, units=1):
+    """build_inputs + the device-resident clouds (inputs are in HBM before the timed region starts)."""
+    from rescan_amd import capi
+    w = build_inputs(n_points, seed, units)
+    cell = float(os.environ.get("RS_BENCH_CELL", "-1")) if knn == "hash" else 0.0
+    s0, s1 = w["s0"], w["s1"]
+    w["scan0"] = capi.Cloud(s0["points"], s0["normals"], cell_size=cell)      # ICP target
+    w["scan1"] = capi.Cloud(s1["points"], s1["normals"], cell_size=cell)      # ICP source, score + label scene
+    op, on = w["obj_score_np"]
+    w["obj_score"] = capi.Cloud(op, on, cell_size=cell if cell != 0 else -1.0)
+    for p in w["plc"]:
+        p["cloud"] = w["plc"][p["same_as"]]["cloud"] if "same_as" in p else capi.Cloud(p["np"][0], p["np"][1], cell_size=cell if cell != 0 else -1.0)
     return w
 
 
 _POOL = None
 
 
+def _pool():
+    global _POOL
+    if _POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(max_workers=3)
+    return _POOL
+
+
 def run_step(w, dist_ctx=None, concurrent=True):
-    """One pass of the hot path.  Returns the outputs (poses, scores, labels).
+    """One pass of the hot path (single GPU, or one replica of --replicas).  Returns the outputs (poses, scores, labels).
 
     The three consumers are independent (in the reference they even run in different processes),
     so they are issued from three host threads; the library gives every thread its own HIP stream
     and workspaces, and the GPU overlaps the ICP chain with the score batch and the label pass."""
     from rescan_amd import capi
-    global _POOL
 
     def icp():
         return capi.icp_align(w["scan1"], w["scan0"], w["icp_T0"], I4, 0.10, np.deg2rad(60.0),
@@ -95,10 +131,7 @@ def run_step(w, dist_ctx=None, concurrent=True):
                                           [0] * len(w["plc"]), [p["cls"] for p in w["plc"]], 0.05, False)
 
     if concurrent:
-        if _POOL is None:
-            from concurrent.futures import ThreadPoolExecutor
-            _POOL = ThreadPoolExecutor(max_workers=3)
-        f = [_POOL.submit(fn) for fn in (icp, score, label)]
+        f = [_pool().submit(fn) for fn in (icp, score, label)]
         (err, T, it), scores, res = f[0].result(), f[1].result(), f[2].result()
     else:
         (err, T, it), scores, res = icp(), score(), label()
@@ -107,7 +140,7 @@ def run_step(w, dist_ctx=None, concurrent=True):
         # step's kernels): one exchange in flight, the last one is waited for before the timed region closes (exchange_wait).
         exchange_wait()
         _XCH["pending"] = _exchange_pool().submit(exchange_results, dist_ctx[0], dist_ctx[1], T, err, scores, res)
-    return err, T, scores, res
+    return dict(err=err, T=T, scores=scores, labels=res["labels"], min_dists=res["min_dists"])
 
 
 def _exchange_pool():
@@ -126,11 +159,8 @@ _XCH = {}
 
 
 def exchange_results(dist, dev, T, err, scores, res):
-    """The exchange step of the multi-GPU path (north_star: 'RCCL all-gather of the resulting 4x4
-    poses / unary cost rows'): every rank receives every rank's pose + error + scores and label
-    partials (labels int8 + min_dists f32) in ONE all-gather per step — the payload (5 MB per rank at
-    1 M points) is far below what xGMI moves in a millisecond, so the step is bound by launches, not bytes
-    (SURVEY.md §8e).  Scene sizes differ slightly across ranks: the label arrays are padded to the common
+    """--replicas: every rank receives every rank's pose + error + scores and label partials (labels int8 + min_dists
+    f32) in ONE all-gather per step.  Scene sizes differ slightly across ranks: the label arrays are padded to the common
     maximum, agreed on once.  Packed per rank: int64 n | f32 pose, err, scores | f32 min_dists[nmax] |
     int8 labels[nmax].  Returns per-rank views (small, labels, min_dists) of the gathered buffer."""
     import torch
@@ -170,6 +200,83 @@ def exchange_results(dist, dev, T, err, scores, res):
         gm.append(b[o_mind:o_lab].view(torch.float32))
         gl.append(b[o_lab:o_lab + nmax].view(torch.int8))
     return out, gl, gm
+
+
+# ---- the sharded route (north_star / configs[3]) ----------------------------------------------------------------
+
+class Sharded:
+    """One scene, units sharded over the ranks, rows gathered on the device (rescan_amd/dist.py: shard_*).
+    Two send / receive buffer sets: the exchange of step s (copy of the small results, all-gather, fold, download of the
+    folded labels) runs on its own host thread while step s + 1 computes into the other set."""
+
+    def __init__(self, w, dist, dev, rank, world):
+        import torch
+        from rescan_amd import dist as rd
+        self.w, self.dist, self.dev, self.rank, self.world = w, dist, dev, rank, world
+        n_plc = len(w["plc"])
+        self.lay = rd.ShardLayout(world, len(w["icp_T0s"]), len(w["score_poses"]), n_plc, w["n_scan1"])
+        order, _, radii = rd.arrangement_plan([0] * n_plc, [p["cls"] for p in w["plc"]], 0.05)
+        self.order = order
+        self.units = dict(
+            icp=(w["scan1"], w["scan0"], w["icp_T0s"], 0.10, np.deg2rad(60.0), ICP_ITERS),
+            score=(w["obj_score"], w["scan1"], w["score_poses"], 0.1, 64),
+            label=(w["scan1"], w["plc_poses"][order], [w["plc"][i]["cloud"] for i in order], radii))
+        self.bufs = []
+        for _ in range(2):
+            send = torch.zeros(self.lay.words, dtype=torch.float32, device=dev)
+            recv = send if world == 1 and dist is None else torch.zeros(world * self.lay.words, dtype=torch.float32, device=dev)
+            small = torch.zeros(self.lay.small_words, dtype=torch.float32).pin_memory()
+            self.bufs.append((send, recv, small))
+        self.step_index = 0
+        self.t_gather = self.t_fold = 0.0; self.n_exchanges = 0      # host-side durations of the exchange thread's two halves
+
+    def exchange(self, b):
+        import torch
+        from rescan_amd import capi, dist as rd
+        torch.cuda.set_device(self.dev)                # (exchange thread)
+        send, recv, small = b
+        t0 = time.perf_counter()
+        rd.shard_publish(self.lay, send, small)
+        if self.dist is not None:
+            self.dist.all_gather_into_tensor(recv, send)
+        torch.cuda.current_stream().synchronize()
+        t1 = time.perf_counter()
+        out = rd.shard_fold(capi, self.lay, recv)
+        self.t_gather += t1 - t0; self.t_fold += time.perf_counter() - t1; self.n_exchanges += 1
+        return out
+
+    def step(self, concurrent=True):
+        from rescan_amd import capi, dist as rd
+        b = self.bufs[self.step_index & 1]
+        self.step_index += 1
+        rd.shard_compute(capi, self.lay, self.rank, self.units, b[0], b[2], threads=_pool() if concurrent else None)
+        prev = exchange_wait()                          # at most one exchange in flight, so the other buffer set is free again
+        _XCH["pending"] = _exchange_pool().submit(self.exchange, b)
+        return prev
+
+
+def parity_block(out, n_points, seed, knn, units):
+    """Distance of the LAST step's outputs from tests/golden/bench_seed11.npz — what the compiled reference computes for
+    the same inputs (oracle/gen_golden_bench.py: pose / error after the 10 fixed iterations composed from the reference's
+    icp_find_corrs + icp_estimate_rigid_xform_pt2pl, the 256 scores of mgs_compute_object_alignment_score; labels by the
+    C restatement, the reference's label TU needs gco).  Computed outside the timed region."""
+    import hashlib
+    path = os.path.join(ROOT, "tests", "golden", "bench_seed11.npz")
+    if not os.path.exists(path) or n_points != 1_000_000 or seed != 11:
+        return None
+    g = np.load(path)
+    blk = {"fixture": "tests/golden/bench_seed11.npz", "knn": knn}
+    blk["pose_dist"] = float(np.linalg.norm(np.asarray(out["T"], np.float64).ravel() - g["icp_pose"].astype(np.float64)))
+    blk["err_abs_diff"] = float(abs(float(out["err"]) - float(g["icp_err"])))
+    sc = np.asarray(out["scores"], np.float64)[:N_POSES]
+    blk["score_max_abs_err"] = float(np.abs(sc - g["scores"].astype(np.float64)).max())
+    if units == 1:
+        blk["label_mismatches"] = int((out["labels"] != g["labels"]).sum())
+        blk["min_dists_identical"] = bool(hashlib.sha256(np.ascontiguousarray(out["min_dists"], np.float32).tobytes()).hexdigest() == str(g["min_dists_sha"]))
+    else:
+        blk["labels"] = "not compared: %d placements instead of the fixture's %d" % (units * N_PLACEMENTS, N_PLACEMENTS)
+    blk["tolerance"] = {"pose_dist": 1e-4, "score_max_abs_err": 2e-6, "label_mismatches": 0}
+    return blk
 
 
 def cpu_baseline(w, budget_s=20.0):
@@ -253,6 +360,8 @@ def main():
                     help="candidate layout: LDS spatial-hash cells (default) or one brute tile")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial", action="store_true", help="issue the three consumers one after another")
+    ap.add_argument("--shard", action="store_true", help="the sharded route (default for --gpus > 1) also at N = 1")
+    ap.add_argument("--replicas", action="store_true", help="--gpus > 1: every rank its own scene (configs[4]) instead of one sharded scene")
     args = ap.parse_args()
 
     import torch
@@ -276,8 +385,12 @@ def main():
     from rescan_amd import capi
     capi.init(local_rank)
 
-    w = build_workload(args.points, seed=11 + rank, knn=args.knn)
+    sharded = args.shard or (world > 1 and not args.replicas)
+    seed = 11 if sharded else 11 + rank
+    units = world if sharded else 1
+    w = build_workload(args.points, seed=seed, knn=args.knn, units=units)
     dist_ctx = (dist, dev) if dist is not None else None
+    sh = Sharded(w, dist, dev, rank, world) if sharded else None
 
     def barrier():
         if dist is not None:
@@ -285,9 +398,26 @@ def main():
         torch.cuda.synchronize()
 
     conc = not args.serial
+    last = None
+
+    def one_step():
+        nonlocal last
+        if sh is not None:
+            r = sh.step(conc)
+            if r is not None:
+                last = r
+        else:
+            last = run_step(w, dist_ctx, conc)
+
+    def drain():
+        nonlocal last
+        r = exchange_wait()                         # the last step's exchange belongs to the timed region
+        if sh is not None and r is not None:
+            last = r
+
     for _ in range(args.warmup):
-        run_step(w, dist_ctx, conc)
-    exchange_wait()
+        one_step()
+    drain()
     capi.profile_enable(True)
     capi.profile_reset()
     import gc
@@ -296,9 +426,9 @@ def main():
     t0 = time.perf_counter()
     marks = []
     for _ in range(args.steps):
-        run_step(w, dist_ctx, conc)
+        one_step()
         marks.append(time.perf_counter())       # (a step ends with its results on the host: no extra synchronisation)
-    exchange_wait()                             # the last step's exchange belongs to the timed region
+    drain()
     barrier()
     elapsed = time.perf_counter() - t0
     gc.enable()
@@ -307,18 +437,19 @@ def main():
         print("slow steps (index, ms):", [(int(k), round(float(v), 2)) for k, v in enumerate(step_ms) if v > 1.3 * np.median(step_ms)], file=sys.stderr)
     capi.profile_enable(False)
 
-    pairs_rank = sum(w["pairs"].values()) * args.steps
+    pairs_unit = sum(w["pairs"].values())
+    pairs_total = float(pairs_unit * args.steps * (world if not sharded else units))
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        p = torch.tensor([pairs_rank], device=dev, dtype=torch.float64)
-        dist.all_reduce(p, op=dist.ReduceOp.SUM)
-        pairs_total = float(p.item())
-    else:
-        pairs_total = float(pairs_rank)
 
     if rank == 0:
+        if sh is not None:
+            errs, Ts, its, scores, labels, mind = last
+            out = dict(err=errs[0], T=Ts[0], scores=scores, labels=labels, min_dists=mind)
+        else:
+            out = last
         # dominant kernel: the ICP correspondence search (k_icp_corr)
         prof = {k: capi.profile_read(k) for k in ("nn_icp", "icp_moments", "nn_score", "nn_label")}
         per_step = {k: v[1] / max(1, v[0]) * (ICP_ITERS if k in ("nn_icp", "icp_moments") else 1) for k, v in prof.items()}
@@ -330,34 +461,39 @@ def main():
         elif dom == "nn_score":
             bytes_launch = N_POSES * w["n_obj"] * 40 + w["n_scan1"] * 16
         elif dom == "nn_label":
-            bytes_launch = len(w["plc"]) * w["n_scan1"] * 46 + sum(len(p["np"][0]) for p in w["plc"]) * 16
+            bytes_launch = N_PLACEMENTS * w["n_scan1"] * 46 + sum(len(p["np"][0]) for p in w["plc"][:N_PLACEMENTS]) * 16
         else:
             bytes_launch = w["n_scan1"] * 56
         avg_s = (ms / max(1, n_l)) * 1e-3
         achieved = bytes_launch / avg_s / 1e9 if avg_s > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(dom)
-            except Exception:
-                traffic = None
+        traffic, traffic_note = read_traffic(dom)
+        if sharded:
+            wl = ("configs[3]: ONE scene (~1M-pt scans) replicated per rank, units sharded over the ranks: %d x {ICP-NN 10 it x scan->scan, "
+                  "score-NN 256 poses x 10k, label-NN 8 placements}; per-placement rows all-gathered on the device, ordered fold" % units)
+        else:
+            wl = ("configs[1]: single scene, 2 timesteps, ~1M-pt scans on 1xMI355X per rank: "
+                  "ICP-NN 10 it x scan->scan + score-NN 256 poses x 10k + label-NN 8 placements")
         line = {
             "metric": "point-pairs/sec (ICP-NN + score-NN + segment-NN) per scene",
             "value": pairs_total / elapsed, "unit": "point-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: single scene, 2 timesteps, ~1M-pt scans on 1xMI355X per rank: "
-                                   "ICP-NN 10 it x scan->scan + score-NN 256 poses x 10k + label-NN 8 placements",
+            "config": {"workload": wl,
                        "knn": "lds-hash-cells" if args.knn == "hash" else "brute-tile",
+                       "route": "sharded" if sharded else ("replicas" if world > 1 else "single"),
                        "n_scan0": w["n_scan0"], "n_scan1": w["n_scan1"], "n_obj": w["n_obj"],
-                       "pairs_per_step": sum(w["pairs"].values()), "pairs_split": w["pairs"],
+                       "pairs_per_step": pairs_unit * (units if sharded else world), "pairs_split_per_unit": w["pairs"],
                        "issue": "3 host threads / 3 HIP streams (ICP chain | score batch | label pass)" if conc else "serial",
-                       "exchange": "one fused all_gather(poses, scores, label partials) per step, overlapped with the next step" if dist is not None else "none"},
+                       "exchange": ("one all_gather of the per-rank send buffers (poses, errors, scores, per-placement rows: %.1f MB per rank) per step, "
+                                    "overlapped with the next step; ordered fold of the rows on the device; on the exchange thread: publish + all_gather %.3f ms, "
+                                    "fold + download of poses / scores / labels %.3f ms per step"
+                                    % (sh.lay.words * 4 / 1e6, sh.t_gather / max(1, sh.n_exchanges) * 1e3, sh.t_fold / max(1, sh.n_exchanges) * 1e3)) if sharded
+                                   else ("one fused all_gather(poses, scores, label partials) per step, overlapped with the next step" if dist is not None else "none")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                          "avg_launch_ms": ms / max(1, n_l), "launches": n_l, "alg_bytes_per_launch": bytes_launch},
+            "parity": parity_block(out, args.points, seed, args.knn, units),
             "ms_per_step_spread": {"min": float(step_ms.min()), "median": float(np.median(step_ms)), "max": float(step_ms.max())},
             # per-launch averages x launches per step (the ICP loop's events are sampled: one call in RS_HIP_PROF_EVERY)
             "kernel_ms_per_step": per_step,
@@ -368,7 +504,7 @@ def main():
         cand = capi.profile_read("candidates")[0]
         line["candidate_evals"] = {"per_step": cand * 64 / args.steps, "per_s": cand * 64 / elapsed,
                                    "candidates_staged_per_step": cand / args.steps,
-                                   "per_point_pair": cand * 64 / args.steps / max(1, sum(w["pairs"].values()))}
+                                   "per_point_pair": cand * 64 / args.steps / max(1, pairs_unit)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 cb = cpu_baseline(w)
@@ -384,6 +520,24 @@ def main():
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def read_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the PMC passes (tools/profile.sh traffic -> profiles/pmc_traffic.json).
+    Counters cannot be collected inside this process (rocprofv3 wraps the command), so the file is a separate run of the
+    same command; it is REFUSED when it is older than the library it claims to describe."""
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(tpath):
+        return None, "no profiles/pmc_traffic.json"
+    try:
+        t = json.load(open(tpath))
+    except Exception as e:
+        return None, f"unreadable: {e}"
+    from rescan_amd.build import sources_sha
+    want = sources_sha()
+    if t.get("kernels_sha") != want:
+        return None, "profiles/pmc_traffic.json was collected for other kernel sources (kernels_sha %s, now %s): stale, not reported" % (t.get("kernels_sha"), want)
+    return t.get(kernel), "profiles/pmc_traffic.json (tools/profile.sh traffic, same kernel sources: %s)" % want
 
 
 if __name__ == "__main__":

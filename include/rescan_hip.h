@@ -155,6 +155,15 @@ int rs_hip_label_rows( const rs_hip_cloud_t* scene, const rs_hip_placement_t* pl
 void rs_hip_combine_label_rows( const float* rows, int32_t n_rows, int64_t scene_n, int32_t label_base,
                                 int8_t* labels, float* min_dists );
 
+/* The same ordered arg-min over rows that already sit in DEVICE memory — the gathered send buffers of the multi-GPU
+ * route (placements sharded across GPUs, rows all-gathered over RCCL, then folded in the sorted order of
+ * rs_pointcloud_filters.cpp:823-848).  Row k starts at rows_device + row_offsets[k] (in floats; row_offsets is a host
+ * array, so rows of different ranks may sit anywhere in one gathered buffer) and holds scene_n floats.  labels / min_dists
+ * are host arrays: continued from the caller's values like rs_hip_assign_labels, or — fresh != 0 — started on the device
+ * from the loop's initial state (label 0, min_dist 1e9: rs_pointcloud_filters.cpp:799-802,820) without an upload. */
+int rs_hip_fold_label_rows_device( const float* rows_device, const int64_t* row_offsets, int32_t n_rows, int64_t scene_n,
+                                   int32_t label_base, int8_t* labels, float* min_dists, int32_t fresh );
+
 /* rspf_arrangement_to_labels ordering + two passes (lib/rs/rs_pointcloud_filters.cpp:780-848):
  * sorts placement indices (dynamic first, then by class index; stable), runs the dynamic
  * pass with `radius` and the static pass with 1.5*radius (or resets min_dists when

@@ -1,0 +1,120 @@
+"""TEST INFRASTRUCTURE.  Pins the HEADLINE workload (bench.py, BASELINE.json configs[1]) and a sweep of scan-sized
+ICP runs against oracle/_ref — the real reference compiled in place from /root/reference.  Run in the build
+container only; the fixtures are committed so the GPU box, which has no /root/reference, can check against them.
+
+  tests/golden/bench_seed11.npz   for bench.build_inputs(1_000_000, seed=11):
+        icp_pose / icp_err / icp_n_corrs[10] / icp_errs[10]   10 FIXED iterations composed from the reference's own
+              icp_find_corrs + icp_estimate_rigid_xform_pt2pl (lib/rs/icp.h:306-412,210-298) with the loop of
+              icp_align (:433-497, radius schedule :493) minus the stop test (oracle/ref_driver.cpp: ref_icp_iterate)
+        scores[256]                mgs_compute_object_alignment_score (apps/pose_proposal/pose_proposal.cpp:93-158), K = 64
+        labels / min_dists digest  rspf_arrangement_to_labels by the C RESTATEMENT (oracle/rs_oracle.c) — the reference TU
+              needs the un-vendored gco header, SURVEY.md §8c — labels int8[n] stored whole, min_dists as a sha256 +
+              a strided sample
+        input digests              sha256 of the generated inputs, so that a test on another machine notices if the
+              generator (numpy, rescan_amd/synth.py) no longer produces the arrays the fixture was made for
+
+  tests/golden/icp_sweep.npz      24 scan-to-scan icp_align runs (seeds 1..24) on >= 100 k-point scans, the
+        reference's own icp_align (stop test included): final pose, error; iteration counts from ref_icp_iterate
+        with the stop test on (same loop; asserted to end at the same pose bit for bit)
+
+Usage:  python oracle/gen_golden_bench.py [--bench-only | --sweep-only]
+"""
+import ctypes as C
+import hashlib
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle.pyoracle import Oracle, Ref, build, f32p, i32p  # noqa: E402
+from rescan_amd import synth  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+I4 = np.eye(4, dtype=np.float32).ravel()
+SWEEP_SEEDS = list(range(1, 25))
+SWEEP_POINTS = 120_000
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def ref_iterate(R, p1, n1, p2, n2, T0, T2, max_dist, max_angle, n_iters, stop_test):
+    f = R.lib.ref_icp_iterate
+    f.restype = C.c_int32
+    f.argtypes = [f32p, f32p, C.c_int32, f32p, f32p, C.c_int32, f32p, f32p, C.c_float, C.c_float, C.c_int32, C.c_int32,
+                  i32p, f32p, C.POINTER(C.c_float)]
+    T = np.ascontiguousarray(T0, np.float32).ravel().copy()
+    nc = np.zeros(n_iters, np.int32); errs = np.zeros(n_iters, np.float32); err = C.c_float()
+    done = f(p1, n1, len(p1), p2, n2, len(p2), T, np.ascontiguousarray(T2, np.float32).ravel(), float(max_dist), float(max_angle),
+             int(n_iters), int(stop_test), nc, errs, C.byref(err))
+    return T, np.float32(err.value), done, nc, errs
+
+
+def sweep_inputs(seed):
+    """Scan-to-scan case `seed` of the sweep: two timesteps of one room of ~SWEEP_POINTS points, a start pose and the
+    icp_align parameters of the reference's three call sites in turn."""
+    rng = np.random.default_rng(1000 + seed)
+    s0 = synth.scene_for_point_count(int(SWEEP_POINTS * 0.84), seed=seed, timestep=0)
+    s1 = synth.scene_for_point_count(int(SWEEP_POINTS * 0.84), seed=seed, timestep=1)
+    max_dist, max_angle = [(0.10, 60.0), (0.075, 50.0), (0.05, 10.0)][seed % 3]
+    T0 = synth.perturbed_pose(I4, rng, [0.005, 0.02, 0.05][(seed // 3) % 3], [0.005, 0.02, 0.04][(seed // 9) % 3])
+    return s0, s1, T0, np.float32(max_dist), np.float32(np.deg2rad(max_angle))
+
+
+def gen_bench(R, O):
+    import bench
+    t = time.time()
+    w = bench.build_inputs(1_000_000, seed=11)
+    s0, s1 = w["s0"], w["s1"]
+    print(f"inputs: {w['n_scan0']} / {w['n_scan1']} scan points, {w['n_obj']} object points ({time.time()-t:.1f} s)", flush=True)
+    t = time.time()
+    T, err, done, nc, errs = ref_iterate(R, s1["points"], s1["normals"], s0["points"], s0["normals"], w["icp_T0"], I4,
+                                         0.10, np.float32(np.deg2rad(60.0)), bench.ICP_ITERS, 0)
+    print(f"icp: {done} iterations, err {err}, n_corrs {nc.tolist()} ({time.time()-t:.1f} s)", flush=True)
+    assert done == bench.ICP_ITERS
+    t = time.time()
+    op, on = w["obj_score_np"]
+    scores = R.alignment_scores(s1["points"], s1["normals"], op, on, w["score_poses"], 64)
+    print(f"scores: mean {scores.mean():.4f} ({time.time()-t:.1f} s)", flush=True)
+    t = time.time()
+    objs = [dict(pos=p["np"][0], nor=p["np"][1], class_idx=p["cls"], is_static=0) for p in w["plc"]]
+    plcs = [dict(pose=p["pose"], object_idx=k, uidx=k) for k, p in enumerate(w["plc"])]
+    lab = O.arrangement_to_labels(s1["points"], s1["normals"], objs, plcs, 0.05, 0, 0)
+    print(f"labels: {int((lab['labels'] > 0).sum())} labelled ({time.time()-t:.1f} s)", flush=True)
+    np.savez_compressed(
+        os.path.join(OUT, "bench_seed11.npz"),
+        n_points=1_000_000, seed=11, n_scan0=w["n_scan0"], n_scan1=w["n_scan1"], n_obj=w["n_obj"],
+        in_sha=np.array([sha(s0["points"]), sha(s0["normals"]), sha(s1["points"]), sha(s1["normals"]), sha(op), sha(on),
+                         sha(w["score_poses"]), sha(w["plc_poses"]), sha(w["icp_T0"])]),
+        icp_T0=w["icp_T0"], icp_pose=T, icp_err=err, icp_n_corrs=nc, icp_errs=errs,
+        scores=scores, labels=lab["labels"], order=lab["order"],
+        min_dists_sha=sha(lab["min_dists"]), min_dists_sample=lab["min_dists"][::257].copy())
+
+
+def gen_sweep(R):
+    poses, errs, iters, T0s, params, sizes, digests = [], [], [], [], [], [], []
+    for seed in SWEEP_SEEDS:
+        t = time.time()
+        s0, s1, T0, md, ma = sweep_inputs(seed)
+        e, T, _ = R.icp_align(s1["points"], s1["normals"], s0["points"], s0["normals"], T0, I4, md, ma)
+        T2, e2, done, _, _ = ref_iterate(R, s1["points"], s1["normals"], s0["points"], s0["normals"], T0, I4, md, ma, 100, 1)
+        assert (T2 == T).all() and np.float32(e) == e2, "ref_icp_iterate (stop test on) must BE icp_align"
+        poses.append(T); errs.append(np.float32(e)); iters.append(done); T0s.append(T0); params.append([md, ma])
+        sizes.append([len(s1["points"]), len(s0["points"])]); digests.append(sha(s1["points"]) + sha(s0["points"]))
+        print(f"sweep seed {seed:2d}: n {len(s1['points'])} r {md:.3f} iters {done} err {e:.6f} ({time.time()-t:.1f} s)", flush=True)
+    np.savez_compressed(os.path.join(OUT, "icp_sweep.npz"), seeds=np.array(SWEEP_SEEDS), n_points=SWEEP_POINTS,
+                        pose=np.stack(poses), err=np.array(errs, np.float32), iters=np.array(iters, np.int32),
+                        T0=np.stack(T0s), params=np.array(params, np.float32), sizes=np.array(sizes), in_sha=np.array(digests))
+
+
+if __name__ == "__main__":
+    build(ref=True)
+    R, O = Ref(), Oracle()
+    if "--sweep-only" not in sys.argv:
+        gen_bench(R, O)
+    if "--bench-only" not in sys.argv:
+        gen_sweep(R)

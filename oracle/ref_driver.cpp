@@ -180,6 +180,50 @@ int32_t ref_icp_find_corrs_grid( void* index2, float* pts1, float* nor1, int32_t
   return nc;
 }
 
+// The body of icp_align's loop (lib/rs/icp.h:433-497) composed from the reference's own icp_find_corrs and
+// icp_estimate_rigid_xform_pt2pl, with the stop test at :489 switchable: bench.py runs a FIXED number of iterations
+// ("10 fixed iterations with the reference's radius schedule"), which icp_align itself cannot be
+// asked for.  Grids are built once with the initial max_dist (:436-437), the radius follows :493.  n_corrs / errs
+// (capacity n_iters, may be NULL) receive the per-iteration correspondence counts and errors; returns the number
+// of iterations that reached the estimator.
+int32_t ref_icp_iterate( float* pts1, float* nor1, int32_t n1, float* pts2, float* nor2, int32_t n2,
+                         float* T1, const float* T2, float max_dist, float max_angle, int32_t n_iters, int32_t stop_test,
+                         int32_t* n_corrs_out, float* errs_out, float* err_out )
+{
+  msh_mat4_t t1, t2; memcpy( t1.data, T1, 64 ); memcpy( t2.data, T2, 64 );
+  msh_vec3_t *cp1 = NULL, *cn1 = NULL, *cp2 = NULL, *cn2 = NULL; float* cw = NULL; int32_t nc = 0;
+  msh_hash_grid_t index1 = {0}; msh_hash_grid_t index2 = {0};
+  msh_hash_grid_init_3d( &index1, pts1, n1, max_dist );                                   // :436-437
+  msh_hash_grid_init_3d( &index2, pts2, n2, max_dist );
+  float prev_err = 1e6, err = 1e6;                                                         // :441-442
+  int32_t done = 0;
+  for( int i = 0; i < n_iters; ++i )
+  {
+    prev_err = err;
+    icp_find_corrs( (msh_vec3_t*)pts1, (msh_vec3_t*)nor1, n1, &index1, (msh_vec3_t*)pts2, (msh_vec3_t*)nor2, n2, &index2,
+                    t1, t2, &cp1, &cn1, &cp2, &cn2, &cw, &nc, max_dist, max_angle );     // :449-451
+    if( n_corrs_out ) n_corrs_out[i] = nc;
+    if( nc == 0 ) break;                                                                   // :455-459
+    float total_weight = 0.0;
+    for( int j = 0; j < nc; ++j ) total_weight += cw[j];                                   // :461-465
+    if( total_weight <= 1e-7 ) break;                                                      // :466-470
+    err = icp_estimate_rigid_xform_pt2pl( cp1, cp2, cn2, cw, nc, &t1 );                    // :477-478
+    if( errs_out ) errs_out[i] = err;
+    done = i + 1;
+    float delta = fabsf( prev_err - err );
+    if( stop_test && i > 5 && delta < 1e-5 ) break;                                        // :489
+    max_dist = msh_max( max_dist * 0.95, 0.05 );                                           // :493
+  }
+  free( cp1 ); free( cp2 ); free( cn2 ); free( cw );       // (corr_nor1 is the array the reference itself never frees, :319)
+  free( cn1 );
+  if( index1.bin_table ) msh_hg_map_free( index1.bin_table );
+  if( index2.bin_table ) msh_hg_map_free( index2.bin_table );
+  msh_hash_grid_term( &index1 ); msh_hash_grid_term( &index2 );
+  memcpy( T1, t1.data, 64 );
+  if( err_out ) *err_out = err;
+  return done;
+}
+
 float ref_icp_estimate_pt2pl( float* p1, float* p2, float* n2, float* w, int32_t n, float* T1 )
 {
   msh_mat4_t t1; memcpy( t1.data, T1, 64 );

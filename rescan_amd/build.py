@@ -16,6 +16,16 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fn
          "-Wall", "-Wno-unused-function"]
 
 
+def sources_sha():
+    """Short digest of the device/host sources the library is built from: profiles that describe kernels carry it, and
+    bench.py refuses a PMC traffic file made for other sources."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SOURCES + [x for x in HEADERS if x.endswith(".h") and not x.startswith("..")]):
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _stale():
     if not os.path.exists(LIB) or not os.path.exists(DROPIN):
         return True

@@ -44,6 +44,8 @@ SIGNATURES = {
     "rs_hip_assign_labels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, i8p, f32p]),
     "rs_hip_label_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int]),
     "rs_hip_combine_label_rows": (None, [f32p, C.c_int32, C.c_int64, C.c_int32, i8p, f32p]),
+    "rs_hip_fold_label_rows_device": (C.c_int, [C.c_void_p, np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS"), C.c_int32,
+                                                C.c_int64, C.c_int32, i8p, f32p, C.c_int32]),
     "rs_hip_arrangement_to_labels": (C.c_int, [C.c_void_p, f32p, C.c_void_p, i32p, i32p, C.c_int32, C.c_float,
                                                C.c_int, i8p, f32p, i32p]),
     "rs_hip_compute_neighborhood": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float, i32p, i32p, f32p,
@@ -274,6 +276,18 @@ def label_rows(scene, poses, objects, radii, out_device_ptr=None):
 def combine_label_rows(rows, labels, min_dists, label_base=0):
     rows = _f32(rows)
     load().rs_hip_combine_label_rows(rows, rows.shape[0], rows.shape[1], int(label_base), labels, min_dists)
+    return labels, min_dists
+
+
+def fold_label_rows_device(rows_device_ptr, row_offsets, scene_n, labels=None, min_dists=None, label_base=0):
+    """Ordered arg-min over rows that sit in device memory (row k at rows_device_ptr + 4*row_offsets[k]).
+    Without labels / min_dists the fold starts from the loop's initial state (label 0, 1e9) on the device."""
+    off = np.ascontiguousarray(row_offsets, np.int64)
+    fresh = labels is None or min_dists is None
+    if fresh:
+        labels = np.empty(int(scene_n), np.int8); min_dists = np.empty(int(scene_n), np.float32)
+    _check(load().rs_hip_fold_label_rows_device(C.c_void_p(rows_device_ptr), off, len(off), int(scene_n), int(label_base),
+                                                labels, min_dists, 1 if fresh else 0))
     return labels, min_dists
 
 

@@ -98,7 +98,7 @@ struct Workspace
 {
   DevBuf state, slot, d2, dot, stat_acc, mom_part, res, wexp, queue, queue_count;   // ICP
   DevBuf poses, score_part, scores;                                             // score
-  DevBuf plc, labels, mind;                                                     // labels
+  DevBuf plc, labels, mind, fold_off;                                           // labels
   DevBuf q4, rd2, ridx, rnn, rows;                                              // rows / misc
   DevBuf enor, ecount, eoffset, e1, e2, ew;                                     // neighbourhood edges
   DevBuf cert_r, cert_dot, cert_slack;                                                    // ICP certificates
@@ -1104,6 +1104,29 @@ void rs_hip_combine_label_rows( const float* rows, int32_t n_rows, int64_t scene
     for( int64_t j = 0; j < scene_n; ++j )
       if( r[j] < min_dists[j] ) { min_dists[j] = r[j]; labels[j] = (int8_t)( label_base + k + 1 ); }   // rs_pointcloud_filters.cpp:763,772-773
   }
+}
+
+int rs_hip_fold_label_rows_device( const float* rows_device, const int64_t* row_offsets, int32_t n_rows, int64_t scene_n,
+                                   int32_t label_base, int8_t* labels, float* min_dists, int32_t fresh )
+{
+  int rc = ensure_ready(); if( rc ) return rc;
+  if( n_rows < 0 || scene_n < 0 || !labels || !min_dists || ( n_rows > 0 && ( !rows_device || !row_offsets ) ) ) { set_err( "fold_label_rows_device: bad arguments" ); return RS_HIP_E_ARG; }
+  if( label_base + n_rows > 127 ) { set_err( "fold_label_rows_device: more than 127 placements do not fit the reference's int8 labels" ); return RS_HIP_E_CAPACITY; }
+  if( n_rows == 0 || scene_n == 0 ) return RS_HIP_OK;
+  const size_t ns = (size_t)scene_n;
+  if( ( rc = g_ws.labels.ensure( ns ) ) || ( rc = g_ws.mind.ensure( ns * 4 ) ) || ( rc = g_ws.fold_off.ensure( (size_t)n_rows * 8 ) ) ) return rc;
+  if( !fresh )
+  {
+    HIP_TRY( hipMemcpyAsync( g_ws.labels.p, labels, ns, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+    HIP_TRY( hipMemcpyAsync( g_ws.mind.p, min_dists, ns * 4, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+  }
+  HIP_TRY( hipMemcpyAsync( g_ws.fold_off.p, row_offsets, (size_t)n_rows * 8, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+  { ProfScope ps( "label_fold" );
+    launch_label_fold( rows_device, g_ws.fold_off.as<long long>(), n_rows, (long long)scene_n, label_base, g_ws.labels.as<int8_t>(), g_ws.mind.as<float>(), fresh != 0, g_stream ); }
+  HIP_TRY( hipMemcpyAsync( labels, g_ws.labels.p, ns, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipMemcpyAsync( min_dists, g_ws.mind.p, ns * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
+  return RS_HIP_OK;
 }
 
 int rs_hip_arrangement_to_labels( const rs_hip_cloud_t* scene,

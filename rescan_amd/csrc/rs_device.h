@@ -142,6 +142,8 @@ struct LabelLaunch
   float*       rows;           // n_pl x ns rows (row mode) or null
 };
 void launch_label( const LabelLaunch& L, hipStream_t st );
+// ordered fold of device-resident rows (row k at rows + offsets[k], n floats each; offsets is a device array)
+void launch_label_fold( const float* rows, const long long* offsets, int n_rows, long long n, int label_base, int8_t* labels, float* min_d, bool fresh, hipStream_t st );
 
 struct RowsLaunch
 {

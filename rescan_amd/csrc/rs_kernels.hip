@@ -1835,6 +1835,28 @@ void launch_label( const LabelLaunch& L, hipStream_t st )
   hipLaunchKernelGGL( k_label, dim3( ( L.scene.n_tiles + WAVES_PER_BLOCK - 1 ) / WAVES_PER_BLOCK ), dim3( BLOCK ), 0, st, L );
 }
 
+// Ordered arg-min over per-placement rows that already sit in device memory (the gathered send buffers of the sharded
+// route): rows 0..n-1 applied in order with the strict `<` of rs_pointcloud_filters.cpp:763, so an earlier
+// placement wins a tie exactly as in the sequential loop.  Row k starts at rows + offsets[k] (floats).
+__global__ __launch_bounds__( BLOCK ) void k_label_fold( const float* rows, const long long* offsets, int n_rows, long long n, int label_base,
+                                                         int8_t* labels, float* min_d, bool fresh )
+{
+  const long long j = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if( j >= n ) return;
+  float best = 1e9f; int label = 0;                                            // :799-802,820
+  if( !fresh ) { best = min_d[j]; label = labels[j]; }
+  for( int k = 0; k < n_rows; ++k )
+  {
+    const float v = rows[offsets[k] + j];
+    if( v < best ) { best = v; label = label_base + k + 1; }                  // :763,772-773
+  }
+  min_d[j] = best; labels[j] = (int8_t)label;
+}
+void launch_label_fold( const float* rows, const long long* offsets, int n_rows, long long n, int label_base, int8_t* labels, float* min_d, bool fresh, hipStream_t st )
+{
+  hipLaunchKernelGGL( k_label_fold, dim3( (unsigned)( ( n + BLOCK - 1 ) / BLOCK ) ), dim3( BLOCK ), 0, st, rows, offsets, n_rows, n, label_base, labels, min_d, fresh );
+}
+
 // ------------------------------------------------------------------------------------------
 // Generic rows: the k nearest within the radius, ascending  (msh_hash_grid.h:1090-1259)
 // Compatibility path for callers that want the whole neighbour list.  Selection by

@@ -91,3 +91,102 @@ def sharded_scores(dist, rank, world, poses, run_scores, to_tensor):
     local = run_scores(poses[lo:hi]).reshape(-1, 1) if hi > lo else np.zeros((0, 1), np.float32)
     g = all_gather_ragged(dist, to_tensor(np.ascontiguousarray(local, np.float32)), counts)
     return g.cpu().numpy()[:, 0].copy()
+
+
+# ---------------------------------------------------------------------------------------------
+# The same split driven by the HIP path (bench.py --shard, tests/test_gpu_parity.py): one scene
+# replicated on every GPU, the units of the three consumers sharded, per-placement label rows
+# written by the kernel straight into the rank's send buffer, ONE all-gather, ordered fold.
+# ---------------------------------------------------------------------------------------------
+
+def arrangement_plan(is_static, class_idx, radius):
+    """The order and per-placement radii of rspf_arrangement_to_labels with prioritize_static = 0 (its only call
+    site, apps/segment_transfer/main.cpp:389): stable sort by (is_static << 10 | class_idx)
+    (lib/rs/rs_pointcloud_filters.cpp:724-736,823-827), first static entry or 0 (:830-835), radius for the
+    dynamic run and 1.5 x radius from the first static entry on (:837-848).  Folding the rows of the sorted
+    placements in order with strict `<` from (label 0, 1e9) is then exactly the two passes."""
+    key = [(int(s) << 10) | int(c) for s, c in zip(is_static, class_idx)]
+    order = sorted(range(len(key)), key=lambda i: key[i])          # Python's sort is stable
+    first_static = next((k for k, i in enumerate(order) if is_static[i]), 0)
+    radii = [np.float32(radius) if k < first_static else np.float32(1.5) * np.float32(radius) for k in range(len(order))]
+    return order, first_static, radii
+
+
+class ShardLayout:
+    """Where a rank's results sit in its send buffer (float32 words), identical on every rank:
+         [ icp: n_icp_max x 18 (pose 16, err, iterations) | scores: n_score_max | rows: n_plc_max x n_scene ]
+    n_*_max = the largest slice any rank owns, so the all-gather is one fixed-size collective."""
+
+    def __init__(self, world, n_icp, n_score, n_plc, n_scene):
+        self.world, self.n_icp, self.n_score, self.n_plc, self.n_scene = int(world), int(n_icp), int(n_score), int(n_plc), int(n_scene)
+        cap = lambda n: max(shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world))  # noqa: E731
+        self.icp_cap, self.score_cap, self.plc_cap = cap(n_icp), cap(n_score), cap(n_plc)
+        self.off_icp = 0
+        self.off_score = self.off_icp + 18 * self.icp_cap
+        self.off_rows = (self.off_score + self.score_cap + 63) // 64 * 64          # rows start 256-byte aligned
+        self.words = self.off_rows + self.plc_cap * self.n_scene
+        self.small_words = self.off_rows
+
+    def slices(self, rank):
+        return (shard_range(self.n_icp, rank, self.world), shard_range(self.n_score, rank, self.world),
+                shard_range(self.n_plc, rank, self.world))
+
+
+def shard_compute(capi, lay, rank, units, send, small_host, threads=None):
+    """This rank's share of one step, results into `send` (a float32 device tensor of lay.words):
+    units = dict(icp=(source, target, T0s, max_dist, max_angle, iters), score=(object, scene, poses, radius, K),
+                 label=(scene, poses_sorted, clouds_sorted, radii_sorted)).
+    The label kernel writes its rows into the send buffer itself (rs_hip_label_rows, rows_device = 1); poses / errors /
+    scores (a few KB) pass through `small_host` (pinned float32[lay.small_words]).  Returns nothing: call
+    shard_publish afterwards from the thread that owns torch's stream."""
+    (i0, i1), (s0, s1), (p0, p1) = lay.slices(rank)
+    src, tgt, T0s, max_dist, max_angle, iters = units["icp"]
+    obj, scn, poses, radius, K = units["score"]
+    lscene, lposes, lclouds, lradii = units["label"]
+    sh = small_host.numpy() if hasattr(small_host, "numpy") else small_host
+    sh[:] = 0.0
+
+    def icp():
+        if i1 > i0:
+            errs, Ts, its = capi.icp_align_batch(src, tgt, T0s[i0:i1], max_dist=max_dist, max_angle=max_angle, max_iter=iters, fixed_iters=True)
+            blk = sh[lay.off_icp: lay.off_icp + 18 * (i1 - i0)].reshape(-1, 18)
+            blk[:, :16] = Ts.reshape(-1, 16); blk[:, 16] = errs; blk[:, 17] = its
+
+    def score():
+        if s1 > s0:
+            sh[lay.off_score: lay.off_score + (s1 - s0)] = capi.alignment_scores(obj, scn, poses[s0:s1], radius, K)
+
+    def label():
+        if p1 > p0:
+            capi.label_rows(lscene, lposes[p0:p1], lclouds[p0:p1], lradii[p0:p1], out_device_ptr=send.data_ptr() + 4 * lay.off_rows)
+            capi.synchronize()            # the rows are complete before the collective (another stream) reads them
+
+    if threads is not None:
+        for f in [threads.submit(fn) for fn in (icp, score, label)]:
+            f.result()
+    else:
+        icp(); score(); label()
+
+
+def shard_publish(lay, send, small_host):
+    """Copies the small results next to the rows (torch's current stream)."""
+    import torch
+    t = small_host if isinstance(small_host, torch.Tensor) else torch.from_numpy(small_host)
+    send[: lay.small_words].copy_(t, non_blocking=True)
+
+
+def shard_fold(capi, lay, recv):
+    """recv = the all-gathered send buffers (float32 device tensor, lay.world x lay.words), complete (the caller has
+    waited for the collective).  Returns (errs, Ts, iters, scores, labels, min_dists) for ALL units, in unit order:
+    the small blocks are read back, the rows are folded on the device in the sorted placement order."""
+    W = lay.words
+    small = recv.view(lay.world, W)[:, : lay.small_words].cpu().numpy()
+    Ts, errs, its, scores, offsets = [], [], [], [], []
+    for r in range(lay.world):
+        (i0, i1), (s0, s1), (p0, p1) = lay.slices(r)
+        blk = small[r, lay.off_icp: lay.off_icp + 18 * (i1 - i0)].reshape(-1, 18)
+        Ts.append(blk[:, :16]); errs.append(blk[:, 16]); its.append(blk[:, 17].astype(np.int32))
+        scores.append(small[r, lay.off_score: lay.off_score + (s1 - s0)])
+        offsets += [r * W + lay.off_rows + k * lay.n_scene for k in range(p1 - p0)]
+    labels, mind = capi.fold_label_rows_device(recv.data_ptr(), offsets, lay.n_scene)   # from (0, 1e9): rs_pointcloud_filters.cpp:799-802,820
+    return (np.concatenate(errs), np.concatenate(Ts).copy(), np.concatenate(its), np.concatenate(scores), labels, mind)

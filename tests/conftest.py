@@ -15,6 +15,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _torch_owns_the_hip_runtime_first():
+    """On a GPU box torch must initialise HIP before librescan_hip.so does: torch ships its own copy of the HIP runtime,
+    and whichever copy is loaded second finds no device.  (bench.py has the same order.)  No-op without a GPU."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
+    yield
+
+
 def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, name)))
 

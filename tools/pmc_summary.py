@@ -22,6 +22,10 @@ if __name__ == "__main__":
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
             f = glob.glob(f"gpurun_out/pmc_{c}/*/*counter_collection.csv")[0]
             out[c] = {k: v[c] for k, v in per_kernel(f).items() if c in v}
+        import os
+        sys.path.insert(0, os.getcwd())
+        from rescan_amd.build import sources_sha
+        out["kernels_sha"] = sources_sha()          # the sources of the library these counters were collected with
         json.dump(out, open("gpurun_out/pmc_traffic_raw.json", "w"), indent=1)
         for k in sorted(out["FETCH_SIZE"]):
             print(k, "FETCH_SIZE avg KB", round(out["FETCH_SIZE"][k][0], 1),
@@ -43,6 +47,7 @@ if __name__ == "__main__":
                         "scratch (phase A and the score / label kernels: occupancy-6 register caps), not results."}
         for d, (names, per) in doms.items():
             out[d] = total(names) / F[per][1]
+        out["kernels_sha"] = raw.get("kernels_sha")
         out["raw_avg_KB"] = {c: {k: v[0] for k, v in raw[c].items()} for c in ("FETCH_SIZE", "WRITE_SIZE")}
         json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
         print({d: round(out[d] / 1e6, 1) for d in doms}, "MB per launch")
