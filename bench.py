@@ -226,22 +226,25 @@ class Sharded:
             send = torch.zeros(self.lay.words, dtype=torch.float32, device=dev)
             recv = send if world == 1 and dist is None else torch.zeros(world * self.lay.words, dtype=torch.float32, device=dev)
             small = torch.zeros(self.lay.small_words, dtype=torch.float32).pin_memory()
-            self.bufs.append((send, recv, small))
+            # the folded labels / min_dists land in caller-owned pinned arrays (the reference's callers own them too)
+            out = (torch.zeros(w["n_scan1"], dtype=torch.int8).pin_memory().numpy(), torch.zeros(w["n_scan1"], dtype=torch.float32).pin_memory().numpy())
+            self.bufs.append((send, recv, small, out))
         self.step_index = 0
+        self.t_compute = self.t_wait = 0.0
         self.t_gather = self.t_fold = 0.0; self.n_exchanges = 0      # host-side durations of the exchange thread's two halves
 
     def exchange(self, b):
         import torch
         from rescan_amd import capi, dist as rd
         torch.cuda.set_device(self.dev)                # (exchange thread)
-        send, recv, small = b
+        send, recv, small, outbuf = b
         t0 = time.perf_counter()
         rd.shard_publish(self.lay, send, small)
         if self.dist is not None:
             self.dist.all_gather_into_tensor(recv, send)
         torch.cuda.current_stream().synchronize()
         t1 = time.perf_counter()
-        out = rd.shard_fold(capi, self.lay, recv)
+        out = rd.shard_fold(capi, self.lay, recv, outbuf)
         self.t_gather += t1 - t0; self.t_fold += time.perf_counter() - t1; self.n_exchanges += 1
         return out
 
@@ -249,9 +252,12 @@ class Sharded:
         from rescan_amd import capi, dist as rd
         b = self.bufs[self.step_index & 1]
         self.step_index += 1
+        t0 = time.perf_counter()
         rd.shard_compute(capi, self.lay, self.rank, self.units, b[0], b[2], threads=_pool() if concurrent else None)
+        t1 = time.perf_counter()
         prev = exchange_wait()                          # at most one exchange in flight, so the other buffer set is free again
         _XCH["pending"] = _exchange_pool().submit(self.exchange, b)
+        self.t_compute += t1 - t0; self.t_wait += time.perf_counter() - t1
         return prev
 
 
@@ -363,6 +369,12 @@ def main():
     ap.add_argument("--shard", action="store_true", help="the sharded route (default for --gpus > 1) also at N = 1")
     ap.add_argument("--replicas", action="store_true", help="--gpus > 1: every rank its own scene (configs[4]) instead of one sharded scene")
     args = ap.parse_args()
+
+    # stdout carries the ONE JSON line and nothing else: whatever libraries print there (RCCL's version banner at the first
+    # collective) goes to stderr for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -487,8 +499,9 @@ def main():
                        "issue": "3 host threads / 3 HIP streams (ICP chain | score batch | label pass)" if conc else "serial",
                        "exchange": ("one all_gather of the per-rank send buffers (poses, errors, scores, per-placement rows: %.1f MB per rank) per step, "
                                     "overlapped with the next step; ordered fold of the rows on the device; on the exchange thread: publish + all_gather %.3f ms, "
-                                    "fold + download of poses / scores / labels %.3f ms per step"
-                                    % (sh.lay.words * 4 / 1e6, sh.t_gather / max(1, sh.n_exchanges) * 1e3, sh.t_fold / max(1, sh.n_exchanges) * 1e3)) if sharded
+                                    "fold + download of poses / scores / labels %.3f ms per step; main thread: compute %.3f ms, waiting for the previous exchange %.3f ms per step"
+                                    % (sh.lay.words * 4 / 1e6, sh.t_gather / max(1, sh.n_exchanges) * 1e3, sh.t_fold / max(1, sh.n_exchanges) * 1e3,
+                                       sh.t_compute / max(1, sh.step_index) * 1e3, sh.t_wait / max(1, sh.step_index) * 1e3)) if sharded
                                    else ("one fused all_gather(poses, scores, label partials) per step, overlapped with the next step" if dist is not None else "none")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
@@ -517,7 +530,8 @@ def main():
             except Exception as e:  # the baseline is reported, never required for the GPU number
                 line["cpu_baseline"] = {"value": None, "unit": "point-pairs/s", "cores": 0, "kind": "reference",
                                         "sample": f"unavailable: {e}"}
-        print(json.dumps(line))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 

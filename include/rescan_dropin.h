@@ -31,7 +31,7 @@ typedef struct rsd_hash_grid                                           /* == msh
   float  min_pt[3];
   float  max_pt[3];
   void*  bin_table;        /* unused by the shim (NULL) */
-  void*  data_buffer;      /* holds the rs_hip_cloud_t* of this grid */
+  void*  data_buffer;      /* holds the shim's handle of this grid (host copy of the points + lazily built device cloud) */
   void*  offsets;          /* unused by the shim (NULL) */
   int32_t  _slab_size;
   double   _inv_cell_size;
@@ -135,8 +135,13 @@ int rsd_rsdb_format_pose_line( char* out, size_t capacity, int32_t uidx, int32_t
 int rsd_rsdb_parse_pose_line( const char* line, int32_t* uidx, int32_t* arrangement_idx, int32_t* object_idx,
                               float* score, rsd_mat4_t* pose );
 
-/* Drop every cached device cloud (the shim caches uploads by host pointer + content hash). */
+/* The shim caches device uploads of host arrays by (pointers, count, sampled fingerprint) — SURVEY.md §8b's
+ * "(pointer, n, generation)" key.  msh_hash_grid_term() invalidates what was built from its grid's array (the reference
+ * terminates a level's grid right before it frees or rebuilds the level, lib/rs/rs_pointcloud.h:879-901);
+ * rsd_cache_invalidate does the same for an array the caller is about to free or edit in place; rsd_cache_clear drops
+ * everything.  RS_DROPIN_FULL_HASH=1 (environment) hashes whole arrays on every call instead of sampling them. */
 void  rsd_cache_clear( void );
+void  rsd_cache_invalidate( const void* host_array );
 
 #ifdef __cplusplus
 }

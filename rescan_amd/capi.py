@@ -279,12 +279,14 @@ def combine_label_rows(rows, labels, min_dists, label_base=0):
     return labels, min_dists
 
 
-def fold_label_rows_device(rows_device_ptr, row_offsets, scene_n, labels=None, min_dists=None, label_base=0):
+def fold_label_rows_device(rows_device_ptr, row_offsets, scene_n, labels=None, min_dists=None, label_base=0, fresh=None):
     """Ordered arg-min over rows that sit in device memory (row k at rows_device_ptr + 4*row_offsets[k]).
-    Without labels / min_dists the fold starts from the loop's initial state (label 0, 1e9) on the device."""
+    fresh (default: when no labels / min_dists are given): the fold starts from the loop's initial state (label 0, 1e9)
+    on the device; labels / min_dists, if given, only receive the result (e.g. pinned buffers that are reused)."""
     off = np.ascontiguousarray(row_offsets, np.int64)
-    fresh = labels is None or min_dists is None
-    if fresh:
+    if fresh is None:
+        fresh = labels is None or min_dists is None
+    if labels is None or min_dists is None:
         labels = np.empty(int(scene_n), np.int8); min_dists = np.empty(int(scene_n), np.float32)
     _check(load().rs_hip_fold_label_rows_device(C.c_void_p(rows_device_ptr), off, len(off), int(scene_n), int(label_base),
                                                 labels, min_dists, 1 if fresh else 0))

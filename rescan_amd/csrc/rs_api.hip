@@ -1173,9 +1173,38 @@ int rs_hip_radius_search( const rs_hip_cloud_t* target, const float* query, int6
   if( n_query == 0 ) return RS_HIP_OK;
   const int nq = (int)n_query;
   const GridView& g = target->view;
-  // order the queries along a Hilbert curve and tile them on the device, exactly like a cloud's query layout
   Workspace& W = g_ws;
   const size_t nn = (size_t)nq, nk = nn * k;
+  // Long rows, or few queries: one wave per query in the caller's order (k_rows_wave) — one launch between the upload and
+  // the download, which is what the reference's unchanged consumers need (mgs_compute_object_alignment_score calls this
+  // tens of thousands of times with a few hundred queries and K = 64, pose_proposal.cpp:115-124).  Short rows of many
+  // queries stay with the tiled successive-minima kernel below, whose cost grows with K but whose tiles share their sweeps.
+  const int wave_path_max_k = 1024;
+  const long long tiled_from = getenv( "RS_HIP_ROWS_TILED_FROM" ) ? atoll( getenv( "RS_HIP_ROWS_TILED_FROM" ) ) : 4096;      // (read per call: tests switch it)
+  if( k <= wave_path_max_k && ( k >= 16 || nq < tiled_from ) && !getenv( "RS_HIP_NO_ROWS_WAVE" ) )
+  {
+    if( ( rc = W.bld_pos.ensure( nn * 12 ) ) || ( rc = W.rd2.ensure( nk * 4 ) ) || ( rc = W.ridx.ensure( nk * 4 ) ) || ( rc = W.rnn.ensure( nn * 4 + 4 ) ) ||
+        ( rc = W.h_a.ensure( nn * 4 + 4 ) ) ) return rc;
+    int* d_nn = W.rnn.as<int>();                 // [nq] counts, [nq] overflow flag
+    HIP_TRY( hipMemcpyAsync( W.bld_pos.p, query, nn * 12, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+    HIP_TRY( hipMemsetAsync( d_nn + nq, 0, 4, g_stream ), RS_HIP_E_RUNTIME );
+    { ProfScope ps( "nn_rows" );
+      launch_rows_wave( g, W.bld_pos.as<float>(), nq, k, radius, radius_sq_of( radius ), W.rd2.as<float>(), W.ridx.as<int>(), d_nn, d_nn + nq, g_stream ); }
+    int* h_nn = W.h_a.as<int>();
+    HIP_TRY( hipMemcpyAsync( h_nn, d_nn, nn * 4 + 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+    HIP_TRY( hipMemcpyAsync( distances_sq, W.rd2.p, nk * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+    HIP_TRY( hipMemcpyAsync( indices, W.ridx.p, nk * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+    HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
+    if( !h_nn[nq] )
+    {
+      uint64_t tot = 0;
+      for( int i = 0; i < nq; ++i ) { tot += (uint64_t)h_nn[i]; if( n_neighbors ) n_neighbors[i] = (size_t)h_nn[i]; }
+      if( total ) *total = tot;
+      return RS_HIP_OK;
+    }
+    // some query has more than 1024 points within the radius: the storage-free kernel below takes the whole call
+  }
+  // order the queries along a Hilbert curve and tile them on the device, exactly like a cloud's query layout
   const size_t tmp_bytes = std::max( build_sort_temp_bytes( nq, 32 ), build_scan_temp_bytes( nn + 1 ) );
   if( ( rc = W.bld_pos.ensure( nn * 12 ) ) || ( rc = W.bld_k0.ensure( ( nn + 1 ) * 4 ) ) || ( rc = W.bld_k1.ensure( ( nn + 1 ) * 4 ) ) || ( rc = W.bld_v0.ensure( nn * 4 ) ) ||
       ( rc = W.bld_v1.ensure( nn * 4 ) ) || ( rc = W.bld_v2.ensure( nn * 4 ) ) || ( rc = W.bld_small.ensure( 64 ) ) || ( rc = W.bld_tmp.ensure( tmp_bytes + 256 ) ) ||

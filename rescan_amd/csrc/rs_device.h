@@ -156,6 +156,10 @@ struct RowsLaunch
   int*         nn;         // nq
 };
 void launch_rows( const RowsLaunch& L, hipStream_t st );
+// one wave per query, queries in the caller's order (AoS xyz on the device); *overflow is set (and nn = -1 written) for a
+// query with more than 1024 points within the radius
+void launch_rows_wave( const GridView& g, const float* q3, int nq, int K, float radius, float radius_sq,
+                       float* out_d2, int* out_idx, int* out_nn, int* overflow, hipStream_t st );
 
 // Scene-coverage term of the arrangement optimiser (apps/segment_transfer/arrangement_optimization.cpp:344-373,
 // 1064-1106 on the voxel grid of lib/rs/intersect.h:59-109): bitmaps instead of byte grids.

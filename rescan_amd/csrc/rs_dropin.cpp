@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <list>
 #include <mutex>
 #include <vector>
@@ -32,22 +33,32 @@ void complain( const char* where )
 }
 
 // ---- device-cloud cache ------------------------------------------------------------------
-// The reference hands the same host arrays to the hot path over and over (the scene level for
-// every proposal, apps/pose_proposal/main.cpp:190-202).  Uploads are cached by
-// (pointers, count, cell size, content hash) and evicted least-recently-used.
+// The reference hands the same host arrays to the hot path over and over (the scene level for every proposal,
+// apps/pose_proposal/main.cpp:190-202; every placement's level-2 cloud, lib/rs/rs_database.h:220-230).  Uploads are
+// cached by (pointers, count, cell size, fingerprint) — SURVEY.md §8b's "(pointer, n, generation)" — and evicted
+// least-recently-used.  The fingerprint is a SAMPLE of the arrays (first and last 64 bytes plus 62 blocks spread over
+// the rest: ~1 KB read per array, whatever its size), enough to notice an array that was freed and re-used, rebuilt or
+// transformed; the full content hash the shim started with cost 2.3 ms per 57 MB on every call, i.e. tens of seconds
+// over the ~35 k score calls of one pose_proposal run.  What a sample cannot see — a caller editing a few points in
+// place — is covered by explicit invalidation: msh_hash_grid_term() drops every entry built from the array its grid was
+// built on (the reference terminates a level's grid right before it frees or rebuilds the level's arrays,
+// lib/rs/rs_pointcloud.h:879-901), rsd_cache_invalidate( ptr ) does the same for a caller's own arrays, rsd_cache_clear()
+// for everything; RS_DROPIN_FULL_HASH=1 brings the full hash back.
 struct Entry
 {
-  const void* pos; const void* nor; int32_t n; float cell; uint64_t hash;
+  const void* pos; const void* nor; int32_t n; float cell; uint64_t hash; uint64_t generation;
   rs_hip_cloud_t* cloud;
 };
 std::list<Entry> g_cache;
 std::mutex g_cache_mutex;
+uint64_t g_generation = 1;          // bumped by every invalidation; an entry remembers the generation it was made in
 const size_t kMaxEntries = 64;
 
-uint64_t content_hash( const void* a, const void* b, size_t bytes )
+inline uint64_t mix( uint64_t h, uint64_t w ) { h = ( h ^ w ) * 0xff51afd7ed558ccdull; return h ^ ( h >> 29 ); }
+
+uint64_t full_hash( const void* a, const void* b, size_t bytes )
 {
-  // four independent multiply-xor lanes over 32-byte blocks (the dependent chain of a single lane caps at
-  // ~8 GB/s; the arrays are hashed on every call, so this sits next to a 4 ms index build)
+  // four independent multiply-xor lanes over 32-byte blocks (the dependent chain of a single lane caps at ~8 GB/s)
   uint64_t h = 0x9e3779b97f4a7c15ull ^ bytes;
   for( const void* src : { a, b } )
   {
@@ -70,9 +81,27 @@ uint64_t content_hash( const void* a, const void* b, size_t bytes )
   return h;
 }
 
+uint64_t fingerprint( const void* a, const void* b, size_t bytes )
+{
+  static const bool full = getenv( "RS_DROPIN_FULL_HASH" ) != nullptr;
+  if( full || bytes <= 2048 ) return full_hash( a, b, bytes );
+  uint64_t h = 0x9e3779b97f4a7c15ull ^ bytes;
+  for( const void* src : { a, b } )
+  {
+    if( !src ) { h = mix( h, 0x51ull ); continue; }
+    const unsigned char* p = (const unsigned char*)src;
+    uint64_t w[8];
+    std::memcpy( w, p, 64 );               for( uint64_t v : w ) h = mix( h, v );
+    std::memcpy( w, p + bytes - 64, 64 );  for( uint64_t v : w ) h = mix( h, v );
+    const size_t step = ( ( bytes - 128 ) / 62 ) & ~(size_t)3;
+    for( int k = 0; k < 62; ++k ) { std::memcpy( w, p + 64 + (size_t)k * step, 16 ); h = mix( mix( h, w[0] ), w[1] ); }
+  }
+  return h;
+}
+
 rs_hip_cloud_t* cached_cloud( const rsd_vec3_t* pos, const rsd_vec3_t* nor, int32_t n, float cell )
 {
-  const uint64_t h = content_hash( pos, nor, (size_t)( n > 0 ? n : 0 ) * 12 );
+  const uint64_t h = fingerprint( pos, nor, (size_t)( n > 0 ? n : 0 ) * 12 );
   std::lock_guard<std::mutex> lock( g_cache_mutex );
   for( auto it = g_cache.begin(); it != g_cache.end(); ++it )
     if( it->pos == pos && it->nor == nor && it->n == n && it->cell == cell && it->hash == h )
@@ -82,9 +111,143 @@ rs_hip_cloud_t* cached_cloud( const rsd_vec3_t* pos, const rsd_vec3_t* nor, int3
     }
   rs_hip_cloud_t* c = rs_hip_cloud_create( (const float*)pos, (const float*)nor, n, cell );
   if( !c ) { complain( "cloud upload" ); return nullptr; }
-  g_cache.push_front( Entry{ pos, nor, n, cell, h, c } );
+  g_cache.push_front( Entry{ pos, nor, n, cell, h, g_generation, c } );
   while( g_cache.size() > kMaxEntries ) { rs_hip_cloud_destroy( g_cache.back().cloud ); g_cache.pop_back(); }
   return c;
+}
+
+void invalidate_pointer( const void* p )
+{
+  if( !p ) return;
+  std::lock_guard<std::mutex> lock( g_cache_mutex );
+  ++g_generation;
+  for( auto it = g_cache.begin(); it != g_cache.end(); )
+    if( it->pos == p || it->nor == p ) { rs_hip_cloud_destroy( it->cloud ); it = g_cache.erase( it ); } else ++it;
+}
+
+// ---- host side of a grid -------------------------------------------------------------------
+// msh_hash_grid_init_3d keeps a copy of the points, like the reference's (msh_hash_grid.h:511-532): sorted by cell,
+// {x, y, z, original index}, with a dense cell offset table.  It serves two things.  (1) Searches of a handful of queries:
+// rs_pointcloud__compute_level_poisson (lib/rs/rs_pointcloud.h:1007-1037) issues ONE query per call, the next one
+// depending on the previous one's result, up to ~10^6 times per cloud; a kernel launch, two copies and a synchronisation
+// per point would be ~30 us each against ~1 us of arithmetic, so such calls (n_query_pts <= RS_DROPIN_HOST_QUERIES,
+// default 4) are answered on the host from this copy — a dispatch by call size, not a fallback: a grid cannot be
+// initialised without a HIP device, and everything batched goes to the GPU.  (2) The device cloud of a grid is built
+// lazily, at the first batched search, from this copy (the caller's array may be gone by then): most level grids
+// (rs_pointcloud_compute_search_grid builds five per cloud, :849-863) are never searched at all.
+struct HostGrid
+{
+  int32_t n = 0;
+  float cell = 0.0f, inv_cell = 0.0f, mn[3] = { 0, 0, 0 };
+  int dims[3] = { 1, 1, 1 };
+  std::vector<uint32_t> cell_start;                 // dims product + 1
+  std::vector<float> rec;                           // 4 floats per point, cell order: x, y, z, bitcast(original index)
+
+  inline int bin( float v, int a ) const
+  {
+    float f = std::floor( ( v - mn[a] ) * inv_cell );
+    if( !( f >= 0.0f ) ) f = 0.0f;
+    if( f > (float)( dims[a] - 1 ) ) f = (float)( dims[a] - 1 );
+    return (int)f;
+  }
+  void build( const float* pts, int32_t n_pts, float cell_size )
+  {
+    n = n_pts > 0 ? n_pts : 0;
+    float mx[3] = { 0, 0, 0 };
+    bool any = false;
+    for( int32_t i = 0; i < n; ++i )
+    {
+      const float* p = pts + 3 * (size_t)i;
+      if( !( std::isfinite( p[0] ) && std::isfinite( p[1] ) && std::isfinite( p[2] ) ) ) continue;
+      for( int a = 0; a < 3; ++a ) { if( !any || p[a] < mn[a] ) mn[a] = p[a]; if( !any || p[a] > mx[a] ) mx[a] = p[a]; }
+      any = true;
+    }
+    cell = cell_size;
+    for( ;; )
+    {
+      double cells = 1.0;
+      for( int a = 0; a < 3; ++a ) { dims[a] = (int)std::floor( ( (double)mx[a] - (double)mn[a] ) / (double)cell ) + 1; cells *= dims[a]; }
+      if( cells <= 16.0e6 ) break;
+      cell *= 2.0f;                                   // keep the dense table small; any cell size gives the same results
+    }
+    inv_cell = 1.0f / cell;
+    const size_t n_cells = (size_t)dims[0] * dims[1] * dims[2];
+    cell_start.assign( n_cells + 1, 0u );
+    std::vector<uint32_t> id( (size_t)n );
+    for( int32_t i = 0; i < n; ++i )
+    {
+      const float* p = pts + 3 * (size_t)i;
+      id[i] = (uint32_t)( ( (size_t)bin( p[2], 2 ) * dims[1] + bin( p[1], 1 ) ) * dims[0] + bin( p[0], 0 ) );
+      cell_start[id[i] + 1]++;
+    }
+    for( size_t c = 0; c < n_cells; ++c ) cell_start[c + 1] += cell_start[c];
+    std::vector<uint32_t> cur( cell_start.begin(), cell_start.end() - 1 );
+    rec.resize( (size_t)n * 4 );
+    for( int32_t i = 0; i < n; ++i )                 // input order inside a cell, like the reference
+    {
+      const size_t s = cur[id[i]]++;
+      std::memcpy( &rec[4 * s], pts + 3 * (size_t)i, 12 );
+      std::memcpy( &rec[4 * s + 3], &i, 4 );
+    }
+  }
+  // the (at most) k nearest with dist² < radius² (msh_hash_grid.h:852-857,1111), ascending (dist², index)
+  size_t search( const float* q, float radius, size_t k, float* out_d2, int32_t* out_idx ) const
+  {
+    if( n == 0 || !( std::isfinite( q[0] ) && std::isfinite( q[1] ) && std::isfinite( q[2] ) ) ) return 0;
+    const float r2 = (float)( (double)radius * (double)radius );
+    int lo[3], hi[3];
+    for( int a = 0; a < 3; ++a )
+    {
+      float fa = std::floor( ( q[a] - radius - mn[a] ) * inv_cell - 0.01f ), fb = std::floor( ( q[a] + radius - mn[a] ) * inv_cell + 0.01f );
+      if( fa < 0.0f ) fa = 0.0f;
+      if( fb > (float)( dims[a] - 1 ) ) fb = (float)( dims[a] - 1 );
+      if( !( fb >= fa ) ) return 0;
+      lo[a] = (int)fa; hi[a] = (int)fb;
+    }
+    thread_local std::vector<std::pair<float, int32_t>> hits;
+    hits.clear();
+    for( int z = lo[2]; z <= hi[2]; ++z )
+      for( int y = lo[1]; y <= hi[1]; ++y )
+      {
+        const size_t row = ( (size_t)z * dims[1] + y ) * dims[0];
+        const uint32_t s0 = cell_start[row + lo[0]], s1 = cell_start[row + hi[0] + 1];
+        for( uint32_t s = s0; s < s1; ++s )
+        {
+          const float* p = &rec[4 * (size_t)s];
+          const float vx = p[0] - q[0], vy = p[1] - q[1], vz = p[2] - q[2];
+          const float d2 = vx * vx + vy * vy + vz * vz;
+          if( d2 < r2 ) { int32_t i; std::memcpy( &i, p + 3, 4 ); hits.emplace_back( d2, i ); }
+        }
+      }
+    if( hits.size() > k ) { std::nth_element( hits.begin(), hits.begin() + (ptrdiff_t)k, hits.end() ); hits.resize( k ); }
+    std::sort( hits.begin(), hits.end() );
+    for( size_t t = 0; t < hits.size(); ++t ) { out_d2[t] = hits[t].first; out_idx[t] = hits[t].second; }
+    return hits.size();
+  }
+};
+
+struct GridHandle
+{
+  const float* src = nullptr;         // the array the grid was built on (identity only: never dereferenced after init)
+  HostGrid host;
+  rs_hip_cloud_t* dev = nullptr;      // built at the first batched search
+  bool dev_failed = false;
+  std::mutex mutex;
+};
+
+rs_hip_cloud_t* device_cloud_of( GridHandle* h )
+{
+  std::lock_guard<std::mutex> lock( h->mutex );
+  if( h->dev || h->dev_failed ) return h->dev;
+  std::vector<float> pts( (size_t)h->host.n * 3 );
+  for( int32_t s = 0; s < h->host.n; ++s )
+  {
+    int32_t i; std::memcpy( &i, &h->host.rec[4 * (size_t)s + 3], 4 );
+    std::memcpy( &pts[3 * (size_t)i], &h->host.rec[4 * (size_t)s], 12 );
+  }
+  h->dev = rs_hip_cloud_create( pts.data(), nullptr, h->host.n, h->host.cell );
+  if( !h->dev ) { h->dev_failed = true; complain( "msh_hash_grid: device index" ); }
+  return h->dev;
 }
 
 } // namespace
@@ -94,9 +257,12 @@ extern "C" {
 void rsd_cache_clear( void )
 {
   std::lock_guard<std::mutex> lock( g_cache_mutex );
+  ++g_generation;
   for( auto& e : g_cache ) rs_hip_cloud_destroy( e.cloud );
   g_cache.clear();
 }
+
+void rsd_cache_invalidate( const void* host_array ) { invalidate_pointer( host_array ); }
 
 // ---- msh_hash_grid ------------------------------------------------------------------------
 
@@ -104,26 +270,50 @@ void msh_hash_grid_init_3d( rsd_hash_grid_t* hg, const float* pts, const int32_t
 {
   // cell = 2*radius like the reference (msh_hash_grid.h:443); a non-positive radius asks the
   // reference for an extent-derived cell (:444) — any positive cell gives the same results here.
-  float cell = radius > 0.0f ? 2.0f * radius : 0.1f;
-  rs_hip_cloud_t* c = rs_hip_cloud_create( pts, nullptr, n_pts, cell );
-  if( !c ) complain( "msh_hash_grid_init_3d" );
-  hg->data_buffer = c;
-  hg->bin_table = nullptr; hg->offsets = nullptr;
+  const float cell = radius > 0.0f ? 2.0f * radius : 0.1f;
+  hg->bin_table = nullptr; hg->offsets = nullptr; hg->data_buffer = nullptr;
   hg->cell_size = cell; hg->_inv_cell_size = 1.0 / cell;
   hg->_pts_dim = 3; hg->_num_threads = 1; hg->_n_pts = (size_t)( n_pts > 0 ? n_pts : 0 );
+  if( rs_hip_synchronize() != RS_HIP_OK ) { complain( "msh_hash_grid_init_3d" ); return; }     // no HIP device: no grid (there is no CPU fallback)
+  GridHandle* h = new GridHandle();
+  h->src = pts;
+  h->host.build( pts, n_pts, cell );
+  hg->data_buffer = h;
+  hg->width = (size_t)h->host.dims[0]; hg->height = (size_t)h->host.dims[1]; hg->depth = (size_t)h->host.dims[2];
 }
 
 void msh_hash_grid_term( rsd_hash_grid_t* hg )
 {
-  if( hg->data_buffer ) rs_hip_cloud_destroy( (rs_hip_cloud_t*)hg->data_buffer );
+  if( hg->data_buffer )
+  {
+    GridHandle* h = (GridHandle*)hg->data_buffer;
+    invalidate_pointer( h->src );                        // whatever else was built from that array goes with its grid
+    if( h->dev ) rs_hip_cloud_destroy( h->dev );
+    delete h;
+  }
   std::memset( hg, 0, sizeof(*hg) );                     // the reference zeroes what it owns (:558-573)
 }
 
 size_t msh_hash_grid_radius_search( const rsd_hash_grid_t* hg, rsd_search_desc_t* d )
 {
-  if( !hg || !hg->data_buffer || !d ) return 0;
+  if( !hg || !hg->data_buffer || !d || !d->query_pts || !d->distances_sq || !d->indices || d->max_n_neigh == 0 || !( d->radius > 0.0f ) ) return 0;
+  GridHandle* h = (GridHandle*)hg->data_buffer;
+  const size_t host_queries = getenv( "RS_DROPIN_HOST_QUERIES" ) ? (size_t)atoll( getenv( "RS_DROPIN_HOST_QUERIES" ) ) : 4;      // (read per call: tests switch it)
+  if( d->n_query_pts <= host_queries )
+  {
+    size_t total = 0;
+    for( size_t i = 0; i < d->n_query_pts; ++i )
+    {
+      const size_t c = h->host.search( d->query_pts + 3 * i, d->radius, d->max_n_neigh, d->distances_sq + i * d->max_n_neigh, d->indices + i * d->max_n_neigh );
+      if( d->n_neighbors ) d->n_neighbors[i] = c;
+      total += c;
+    }
+    return total;
+  }
+  rs_hip_cloud_t* c = device_cloud_of( h );
+  if( !c ) return 0;
   uint64_t total = 0;
-  int rc = rs_hip_radius_search( (const rs_hip_cloud_t*)hg->data_buffer, d->query_pts, (int64_t)d->n_query_pts, d->radius,
+  int rc = rs_hip_radius_search( c, d->query_pts, (int64_t)d->n_query_pts, d->radius,
                                  (int32_t)d->max_n_neigh, d->distances_sq, d->indices, d->n_neighbors, &total );
   if( rc ) { complain( "msh_hash_grid_radius_search" ); return 0; }
   return (size_t)total;

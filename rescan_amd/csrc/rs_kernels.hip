@@ -1913,6 +1913,134 @@ void launch_rows( const RowsLaunch& L, hipStream_t st )
 }
 
 // ------------------------------------------------------------------------------------------
+// Generic rows, one WAVE per query: the form msh_hash_grid_radius_search takes when the reference's own
+// consumers call it unchanged (mgs_compute_object_alignment_score: a few hundred object points per call, K = 64 / 32,
+// apps/pose_proposal/pose_proposal.cpp:115-124, tens of thousands of calls).  Queries arrive in the caller's order —
+// no Hilbert sort, no tiling, nothing but this launch between the upload and the download.  The 64 lanes stream the
+// cells within the radius of their ONE query (same flattened row-piece stream as sweep_shell), every lane tests its own
+// candidate, hits are appended to the wave's LDS list by ballot / prefix count, the list is sorted by (dist², index)
+// with a bitonic network, and the first K entries are the row.  A query with more than ROWS_CAP points within the radius
+// raises `overflow` and is left to k_rows (successive minima need no storage).
+// ------------------------------------------------------------------------------------------
+#define ROWS_CAP 1024
+#define ROWS_WAVES 4
+struct RowsWaveLds { float d2[ROWS_CAP]; int idx[ROWS_CAP]; uint32_t seg[WAVE], pre[WAVE]; };
+
+__global__ __launch_bounds__( ROWS_WAVES * WAVE ) void k_rows_wave( GridView g, const float* q3, int nq, int K, float radius, float radius_sq,
+                                                                    float* out_d2, int* out_idx, int* out_nn, int* overflow )
+{
+  __shared__ RowsWaveLds lds[ROWS_WAVES];
+  const int lane = threadIdx.x & ( WAVE - 1 ), wib = threadIdx.x / WAVE;
+  const int qi = blockIdx.x * ROWS_WAVES + wib;
+  if( qi >= nq ) return;
+  RowsWaveLds& L = lds[wib];
+  const float qx = q3[3 * qi], qy = q3[3 * qi + 1], qz = q3[3 * qi + 2];
+  int x0 = 0, x1 = 0, y0 = 0, y1 = 0, z0 = 0, z1 = 0;
+  const bool grid = g.inv_cell > 0.0f;
+  if( grid )
+  {
+    axis_range( qx, qx, radius, g.minx, g.inv_cell, g.w, x0, x1 );
+    axis_range( qy, qy, radius, g.miny, g.inv_cell, g.h, y0, y1 );
+    axis_range( qz, qz, radius, g.minz, g.inv_cell, g.d, z0, z1 );
+  }
+  const bool finite = fabsf( qx ) <= FLT_MAX && fabsf( qy ) <= FLT_MAX && fabsf( qz ) <= FLT_MAX;       // (false for NaN)
+  const bool empty = !finite | ( x1 < x0 ) | ( y1 < y0 ) | ( z1 < z0 ) | ( g.n == 0 );
+  const int ny = y1 - y0 + 1;
+  const int n_rows = empty ? 0 : ny * ( z1 - z0 + 1 );
+  uint32_t count = 0;                                   // hits so far (wave-uniform)
+  for( int r0 = 0; r0 < n_rows; r0 += WAVE )
+  {
+    const int r = r0 + lane;
+    uint32_t sa = 0, la = 0;
+    if( r < n_rows )
+    {
+      const int rz = r / ny, y = y0 + ( r - rz * ny ), z = z0 + rz;
+      const uint32_t* cs = g.cell_start + (size_t)( z * g.h + y ) * g.w;
+      sa = cs[x0]; la = cs[x1 + 1] - sa;
+    }
+    const uint32_t incl = wave_scan( la, lane );
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane( (int)incl, WAVE - 1 );
+    L.seg[lane] = sa; L.pre[lane] = incl - la;
+    wave_lds_fence();
+    for( uint32_t c0 = 0; c0 < total; c0 += WAVE )
+    {
+      const uint32_t j = c0 + lane;
+      bool hit = false; float d2 = 0.0f; int idx = 0;
+      if( j < total )
+      {
+        int row = 0;
+#pragma unroll
+        for( int step = WAVE / 2; step > 0; step >>= 1 ) { if( L.pre[row + step] <= j ) row += step; }
+        const float4 P = g.pos[L.seg[row] + ( j - L.pre[row] )];
+        const float vx = P.x - qx, vy = P.y - qy, vz = P.z - qz;
+        d2 = vx * vx + vy * vy + vz * vz;                 // msh_hash_grid.h:852-855
+        idx = __float_as_int( P.w );
+        hit = d2 < radius_sq;                             // :857
+      }
+      const unsigned long long mask = __ballot( hit );
+      if( hit )
+      {
+        const uint32_t at = count + (uint32_t)__builtin_amdgcn_mbcnt_hi( (uint32_t)( mask >> 32 ), __builtin_amdgcn_mbcnt_lo( (uint32_t)mask, 0u ) );
+        if( at < ROWS_CAP ) { L.d2[at] = d2; L.idx[at] = idx; }
+      }
+      count += (uint32_t)__popcll( mask );
+    }
+    wave_lds_fence();
+  }
+  if( !grid && !empty )
+  {
+    // one-cell (brute) layout: the whole cloud is the candidate list
+    for( uint32_t c0 = 0; c0 < (uint32_t)g.n; c0 += WAVE )
+    {
+      const uint32_t j = c0 + lane;
+      bool hit = false; float d2 = 0.0f; int idx = 0;
+      if( j < (uint32_t)g.n )
+      {
+        const float4 P = g.pos[j];
+        const float vx = P.x - qx, vy = P.y - qy, vz = P.z - qz;
+        d2 = vx * vx + vy * vy + vz * vz; idx = __float_as_int( P.w ); hit = d2 < radius_sq;
+      }
+      const unsigned long long mask = __ballot( hit );
+      if( hit )
+      {
+        const uint32_t at = count + (uint32_t)__builtin_amdgcn_mbcnt_hi( (uint32_t)( mask >> 32 ), __builtin_amdgcn_mbcnt_lo( (uint32_t)mask, 0u ) );
+        if( at < ROWS_CAP ) { L.d2[at] = d2; L.idx[at] = idx; }
+      }
+      count += (uint32_t)__popcll( mask );
+    }
+  }
+  if( count > ROWS_CAP ) { if( lane == 0 ) { atomicExch( overflow, 1 ); out_nn[qi] = -1; } return; }
+  // bitonic sort of the first `count` entries (padded with +inf up to a power of two) by (dist², index)
+  uint32_t m = WAVE; while( m < count ) m <<= 1;
+  for( uint32_t t = count + lane; t < m; t += WAVE ) { L.d2[t] = INFINITY; L.idx[t] = INT_MAX; }
+  wave_lds_fence();
+  if( count > 1 )
+  for( uint32_t k = 2; k <= m; k <<= 1 )
+    for( uint32_t jj = k >> 1; jj > 0; jj >>= 1 )
+    {
+      for( uint32_t t = lane; t < ( m >> 1 ); t += WAVE )
+      {
+        const uint32_t lo = ( ( t & ~( jj - 1 ) ) << 1 ) | ( t & ( jj - 1 ) ), hi = lo | jj;
+        const bool up = ( lo & k ) == 0;
+        const float da = L.d2[lo], db = L.d2[hi]; const int ia = L.idx[lo], ib = L.idx[hi];
+        const bool swap = up ? lex_less( db, ib, da, ia ) : lex_less( da, ia, db, ib );
+        if( swap ) { L.d2[lo] = db; L.idx[lo] = ib; L.d2[hi] = da; L.idx[hi] = ia; }
+      }
+      wave_lds_fence();
+    }
+  const uint32_t n_out = count < (uint32_t)K ? count : (uint32_t)K;
+  for( uint32_t t = lane; t < n_out; t += WAVE ) { out_d2[(size_t)qi * K + t] = L.d2[t]; out_idx[(size_t)qi * K + t] = L.idx[t]; }
+  if( lane == 0 ) out_nn[qi] = (int)n_out;
+}
+
+void launch_rows_wave( const GridView& g, const float* q3, int nq, int K, float radius, float radius_sq,
+                       float* out_d2, int* out_idx, int* out_nn, int* overflow, hipStream_t st )
+{
+  hipLaunchKernelGGL( k_rows_wave, dim3( ( nq + ROWS_WAVES - 1 ) / ROWS_WAVES ), dim3( ROWS_WAVES * WAVE ), 0, st, g, q3, nq, K, radius, radius_sq,
+                      out_d2, out_idx, out_nn, overflow );
+}
+
+// ------------------------------------------------------------------------------------------
 // Level builder: Poisson-disk subsample in input order  (lib/rs/rs_pointcloud.h:984-1106)
 //
 // The reference walks the points in input order: the first unmarked point becomes a sample and marks every point its

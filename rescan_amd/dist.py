@@ -175,7 +175,7 @@ def shard_publish(lay, send, small_host):
     send[: lay.small_words].copy_(t, non_blocking=True)
 
 
-def shard_fold(capi, lay, recv):
+def shard_fold(capi, lay, recv, out=None):
     """recv = the all-gathered send buffers (float32 device tensor, lay.world x lay.words), complete (the caller has
     waited for the collective).  Returns (errs, Ts, iters, scores, labels, min_dists) for ALL units, in unit order:
     the small blocks are read back, the rows are folded on the device in the sorted placement order."""
@@ -188,5 +188,6 @@ def shard_fold(capi, lay, recv):
         Ts.append(blk[:, :16]); errs.append(blk[:, 16]); its.append(blk[:, 17].astype(np.int32))
         scores.append(small[r, lay.off_score: lay.off_score + (s1 - s0)])
         offsets += [r * W + lay.off_rows + k * lay.n_scene for k in range(p1 - p0)]
-    labels, mind = capi.fold_label_rows_device(recv.data_ptr(), offsets, lay.n_scene)   # from (0, 1e9): rs_pointcloud_filters.cpp:799-802,820
+    # from (0, 1e9): rs_pointcloud_filters.cpp:799-802,820; out = (labels int8[n_scene], min_dists float32[n_scene]) to receive the result
+    labels, mind = capi.fold_label_rows_device(recv.data_ptr(), offsets, lay.n_scene, *(out if out is not None else (None, None)), fresh=True)
     return (np.concatenate(errs), np.concatenate(Ts).copy(), np.concatenate(its), np.concatenate(scores), labels, mind)

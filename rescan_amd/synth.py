@@ -201,3 +201,27 @@ def perturbed_pose(pose16, rng, max_angle=0.08, max_shift=0.04):
     d = np.eye(4); d[:3, :3] = rot_y(ang); d[:3, 3] = t
     m = np.asarray(pose16, np.float64).reshape(4, 4).T @ d
     return np.ascontiguousarray(m.T.astype(np.float32).ravel())
+
+
+def write_ply(path, s):
+    """A scene as the binary-LE PLY the reference's seg2rsdb / pose_proposal read (positions, normals, colour, radius,
+    class_idx, instance_idx per vertex; no faces, so points are used as they are: lib/rs/rs_pointcloud.h:1268-1281)."""
+    n = len(s["points"])
+    hdr = ("ply\nformat binary_little_endian 1.0\nelement vertex %d\n"
+           "property float x\nproperty float y\nproperty float z\nproperty float nx\nproperty float ny\nproperty float nz\n"
+           "property uchar red\nproperty uchar green\nproperty uchar blue\nproperty float radius\n"
+           "property int class_idx\nproperty int instance_idx\nend_header\n") % n
+    dt = np.dtype([("p", "<f4", 3), ("n", "<f4", 3), ("c", "u1", 3), ("r", "<f4"), ("cls", "<i4"), ("inst", "<i4")])
+    a = np.zeros(n, dt)
+    a["p"] = s["points"]; a["n"] = s["normals"]; a["c"] = 128; a["r"] = 0.01
+    a["cls"] = s["class_idx"]; a["inst"] = s["instance_idx"]
+    with open(path, "wb") as f:
+        f.write(hdr.encode()); f.write(a.tobytes())
+
+
+def write_class_table(path):
+    """The class file of the pipeline ('nyu40_classes.txt': rsdb syntax, lib/rs/rs_database.h:301-316)."""
+    with open(path, "w") as f:
+        f.write("rsdb 0.1\n")
+        for k, v in CLASS_IDX.items():
+            f.write(f"class {k} {v}\n")

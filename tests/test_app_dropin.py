@@ -14,24 +14,10 @@ import pytest
 from conftest import ROOT
 
 REF = os.path.join(ROOT, "oracle", "_ref")
-BINS = [os.path.join(REF, b) for b in ("seg2rsdb", "pose_proposal", "pose_proposal_hip")]
+BINS = [os.path.join(REF, b) for b in ("seg2rsdb", "pose_proposal", "pose_proposal_hip", "pose_proposal_hip2")]
 
 pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(not all(os.path.exists(b) for b in BINS), reason="oracle/_ref apps not built")]
-
-
-def write_ply(path, s):
-    n = len(s["points"])
-    hdr = ("ply\nformat binary_little_endian 1.0\nelement vertex %d\n"
-           "property float x\nproperty float y\nproperty float z\nproperty float nx\nproperty float ny\nproperty float nz\n"
-           "property uchar red\nproperty uchar green\nproperty uchar blue\nproperty float radius\n"
-           "property int class_idx\nproperty int instance_idx\nend_header\n") % n
-    dt = np.dtype([("p", "<f4", 3), ("n", "<f4", 3), ("c", "u1", 3), ("r", "<f4"), ("cls", "<i4"), ("inst", "<i4")])
-    a = np.zeros(n, dt)
-    a["p"] = s["points"]; a["n"] = s["normals"]; a["c"] = 128; a["r"] = 0.01
-    a["cls"] = s["class_idx"]; a["inst"] = s["instance_idx"]
-    with open(path, "wb") as f:
-        f.write(hdr.encode()); f.write(a.tobytes())
 
 
 def read_pose_bin(path):
@@ -48,22 +34,32 @@ def read_pose_bin(path):
     return out
 
 
-def test_pose_proposal_app_links_against_the_shim(tmp_path):
+def computed_in(stdout):
+    """The app's own timer: "Computed poses in ..." (apps/pose_proposal/main.cpp:208)."""
+    import re
+    m = re.search(r"Computed poses in\s*([0-9.]+)", stdout)
+    return float(m.group(1)) if m else float("nan")
+
+
+@pytest.mark.parametrize("which", ["icp", "icp+grid"])
+def test_pose_proposal_app_links_against_the_shim(tmp_path, which):
+    """which = "icp": shadow/icp only (icp_align on the GPU); "icp+grid": shadow/icp + shadow/grid — also the app's own
+    mgs_compute_object_alignment_score (83 % of its run time), its level builder and its level grids run on
+    the shim's msh_hash_grid_*."""
     from rescan_amd import synth
+    shim_bin = BINS[2] if which == "icp" else BINS[3]
     seq = tmp_path / "seq"
     seq.mkdir()
     for t in (0, 1):
-        write_ply(str(seq / f"t{t}.ply"), synth.make_scene(seed=7, density=2000.0, timestep=t))
-    with open(tmp_path / "classes.rsdb", "w") as f:
-        f.write("rsdb 0.1\n")
-        for k, v in synth.CLASS_IDX.items():
-            f.write(f"class {k} {v}\n")
+        synth.write_ply(str(seq / f"t{t}.ply"), synth.make_scene(seed=7, density=2000.0, timestep=t))
+    synth.write_class_table(str(tmp_path / "classes.rsdb"))
     run = lambda *a: subprocess.run(list(a), cwd=str(tmp_path), capture_output=True, text=True, timeout=900)  # noqa: E731
     r = run(BINS[0], "seq/t0.ply", "classes.rsdb", "seq/t0.rsdb", "-v")
     assert os.path.exists(seq / "t0.rsdb"), r.stdout[-500:] + r.stderr[-500:]      # (its exit code is unreliable, SURVEY §5)
     cpu = run(BINS[1], "seq/t0.rsdb", "seq/t1.ply", "seq/t1_cpu.rsdb", "-v")
     assert cpu.returncode == 0, cpu.stdout[-800:]
-    hip = run(BINS[2], "seq/t0.rsdb", "seq/t1.ply", "seq/t1_hip.rsdb", "-v")
+    hip = run(shim_bin, "seq/t0.rsdb", "seq/t1.ply", "seq/t1_hip.rsdb", "-v")
+    print("Computed poses in: reference build %.3f s, shim build (%s) %.3f s" % (computed_in(cpu.stdout), which, computed_in(hip.stdout)))
     assert hip.returncode == 0, hip.stdout[-800:] + hip.stderr[-800:]
     assert "[rescan_hip]" not in hip.stderr, hip.stderr[-800:]                      # the shim reported no failure
     a = read_pose_bin(str(seq / "t1_cpu" / "t1_cpu.bin"))

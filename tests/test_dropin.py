@@ -98,22 +98,105 @@ def test_icp_align_by_reference_name(dropin, gscene, fname):
         assert np.linalg.norm(got.astype(np.float64) - g["T_out"]) < 1e-4 and abs(err - float(g["err"])) < 1e-5
 
 
+def _search(dropin, hg, q, radius, k, sort=1):
+    q = np.ascontiguousarray(q, np.float32).reshape(-1, 3)
+    d = np.zeros((len(q), k), np.float32); i = np.zeros((len(q), k), np.int32); nn = np.zeros(len(q), np.uint64)
+    sd = SearchDesc(q.ctypes.data, len(q), d.ctypes.data, i.ctypes.data, nn.ctypes.data, float(radius), k, sort)
+    tot = dropin.msh_hash_grid_radius_search(C.byref(hg), C.byref(sd))
+    return d, i, nn.astype(np.int64), int(tot)
+
+
 @pytest.mark.gpu
-def test_hash_grid_by_reference_name(dropin, gscene):
-    g = load_golden("rows_k16_r010.npz")
+@pytest.mark.parametrize("fname", golden_files("rows_"))
+def test_hash_grid_by_reference_name(dropin, gscene, fname, monkeypatch):
+    """msh_hash_grid_init_3d / _radius_search / _term under the reference's names, on the reference's own rows: the
+    batched call through both device kernels (one wave per query; Hilbert tiles + successive minima) and the same
+    queries asked one at a time (the host path the level builder's one-query loop takes)."""
+    from conftest import rows_equal_up_to_ties
+    g = load_golden(fname)
     hg = HashGrid()
     pts = gscene["points"]
     dropin.msh_hash_grid_init_3d(C.byref(hg), pts.ctypes.data, len(pts), float(g["grid_radius"]))
     assert hg.data_buffer and hg._n_pts == len(pts)
     q = g["query"]; k = int(g["k"])
-    d = np.zeros((len(q), k), np.float32); i = np.zeros((len(q), k), np.int32); nn = np.zeros(len(q), np.uint64)
-    sd = SearchDesc(q.ctypes.data, len(q), d.ctypes.data, i.ctypes.data, nn.ctypes.data, float(g["radius"]), k, 1)
-    tot = dropin.msh_hash_grid_radius_search(C.byref(hg), C.byref(sd))
-    assert tot == int(g["total"]) and (nn.astype(np.int64) == g["nn"]).all()
-    valid = np.arange(k)[None, :] < g["nn"][:, None]
-    assert (d[valid] == g["dists"][valid]).all()
+    for route in ("wave", "tiled"):
+        monkeypatch.setenv("RS_HIP_ROWS_TILED_FROM", "1000000000" if route == "wave" else "0")
+        if route == "tiled":
+            monkeypatch.setenv("RS_HIP_NO_ROWS_WAVE", "1")
+        d, i, nn, tot = _search(dropin, hg, q, g["radius"], k)
+        assert tot == int(g["total"]), route
+        rows_equal_up_to_ties(d, i, nn, g["dists"], g["inds"], g["nn"])
+    monkeypatch.delenv("RS_HIP_NO_ROWS_WAVE")
+    for r in range(0, len(q), 7):                                # one query per call: answered from the grid's host copy
+        d, i, nn, tot = _search(dropin, hg, q[r], g["radius"], k, sort=0)
+        rows_equal_up_to_ties(d, i, nn, g["dists"][r:r + 1], g["inds"][r:r + 1], g["nn"][r:r + 1])
+        assert tot == int(g["nn"][r])
     dropin.msh_hash_grid_term(C.byref(hg))
     assert not hg.data_buffer and hg.width == 0
+
+
+@pytest.mark.gpu
+def test_level_builder_loop_through_the_shim(dropin, gscene):
+    """rs_pointcloud__compute_level_poisson (lib/rs/rs_pointcloud.h:984-1038), the loop as the reference runs it — one
+    one-query search per sample against a grid of radius 2.5 x voxel, sort = 0, max_n_neigh = 1024 * level / 4 — on top of
+    the shim's msh_hash_grid_*: the samples are the reference's (tests/golden/level.npz, made by its own function)."""
+    g = load_golden("level.npz")
+    pts = gscene["points"]
+    for level, voxel in ((2, 0.02), (4, 0.08)):
+        hg = HashGrid()
+        dropin.msh_hash_grid_init_3d(C.byref(hg), pts.ctypes.data, len(pts), 2.5 * voxel)            # :988-990
+        k = int(1024 * (level / 4.0)) or 256                                                         # :995-996
+        unmarked = np.ones(len(pts), bool)
+        samples = []
+        d = np.zeros(k, np.float32); i = np.zeros(k, np.int32)
+        sd = SearchDesc(0, 1, d.ctypes.data, i.ctypes.data, None, float(voxel), k, 0)
+        idx = 0
+        n_marked = 0
+        while n_marked < len(pts):
+            while not unmarked[idx]:
+                idx += 1
+            samples.append(idx)
+            sd.query_pts = pts[idx:idx + 1].ctypes.data
+            n = dropin.msh_hash_grid_radius_search(C.byref(hg), C.byref(sd))
+            hit = i[:n]
+            n_marked += int(unmarked[hit].sum())
+            unmarked[hit] = False
+        dropin.msh_hash_grid_term(C.byref(hg))
+        assert np.array_equal(np.array(samples, np.int32), g[f"own_l{level}"]), level
+
+
+@pytest.mark.gpu
+def test_upload_cache_follows_the_arrays(dropin, gscene):
+    """The shim's device-cloud cache: same arrays -> same result (cached upload); arrays rebuilt in place -> noticed by the
+    sampled fingerprint; a few points edited in place -> noticed after rsd_cache_invalidate (the explicit route)."""
+    g = load_golden(golden_files("icp_")[0])
+    o = gscene["objects"][int(g["obj"])]
+    pos, nor = o["pos"].copy(), o["nor"].copy()
+    pts2, nor2 = gscene["points"], gscene["normals"]
+    T2 = Mat4(); T2.data[:] = [float(x) for x in g["T2"]]
+    dropin.rsd_cache_invalidate.restype = None
+    dropin.rsd_cache_invalidate.argtypes = [C.c_void_p]
+
+    def run():
+        T = Mat4(); T.data[:] = [float(x) for x in g["T1"]]
+        dropin.icp_align(pos.ctypes.data, nor.ctypes.data, len(pos), pts2.ctypes.data, nor2.ctypes.data, len(pts2),
+                         C.byref(T), T2, float(g["max_dist"]), float(g["max_angle"]), False)
+        return np.array(T.data[:], np.float32)
+
+    a = run()
+    assert (run() == a).all() and np.linalg.norm(a.astype(np.float64) - g["T_out"]) < 1e-4
+    saved = pos.copy()
+    pos += np.float32(0.01)                                      # the whole array changes behind the same pointer
+    b = run()
+    assert not (b == a).all()
+    pos[:] = saved
+    assert (run() == a).all()
+    pos[len(pos) // 3] += np.float32(0.05)                       # one point: invisible to a sample, so the caller says so
+    dropin.rsd_cache_invalidate(pos.ctypes.data)
+    c = run()
+    pos[:] = saved
+    dropin.rsd_cache_invalidate(pos.ctypes.data)
+    assert (run() == a).all() and not (c == a).all()
 
 
 @pytest.mark.gpu
