@@ -13,7 +13,7 @@ container only; the fixtures are committed so the GPU box, which has no /root/re
         input digests              sha256 of the generated inputs, so that a test on another machine notices if the
               generator (numpy, rescan_amd/synth.py) no longer produces the arrays the fixture was made for
 
-  tests/golden/icp_sweep.npz      24 scan-to-scan icp_align runs (seeds 1..24) on >= 100 k-point scans, the
+  tests/golden/sweep_icp.npz      24 scan-to-scan icp_align runs (seeds 1..24) on >= 100 k-point scans, the
         reference's own icp_align (stop test included): final pose, error; iteration counts from ref_icp_iterate
         with the stop test on (same loop; asserted to end at the same pose bit for bit)
 
@@ -106,7 +106,7 @@ def gen_sweep(R):
         poses.append(T); errs.append(np.float32(e)); iters.append(done); T0s.append(T0); params.append([md, ma])
         sizes.append([len(s1["points"]), len(s0["points"])]); digests.append(sha(s1["points"]) + sha(s0["points"]))
         print(f"sweep seed {seed:2d}: n {len(s1['points'])} r {md:.3f} iters {done} err {e:.6f} ({time.time()-t:.1f} s)", flush=True)
-    np.savez_compressed(os.path.join(OUT, "icp_sweep.npz"), seeds=np.array(SWEEP_SEEDS), n_points=SWEEP_POINTS,
+    np.savez_compressed(os.path.join(OUT, "sweep_icp.npz"), seeds=np.array(SWEEP_SEEDS), n_points=SWEEP_POINTS,
                         pose=np.stack(poses), err=np.array(errs, np.float32), iters=np.array(iters, np.int32),
                         T0=np.stack(T0s), params=np.array(params, np.float32), sizes=np.array(sizes), in_sha=np.array(digests))
 

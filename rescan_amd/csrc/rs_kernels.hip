@@ -290,6 +290,20 @@ struct WaveLds
   float    nx[WAVE], ny[WAVE], nz[WAVE];   // their normals, same layout
   uint32_t slot[WAVE];     // their positions in the cell-sorted cloud
   uint32_t seg_a[WAVE], len_a[WAVE], seg_b[WAVE], pre[WAVE];   // row pieces of the current batch
+  uint32_t evals;          // profiling only (lane 0): candidates this wave staged and evaluated, flushed once by EvalScope
+};
+
+// Profiling only (GridView::evals non-null): the wave's candidate count goes to the sharded device counters ONCE, when the
+// wave leaves the kernel — an atomic per sweep was most of what WRITE_SIZE saw of k_label (75 MB per launch for 5 MB of
+// results: atomics execute at the memory side, 64 B each) and a good part of k_icp_corr's.
+struct EvalScope
+{
+  unsigned long long* evals; WaveLds& L; int lane;
+  __device__ __forceinline__ EvalScope( unsigned long long* e, WaveLds& l, int ln ) : evals( e ), L( l ), lane( ln ) { if( evals && lane == 0 ) L.evals = 0u; }
+  __device__ __forceinline__ ~EvalScope()
+  {
+    if( evals && lane == 0 && L.evals ) atomicAdd( evals + 8 * ( ( blockIdx.x + 37 * blockIdx.y ) & ( EVAL_SHARDS - 1 ) ), (unsigned long long)L.evals );   // sharded, one cache line each
+  }
 };
 
 // Stream every point of (out \ in) through the wave's LDS and call f( X, Y, Z, k ) for every
@@ -384,7 +398,7 @@ __device__ __forceinline__ uint32_t sweep_shell( const GridView& g, const CellBo
     }
     wave_lds_fence();
   }
-  if( g.evals && lane == 0 && evaluated ) atomicAdd( g.evals + 8 * ( ( blockIdx.x + 37 * blockIdx.y ) & ( EVAL_SHARDS - 1 ) ), (unsigned long long)evaluated );   // sharded, one cache line each
+  if( g.evals && lane == 0 ) L.evals += evaluated;       // (flushed by the kernel's EvalScope)
   return streamed;
 }
 
@@ -474,7 +488,7 @@ __device__ __forceinline__ bool sweep_by_rows( const GridView& g, const CellBox&
     wave_lds_fence();
     c0 = cn;
   }
-  if( g.evals && lane == 0 && ( t0 + t1 + t2 + t3 ) ) atomicAdd( g.evals + 8 * ( ( blockIdx.x + 37 * blockIdx.y ) & ( EVAL_SHARDS - 1 ) ), (unsigned long long)( ( t0 + t1 + t2 + t3 ) / 4 ) );   // (each candidate is tested by 16 lanes, not 64)
+  if( g.evals && lane == 0 ) L.evals += ( t0 + t1 + t2 + t3 ) / 4;   // (each candidate is tested by 16 lanes, not 64)
   return true;
 }
 
@@ -1098,9 +1112,15 @@ __device__ __forceinline__ void icp_iteration_reset( const IcpLaunch& L, int pro
     for( int k = threadIdx.x; k < STAT_SHARDS * 4; k += blockDim.x ) L.stat_acc[(size_t)prob * STAT_SHARDS * 4 + k] = 0ull;
 }
 
+#ifndef RS_XCD_MAP
+#define RS_XCD_MAP 1
+#endif
+// workgroups of phase A's natural part per XCD class (see k_icp_corr)
+__host__ __device__ inline int icp_blocks_per_xcd( int n_tiles ) { return ( ( n_tiles + WAVES_PER_BLOCK - 1 ) / WAVES_PER_BLOCK + 7 ) / 8; }
+
 // Phase A: one wave per tile, first shell(s) only; unsettled tiles are queued.
 #ifndef RS_ICP_OCC
-#define RS_ICP_OCC 6      // waves per SIMD the register allocation aims at: 80 VGPRs, 36 B of scratch per lane (7: 72 VGPRs, 80 B — slower and 100 MB more HBM-side traffic per search; 5: none, +3 % time)
+#define RS_ICP_OCC 5      // waves per SIMD the register allocation aims at: 95 VGPRs, no scratch (6: 80 VGPRs and 76 B of scratch per lane — same time, and every spilled dword is HBM-side traffic)
 #endif
 __global__ __launch_bounds__( BLOCK, RS_ICP_OCC ) void k_icp_corr( IcpLaunch L )
 {
@@ -1109,25 +1129,39 @@ __global__ __launch_bounds__( BLOCK, RS_ICP_OCC ) void k_icp_corr( IcpLaunch L )
   if( L.active[prob] == 0 ) return;
   const int lane = threadIdx.x & ( WAVE - 1 );
   const int wib = threadIdx.x / WAVE;
+  EvalScope eval_scope( L.tgt.evals, lds[wib], lane );
   // Slowest first: the kernel ends when its slowest tile does, and the slow tiles (several shells, a rank
   // pass) are the same from one iteration to the next.  The previous iteration listed them; the first
   // HEAVY_SLOTS wave slots of the grid take that list, the rest walk the tiles in their natural (Hilbert)
   // order — which the caches depend on — and skip the listed ones.
   int slot = blockIdx.x * WAVES_PER_BLOCK + wib;
   int tile;
+  // XCD-aware order of the natural (Hilbert) part: workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8
+  // share one), each XCD with its own 4 MB L2.  Walking the tiles in plain order would have every XCD touch every part of
+  // the 32 MB target cloud; instead XCD class c = b mod 8 walks the c-th eighth of the Hilbert order, so an XCD's L2 only
+  // ever sees its own part of the scene (and the seams).  Which XCD a class lands on does not matter.
+  auto natural_tile = [&]( int block ) -> int
+  {
+#if RS_XCD_MAP
+    const int per = icp_blocks_per_xcd( L.src.n_tiles );
+    return ( ( block & 7 ) * per + ( block >> 3 ) ) * WAVES_PER_BLOCK + wib;
+#else
+    return block * WAVES_PER_BLOCK + wib;
+#endif
+  };
   if( L.heavy_in )
   {
     const int* hv = L.heavy_in + (size_t)prob * ( L.src.n_tiles + HEAVY_SLOTS + 1 );     // [0] count | list HEAVY_SLOTS | per-tile position+1 or 0
     if( slot < HEAVY_SLOTS ) { if( slot >= min( uni( hv[0] ), HEAVY_SLOTS ) ) return; tile = uni( hv[1 + slot] ); }
     else
     {
-      tile = slot - HEAVY_SLOTS;
+      tile = natural_tile( (int)blockIdx.x - HEAVY_SLOTS / WAVES_PER_BLOCK );
       if( tile >= L.src.n_tiles ) return;
       const int listed = uni( hv[1 + HEAVY_SLOTS + tile] );
       if( listed > 0 && listed <= HEAVY_SLOTS ) return;       // a front slot has it
     }
   }
-  else { tile = slot; if( tile >= L.src.n_tiles ) return; }
+  else { tile = natural_tile( (int)blockIdx.x ); if( tile >= L.src.n_tiles ) return; }
   const int i = (int)L.src.tiles[tile] + lane;
   const bool active = i < (int)L.src.tiles[tile + 1];
 
@@ -1181,6 +1215,7 @@ __global__ __launch_bounds__( NW * WAVE, RS_COOP_OCC ) void k_icp_corr_coop( Icp
   if( L.active[prob] == 0 ) return;
   const int lane = threadIdx.x & ( WAVE - 1 );
   const int wib = threadIdx.x / WAVE;
+  EvalScope eval_scope( L.tgt.evals, lds[wib], lane );
   const int n_queued = L.coop_all ? L.src.n_tiles : L.queue_count[prob];     // coop_all: phase A was not launched, every tile is searched here
   Xform T1;
 #pragma unroll
@@ -1640,7 +1675,8 @@ void launch_icp_corr( const IcpLaunch& L, hipStream_t st )
   // queue_count is zero on entry: cleared once by the host, then by the workgroup that ends every iteration (icp_iteration_reset)
   // A launch of a few hundred tiles leaves every wave alone on its SIMD, i.e. latency-bound, and phase A's slowest tile
   // sets its time: such launches skip phase A and give every tile a workgroup straight away (coop_all).
-  dim3 grid( ( L.src.n_tiles + ( L.heavy_in ? HEAVY_SLOTS : 0 ) + WAVES_PER_BLOCK - 1 ) / WAVES_PER_BLOCK, L.n_prob );
+  static_assert( HEAVY_SLOTS % ( 8 * WAVES_PER_BLOCK ) == 0, "the front slots must not shift the XCD class of the natural part" );
+  dim3 grid( ( L.heavy_in ? HEAVY_SLOTS / WAVES_PER_BLOCK : 0 ) + 8 * icp_blocks_per_xcd( L.src.n_tiles ), L.n_prob );
   if( !L.coop_all ) hipLaunchKernelGGL( k_icp_corr, grid, dim3( BLOCK ), 0, st, L );
   // the queue length is only known on the device: a fixed grid strides over it
   int coop_blocks = L.src.n_tiles < 2048 ? L.src.n_tiles : 2048;
@@ -1699,6 +1735,7 @@ __global__ __launch_bounds__( BLOCK, RS_SCORE_OCC ) void k_score( ScoreLaunch L 
   const int pose = blockIdx.y;
   const int lane = threadIdx.x & ( WAVE - 1 );
   const int wib = threadIdx.x / WAVE;
+  EvalScope eval_scope( L.scene.evals, lds[wib], lane );
   const int tile = blockIdx.x * WAVES_PER_BLOCK + wib;
   if( tile >= L.obj.n_tiles ) return;
   const int i = (int)L.obj.tiles[tile] + lane;
@@ -1727,6 +1764,7 @@ __global__ __launch_bounds__( COOP_BLOCK ) void k_score_coop( ScoreLaunch L )
   __shared__ CoopLds<COOP_WAVES> coop;
   const int lane = threadIdx.x & ( WAVE - 1 );
   const int wib = threadIdx.x / WAVE;
+  EvalScope eval_scope( L.scene.evals, lds[wib], lane );
   const int n_queued = *L.queue_count;
   for( int b = blockIdx.x; b < n_queued; b += gridDim.x )
   {
@@ -1793,6 +1831,7 @@ __global__ __launch_bounds__( BLOCK, RS_LABEL_OCC ) void k_label( LabelLaunch L 
   __shared__ WaveLds lds[WAVES_PER_BLOCK];
   const int lane = threadIdx.x & ( WAVE - 1 );
   const int wib = threadIdx.x / WAVE;
+  EvalScope eval_scope( ( L.n_pl > 0 ? L.pl[0].g.evals : nullptr ), lds[wib], lane );
   const int tile = blockIdx.x * WAVES_PER_BLOCK + wib;
   if( tile >= L.scene.n_tiles ) return;
   const int i = (int)L.scene.tiles[tile] + lane;
@@ -1869,6 +1908,7 @@ __global__ __launch_bounds__( BLOCK ) void k_rows( RowsLaunch L )
   __shared__ WaveLds lds[WAVES_PER_BLOCK];
   const int lane = threadIdx.x & ( WAVE - 1 );
   const int wib = threadIdx.x / WAVE;
+  EvalScope eval_scope( L.tgt.evals, lds[wib], lane );
   const int tile = blockIdx.x * WAVES_PER_BLOCK + wib;
   if( tile >= L.q.n_tiles ) return;
   const int i = (int)L.q.tiles[tile] + lane;
@@ -1936,7 +1976,7 @@ __global__ __launch_bounds__( ROWS_WAVES * WAVE ) void k_rows_wave( GridView g, 
   RowsWaveLds& L = lds[wib];
   const float qx = q3[3 * qi], qy = q3[3 * qi + 1], qz = q3[3 * qi + 2];
   int x0 = 0, x1 = 0, y0 = 0, y1 = 0, z0 = 0, z1 = 0;
-  const bool grid = g.inv_cell > 0.0f;
+  const bool grid = g.inv_cell > 0.0f;       // (the one-cell brute layout has a one-entry table: cell (0,0,0) is the whole cloud)
   if( grid )
   {
     axis_range( qx, qx, radius, g.minx, g.inv_cell, g.w, x0, x1 );
@@ -1986,28 +2026,6 @@ __global__ __launch_bounds__( ROWS_WAVES * WAVE ) void k_rows_wave( GridView g, 
       count += (uint32_t)__popcll( mask );
     }
     wave_lds_fence();
-  }
-  if( !grid && !empty )
-  {
-    // one-cell (brute) layout: the whole cloud is the candidate list
-    for( uint32_t c0 = 0; c0 < (uint32_t)g.n; c0 += WAVE )
-    {
-      const uint32_t j = c0 + lane;
-      bool hit = false; float d2 = 0.0f; int idx = 0;
-      if( j < (uint32_t)g.n )
-      {
-        const float4 P = g.pos[j];
-        const float vx = P.x - qx, vy = P.y - qy, vz = P.z - qz;
-        d2 = vx * vx + vy * vy + vz * vz; idx = __float_as_int( P.w ); hit = d2 < radius_sq;
-      }
-      const unsigned long long mask = __ballot( hit );
-      if( hit )
-      {
-        const uint32_t at = count + (uint32_t)__builtin_amdgcn_mbcnt_hi( (uint32_t)( mask >> 32 ), __builtin_amdgcn_mbcnt_lo( (uint32_t)mask, 0u ) );
-        if( at < ROWS_CAP ) { L.d2[at] = d2; L.idx[at] = idx; }
-      }
-      count += (uint32_t)__popcll( mask );
-    }
   }
   if( count > ROWS_CAP ) { if( lane == 0 ) { atomicExch( overflow, 1 ); out_nn[qi] = -1; } return; }
   // bitonic sort of the first `count` entries (padded with +inf up to a power of two) by (dist², index)
@@ -2070,6 +2088,7 @@ __global__ __launch_bounds__( BLOCK ) void k_level_neighbours( LevelLaunch L )
   __shared__ WaveLds lds[WAVES_PER_BLOCK];
   const int lane = threadIdx.x & ( WAVE - 1 );
   const int wib = threadIdx.x / WAVE;
+  EvalScope eval_scope( L.tgt.evals, lds[wib], lane );
   const int tile = blockIdx.x * WAVES_PER_BLOCK + wib;
   if( tile >= L.q.n_tiles ) return;
   const int i = (int)L.q.tiles[tile] + lane;

@@ -4,7 +4,7 @@
   computes for the same inputs (oracle/gen_golden_bench.py): pose / error after the 10 fixed ICP iterations, per-iteration
   correspondence counts, the 256 alignment scores; labels / min_dists against the C restatement's (the reference's label TU
   needs the un-vendored gco header).
-* 24 scan-to-scan icp_align runs on >= 100 k-point scans against tests/golden/icp_sweep.npz (the reference's own icp_align):
+* 24 scan-to-scan icp_align runs on >= 100 k-point scans against tests/golden/sweep_icp.npz (the reference's own icp_align):
   the fp64-moment estimator used for sources above RS_HIP_REF_ORDER_BELOW, and the reference-order estimator.
 * the sharded route of bench.py (--shard / --gpus N): world of one, and a 2-way split simulated on one device, bit-identical
   to the unsharded entry points.
@@ -139,7 +139,7 @@ def test_scan_sized_icp_sweep_vs_reference(capi):
     bit for bit.  fp64-moment estimator (the default above 65 536 source points): the distances are REPORTED and counted —
     the moments are exact where the reference's fp32 chains carry their own rounding, so a run may end
     farther than 1e-4 from the reference without either being wrong; the policy bound is on how many do."""
-    g = load_golden("icp_sweep.npz")
+    g = load_golden("sweep_icp.npz")
     prev = capi.icp_reference_order_below(-1)
     over, worst, iter_diff, exact = [], 0.0, 0, 0
     try:
