@@ -244,7 +244,7 @@ class Sharded:
             self.dist.all_gather_into_tensor(recv, send)
         torch.cuda.current_stream().synchronize()
         t1 = time.perf_counter()
-        out = rd.shard_fold(capi, self.lay, recv, outbuf)
+        out = rd.shard_fold(capi, self.lay, recv, outbuf, scene=self.w["scan1"])
         self.t_gather += t1 - t0; self.t_fold += time.perf_counter() - t1; self.n_exchanges += 1
         return out
 

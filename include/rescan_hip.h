@@ -145,8 +145,11 @@ int rs_hip_assign_labels( const rs_hip_cloud_t* scene, const rs_hip_placement_t*
 /* The per-placement "unary cost rows" of the same loop, for sharding placements across
  * GPUs: rows[i*scene_n + j] = dist² of scene point j to placement i's nearest object point
  * if one lies within the radius AND passes the 70° normal gate, +inf otherwise.
- * rows_device != 0: `rows` is a device pointer (e.g. a torch tensor that will be
- * all-gathered); otherwise a host pointer. */
+ * rows_device = 0: `rows` is a host pointer.  rows_device = 1: a device pointer (e.g. a torch tensor that will be
+ * all-gathered), rows indexed by scene point in input order like the host form.  rows_device = 2: a device pointer, rows
+ * indexed by the scene cloud's QUERY slot — the order the kernel produces them in (coalesced, no re-ordering pass);
+ * rs_hip_fold_label_rows_device takes such rows when it is given the same scene cloud (every rank of the multi-GPU route
+ * builds the same cloud from the same scene, so the rows of all ranks share that order). */
 int rs_hip_label_rows( const rs_hip_cloud_t* scene, const rs_hip_placement_t* placements,
                        int32_t n, float* rows, int rows_device );
 
@@ -162,7 +165,8 @@ void rs_hip_combine_label_rows( const float* rows, int32_t n_rows, int64_t scene
  * are host arrays: continued from the caller's values like rs_hip_assign_labels, or — fresh != 0 — started on the device
  * from the loop's initial state (label 0, min_dist 1e9: rs_pointcloud_filters.cpp:799-802,820) without an upload. */
 int rs_hip_fold_label_rows_device( const float* rows_device, const int64_t* row_offsets, int32_t n_rows, int64_t scene_n,
-                                   int32_t label_base, int8_t* labels, float* min_dists, int32_t fresh );
+                                   int32_t label_base, int8_t* labels, float* min_dists, int32_t fresh,
+                                   const rs_hip_cloud_t* rows_in_query_order_of /* NULL: rows in input order */ );
 
 /* rspf_arrangement_to_labels ordering + two passes (lib/rs/rs_pointcloud_filters.cpp:780-848):
  * sorts placement indices (dynamic first, then by class index; stable), runs the dynamic

@@ -45,7 +45,7 @@ SIGNATURES = {
     "rs_hip_label_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int]),
     "rs_hip_combine_label_rows": (None, [f32p, C.c_int32, C.c_int64, C.c_int32, i8p, f32p]),
     "rs_hip_fold_label_rows_device": (C.c_int, [C.c_void_p, np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS"), C.c_int32,
-                                                C.c_int64, C.c_int32, i8p, f32p, C.c_int32]),
+                                                C.c_int64, C.c_int32, i8p, f32p, C.c_int32, C.c_void_p]),
     "rs_hip_arrangement_to_labels": (C.c_int, [C.c_void_p, f32p, C.c_void_p, i32p, i32p, C.c_int32, C.c_float,
                                                C.c_int, i8p, f32p, i32p]),
     "rs_hip_compute_neighborhood": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float, i32p, i32p, f32p,
@@ -261,12 +261,13 @@ def assign_labels(scene, poses, objects, radii, labels, min_dists, label_base=0)
     return labels, min_dists
 
 
-def label_rows(scene, poses, objects, radii, out_device_ptr=None):
-    """Per-placement unary rows.  With out_device_ptr the rows stay on the GPU (for an all-gather)."""
+def label_rows(scene, poses, objects, radii, out_device_ptr=None, query_order=False):
+    """Per-placement unary rows.  With out_device_ptr the rows stay on the GPU (for an all-gather): indexed by scene point
+    in input order, or — query_order — by the scene cloud's query slot (what the kernel writes, no re-ordering pass)."""
     arr = _placements(poses, objects, radii)
     n = len(objects)
     if out_device_ptr is not None:
-        _check(load().rs_hip_label_rows(scene.handle, C.addressof(arr), n, C.c_void_p(out_device_ptr), 1))
+        _check(load().rs_hip_label_rows(scene.handle, C.addressof(arr), n, C.c_void_p(out_device_ptr), 2 if query_order else 1))
         return None
     rows = np.zeros((n, scene.n), np.float32)
     _check(load().rs_hip_label_rows(scene.handle, C.addressof(arr), n, rows.ctypes.data_as(C.c_void_p), 0))
@@ -279,17 +280,20 @@ def combine_label_rows(rows, labels, min_dists, label_base=0):
     return labels, min_dists
 
 
-def fold_label_rows_device(rows_device_ptr, row_offsets, scene_n, labels=None, min_dists=None, label_base=0, fresh=None):
+def fold_label_rows_device(rows_device_ptr, row_offsets, scene_n, labels=None, min_dists=None, label_base=0, fresh=None, query_order_of=None):
     """Ordered arg-min over rows that sit in device memory (row k at rows_device_ptr + 4*row_offsets[k]).
     fresh (default: when no labels / min_dists are given): the fold starts from the loop's initial state (label 0, 1e9)
-    on the device; labels / min_dists, if given, only receive the result (e.g. pinned buffers that are reused)."""
+    on the device; labels / min_dists, if given, only receive the result (e.g. pinned buffers that are reused).
+    query_order_of: the scene Cloud whose query order the rows are in (label_rows(..., query_order=True)); the result is
+    returned in input order either way."""
     off = np.ascontiguousarray(row_offsets, np.int64)
     if fresh is None:
         fresh = labels is None or min_dists is None
     if labels is None or min_dists is None:
         labels = np.empty(int(scene_n), np.int8); min_dists = np.empty(int(scene_n), np.float32)
     _check(load().rs_hip_fold_label_rows_device(C.c_void_p(rows_device_ptr), off, len(off), int(scene_n), int(label_base),
-                                                labels, min_dists, 1 if fresh else 0))
+                                                labels, min_dists, 1 if fresh else 0,
+                                                query_order_of.handle if query_order_of is not None else None))
     return labels, min_dists
 
 

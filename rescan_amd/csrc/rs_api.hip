@@ -98,7 +98,7 @@ struct Workspace
 {
   DevBuf state, slot, d2, dot, stat_acc, mom_part, res, wexp, queue, queue_count;   // ICP
   DevBuf poses, score_part, scores;                                             // score
-  DevBuf plc, labels, mind, fold_off;                                           // labels
+  DevBuf plc, labels, mind, fold_off, labels_o, mind_o, rows_o;                 // labels (state in query order; *_o: input order)
   DevBuf q4, rd2, ridx, rnn, rows;                                              // rows / misc
   DevBuf enor, ecount, eoffset, e1, e2, ew;                                     // neighbourhood edges
   DevBuf cert_r, cert_dot, cert_slack;                                                    // ICP certificates
@@ -624,6 +624,7 @@ int icp_prepare( IcpCtx& cx, const rs_hip_cloud_t* src, const rs_hip_cloud_t* tg
   L.solve = 0; L.iter_index = 0; L.fixed_iters = 0;
   L.seed = getenv( "RS_HIP_NO_SEED" ) ? 0 : 1;
   L.by_rows = getenv( "RS_HIP_NO_BY_ROWS" ) ? 0 : 1;
+  L.bounded_only = getenv( "RS_HIP_NO_BOUNDED_ONLY" ) ? 0 : 1;
   L.cert_r = nullptr; L.cert_dot = nullptr; L.cert_slack = nullptr; L.tgt_nor_max = tgt->nor_max;
   L.m_slot = g_ws.slot.as<int>(); L.m_d2 = g_ws.d2.as<float>(); L.m_dot = g_ws.dot.as<float>();
   L.stat_acc = nullptr;       // set by the align loop (fp64 estimator only)
@@ -1051,6 +1052,43 @@ static int label_upload_placements( const rs_hip_placement_t* pl, int32_t n )
   return RS_HIP_OK;
 }
 
+// The label state of a scene lives on the device in the scene's QUERY order (g_ws.labels / g_ws.mind) while a call works on
+// it; host arrays are in input order.  The two orders are exchanged by gathering (rs_kernels.hip: k_label_to_*_order).
+static int label_state_upload( const rs_hip_cloud_t* scene, const int8_t* labels, const float* min_dists )
+{
+  const size_t ns = (size_t)scene->n;
+  int rc;
+  if( ( rc = g_ws.labels.ensure( ns ) ) || ( rc = g_ws.mind.ensure( ns * 4 ) ) || ( rc = g_ws.labels_o.ensure( ns ) ) || ( rc = g_ws.mind_o.ensure( ns * 4 ) ) ) return rc;
+  HIP_TRY( hipMemcpyAsync( g_ws.labels_o.p, labels, ns, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipMemcpyAsync( g_ws.mind_o.p, min_dists, ns * 4, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+  launch_label_to_query_order( scene->d_qpos, (long long)ns, g_ws.mind_o.as<float>(), g_ws.mind.as<float>(), g_ws.labels_o.as<int8_t>(), g_ws.labels.as<int8_t>(), g_stream );
+  return RS_HIP_OK;
+}
+static int label_state_download( const rs_hip_cloud_t* scene, int8_t* labels, float* min_dists )
+{
+  const size_t ns = (size_t)scene->n;
+  int rc;
+  if( ( rc = g_ws.labels_o.ensure( ns ) ) || ( rc = g_ws.mind_o.ensure( ns * 4 ) ) ) return rc;
+  launch_label_to_input_order( scene->d_qby_orig, (long long)ns, g_ws.mind.as<float>(), g_ws.mind_o.as<float>(), 1, g_ws.labels.as<int8_t>(), g_ws.labels_o.as<int8_t>(), g_stream );
+  HIP_TRY( hipMemcpyAsync( labels, g_ws.labels_o.p, ns, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipMemcpyAsync( min_dists, g_ws.mind_o.p, ns * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
+  return RS_HIP_OK;
+}
+// one launch of the placement loop over the uploaded placements [first, first + n) (label_upload_placements) on the device-resident state
+static int label_chain( const rs_hip_cloud_t* scene, int32_t first, int32_t n, int32_t label_base, bool fresh )
+{
+  int rc;
+  const size_t ns = (size_t)scene->n;
+  if( ( rc = g_ws.labels.ensure( ns ) ) || ( rc = g_ws.mind.ensure( ns * 4 ) ) ) return rc;
+  LabelLaunch L{};
+  L.scene = scene->qview; L.pl = g_ws.plc.as<PlacementDev>() + first; L.n_pl = n;
+  L.label_base = label_base; L.gate_tmin = label_gate_threshold();
+  L.labels = g_ws.labels.as<int8_t>(); L.min_d = g_ws.mind.as<float>(); L.rows = nullptr; L.fresh = fresh ? 1 : 0;
+  { ProfScope ps( "nn_label" ); launch_label( L, g_stream ); }
+  return RS_HIP_OK;
+}
+
 int rs_hip_assign_labels( const rs_hip_cloud_t* scene, const rs_hip_placement_t* placements,
                           int32_t n, int32_t label_base, int8_t* labels, float* min_dists )
 {
@@ -1058,38 +1096,32 @@ int rs_hip_assign_labels( const rs_hip_cloud_t* scene, const rs_hip_placement_t*
   if( !scene || !scene->has_nor || !labels || !min_dists || n < 0 || ( n > 0 && !placements ) ) { set_err( "assign_labels: bad arguments" ); return RS_HIP_E_ARG; }
   if( label_base + n > 127 ) { set_err( "assign_labels: more than 127 placements do not fit the reference's int8 labels" ); return RS_HIP_E_CAPACITY; }
   if( n == 0 || scene->n == 0 ) return RS_HIP_OK;
-  const size_t ns = (size_t)scene->n;
-  if( ( rc = label_upload_placements( placements, n ) ) || ( rc = g_ws.labels.ensure( ns ) ) || ( rc = g_ws.mind.ensure( ns * 4 ) ) ) return rc;
-  HIP_TRY( hipMemcpyAsync( g_ws.labels.p, labels, ns, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
-  HIP_TRY( hipMemcpyAsync( g_ws.mind.p, min_dists, ns * 4, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
-  LabelLaunch L{};
-  L.scene = scene->qview; L.pl = g_ws.plc.as<PlacementDev>(); L.n_pl = n;
-  L.label_base = label_base; L.gate_tmin = label_gate_threshold();
-  L.labels = g_ws.labels.as<int8_t>(); L.min_d = g_ws.mind.as<float>(); L.rows = nullptr;
-  { ProfScope ps( "nn_label" ); launch_label( L, g_stream ); }
-  HIP_TRY( hipMemcpyAsync( labels, g_ws.labels.p, ns, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
-  HIP_TRY( hipMemcpyAsync( min_dists, g_ws.mind.p, ns * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
-  HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
-  return RS_HIP_OK;
+  if( ( rc = label_upload_placements( placements, n ) ) || ( rc = label_state_upload( scene, labels, min_dists ) ) || ( rc = label_chain( scene, 0, n, label_base, false ) ) ) return rc;
+  return label_state_download( scene, labels, min_dists );
 }
 
 int rs_hip_label_rows( const rs_hip_cloud_t* scene, const rs_hip_placement_t* placements,
                        int32_t n, float* rows, int rows_device )
 {
   int rc = ensure_ready(); if( rc ) return rc;
-  if( !scene || !scene->has_nor || !rows || n < 0 || ( n > 0 && !placements ) ) { set_err( "label_rows: bad arguments" ); return RS_HIP_E_ARG; }
+  if( !scene || !scene->has_nor || !rows || n < 0 || ( n > 0 && !placements ) || rows_device < 0 || rows_device > 2 ) { set_err( "label_rows: bad arguments" ); return RS_HIP_E_ARG; }
   if( n == 0 || scene->n == 0 ) return RS_HIP_OK;
   const size_t ns = (size_t)scene->n;
   if( ( rc = label_upload_placements( placements, n ) ) ) return rc;
+  // the kernel writes a row in the scene's query order (coalesced); rows_device = 2 hands that to the caller as it is
   float* d_rows = rows;
-  if( !rows_device ) { if( ( rc = g_ws.rows.ensure( (size_t)n * ns * 4 ) ) ) return rc; d_rows = g_ws.rows.as<float>(); }
+  if( rows_device != 2 ) { if( ( rc = g_ws.rows.ensure( (size_t)n * ns * 4 ) ) ) return rc; d_rows = g_ws.rows.as<float>(); }
   LabelLaunch L{};
   L.scene = scene->qview; L.pl = g_ws.plc.as<PlacementDev>(); L.n_pl = n;
   L.label_base = 0; L.gate_tmin = label_gate_threshold(); L.labels = nullptr; L.min_d = nullptr; L.rows = d_rows;
   { ProfScope ps( "nn_label" ); launch_label( L, g_stream ); }
-  if( !rows_device )
+  if( rows_device == 2 ) return RS_HIP_OK;
+  float* d_out = rows;
+  if( rows_device == 0 ) { if( ( rc = g_ws.rows_o.ensure( (size_t)n * ns * 4 ) ) ) return rc; d_out = g_ws.rows_o.as<float>(); }
+  launch_label_to_input_order( scene->d_qby_orig, (long long)ns, d_rows, d_out, n, nullptr, nullptr, g_stream );
+  if( rows_device == 0 )
   {
-    HIP_TRY( hipMemcpyAsync( rows, d_rows, (size_t)n * ns * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+    HIP_TRY( hipMemcpyAsync( rows, d_out, (size_t)n * ns * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
     HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
   }
   return RS_HIP_OK;
@@ -1107,22 +1139,30 @@ void rs_hip_combine_label_rows( const float* rows, int32_t n_rows, int64_t scene
 }
 
 int rs_hip_fold_label_rows_device( const float* rows_device, const int64_t* row_offsets, int32_t n_rows, int64_t scene_n,
-                                   int32_t label_base, int8_t* labels, float* min_dists, int32_t fresh )
+                                   int32_t label_base, int8_t* labels, float* min_dists, int32_t fresh,
+                                   const rs_hip_cloud_t* rows_in_query_order_of )
 {
   int rc = ensure_ready(); if( rc ) return rc;
   if( n_rows < 0 || scene_n < 0 || !labels || !min_dists || ( n_rows > 0 && ( !rows_device || !row_offsets ) ) ) { set_err( "fold_label_rows_device: bad arguments" ); return RS_HIP_E_ARG; }
   if( label_base + n_rows > 127 ) { set_err( "fold_label_rows_device: more than 127 placements do not fit the reference's int8 labels" ); return RS_HIP_E_CAPACITY; }
+  const rs_hip_cloud_t* qc = rows_in_query_order_of;
+  if( qc && qc->n != scene_n ) { set_err( "fold_label_rows_device: the cloud has %d points, the rows %lld", qc->n, (long long)scene_n ); return RS_HIP_E_ARG; }
   if( n_rows == 0 || scene_n == 0 ) return RS_HIP_OK;
   const size_t ns = (size_t)scene_n;
   if( ( rc = g_ws.labels.ensure( ns ) ) || ( rc = g_ws.mind.ensure( ns * 4 ) ) || ( rc = g_ws.fold_off.ensure( (size_t)n_rows * 8 ) ) ) return rc;
   if( !fresh )
   {
-    HIP_TRY( hipMemcpyAsync( g_ws.labels.p, labels, ns, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
-    HIP_TRY( hipMemcpyAsync( g_ws.mind.p, min_dists, ns * 4, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+    if( qc ) { if( ( rc = label_state_upload( qc, labels, min_dists ) ) ) return rc; }
+    else
+    {
+      HIP_TRY( hipMemcpyAsync( g_ws.labels.p, labels, ns, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+      HIP_TRY( hipMemcpyAsync( g_ws.mind.p, min_dists, ns * 4, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+    }
   }
   HIP_TRY( hipMemcpyAsync( g_ws.fold_off.p, row_offsets, (size_t)n_rows * 8, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
   { ProfScope ps( "label_fold" );
     launch_label_fold( rows_device, g_ws.fold_off.as<long long>(), n_rows, (long long)scene_n, label_base, g_ws.labels.as<int8_t>(), g_ws.mind.as<float>(), fresh != 0, g_stream ); }
+  if( qc ) return label_state_download( qc, labels, min_dists );
   HIP_TRY( hipMemcpyAsync( labels, g_ws.labels.p, ns, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
   HIP_TRY( hipMemcpyAsync( min_dists, g_ws.mind.p, ns * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
   HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
@@ -1137,8 +1177,10 @@ int rs_hip_arrangement_to_labels( const rs_hip_cloud_t* scene,
 {
   int rc = ensure_ready(); if( rc ) return rc;
   if( !scene || !labels || !min_dists || n < 0 || ( n > 0 && ( !poses || !objects || !is_static || !class_idx ) ) ) { set_err( "arrangement_to_labels: bad arguments" ); return RS_HIP_E_ARG; }
+  for( int i = 0; i < n; ++i ) if( !objects[i] || !objects[i]->has_nor ) { set_err( "arrangement_to_labels: placement %d has no object cloud with normals", i ); return RS_HIP_E_ARG; }
   const int64_t ns = scene->n;
-  for( int64_t j = 0; j < ns; ++j ) { labels[j] = 0; min_dists[j] = 1e9; }                 // :799-802, :820
+  if( n > 127 ) { set_err( "arrangement_to_labels: more than 127 placements do not fit the reference's int8 labels" ); return RS_HIP_E_CAPACITY; }
+  if( !scene->has_nor && ns > 0 && n > 0 ) { set_err( "arrangement_to_labels: the scene cloud needs normals" ); return RS_HIP_E_ARG; }
   // :823-827 — qsort by (is_static << 10 | class_idx); glibc's qsort is a stable merge sort
   std::vector<int32_t> ord( n );
   for( int i = 0; i < n; ++i ) ord[i] = i;
@@ -1153,9 +1195,20 @@ int rs_hip_arrangement_to_labels( const rs_hip_cloud_t* scene,
     std::memcpy( pl[i].pose, poses + 16 * ord[i], 64 ); pl[i].object = objects[ord[i]];
     pl[i].radius = ( i < first_static ) ? radius : ( prioritize_static ? radius : 1.5f * radius );   // :837-848
   }
-  if( ( rc = rs_hip_assign_labels( scene, pl.data(), first_static, 0, labels, min_dists ) ) ) return rc;
-  if( prioritize_static ) for( int64_t j = 0; j < ns; ++j ) min_dists[j] = 1e9;              // :841-844
-  return rs_hip_assign_labels( scene, pl.data() + first_static, n - first_static, first_static, labels, min_dists );
+  if( ns == 0 ) return RS_HIP_OK;
+  if( n == 0 ) { for( int64_t j = 0; j < ns; ++j ) { labels[j] = 0; min_dists[j] = 1e9; } return RS_HIP_OK; }     // :799-802, :820
+  // Both passes run on the device-resident state (query order), which starts from (label 0, min_dist 1e9) inside the first
+  // launch; only the final labels / min_dists come back (one gather to input order, one download).
+  if( ( rc = label_upload_placements( pl.data(), n ) ) ) return rc;          // all of them once: the two launches read their parts
+  bool have_state = false;
+  if( first_static > 0 ) { if( ( rc = label_chain( scene, 0, first_static, 0, true ) ) ) return rc; have_state = true; }
+  if( prioritize_static && have_state )                                                      // :841-844: min_dists start over, labels stay
+  {
+    const float big = 1e9f; uint32_t bits; std::memcpy( &bits, &big, 4 );
+    HIP_TRY( hipMemsetD32Async( (hipDeviceptr_t)g_ws.mind.p, (int)bits, (size_t)ns, g_stream ), RS_HIP_E_RUNTIME );
+  }
+  if( ( rc = label_chain( scene, first_static, n - first_static, first_static, !have_state ) ) ) return rc;
+  return label_state_download( scene, labels, min_dists );
 }
 
 // ------------------------------------------------------------------------------------------

@@ -92,6 +92,7 @@ struct IcpLaunch
   int*    ticket;       // (unused, kept zero)
   int     warm;         // m_slot holds last iteration's matches: use them as starting candidates
   int     seed;         // (when !warm) start from the best usable point of the query's own cell
+  int     bounded_only; // (when warm) phase A only takes tiles whose lanes all start from a candidate; the rest goes straight to the cooperative kernel
   int     by_rows;      // (when warm) per-row sweep of the tiles whose lanes all start from a candidate (rs_kernels.hip: sweep_by_rows)
   // certificates issued by every search and consulted when a point has no usable previous match (rs_kernels.hip: icp_certificate); null = off
   float*  cert_r;       // n_prob x nq
@@ -137,11 +138,15 @@ struct LabelLaunch
   const PlacementDev* pl;      // device array
   int          n_pl, label_base;
   float        gate_tmin;
-  int8_t*      labels;         // scene original order (chain mode) or null
-  float*       min_d;          // scene original order (chain mode) or null
-  float*       rows;           // n_pl x ns rows (row mode) or null
+  int8_t*      labels;         // scene QUERY order (chain mode) or null
+  float*       min_d;          // scene QUERY order (chain mode) or null
+  float*       rows;           // n_pl x ns rows, QUERY order (row mode) or null
+  int          fresh;          // chain mode: start from (label 0, min_dist 1e9) instead of reading labels / min_d
 };
 void launch_label( const LabelLaunch& L, hipStream_t st );
+// between a cloud's query order and its input order, by gathering (n_f float arrays of n entries back to back, and/or one int8 array)
+void launch_label_to_input_order( const int* by_orig, long long n, const float* in_f, float* out_f, int n_f, const int8_t* in_b, int8_t* out_b, hipStream_t st );
+void launch_label_to_query_order( const float4* qpos, long long n, const float* in_f, float* out_f, const int8_t* in_b, int8_t* out_b, hipStream_t st );
 // ordered fold of device-resident rows (row k at rows + offsets[k], n floats each; offsets is a device array)
 void launch_label_fold( const float* rows, const long long* offsets, int n_rows, long long n, int label_base, int8_t* labels, float* min_d, bool fresh, hipStream_t st );
 

@@ -697,7 +697,11 @@ __device__ __forceinline__ CellBox box_clip( const CellBox& a, const CellBox& c 
 // queues the tile for the cooperative kernel, which sweeps the whole box with several waves
 // (a lone wave needs ~0.7 ms for the ~10^4 candidates of a cluttered corner; the bulk of the
 // tiles settle in the first shell with a few hundred).
-template <bool GATED, bool WARM = false>
+// BOUNDED_ONLY (the warm ICP iterations' phase A): only the one-sweep path of a tile whose lanes all start from a candidate;
+// any other tile is handed off at once (*handoff) — the cooperative kernel gives it a workgroup straight away instead of
+// after a lone wave's first shells, and this instantiation carries no shell loop (registers: phase A then fits 6 waves per
+// SIMD without scratch).
+template <bool GATED, bool WARM = false, bool BOUNDED_ONLY = false>
 __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
                                               float qx, float qy, float qz, float nx, float ny, float nz,
                                               float radius, float radius_sq, float tmin, int K,
@@ -727,6 +731,7 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
   }
   cur = core; prev = core;
   bool have_prev = false;
+  if( BOUNDED_ONLY && !all_bounded ) { *handoff = true; return m; }
   if( all_bounded )
   {
     // Every lane starts from a genuine candidate (ICP iterations >= 2): whatever can beat or precede it
@@ -744,7 +749,7 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
     if( dbg_unsettled ) { dbg_unsettled[1] = (int)streamed; dbg_unsettled[3] = 1; }
     sweeps = 1;
   }
-  else
+  else if( !BOUNDED_ONLY )
   {
   // shells: the tile's own cells first (they hold the nearest candidates, so the per-lane bounds are
   // tight before the bulk arrives), then grown by 1, 2, 4, ... cells.  Of each shell only the part within
@@ -1119,10 +1124,18 @@ __device__ __forceinline__ void icp_iteration_reset( const IcpLaunch& L, int pro
 __host__ __device__ inline int icp_blocks_per_xcd( int n_tiles ) { return ( ( n_tiles + WAVES_PER_BLOCK - 1 ) / WAVES_PER_BLOCK + 7 ) / 8; }
 
 // Phase A: one wave per tile, first shell(s) only; unsettled tiles are queued.
-#ifndef RS_ICP_OCC
-#define RS_ICP_OCC 5      // waves per SIMD the register allocation aims at: 95 VGPRs, no scratch (6: 80 VGPRs and 76 B of scratch per lane — same time, and every spilled dword is HBM-side traffic)
+// Waves per SIMD the register allocation aims at.  6 = 80 VGPRs: the warm instantiation (no shell loop) then keeps 16 B of
+// scratch per lane, the cold one (iteration 0 only) 36 B; 5 = 87-95 VGPRs, no scratch at all.  Measured on the bench
+// (interleaved repeats, profiles/r02/ab_*.txt): 6 waves are 2.4 % faster per concurrent step, 5 waves move ~15 MB less per
+// search (HBM-side traffic 1.7x instead of 1.9x the algorithmic bytes).  `value` is the metric: 6.
+#ifndef RS_ICP_WARM_OCC
+#define RS_ICP_WARM_OCC 6
 #endif
-__global__ __launch_bounds__( BLOCK, RS_ICP_OCC ) void k_icp_corr( IcpLaunch L )
+#ifndef RS_ICP_OCC
+#define RS_ICP_OCC 6
+#endif
+template <bool BOUNDED_ONLY>
+__global__ __launch_bounds__( BLOCK, BOUNDED_ONLY ? RS_ICP_WARM_OCC : RS_ICP_OCC ) void k_icp_corr( IcpLaunch L )
 {
   __shared__ WaveLds lds[WAVES_PER_BLOCK];
   const int prob = blockIdx.y;
@@ -1176,7 +1189,7 @@ __global__ __launch_bounds__( BLOCK, RS_ICP_OCC ) void k_icp_corr( IcpLaunch L )
   int unsettled[4] = { 0, 0, 0, 0 };
   const Match init = icp_warm_start( L, prob, i, active, qx, qy, qz, nx, ny, nz );
   const bool search = active & !icp_certificate( L, prob, i, active & !init.found, qx, qy, qz, nx, ny, nz );
-  Match m = tile_search<true, true>( L.tgt, search, qx, qy, qz, nx, ny, nz, L.radius, L.radius_sq, L.gate_tmin, L.K,
+  Match m = tile_search<true, true, BOUNDED_ONLY>( L.tgt, search, qx, qy, qz, nx, ny, nz, L.radius, L.radius_sq, L.gate_tmin, L.K,
                                lds[wib], lane, L.solo_stages, &handoff, DBG( L ) ? unsettled : nullptr, init, &sweeps, L.by_rows != 0 );
   if( L.heavy_out && lane == 0 )
   {
@@ -1677,7 +1690,11 @@ void launch_icp_corr( const IcpLaunch& L, hipStream_t st )
   // sets its time: such launches skip phase A and give every tile a workgroup straight away (coop_all).
   static_assert( HEAVY_SLOTS % ( 8 * WAVES_PER_BLOCK ) == 0, "the front slots must not shift the XCD class of the natural part" );
   dim3 grid( ( L.heavy_in ? HEAVY_SLOTS / WAVES_PER_BLOCK : 0 ) + 8 * icp_blocks_per_xcd( L.src.n_tiles ), L.n_prob );
-  if( !L.coop_all ) hipLaunchKernelGGL( k_icp_corr, grid, dim3( BLOCK ), 0, st, L );
+  if( !L.coop_all )
+  {
+    if( L.warm && L.bounded_only ) hipLaunchKernelGGL( k_icp_corr<true>, grid, dim3( BLOCK ), 0, st, L );
+    else                           hipLaunchKernelGGL( k_icp_corr<false>, grid, dim3( BLOCK ), 0, st, L );
+  }
   // the queue length is only known on the device: a fixed grid strides over it
   int coop_blocks = L.src.n_tiles < 2048 ? L.src.n_tiles : 2048;
   const dim3 cgrid( coop_blocks > 0 ? coop_blocks : 1, L.n_prob );
@@ -1838,11 +1855,14 @@ __global__ __launch_bounds__( BLOCK, RS_LABEL_OCC ) void k_label( LabelLaunch L 
   const bool active = i < (int)L.scene.tiles[tile + 1];
   float4 p = make_float4( 0, 0, 0, 0 ), n = make_float4( 0, 0, 0, 0 );
   if( active ) { p = L.scene.pos[i]; n = L.scene.nor[i]; }
-  const int orig = __float_as_int( p.w );
 
-  float best_min = 1e9f;
+  // Everything this kernel reads and writes per point is indexed by the point's QUERY slot i: coalesced.  (Indexed by the
+  // original index — a random permutation of the slots — every 4-byte access was its own memory transaction: 75 MB written
+  // and 215 MB fetched per launch for 5 MB of results.)  k_label_to_input_order / k_label_to_query_order move whole arrays
+  // between the two orders by GATHERING, whose random side is a read that the L2 absorbs.
+  float best_min = 1e9f;                                                       // :799-802,820
   int label = 0;
-  if( active && L.min_d ) { best_min = L.min_d[orig]; label = L.labels[orig]; }
+  if( active && L.min_d && !L.fresh ) { best_min = L.min_d[i]; label = L.labels[i]; }
 
   for( int k = 0; k < L.n_pl; ++k )
   {
@@ -1863,15 +1883,45 @@ __global__ __launch_bounds__( BLOCK, RS_LABEL_OCC ) void k_label( LabelLaunch L 
       float dot = fabsf( n1x * n2x + n1y * n2y + n1z * n2z );                  // :769
       ok = ( dot >= L.gate_tmin ) && ( dot <= 1.0f );
     }
-    if( L.rows ) { if( active ) L.rows[(size_t)k * L.scene.n + orig] = ok ? m.d2 : INFINITY; }
+    if( L.rows ) { if( active ) L.rows[(size_t)k * L.scene.n + i] = ok ? m.d2 : INFINITY; }
     else if( ok ) { best_min = m.d2; label = L.label_base + k + 1; }
   }
-  if( active && L.min_d ) { L.min_d[orig] = best_min; L.labels[orig] = (int8_t)label; }
+  if( active && L.min_d ) { L.min_d[i] = best_min; L.labels[i] = (int8_t)label; }
 }
 
 void launch_label( const LabelLaunch& L, hipStream_t st )
 {
   hipLaunchKernelGGL( k_label, dim3( ( L.scene.n_tiles + WAVES_PER_BLOCK - 1 ) / WAVES_PER_BLOCK ), dim3( BLOCK ), 0, st, L );
+}
+
+// query order -> input order: thread j (an original index) reads its slot's values.  n_f float arrays of n entries, one after
+// the other, and (optionally) one int8 array.
+__global__ __launch_bounds__( BLOCK ) void k_label_to_input_order( const int* by_orig, long long n, const float* in_f, float* out_f, int n_f,
+                                                                   const int8_t* in_b, int8_t* out_b )
+{
+  const long long j = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if( j >= n ) return;
+  const int s = by_orig[j];
+  for( int a = 0; a < n_f; ++a ) out_f[(size_t)a * n + j] = in_f[(size_t)a * n + s];
+  if( in_b ) out_b[j] = in_b[s];
+}
+// input order -> query order: thread s (a slot) reads the values of its original index (pos[s].w)
+__global__ __launch_bounds__( BLOCK ) void k_label_to_query_order( const float4* qpos, long long n, const float* in_f, float* out_f,
+                                                                   const int8_t* in_b, int8_t* out_b )
+{
+  const long long s = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if( s >= n ) return;
+  const int j = __float_as_int( qpos[s].w );
+  if( in_f ) out_f[s] = in_f[j];
+  if( in_b ) out_b[s] = in_b[j];
+}
+void launch_label_to_input_order( const int* by_orig, long long n, const float* in_f, float* out_f, int n_f, const int8_t* in_b, int8_t* out_b, hipStream_t st )
+{
+  hipLaunchKernelGGL( k_label_to_input_order, dim3( (unsigned)( ( n + BLOCK - 1 ) / BLOCK ) ), dim3( BLOCK ), 0, st, by_orig, n, in_f, out_f, n_f, in_b, out_b );
+}
+void launch_label_to_query_order( const float4* qpos, long long n, const float* in_f, float* out_f, const int8_t* in_b, int8_t* out_b, hipStream_t st )
+{
+  hipLaunchKernelGGL( k_label_to_query_order, dim3( (unsigned)( ( n + BLOCK - 1 ) / BLOCK ) ), dim3( BLOCK ), 0, st, qpos, n, in_f, out_f, in_b, out_b );
 }
 
 // Ordered arg-min over per-placement rows that already sit in device memory (the gathered send buffers of the sharded

@@ -158,7 +158,9 @@ def shard_compute(capi, lay, rank, units, send, small_host, threads=None):
 
     def label():
         if p1 > p0:
-            capi.label_rows(lscene, lposes[p0:p1], lclouds[p0:p1], lradii[p0:p1], out_device_ptr=send.data_ptr() + 4 * lay.off_rows)
+            # rows in the scene cloud's query order: what the kernel writes (coalesced); every rank builds the same cloud from
+            # the same scene, so the gathered rows share that order and shard_fold hands the cloud to the fold
+            capi.label_rows(lscene, lposes[p0:p1], lclouds[p0:p1], lradii[p0:p1], out_device_ptr=send.data_ptr() + 4 * lay.off_rows, query_order=True)
             capi.synchronize()            # the rows are complete before the collective (another stream) reads them
 
     if threads is not None:
@@ -175,7 +177,7 @@ def shard_publish(lay, send, small_host):
     send[: lay.small_words].copy_(t, non_blocking=True)
 
 
-def shard_fold(capi, lay, recv, out=None):
+def shard_fold(capi, lay, recv, out=None, scene=None):
     """recv = the all-gathered send buffers (float32 device tensor, lay.world x lay.words), complete (the caller has
     waited for the collective).  Returns (errs, Ts, iters, scores, labels, min_dists) for ALL units, in unit order:
     the small blocks are read back, the rows are folded on the device in the sorted placement order."""
@@ -189,5 +191,7 @@ def shard_fold(capi, lay, recv, out=None):
         scores.append(small[r, lay.off_score: lay.off_score + (s1 - s0)])
         offsets += [r * W + lay.off_rows + k * lay.n_scene for k in range(p1 - p0)]
     # from (0, 1e9): rs_pointcloud_filters.cpp:799-802,820; out = (labels int8[n_scene], min_dists float32[n_scene]) to receive the result
-    labels, mind = capi.fold_label_rows_device(recv.data_ptr(), offsets, lay.n_scene, *(out if out is not None else (None, None)), fresh=True)
+    # scene: the Cloud in whose query order shard_compute wrote the rows
+    labels, mind = capi.fold_label_rows_device(recv.data_ptr(), offsets, lay.n_scene, *(out if out is not None else (None, None)), fresh=True,
+                                               query_order_of=scene)
     return (np.concatenate(errs), np.concatenate(Ts).copy(), np.concatenate(its), np.concatenate(scores), labels, mind)

@@ -119,10 +119,36 @@ def test_headline_sharded_route_is_bit_identical(capi, bench_mod, headline):
             rd.shard_compute(capi, lay, rank, units, send, small)
             rd.shard_publish(lay, send, small)
         torch.cuda.synchronize()
-        errs, Ts, its, scores, labels, mind = rd.shard_fold(capi, lay, recv)
+        errs, Ts, its, scores, labels, mind = rd.shard_fold(capi, lay, recv, scene=w["scan1"])
         assert (Ts[0] == T0).all() and (Ts[1] == T0).all() and errs[0] == np.float32(err0) and its[0] == it0, f"world {world}: ICP"
         assert (scores == sc0).all(), f"world {world}: scores"
         assert (labels == lab0["labels"]).all() and (mind == lab0["min_dists"]).all(), f"world {world}: labels"
+
+
+def test_label_rows_in_all_three_forms(capi, headline):
+    """rs_hip_label_rows: host rows (input order), device rows in input order, device rows in the scene's query order — the
+    last folded by rs_hip_fold_label_rows_device with the scene cloud — all give the rows / labels of the placement loop."""
+    import torch
+    from rescan_amd import dist as rd
+    w, g = headline
+    n_plc, ns = len(w["plc"]), w["n_scan1"]
+    order, _, radii = rd.arrangement_plan([0] * n_plc, [p["cls"] for p in w["plc"]], 0.05)
+    poses, clouds = w["plc_poses"][order], [w["plc"][i]["cloud"] for i in order]
+    host = capi.label_rows(w["scan1"], poses, clouds, radii)
+    dev = torch.zeros(n_plc * ns, dtype=torch.float32, device="cuda:0")
+    capi.label_rows(w["scan1"], poses, clouds, radii, out_device_ptr=dev.data_ptr()); capi.synchronize()
+    assert np.array_equal(dev.cpu().numpy().reshape(n_plc, ns), host)
+    labels = np.zeros(ns, np.int8); mind = np.full(ns, 1e9, np.float32)
+    capi.combine_label_rows(host, labels, mind)
+    assert (labels == g["labels"]).all() and sha(mind) == str(g["min_dists_sha"])
+    capi.label_rows(w["scan1"], poses, clouds, radii, out_device_ptr=dev.data_ptr(), query_order=True); capi.synchronize()
+    offs = [k * ns for k in range(n_plc)]
+    l2, m2 = capi.fold_label_rows_device(dev.data_ptr(), offs, ns, query_order_of=w["scan1"])
+    assert (l2 == labels).all() and (m2 == mind).all()
+    # continued from a caller's state: the first three rows, then the rest
+    l3, m3 = capi.fold_label_rows_device(dev.data_ptr(), offs[:3], ns, query_order_of=w["scan1"])
+    l3, m3 = capi.fold_label_rows_device(dev.data_ptr(), offs[3:], ns, l3, m3, label_base=3, query_order_of=w["scan1"])
+    assert (l3 == labels).all() and (m3 == mind).all()
 
 
 # ---- scan-sized sources: which estimator ---------------------------------------------------------------------------
