@@ -1214,6 +1214,50 @@ __global__ __launch_bounds__( BLOCK, BOUNDED_ONLY ? RS_ICP_WARM_OCC : RS_ICP_OCC
   icp_emit( L, prob, tile, i, active, lane, m, active & !search );
 }
 
+// One tile searched by all NW waves of its workgroup: queries, warm start, certificates (checked by ONE wave — the check ages
+// the certificate in place, and the waves must agree on who searches), cooperative search, results written by wave 0.
+// Returns whether some lane had to search without a starting candidate (the tile is "not bounded": worth a workgroup again
+// next iteration).  Ends with a barrier: the merge slots may be reused at once.
+template <int NW>
+__device__ __forceinline__ bool icp_coop_tile( const IcpLaunch& L, const Xform& T1, int prob, int tile, WaveLds& lds, CoopLds<NW>& coop,
+                                               unsigned long long& s_skip, int wib, int lane, int dbg_slot )
+{
+  const int i = (int)L.src.tiles[tile] + lane;
+  const bool active = i < (int)L.src.tiles[tile + 1];
+  float qx, qy, qz, nx, ny, nz;
+  icp_query( L, T1, i, active, qx, qy, qz, nx, ny, nz );
+  const unsigned long long t_begin = DBG( L ) ? wall_clock64() : 0ull;
+  unsigned long long stamps[8];
+  const Match init = icp_warm_start( L, prob, i, active, qx, qy, qz, nx, ny, nz );
+  if( wib == 0 )
+  {
+    const unsigned long long skip_mask = __ballot( icp_certificate( L, prob, i, active & !init.found, qx, qy, qz, nx, ny, nz ) );
+    if( lane == 0 ) s_skip = skip_mask;
+  }
+  __syncthreads();
+  const bool search = active & !( ( s_skip >> lane ) & 1ull );
+  uint32_t streamed = 0;
+  Match m = coop_search<true, NW, true>( L.tgt, search, qx, qy, qz, nx, ny, nz, L.radius, L.radius_sq, L.gate_tmin, L.K,
+                               lds, coop, wib, lane, init, DBG( L ) ? &streamed : nullptr, DBG( L ) ? stamps : nullptr );
+  if( DBG( L ) && wib == 0 && dbg_slot >= 0 )
+  {
+    const int n_search = __popcll( __ballot( search ) ), n_unm = __popcll( __ballot( search & !m.found ) );
+    if( lane == 0 )
+    {
+      unsigned long long* d = DBG( L ) + 2 * (size_t)L.src.n_tiles + 4 * (size_t)dbg_slot;
+      const unsigned long long t_end = wall_clock64();
+      // [0] total | [1] streamed | lanes | phases packed: setup, shell 1, shell 2, rest (each 16 bits, ticks of 10 ns)
+      auto clip = []( unsigned long long v ) { return v > 0xffffull ? 0xffffull : v; };
+      d[0] = t_end - t_begin; d[1] = streamed; d[2] = (unsigned long long)n_search | ( (unsigned long long)n_unm << 8 );
+      d[3] = clip( stamps[0] - t_begin ) | ( clip( stamps[1] - stamps[0] ) << 16 ) | ( clip( stamps[2] - stamps[1] ) << 32 ) | ( clip( t_end - stamps[2] ) << 48 );
+    }
+  }
+  if( wib == 0 ) icp_emit( L, prob, tile, i, active, lane, m, active & !search );
+  const bool not_bounded = __any( search & !init.found );
+  __syncthreads();                               // merge slots are reused by the next tile
+  return not_bounded;
+}
+
 // Phase B: one workgroup per queued tile, whole box, chunks shared by its waves.
 #ifndef RS_COOP_OCC
 #define RS_COOP_OCC 5      // waves per SIMD the cooperative kernel's register allocation aims at (96 VGPRs: no spills; 6 = 80 VGPRs spilt 56 B per lane for no gain in time)
@@ -1236,40 +1280,7 @@ __global__ __launch_bounds__( NW * WAVE, RS_COOP_OCC ) void k_icp_corr_coop( Icp
   for( int b = blockIdx.x; b < n_queued; b += gridDim.x )
   {
     const int tile = L.coop_all ? b : L.queue[(size_t)prob * L.src.n_tiles + b];
-    const int i = (int)L.src.tiles[tile] + lane;
-    const bool active = i < (int)L.src.tiles[tile + 1];
-    float qx, qy, qz, nx, ny, nz;
-    icp_query( L, T1, i, active, qx, qy, qz, nx, ny, nz );
-    const unsigned long long t_begin = DBG( L ) ? wall_clock64() : 0ull;
-    unsigned long long stamps[8];
-    const Match init = icp_warm_start( L, prob, i, active, qx, qy, qz, nx, ny, nz );
-    // the certificate check ages the certificate in place: ONE wave does it and tells the others (each wave
-    // re-reading what another has just aged would decide differently, and the waves must agree on who searches)
-    if( wib == 0 )
-    {
-      const unsigned long long skip_mask = __ballot( icp_certificate( L, prob, i, active & !init.found, qx, qy, qz, nx, ny, nz ) );
-      if( lane == 0 ) s_skip = skip_mask;
-    }
-    __syncthreads();
-    const bool search = active & !( ( s_skip >> lane ) & 1ull );
-    uint32_t streamed = 0;
-    Match m = coop_search<true, NW, true>( L.tgt, search, qx, qy, qz, nx, ny, nz, L.radius, L.radius_sq, L.gate_tmin, L.K,
-                                 lds[wib], coop, wib, lane, init, DBG( L ) ? &streamed : nullptr, DBG( L ) ? stamps : nullptr );
-    if( DBG( L ) && wib == 0 )
-    {
-      const int n_search = __popcll( __ballot( search ) ), n_unm = __popcll( __ballot( search & !m.found ) );
-      if( lane == 0 )
-      {
-        unsigned long long* d = DBG( L ) + 2 * (size_t)L.src.n_tiles + 4 * (size_t)b;
-        const unsigned long long t_end = wall_clock64();
-        // [0] total | [1] streamed | lanes | phases packed: setup, shell 1, shell 2, rest (each 16 bits, ticks of 10 ns)
-        auto clip = []( unsigned long long v ) { return v > 0xffffull ? 0xffffull : v; };
-        d[0] = t_end - t_begin; d[1] = streamed; d[2] = (unsigned long long)n_search | ( (unsigned long long)n_unm << 8 );
-        d[3] = clip( stamps[0] - t_begin ) | ( clip( stamps[1] - stamps[0] ) << 16 ) | ( clip( stamps[2] - stamps[1] ) << 32 ) | ( clip( t_end - stamps[2] ) << 48 );
-      }
-    }
-    if( wib == 0 ) icp_emit( L, prob, tile, i, active, lane, m, active & !search );
-    __syncthreads();                               // merge slots are reused by the next queued tile
+    icp_coop_tile<NW>( L, T1, prob, tile, lds[wib], coop, s_skip, wib, lane, b );
   }
 }
 

@@ -108,6 +108,7 @@ def main():
                      os.path.join(name, stems[0] + ".rsdb"), "-v"], work)
         assert os.path.exists(os.path.join(work, name, stems[0] + ".rsdb")), r.stdout[-400:] + r.stderr[-400:]
         rows.append(dict(sequence=name, stage="seg2rsdb", build="ref", wall_s=dt))
+        print(f"[scene_list] {name} seg2rsdb: {dt:.1f} s", file=sys.stderr, flush=True)
 
     def pose_proposal(name, build, device):
         stems = list_subsequences(os.path.join(work, name, "gt_segmentation"))
@@ -120,6 +121,7 @@ def main():
             dst = os.path.join(name, f"{stem}_pp_{build}.rsdb")
             r, dt = run([os.path.join(REF, BUILDS[build]), prev, os.path.join(name, "gt_segmentation", stem + ".ply"), dst, "-v"], work, env)
             ok = r.returncode == 0 and "[rescan_hip]" not in r.stderr
+            print(f"[scene_list] {name} {build}: {dt:.1f} s (computed poses in {computed_in(r.stdout)}) ok={ok}", file=sys.stderr, flush=True)
             out.append(dict(sequence=name, stage="pose_proposal", build=build, wall_s=dt, computed_poses_s=computed_in(r.stdout), ok=ok,
                             bin=os.path.join(work, name, f"{stem}_pp_{build}", f"{stem}_pp_{build}.bin"), err=(r.stderr[-300:] if not ok else "")))
             # (the next timestep would read segment_transfer's output of this one: not available, see the docstring)
