@@ -92,6 +92,15 @@ int   rsd_arrangement_to_labels( const rsd_vec3_t* scn_pos, const rsd_vec3_t* sc
                                  const rsd_mat4_t* poses, const int32_t* is_static, const int32_t* class_idx, int32_t n_plc,
                                  float radius, bool prioritize_static, int8_t* labels, int32_t* sorted_order );
 
+/* The whole of rspf_arrangement_to_labels (lib/rs/rs_pointcloud_filters.cpp:780-879) including its tail (:851-869): the
+ * outputs are in_pc->class_ids[lvl] / instance_ids[lvl] themselves — class of the labelled placement's object, the
+ * placement's uidx, (rsdb_get_class_idx( rsdb, "unlabelled" ), RSPF_MAX_INSTANCES) where no placement claimed the point. */
+int   rsd_arrangement_to_ids( const rsd_vec3_t* scn_pos, const rsd_vec3_t* scn_nor, int32_t n_scn,
+                              const rsd_vec3_t* const* obj_pos, const rsd_vec3_t* const* obj_nor, const int32_t* obj_n,
+                              const rsd_mat4_t* poses, const int32_t* is_static, const int32_t* class_idx, const int32_t* uidx, int32_t n_plc,
+                              float radius, bool prioritize_static, int32_t unlabelled_class_idx,
+                              int32_t* class_ids, int32_t* instance_ids );
+
 /* rspf_compute_neighborhood (lib/rs/rs_pointcloud_filters.cpp:674-722) on pc->positions/normals[lvl]:
  * fills the caller's edge arrays (capacity >= n*max_nn; the reference's hashtable would hold as many),
  * idx1/idx2/weight being the fields of its edge_t (:664-669).  Returns the edge count (< 0: error). */

@@ -179,6 +179,16 @@ int rs_hip_arrangement_to_labels( const rs_hip_cloud_t* scene,
                                   float radius, int prioritize_static,
                                   int8_t* labels, float* min_dists, int32_t* sorted_order );
 
+/* The same plus the function's tail (lib/rs/rs_pointcloud_filters.cpp:851-869): temporary labels -> in_pc->class_ids[lvl] /
+ * instance_ids[lvl] — class of the labelled placement's object and the placement's uidx; label 0 gives
+ * (unlabelled_class_idx = rsdb_get_class_idx( rsdb, "unlabelled" ), RSPF_MAX_INSTANCES = 1024).  uidx is per placement
+ * (rs_obj_plcmnt_t.uidx).  labels / min_dists / sorted_order may be NULL. */
+int rs_hip_arrangement_to_ids( const rs_hip_cloud_t* scene,
+                               const float* poses /* 16*n */, const rs_hip_cloud_t* const* objects /* n */,
+                               const int32_t* is_static, const int32_t* class_idx, const int32_t* uidx, int32_t n,
+                               float radius, int prioritize_static, int32_t unlabelled_class_idx,
+                               int32_t* class_ids, int32_t* instance_ids, int8_t* labels, float* min_dists, int32_t* sorted_order );
+
 /* ---- level builder ---------------------------------------------------- */
 
 /* rs_pointcloud__compute_level_poisson (lib/rs/rs_pointcloud.h:984-1106): Poisson-disk subsample of
@@ -199,6 +209,12 @@ int rs_hip_level_samples( const rs_hip_cloud_t* cloud, float radius, int32_t max
  * capacity = size of base) and n_samples (may be NULL) receive the samples.  NULL on failure. */
 rs_hip_cloud_t* rs_hip_cloud_create_level( const rs_hip_cloud_t* base, float radius, int32_t max_n_neigh, float cell_size,
                                            int32_t* sample_idx, int32_t* n_samples );
+
+/* The gathers that end the level builder (lib/rs/rs_pointcloud.h:1090-1099): for each of n_arrays per-point arrays of the
+ * base level (host pointers, `words[a]` 32-bit words per point: 3 for positions / normals / colours, 1 for radii, qualities,
+ * class and instance ids), dst[a][i] = src[a][sample_idx[i]].  Entries with a NULL src or dst are skipped. */
+int rs_hip_gather_attributes( const int32_t* sample_idx, int32_t count, int32_t n_src,
+                              const void* const* src, const int32_t* words, void* const* dst, int32_t n_arrays );
 
 /* ---- neighbourhood graph ------------------------------------------ */
 

@@ -48,6 +48,9 @@ SIGNATURES = {
                                                 C.c_int64, C.c_int32, i8p, f32p, C.c_int32, C.c_void_p]),
     "rs_hip_arrangement_to_labels": (C.c_int, [C.c_void_p, f32p, C.c_void_p, i32p, i32p, C.c_int32, C.c_float,
                                                C.c_int, i8p, f32p, i32p]),
+    "rs_hip_arrangement_to_ids": (C.c_int, [C.c_void_p, f32p, C.c_void_p, i32p, i32p, i32p, C.c_int32, C.c_float, C.c_int, C.c_int32,
+                                            i32p, i32p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rs_hip_gather_attributes": (C.c_int, [i32p, C.c_int32, C.c_int32, C.c_void_p, i32p, C.c_void_p, C.c_int32]),
     "rs_hip_compute_neighborhood": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float, i32p, i32p, f32p,
                                               C.c_int64, C.POINTER(C.c_int64)]),
     "rs_hip_coverage_create": (C.c_void_p, [f32p, f32p, C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_float]),
@@ -307,6 +310,33 @@ def arrangement_to_labels(scene, poses, objects, is_static, class_idx, radius=0.
         np.ascontiguousarray(is_static, np.int32), np.ascontiguousarray(class_idx, np.int32), n,
         float(radius), int(bool(prioritize_static)), labels, mind, order))
     return dict(labels=labels, min_dists=mind, order=order[:n])
+
+
+def arrangement_to_ids(scene, poses, objects, is_static, class_idx, uidx, radius=0.05, prioritize_static=False, unlabelled_class_idx=0):
+    """rspf_arrangement_to_labels including its tail (:851-869).  Returns dict(class_ids, instance_ids, labels, min_dists, order)."""
+    n = len(objects)
+    handles = (C.c_void_p * max(1, n))(*[o.handle for o in objects])
+    cls = np.zeros(scene.n, np.int32); inst = np.zeros(scene.n, np.int32)
+    labels = np.zeros(scene.n, np.int8); mind = np.zeros(scene.n, np.float32); order = np.zeros(max(1, n), np.int32)
+    _check(load().rs_hip_arrangement_to_ids(
+        scene.handle, _f32(poses).reshape(-1, 16), C.addressof(handles), np.ascontiguousarray(is_static, np.int32),
+        np.ascontiguousarray(class_idx, np.int32), np.ascontiguousarray(uidx, np.int32), n, float(radius), int(bool(prioritize_static)),
+        int(unlabelled_class_idx), cls, inst, labels.ctypes.data_as(C.c_void_p), mind.ctypes.data_as(C.c_void_p), order.ctypes.data_as(C.c_void_p)))
+    return dict(class_ids=cls, instance_ids=inst, labels=labels, min_dists=mind, order=order[:n])
+
+
+def gather_attributes(sample_idx, arrays):
+    """dst[a][i] = arrays[a][sample_idx[i]] on the device (the level builder's attribute gathers); arrays: list of 2-D or 1-D
+    float32 / int32 arrays over the base level's points."""
+    idx = np.ascontiguousarray(sample_idx, np.int32)
+    srcs = [np.ascontiguousarray(a) for a in arrays]
+    for a in srcs:
+        assert a.dtype.itemsize == 4
+    words = np.array([int(np.prod(a.shape[1:])) if a.ndim > 1 else 1 for a in srcs], np.int32)
+    outs = [np.empty((len(idx),) + a.shape[1:], a.dtype) for a in srcs]
+    sp = (C.c_void_p * len(srcs))(*[a.ctypes.data for a in srcs]); dp = (C.c_void_p * len(srcs))(*[o.ctypes.data for o in outs])
+    _check(load().rs_hip_gather_attributes(idx, len(idx), len(srcs[0]) if srcs else 0, C.addressof(sp), words, C.addressof(dp), len(srcs)))
+    return outs
 
 
 def mat4_inverse(m):

@@ -98,7 +98,7 @@ struct Workspace
 {
   DevBuf state, slot, d2, dot, stat_acc, mom_part, res, wexp, queue, queue_count;   // ICP
   DevBuf poses, score_part, scores;                                             // score
-  DevBuf plc, labels, mind, fold_off, labels_o, mind_o, rows_o;                 // labels (state in query order; *_o: input order)
+  DevBuf plc, labels, mind, fold_off, labels_o, mind_o, rows_o, ids_tab, ids_out, attr_in, attr_out;                 // labels (state in query order; *_o: input order)
   DevBuf q4, rd2, ridx, rnn, rows;                                              // rows / misc
   DevBuf enor, ecount, eoffset, e1, e2, ew;                                     // neighbourhood edges
   DevBuf cert_r, cert_dot, cert_slack;                                                    // ICP certificates
@@ -257,6 +257,13 @@ int rs_hip_init( int device )
     return RS_HIP_E_NODEVICE;
   }
   if( device < 0 || device >= count ) { set_err( "rs_hip_init: device %d out of range (%d devices)", device, count ); return RS_HIP_E_ARG; }
+  // Callers wait for small results thousands of times per second (the unchanged pose_proposal: ~37 k searches per run):
+  // spin on completion instead of sleeping.  Refused (harmlessly) when the process has set up the device already; RS_HIP_SCHEDULE=yield|auto keeps the default.
+  {
+    const char* sch = getenv( "RS_HIP_SCHEDULE" );
+    if( !sch || !std::strcmp( sch, "spin" ) ) (void)hipSetDeviceFlags( hipDeviceScheduleSpin );
+    (void)hipGetLastError();
+  }
   HIP_TRY( hipSetDevice( device ), RS_HIP_E_NODEVICE );
   g_device = device;
   g_ready = true;
@@ -1169,24 +1176,24 @@ int rs_hip_fold_label_rows_device( const float* rows_device, const int64_t* row_
   return RS_HIP_OK;
 }
 
-int rs_hip_arrangement_to_labels( const rs_hip_cloud_t* scene,
-                                  const float* poses, const rs_hip_cloud_t* const* objects,
-                                  const int32_t* is_static, const int32_t* class_idx, int32_t n,
-                                  float radius, int prioritize_static,
-                                  int8_t* labels, float* min_dists, int32_t* sorted_order )
+// rspf_arrangement_to_labels :780-848 on the device-resident state: order, the two passes.  Leaves the state in g_ws.labels /
+// g_ws.mind (query order) and the sorted order in `ord`; *launched = 0 when there was nothing to launch (n = 0 or an empty scene).
+static int arrangement_passes( const rs_hip_cloud_t* scene, const float* poses, const rs_hip_cloud_t* const* objects,
+                               const int32_t* is_static, const int32_t* class_idx, int32_t n, float radius, int prioritize_static,
+                               std::vector<int32_t>& ord, int* launched )
 {
-  int rc = ensure_ready(); if( rc ) return rc;
-  if( !scene || !labels || !min_dists || n < 0 || ( n > 0 && ( !poses || !objects || !is_static || !class_idx ) ) ) { set_err( "arrangement_to_labels: bad arguments" ); return RS_HIP_E_ARG; }
+  int rc;
+  *launched = 0;
+  if( !scene || n < 0 || ( n > 0 && ( !poses || !objects || !is_static || !class_idx ) ) ) { set_err( "arrangement_to_labels: bad arguments" ); return RS_HIP_E_ARG; }
   for( int i = 0; i < n; ++i ) if( !objects[i] || !objects[i]->has_nor ) { set_err( "arrangement_to_labels: placement %d has no object cloud with normals", i ); return RS_HIP_E_ARG; }
   const int64_t ns = scene->n;
   if( n > 127 ) { set_err( "arrangement_to_labels: more than 127 placements do not fit the reference's int8 labels" ); return RS_HIP_E_CAPACITY; }
   if( !scene->has_nor && ns > 0 && n > 0 ) { set_err( "arrangement_to_labels: the scene cloud needs normals" ); return RS_HIP_E_ARG; }
   // :823-827 — qsort by (is_static << 10 | class_idx); glibc's qsort is a stable merge sort
-  std::vector<int32_t> ord( n );
+  ord.resize( (size_t)n );
   for( int i = 0; i < n; ++i ) ord[i] = i;
   std::stable_sort( ord.begin(), ord.end(), [&]( int a, int b ) {
     return ( ( is_static[a] << 10 ) | class_idx[a] ) < ( ( is_static[b] << 10 ) | class_idx[b] ); } );
-  if( sorted_order ) for( int i = 0; i < n; ++i ) sorted_order[i] = ord[i];
   int first_static = 0;                                                                      // :830-835
   for( int i = 0; i < n; ++i ) if( is_static[ord[i]] ) { first_static = i; break; }
   std::vector<rs_hip_placement_t> pl( n );
@@ -1195,8 +1202,7 @@ int rs_hip_arrangement_to_labels( const rs_hip_cloud_t* scene,
     std::memcpy( pl[i].pose, poses + 16 * ord[i], 64 ); pl[i].object = objects[ord[i]];
     pl[i].radius = ( i < first_static ) ? radius : ( prioritize_static ? radius : 1.5f * radius );   // :837-848
   }
-  if( ns == 0 ) return RS_HIP_OK;
-  if( n == 0 ) { for( int64_t j = 0; j < ns; ++j ) { labels[j] = 0; min_dists[j] = 1e9; } return RS_HIP_OK; }     // :799-802, :820
+  if( ns == 0 || n == 0 ) return RS_HIP_OK;
   // Both passes run on the device-resident state (query order), which starts from (label 0, min_dist 1e9) inside the first
   // launch; only the final labels / min_dists come back (one gather to input order, one download).
   if( ( rc = label_upload_placements( pl.data(), n ) ) ) return rc;          // all of them once: the two launches read their parts
@@ -1208,7 +1214,81 @@ int rs_hip_arrangement_to_labels( const rs_hip_cloud_t* scene,
     HIP_TRY( hipMemsetD32Async( (hipDeviceptr_t)g_ws.mind.p, (int)bits, (size_t)ns, g_stream ), RS_HIP_E_RUNTIME );
   }
   if( ( rc = label_chain( scene, first_static, n - first_static, first_static, !have_state ) ) ) return rc;
+  *launched = 1;
+  return RS_HIP_OK;
+}
+
+int rs_hip_arrangement_to_labels( const rs_hip_cloud_t* scene,
+                                  const float* poses, const rs_hip_cloud_t* const* objects,
+                                  const int32_t* is_static, const int32_t* class_idx, int32_t n,
+                                  float radius, int prioritize_static,
+                                  int8_t* labels, float* min_dists, int32_t* sorted_order )
+{
+  int rc = ensure_ready(); if( rc ) return rc;
+  if( !labels || !min_dists ) { set_err( "arrangement_to_labels: bad arguments" ); return RS_HIP_E_ARG; }
+  std::vector<int32_t> ord; int launched = 0;
+  if( ( rc = arrangement_passes( scene, poses, objects, is_static, class_idx, n, radius, prioritize_static, ord, &launched ) ) ) return rc;
+  if( sorted_order ) for( int i = 0; i < n; ++i ) sorted_order[i] = ord[i];
+  if( !launched ) { for( int64_t j = 0; j < scene->n; ++j ) { labels[j] = 0; min_dists[j] = 1e9; } return RS_HIP_OK; }     // :799-802, :820
   return label_state_download( scene, labels, min_dists );
+}
+
+int rs_hip_arrangement_to_ids( const rs_hip_cloud_t* scene,
+                               const float* poses, const rs_hip_cloud_t* const* objects,
+                               const int32_t* is_static, const int32_t* class_idx, const int32_t* uidx, int32_t n,
+                               float radius, int prioritize_static, int32_t unlabelled_class_idx,
+                               int32_t* class_ids, int32_t* instance_ids, int8_t* labels, float* min_dists, int32_t* sorted_order )
+{
+  int rc = ensure_ready(); if( rc ) return rc;
+  if( !class_ids || !instance_ids || ( n > 0 && !uidx ) ) { set_err( "arrangement_to_ids: bad arguments" ); return RS_HIP_E_ARG; }
+  std::vector<int32_t> ord; int launched = 0;
+  if( ( rc = arrangement_passes( scene, poses, objects, is_static, class_idx, n, radius, prioritize_static, ord, &launched ) ) ) return rc;
+  if( sorted_order ) for( int i = 0; i < n; ++i ) sorted_order[i] = ord[i];
+  const size_t ns = (size_t)scene->n;
+  if( !launched )
+  {
+    for( size_t j = 0; j < ns; ++j ) { class_ids[j] = unlabelled_class_idx; instance_ids[j] = 1024; if( labels ) labels[j] = 0; if( min_dists ) min_dists[j] = 1e9; }
+    return RS_HIP_OK;
+  }
+  // :851-869 on the device, fused with the move from query order to input order
+  std::vector<int32_t> tab( (size_t)2 * n );
+  for( int i = 0; i < n; ++i ) { tab[i] = class_idx[ord[i]]; tab[n + i] = uidx[ord[i]]; }
+  if( ( rc = g_ws.ids_tab.ensure( tab.size() * 4 ) ) || ( rc = g_ws.ids_out.ensure( ns * 8 ) ) || ( rc = g_ws.labels_o.ensure( ns ) ) || ( rc = g_ws.mind_o.ensure( ns * 4 ) ) ) return rc;
+  HIP_TRY( hipMemcpyAsync( g_ws.ids_tab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+  int* d_cls = g_ws.ids_out.as<int>(); int* d_inst = d_cls + ns;
+  launch_label_ids_to_input_order( scene->d_qby_orig, (long long)ns, g_ws.labels.as<int8_t>(), g_ws.mind.as<float>(), g_ws.ids_tab.as<int>(), g_ws.ids_tab.as<int>() + n,
+                                   unlabelled_class_idx, d_cls, d_inst, g_ws.labels_o.as<int8_t>(), g_ws.mind_o.as<float>(), g_stream );
+  HIP_TRY( hipMemcpyAsync( class_ids, d_cls, ns * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipMemcpyAsync( instance_ids, d_inst, ns * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+  if( labels ) HIP_TRY( hipMemcpyAsync( labels, g_ws.labels_o.p, ns, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+  if( min_dists ) HIP_TRY( hipMemcpyAsync( min_dists, g_ws.mind_o.p, ns * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );               // (`tab` is still alive here)
+  return RS_HIP_OK;
+}
+
+// The attribute gathers that end rs_pointcloud__compute_level_poisson (lib/rs/rs_pointcloud.h:1090-1099): every per-point
+// array of level 0 at the sample indices.  Arrays are host pointers (any of them may be NULL), `words` 32-bit words per point.
+int rs_hip_gather_attributes( const int32_t* sample_idx, int32_t count, int32_t n_src,
+                              const void* const* src, const int32_t* words, void* const* dst, int32_t n_arrays )
+{
+  int rc = ensure_ready(); if( rc ) return rc;
+  if( count < 0 || n_src < 0 || n_arrays < 0 || ( count > 0 && !sample_idx ) || ( n_arrays > 0 && ( !src || !words || !dst ) ) ) { set_err( "gather_attributes: bad arguments" ); return RS_HIP_E_ARG; }
+  if( count == 0 || n_arrays == 0 ) return RS_HIP_OK;
+  for( int32_t i = 0; i < count; ++i ) if( sample_idx[i] < 0 || sample_idx[i] >= n_src ) { set_err( "gather_attributes: sample index %d out of range", sample_idx[i] ); return RS_HIP_E_ARG; }
+  if( ( rc = g_ws.lvl_samples.ensure( (size_t)count * 4 ) ) ) return rc;
+  HIP_TRY( hipMemcpyAsync( g_ws.lvl_samples.p, sample_idx, (size_t)count * 4, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+  for( int a = 0; a < n_arrays; ++a )
+  {
+    if( !src[a] || !dst[a] ) continue;
+    if( words[a] <= 0 ) { set_err( "gather_attributes: array %d has no width", a ); return RS_HIP_E_ARG; }
+    const size_t in_b = (size_t)n_src * words[a] * 4, out_b = (size_t)count * words[a] * 4;
+    if( ( rc = g_ws.attr_in.ensure( in_b ) ) || ( rc = g_ws.attr_out.ensure( out_b ) ) ) return rc;
+    HIP_TRY( hipMemcpyAsync( g_ws.attr_in.p, src[a], in_b, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+    launch_gather_words( g_ws.attr_in.as<uint32_t>(), g_ws.lvl_samples.as<int>(), count, words[a], g_ws.attr_out.as<uint32_t>(), g_stream );
+    HIP_TRY( hipMemcpyAsync( dst[a], g_ws.attr_out.p, out_b, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+    HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );      // the two staging buffers are reused by the next array
+  }
+  return RS_HIP_OK;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1236,22 +1316,37 @@ int rs_hip_radius_search( const rs_hip_cloud_t* target, const float* query, int6
   const long long tiled_from = getenv( "RS_HIP_ROWS_TILED_FROM" ) ? atoll( getenv( "RS_HIP_ROWS_TILED_FROM" ) ) : 4096;      // (read per call: tests switch it)
   if( k <= wave_path_max_k && ( k >= 16 || nq < tiled_from ) && !getenv( "RS_HIP_NO_ROWS_WAVE" ) )
   {
-    if( ( rc = W.bld_pos.ensure( nn * 12 ) ) || ( rc = W.rd2.ensure( nk * 4 ) ) || ( rc = W.ridx.ensure( nk * 4 ) ) || ( rc = W.rnn.ensure( nn * 4 + 4 ) ) ||
-        ( rc = W.h_a.ensure( nn * 4 + 4 ) ) ) return rc;
-    int* d_nn = W.rnn.as<int>();                 // [nq] counts, [nq] overflow flag
-    HIP_TRY( hipMemcpyAsync( W.bld_pos.p, query, nn * 12, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
-    HIP_TRY( hipMemsetAsync( d_nn + nq, 0, 4, g_stream ), RS_HIP_E_RUNTIME );
+    // One upload, one launch, one download, one synchronisation: the call is latency (the unchanged pose_proposal makes
+    // ~35 k of them per run).  Queries and the overflow flag travel in one pinned block; counts, distances and indices
+    // come back in one, and are handed to the caller's arrays on the host.
+    const size_t up_words = nn * 3, down_words = ( nn + 1 ) + 2 * nk;
+    if( ( rc = W.bld_pos.ensure( up_words * 4 ) ) || ( rc = W.rows.ensure( down_words * 4 ) ) ||
+        ( rc = W.h_a.ensure( down_words * 4 ) ) || ( rc = W.h_b.ensure( up_words * 4 ) ) ) return rc;
+    float* h_up = W.h_b.as<float>();
+    std::memcpy( h_up, query, nn * 12 );
+    float* d_up = W.bld_pos.as<float>();
+    int* d_nn = W.rows.as<int>();                      // [nq] counts (-1: more than 1024 points within the radius), one spare word, then the rows
+    float* d_d2 = W.rows.as<float>() + ( nn + 1 ); int* d_idx = W.rows.as<int>() + ( nn + 1 ) + nk;
+    HIP_TRY( hipMemcpyAsync( d_up, h_up, up_words * 4, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
     { ProfScope ps( "nn_rows" );
-      launch_rows_wave( g, W.bld_pos.as<float>(), nq, k, radius, radius_sq_of( radius ), W.rd2.as<float>(), W.ridx.as<int>(), d_nn, d_nn + nq, g_stream ); }
+      launch_rows_wave( g, d_up, nq, k, radius, radius_sq_of( radius ), d_d2, d_idx, d_nn, d_nn + nq, g_stream ); }
     int* h_nn = W.h_a.as<int>();
-    HIP_TRY( hipMemcpyAsync( h_nn, d_nn, nn * 4 + 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
-    HIP_TRY( hipMemcpyAsync( distances_sq, W.rd2.p, nk * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
-    HIP_TRY( hipMemcpyAsync( indices, W.ridx.p, nk * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+    HIP_TRY( hipMemcpyAsync( h_nn, d_nn, down_words * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
     HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
-    if( !h_nn[nq] )
+    bool overflow = false;
+    for( int i = 0; i < nq; ++i ) overflow |= h_nn[i] < 0;
+    if( !overflow )
     {
+      // rows are written up to their counts only: copy exactly those (the caller's arrays keep whatever else they held, like the reference's)
+      const float* hd = (const float*)( h_nn + nn + 1 ); const int* hi = h_nn + nn + 1 + nk;
       uint64_t tot = 0;
-      for( int i = 0; i < nq; ++i ) { tot += (uint64_t)h_nn[i]; if( n_neighbors ) n_neighbors[i] = (size_t)h_nn[i]; }
+      for( int i = 0; i < nq; ++i )
+      {
+        const size_t c = (size_t)h_nn[i];
+        std::memcpy( distances_sq + (size_t)i * k, hd + (size_t)i * k, c * 4 );
+        std::memcpy( indices + (size_t)i * k, hi + (size_t)i * k, c * 4 );
+        tot += c; if( n_neighbors ) n_neighbors[i] = c;
+      }
       if( total ) *total = tot;
       return RS_HIP_OK;
     }

@@ -147,6 +147,9 @@ void launch_label( const LabelLaunch& L, hipStream_t st );
 // between a cloud's query order and its input order, by gathering (n_f float arrays of n entries back to back, and/or one int8 array)
 void launch_label_to_input_order( const int* by_orig, long long n, const float* in_f, float* out_f, int n_f, const int8_t* in_b, int8_t* out_b, hipStream_t st );
 void launch_label_to_query_order( const float4* qpos, long long n, const float* in_f, float* out_f, const int8_t* in_b, int8_t* out_b, hipStream_t st );
+void launch_label_ids_to_input_order( const int* by_orig, long long n, const int8_t* labels_q, const float* mind_q, const int* plc_class, const int* plc_uidx,
+                                      int unlabelled_class, int* class_ids, int* instance_ids, int8_t* labels, float* min_d, hipStream_t st );
+void launch_gather_words( const uint32_t* src, const int* idx, long long count, int words, uint32_t* dst, hipStream_t st );
 // ordered fold of device-resident rows (row k at rows + offsets[k], n floats each; offsets is a device array)
 void launch_label_fold( const float* rows, const long long* offsets, int n_rows, long long n, int label_base, int8_t* labels, float* min_d, bool fresh, hipStream_t st );
 

@@ -8,6 +8,7 @@
 #include "../../include/rescan_dropin.h"
 #include "../../include/rescan_hip.h"
 
+#include <chrono>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
@@ -31,6 +32,26 @@ void complain( const char* where )
 {
   fprintf( stderr, "[rescan_hip] %s: %s\n", where, rs_hip_last_error() );
 }
+
+// RS_DROPIN_STATS=1: where the shim's time went, printed when the process ends (calls / seconds per entry point and route)
+struct Stats
+{
+  bool on = getenv( "RS_DROPIN_STATS" ) != nullptr;
+  struct Row { const char* name; unsigned long long calls = 0, items = 0; double seconds = 0.0; };
+  Row rows[8] = { { "grid init (host index)" }, { "grid device index (lazy)" }, { "radius_search, host path" }, { "radius_search, device path" },
+                  { "icp_align" }, { "scores (flat entry)" }, { "labels (flat entry)" }, { "other" } };
+  ~Stats()
+  {
+    if( !on ) return;
+    for( const Row& r : rows ) if( r.calls ) fprintf( stderr, "[rescan_hip stats] %-28s %9llu calls %12llu items %9.3f s\n", r.name, r.calls, r.items, r.seconds );
+  }
+} g_stats;
+struct Timed
+{
+  Stats::Row* r; std::chrono::steady_clock::time_point t0;
+  Timed( int row, unsigned long long items ) : r( g_stats.on ? &g_stats.rows[row] : nullptr ) { if( r ) { r->calls++; r->items += items; t0 = std::chrono::steady_clock::now(); } }
+  ~Timed() { if( r ) r->seconds += std::chrono::duration<double>( std::chrono::steady_clock::now() - t0 ).count(); }
+};
 
 // ---- device-cloud cache ------------------------------------------------------------------
 // The reference hands the same host arrays to the hot path over and over (the scene level for every proposal,
@@ -239,6 +260,7 @@ rs_hip_cloud_t* device_cloud_of( GridHandle* h )
 {
   std::lock_guard<std::mutex> lock( h->mutex );
   if( h->dev || h->dev_failed ) return h->dev;
+  Timed t( 1, (unsigned long long)h->host.n );
   std::vector<float> pts( (size_t)h->host.n * 3 );
   for( int32_t s = 0; s < h->host.n; ++s )
   {
@@ -277,7 +299,7 @@ void msh_hash_grid_init_3d( rsd_hash_grid_t* hg, const float* pts, const int32_t
   if( rs_hip_synchronize() != RS_HIP_OK ) { complain( "msh_hash_grid_init_3d" ); return; }     // no HIP device: no grid (there is no CPU fallback)
   GridHandle* h = new GridHandle();
   h->src = pts;
-  h->host.build( pts, n_pts, cell );
+  { Timed t( 0, (unsigned long long)( n_pts > 0 ? n_pts : 0 ) ); h->host.build( pts, n_pts, cell ); }
   hg->data_buffer = h;
   hg->width = (size_t)h->host.dims[0]; hg->height = (size_t)h->host.dims[1]; hg->depth = (size_t)h->host.dims[2];
 }
@@ -301,6 +323,7 @@ size_t msh_hash_grid_radius_search( const rsd_hash_grid_t* hg, rsd_search_desc_t
   const size_t host_queries = getenv( "RS_DROPIN_HOST_QUERIES" ) ? (size_t)atoll( getenv( "RS_DROPIN_HOST_QUERIES" ) ) : 4;      // (read per call: tests switch it)
   if( d->n_query_pts <= host_queries )
   {
+    Timed t( 2, d->n_query_pts );
     size_t total = 0;
     for( size_t i = 0; i < d->n_query_pts; ++i )
     {
@@ -312,6 +335,7 @@ size_t msh_hash_grid_radius_search( const rsd_hash_grid_t* hg, rsd_search_desc_t
   }
   rs_hip_cloud_t* c = device_cloud_of( h );
   if( !c ) return 0;
+  Timed t( 3, d->n_query_pts );
   uint64_t total = 0;
   int rc = rs_hip_radius_search( c, d->query_pts, (int64_t)d->n_query_pts, d->radius,
                                  (int32_t)d->max_n_neigh, d->distances_sq, d->indices, d->n_neighbors, &total );
@@ -327,6 +351,7 @@ float icp_align( rsd_vec3_t* pts1, rsd_vec3_t* nor1, int32_t n_pts1, rsd_vec3_t*
   // the reference builds its grids with radius = max_dist (icp.h:436-437); the cell size does not
   // change results here, so the clouds use the density-derived cell (fastest, and shared with the
   // score / label entry points through the cache)
+  Timed timed( 4, (unsigned long long)( n_pts1 > 0 ? n_pts1 : 0 ) );
   rs_hip_cloud_t* src = cached_cloud( pts1, nor1, n_pts1, -1.0f );
   rs_hip_cloud_t* tgt = cached_cloud( pts2, nor2, n_pts2, -1.0f );
   float err = 1e6f; int32_t iters = 0;
@@ -418,6 +443,26 @@ int rsd_arrangement_to_labels( const rsd_vec3_t* scn_pos, const rsd_vec3_t* scn_
   int rc = rs_hip_arrangement_to_labels( scn, (const float*)poses, objs.data(), is_static, class_idx, n_plc, radius,
                                          prioritize_static ? 1 : 0, labels, min_dists.data(), sorted_order );
   if( rc ) complain( "arrangement_to_labels" );
+  return rc;
+}
+
+int rsd_arrangement_to_ids( const rsd_vec3_t* scn_pos, const rsd_vec3_t* scn_nor, int32_t n_scn,
+                            const rsd_vec3_t* const* obj_pos, const rsd_vec3_t* const* obj_nor, const int32_t* obj_n,
+                            const rsd_mat4_t* poses, const int32_t* is_static, const int32_t* class_idx, const int32_t* uidx, int32_t n_plc,
+                            float radius, bool prioritize_static, int32_t unlabelled_class_idx,
+                            int32_t* class_ids, int32_t* instance_ids )
+{
+  rs_hip_cloud_t* scn = cached_cloud( scn_pos, scn_nor, n_scn, -1.0f );
+  if( !scn ) return RS_HIP_E_RUNTIME;
+  std::vector<const rs_hip_cloud_t*> objs( (size_t)( n_plc > 0 ? n_plc : 0 ) );
+  for( int i = 0; i < n_plc; ++i )
+  {
+    objs[i] = cached_cloud( obj_pos[i], obj_nor[i], obj_n[i], -1.0f );
+    if( !objs[i] ) return RS_HIP_E_RUNTIME;
+  }
+  int rc = rs_hip_arrangement_to_ids( scn, (const float*)poses, objs.data(), is_static, class_idx, uidx, n_plc, radius,
+                                      prioritize_static ? 1 : 0, unlabelled_class_idx, class_ids, instance_ids, nullptr, nullptr, nullptr );
+  if( rc ) complain( "arrangement_to_ids" );
   return rc;
 }
 

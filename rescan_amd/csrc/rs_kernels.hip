@@ -1926,6 +1926,41 @@ __global__ __launch_bounds__( BLOCK ) void k_label_to_query_order( const float4*
   if( in_f ) out_f[s] = in_f[j];
   if( in_b ) out_b[s] = in_b[j];
 }
+// The tail of rspf_arrangement_to_labels (lib/rs/rs_pointcloud_filters.cpp:851-869): temporary labels -> class / instance
+// ids, written in input order together with the state's move out of query order.  label 0: (unlabelled class, 1024).
+__global__ __launch_bounds__( BLOCK ) void k_label_ids_to_input_order( const int* by_orig, long long n, const int8_t* labels_q, const float* mind_q,
+                                                                       const int* plc_class, const int* plc_uidx, int unlabelled_class,
+                                                                       int* class_ids, int* instance_ids, int8_t* labels, float* min_d )
+{
+  const long long j = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if( j >= n ) return;
+  const int s = by_orig[j];
+  const int l = labels_q[s];
+  class_ids[j] = l == 0 ? unlabelled_class : plc_class[l - 1];            // :856-866
+  instance_ids[j] = l == 0 ? 1024 : plc_uidx[l - 1];                      // RSPF_MAX_INSTANCES (:20)
+  labels[j] = (int8_t)l; min_d[j] = mind_q[s];
+}
+void launch_label_ids_to_input_order( const int* by_orig, long long n, const int8_t* labels_q, const float* mind_q, const int* plc_class, const int* plc_uidx,
+                                      int unlabelled_class, int* class_ids, int* instance_ids, int8_t* labels, float* min_d, hipStream_t st )
+{
+  hipLaunchKernelGGL( k_label_ids_to_input_order, dim3( (unsigned)( ( n + BLOCK - 1 ) / BLOCK ) ), dim3( BLOCK ), 0, st, by_orig, n, labels_q, mind_q,
+                      plc_class, plc_uidx, unlabelled_class, class_ids, instance_ids, labels, min_d );
+}
+
+// dst[i] = src[idx[i]] for records of `words` 32-bit words (the attribute gathers of a level, lib/rs/rs_pointcloud.h:1090-1099)
+__global__ __launch_bounds__( BLOCK ) void k_gather_words( const uint32_t* src, const int* idx, long long count, int words, uint32_t* dst )
+{
+  const long long t = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if( t >= count * words ) return;
+  const long long i = t / words; const int w = (int)( t - i * words );
+  dst[t] = src[(size_t)idx[i] * words + w];
+}
+void launch_gather_words( const uint32_t* src, const int* idx, long long count, int words, uint32_t* dst, hipStream_t st )
+{
+  if( count <= 0 ) return;
+  hipLaunchKernelGGL( k_gather_words, dim3( (unsigned)( ( count * words + BLOCK - 1 ) / BLOCK ) ), dim3( BLOCK ), 0, st, src, idx, count, words, dst );
+}
+
 void launch_label_to_input_order( const int* by_orig, long long n, const float* in_f, float* out_f, int n_f, const int8_t* in_b, int8_t* out_b, hipStream_t st )
 {
   hipLaunchKernelGGL( k_label_to_input_order, dim3( (unsigned)( ( n + BLOCK - 1 ) / BLOCK ) ), dim3( BLOCK ), 0, st, by_orig, n, in_f, out_f, n_f, in_b, out_b );

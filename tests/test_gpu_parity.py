@@ -243,6 +243,38 @@ def test_labels_prioritize_static_vs_oracle(capi, oracle, gscene, scene_clouds):
     assert (res["labels"] == want["labels"]).all() and (res["min_dists"] == want["min_dists"]).all()
 
 
+@pytest.mark.parametrize("fname", golden_files("labels_"))
+@pytest.mark.parametrize("prioritize", [False, True])
+def test_class_and_instance_ids_vs_oracle(capi, oracle, gscene, scene_clouds, fname, prioritize):
+    """The tail of rspf_arrangement_to_labels (lib/rs/rs_pointcloud_filters.cpp:851-869), mapped on the device: the class of
+    the labelled placement's object, the placement's uidx, (unlabelled class, 1024) where nothing was assigned."""
+    d, objs, plcs = label_case(gscene, fname)
+    clouds, _ = scene_clouds
+    unl = 37
+    want = oracle.arrangement_to_labels(gscene["points"], gscene["normals"], objs, plcs, 0.05, int(prioritize), unl)
+    oc = [capi.Cloud(o["pos"], o["nor"], cell_size=0.1) for o in objs]
+    res = capi.arrangement_to_ids(clouds[0.05], np.stack([p["pose"] for p in plcs]), [oc[p["object_idx"]] for p in plcs],
+                                  [objs[p["object_idx"]]["is_static"] for p in plcs], [objs[p["object_idx"]]["class_idx"] for p in plcs],
+                                  [p["uidx"] for p in plcs], 0.05, prioritize, unl)
+    assert (res["class_ids"] == want["class_ids"]).all() and (res["instance_ids"] == want["instance_ids"]).all()
+    assert (res["labels"] == want["labels"]).all() and (res["min_dists"] == want["min_dists"]).all()
+    assert (res["instance_ids"][res["labels"] == 0] == 1024).all() and (res["class_ids"][res["labels"] == 0] == unl).all()
+
+
+def test_level_attribute_gathers(capi, gscene):
+    """rs_pointcloud.h:1090-1099: every per-point array of level 0 at the level's sample indices."""
+    g = load_golden("level.npz")
+    pts = gscene["points"]
+    rng = np.random.default_rng(5)
+    col = rng.random((len(pts), 3)).astype(np.float32); rad = rng.random(len(pts)).astype(np.float32)
+    cls = rng.integers(0, 40, len(pts)).astype(np.int32)
+    idx = g["own_l2"]
+    out = capi.gather_attributes(idx, [pts, gscene["normals"], col, rad, cls])
+    for got, src in zip(out, [pts, gscene["normals"], col, rad, cls]):
+        assert np.array_equal(got, src[idx])
+    assert capi.gather_attributes(np.zeros(0, np.int32), [rad])[0].shape == (0,)
+
+
 # ---- neighbourhood graph (SURVEY §8f row 1) -------------------------------------------------
 
 def _edges_sorted(a, b, w, n):

@@ -63,9 +63,13 @@ def read_pose_bin(path):
     return out
 
 
-def run(cmd, cwd, env=None, timeout=3000):
+def run(cmd, cwd, env=None, timeout=240):
     t = time.perf_counter()
-    r = subprocess.run(cmd, cwd=cwd, capture_output=True, text=True, timeout=timeout, env=env)
+    try:
+        r = subprocess.run(cmd, cwd=cwd, capture_output=True, text=True, timeout=timeout, env=env)
+    except subprocess.TimeoutExpired as e:
+        r = subprocess.CompletedProcess(cmd, returncode=-9, stdout=(e.stdout or b"").decode(errors="replace") if isinstance(e.stdout, bytes) else (e.stdout or ""),
+                                        stderr="timed out after %d s" % timeout)
     return r, time.perf_counter() - t
 
 
@@ -118,6 +122,12 @@ def main():
             env = dict(os.environ)
             if build in ("icp", "grid"):
                 env["HIP_VISIBLE_DEVICES"] = str(device)
+            if build == "omp":
+                # The reference's OpenMP split (msh_hash_grid.h:1119-1133) underflows `high_lim - low_lim` whenever
+                # (T - 1) * ceil(n / T) > n for a call's n query points — with the 128 threads of this host that is every
+                # object level of a few hundred points, and the app then loops (practically) forever.  8 threads is what
+                # SURVEY.md §6 measured (4.2x, byte-identical output); a run that still hangs is cut off and reported as failed.
+                env["OMP_NUM_THREADS"] = os.environ.get("RS_SCENE_LIST_OMP_THREADS", "8")
             dst = os.path.join(name, f"{stem}_pp_{build}.rsdb")
             r, dt = run([os.path.join(REF, BUILDS[build]), prev, os.path.join(name, "gt_segmentation", stem + ".ply"), dst, "-v"], work, env)
             ok = r.returncode == 0 and "[rescan_hip]" not in r.stderr
@@ -170,6 +180,7 @@ def main():
                               identical=int(sum(r.get("identical", 0) for r in pr)), proposals=int(sum(r.get("n_proposals", 0) for r in pr)))
     out = dict(config="BASELINE.json configs[0]/[4]: scene_list batch, seg2rsdb -> pose_proposal (segment_transfer not run: gco-v3.0 is not vendored)",
                sequences=names, points_per_scan=n_pts, density=args.density, gpus=args.gpus, host_cores=len(os.sched_getaffinity(0)),
+               omp_threads=int(os.environ.get("RS_SCENE_LIST_OMP_THREADS", "8")),
                builds_missing=missing, summary=summary, rows=rows)
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     json.dump(out, open(args.out, "w"), indent=1)
