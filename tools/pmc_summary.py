@@ -38,15 +38,18 @@ if __name__ == "__main__":
         F, W = raw["FETCH_SIZE"], raw["WRITE_SIZE"]
         def total(names):
             return sum((2 * F[k][0] + W.get(k, (0, 0))[0]) * F[k][1] for k in F if any(n in k for n in names)) * 1024
-        doms = {"nn_icp": (["k_icp_corr"], "rs::k_icp_corr"), "icp_moments": (["k_icp_moments", "k_icp_update"], "rs::k_icp_moments"),
-                "nn_score": (["k_score"], "rs::k_score"), "nn_label": (["k_label"], "rs::k_label")}
+        # domain -> (kernels that belong to it, kernels whose launches count as ONE unit of it)
+        doms = {"nn_icp": (["k_icp_corr"], ["k_icp_corr<"]), "icp_moments": (["k_icp_moments", "k_icp_update"], ["k_icp_moments"]),
+                "nn_score": (["k_score"], ["rs::k_score("]), "nn_label": (["k_label"], ["rs::k_label("])}
         out = {"_note": "HBM-side bytes per launch from rocprofv3 PMC (separate FETCH_SIZE and WRITE_SIZE passes of `bench.py --steps 2 "
                         "--warmup 1 --serial`, tools/profile.sh traffic, folded by tools/pmc_summary.py --fold), FETCH_SIZE doubled as "
                         "MI355X_MICROARCH.md \u00a7HBM prescribes for 16-B-per-lane reads on gfx950; WRITE_SIZE as reported.  nn_icp = "
-                        "k_icp_corr + k_icp_corr_coop<4|8> (one search).  Part of the search kernels' writes are register spills to "
-                        "scratch (phase A and the score / label kernels: occupancy-6 register caps), not results."}
+                        "k_icp_corr<cold|warm> + k_icp_corr_coop<4|8> (one search); nn_label = k_label + the gather to input order.  "
+                        "Atomics (statistics, queues, the profiling counters) execute at the memory side and count 64 B each."}
+        def launches(keys):
+            return sum(F[k][1] for k in F if any(q in (k + "(") for q in keys) and "coop" not in k)
         for d, (names, per) in doms.items():
-            out[d] = total(names) / F[per][1]
+            out[d] = total(names) / max(1, launches(per))
         out["kernels_sha"] = raw.get("kernels_sha")
         out["raw_avg_KB"] = {c: {k: v[0] for k, v in raw[c].items()} for c in ("FETCH_SIZE", "WRITE_SIZE")}
         json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
