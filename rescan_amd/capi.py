@@ -36,6 +36,8 @@ SIGNATURES = {
     "rs_hip_icp_align": (C.c_int, [C.c_void_p, C.c_void_p, f32p, f32p, C.c_float, C.c_float, C.c_int32, C.c_int32,
                                    C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "rs_hip_icp_reference_order_below": (C.c_int32, [C.c_int32]),
+    "rs_hip_icp_replay_below": (C.c_int32, [C.c_int32]),
+    "rs_hip_icp_replay_redone": (C.c_int32, []),
     "rs_hip_icp_align_batch": (C.c_int, [C.c_void_p, C.c_void_p, f32p, C.c_int32, f32p, C.c_float, C.c_float,
                                          C.c_int32, C.c_int32, f32p, i32p]),
     "rs_hip_icp_find_corrs": (C.c_int, [C.c_void_p, C.c_void_p, f32p, f32p, C.c_float, C.c_float,
@@ -198,6 +200,16 @@ def icp_reference_order_below(n_points=-1):
     """Sources of at most n_points points run the estimator in the reference's accumulation order (bit-identical
     results); -1 only reads.  Returns the previous threshold."""
     return int(load().rs_hip_icp_reference_order_below(int(n_points)))
+
+
+def icp_replay_below(n_points=-1):
+    """Threshold up to which sources above the reference-order threshold get the reference's sums computed in parallel
+    (same bits); -1 only reads.  Returns the previous threshold."""
+    return int(load().rs_hip_icp_replay_below(int(n_points)))
+
+
+def icp_replay_redone():
+    return int(load().rs_hip_icp_replay_redone())
 
 
 def icp_align(source, target, T1, T2=IDENTITY, max_dist=0.1, max_angle=np.deg2rad(60.0), max_iter=100,

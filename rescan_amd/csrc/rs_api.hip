@@ -108,6 +108,7 @@ struct Workspace
   DevBuf tmp_pos, tmp_pos2, tmp_nor2;                                           // estimate-only
   DevBuf lvl_pos, lvl_nor, lvl_cnt, lvl_within, lvl_offset, lvl_adj, lvl_state, lvl_misc, lvl_flags, lvl_scan, lvl_samples, lvl_tmp, lvl_cursor, lvl_work_a, lvl_work_b;   // level builder
   DevBuf faith;                                                                 // reference-order estimator: correspondences in source order
+  DevBuf rp_segsum, rp_guess, rp_seg, rp_totals, rp_redone;                     // ... its parallel form (replay)
   PinBuf h_a, h_b, h_c;
 };
 thread_local Workspace g_ws;
@@ -118,6 +119,10 @@ bool g_prof = false;
 // (bit-identical poses, errors and iteration counts); larger ones the fp64 moment reduction.  65 536 covers
 // every icp_align call site of the reference (level-2 objects, 2-10 k points; scene extracts of up to ~50 k).
 std::atomic<int> g_ref_order_below{ getenv( "RS_HIP_REF_ORDER_BELOW" ) ? atoi( getenv( "RS_HIP_REF_ORDER_BELOW" ) ) : 65536 };
+// Above that and up to this many source points the SAME sums are computed in parallel (rs_kernels.hip: "replay" — the reference's
+// bits again, about twice as fast as the sequential chains on scan-sized sources, still ten times the fp64 moments: off by
+// default); beyond, the fp64 moments.
+std::atomic<int> g_replay_below{ getenv( "RS_HIP_REPLAY_BELOW" ) ? atoi( getenv( "RS_HIP_REPLAY_BELOW" ) ) : 0 };
 std::mutex g_prof_mutex;
 struct ProfEntry { std::vector<std::pair<hipEvent_t, hipEvent_t>> spans; int64_t launches = 0; double ms = 0.0; };
 std::map<std::string, ProfEntry> g_profmap;
@@ -642,6 +647,20 @@ int icp_prepare( IcpCtx& cx, const rs_hip_cloud_t* src, const rs_hip_cloud_t* tg
   return RS_HIP_OK;
 }
 
+// buffers of the parallel reference-order estimator for n_prob problems of n_source points
+int replay_prepare( ReplayBufs& B, int n_prob, int n_source )
+{
+  B.n_seg = replay_segments( n_source );
+  const size_t rows = (size_t)n_prob * ICP_NMOM * (size_t)B.n_seg;
+  int rc;
+  if( ( rc = g_ws.rp_segsum.ensure( rows * 8 ) ) || ( rc = g_ws.rp_guess.ensure( rows * 8 ) ) || ( rc = g_ws.rp_seg.ensure( rows * replay_seg_bytes() ) ) ||
+      ( rc = g_ws.rp_totals.ensure( (size_t)n_prob * 3 * ICP_NMOM * 8 ) ) || ( rc = g_ws.rp_redone.ensure( (size_t)n_prob * 4 + 64 ) ) ) return rc;
+  B.segsum = g_ws.rp_segsum.as<double>(); B.guess = g_ws.rp_guess.as<double>(); B.seg = (ReplaySeg*)g_ws.rp_seg.p;
+  B.totals = g_ws.rp_totals.as<double>(); B.redone = g_ws.rp_redone.as<int>();
+  HIP_TRY( hipMemsetAsync( g_ws.rp_redone.p, 0, (size_t)n_prob * 4 + 64, g_stream ), RS_HIP_E_RUNTIME );
+  return RS_HIP_OK;
+}
+
 // initial loop state (icp.h:441-442: errors start at 1e6)
 int icp_upload_state( IcpCtx& cx, const float* T1s, size_t np )
 {
@@ -778,10 +797,14 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
   if( source->n == 0 ) { for( int p = 0; p < n; ++p ) { errs[p] = 1e6f; if( iters ) iters[p] = 1; } return RS_HIP_OK; }   // n_corrs == 0 on the first search
   if( ( rc = icp_enable_certificates( cx, (size_t)n, (size_t)source->n ) ) ) return rc;
   if( ( rc = icp_upload_state( cx, T1s, (size_t)n ) ) ) return rc;
-  if( source->n <= g_ref_order_below.load() )
+  const bool ref_order = source->n <= g_ref_order_below.load();
+  const bool replay = !ref_order && source->n <= g_replay_below.load();
+  ReplayBufs RB{};
+  if( ref_order || replay )
   {
     if( ( rc = g_ws.faith.ensure( (size_t)n * FAITH_REC * (size_t)source->n * 4 ) ) ) return rc;
     cx.L.faith = g_ws.faith.as<float>();
+    if( replay && ( rc = replay_prepare( RB, n, source->n ) ) ) return rc;
   }
   else
   {
@@ -835,7 +858,8 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
       prof.mark( "nn_icp" ); launch_icp_corr( cx.L, g_stream );
       if( debug ) icp_debug_after( cx, source->n, n, i, max_dist );
       prof.mark( "icp_moments" );
-      if( cx.L.faith ) launch_icp_faithful( cx.L, g_stream ); else launch_icp_moments( cx.L, g_stream );
+      if( replay ) launch_icp_replay( cx.L, RB, g_stream );
+      else if( cx.L.faith ) launch_icp_faithful( cx.L, g_stream ); else launch_icp_moments( cx.L, g_stream );
       double nd = max_dist * 0.95;                                      // icp.h:493
       max_dist = (float)( nd > 0.05 ? nd : 0.05 );
     }
@@ -856,6 +880,20 @@ int32_t rs_hip_icp_reference_order_below( int32_t n_points )
   const int prev = g_ref_order_below.load();
   if( n_points >= 0 ) g_ref_order_below.store( n_points );
   return prev;
+}
+
+int32_t rs_hip_icp_replay_below( int32_t n_points )
+{
+  const int prev = g_replay_below.load();
+  if( n_points >= 0 ) g_replay_below.store( n_points );
+  return prev;
+}
+
+int32_t rs_hip_icp_replay_redone( void )
+{
+  int v = 0;
+  if( g_ws.rp_redone.p && hipMemcpy( &v, g_ws.rp_redone.p, 4, hipMemcpyDeviceToHost ) != hipSuccess ) return -1;
+  return v;
 }
 
 int rs_hip_icp_align( const rs_hip_cloud_t* source, const rs_hip_cloud_t* target,
@@ -970,13 +1008,19 @@ int rs_hip_icp_estimate_pt2pl( const float* pts1, const float* pts2, const float
   L.radius = 1.0f; L.m_slot = g_ws.slot.as<int>(); L.m_d2 = g_ws.d2.as<float>(); L.m_dot = g_ws.dot.as<float>();
   L.mom_part = g_ws.mom_part.as<double>(); L.res = g_ws.res.as<double>();
   L.n_mom_blocks = std::max( 1, std::min( 256, ( n + 255 ) / 256 ) ); L.w_explicit = g_ws.wexp.as<float>();
-  if( n <= g_ref_order_below.load() )
+  if( n <= std::max( g_ref_order_below.load(), g_replay_below.load() ) )
   {
-    // the reference's own accumulation order (k_icp_faithful): solve and pose update on the device too
+    // the reference's own accumulation order (k_icp_faithful, or its parallel form): solve and pose update on the device too
     if( ( rc = g_ws.faith.ensure( nn * FAITH_REC * 4 ) ) ) return rc;
     L.faith = g_ws.faith.as<float>(); L.by_orig = nullptr; L.err = g_ws.state.as<float>() + 34;
     // (the points are presented untransformed, so the state's pose stays the identity uploaded above and T1 is multiplied in afterwards)
-    { ProfScope ps( "icp_moments" ); launch_icp_faithful( L, g_stream ); }
+    if( n <= g_ref_order_below.load() ) { ProfScope ps( "icp_moments" ); launch_icp_faithful( L, g_stream ); }
+    else
+    {
+      ReplayBufs RB{};
+      if( ( rc = replay_prepare( RB, 1, n ) ) ) return rc;
+      ProfScope ps( "icp_moments" ); launch_icp_replay( L, RB, g_stream );
+    }
     float out[ICP_STATE_WORDS];
     HIP_TRY( hipMemcpyAsync( out, g_ws.state.p, sizeof( out ), hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
     HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );

@@ -114,6 +114,20 @@ void launch_icp_corr( const IcpLaunch& L, hipStream_t st );     // phase A, phas
 void launch_icp_moments( const IcpLaunch& L, hipStream_t st );  // weights + moments (+ solve and loop-state update if L.solve)
 constexpr int FAITH_REC = 11;   // per correspondence: dist² (< 0: none), dot | weight, p, q, n
 void launch_icp_faithful( const IcpLaunch& L, hipStream_t st ); // the same step with the reference's own accumulation order and precisions
+// ... and the same bits computed in parallel (rs_kernels.hip: "replay"): per problem and accumulator row (ICP_NMOM rows per pass)
+struct ReplaySeg;
+struct ReplayBufs
+{
+  int     n_seg;        // segments of 128 source points
+  double* segsum;       // n_prob x ICP_NMOM x n_seg
+  double* guess;        // n_prob x ICP_NMOM x n_seg
+  ReplaySeg* seg;       // n_prob x ICP_NMOM x n_seg
+  double* totals;       // n_prob x 3 passes x ICP_NMOM: the accumulators' final values
+  int*    redone;       // n_prob: segments re-added sequentially (diagnostics; may be null)
+};
+void   launch_icp_replay( const IcpLaunch& L, const ReplayBufs& B, hipStream_t st );
+int    replay_segments( int n_source );
+size_t replay_seg_bytes();
 
 struct ScoreLaunch
 {

@@ -1694,6 +1694,392 @@ __global__ __launch_bounds__( FAITH_THREADS ) void k_icp_faithful( IcpLaunch L )
   if( !L.fixed_iters && L.iter_index > 5 && delta < 1e-5 ) L.active[prob] = 0;   // icp.h:489
 }
 
+// ------------------------------------------------------------------------------------------
+// The reference-order estimator, in parallel ("replay")
+//
+// k_icp_faithful above runs each of the reference's accumulators as ONE sequential chain: 10-12 ns per source point and
+// iteration, 1.5 ms per iteration on a 134 k-point scan.  The same bits can be had in parallel, because of what an IEEE
+// addition S + x does while S stays inside one binade [2^e, 2^(e+1)): it adds x ROUNDED TO THE BINADE'S GRID (ulp u), and that
+// rounding does not depend on S — except for an exact tie (x mod u = u/2), which goes to the even neighbour, i.e. depends on
+// the parity of S's mantissa.  So over a stretch of addends during which the accumulator stays inside its binade, the
+// sequential sum is   S_out = S_in + D(parity of S_in),   with D a constant of the stretch.
+//
+//   k_replay_sums   cuts the source (original order) into segments of 128 points and sums every accumulator's addends per
+//                   segment in fp64;
+//   k_replay_scan   prefix-sums those per accumulator: a GUESS of the accumulator's value at every segment start (good to a
+//                   few thousand ulps: the real chain's own rounding is what it misses);
+//   k_replay_run    runs, for every segment and accumulator in parallel, the real fp32 (fp64) chain over the segment from the
+//                   guess — once per CLASS of the start's mantissa modulo 4 — and records for which exact starts of that class
+//                   the chain is the exact chain shifted: the shift delta = (exact start - class start), in units of the
+//                   start's ulp, must keep every intermediate value strictly inside the binade the class's chain visits at
+//                   that step (an interval for delta, intersected over the 128 steps — the chain may cross binades), and must
+//                   be an EVEN number of grid steps in every binade visited (so that ties round the same way: delta a multiple
+//                   of 2^(k+1) where the grid is 2^k coarser than the start's);
+//   k_replay_walk   one wave per accumulator walks the segments in order with the EXACT value: if its sign / exponent are the
+//                   guess's and delta passes the class's tests, the segment's result is the class's end value shifted by delta
+//                   (in the end binade's grid) — exact, by the argument above; otherwise (a sign change inside the segment,
+//                   the start of a chain, a guess in the wrong binade) the wave re-adds the segment's 128 addends one after
+//                   the other.
+//
+// Three passes like k_icp_faithful (statistics -> weights and centroids -> normal equations), each needing the previous one's
+// totals; every block recomputes the few scalars between passes itself.  Addends come from the same faith_terms<PASS> the
+// sequential kernel uses.  Result: the reference's bits (tests: against k_icp_faithful and the reference-generated fixtures).
+// ------------------------------------------------------------------------------------------
+#define REPLAY_SEG 128
+#define REPLAY_PITCH ( REPLAY_SEG + 4 )
+
+template <int PASS> struct ReplayRows;
+template <> struct ReplayRows<1> { enum { NF = 3, ND = 0 }; };     // Σd², Σd⁴, count
+template <> struct ReplayRows<2> { enum { NF = 7, ND = 0 }; };     // Σw, Σw·p (3), Σw·q (3)
+template <> struct ReplayRows<3> { enum { NF = 33, ND = 2 }; };    // 3x3 blocks, rhs | Σw·s², Σw (fp64 in the reference)
+
+#define REPLAY_CLS 4
+// What k_replay_run records per (accumulator, segment) and class c = (start mantissa mod 4) — start = the guess's bits with
+// the two low mantissa bits cleared, class start = start | c.  With delta = m - (class start's mantissa): the record is
+// usable iff sign + exponent match, dmin <= delta <= dmax (dmax < dmin: never) and delta is a multiple of 2 << need_k; the
+// result is then `end` with its mantissa advanced by delta >> k_end (k_end >= 0) or delta << -k_end.
+struct ReplayCls { long long dmin, dmax; unsigned long long end; int need_k, k_end; };
+struct ReplaySeg { unsigned long long start; unsigned long long pad; ReplayCls cls[REPLAY_CLS]; };
+
+// the scalars between the passes, from the totals of the finished passes (identical code to k_icp_faithful's)
+__device__ __forceinline__ bool replay_params( const IcpLaunch& L, int prob, int pass, const double* totals /* ICP_NMOM per pass */, FaithPar& P )
+{
+  P.w_explicit = L.w_explicit != nullptr; P.use_sd = false; P.max_dist = L.radius; P.cut = 0.0f;
+  P.c1[0] = P.c1[1] = P.c1[2] = P.c2[0] = P.c2[1] = P.c2[2] = 0.0f;
+  if( pass >= 2 && !P.w_explicit )
+  {
+    const double* t1 = totals;                                         // pass 1: Σd², Σd⁴, count (floats kept in doubles)
+    const float cnt = (float)t1[2];
+    if( cnt == 0.0f ) return false;
+    const float mean = __fdiv_rn( (float)t1[0], cnt );                 // msh_std.h:1800-1825
+    const float var = __fdiv_rn( (float)t1[1], cnt ) - mean * mean;
+    const float sd = (float)sqrt( (double)var );
+    P.use_sd = sd > 0.000001;
+    P.cut = 2.5f * sd;
+  }
+  if( pass >= 3 )
+  {
+    const double* t2 = totals + ICP_NMOM;                              // pass 2: Σw, Σw·p, Σw·q
+    const float total = (float)t2[0];
+    if( total <= 1e-7 ) return false;
+    const float inv = __fdiv_rn( 1.0f, total );
+#pragma unroll
+    for( int a = 0; a < 3; ++a ) { P.c1[a] = (float)t2[1 + a] * inv; P.c2[a] = (float)t2[4 + a] * inv; }
+  }
+  return true;
+}
+
+// the addends of segment g for pass PASS, into term[row][t] (all rows of the pass, 128 columns; columns past the cloud hold +0)
+template <int PASS>
+__device__ __forceinline__ void replay_terms( const IcpLaunch& L, int prob, int g, const FaithPar& P, float ( *term )[REPLAY_PITCH] )
+{
+  const int n = L.src.n;
+  const float* F = L.faith + (size_t)prob * FAITH_REC * n;
+  for( int t = threadIdx.x; t < REPLAY_SEG; t += blockDim.x )
+  {
+    FaithRec r; faith_load( F, n, g * REPLAY_SEG + t, r );
+    faith_terms<PASS>( r, P, reinterpret_cast<float ( * )[FAITH_PITCH]>( term ), t );
+  }
+}
+static_assert( REPLAY_PITCH == FAITH_PITCH, "replay_terms reuses faith_terms' LDS layout" );
+
+template <int PASS>
+__global__ __launch_bounds__( REPLAY_SEG ) void k_replay_sums( IcpLaunch L, ReplayBufs B )
+{
+  __shared__ __attribute__( ( aligned( 16 ) ) ) float term[ICP_NMOM][REPLAY_PITCH];
+  const int prob = blockIdx.y, g = blockIdx.x;
+  if( L.active[prob] == 0 ) return;
+  FaithPar P;
+  const double* totals = B.totals + (size_t)prob * 3 * ICP_NMOM;
+  if( !replay_params( L, prob, PASS, totals, P ) ) return;
+  replay_terms<PASS>( L, prob, g, P, term );
+  __syncthreads();
+  constexpr int NR = ReplayRows<PASS>::NF + ReplayRows<PASS>::ND;
+  if( threadIdx.x < NR )
+  {
+    double a = 0.0;
+    for( int t = 0; t < REPLAY_SEG; ++t ) a += (double)term[threadIdx.x][t];
+    B.segsum[( (size_t)prob * ICP_NMOM + threadIdx.x ) * B.n_seg + g] = a;
+  }
+}
+
+// exclusive prefix over the segments, per accumulator: the guesses (as the accumulator's own type: float rows, double rows)
+template <int PASS>
+__global__ __launch_bounds__( WAVE ) void k_replay_scan( IcpLaunch L, ReplayBufs B )
+{
+  const int prob = blockIdx.y, row = blockIdx.x;
+  if( L.active[prob] == 0 ) return;
+  const int lane = threadIdx.x;
+  const double* in = B.segsum + ( (size_t)prob * ICP_NMOM + row ) * B.n_seg;
+  double* out = B.guess + ( (size_t)prob * ICP_NMOM + row ) * B.n_seg;
+  double carry = 0.0;
+  for( int g0 = 0; g0 < B.n_seg; g0 += WAVE )
+  {
+    const int g = g0 + lane;
+    double v = g < B.n_seg ? in[g] : 0.0;
+    // inclusive scan over the 64 lanes (any association will do: this is a guess)
+    double incl = v;
+#pragma unroll
+    for( int d = 1; d < WAVE; d <<= 1 )
+    {
+      const double up = __shfl_up( incl, d );
+      if( lane >= d ) incl += up;
+    }
+    if( g < B.n_seg ) out[g] = carry + ( incl - v );
+    carry += __shfl( incl, WAVE - 1 );
+  }
+}
+
+// one accumulator type: the bit-level view of fp32 / fp64 the replay needs
+template <class T> struct Bits;
+template <> struct Bits<float>
+{
+  typedef uint32_t U; enum { MBITS = 23 };
+  static __device__ __forceinline__ U of( float v ) { return __float_as_uint( v ); }
+  static __device__ __forceinline__ float from( U b ) { return __uint_as_float( b ); }
+};
+template <> struct Bits<double>
+{
+  typedef unsigned long long U; enum { MBITS = 52 };
+  static __device__ __forceinline__ U of( double v ) { return (U)__double_as_longlong( v ); }
+  static __device__ __forceinline__ double from( U b ) { return __longlong_as_double( (long long)b ); }
+};
+
+// the chain of one (accumulator, segment, class)
+template <class T>
+__device__ __forceinline__ void replay_run_chain( const float* row, double guess, int c, ReplaySeg& out )
+{
+  typedef typename Bits<T>::U U;
+  constexpr int MB = Bits<T>::MBITS, EB = 8 * sizeof(T) - 1 - MB;
+  constexpr int KMAX = MB == 23 ? 20 : 8;                       // (shifted mantissas must fit 63 bits)
+  const U mmask = ( (U)1 << MB ) - 1, emax = ( (U)1 << EB ) - 1;
+  const T gT = (T)guess;
+  const U gb = Bits<T>::of( gT ) & ~(U)( REPLAY_CLS - 1 );
+  const int e0 = (int)( ( gb >> MB ) & emax );
+  const bool usable = e0 != 0 && e0 != (int)emax;               // normal, finite, non-zero
+  if( c == 0 ) { out.start = (unsigned long long)gb; out.pad = 0ull; }
+  const U sb = gb | (U)c;
+  T acc = Bits<T>::from( sb );
+  const long long m0 = (long long)( sb & mmask );
+  long long dmin = 1 - m0, dmax = (long long)mmask - 1 - m0;
+  int need_k = 0, k = 0;
+  bool valid = usable;
+  for( int t = 0; t < REPLAY_SEG; ++t )
+  {
+    acc += (T)row[t];
+    const U b = Bits<T>::of( acc );
+    const int e = (int)( ( b >> MB ) & emax );
+    k = e - e0;
+    valid = valid && !( ( b ^ sb ) >> ( 8 * sizeof(T) - 1 ) ) && e != 0 && e != (int)emax && k <= KMAX && k >= -KMAX;
+    const int kk = valid ? k : 0;                              // (keeps the shifts below defined once the chain is lost)
+    const long long M = (long long)( b & mmask );
+    long long lo = 1 - M, hi = (long long)mmask - 1 - M;       // allowed shift of this value, in its own binade's grid steps
+    if( kk >= 0 ) { lo <<= kk; hi <<= kk; need_k = kk > need_k ? kk : need_k; }
+    else
+    {
+      const int sh = -kk; const long long rnd = ( 1ll << sh ) - 1;
+      lo = lo >= 0 ? ( ( lo + rnd ) >> sh ) : -( ( -lo ) >> sh );          // ceil( lo / 2^sh )
+      hi = hi >= 0 ? ( hi >> sh ) : -( ( -hi + rnd ) >> sh );              // floor( hi / 2^sh )
+    }
+    dmin = lo > dmin ? lo : dmin; dmax = hi < dmax ? hi : dmax;
+  }
+  ReplayCls r;
+  r.dmin = valid ? dmin : 1; r.dmax = valid ? dmax : 0;
+  r.end = (unsigned long long)Bits<T>::of( acc );
+  r.need_k = need_k; r.k_end = valid ? k : 0;
+  out.cls[c] = r;
+}
+
+#define REPLAY_RUN_THREADS 192        // >= 35 rows x 4 classes and >= REPLAY_SEG term producers
+template <int PASS>
+__global__ __launch_bounds__( REPLAY_RUN_THREADS ) void k_replay_run( IcpLaunch L, ReplayBufs B )
+{
+  __shared__ __attribute__( ( aligned( 16 ) ) ) float term[ICP_NMOM][REPLAY_PITCH];
+  const int prob = blockIdx.y, g = blockIdx.x;
+  if( L.active[prob] == 0 ) return;
+  FaithPar P;
+  const double* totals = B.totals + (size_t)prob * 3 * ICP_NMOM;
+  if( !replay_params( L, prob, PASS, totals, P ) ) return;
+  replay_terms<PASS>( L, prob, g, P, term );
+  __syncthreads();
+  constexpr int NF = ReplayRows<PASS>::NF, NR = NF + ReplayRows<PASS>::ND;
+  static_assert( NR * REPLAY_CLS <= REPLAY_RUN_THREADS, "one thread per (row, class)" );
+  const int row = threadIdx.x / REPLAY_CLS, c = threadIdx.x % REPLAY_CLS;
+  if( row < NR )
+  {
+    const size_t o = ( (size_t)prob * ICP_NMOM + row ) * B.n_seg + g;
+    if( row < NF ) replay_run_chain<float>( term[row], B.guess[o], c, B.seg[o] );
+    else           replay_run_chain<double>( term[row], B.guess[o], c, B.seg[o] );
+  }
+}
+
+// The walk of one accumulator over its segments, with the exact value.  Lane l of the wave holds the record of segment g0 + l
+// in registers; step j fetches lane j's fields with v_readlane (j is uniform), so the running value, the record and all the
+// arithmetic of a step live in SCALAR registers: no memory access and no vector-ALU latency on the chain of 10^3-10^4 dependent
+// steps (a version that read the records from LDS spent 740 cycles per step).
+template <class T> struct ReplayFields;
+template <> struct ReplayFields<float>  { typedef int I; };
+template <> struct ReplayFields<double> { typedef long long I; };
+
+__device__ __forceinline__ int rl( int v, int lane ) { return __builtin_amdgcn_readlane( v, lane ); }
+__device__ __forceinline__ uint32_t rl( uint32_t v, int lane ) { return (uint32_t)__builtin_amdgcn_readlane( (int)v, lane ); }
+__device__ __forceinline__ long long rl( long long v, int lane )
+{
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane( (int)(uint32_t)v, lane ), hi = (uint32_t)__builtin_amdgcn_readlane( (int)(uint32_t)( (unsigned long long)v >> 32 ), lane );
+  return (long long)( ( (unsigned long long)hi << 32 ) | lo );
+}
+__device__ __forceinline__ unsigned long long rl( unsigned long long v, int lane ) { return (unsigned long long)rl( (long long)v, lane ); }
+__device__ __forceinline__ uint32_t first_lane( uint32_t v ) { return (uint32_t)__builtin_amdgcn_readfirstlane( (int)v ); }
+__device__ __forceinline__ unsigned long long first_lane( unsigned long long v )
+{
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane( (int)(uint32_t)v ), hi = (uint32_t)__builtin_amdgcn_readfirstlane( (int)(uint32_t)( v >> 32 ) );
+  return ( (unsigned long long)hi << 32 ) | lo;
+}
+
+template <class T, int PASS>
+__device__ __forceinline__ T replay_walk_row( const IcpLaunch& L, const ReplayBufs& B, int prob, int row, const FaithPar& P,
+                                               float ( *term )[REPLAY_PITCH], int lane, int* n_redone )
+{
+  typedef typename Bits<T>::U U; typedef typename ReplayFields<T>::I I;
+  constexpr int MB = Bits<T>::MBITS;
+  const U mmask = ( (U)1 << MB ) - 1;
+  const long long clampv = 1ll << ( MB + 2 );           // |delta| < 2^MB: bounds beyond that say nothing
+  const ReplaySeg* segs = B.seg + ( (size_t)prob * ICP_NMOM + row ) * B.n_seg;
+  U sb = 0;                                             // the running value's bits (uniform): +0
+  int redone = 0;
+  ReplaySeg nxt;                                        // the next batch's record of this lane, in flight while this batch is walked
+  if( lane < B.n_seg ) nxt = segs[lane];
+  for( int g0 = 0; g0 < B.n_seg; g0 += WAVE )
+  {
+    // this lane's segment of the batch, compact and typed
+    U f_start = 0; I f_dmin[REPLAY_CLS], f_dmax[REPLAY_CLS]; U f_end[REPLAY_CLS]; int f_meta[REPLAY_CLS];
+#pragma unroll
+    for( int c = 0; c < REPLAY_CLS; ++c ) { f_dmin[c] = 1; f_dmax[c] = 0; f_end[c] = 0; f_meta[c] = 64 << 8; }
+    if( g0 + lane < B.n_seg )
+    {
+      const ReplaySeg q = nxt;
+      f_start = (U)q.start;
+#pragma unroll
+      for( int c = 0; c < REPLAY_CLS; ++c )
+      {
+        const long long lo = q.cls[c].dmin, hi = q.cls[c].dmax;
+        f_dmin[c] = (I)( lo < -clampv ? -clampv : ( lo > clampv ? clampv : lo ) );
+        f_dmax[c] = (I)( hi < -clampv ? -clampv : ( hi > clampv ? clampv : hi ) );
+        f_end[c] = (U)q.cls[c].end;
+        f_meta[c] = q.cls[c].need_k | ( ( q.cls[c].k_end + 64 ) << 8 );
+      }
+    }
+    if( g0 + WAVE + lane < B.n_seg ) nxt = segs[g0 + WAVE + lane];
+    const int n_here = min( WAVE, B.n_seg - g0 );
+    for( int j = 0; j < n_here; ++j )
+    {
+      const U start = rl( f_start, j );
+      const int c = (int)( sb & ( REPLAY_CLS - 1 ) );
+      I dmin, dmax; U eb; int meta;
+      switch( c )                                        // (uniform)
+      {
+        case 0:  dmin = rl( f_dmin[0], j ); dmax = rl( f_dmax[0], j ); eb = rl( f_end[0], j ); meta = rl( f_meta[0], j ); break;
+        case 1:  dmin = rl( f_dmin[1], j ); dmax = rl( f_dmax[1], j ); eb = rl( f_end[1], j ); meta = rl( f_meta[1], j ); break;
+        case 2:  dmin = rl( f_dmin[2], j ); dmax = rl( f_dmax[2], j ); eb = rl( f_end[2], j ); meta = rl( f_meta[2], j ); break;
+        default: dmin = rl( f_dmin[3], j ); dmax = rl( f_dmax[3], j ); eb = rl( f_end[3], j ); meta = rl( f_meta[3], j ); break;
+      }
+      const I d = (I)( sb & mmask ) - (I)( ( start & mmask ) | (U)c );                       // a multiple of 4
+      const int need_k = meta & 255, k_end = ( meta >> 8 ) - 64;
+      const bool ok = ( ( sb ^ start ) & ~mmask ) == 0 && d >= dmin && d <= dmax && ( d & ( ( (I)2 << need_k ) - 1 ) ) == 0;
+      if( ok )
+      {
+        const I adv = k_end >= 0 ? ( d >> k_end ) : ( d << -k_end );
+        sb = ( eb & ~mmask ) | (U)( (I)( eb & mmask ) + adv );
+        continue;
+      }
+      // re-add the segment's addends one after the other (uniform over the wave: the value and the record are)
+      ++redone;
+      __syncthreads();                                  // (one wave per block: orders the reuse of `term`)
+      replay_terms<PASS>( L, prob, g0 + j, P, term );
+      __syncthreads();
+      T acc = Bits<T>::from( sb );
+      const float4* row4 = reinterpret_cast<const float4*>( term[row] );
+#pragma unroll 8
+      for( int t4 = 0; t4 < REPLAY_SEG / 4; ++t4 ) { const float4 v = row4[t4]; acc += (T)v.x; acc += (T)v.y; acc += (T)v.z; acc += (T)v.w; }
+      sb = first_lane( Bits<T>::of( acc ) );
+    }
+  }
+  if( n_redone ) *n_redone = redone;
+  return Bits<T>::from( sb );
+}
+
+template <int PASS>
+__global__ __launch_bounds__( WAVE ) void k_replay_walk( IcpLaunch L, ReplayBufs B )
+{
+  __shared__ __attribute__( ( aligned( 16 ) ) ) float term[ICP_NMOM][REPLAY_PITCH];
+  const int prob = blockIdx.y, row = blockIdx.x;
+  if( L.active[prob] == 0 ) return;
+  FaithPar P;
+  double* totals = B.totals + (size_t)prob * 3 * ICP_NMOM;
+  if( !replay_params( L, prob, PASS, totals, P ) ) return;
+  constexpr int NF = ReplayRows<PASS>::NF;
+  const int lane = threadIdx.x;
+  int redone = 0;
+  double v;
+  if( row < NF ) v = (double)replay_walk_row<float, PASS>( L, B, prob, row, P, term, lane, &redone );
+  else           v = replay_walk_row<double, PASS>( L, B, prob, row, P, term, lane, &redone );
+  if( lane == 0 )
+  {
+    totals[( PASS - 1 ) * ICP_NMOM + row] = v;        // (floats are exact in a double)
+    if( B.redone ) atomicAdd( B.redone + prob, redone );
+  }
+}
+
+// the rest of the iteration (icp.h:253-295, 455-493), as k_icp_faithful's last thread does it
+__global__ __launch_bounds__( WAVE ) void k_replay_finish( IcpLaunch L, ReplayBufs B )
+{
+  const int prob = blockIdx.x;
+  if( L.active[prob] == 0 || threadIdx.x != 0 ) return;
+  if( L.solve ) icp_iteration_reset( L, prob );
+  const double* totals = B.totals + (size_t)prob * 3 * ICP_NMOM;
+  FaithPar P;
+  const bool ok = replay_params( L, prob, 3, totals, P );
+  if( !ok )                                             // icp.h:455-459 / 466-470: no correspondences, or the weights vanished
+  {
+    if( L.solve ) { L.prev_err[prob] = L.err[prob]; L.iters[prob] += 1; L.active[prob] = 0; }
+    return;
+  }
+  const double* t3 = totals + 2 * ICP_NMOM;
+  float A[33];
+  for( int k = 0; k < 33; ++k ) A[k] = (float)t3[k];
+  Mat4 T;
+  for( int k = 0; k < 16; ++k ) { T.m[k] = L.T1[prob * 16 + k]; if( L.solve ) L.T1_prev[prob * 16 + k] = T.m[k]; }
+  float e;
+  icp_solve_ref_order( A, t3[33], t3[34], P.c1, T, e );
+  for( int k = 0; k < 16; ++k ) L.T1[prob * 16 + k] = T.m[k];
+  if( !L.solve ) { L.err[prob] = e; return; }
+  L.prev_err[prob] = L.err[prob];
+  L.iters[prob] += 1;
+  L.err[prob] = e;
+  const float delta = fabsf( L.prev_err[prob] - e );
+  if( !L.fixed_iters && L.iter_index > 5 && delta < 1e-5 ) L.active[prob] = 0;   // icp.h:489
+}
+
+template <int PASS>
+static void launch_replay_pass( const IcpLaunch& L, const ReplayBufs& B, hipStream_t st )
+{
+  constexpr int NR = ReplayRows<PASS>::NF + ReplayRows<PASS>::ND;
+  hipLaunchKernelGGL( k_replay_sums<PASS>, dim3( B.n_seg, L.n_prob ), dim3( REPLAY_SEG ), 0, st, L, B );
+  hipLaunchKernelGGL( k_replay_scan<PASS>, dim3( NR, L.n_prob ), dim3( WAVE ), 0, st, L, B );
+  hipLaunchKernelGGL( k_replay_run<PASS>, dim3( B.n_seg, L.n_prob ), dim3( REPLAY_RUN_THREADS ), 0, st, L, B );
+  hipLaunchKernelGGL( k_replay_walk<PASS>, dim3( NR, L.n_prob ), dim3( WAVE ), 0, st, L, B );
+}
+void launch_icp_replay( const IcpLaunch& L, const ReplayBufs& B, hipStream_t st )
+{
+  hipLaunchKernelGGL( k_icp_faith_gather, dim3( ( L.src.n + BLOCK - 1 ) / BLOCK, L.n_prob ), dim3( BLOCK ), 0, st, L );
+  if( !L.w_explicit ) launch_replay_pass<1>( L, B, st );
+  launch_replay_pass<2>( L, B, st );
+  launch_replay_pass<3>( L, B, st );
+  hipLaunchKernelGGL( k_replay_finish, dim3( L.n_prob ), dim3( WAVE ), 0, st, L, B );
+}
+int replay_segments( int n_source ) { return ( n_source + REPLAY_SEG - 1 ) / REPLAY_SEG; }
+size_t replay_seg_bytes() { return sizeof( ReplaySeg ); }
+
 void launch_icp_corr( const IcpLaunch& L, hipStream_t st )
 {
   // queue_count is zero on entry: cleared once by the host, then by the workgroup that ends every iteration (icp_iteration_reset)

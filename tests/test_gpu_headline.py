@@ -166,16 +166,20 @@ def test_scan_sized_icp_sweep_vs_reference(capi):
     the moments are exact where the reference's fp32 chains carry their own rounding, so a run may end
     farther than 1e-4 from the reference without either being wrong; the policy bound is on how many do."""
     g = load_golden("sweep_icp.npz")
-    prev = capi.icp_reference_order_below(-1)
-    over, worst, iter_diff, exact = [], 0.0, 0, 0
+    prev = capi.icp_reference_order_below(-1); prev_replay = capi.icp_replay_below(-1)
+    over, worst, iter_diff, exact, replay_exact, redone = [], 0.0, 0, 0, 0, []
     try:
         for k, seed in enumerate(g["seeds"]):
             s0, s1, T0, md, ma = _sweep_case(int(seed))
             assert sha(s1["points"]) + sha(s0["points"]) == str(g["in_sha"][k])
             assert np.array_equal(T0, g["T0"][k])
             a, b = capi.Cloud(s0["points"], s0["normals"]), capi.Cloud(s1["points"], s1["normals"])
-            capi.icp_reference_order_below(0)                       # fp64 moments
+            capi.icp_reference_order_below(0); capi.icp_replay_below(0)         # fp64 moments
             e64, T64, it64 = capi.icp_align(b, a, T0, I4, float(md), float(ma))
+            capi.icp_replay_below(1 << 30)                          # the reference's sums, computed in parallel
+            ep, Tp, itp = capi.icp_align(b, a, T0, I4, float(md), float(ma))
+            replay_exact += int((Tp == g["pose"][k]).all() and itp == int(g["iters"][k]) and np.float32(ep) == g["err"][k])
+            redone.append(capi.icp_replay_redone())
             capi.icp_reference_order_below(1 << 30)                 # reference order
             er, Tr, itr = capi.icp_align(b, a, T0, I4, float(md), float(ma))
             d64 = float(np.linalg.norm(T64.astype(np.float64) - g["pose"][k].astype(np.float64)))
@@ -189,7 +193,9 @@ def test_scan_sized_icp_sweep_vs_reference(capi):
             assert dr < POSE_TOL and itr == int(g["iters"][k]), f"seed {seed}: reference-order estimator {dr:.2e}, {itr} iterations"
             a.close(); b.close()
     finally:
-        capi.icp_reference_order_below(prev)
+        capi.icp_reference_order_below(prev); capi.icp_replay_below(prev_replay)
+    print(f"parallel reference order (replay): {replay_exact} of {len(g['seeds'])} bit-identical to the reference; segments re-added in the last iteration: {redone}")
+    assert replay_exact == exact
     print(f"fp64 moments: {len(over)} of {len(g['seeds'])} runs end >= 1e-4 from the reference (worst {worst:.2e}); {iter_diff} stop an iteration apart")
     print(f"reference order: {exact} of {len(g['seeds'])} bit-identical (pose, error, iterations)")
     assert exact >= len(g["seeds"]) - 1              # (an exact fp32 distance tie may cost one run a few 1e-5)

@@ -126,6 +126,26 @@ def test_icp_align_reference_order_is_bit_identical(capi, gscene, scene_clouds, 
     assert iters == int(g["iters"])
 
 
+@pytest.mark.parametrize("fname", golden_files("icp_"))
+def test_icp_parallel_reference_order_is_the_sequential_one(capi, gscene, scene_clouds, fname):
+    """The reference-order estimator computed in parallel (replay: speculative segments + exact walk) returns the bits of the
+    sequential chains (k_icp_faithful) — and so the reference's — on every ICP fixture."""
+    g = load_golden(fname)
+    clouds, objs = scene_clouds
+    o = objs[int(g["obj"])]
+    prev, prev_r = capi.icp_reference_order_below(-1), capi.icp_replay_below(-1)
+    md = float(g["max_dist"])
+    try:
+        capi.icp_reference_order_below(1 << 30)
+        e_s, T_s, it_s = capi.icp_align(o, clouds[round(md, 3)], g["T1"], g["T2"], md, g["max_angle"])
+        capi.icp_reference_order_below(0); capi.icp_replay_below(1 << 30)
+        e_p, T_p, it_p = capi.icp_align(o, clouds[round(md, 3)], g["T1"], g["T2"], md, g["max_angle"])
+    finally:
+        capi.icp_reference_order_below(prev); capi.icp_replay_below(prev_r)
+    assert (T_p == T_s).all() and e_p == e_s and it_p == it_s
+    assert T_p.tobytes() == np.asarray(g["T_out"], np.float32).ravel().tobytes() and it_p == int(g["iters"])
+
+
 def test_icp_reference_order_vs_oracle_seeded(capi, oracle):
     """The same on fresh seeded scenes, as a batch (every problem of a batch is its own sequential chain), for
     whole scans with the threshold lifted, and for the estimator entry point; and the fp64 reduction, which larger
