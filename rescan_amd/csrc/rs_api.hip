@@ -108,7 +108,7 @@ struct Workspace
   DevBuf tmp_pos, tmp_pos2, tmp_nor2;                                           // estimate-only
   DevBuf lvl_pos, lvl_nor, lvl_cnt, lvl_within, lvl_offset, lvl_adj, lvl_state, lvl_misc, lvl_flags, lvl_scan, lvl_samples, lvl_tmp, lvl_cursor, lvl_work_a, lvl_work_b;   // level builder
   DevBuf faith;                                                                 // reference-order estimator: correspondences in source order
-  DevBuf rp_segsum, rp_guess, rp_seg, rp_totals, rp_redone;                     // ... its parallel form (replay)
+  DevBuf rp_segsum, rp_guess, rp_seg, rp_super, rp_totals, rp_redone;                     // ... its parallel form (replay)
   PinBuf h_a, h_b, h_c;
 };
 thread_local Workspace g_ws;
@@ -650,12 +650,13 @@ int icp_prepare( IcpCtx& cx, const rs_hip_cloud_t* src, const rs_hip_cloud_t* tg
 // buffers of the parallel reference-order estimator for n_prob problems of n_source points
 int replay_prepare( ReplayBufs& B, int n_prob, int n_source )
 {
-  B.n_seg = replay_segments( n_source );
-  const size_t rows = (size_t)n_prob * ICP_NMOM * (size_t)B.n_seg;
+  B.n_seg = replay_segments( n_source ); B.n_super = replay_superblocks( n_source );
+  const size_t rows = (size_t)n_prob * ICP_NMOM * (size_t)B.n_seg, srows = (size_t)n_prob * ICP_NMOM * (size_t)B.n_super;
   int rc;
-  if( ( rc = g_ws.rp_segsum.ensure( rows * 8 ) ) || ( rc = g_ws.rp_guess.ensure( rows * 8 ) ) || ( rc = g_ws.rp_seg.ensure( rows * replay_seg_bytes() ) ) ||
+  if( ( rc = g_ws.rp_segsum.ensure( rows * 8 ) ) || ( rc = g_ws.rp_guess.ensure( 3 * rows * 8 ) ) || ( rc = g_ws.rp_seg.ensure( rows * replay_seg_bytes() ) ) ||
+      ( rc = g_ws.rp_super.ensure( srows * replay_seg_bytes() ) ) ||
       ( rc = g_ws.rp_totals.ensure( (size_t)n_prob * 3 * ICP_NMOM * 8 ) ) || ( rc = g_ws.rp_redone.ensure( (size_t)n_prob * 4 + 64 ) ) ) return rc;
-  B.segsum = g_ws.rp_segsum.as<double>(); B.guess = g_ws.rp_guess.as<double>(); B.seg = (ReplaySeg*)g_ws.rp_seg.p;
+  B.segsum = g_ws.rp_segsum.as<double>(); B.guess = g_ws.rp_guess.as<double>(); B.seg = (ReplaySeg*)g_ws.rp_seg.p; B.super = (ReplaySeg*)g_ws.rp_super.p;
   B.totals = g_ws.rp_totals.as<double>(); B.redone = g_ws.rp_redone.as<int>();
   HIP_TRY( hipMemsetAsync( g_ws.rp_redone.p, 0, (size_t)n_prob * 4 + 64, g_stream ), RS_HIP_E_RUNTIME );
   return RS_HIP_OK;

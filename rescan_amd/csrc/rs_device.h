@@ -119,14 +119,17 @@ struct ReplaySeg;
 struct ReplayBufs
 {
   int     n_seg;        // segments of 128 source points
+  int     n_super;      // superblocks of 64 segments
   double* segsum;       // n_prob x ICP_NMOM x n_seg
-  double* guess;        // n_prob x ICP_NMOM x n_seg
+  double* guess;        // n_prob x 3 passes x ICP_NMOM x n_seg
   ReplaySeg* seg;       // n_prob x ICP_NMOM x n_seg
+  ReplaySeg* super;     // n_prob x ICP_NMOM x n_super: 64 segments composed
   double* totals;       // n_prob x 3 passes x ICP_NMOM: the accumulators' final values
   int*    redone;       // n_prob: segments re-added sequentially (diagnostics; may be null)
 };
 void   launch_icp_replay( const IcpLaunch& L, const ReplayBufs& B, hipStream_t st );
 int    replay_segments( int n_source );
+int    replay_superblocks( int n_source );
 size_t replay_seg_bytes();
 
 struct ScoreLaunch

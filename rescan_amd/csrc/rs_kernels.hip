@@ -1811,7 +1811,7 @@ __global__ __launch_bounds__( WAVE ) void k_replay_scan( IcpLaunch L, ReplayBufs
   if( L.active[prob] == 0 ) return;
   const int lane = threadIdx.x;
   const double* in = B.segsum + ( (size_t)prob * ICP_NMOM + row ) * B.n_seg;
-  double* out = B.guess + ( (size_t)prob * ICP_NMOM + row ) * B.n_seg;
+  double* out = B.guess + ( ( (size_t)prob * 3 + ( PASS - 1 ) ) * ICP_NMOM + row ) * B.n_seg;
   double carry = 0.0;
   for( int g0 = 0; g0 < B.n_seg; g0 += WAVE )
   {
@@ -1874,7 +1874,7 @@ __device__ __forceinline__ void replay_run_chain( const float* row, double guess
     const int kk = valid ? k : 0;                              // (keeps the shifts below defined once the chain is lost)
     const long long M = (long long)( b & mmask );
     long long lo = 1 - M, hi = (long long)mmask - 1 - M;       // allowed shift of this value, in its own binade's grid steps
-    if( kk >= 0 ) { lo <<= kk; hi <<= kk; need_k = kk > need_k ? kk : need_k; }
+    if( kk >= 0 ) { lo *= ( 1ll << kk ); hi *= ( 1ll << kk ); need_k = kk > need_k ? kk : need_k; }
     else
     {
       const int sh = -kk; const long long rnd = ( 1ll << sh ) - 1;
@@ -1908,10 +1908,79 @@ __global__ __launch_bounds__( REPLAY_RUN_THREADS ) void k_replay_run( IcpLaunch 
   if( row < NR )
   {
     const size_t o = ( (size_t)prob * ICP_NMOM + row ) * B.n_seg + g;
-    if( row < NF ) replay_run_chain<float>( term[row], B.guess[o], c, B.seg[o] );
-    else           replay_run_chain<double>( term[row], B.guess[o], c, B.seg[o] );
+    const double guess = B.guess[( ( (size_t)prob * 3 + ( PASS - 1 ) ) * ICP_NMOM + row ) * B.n_seg + g];
+    if( row < NF ) replay_run_chain<float>( term[row], guess, c, B.seg[o] );
+    else           replay_run_chain<double>( term[row], guess, c, B.seg[o] );
   }
 }
+
+// 64 consecutive segments composed into ONE record of the same form, per class of the first segment's start: the walk can then
+// take 8 192 addends in a step.  With delta the (class-aligned) offset of the exact value at the superblock's start, the exact
+// value entering segment s is  base_s + delta * 2^-K_s  (base_s: where the guess chains lead when delta = 0; K_s: how much
+// coarser the grid has become); segment s's own tests on its delta_s = (base_s - its class start) + delta * 2^-K_s turn into an
+// interval and a divisibility condition on delta, and its result into the next base.  Anything that does not fit (a base in
+// another binade than the segment's guess, a constant part that fails the segment's divisibility) makes the class unusable, and
+// the walk then steps through the superblock's segments one by one.
+#define REPLAY_SUPER 64
+template <class T>
+__device__ __forceinline__ void replay_compose_chain( const ReplaySeg* segs, int n, int c0, ReplaySeg& out )
+{
+  typedef typename Bits<T>::U U;
+  constexpr int MB = Bits<T>::MBITS;
+  constexpr int KMAX = MB == 23 ? 20 : 8;
+  const U mmask = ( (U)1 << MB ) - 1;
+  const long long big = 1ll << ( MB + 3 );                        // |delta| < 2^MB
+  U base = (U)segs[0].start | (U)c0;
+  if( c0 == 0 ) { out.start = segs[0].start; out.pad = 0ull; }
+  long long dmin = -big, dmax = big;
+  int modlog = 2, K = 0;                                           // delta is a multiple of 4 (class); grid shift so far
+  bool valid = true;
+  for( int s = 0; s < n && valid; ++s )
+  {
+    const U st = (U)segs[s].start;
+    if( ( ( base ^ st ) & ~mmask ) != 0 ) { valid = false; break; }
+    const int c = (int)( base & ( REPLAY_CLS - 1 ) );
+    const ReplayCls r = segs[s].cls[c];
+    if( r.dmax < r.dmin ) { valid = false; break; }
+    const long long cst = (long long)( base & mmask ) - (long long)( ( st & mmask ) | (U)c );        // a multiple of 4
+    if( ( cst & ( ( 2ll << r.need_k ) - 1 ) ) != 0 ) { valid = false; break; }
+    // r.dmin <= cst + delta * 2^-K <= r.dmax
+    long long lo = r.dmin - cst, hi = r.dmax - cst;
+    lo = lo < -big ? -big : lo; hi = hi > big ? big : hi;
+    if( K >= 0 ) { lo *= ( 1ll << K ); hi *= ( 1ll << K ); }
+    else { const int sh = -K; const long long rnd = ( 1ll << sh ) - 1; lo = lo >= 0 ? ( ( lo + rnd ) >> sh ) : -( ( -lo ) >> sh ); hi = hi >= 0 ? ( hi >> sh ) : -( ( -hi + rnd ) >> sh ); }
+    dmin = lo > dmin ? lo : dmin; dmax = hi < dmax ? hi : dmax;
+    // delta * 2^-K must keep the class (multiple of 4) and the segment's divisibility
+    const int need = K + ( r.need_k + 1 > 2 ? r.need_k + 1 : 2 );
+    modlog = need > modlog ? need : modlog;
+    // next base, next grid
+    const U eb = (U)r.end;
+    const long long adv = r.k_end >= 0 ? ( cst >> r.k_end ) : cst * ( 1ll << -r.k_end );
+    base = ( eb & ~mmask ) | (U)( (long long)( eb & mmask ) + adv );
+    K += r.k_end;
+    if( K > KMAX || K < -KMAX || modlog > MB ) valid = false;
+  }
+  ReplayCls q;
+  q.dmin = valid ? dmin : 1; q.dmax = valid ? dmax : 0;
+  q.end = (unsigned long long)base; q.need_k = modlog - 1; q.k_end = valid ? K : 0;
+  out.cls[c0] = q;
+}
+
+template <int PASS>
+__global__ __launch_bounds__( REPLAY_RUN_THREADS ) void k_replay_compose( IcpLaunch L, ReplayBufs B )
+{
+  const int prob = blockIdx.y, sb = blockIdx.x;
+  if( L.active[prob] == 0 ) return;
+  constexpr int NF = ReplayRows<PASS>::NF, NR = NF + ReplayRows<PASS>::ND;
+  const int row = threadIdx.x / REPLAY_CLS, c = threadIdx.x % REPLAY_CLS;
+  if( row >= NR ) return;
+  const int g0 = sb * REPLAY_SUPER, n = min( REPLAY_SUPER, B.n_seg - g0 );
+  const ReplaySeg* segs = B.seg + ( (size_t)prob * ICP_NMOM + row ) * B.n_seg + g0;
+  ReplaySeg& out = B.super[( (size_t)prob * ICP_NMOM + row ) * B.n_super + sb];
+  if( row < NF ) replay_compose_chain<float>( segs, n, c, out );
+  else           replay_compose_chain<double>( segs, n, c, out );
+}
+
 
 // The walk of one accumulator over its segments, with the exact value.  Lane l of the wave holds the record of segment g0 + l
 // in registers; step j fetches lane j's fields with v_readlane (j is uniform), so the running value, the record and all the
@@ -1936,72 +2005,87 @@ __device__ __forceinline__ unsigned long long first_lane( unsigned long long v )
   return ( (unsigned long long)hi << 32 ) | lo;
 }
 
+// one lane's record, compact and typed, for the scalar walk
+template <class T> struct ReplayLaneRec
+{
+  typedef typename Bits<T>::U U; typedef typename ReplayFields<T>::I I;
+  U start; I dmin[REPLAY_CLS], dmax[REPLAY_CLS]; U end[REPLAY_CLS]; int meta[REPLAY_CLS];
+  __device__ __forceinline__ void clear() { start = 0; for( int c = 0; c < REPLAY_CLS; ++c ) { dmin[c] = 1; dmax[c] = 0; end[c] = 0; meta[c] = 64 << 8; } }
+  __device__ __forceinline__ void load( const ReplaySeg& q )
+  {
+    const long long clampv = 1ll << ( Bits<T>::MBITS + 2 );       // |delta| < 2^MBITS: bounds beyond that say nothing
+    start = (U)q.start;
+#pragma unroll
+    for( int c = 0; c < REPLAY_CLS; ++c )
+    {
+      const long long lo = q.cls[c].dmin, hi = q.cls[c].dmax;
+      dmin[c] = (I)( lo < -clampv ? -clampv : ( lo > clampv ? clampv : lo ) );
+      dmax[c] = (I)( hi < -clampv ? -clampv : ( hi > clampv ? clampv : hi ) );
+      end[c] = (U)q.cls[c].end;
+      meta[c] = q.cls[c].need_k | ( ( q.cls[c].k_end + 64 ) << 8 );
+    }
+  }
+  // lane j's record applied to the (uniform) value sb: true and sb advanced, or false
+  __device__ __forceinline__ bool apply( int j, U& sb ) const
+  {
+    const U mmask = ( (U)1 << Bits<T>::MBITS ) - 1;
+    const U st = rl( start, j );
+    const int c = (int)( sb & ( REPLAY_CLS - 1 ) );
+    I lo, hi; U eb; int m;
+    switch( c )                                          // (uniform)
+    {
+      case 0:  lo = rl( dmin[0], j ); hi = rl( dmax[0], j ); eb = rl( end[0], j ); m = rl( meta[0], j ); break;
+      case 1:  lo = rl( dmin[1], j ); hi = rl( dmax[1], j ); eb = rl( end[1], j ); m = rl( meta[1], j ); break;
+      case 2:  lo = rl( dmin[2], j ); hi = rl( dmax[2], j ); eb = rl( end[2], j ); m = rl( meta[2], j ); break;
+      default: lo = rl( dmin[3], j ); hi = rl( dmax[3], j ); eb = rl( end[3], j ); m = rl( meta[3], j ); break;
+    }
+    const I d = (I)( sb & mmask ) - (I)( ( st & mmask ) | (U)c );                           // a multiple of 4
+    const int need_k = m & 255, k_end = ( m >> 8 ) - 64;
+    const bool ok = ( ( sb ^ st ) & ~mmask ) == 0 && d >= lo && d <= hi && ( d & ( ( (I)2 << need_k ) - 1 ) ) == 0;
+    if( ok )
+    {
+      const I adv = k_end >= 0 ? ( d >> k_end ) : d * ( (I)1 << -k_end );
+      sb = ( eb & ~mmask ) | (U)( (I)( eb & mmask ) + adv );
+    }
+    return ok;
+  }
+};
+
 template <class T, int PASS>
 __device__ __forceinline__ T replay_walk_row( const IcpLaunch& L, const ReplayBufs& B, int prob, int row, const FaithPar& P,
                                                float ( *term )[REPLAY_PITCH], int lane, int* n_redone )
 {
-  typedef typename Bits<T>::U U; typedef typename ReplayFields<T>::I I;
-  constexpr int MB = Bits<T>::MBITS;
-  const U mmask = ( (U)1 << MB ) - 1;
-  const long long clampv = 1ll << ( MB + 2 );           // |delta| < 2^MB: bounds beyond that say nothing
+  typedef typename Bits<T>::U U;
   const ReplaySeg* segs = B.seg + ( (size_t)prob * ICP_NMOM + row ) * B.n_seg;
+  const ReplaySeg* sups = B.super + ( (size_t)prob * ICP_NMOM + row ) * B.n_super;
   U sb = 0;                                             // the running value's bits (uniform): +0
   int redone = 0;
-  ReplaySeg nxt;                                        // the next batch's record of this lane, in flight while this batch is walked
-  if( lane < B.n_seg ) nxt = segs[lane];
-  for( int g0 = 0; g0 < B.n_seg; g0 += WAVE )
+  for( int s0 = 0; s0 < B.n_super; s0 += WAVE )
   {
-    // this lane's segment of the batch, compact and typed
-    U f_start = 0; I f_dmin[REPLAY_CLS], f_dmax[REPLAY_CLS]; U f_end[REPLAY_CLS]; int f_meta[REPLAY_CLS];
-#pragma unroll
-    for( int c = 0; c < REPLAY_CLS; ++c ) { f_dmin[c] = 1; f_dmax[c] = 0; f_end[c] = 0; f_meta[c] = 64 << 8; }
-    if( g0 + lane < B.n_seg )
+    ReplayLaneRec<T> sup; sup.clear();                  // lane l: superblock s0 + l
+    if( s0 + lane < B.n_super ) sup.load( sups[s0 + lane] );
+    const int n_sup = min( WAVE, B.n_super - s0 );
+    for( int js = 0; js < n_sup; ++js )
     {
-      const ReplaySeg q = nxt;
-      f_start = (U)q.start;
-#pragma unroll
-      for( int c = 0; c < REPLAY_CLS; ++c )
+      if( sup.apply( js, sb ) ) continue;               // 64 segments in one step
+      // step through the superblock's segments
+      const int g0 = ( s0 + js ) * REPLAY_SUPER, n_here = min( REPLAY_SUPER, B.n_seg - g0 );
+      ReplayLaneRec<T> seg; seg.clear();
+      if( lane < n_here ) seg.load( segs[g0 + lane] );
+      for( int j = 0; j < n_here; ++j )
       {
-        const long long lo = q.cls[c].dmin, hi = q.cls[c].dmax;
-        f_dmin[c] = (I)( lo < -clampv ? -clampv : ( lo > clampv ? clampv : lo ) );
-        f_dmax[c] = (I)( hi < -clampv ? -clampv : ( hi > clampv ? clampv : hi ) );
-        f_end[c] = (U)q.cls[c].end;
-        f_meta[c] = q.cls[c].need_k | ( ( q.cls[c].k_end + 64 ) << 8 );
-      }
-    }
-    if( g0 + WAVE + lane < B.n_seg ) nxt = segs[g0 + WAVE + lane];
-    const int n_here = min( WAVE, B.n_seg - g0 );
-    for( int j = 0; j < n_here; ++j )
-    {
-      const U start = rl( f_start, j );
-      const int c = (int)( sb & ( REPLAY_CLS - 1 ) );
-      I dmin, dmax; U eb; int meta;
-      switch( c )                                        // (uniform)
-      {
-        case 0:  dmin = rl( f_dmin[0], j ); dmax = rl( f_dmax[0], j ); eb = rl( f_end[0], j ); meta = rl( f_meta[0], j ); break;
-        case 1:  dmin = rl( f_dmin[1], j ); dmax = rl( f_dmax[1], j ); eb = rl( f_end[1], j ); meta = rl( f_meta[1], j ); break;
-        case 2:  dmin = rl( f_dmin[2], j ); dmax = rl( f_dmax[2], j ); eb = rl( f_end[2], j ); meta = rl( f_meta[2], j ); break;
-        default: dmin = rl( f_dmin[3], j ); dmax = rl( f_dmax[3], j ); eb = rl( f_end[3], j ); meta = rl( f_meta[3], j ); break;
-      }
-      const I d = (I)( sb & mmask ) - (I)( ( start & mmask ) | (U)c );                       // a multiple of 4
-      const int need_k = meta & 255, k_end = ( meta >> 8 ) - 64;
-      const bool ok = ( ( sb ^ start ) & ~mmask ) == 0 && d >= dmin && d <= dmax && ( d & ( ( (I)2 << need_k ) - 1 ) ) == 0;
-      if( ok )
-      {
-        const I adv = k_end >= 0 ? ( d >> k_end ) : ( d << -k_end );
-        sb = ( eb & ~mmask ) | (U)( (I)( eb & mmask ) + adv );
-        continue;
-      }
-      // re-add the segment's addends one after the other (uniform over the wave: the value and the record are)
-      ++redone;
-      __syncthreads();                                  // (one wave per block: orders the reuse of `term`)
-      replay_terms<PASS>( L, prob, g0 + j, P, term );
-      __syncthreads();
-      T acc = Bits<T>::from( sb );
-      const float4* row4 = reinterpret_cast<const float4*>( term[row] );
+        if( seg.apply( j, sb ) ) continue;
+        // re-add the segment's addends one after the other (uniform over the wave: the value and the record are)
+        ++redone;
+        __syncthreads();                                // (one wave per block: orders the reuse of `term`)
+        replay_terms<PASS>( L, prob, g0 + j, P, term );
+        __syncthreads();
+        T acc = Bits<T>::from( sb );
+        const float4* row4 = reinterpret_cast<const float4*>( term[row] );
 #pragma unroll 8
-      for( int t4 = 0; t4 < REPLAY_SEG / 4; ++t4 ) { const float4 v = row4[t4]; acc += (T)v.x; acc += (T)v.y; acc += (T)v.z; acc += (T)v.w; }
-      sb = first_lane( Bits<T>::of( acc ) );
+        for( int t4 = 0; t4 < REPLAY_SEG / 4; ++t4 ) { const float4 v = row4[t4]; acc += (T)v.x; acc += (T)v.y; acc += (T)v.z; acc += (T)v.w; }
+        sb = first_lane( Bits<T>::of( acc ) );
+      }
     }
   }
   if( n_redone ) *n_redone = redone;
@@ -2067,6 +2151,7 @@ static void launch_replay_pass( const IcpLaunch& L, const ReplayBufs& B, hipStre
   hipLaunchKernelGGL( k_replay_sums<PASS>, dim3( B.n_seg, L.n_prob ), dim3( REPLAY_SEG ), 0, st, L, B );
   hipLaunchKernelGGL( k_replay_scan<PASS>, dim3( NR, L.n_prob ), dim3( WAVE ), 0, st, L, B );
   hipLaunchKernelGGL( k_replay_run<PASS>, dim3( B.n_seg, L.n_prob ), dim3( REPLAY_RUN_THREADS ), 0, st, L, B );
+  hipLaunchKernelGGL( k_replay_compose<PASS>, dim3( B.n_super, L.n_prob ), dim3( REPLAY_RUN_THREADS ), 0, st, L, B );
   hipLaunchKernelGGL( k_replay_walk<PASS>, dim3( NR, L.n_prob ), dim3( WAVE ), 0, st, L, B );
 }
 void launch_icp_replay( const IcpLaunch& L, const ReplayBufs& B, hipStream_t st )
@@ -2078,6 +2163,7 @@ void launch_icp_replay( const IcpLaunch& L, const ReplayBufs& B, hipStream_t st 
   hipLaunchKernelGGL( k_replay_finish, dim3( L.n_prob ), dim3( WAVE ), 0, st, L, B );
 }
 int replay_segments( int n_source ) { return ( n_source + REPLAY_SEG - 1 ) / REPLAY_SEG; }
+int replay_superblocks( int n_source ) { return ( replay_segments( n_source ) + REPLAY_SUPER - 1 ) / REPLAY_SUPER; }
 size_t replay_seg_bytes() { return sizeof( ReplaySeg ); }
 
 void launch_icp_corr( const IcpLaunch& L, hipStream_t st )
