@@ -100,7 +100,7 @@ int rs_hip_icp_align( const rs_hip_cloud_t* source, const rs_hip_cloud_t* target
  * 0 = always the fp64 reduction; n_points < 0 only reads.  Returns the previous threshold.  Applies to
  * rs_hip_icp_align, rs_hip_icp_align_batch and rs_hip_icp_estimate_pt2pl. */
 int32_t rs_hip_icp_reference_order_below( int32_t n_points );
-/* Sources larger than that, up to `n_points` points (default 0 = off; environment RS_HIP_REPLAY_BELOW), get the SAME sums —
+/* Sources larger than that, up to `n_points` points (default 262144; environment RS_HIP_REPLAY_BELOW), get the SAME sums —
  * the reference's sequential fp32 / fp64 chains, bit for bit — computed in parallel: segments of 128 points are added
  * speculatively from a guessed start, for both parities of its last mantissa bit, and a walk over the segments with the exact
  * value accepts a segment when the accumulator provably stayed inside its binade.  0 = never; n_points < 0 only

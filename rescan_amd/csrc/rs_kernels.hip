@@ -1966,21 +1966,32 @@ __device__ __forceinline__ void replay_compose_chain( const ReplaySeg* segs, int
   out.cls[c0] = q;
 }
 
+// four accumulator rows per workgroup: their superblock's 64 records are staged in LDS (coalesced), then one thread per
+// (row, class) composes from there (a thread chasing 64 dependent records in global memory took 50-100 us)
+#define REPLAY_COMPOSE_ROWS 4
 template <int PASS>
-__global__ __launch_bounds__( REPLAY_RUN_THREADS ) void k_replay_compose( IcpLaunch L, ReplayBufs B )
+__global__ __launch_bounds__( WAVE ) void k_replay_compose( IcpLaunch L, ReplayBufs B )
 {
-  const int prob = blockIdx.y, sb = blockIdx.x;
+  __shared__ __attribute__( ( aligned( 16 ) ) ) ReplaySeg stage[REPLAY_COMPOSE_ROWS][REPLAY_SUPER];
+  static_assert( sizeof( ReplaySeg ) % 16 == 0, "staged with 16-byte copies" );
+  const int prob = blockIdx.z, sb = blockIdx.x, row0 = blockIdx.y * REPLAY_COMPOSE_ROWS;
   if( L.active[prob] == 0 ) return;
   constexpr int NF = ReplayRows<PASS>::NF, NR = NF + ReplayRows<PASS>::ND;
-  const int row = threadIdx.x / REPLAY_CLS, c = threadIdx.x % REPLAY_CLS;
-  if( row >= NR ) return;
   const int g0 = sb * REPLAY_SUPER, n = min( REPLAY_SUPER, B.n_seg - g0 );
-  const ReplaySeg* segs = B.seg + ( (size_t)prob * ICP_NMOM + row ) * B.n_seg + g0;
+  constexpr int Q = sizeof( ReplaySeg ) / 16;
+  for( int r = 0; r < REPLAY_COMPOSE_ROWS && row0 + r < NR; ++r )
+  {
+    const uint4* src = reinterpret_cast<const uint4*>( B.seg + ( (size_t)prob * ICP_NMOM + row0 + r ) * B.n_seg + g0 );
+    uint4* dst = reinterpret_cast<uint4*>( stage[r] );
+    for( int k = threadIdx.x; k < n * Q; k += WAVE ) dst[k] = src[k];
+  }
+  __syncthreads();
+  const int r = threadIdx.x / REPLAY_CLS, c = threadIdx.x % REPLAY_CLS, row = row0 + r;
+  if( r >= REPLAY_COMPOSE_ROWS || row >= NR ) return;
   ReplaySeg& out = B.super[( (size_t)prob * ICP_NMOM + row ) * B.n_super + sb];
-  if( row < NF ) replay_compose_chain<float>( segs, n, c, out );
-  else           replay_compose_chain<double>( segs, n, c, out );
+  if( row < NF ) replay_compose_chain<float>( stage[r], n, c, out );
+  else           replay_compose_chain<double>( stage[r], n, c, out );
 }
-
 
 // The walk of one accumulator over its segments, with the exact value.  Lane l of the wave holds the record of segment g0 + l
 // in registers; step j fetches lane j's fields with v_readlane (j is uniform), so the running value, the record and all the
@@ -2151,7 +2162,7 @@ static void launch_replay_pass( const IcpLaunch& L, const ReplayBufs& B, hipStre
   hipLaunchKernelGGL( k_replay_sums<PASS>, dim3( B.n_seg, L.n_prob ), dim3( REPLAY_SEG ), 0, st, L, B );
   hipLaunchKernelGGL( k_replay_scan<PASS>, dim3( NR, L.n_prob ), dim3( WAVE ), 0, st, L, B );
   hipLaunchKernelGGL( k_replay_run<PASS>, dim3( B.n_seg, L.n_prob ), dim3( REPLAY_RUN_THREADS ), 0, st, L, B );
-  hipLaunchKernelGGL( k_replay_compose<PASS>, dim3( B.n_super, L.n_prob ), dim3( REPLAY_RUN_THREADS ), 0, st, L, B );
+  hipLaunchKernelGGL( k_replay_compose<PASS>, dim3( B.n_super, ( NR + REPLAY_COMPOSE_ROWS - 1 ) / REPLAY_COMPOSE_ROWS, L.n_prob ), dim3( WAVE ), 0, st, L, B );
   hipLaunchKernelGGL( k_replay_walk<PASS>, dim3( NR, L.n_prob ), dim3( WAVE ), 0, st, L, B );
 }
 void launch_icp_replay( const IcpLaunch& L, const ReplayBufs& B, hipStream_t st )

@@ -111,3 +111,26 @@ def test_world2_gloo():
         assert ok_labels, f"rank {rank}: folded labels differ from the sequential loop"
         assert ok_icp, f"rank {rank}: gathered ICP results differ"
         assert ok_sc, f"rank {rank}: gathered scores differ"
+
+
+def test_shard_layout_and_arrangement_plan():
+    """Pure bookkeeping of the HIP-driven sharded route (rescan_amd/dist.py): every unit is owned by exactly one rank, the send
+    buffers have one fixed size, and the arrangement plan is rspf_arrangement_to_labels' order (stable sort by
+    (is_static << 10 | class), first static entry or 0, 1.5 x radius from there on)."""
+    from rescan_amd.dist import ShardLayout, arrangement_plan, shard_range
+    for world in (1, 2, 3, 8):
+        lay = ShardLayout(world, n_icp=5, n_score=257, n_plc=11, n_scene=1000)
+        seen = [[0] * 5, [0] * 257, [0] * 11]
+        for r in range(world):
+            for k, (lo, hi) in enumerate(lay.slices(r)):
+                for u in range(lo, hi):
+                    seen[k][u] += 1
+                cap = (lay.icp_cap, lay.score_cap, lay.plc_cap)[k]
+                assert hi - lo <= cap
+        assert all(all(v == 1 for v in s) for s in seen)
+        assert lay.words == lay.off_rows + lay.plc_cap * 1000 and lay.off_rows % 64 == 0 and lay.off_score == 18 * lay.icp_cap
+    order, first_static, radii = arrangement_plan([0, 1, 0, 1, 0], [7, 1, 5, 2, 5], 0.05)
+    assert order == [2, 4, 0, 1, 3] and first_static == 3
+    assert [float(r) for r in radii] == [float(np.float32(0.05))] * 3 + [float(np.float32(1.5) * np.float32(0.05))] * 2
+    order, first_static, radii = arrangement_plan([0, 0], [3, 2], 0.05)           # no static placement: everything at 1.5 x radius
+    assert order == [1, 0] and first_static == 0 and all(float(r) == float(np.float32(1.5) * np.float32(0.05)) for r in radii)

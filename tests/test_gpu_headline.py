@@ -110,7 +110,7 @@ def test_headline_sharded_route_is_bit_identical(capi, bench_mod, headline):
     err0, T0, it0 = capi.icp_align(w["scan1"], w["scan0"], w["icp_T0"], I4, 0.10, np.deg2rad(60.0), max_iter=bench_mod.ICP_ITERS, fixed_iters=True)
     sc0 = capi.alignment_scores(w["obj_score"], w["scan1"], w["score_poses"], 0.1, 64)
     lab0 = capi.arrangement_to_labels(w["scan1"], w["plc_poses"], [p["cloud"] for p in w["plc"]], [0] * n_plc, [p["cls"] for p in w["plc"]], 0.05, False)
-    for world in (1, 2):
+    for world in (1, 2, 3):                                          # (3: ragged slices — 2 ICP problems, 256 poses, 8 placements over 3 ranks)
         lay = rd.ShardLayout(world, len(T0s), len(w["score_poses"]), n_plc, w["n_scan1"])
         recv = torch.zeros(world * lay.words, dtype=torch.float32, device=dev)
         for rank in range(world):

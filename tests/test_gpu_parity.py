@@ -83,6 +83,20 @@ def test_rows_edge_cases(capi, oracle):
     assert tot == 0
 
 
+def test_rows_more_than_the_wave_kernels_list_can_hold(capi, oracle, gscene):
+    """k_rows_wave keeps a query's hits in a 1 024-entry LDS list; a query with more points within the radius sends the whole
+    call to the storage-free kernel.  Same rows either way (radius 0.4 m: thousands of points within reach)."""
+    pts = gscene["points"]
+    tgt = capi.Cloud(pts, None, cell_size=0.1)
+    q = np.ascontiguousarray(pts[::997][:12])
+    d, i, nn, tot = capi.radius_search(tgt, q, 0.4, 32)
+    g = oracle.grid_create(pts, 0.2)
+    dw, iw, nw, totw = oracle.radius_search(g, q, 0.4, 32, 1)
+    oracle.grid_destroy(g)
+    assert (nn == 32).all()
+    rows_equal_up_to_ties(dw, iw, nw, d, i, nn.astype(np.int64))
+
+
 # ---- ICP ---------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("fname", golden_files("corrs_"))
@@ -190,16 +204,23 @@ def test_icp_reference_order_vs_oracle_seeded(capi, oracle):
         capi.icp_reference_order_below(prev)
 
 
-def test_icp_batch_matches_single(capi, gscene, scene_clouds):
+@pytest.mark.parametrize("estimator", ["sequential chains", "parallel chains", "fp64 moments"])
+def test_icp_batch_matches_single(capi, gscene, scene_clouds, estimator):
     clouds, objs = scene_clouds
     rng = np.random.default_rng(3)
     from rescan_amd import synth
     o = gscene["objects"][1]
     T0s = np.stack([synth.perturbed_pose(o["pose"], rng) for _ in range(5)])
-    errs, Ts, its = capi.icp_align_batch(objs[1], clouds[0.1], T0s, I4, 0.1, np.deg2rad(60.0))
-    for k in range(5):
-        e, T, it = capi.icp_align(objs[1], clouds[0.1], T0s[k], I4, 0.1, np.deg2rad(60.0))
-        assert (T == Ts[k]).all() and e == errs[k] and it == its[k]
+    prev, prev_r = capi.icp_reference_order_below(-1), capi.icp_replay_below(-1)
+    try:
+        capi.icp_reference_order_below(1 << 30 if estimator == "sequential chains" else 0)
+        capi.icp_replay_below(1 << 30 if estimator == "parallel chains" else 0)
+        errs, Ts, its = capi.icp_align_batch(objs[1], clouds[0.1], T0s, I4, 0.1, np.deg2rad(60.0))
+        for k in range(5):
+            e, T, it = capi.icp_align(objs[1], clouds[0.1], T0s[k], I4, 0.1, np.deg2rad(60.0))
+            assert (T == Ts[k]).all() and e == errs[k] and it == its[k]
+    finally:
+        capi.icp_reference_order_below(prev); capi.icp_replay_below(prev_r)
 
 
 def test_icp_no_correspondences(capi, scene_clouds):
