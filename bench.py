@@ -36,8 +36,12 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# (RS_HIP_PROF_EVERY=n in the environment: only every n-th ICP call carries the live profile's events — they sit between the
-#  dependent launches of the chain and cost ~2 % of a step; the default times every launch of the timed region.)
+# The live profile of the ICP chain is SAMPLED: every 4th icp_align call of the timed region carries the HIP events its kernels
+# are timed with (RS_HIP_PROF_EVERY=1 in the environment times every call).  An event recorded between two dependent launches is
+# a packet of its own: two per ICP iteration cost 2.3 % of a step (3.05 against 2.98 ms, same box, interleaved repeats:
+# profiles/r02/ab_profiling_events.txt; events carried inside the kernels' dispatch packets — hipExtLaunchKernelGGL — cost more:
+# 3.11).  The score and label kernels are timed on every call.
+os.environ.setdefault("RS_HIP_PROF_EVERY", "4")
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
 ICP_ITERS = 10
