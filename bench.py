@@ -162,6 +162,18 @@ def exchange_wait():
 _XCH = {}
 
 
+def all_gather_flat(dist, recv, send):
+    """recv = the concatenation of every rank's send (device tensors).  RCCL: one all_gather_into_tensor.  Under the one-GPU
+    rehearsal (gloo) the buffers pass through the host."""
+    if dist.get_backend() == "gloo":
+        import torch
+        parts = [torch.empty(send.numel(), dtype=send.dtype) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, send.cpu())
+        recv.copy_(torch.cat(parts))
+    else:
+        dist.all_gather_into_tensor(recv, send)
+
+
 def exchange_results(dist, dev, T, err, scores, res):
     """--replicas: every rank receives every rank's pose + error + scores and label partials (labels int8 + min_dists
     f32) in ONE all-gather per step.  Scene sizes differ slightly across ranks: the label arrays are padded to the common
@@ -176,7 +188,7 @@ def exchange_results(dist, dev, T, err, scores, res):
     small = np.concatenate([np.asarray(T, np.float32).ravel(), [np.float32(err)], np.asarray(scores, np.float32)]).astype(np.float32)
     st = _XCH.get("st")
     if st is None or st["n"] != len(lab) or st["n_small"] != len(small) or st["world"] != world:
-        n = torch.tensor([len(lab)], device=dev, dtype=torch.int64)
+        n = torch.tensor([len(lab)], device=dev if dist.get_backend() != "gloo" else "cpu", dtype=torch.int64)
         dist.all_reduce(n, op=dist.ReduceOp.MAX)
         nmax = int(n.item())
         o_small, o_mind = 8, 8 + 4 * len(small)
@@ -196,7 +208,7 @@ def exchange_results(dist, dev, T, err, scores, res):
     hm = h[o_mind:o_lab].view(np.float32); hm[: len(mind)] = mind; hm[len(mind):] = 1e9
     hl = h[o_lab:o_lab + nmax].view(np.int8); hl[: len(lab)] = lab; hl[len(lab):] = 0
     st["send"].copy_(st["host"])
-    dist.all_gather_into_tensor(st["recv"], st["send"])
+    all_gather_flat(dist, st["recv"], st["send"])
     out, gl, gm = [], [], []
     for r in range(world):
         b = st["recv"][r * nbytes:(r + 1) * nbytes]
@@ -245,7 +257,7 @@ class Sharded:
         t0 = time.perf_counter()
         rd.shard_publish(self.lay, send, small)
         if self.dist is not None:
-            self.dist.all_gather_into_tensor(recv, send)
+            all_gather_flat(self.dist, recv, send)
         torch.cuda.current_stream().synchronize()
         t1 = time.perf_counter()
         out = rd.shard_fold(capi, self.lay, recv, outbuf, scene=self.w["scan1"])
@@ -387,6 +399,10 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    # (RS_BENCH_ONE_DEVICE=1: rehearsal of the multi-rank plumbing on a ONE-GPU box — every rank on device 0, exchange over gloo)
+    one_device = bool(os.environ.get("RS_BENCH_ONE_DEVICE"))
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -396,7 +412,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if one_device:
+            dist.init_process_group("gloo")            # RCCL refuses two ranks on one device
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from rescan_amd import capi
     capi.init(local_rank)
@@ -456,7 +475,7 @@ def main():
     pairs_unit = sum(w["pairs"].values())
     pairs_total = float(pairs_unit * args.steps * (world if not sharded else units))
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if dist.get_backend() != "gloo" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
