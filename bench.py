@@ -115,6 +115,43 @@ def _pool():
     return _POOL
 
 
+_ROLE_POOLS = None
+
+
+def _role_pools():
+    """One single-thread executor per consumer (ICP chain, score batch, label pass): a consumer always runs on the same host
+    thread, i.e. on the same HIP stream — and the streams are given disjoint sets of XCDs: the ICP chain (a sequence of short
+    latency-bound kernels) keeps 5 of the chip's 8 XCDs to itself, the two batch consumers (throughput-bound, finished long
+    before the chain) share the other 3.  On the whole chip the batch kernels' waves sit among the chain's and stretch it:
+    3.07 ms per step shared, 2.92-2.96 partitioned 5 + 3 (same box, interleaved repeats: profiles/r02/ab_cu_split*.txt; 4 + 4
+    and 4.5 + 3.5 are slower, 6 + 2 makes the score batch the longer of the two; partitions that cut through an XCD are bad).
+    RS_BENCH_CU_SPLIT=<fraction of the CUs for the chain> overrides (0 = no partition)."""
+    global _ROLE_POOLS
+    if _ROLE_POOLS is None:
+        from concurrent.futures import ThreadPoolExecutor
+        from rescan_amd import capi
+        import torch
+        _ROLE_POOLS = [ThreadPoolExecutor(max_workers=1) for _ in range(3)]
+        n_cu = int(torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count)
+        split = float(os.environ.get("RS_BENCH_CU_SPLIT", "0.625" if n_cu == 256 else "0"))
+        if split > 0.0:
+            k = int(round(split * n_cu))
+            masks = [[1] * k + [0] * (n_cu - k), [0] * k + [1] * (n_cu - k), [0] * k + [1] * (n_cu - k)]
+            try:
+                for ex, m in zip(_ROLE_POOLS, masks):
+                    ex.submit(capi.stream_cu_mask, m).result()
+                _ROLE_POOLS.append("ICP chain on CUs [0,%d), score + label on [%d,%d)" % (k, k, n_cu))
+            except Exception as e:       # a runtime without CU masks: the streams stay as they are
+                _ROLE_POOLS.append("none (%s)" % e)
+        else:
+            _ROLE_POOLS.append("none")
+    return _ROLE_POOLS[:3]
+
+
+def cu_partition_note():
+    return _ROLE_POOLS[3] if _ROLE_POOLS else "none"
+
+
 def run_step(w, dist_ctx=None, concurrent=True):
     """One pass of the hot path (single GPU, or one replica of --replicas).  Returns the outputs (poses, scores, labels).
 
@@ -135,7 +172,7 @@ def run_step(w, dist_ctx=None, concurrent=True):
                                           [0] * len(w["plc"]), [p["cls"] for p in w["plc"]], 0.05, False)
 
     if concurrent:
-        f = [_pool().submit(fn) for fn in (icp, score, label)]
+        f = [ex.submit(fn) for ex, fn in zip(_role_pools(), (icp, score, label))]
         (err, T, it), scores, res = f[0].result(), f[1].result(), f[2].result()
     else:
         (err, T, it), scores, res = icp(), score(), label()
@@ -269,7 +306,7 @@ class Sharded:
         b = self.bufs[self.step_index & 1]
         self.step_index += 1
         t0 = time.perf_counter()
-        rd.shard_compute(capi, self.lay, self.rank, self.units, b[0], b[2], threads=_pool() if concurrent else None)
+        rd.shard_compute(capi, self.lay, self.rank, self.units, b[0], b[2], threads=_role_pools() if concurrent else None)
         t1 = time.perf_counter()
         prev = exchange_wait()                          # at most one exchange in flight, so the other buffer set is free again
         _XCH["pending"] = _exchange_pool().submit(self.exchange, b)
@@ -519,7 +556,7 @@ def main():
                        "route": "sharded" if sharded else ("replicas" if world > 1 else "single"),
                        "n_scan0": w["n_scan0"], "n_scan1": w["n_scan1"], "n_obj": w["n_obj"],
                        "pairs_per_step": pairs_unit * (units if sharded else world), "pairs_split_per_unit": w["pairs"],
-                       "issue": "3 host threads / 3 HIP streams (ICP chain | score batch | label pass)" if conc else "serial",
+                       "issue": ("3 host threads / 3 HIP streams (ICP chain | score batch | label pass); CU partition: " + cu_partition_note()) if conc else "serial",
                        "exchange": ("one all_gather of the per-rank send buffers (poses, errors, scores, per-placement rows: %.1f MB per rank) per step, "
                                     "overlapped with the next step; ordered fold of the rows on the device; on the exchange thread: publish + all_gather %.3f ms, "
                                     "fold + download of poses / scores / labels %.3f ms per step; main thread: compute %.3f ms, waiting for the previous exchange %.3f ms per step"

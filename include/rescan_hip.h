@@ -35,6 +35,10 @@ const char* rs_hip_last_error( void );
  * library's own stream. */
 int         rs_hip_set_stream( void* hip_stream );
 int         rs_hip_synchronize( void );
+/* Restrict the calling thread's own stream to the compute units whose bits are set in mask (n_words x 32 bits, CU 0 = bit 0 of
+ * word 0): independent operators issued from different threads can be kept off each other's CUs (a latency-bound chain beside
+ * a throughput-bound batch).  Replaces the thread's stream; pending work on the old one is waited for. */
+int         rs_hip_stream_cu_mask( const uint32_t* mask, int32_t n_words );
 /* ABI/version string, e.g. "rescan_hip 0.1 gfx950". */
 const char* rs_hip_version( void );
 
