@@ -136,11 +136,14 @@ def _role_pools():
         split = float(os.environ.get("RS_BENCH_CU_SPLIT", "0.625" if n_cu == 256 else "0"))
         if split > 0.0:
             k = int(round(split * n_cu))
-            masks = [[1] * k + [0] * (n_cu - k), [0] * k + [1] * (n_cu - k), [0] * k + [1] * (n_cu - k)]
+            lo = int(round(float(os.environ.get("RS_BENCH_CU_BATCH_LO", split)) * n_cu))     # experiment: overlapping partitions
+            label_on = os.environ.get("RS_BENCH_LABEL_ON", "chain")
+            chain, batch = [1] * k + [0] * (n_cu - k), [0] * lo + [1] * (n_cu - lo)
+            masks = [chain, batch, {"chain": chain, "batch": batch, "all": [1] * n_cu}[label_on]]
             try:
                 for ex, m in zip(_ROLE_POOLS, masks):
                     ex.submit(capi.stream_cu_mask, m).result()
-                _ROLE_POOLS.append("ICP chain on CUs [0,%d), score + label on [%d,%d)" % (k, k, n_cu))
+                _ROLE_POOLS.append("mask bits [0,%d) ICP chain%s, [%d,%d) score batch%s" % (k, " + label pass" if label_on == "chain" else "", lo, n_cu, " + label pass" if label_on == "batch" else ""))
             except Exception as e:       # a runtime without CU masks: the streams stay as they are
                 _ROLE_POOLS.append("none (%s)" % e)
         else:

@@ -39,6 +39,9 @@ int         rs_hip_synchronize( void );
  * word 0): independent operators issued from different threads can be kept off each other's CUs (a latency-bound chain beside
  * a throughput-bound batch).  Replaces the thread's stream; pending work on the old one is waited for. */
 int         rs_hip_stream_cu_mask( const uint32_t* mask, int32_t n_words );
+/* Diagnostic: out[b] = XCC_ID | HW_ID << 8 of workgroup b of a probe launch on the calling thread's stream (which CUs a
+ * CU mask really selects: tools/cu_mask_probe.py). */
+int         rs_hip_probe_placement( uint32_t* out_host, int32_t n_blocks );
 /* ABI/version string, e.g. "rescan_hip 0.1 gfx950". */
 const char* rs_hip_version( void );
 

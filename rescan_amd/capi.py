@@ -24,6 +24,7 @@ SIGNATURES = {
     "rs_hip_set_stream": (C.c_int, [C.c_void_p]),
     "rs_hip_synchronize": (C.c_int, []),
     "rs_hip_stream_cu_mask": (C.c_int, [np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS"), C.c_int32]),
+    "rs_hip_probe_placement": (C.c_int, [np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS"), C.c_int32]),
     "rs_hip_version": (C.c_char_p, []),
     "rs_hip_profile_enable": (C.c_int, [C.c_int]),
     "rs_hip_profile_reset": (C.c_int, []),
@@ -125,6 +126,14 @@ def stream_cu_mask(bits):
         if v:
             words[k // 32] |= np.uint32(1 << (k % 32))
     _check(load().rs_hip_stream_cu_mask(words, len(words)))
+
+
+def probe_placement(n_blocks=4096):
+    """(xcc, se, sh, cu) of each workgroup of a probe launch on the calling thread's stream (diagnostic)."""
+    out = np.zeros(n_blocks, np.uint32)
+    _check(load().rs_hip_probe_placement(out, n_blocks))
+    hw = out >> 8
+    return out & 15, (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 15
 
 
 def profile_enable(on=True):

@@ -296,6 +296,32 @@ int rs_hip_stream_cu_mask( const uint32_t* mask, int32_t n_words )
   return RS_HIP_OK;
 }
 
+// Diagnostic: where the hardware places the workgroups of the calling thread's stream.  out[b] = XCC_ID | HW_ID << 8 of
+// block b's first wave (HW_ID: CU_ID bits 11:8, SH_ID 12, SE_ID 15:13).  Used by tools/cu_mask_probe.py to find out which
+// CUs a mask bit stands for — the partition bench.py uses is chosen from that.
+__global__ void k_probe_placement( uint32_t* out, int spin )
+{
+  uint32_t xcc, hw;
+  asm volatile( "s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"( xcc ) );
+  asm volatile( "s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"( hw ) );
+  const long long t0 = wall_clock64();
+  while( wall_clock64() - t0 < spin ) { }                 // hold the slot so that the blocks spread over everything allowed
+  if( threadIdx.x == 0 ) out[blockIdx.x] = ( xcc & 15u ) | ( hw << 8 );
+}
+int rs_hip_probe_placement( uint32_t* out_host, int32_t n_blocks )
+{
+  int rc = ensure_ready(); if( rc ) return rc;
+  if( !out_host || n_blocks <= 0 ) { set_err( "probe_placement: bad arguments" ); return RS_HIP_E_ARG; }
+  uint32_t* d = nullptr;
+  HIP_TRY( hipMalloc( (void**)&d, (size_t)n_blocks * 4 ), RS_HIP_E_RUNTIME );
+  hipLaunchKernelGGL( k_probe_placement, dim3( n_blocks ), dim3( 256 ), 0, g_stream, d, 20000 );   // 100 MHz clock: 200 us
+  hipError_t e = hipMemcpyAsync( out_host, d, (size_t)n_blocks * 4, hipMemcpyDeviceToHost, g_stream );
+  if( e == hipSuccess ) e = hipStreamSynchronize( g_stream );
+  (void)hipFree( d );
+  HIP_TRY( e, RS_HIP_E_RUNTIME );
+  return RS_HIP_OK;
+}
+
 int rs_hip_synchronize( void )
 {
   int rc = ensure_ready(); if( rc ) return rc;
@@ -1082,6 +1108,7 @@ int rs_hip_alignment_scores( const rs_hip_cloud_t* object, const rs_hip_cloud_t*
   L.K = max_n_neigh; L.sigma = (double)radius; L.part = g_ws.score_part.as<double>(); L.scores = g_ws.scores.as<float>();
   L.queue = g_ws.queue.as<int>(); L.queue_count = g_ws.queue_count.as<int>();
   L.solo_stages = handoff_threshold( (long long)n_tiles * n_poses );
+  L.by_rows = getenv( "RS_HIP_SCORE_ROWS" ) ? 1 : 0;      // opt-in: 2.2x fewer evaluations, but 1.8x more staged and slower
   // the launch grid's y dimension is limited to 65535 poses per launch
   for( int p0 = 0; p0 < n_poses; p0 += 65535 )
   {

@@ -146,6 +146,7 @@ struct ScoreLaunch
   int*         queue;      // n_poses x n_tiles items (pose*n_tiles + tile) for the cooperative kernel
   int*         queue_count;
   int          solo_stages;
+  int          by_rows;    // launches that hand nothing off: the row-wise cold search (rs_kernels.hip: tile_search_rows)
 };
 void launch_score( const ScoreLaunch& L, hipStream_t st );
 
