@@ -282,27 +282,30 @@ __device__ __forceinline__ float box_cover( const GridView& g, const CellBox& cu
 // shell sweep
 // ------------------------------------------------------------------------------------------
 
-// Per-wave LDS.
-struct WaveLds
+// Per-wave LDS.  CAP = staged candidates per round (the per-row cold search of the score batch stages more than a wave's worth).
+template <int CAP>
+struct WaveLdsT
 {
-  float    px[WAVE], py[WAVE], pz[WAVE];   // staged candidates, one array per coordinate so that four
-  int      pidx[WAVE];                     // consecutive candidates load as one ds_read_b128 per coordinate
-  float    nx[WAVE], ny[WAVE], nz[WAVE];   // their normals, same layout
-  uint32_t slot[WAVE];     // their positions in the cell-sorted cloud
+  float    px[CAP], py[CAP], pz[CAP];      // staged candidates, one array per coordinate so that four
+  int      pidx[CAP];                      // consecutive candidates load as one ds_read_b128 per coordinate
+  float    nx[CAP], ny[CAP], nz[CAP];      // their normals, same layout
+  uint32_t slot[CAP];      // their positions in the cell-sorted cloud
   uint32_t seg_a[WAVE], len_a[WAVE], seg_b[WAVE], pre[WAVE];   // row pieces of the current batch
   uint32_t evals;          // profiling only (lane 0): candidates this wave staged and evaluated, flushed once by EvalScope
 };
+typedef WaveLdsT<WAVE> WaveLds;
 
 // Profiling only (GridView::evals non-null): the wave's candidate count goes to the sharded device counters ONCE, when the
 // wave leaves the kernel — an atomic per sweep was most of what WRITE_SIZE saw of k_label (75 MB per launch for 5 MB of
 // results: atomics execute at the memory side, 64 B each) and a good part of k_icp_corr's.
 struct EvalScope
 {
-  unsigned long long* evals; WaveLds& L; int lane;
-  __device__ __forceinline__ EvalScope( unsigned long long* e, WaveLds& l, int ln ) : evals( e ), L( l ), lane( ln ) { if( evals && lane == 0 ) L.evals = 0u; }
+  unsigned long long* evals; uint32_t& count; int lane;
+  template <class LDS>
+  __device__ __forceinline__ EvalScope( unsigned long long* e, LDS& l, int ln ) : evals( e ), count( l.evals ), lane( ln ) { if( evals && lane == 0 ) count = 0u; }
   __device__ __forceinline__ ~EvalScope()
   {
-    if( evals && lane == 0 && L.evals ) atomicAdd( evals + 8 * ( ( blockIdx.x + 37 * blockIdx.y ) & ( EVAL_SHARDS - 1 ) ), (unsigned long long)L.evals );   // sharded, one cache line each
+    if( evals && lane == 0 && count ) atomicAdd( evals + 8 * ( ( blockIdx.x + 37 * blockIdx.y ) & ( EVAL_SHARDS - 1 ) ), (unsigned long long)count );   // sharded, one cache line each
   }
 };
 
@@ -530,8 +533,8 @@ __device__ __forceinline__ void dist2x4( const float4& X, const float4& Y, const
 // Three levels: (1) distances only — most groups end here; (2) some lane has a candidate inside its
 // bound (lanes without a match see that for everything within the radius): the gate of all four,
 // packed like the distances; (3) a candidate passed both: settle it one by one.
-template <bool GATED, bool SELF>
-__device__ __forceinline__ void consider4( const float4& X, const float4& Y, const float4& Z, int k, const WaveLds& L,
+template <bool GATED, bool SELF, class LDS>
+__device__ __forceinline__ void consider4( const float4& X, const float4& Y, const float4& Z, int k, const LDS& L,
                                            float qx, float qy, float qz, float nx, float ny, float nz,
                                            float tmin, float& bound, Match& m, int& seen_closer )
 {
@@ -591,7 +594,8 @@ __device__ __forceinline__ void consider4( const float4& X, const float4& Y, con
 }
 
 // count, among four candidates, those that precede (bd2, bidx) within the radius
-__device__ __forceinline__ int precede4( const float4& X, const float4& Y, const float4& Z, int k, const WaveLds& L,
+template <class LDS>
+__device__ __forceinline__ int precede4( const float4& X, const float4& Y, const float4& Z, int k, const LDS& L,
                                          float qx, float qy, float qz, float radius_sq, float bd2, int bidx )
 {
   float d[4];
@@ -875,13 +879,16 @@ __device__ __forceinline__ float rbox_cover( const GridView& g, const RowBox& cu
   return c - ( 1e-4f * g.cell + 2e-5f );
 }
 
-// Every row streams (its out \ its in) through its quarter of the wave's LDS arrays: f( X, Y, Z, k ) for every group of four
-// staged candidates k..k+3 of the calling lane's row (k differs between rows).  Sentinels as in sweep_shell.
-template <bool WITH_NOR, class F>
+// Every row streams (its out \ its in) through its quarter of the wave's LDS arrays, RB candidates per row and round (RB / 16
+// loads in flight per lane: with 16 a round is four candidate groups per lane, too little work to cover the loads of the next):
+// f( X, Y, Z, k ) for every group of four staged candidates k..k+3 of the calling lane's row (k differs between rows).
+// Sentinels as in sweep_shell.  LDS = WaveLdsT<4 * RB>.
+template <bool WITH_NOR, int RB, class LDS, class F>
 __device__ __forceinline__ uint32_t sweep_rows_shell( const GridView& g, const RowBox& out, const RowBox& in, bool in_valid,
-                                                      WaveLds& L, int lane, F&& f )
+                                                      LDS& L, int lane, F&& f )
 {
-  const int l16 = lane & 15, base = lane & 48;
+  constexpr int NF = RB / 16;
+  const int l16 = lane & 15, tbase = lane & 48, sbase = ( lane >> 4 ) * RB;
   const int ny = out.y1 - out.y0 + 1, nz = out.z1 - out.z0 + 1;
   const int n_rows = rbox_empty( out ) ? 0 : ny * nz;
   const float inv_ny = 1.0f / (float)max( ny, 1 );
@@ -914,39 +921,48 @@ __device__ __forceinline__ uint32_t sweep_rows_shell( const GridView& g, const R
     const uint32_t t2 = (uint32_t)__builtin_amdgcn_readlane( (int)total, 47 ), t3 = (uint32_t)__builtin_amdgcn_readlane( (int)total, 63 );
     const uint32_t longest = max( max( t0, t1 ), max( t2, t3 ) );
     streamed += t0 + t1 + t2 + t3;
-    auto fetch = [&]( uint32_t c0, float4& P, float4& N, uint32_t& src )
+    float4 P[NF], N[NF]; uint32_t src[NF];
+    auto fetch = [&]( uint32_t c0 )
     {
-      const uint32_t j = c0 + (uint32_t)l16;
-      P = make_float4( FLT_MAX, FLT_MAX, FLT_MAX, 0.0f ); N = make_float4( 0.0f, 0.0f, 0.0f, 0.0f ); src = 0;
-      if( j < total )
-      {
-        int row = 0;                                   // last cell row of this lane's row whose first candidate number is <= j
 #pragma unroll
-        for( int step = 8; step > 0; step >>= 1 ) { if( L.pre[base + row + step] <= j ) row += step; }
-        const uint32_t off = j - L.pre[base + row];
-        const uint32_t la_r = L.len_a[base + row];
-        src = ( off < la_r ) ? ( L.seg_a[base + row] + off ) : ( L.seg_b[base + row] + ( off - la_r ) );
-        P = g.pos[src];
-        if( WITH_NOR ) N = g.nor[src];
+      for( int q = 0; q < NF; ++q )
+      {
+        const uint32_t j = c0 + (uint32_t)( 16 * q + l16 );
+        P[q] = make_float4( FLT_MAX, FLT_MAX, FLT_MAX, 0.0f ); N[q] = make_float4( 0.0f, 0.0f, 0.0f, 0.0f ); src[q] = 0;
+        if( j < total )
+        {
+          int row = 0;                                 // last cell row of this lane's row whose first candidate number is <= j
+#pragma unroll
+          for( int step = 8; step > 0; step >>= 1 ) { if( L.pre[tbase + row + step] <= j ) row += step; }
+          const uint32_t off = j - L.pre[tbase + row];
+          const uint32_t la_r = L.len_a[tbase + row];
+          src[q] = ( off < la_r ) ? ( L.seg_a[tbase + row] + off ) : ( L.seg_b[tbase + row] + ( off - la_r ) );
+          P[q] = g.pos[src[q]];
+          if( WITH_NOR ) N[q] = g.nor[src[q]];
+        }
       }
     };
-    float4 P, N; uint32_t src;
     uint32_t c0 = 0;
-    if( c0 < longest ) fetch( c0, P, N, src );
+    if( c0 < longest ) fetch( c0 );
     while( c0 < longest )
     {
-      L.px[lane] = P.x; L.py[lane] = P.y; L.pz[lane] = P.z; L.pidx[lane] = __float_as_int( P.w );
-      if( WITH_NOR ) { L.nx[lane] = N.x; L.ny[lane] = N.y; L.nz[lane] = N.z; }
-      L.slot[lane] = src;
+#pragma unroll
+      for( int q = 0; q < NF; ++q )
+      {
+        const int e = sbase + 16 * q + l16;
+        L.px[e] = P[q].x; L.py[e] = P[q].y; L.pz[e] = P[q].z; L.pidx[e] = __float_as_int( P[q].w );
+        if( WITH_NOR ) { L.nx[e] = N[q].x; L.ny[e] = N[q].y; L.nz[e] = N[q].z; }
+        L.slot[e] = src[q];
+      }
       wave_lds_fence();
-      const uint32_t cn = c0 + 16u;
-      if( cn < longest ) fetch( cn, P, N, src );       // in flight during the evaluation
+      const uint32_t cn = c0 + (uint32_t)RB;
+      if( cn < longest ) fetch( cn );                  // in flight during the evaluation
       const uint32_t left = longest - c0;
-      const int n4 = left >= 16u ? 4 : (int)( ( left + 3u ) >> 2 );
+      const int n4 = left >= (uint32_t)RB ? RB / 4 : (int)( ( left + 3u ) >> 2 );
 #pragma unroll 1
       for( int k4 = 0; k4 < n4; ++k4 )
       {
-        const int k = base + 4 * k4;
+        const int k = sbase + 4 * k4;
         const float4 X = *reinterpret_cast<const float4*>( &L.px[k] );
         const float4 Y = *reinterpret_cast<const float4*>( &L.py[k] );
         const float4 Z = *reinterpret_cast<const float4*>( &L.pz[k] );
@@ -962,10 +978,10 @@ __device__ __forceinline__ uint32_t sweep_rows_shell( const GridView& g, const R
 }
 
 // The cold search of one tile, row by row.  Same result as tile_search<GATED>( ..., no hand-off, no starting candidate ).
-template <bool GATED>
+template <bool GATED, int RB, class LDS>
 __device__ __forceinline__ Match tile_search_rows( const GridView& g, bool active,
                                                    float qx, float qy, float qz, float nx, float ny, float nz,
-                                                   float radius, float radius_sq, float tmin, int K, WaveLds& L, int lane )
+                                                   float radius, float radius_sq, float tmin, int K, LDS& L, int lane )
 {
   Match m = no_match();
   if( !__any( active ) ) return m;
@@ -984,7 +1000,7 @@ __device__ __forceinline__ Match tile_search_rows( const GridView& g, bool activ
     if( row_done ) { out.x0 = 0; out.x1 = -1; }
     const float cov = rbox_cover( g, cur, full, qx, qy, qz );
     const float cov_sq = cov > 0.0f ? cov * cov : 0.0f;
-    sweep_rows_shell<GATED>( g, out, prev, have_prev, L, lane, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
+    sweep_rows_shell<GATED, RB>( g, out, prev, have_prev, L, lane, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
     {
       // how many candidates of this shell lie within the lane's cover distance (a lower bound of those within it overall)
       float d0, d1, d2, d3;
@@ -1017,7 +1033,7 @@ __device__ __forceinline__ Match tile_search_rows( const GridView& g, bool activ
     {
       int rank = 0;
       const RowBox rb = rbox_clip( row_cell_box( g, need_rank, reach_of( m, radius ), 0.0f, qx, qy, qz ), cur );
-      sweep_rows_shell<false>( g, rb, rb, false, L, lane, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
+      sweep_rows_shell<false, RB>( g, rb, rb, false, L, lane, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
       { rank += need_rank ? precede4( X, Y, Z, k4, L, qx, qy, qz, radius_sq, m.d2, m.idx ) : 0; } );
       if( need_rank && rank >= K ) { m.found = false; m.slot = -1; }
     }
@@ -2448,9 +2464,15 @@ __device__ __forceinline__ void score_emit( const ScoreLaunch& L, int pose, int 
 #ifndef RS_SCORE_OCC
 #define RS_SCORE_OCC 6
 #endif
-__global__ __launch_bounds__( BLOCK, RS_SCORE_OCC ) void k_score( ScoreLaunch L )
+#ifndef RS_SCORE_ROWS_OCC
+#define RS_SCORE_ROWS_OCC 5
+#endif
+// RB = 0: the tile-wide search (with hand-off to k_score_coop); RB = 16: the cold search row by row, RB candidates per row and round
+template <int RB>
+__global__ __launch_bounds__( BLOCK, RB ? RS_SCORE_ROWS_OCC : RS_SCORE_OCC ) void k_score( ScoreLaunch L )
 {
-  __shared__ WaveLds lds[WAVES_PER_BLOCK];
+  typedef WaveLdsT<( RB ? 4 * RB : WAVE )> Lds;
+  __shared__ Lds lds[WAVES_PER_BLOCK];
   const int pose = blockIdx.y;
   const int lane = threadIdx.x & ( WAVE - 1 );
   const int wib = threadIdx.x / WAVE;
@@ -2468,8 +2490,8 @@ __global__ __launch_bounds__( BLOCK, RS_SCORE_OCC ) void k_score( ScoreLaunch L 
   // (starting from the query's own cell, as the cold ICP search does, measured 10 % slower here: bad poses leave
   //  most lanes without a usable point in their cell, and the mixed tiles pay for the seed without skipping the shells)
   Match m;
-  if( L.by_rows && L.solo_stages == 0x7fffffff && L.scene.inv_cell > 0.0f )       // (big batches: nothing is handed off)
-  { handoff = false; m = tile_search_rows<true>( L.scene, active, qx, qy, qz, nx, ny, nz, (float)L.sigma, L.radius_sq, L.gate_tmin, L.K, lds[wib], lane ); }
+  if constexpr( RB > 0 )
+  { handoff = false; m = tile_search_rows<true, RB>( L.scene, active, qx, qy, qz, nx, ny, nz, (float)L.sigma, L.radius_sq, L.gate_tmin, L.K, lds[wib], lane ); }
   else
     m = tile_search<true>( L.scene, active, qx, qy, qz, nx, ny, nz, (float)L.sigma, L.radius_sq, L.gate_tmin, L.K,
                            lds[wib], lane, L.solo_stages, &handoff, nullptr, no_match() );
@@ -2526,7 +2548,10 @@ void launch_score( const ScoreLaunch& L, hipStream_t st )
 {
   (void)hipMemsetAsync( L.queue_count, 0, sizeof(int), st );
   dim3 grid( ( L.obj.n_tiles + WAVES_PER_BLOCK - 1 ) / WAVES_PER_BLOCK, L.n_poses );
-  hipLaunchKernelGGL( k_score, grid, dim3( BLOCK ), 0, st, L );
+  // by_rows: big batches on a cell grid only — nothing is handed off there.  (16 candidates per row and round; 32 and 64 were
+  // measured too: 1.70 and 2.15 ms against 1.53 — rows of unequal length evaluate sentinels up to the longest one's count.)
+  if( L.by_rows && L.solo_stages == 0x7fffffff && L.scene.inv_cell > 0.0f ) hipLaunchKernelGGL( k_score<16>, grid, dim3( BLOCK ), 0, st, L );
+  else hipLaunchKernelGGL( k_score<0>, grid, dim3( BLOCK ), 0, st, L );
   long long items = (long long)L.obj.n_tiles * L.n_poses;
   hipLaunchKernelGGL( k_score_coop, dim3( items < 4096 ? (int)( items > 0 ? items : 1 ) : 4096 ), dim3( COOP_BLOCK ), 0, st, L );
   hipLaunchKernelGGL( k_score_final, dim3( L.n_poses ), dim3( BLOCK ), 0, st, L );

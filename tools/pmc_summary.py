@@ -10,7 +10,7 @@ def per_kernel(path):
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     cnt = collections.defaultdict(collections.Counter)
     for r in csv.DictReader(open(path)):
-        k = r["Kernel_Name"].split("(")[0]
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         cnt[k][r["Counter_Name"]] += 1
     return {k: {c: (v / cnt[k][c], cnt[k][c]) for c, v in d.items()} for k, d in agg.items()}
@@ -40,7 +40,7 @@ if __name__ == "__main__":
             return sum((2 * F[k][0] + W.get(k, (0, 0))[0]) * F[k][1] for k in F if any(n in k for n in names)) * 1024
         # domain -> (kernels that belong to it, kernels whose launches count as ONE unit of it)
         doms = {"nn_icp": (["k_icp_corr"], ["k_icp_corr<"]), "icp_moments": (["k_icp_moments", "k_icp_update"], ["k_icp_moments"]),
-                "nn_score": (["k_score"], ["rs::k_score("]), "nn_label": (["k_label"], ["rs::k_label("])}
+                "nn_score": (["k_score"], ["rs::k_score<"]), "nn_label": (["k_label"], ["rs::k_label("])}
         out = {"_note": "HBM-side bytes per launch from rocprofv3 PMC (separate FETCH_SIZE and WRITE_SIZE passes of `bench.py --steps 2 "
                         "--warmup 1 --serial`, tools/profile.sh traffic, folded by tools/pmc_summary.py --fold), FETCH_SIZE doubled as "
                         "MI355X_MICROARCH.md \u00a7HBM prescribes for 16-B-per-lane reads on gfx950; WRITE_SIZE as reported.  nn_icp = "
