@@ -120,12 +120,15 @@ _ROLE_POOLS = None
 
 def _role_pools():
     """One single-thread executor per consumer (ICP chain, score batch, label pass): a consumer always runs on the same host
-    thread, i.e. on the same HIP stream — and the streams are given disjoint sets of XCDs: the ICP chain (a sequence of short
-    latency-bound kernels) keeps 5 of the chip's 8 XCDs to itself, the two batch consumers (throughput-bound, finished long
-    before the chain) share the other 3.  On the whole chip the batch kernels' waves sit among the chain's and stretch it:
-    3.07 ms per step shared, 2.92-2.96 partitioned 5 + 3 (same box, interleaved repeats: profiles/r02/ab_cu_split*.txt; 4 + 4
-    and 4.5 + 3.5 are slower, 6 + 2 makes the score batch the longer of the two; partitions that cut through an XCD are bad).
-    RS_BENCH_CU_SPLIT=<fraction of the CUs for the chain> overrides (0 = no partition)."""
+    thread, i.e. on the same HIP stream — and the streams are confined to disjoint sets of CUs (rs_hip_stream_cu_mask).  A bit
+    of the mask is not "a CU of the chip in order": bit i is CU slot i / 8 of XCD i % 8 and slot j is a CU of shader engine
+    j % 4 (tools/cu_mask_probe.py, profiles/r02/cu_mask_probe.txt), so bits [0,160) | [160,256) give the ICP chain 5 CUs of every
+    shader engine of every XCD and the score batch the other 3; the shader engines hand out workgroups evenly, so splits that
+    leave them unequal run at the smallest one's pace (granularity: 32 bits).  The chain (short latency-bound kernels) gets CUs
+    no long-lived score wave sits on; the label pass, 0.4 ms, shares the chain's side.  3.07 ms per step unpartitioned,
+    2.95 with 5 + 3 and the label pass beside the score batch, 2.80 with it beside the chain (interleaved repeats on one box:
+    profiles/r02/ab_cu_split*.txt, ab_label_on_chain_and_no_partition_experiments.txt).
+    RS_BENCH_CU_SPLIT=<fraction of the mask bits for the chain> overrides (0 = no partition); RS_BENCH_LABEL_ON=chain|batch|all."""
     global _ROLE_POOLS
     if _ROLE_POOLS is None:
         from concurrent.futures import ThreadPoolExecutor
@@ -143,7 +146,10 @@ def _role_pools():
             try:
                 for ex, m in zip(_ROLE_POOLS, masks):
                     ex.submit(capi.stream_cu_mask, m).result()
-                _ROLE_POOLS.append("mask bits [0,%d) ICP chain%s, [%d,%d) score batch%s" % (k, " + label pass" if label_on == "chain" else "", lo, n_cu, " + label pass" if label_on == "batch" else ""))
+                f_chain, f_batch = k / n_cu, (n_cu - lo) / n_cu
+                f_label = {"chain": f_chain, "batch": f_batch, "all": 1.0}[label_on]
+                _CU_SHARES.update({"nn_icp": f_chain, "icp_moments": f_chain, "nn_score": f_batch, "nn_label": f_label})
+                _ROLE_POOLS.append("CU mask bits [0,%d) (%d CUs of every shader engine of every XCD) ICP chain%s, [%d,%d) score batch%s" % (k, k // 32, " + label pass" if label_on == "chain" else "", lo, n_cu, " + label pass" if label_on == "batch" else ""))
             except Exception as e:       # a runtime without CU masks: the streams stay as they are
                 _ROLE_POOLS.append("none (%s)" % e)
         else:
@@ -153,6 +159,14 @@ def _role_pools():
 
 def cu_partition_note():
     return _ROLE_POOLS[3] if _ROLE_POOLS else "none"
+
+
+_CU_SHARES = {}
+
+
+def cu_shares():
+    """Fraction of the chip's CUs each domain's stream may use (1.0 without a partition)."""
+    return dict(_CU_SHARES)
 
 
 def run_step(w, dist_ctx=None, concurrent=True):
@@ -525,20 +539,25 @@ def main():
             out = dict(err=errs[0], T=Ts[0], scores=scores, labels=labels, min_dists=mind)
         else:
             out = last
-        # dominant kernel: the ICP correspondence search (k_icp_corr)
+        # Dominant kernel: the one that takes the largest share of the GPU — time per step x the fraction of the CUs its stream is
+        # confined to (with the CU partition the score batch runs ~2.6 ms on 3/8 of the chip beside the ICP chain's ~2.3 ms of
+        # searches on 5/8; serial or unpartitioned the shares are 1 and this is plain time).  Every domain's figures are in
+        # roofline_by_kernel.
         prof = {k: capi.profile_read(k) for k in ("nn_icp", "icp_moments", "nn_score", "nn_label")}
         per_step = {k: v[1] / max(1, v[0]) * (ICP_ITERS if k in ("nn_icp", "icp_moments") else 1) for k, v in prof.items()}
-        dom = max(per_step, key=per_step.get)
+        shares = cu_shares() if conc else {}
+        alg_bytes = {"nn_icp": w["n_scan1"] * 56 + w["n_scan0"] * 16,            # per launch (SURVEY.md §8d / BASELINE.md §3.5)
+                     "nn_score": N_POSES * w["n_obj"] * 40 + w["n_scan1"] * 16,
+                     "nn_label": N_PLACEMENTS * w["n_scan1"] * 46 + sum(len(p["np"][0]) for p in w["plc"][:N_PLACEMENTS]) * 16,
+                     "icp_moments": w["n_scan1"] * 56}
+        by_kernel = {}
+        for k, (n_k, ms_k) in prof.items():
+            avg = (ms_k / max(1, n_k)) * 1e-3
+            by_kernel[k] = {"avg_launch_ms": avg * 1e3, "launches": n_k, "alg_bytes_per_launch": alg_bytes[k], "cu_share": shares.get(k, 1.0),
+                            "achieved_GBs": alg_bytes[k] / avg / 1e9 if avg > 0 else 0.0, "frac": (alg_bytes[k] / avg / 1e9 / HBM_PEAK_GBS) if avg > 0 else 0.0}
+        dom = max(per_step, key=lambda k: per_step[k] * shares.get(k, 1.0))
         n_l, ms = prof[dom]
-        # algorithmic bytes per launch (SURVEY.md §8d / BASELINE.md §3.5)
-        if dom == "nn_icp":
-            bytes_launch = w["n_scan1"] * 56 + w["n_scan0"] * 16
-        elif dom == "nn_score":
-            bytes_launch = N_POSES * w["n_obj"] * 40 + w["n_scan1"] * 16
-        elif dom == "nn_label":
-            bytes_launch = N_PLACEMENTS * w["n_scan1"] * 46 + sum(len(p["np"][0]) for p in w["plc"][:N_PLACEMENTS]) * 16
-        else:
-            bytes_launch = w["n_scan1"] * 56
+        bytes_launch = alg_bytes[dom]
         avg_s = (ms / max(1, n_l)) * 1e-3
         achieved = bytes_launch / avg_s / 1e9 if avg_s > 0 else 0.0
         traffic, traffic_note = read_traffic(dom)
@@ -568,7 +587,9 @@ def main():
                                    else ("one fused all_gather(poses, scores, label partials) per step, overlapped with the next step" if dist is not None else "none")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
-                         "avg_launch_ms": ms / max(1, n_l), "launches": n_l, "alg_bytes_per_launch": bytes_launch},
+                         "avg_launch_ms": ms / max(1, n_l), "launches": n_l, "alg_bytes_per_launch": bytes_launch,
+                         "dominant_by": "time per step x share of the CUs the kernel's stream is confined to", "cu_share": shares.get(dom, 1.0)},
+            "roofline_by_kernel": by_kernel,
             "parity": parity_block(out, args.points, seed, args.knn, units),
             "ms_per_step_spread": {"min": float(step_ms.min()), "median": float(np.median(step_ms)), "max": float(step_ms.max())},
             # per-launch averages x launches per step (the ICP loop's events are sampled: one call in RS_HIP_PROF_EVERY)
