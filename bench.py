@@ -157,6 +157,18 @@ def _role_pools():
     return _ROLE_POOLS[:3]
 
 
+def host_cpu_stat():
+    """(quota string, throttled periods, throttled microseconds) of this container's CPU cgroup, or None: a step that falls into
+    a throttled period stalls with every thread of the process, whatever the GPU does."""
+    try:
+        quota = open("/sys/fs/cgroup/cpu.max").read().strip() if os.path.exists("/sys/fs/cgroup/cpu.max") else None
+        f = "/sys/fs/cgroup/cpu.stat" if os.path.exists("/sys/fs/cgroup/cpu.stat") else "/sys/fs/cgroup/cpu/cpu.stat"
+        d = dict(line.split() for line in open(f).read().strip().splitlines())
+        return quota, int(d.get("nr_throttled", 0)), int(d.get("throttled_usec", d.get("throttled_time", 0)))
+    except Exception:
+        return None
+
+
 def cu_partition_note():
     return _ROLE_POOLS[3] if _ROLE_POOLS else "none"
 
@@ -512,6 +524,7 @@ def main():
     import gc
     gc.collect(); gc.disable()                  # no collector pauses inside the timed region
     barrier()
+    cpu_before = host_cpu_stat()
     t0 = time.perf_counter()
     marks = []
     for _ in range(args.steps):
@@ -520,6 +533,7 @@ def main():
     drain()
     barrier()
     elapsed = time.perf_counter() - t0
+    cpu_after = host_cpu_stat()
     gc.enable()
     step_ms = np.diff(np.array([t0] + marks)) * 1e3
     if os.environ.get("RS_BENCH_PRINT_STEPS") and rank == 0:
@@ -591,7 +605,11 @@ def main():
                          "dominant_by": "time per step x share of the CUs the kernel's stream is confined to", "cu_share": shares.get(dom, 1.0)},
             "roofline_by_kernel": by_kernel,
             "parity": parity_block(out, args.points, seed, args.knn, units),
-            "ms_per_step_spread": {"min": float(step_ms.min()), "median": float(np.median(step_ms)), "max": float(step_ms.max())},
+            "ms_per_step_spread": {"min": float(step_ms.min()), "median": float(np.median(step_ms)), "max": float(step_ms.max()),
+                                   "steps_over_1.3x_median": int((step_ms > 1.3 * np.median(step_ms)).sum())},
+            # the container's CPU cgroup around the timed region: a throttled period stalls every host thread of the process
+            "host": ({"cpu_max": cpu_before[0], "throttled_periods_in_timed_region": cpu_after[1] - cpu_before[1],
+                      "throttled_usec_in_timed_region": cpu_after[2] - cpu_before[2]} if cpu_before and cpu_after else None),
             # per-launch averages x launches per step (the ICP loop's events are sampled: one call in RS_HIP_PROF_EVERY)
             "kernel_ms_per_step": per_step,
             "profile_sampling": "ICP chain: events on every %s-th call (%d launches timed); score / label: every call" % (os.environ.get("RS_HIP_PROF_EVERY", "1"), n_l),
