@@ -1412,15 +1412,27 @@ int rs_hip_radius_search( const rs_hip_cloud_t* target, const float* query, int6
         ( rc = W.h_a.ensure( down_words * 4 ) ) || ( rc = W.h_b.ensure( up_words * 4 ) ) ) return rc;
     float* h_up = W.h_b.as<float>();
     std::memcpy( h_up, query, nn * 12 );
-    float* d_up = W.bld_pos.as<float>();
-    int* d_nn = W.rows.as<int>();                      // [nq] counts (-1: more than 1024 points within the radius), one spare word, then the rows
-    float* d_d2 = W.rows.as<float>() + ( nn + 1 ); int* d_idx = W.rows.as<int>() + ( nn + 1 ) + nk;
-    HIP_TRY( hipMemcpyAsync( d_up, h_up, up_words * 4, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
-    { ProfScope ps( "nn_rows" );
-      launch_rows_wave( g, d_up, nq, k, radius, radius_sq_of( radius ), d_d2, d_idx, d_nn, d_nn + nq, g_stream ); }
     int* h_nn = W.h_a.as<int>();
-    HIP_TRY( hipMemcpyAsync( h_nn, d_nn, down_words * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
-    HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
+    // Small calls go without the two copies: the pinned blocks are device-visible, the kernel reads the queries from host memory
+    // and stores counts and rows straight into it (a few tens of KB over PCIe), so a call is ONE launch and one synchronisation.
+    static const size_t zero_copy_below = getenv( "RS_HIP_ROWS_ZERO_COPY_BELOW" ) ? (size_t)atoll( getenv( "RS_HIP_ROWS_ZERO_COPY_BELOW" ) ) : ( 256u << 10 );
+    if( down_words * 4 <= zero_copy_below )
+    {
+      { ProfScope ps( "nn_rows" );
+        launch_rows_wave( g, h_up, nq, k, radius, radius_sq_of( radius ), (float*)( h_nn + nn + 1 ), h_nn + nn + 1 + nk, h_nn, h_nn + nq, g_stream ); }
+      HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
+    }
+    else
+    {
+      float* d_up = W.bld_pos.as<float>();
+      int* d_nn = W.rows.as<int>();                    // [nq] counts (-1: more than 1024 points within the radius), one spare word, then the rows
+      float* d_d2 = W.rows.as<float>() + ( nn + 1 ); int* d_idx = W.rows.as<int>() + ( nn + 1 ) + nk;
+      HIP_TRY( hipMemcpyAsync( d_up, h_up, up_words * 4, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+      { ProfScope ps( "nn_rows" );
+        launch_rows_wave( g, d_up, nq, k, radius, radius_sq_of( radius ), d_d2, d_idx, d_nn, d_nn + nq, g_stream ); }
+      HIP_TRY( hipMemcpyAsync( h_nn, d_nn, down_words * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+      HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
+    }
     bool overflow = false;
     for( int i = 0; i < nq; ++i ) overflow |= h_nn[i] < 0;
     if( !overflow )

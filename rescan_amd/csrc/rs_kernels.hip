@@ -2782,6 +2782,67 @@ void launch_rows( const RowsLaunch& L, hipStream_t st )
 #define ROWS_WAVES 4
 struct RowsWaveLds { float d2[ROWS_CAP]; int idx[ROWS_CAP]; uint32_t seg[WAVE], pre[WAVE]; };
 
+// Bitonic sort of 64 U entries by (dist², index), entry e = 64 u + lane held in registers: exchanges at distance >= 64 are
+// between a lane's own registers, the others one lane permute per register — against one LDS round trip (read, compare, write,
+// fence) per stage when the row sits in LDS: 28 stages cost 1.2 us instead of 6 for 128 hits, and the sort is half of what a
+// wave of a small call does.
+template <int U>
+__device__ __forceinline__ void rows_sort_regs( float ( &d )[U], int ( &ix )[U], int lane )
+{
+#pragma unroll
+  for( int k = 2; k <= WAVE * U; k <<= 1 )
+  {
+#pragma unroll
+    for( int jj = k >> 1; jj > 0; jj >>= 1 )
+    {
+      if( jj >= WAVE )
+      {
+        const int du = jj / WAVE;
+#pragma unroll
+        for( int u = 0; u < U; ++u )
+        {
+          if( u & du ) continue;
+          const int v = u | du;
+          const bool up = ( ( u * WAVE + lane ) & k ) == 0;
+          const bool sw = up ? lex_less( d[v], ix[v], d[u], ix[u] ) : lex_less( d[u], ix[u], d[v], ix[v] );
+          const float td = d[u]; const int ti = ix[u];
+          d[u] = sw ? d[v] : td; ix[u] = sw ? ix[v] : ti;
+          d[v] = sw ? td : d[v]; ix[v] = sw ? ti : ix[v];
+        }
+      }
+      else
+      {
+#pragma unroll
+        for( int u = 0; u < U; ++u )
+        {
+          const float pd = __shfl_xor( d[u], jj, WAVE ); const int pi = __shfl_xor( ix[u], jj, WAVE );
+          const bool keep_min = ( ( lane & jj ) == 0 ) == ( ( ( u * WAVE + lane ) & k ) == 0 );
+          const bool take = keep_min ? lex_less( pd, pi, d[u], ix[u] ) : lex_less( d[u], ix[u], pd, pi );
+          d[u] = take ? pd : d[u]; ix[u] = take ? pi : ix[u];
+        }
+      }
+    }
+  }
+}
+template <int U>
+__device__ __forceinline__ void rows_sort_emit( const RowsWaveLds& L, uint32_t count, uint32_t n_out, int lane, float* out_d2, int* out_idx )
+{
+  float d[U]; int ix[U];
+#pragma unroll
+  for( int u = 0; u < U; ++u )
+  {
+    const uint32_t e = (uint32_t)( u * WAVE + lane );
+    d[u] = e < count ? L.d2[e] : INFINITY; ix[u] = e < count ? L.idx[e] : INT_MAX;
+  }
+  rows_sort_regs<U>( d, ix, lane );
+#pragma unroll
+  for( int u = 0; u < U; ++u )
+  {
+    const uint32_t e = (uint32_t)( u * WAVE + lane );
+    if( e < n_out ) { out_d2[e] = d[u]; out_idx[e] = ix[u]; }
+  }
+}
+
 __global__ __launch_bounds__( ROWS_WAVES * WAVE ) void k_rows_wave( GridView g, const float* q3, int nq, int K, float radius, float radius_sq,
                                                                     float* out_d2, int* out_idx, int* out_nn, int* overflow )
 {
@@ -2818,33 +2879,58 @@ __global__ __launch_bounds__( ROWS_WAVES * WAVE ) void k_rows_wave( GridView g, 
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane( (int)incl, WAVE - 1 );
     L.seg[lane] = sa; L.pre[lane] = incl - la;
     wave_lds_fence();
-    for( uint32_t c0 = 0; c0 < total; c0 += WAVE )
+    // four chunks of 64 candidates per round, their loads issued together: a small call is one wave per query with nothing else
+    // on its SIMD, so every dependent load is exposed latency (a 3 x 3 x 3-cell neighbourhood is 4-6 chunks)
+    for( uint32_t c0 = 0; c0 < total; c0 += 4 * WAVE )
     {
-      const uint32_t j = c0 + lane;
-      bool hit = false; float d2 = 0.0f; int idx = 0;
-      if( j < total )
-      {
-        int row = 0;
+      float4 P[4]; bool ok[4];
 #pragma unroll
-        for( int step = WAVE / 2; step > 0; step >>= 1 ) { if( L.pre[row + step] <= j ) row += step; }
-        const float4 P = g.pos[L.seg[row] + ( j - L.pre[row] )];
-        const float vx = P.x - qx, vy = P.y - qy, vz = P.z - qz;
-        d2 = vx * vx + vy * vy + vz * vz;                 // msh_hash_grid.h:852-855
-        idx = __float_as_int( P.w );
-        hit = d2 < radius_sq;                             // :857
-      }
-      const unsigned long long mask = __ballot( hit );
-      if( hit )
+      for( int u = 0; u < 4; ++u )
       {
-        const uint32_t at = count + (uint32_t)__builtin_amdgcn_mbcnt_hi( (uint32_t)( mask >> 32 ), __builtin_amdgcn_mbcnt_lo( (uint32_t)mask, 0u ) );
-        if( at < ROWS_CAP ) { L.d2[at] = d2; L.idx[at] = idx; }
+        const uint32_t j = c0 + (uint32_t)( u * WAVE + lane );
+        ok[u] = j < total;
+        P[u] = make_float4( 0.0f, 0.0f, 0.0f, 0.0f );
+        if( ok[u] )
+        {
+          int row = 0;
+#pragma unroll
+          for( int step = WAVE / 2; step > 0; step >>= 1 ) { if( L.pre[row + step] <= j ) row += step; }
+          P[u] = g.pos[L.seg[row] + ( j - L.pre[row] )];
+        }
       }
-      count += (uint32_t)__popcll( mask );
+#pragma unroll
+      for( int u = 0; u < 4; ++u )
+      {
+        if( c0 + (uint32_t)( u * WAVE ) >= total ) break;
+        const float vx = P[u].x - qx, vy = P[u].y - qy, vz = P[u].z - qz;
+        const float d2 = vx * vx + vy * vy + vz * vz;     // msh_hash_grid.h:852-855
+        const int idx = __float_as_int( P[u].w );
+        const bool hit = ok[u] && d2 < radius_sq;         // :857
+        const unsigned long long mask = __ballot( hit );
+        if( hit )
+        {
+          const uint32_t at = count + (uint32_t)__builtin_amdgcn_mbcnt_hi( (uint32_t)( mask >> 32 ), __builtin_amdgcn_mbcnt_lo( (uint32_t)mask, 0u ) );
+          if( at < ROWS_CAP ) { L.d2[at] = d2; L.idx[at] = idx; }
+        }
+        count += (uint32_t)__popcll( mask );
+      }
     }
     wave_lds_fence();
   }
   if( count > ROWS_CAP ) { if( lane == 0 ) { atomicExch( overflow, 1 ); out_nn[qi] = -1; } return; }
-  // bitonic sort of the first `count` entries (padded with +inf up to a power of two) by (dist², index)
+  // (Ordering a row by counting — every hit counts the hits that precede it and stores itself at that position — instead of
+  //  sorting was tried: 128 hits cost about the same as the 28 LDS round trips of the bitonic network, more hits cost more.)
+  const uint32_t n_out = count < (uint32_t)K ? count : (uint32_t)K;
+  if( count <= 4 * WAVE )
+  {
+    float* od = out_d2 + (size_t)qi * K; int* oi = out_idx + (size_t)qi * K;
+    if( count <= WAVE )          rows_sort_emit<1>( L, count, n_out, lane, od, oi );
+    else if( count <= 2 * WAVE ) rows_sort_emit<2>( L, count, n_out, lane, od, oi );
+    else                         rows_sort_emit<4>( L, count, n_out, lane, od, oi );
+    if( lane == 0 ) out_nn[qi] = (int)n_out;
+    return;
+  }
+  // more than 256 hits: bitonic sort in LDS of the first `count` entries (padded with +inf up to a power of two) by (dist², index)
   uint32_t m = WAVE; while( m < count ) m <<= 1;
   for( uint32_t t = count + lane; t < m; t += WAVE ) { L.d2[t] = INFINITY; L.idx[t] = INT_MAX; }
   wave_lds_fence();
@@ -2862,7 +2948,6 @@ __global__ __launch_bounds__( ROWS_WAVES * WAVE ) void k_rows_wave( GridView g, 
       }
       wave_lds_fence();
     }
-  const uint32_t n_out = count < (uint32_t)K ? count : (uint32_t)K;
   for( uint32_t t = lane; t < n_out; t += WAVE ) { out_d2[(size_t)qi * K + t] = L.d2[t]; out_idx[(size_t)qi * K + t] = L.idx[t]; }
   if( lane == 0 ) out_nn[qi] = (int)n_out;
 }
