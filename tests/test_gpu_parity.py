@@ -649,6 +649,38 @@ def test_icp_is_bit_reproducible_and_thread_safe(capi):
             assert all(key(f.result()) == ref for f in [pool.submit(run) for _ in range(3)])
 
 
+def test_cu_masked_stream_keeps_to_its_cus_and_changes_no_result(capi):
+    """rs_hip_stream_cu_mask (bench.py keeps the score batch off the ICP chain's CUs with it): a worker thread's stream is
+    confined to the mask bits [0, n/2); the probe's workgroups then run on half of the CUs of every XCD and on no other (bit i
+    is CU slot i / 8 of XCD i % 8 — profiles/r02/cu_mask_probe.txt), and an ICP run issued on that stream returns the bits of
+    an unmasked one."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from rescan_amd import synth
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    s0 = synth.scene_for_point_count(120_000, seed=5, timestep=0)
+    s1 = synth.scene_for_point_count(120_000, seed=5, timestep=1)
+    a, b = capi.Cloud(s0["points"], s0["normals"]), capi.Cloud(s1["points"], s1["normals"])
+    T0 = synth.perturbed_pose(I4, np.random.default_rng(3), 0.01, 0.01)
+    run = lambda: capi.icp_align(b, a, T0, I4, 0.10, np.deg2rad(60.0), max_iter=6, fixed_iters=True)   # noqa: E731
+    key = lambda r: (np.float32(r[0]).tobytes(), np.asarray(r[1], np.float32).tobytes())                # noqa: E731
+    ref = key(run())
+
+    def placement():
+        xcc, se, sh, cu = capi.probe_placement(8192)
+        return set(zip(xcc.tolist(), se.tolist(), sh.tolist(), cu.tolist()))
+
+    with ThreadPoolExecutor(max_workers=1) as pool:                 # (the mask belongs to the calling thread's stream)
+        everywhere = pool.submit(placement).result()
+        pool.submit(capi.stream_cu_mask, [1] * (n_cu // 2) + [0] * (n_cu - n_cu // 2)).result()
+        half = pool.submit(placement).result()
+        masked = key(pool.submit(run).result())
+    assert len(everywhere) == n_cu
+    assert half < everywhere and len(half) == n_cu // 2
+    assert len({x for x, _, _, _ in half}) == len({x for x, _, _, _ in everywhere})     # every XCD keeps CUs: the mask is per XCD
+    assert masked == ref
+
+
 def test_cloud_build_edge_cases(capi, oracle):
     """The device-side index build on degenerate inputs: tiny clouds, coincident points, a NaN coordinate,
     a huge sparse extent — searches on them still agree with the oracle."""
