@@ -670,6 +670,12 @@ int icp_prepare( IcpCtx& cx, const rs_hip_cloud_t* src, const rs_hip_cloud_t* tg
     return rc;
   L.queue = g_ws.queue.as<int>(); L.queue_count = g_ws.queue_count.as<int>();
   L.solo_stages = handoff_threshold( (long long)cx.n_waves * n_prob );
+  static const int heavy_streamed = getenv( "RS_HIP_HEAVY_STREAMED" ) ? atoi( getenv( "RS_HIP_HEAVY_STREAMED" ) ) : 400;
+  static const int heavy_handoff = getenv( "RS_HIP_HEAVY_HANDOFF" ) ? atoi( getenv( "RS_HIP_HEAVY_HANDOFF" ) ) : 600;
+  static const int heavy_longest = getenv( "RS_HIP_HEAVY_LONGEST" ) ? atoi( getenv( "RS_HIP_HEAVY_LONGEST" ) ) : 0;
+  L.heavy_streamed = heavy_streamed; L.heavy_handoff = heavy_handoff; L.heavy_longest = heavy_longest;
+  static const int heavy_total = getenv( "RS_HIP_HEAVY_TOTAL" ) ? atoi( getenv( "RS_HIP_HEAVY_TOTAL" ) ) : 0;
+  L.heavy_total = heavy_total;
   float* w = g_ws.state.as<float>();
   L.T1 = w; L.active = (int*)( w + np * 16 ); L.T1_prev = w + np * 17;
   L.iters = (int*)( w + np * 33 ); L.err = w + np * 34; L.prev_err = w + np * 35; L.queued = (int*)( w + np * 36 ); L.ticket = (int*)( w + np * 37 );
@@ -852,7 +858,7 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
     HIP_TRY( hipMemsetAsync( g_ws.stat_acc.p, 0, (size_t)n * STAT_SHARDS * 4 * 8, g_stream ), RS_HIP_E_RUNTIME );
     cx.L.stat_acc = g_ws.stat_acc.as<unsigned long long>();
   }
-  const size_t heavy_words = (size_t)n * ( (size_t)cx.n_waves + HEAVY_SLOTS + 1 );
+  const size_t heavy_words = (size_t)n * heavy_stride( cx.n_waves );
   const bool reorder = !getenv( "RS_HIP_NO_LPT" );
   if( reorder )
   {

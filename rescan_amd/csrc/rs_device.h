@@ -54,6 +54,9 @@ enum { ICP_NMOM = 35,     // raw moments reduced per ICP iteration (see k_icp_mo
 
 // ---- launchers (rs_kernels.hip) ----------------------------------------------------------
 constexpr int HEAVY_SLOTS = 2048;   // wave slots at the front of phase A's grid reserved for the previous iteration's slow tiles
+constexpr int HEAVY_CLASSES = 8;     // one list per XCD class of the natural order: a listed tile stays on the XCD whose L2 holds its part of the target
+constexpr int HEAVY_PER_CLASS = HEAVY_SLOTS / HEAVY_CLASSES;
+__host__ __device__ inline size_t heavy_stride( int n_tiles ) { return (size_t)n_tiles + HEAVY_SLOTS + HEAVY_CLASSES; }
 
 struct IcpLaunch
 {
@@ -103,9 +106,13 @@ struct IcpLaunch
   unsigned long long* dbg;   // diagnostic builds only: per-tile {cycles, candidates} of phase A (null otherwise)
   const float* w_explicit;   // if non-null: weights given per query (estimate-only entry point)
   // slowest-first start of phase A's tiles: every iteration lists its slow tiles for the next one (null: off)
-  //   per problem: [0] count | HEAVY_SLOTS tile ids | n_tiles x (position in the list + 1, or 0)
+  //   per problem (heavy_stride words): HEAVY_CLASSES counts | HEAVY_CLASSES x HEAVY_PER_CLASS tile ids | n_tiles x (1: a front slot has it; 2: handed to the cooperative kernel at once; 0)
   const int* heavy_in;
   int*    heavy_out;
+  int     heavy_streamed;   // a tile that streamed at least this many candidates is listed
+  int     heavy_longest;    // warm launch: a bounded tile whose longest row of 16 lanes faces this many candidates is handed off too (0: never)
+  int     heavy_total;      // ... or, swept tile-wide (boxes too tall for the per-row sweep), when the first 64 cell rows of its box hold this many (0: never)
+  int     heavy_handoff;    // ... and one that streamed this many in a warm launch goes to the cooperative kernel from the next iteration on (flag 2)
   // reference-order estimator (rs_kernels.hip: k_icp_faithful); faith == null: fp64 moments
   const int* by_orig;   // original source index -> query slot (null: identity)
   float*  faith;        // n_prob x FAITH_REC x nq: the correspondences in the source's own order

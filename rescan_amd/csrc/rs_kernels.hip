@@ -317,7 +317,7 @@ struct EvalScope
 // whose running number is congruent to it.
 template <bool WITH_NOR, class F>
 __device__ __forceinline__ uint32_t sweep_shell( const GridView& g, const CellBox& out, const CellBox& in, bool in_valid,
-                                                 WaveLds& L, int lane, int share, int n_share, F&& f )
+                                                 WaveLds& L, int lane, int share, int n_share, F&& f, uint32_t give_up_from = 0xffffffffu )
 {
   const int ny = out.y1 - out.y0 + 1, nz = out.z1 - out.z0 + 1;
   const int n_rows = ny * nz;
@@ -351,6 +351,9 @@ __device__ __forceinline__ uint32_t sweep_shell( const GridView& g, const CellBo
     }
     const uint32_t incl = wave_scan( la + lb, lane );
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane( (int)incl, WAVE - 1 );
+    // (give_up_from: the caller would rather not stream this much with one wave; decided on the first batch of cell rows, before
+    //  anything was evaluated — returns ~0)
+    if( r0 == 0 && total >= give_up_from ) return 0xffffffffu;
     L.seg_a[lane] = sa; L.len_a[lane] = la; L.seg_b[lane] = sb; L.pre[lane] = incl - ( la + lb );
     streamed += total;
     wave_lds_fence();
@@ -412,11 +415,12 @@ __device__ __forceinline__ uint32_t sweep_shell( const GridView& g, const CellBo
 // only: a third of the distance evaluations, which are what phase A's VALU time goes to.  The staged candidates of row r
 // occupy entries [16 r, 16 r + 16) of the wave's LDS arrays; the four rows' ds_read_b128 addresses differ, which the LDS
 // serves at the same rate (it processes 16 lanes of a b128 read at a time anyway).  Candidates that two rows both
-// reach are staged twice — a lane still meets each candidate once.  Returns false (nothing done) when a row's box has
-// more than 16 rows of cells: the caller then sweeps the tile's common box as before.
+// reach are staged twice — a lane still meets each candidate once.  Returns 0 (nothing done) when a row's box has
+// more than 16 rows of cells: the caller then sweeps the tile's common box as before; 2 (nothing done) when the longest row
+// holds give_up_from candidates or more; 1 when the sweep is done.
 template <bool WITH_NOR, class F>
-__device__ __forceinline__ bool sweep_by_rows( const GridView& g, const CellBox& clip, bool mask, float reach,
-                                               float qx, float qy, float qz, WaveLds& L, int lane, F&& f, uint32_t& streamed )
+__device__ __forceinline__ int sweep_by_rows( const GridView& g, const CellBox& clip, bool mask, float reach,
+                                              float qx, float qy, float qz, WaveLds& L, int lane, F&& f, uint32_t& streamed, uint32_t give_up_from = 0xffffffffu )
 {
   const float big = FLT_MAX;
   const float lx = row_min( mask ? qx - reach : big ), hx = row_max( mask ? qx + reach : -big );
@@ -430,7 +434,7 @@ __device__ __forceinline__ bool sweep_by_rows( const GridView& g, const CellBox&
   const bool empty = ( hx < lx ) | ( x1 < x0 ) | ( y1 < y0 ) | ( z1 < z0 );
   const int ny = y1 - y0 + 1;
   const int n_rows = empty ? 0 : ny * ( z1 - z0 + 1 );
-  if( __any( n_rows > 16 ) ) return false;
+  if( __any( n_rows > 16 ) ) return 0;
   const int l16 = lane & 15, base = lane & 48;
   uint32_t sa = 0, la = 0;
   if( l16 < n_rows )
@@ -450,6 +454,7 @@ __device__ __forceinline__ bool sweep_by_rows( const GridView& g, const CellBox&
   const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane( (int)total, 15 ), t1 = (uint32_t)__builtin_amdgcn_readlane( (int)total, 31 );
   const uint32_t t2 = (uint32_t)__builtin_amdgcn_readlane( (int)total, 47 ), t3 = (uint32_t)__builtin_amdgcn_readlane( (int)total, 63 );
   const uint32_t longest = max( max( t0, t1 ), max( t2, t3 ) );
+  if( longest >= give_up_from ) return 2;            // longest / 16 rounds of a lone wave: the caller has something better (nothing was evaluated)
   streamed += t0 + t1 + t2 + t3;
 
   auto fetch = [&]( uint32_t c0, float4& P, float4& N, uint32_t& src )
@@ -492,7 +497,7 @@ __device__ __forceinline__ bool sweep_by_rows( const GridView& g, const CellBox&
     c0 = cn;
   }
   if( g.evals && lane == 0 ) L.evals += ( t0 + t1 + t2 + t3 ) / 4;   // (each candidate is tested by 16 lanes, not 64)
-  return true;
+  return 1;
 }
 
 // Result of a search for one query.
@@ -712,7 +717,10 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
                                               WaveLds& L, int lane, int max_stages, bool* handoff, int* dbg_unsettled,
                                               Match m /* starting candidate: empty, or a genuine one (within radius, gate passed) that only tightens the bounds */,
                                               int* n_sweeps = nullptr /* out: shells swept + rank pass: the tile's cost class */,
-                                              bool by_rows = false /* WARM: sweep_by_rows for tiles whose lanes all start from a candidate */ )
+                                              bool by_rows = false /* WARM: sweep_by_rows for tiles whose lanes all start from a candidate */,
+                                              uint32_t* n_streamed = nullptr /* out: candidates streamed, rank pass included */,
+                                              int bounded_give_up = 0 /* BOUNDED_ONLY: hand a bounded tile off too when its longest row holds this many candidates (0: never) */,
+                                              int bounded_give_up_total = 0 /* ... or, swept tile-wide, when the first 64 cell rows of its box hold this many */ )
 {
   if( handoff ) *handoff = false;
   int sweeps = 0;
@@ -744,11 +752,24 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
     auto step = [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
     { consider4<GATED, WARM>( X, Y, Z, k4, L, qx, qy, qz, nx, ny, nz, tmin, bound, m, seen_closer ); };
     const float reach = reach_of( m, radius );
-    if( by_rows && sweep_by_rows<GATED>( g, full, active, reach, qx, qy, qz, L, lane, step, streamed ) ) cur = full;   // (cur only clips the rank pass's own box)
+    const int swept = by_rows ? sweep_by_rows<GATED>( g, full, active, reach, qx, qy, qz, L, lane, step, streamed,
+                                                      ( BOUNDED_ONLY && bounded_give_up > 0 ) ? (uint32_t)bounded_give_up : 0xffffffffu ) : 0;
+    if( BOUNDED_ONLY && swept == 2 )
+    {
+      // a long sweep for a lone wave (a row with hundreds of candidates: 45-60 us, the launch's tail): the cooperative kernel does
+      // it with a workgroup.  (Handing off the tiles whose boxes are too tall for the per-row sweep as well quintuples the queue.)
+      *handoff = true; return m;
+    }
+    if( swept == 1 ) cur = full;   // (cur only clips the rank pass's own box)
     else
     {
       cur = reach_box( g, full, active, reach, qx, qy, qz );
-      if( !box_empty( cur ) ) streamed += sweep_shell<GATED>( g, cur, cur, false, L, lane, 0, 1, step );
+      if( !box_empty( cur ) )
+      {
+        const uint32_t st = sweep_shell<GATED>( g, cur, cur, false, L, lane, 0, 1, step, ( BOUNDED_ONLY && bounded_give_up_total > 0 ) ? (uint32_t)bounded_give_up_total : 0xffffffffu );
+        if( BOUNDED_ONLY && st == 0xffffffffu ) { *handoff = true; return m; }     // (as above: hundreds of candidates past all 64 lanes)
+        streamed += st;
+      }
     }
     if( dbg_unsettled ) { dbg_unsettled[1] = (int)streamed; dbg_unsettled[3] = 1; }
     sweeps = 1;
@@ -815,9 +836,11 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
       if( dbg_unsettled ) dbg_unsettled[2] = (int)rs;
       if( need_rank && rank >= K ) { m.found = false; m.slot = -1; if( WARM ) m.rank_slack = rank_slack_of( rbands, K ); }
       ++sweeps;
+      streamed += rs;
     }
   }
   if( n_sweeps ) *n_sweeps = sweeps;
+  if( n_streamed ) *n_streamed = streamed;
   return m;
 }
 
@@ -1335,7 +1358,7 @@ __device__ __forceinline__ void icp_iteration_reset( const IcpLaunch& L, int pro
   {
     if( L.queued ) L.queued[prob] = L.queue_count[prob];       // tiles phase A handed off (diagnostics)
     L.queue_count[prob] = 0;                                   // ready for the next iteration's phase A
-    if( L.heavy_in ) const_cast<int*>( L.heavy_in )[(size_t)prob * ( L.src.n_tiles + HEAVY_SLOTS + 1 )] = 0;   // consumed: it is the next iteration's output buffer
+    if( L.heavy_in ) for( int c = 0; c < HEAVY_CLASSES; ++c ) const_cast<int*>( L.heavy_in )[(size_t)prob * heavy_stride( L.src.n_tiles ) + c] = 0;   // consumed: it is the next iteration's output buffer
   }
   if( L.stat_acc )
     for( int k = threadIdx.x; k < STAT_SHARDS * 4; k += blockDim.x ) L.stat_acc[(size_t)prob * STAT_SHARDS * 4 + k] = 0ull;
@@ -1388,14 +1411,32 @@ __global__ __launch_bounds__( BLOCK, BOUNDED_ONLY ? RS_ICP_WARM_OCC : RS_ICP_OCC
   };
   if( L.heavy_in )
   {
-    const int* hv = L.heavy_in + (size_t)prob * ( L.src.n_tiles + HEAVY_SLOTS + 1 );     // [0] count | list HEAVY_SLOTS | per-tile position+1 or 0
-    if( slot < HEAVY_SLOTS ) { if( slot >= min( uni( hv[0] ), HEAVY_SLOTS ) ) return; tile = uni( hv[1 + slot] ); }
+    const int* hv = L.heavy_in + (size_t)prob * heavy_stride( L.src.n_tiles );
+    if( slot < HEAVY_SLOTS )
+    {
+      // front block b serves XCD class b mod 8 (it runs on the XCD the class's natural blocks run on), entry (b / 8) * 4 + wave
+      const int c = (int)blockIdx.x & ( HEAVY_CLASSES - 1 ), p = ( (int)blockIdx.x >> 3 ) * WAVES_PER_BLOCK + wib;
+      if( p >= min( uni( hv[c] ), HEAVY_PER_CLASS ) ) return;
+      tile = uni( hv[HEAVY_CLASSES + c * HEAVY_PER_CLASS + p] );
+    }
     else
     {
       tile = natural_tile( (int)blockIdx.x - HEAVY_SLOTS / WAVES_PER_BLOCK );
       if( tile >= L.src.n_tiles ) return;
-      const int listed = uni( hv[1 + HEAVY_SLOTS + tile] );
-      if( listed > 0 && listed <= HEAVY_SLOTS ) return;       // a front slot has it
+      const int flag = uni( hv[HEAVY_CLASSES + HEAVY_SLOTS + tile] );
+      if( flag == 1 ) return;                                            // a front slot has it
+      if( BOUNDED_ONLY && flag == 2 )
+      {
+        // a tile whose one sweep was so long that a lone wave IS the launch's tail (600+ candidates: 45-60 us, against a launch
+        // that could end after ~45): a workgroup of the cooperative kernel takes it from now on, like an unbounded tile
+        if( lane == 0 )
+        {
+          int q = atomicAdd( L.queue_count + prob, 1 ); L.queue[(size_t)prob * L.src.n_tiles + q] = tile;
+          if( L.heavy_out ) L.heavy_out[(size_t)prob * heavy_stride( L.src.n_tiles ) + HEAVY_CLASSES + HEAVY_SLOTS + tile] = 2;
+          if( DBG( L ) ) { DBG( L )[2 * tile] = wall_clock64(); DBG( L )[2 * tile + 1] = 1ull << 20; }      // (handed off, no time spent)
+        }
+        return;
+      }
     }
   }
   else { tile = natural_tile( (int)blockIdx.x ); if( tile >= L.src.n_tiles ) return; }
@@ -1410,17 +1451,32 @@ __global__ __launch_bounds__( BLOCK, BOUNDED_ONLY ? RS_ICP_WARM_OCC : RS_ICP_OCC
   icp_query( L, T1, i, active, qx, qy, qz, nx, ny, nz );
   bool handoff;
   int sweeps = 0;
+  uint32_t streamed = 0;
   int unsettled[4] = { 0, 0, 0, 0 };
   const Match init = icp_warm_start( L, prob, i, active, qx, qy, qz, nx, ny, nz );
   const bool search = active & !icp_certificate( L, prob, i, active & !init.found, qx, qy, qz, nx, ny, nz );
   Match m = tile_search<true, true, BOUNDED_ONLY>( L.tgt, search, qx, qy, qz, nx, ny, nz, L.radius, L.radius_sq, L.gate_tmin, L.K,
-                               lds[wib], lane, L.solo_stages, &handoff, DBG( L ) ? unsettled : nullptr, init, &sweeps, L.by_rows != 0 );
+                               lds[wib], lane, L.solo_stages, &handoff, DBG( L ) ? unsettled : nullptr, init, &sweeps, L.by_rows != 0, &streamed, L.heavy_longest, L.heavy_total );
   if( L.heavy_out && lane == 0 )
   {
-    int* hv = L.heavy_out + (size_t)prob * ( L.src.n_tiles + HEAVY_SLOTS + 1 );
+    int* hv = L.heavy_out + (size_t)prob * heavy_stride( L.src.n_tiles );
     int listed = 0;
-    if( handoff || sweeps >= 2 ) { const int pos = atomicAdd( hv, 1 ); listed = pos + 1; if( pos < HEAVY_SLOTS ) hv[1 + pos] = tile; }
-    hv[1 + HEAVY_SLOTS + tile] = listed;
+    // What will be slow next time.  A warm launch hands its unbounded tiles off at once — they cost it nothing — and its slow
+    // tiles are the ones that stream many candidates in their one sweep (p50 150 candidates / 12 us, p99.9 750 / 40 us: left in
+    // natural order those start half way through the launch and ARE its tail); the cold launch's are its multi-shell tiles.
+    const bool slow = BOUNDED_ONLY ? ( !handoff && streamed >= (uint32_t)L.heavy_streamed ) : ( handoff || sweeps >= 2 || streamed >= (uint32_t)L.heavy_streamed );
+    if( BOUNDED_ONLY && !handoff && streamed >= (uint32_t)L.heavy_handoff ) listed = 2;
+    else if( slow )
+    {
+#if RS_XCD_MAP
+      const int c = min( ( tile / WAVES_PER_BLOCK ) / icp_blocks_per_xcd( L.src.n_tiles ), HEAVY_CLASSES - 1 );      // the class whose natural range holds the tile
+#else
+      const int c = ( tile / WAVES_PER_BLOCK ) & ( HEAVY_CLASSES - 1 );
+#endif
+      const int pos = atomicAdd( hv + c, 1 );
+      if( pos < HEAVY_PER_CLASS ) { hv[HEAVY_CLASSES + c * HEAVY_PER_CLASS + pos] = tile; listed = 1; }
+    }
+    hv[HEAVY_CLASSES + HEAVY_SLOTS + tile] = listed;
   }
   if( DBG( L ) && lane == 0 )
   {

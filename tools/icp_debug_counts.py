@@ -1,6 +1,6 @@
 """Per-iteration queue / match / certificate counts of the bench's ICP problem (RS_HIP_DEBUG=1 set here)."""
 import os, sys
-os.environ["RS_HIP_DEBUG"] = "1"
+os.environ.setdefault("RS_HIP_DEBUG", "1")
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
