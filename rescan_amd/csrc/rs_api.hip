@@ -674,7 +674,7 @@ int icp_prepare( IcpCtx& cx, const rs_hip_cloud_t* src, const rs_hip_cloud_t* tg
   static const int heavy_handoff = getenv( "RS_HIP_HEAVY_HANDOFF" ) ? atoi( getenv( "RS_HIP_HEAVY_HANDOFF" ) ) : 600;
   static const int heavy_longest = getenv( "RS_HIP_HEAVY_LONGEST" ) ? atoi( getenv( "RS_HIP_HEAVY_LONGEST" ) ) : 0;
   L.heavy_streamed = heavy_streamed; L.heavy_handoff = heavy_handoff; L.heavy_longest = heavy_longest;
-  static const int heavy_total = getenv( "RS_HIP_HEAVY_TOTAL" ) ? atoi( getenv( "RS_HIP_HEAVY_TOTAL" ) ) : 0;
+  static const int heavy_total = getenv( "RS_HIP_HEAVY_TOTAL" ) ? atoi( getenv( "RS_HIP_HEAVY_TOTAL" ) ) : 400;
   L.heavy_total = heavy_total;
   float* w = g_ws.state.as<float>();
   L.T1 = w; L.active = (int*)( w + np * 16 ); L.T1_prev = w + np * 17;
