@@ -672,8 +672,7 @@ int icp_prepare( IcpCtx& cx, const rs_hip_cloud_t* src, const rs_hip_cloud_t* tg
   L.solo_stages = handoff_threshold( (long long)cx.n_waves * n_prob );
   static const int heavy_streamed = getenv( "RS_HIP_HEAVY_STREAMED" ) ? atoi( getenv( "RS_HIP_HEAVY_STREAMED" ) ) : 400;
   static const int heavy_handoff = getenv( "RS_HIP_HEAVY_HANDOFF" ) ? atoi( getenv( "RS_HIP_HEAVY_HANDOFF" ) ) : 600;
-  static const int heavy_longest = getenv( "RS_HIP_HEAVY_LONGEST" ) ? atoi( getenv( "RS_HIP_HEAVY_LONGEST" ) ) : 0;
-  L.heavy_streamed = heavy_streamed; L.heavy_handoff = heavy_handoff; L.heavy_longest = heavy_longest;
+  L.heavy_streamed = heavy_streamed; L.heavy_handoff = heavy_handoff;
   static const int heavy_total = getenv( "RS_HIP_HEAVY_TOTAL" ) ? atoi( getenv( "RS_HIP_HEAVY_TOTAL" ) ) : 400;
   L.heavy_total = heavy_total;
   float* w = g_ws.state.as<float>();

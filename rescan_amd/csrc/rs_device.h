@@ -110,8 +110,7 @@ struct IcpLaunch
   const int* heavy_in;
   int*    heavy_out;
   int     heavy_streamed;   // a tile that streamed at least this many candidates is listed
-  int     heavy_longest;    // warm launch: a bounded tile whose longest row of 16 lanes faces this many candidates is handed off too (0: never)
-  int     heavy_total;      // ... or, swept tile-wide (boxes too tall for the per-row sweep), when the first 64 cell rows of its box hold this many (0: never)
+  int     heavy_total;      // warm launch: a bounded tile swept tile-wide (boxes too tall for the per-row sweep) is handed off too when the first 64 cell rows of its box hold this many candidates (0: never)
   int     heavy_handoff;    // ... and one that streamed this many in a warm launch goes to the cooperative kernel from the next iteration on (flag 2)
   // reference-order estimator (rs_kernels.hip: k_icp_faithful); faith == null: fp64 moments
   const int* by_orig;   // original source index -> query slot (null: identity)

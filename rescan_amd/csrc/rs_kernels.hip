@@ -416,11 +416,10 @@ __device__ __forceinline__ uint32_t sweep_shell( const GridView& g, const CellBo
 // occupy entries [16 r, 16 r + 16) of the wave's LDS arrays; the four rows' ds_read_b128 addresses differ, which the LDS
 // serves at the same rate (it processes 16 lanes of a b128 read at a time anyway).  Candidates that two rows both
 // reach are staged twice — a lane still meets each candidate once.  Returns 0 (nothing done) when a row's box has
-// more than 16 rows of cells: the caller then sweeps the tile's common box as before; 2 (nothing done) when the longest row
-// holds give_up_from candidates or more; 1 when the sweep is done.
+// more than 16 rows of cells: the caller then sweeps the tile's common box as before; 1 when the sweep is done.
 template <bool WITH_NOR, class F>
 __device__ __forceinline__ int sweep_by_rows( const GridView& g, const CellBox& clip, bool mask, float reach,
-                                              float qx, float qy, float qz, WaveLds& L, int lane, F&& f, uint32_t& streamed, uint32_t give_up_from = 0xffffffffu )
+                                              float qx, float qy, float qz, WaveLds& L, int lane, F&& f, uint32_t& streamed )
 {
   const float big = FLT_MAX;
   const float lx = row_min( mask ? qx - reach : big ), hx = row_max( mask ? qx + reach : -big );
@@ -454,7 +453,6 @@ __device__ __forceinline__ int sweep_by_rows( const GridView& g, const CellBox& 
   const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane( (int)total, 15 ), t1 = (uint32_t)__builtin_amdgcn_readlane( (int)total, 31 );
   const uint32_t t2 = (uint32_t)__builtin_amdgcn_readlane( (int)total, 47 ), t3 = (uint32_t)__builtin_amdgcn_readlane( (int)total, 63 );
   const uint32_t longest = max( max( t0, t1 ), max( t2, t3 ) );
-  if( longest >= give_up_from ) return 2;            // longest / 16 rounds of a lone wave: the caller has something better (nothing was evaluated)
   streamed += t0 + t1 + t2 + t3;
 
   auto fetch = [&]( uint32_t c0, float4& P, float4& N, uint32_t& src )
@@ -719,8 +717,7 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
                                               int* n_sweeps = nullptr /* out: shells swept + rank pass: the tile's cost class */,
                                               bool by_rows = false /* WARM: sweep_by_rows for tiles whose lanes all start from a candidate */,
                                               uint32_t* n_streamed = nullptr /* out: candidates streamed, rank pass included */,
-                                              int bounded_give_up = 0 /* BOUNDED_ONLY: hand a bounded tile off too when its longest row holds this many candidates (0: never) */,
-                                              int bounded_give_up_total = 0 /* ... or, swept tile-wide, when the first 64 cell rows of its box hold this many */ )
+                                              int bounded_give_up_total = 0 /* BOUNDED_ONLY: hand a bounded tile off too when, swept tile-wide, the first 64 cell rows of its box hold this many candidates (0: never) */ )
 {
   if( handoff ) *handoff = false;
   int sweeps = 0;
@@ -752,14 +749,8 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
     auto step = [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
     { consider4<GATED, WARM>( X, Y, Z, k4, L, qx, qy, qz, nx, ny, nz, tmin, bound, m, seen_closer ); };
     const float reach = reach_of( m, radius );
-    const int swept = by_rows ? sweep_by_rows<GATED>( g, full, active, reach, qx, qy, qz, L, lane, step, streamed,
-                                                      ( BOUNDED_ONLY && bounded_give_up > 0 ) ? (uint32_t)bounded_give_up : 0xffffffffu ) : 0;
-    if( BOUNDED_ONLY && swept == 2 )
-    {
-      // a long sweep for a lone wave (a row with hundreds of candidates: 45-60 us, the launch's tail): the cooperative kernel does
-      // it with a workgroup.  (Handing off the tiles whose boxes are too tall for the per-row sweep as well quintuples the queue.)
-      *handoff = true; return m;
-    }
+    // (Handing off per-row sweeps with a long row as well — 160 to 320 candidates for one row of 16 lanes — changed nothing.)
+    const int swept = by_rows ? sweep_by_rows<GATED>( g, full, active, reach, qx, qy, qz, L, lane, step, streamed ) : 0;
     if( swept == 1 ) cur = full;   // (cur only clips the rank pass's own box)
     else
     {
@@ -767,7 +758,8 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
       if( !box_empty( cur ) )
       {
         const uint32_t st = sweep_shell<GATED>( g, cur, cur, false, L, lane, 0, 1, step, ( BOUNDED_ONLY && bounded_give_up_total > 0 ) ? (uint32_t)bounded_give_up_total : 0xffffffffu );
-        if( BOUNDED_ONLY && st == 0xffffffffu ) { *handoff = true; return m; }     // (as above: hundreds of candidates past all 64 lanes)
+        // hundreds of candidates past all 64 lanes of a lone wave (35-60 us: the launch's tail): the cooperative kernel does it with a workgroup
+        if( BOUNDED_ONLY && st == 0xffffffffu ) { *handoff = true; return m; }
         streamed += st;
       }
     }
@@ -1368,7 +1360,15 @@ __device__ __forceinline__ void icp_iteration_reset( const IcpLaunch& L, int pro
 #define RS_XCD_MAP 1
 #endif
 // workgroups of phase A's natural part per XCD class (see k_icp_corr)
-__host__ __device__ inline int icp_blocks_per_xcd( int n_tiles ) { return ( ( n_tiles + WAVES_PER_BLOCK - 1 ) / WAVES_PER_BLOCK + 7 ) / 8; }
+// Waves per workgroup of phase A (k_icp_corr).  A workgroup's wave slots and LDS are released when its LAST wave ends, and a
+// warm tile takes its wave 12 us at the median, 17 at the 90th percentile: with four tiles per workgroup a quarter of the slot time
+// was spent waiting for the slowest of four (4 400 of 6 144 slots occupied in the launch's steady state, 5 000-5 200 with one; the
+// concurrent chain's searches 2.22 -> 2.08 ms per step, serial 1.68 -> 1.65: profiles/r02/ab_*experiments.txt).
+#ifndef RS_PA_WAVES
+#define RS_PA_WAVES 1
+#endif
+constexpr int PA_WAVES = RS_PA_WAVES;
+__host__ __device__ inline int icp_blocks_per_xcd( int n_tiles ) { return ( ( n_tiles + PA_WAVES - 1 ) / PA_WAVES + 7 ) / 8; }
 
 // Phase A: one wave per tile, first shell(s) only; unsettled tiles are queued.
 // Waves per SIMD the register allocation aims at.  6 = 80 VGPRs: the warm instantiation (no shell loop) then keeps 16 B of
@@ -1382,9 +1382,9 @@ __host__ __device__ inline int icp_blocks_per_xcd( int n_tiles ) { return ( ( n_
 #define RS_ICP_OCC 6
 #endif
 template <bool BOUNDED_ONLY>
-__global__ __launch_bounds__( BLOCK, BOUNDED_ONLY ? RS_ICP_WARM_OCC : RS_ICP_OCC ) void k_icp_corr( IcpLaunch L )
+__global__ __launch_bounds__( PA_WAVES * WAVE, BOUNDED_ONLY ? RS_ICP_WARM_OCC : RS_ICP_OCC ) void k_icp_corr( IcpLaunch L )
 {
-  __shared__ WaveLds lds[WAVES_PER_BLOCK];
+  __shared__ WaveLds lds[PA_WAVES];
   const int prob = blockIdx.y;
   if( L.active[prob] == 0 ) return;
   const int lane = threadIdx.x & ( WAVE - 1 );
@@ -1394,7 +1394,7 @@ __global__ __launch_bounds__( BLOCK, BOUNDED_ONLY ? RS_ICP_WARM_OCC : RS_ICP_OCC
   // pass) are the same from one iteration to the next.  The previous iteration listed them; the first
   // HEAVY_SLOTS wave slots of the grid take that list, the rest walk the tiles in their natural (Hilbert)
   // order — which the caches depend on — and skip the listed ones.
-  int slot = blockIdx.x * WAVES_PER_BLOCK + wib;
+  int slot = blockIdx.x * PA_WAVES + wib;
   int tile;
   // XCD-aware order of the natural (Hilbert) part: workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8
   // share one), each XCD with its own 4 MB L2.  Walking the tiles in plain order would have every XCD touch every part of
@@ -1404,9 +1404,9 @@ __global__ __launch_bounds__( BLOCK, BOUNDED_ONLY ? RS_ICP_WARM_OCC : RS_ICP_OCC
   {
 #if RS_XCD_MAP
     const int per = icp_blocks_per_xcd( L.src.n_tiles );
-    return ( ( block & 7 ) * per + ( block >> 3 ) ) * WAVES_PER_BLOCK + wib;
+    return ( ( block & 7 ) * per + ( block >> 3 ) ) * PA_WAVES + wib;
 #else
-    return block * WAVES_PER_BLOCK + wib;
+    return block * PA_WAVES + wib;
 #endif
   };
   if( L.heavy_in )
@@ -1415,13 +1415,13 @@ __global__ __launch_bounds__( BLOCK, BOUNDED_ONLY ? RS_ICP_WARM_OCC : RS_ICP_OCC
     if( slot < HEAVY_SLOTS )
     {
       // front block b serves XCD class b mod 8 (it runs on the XCD the class's natural blocks run on), entry (b / 8) * 4 + wave
-      const int c = (int)blockIdx.x & ( HEAVY_CLASSES - 1 ), p = ( (int)blockIdx.x >> 3 ) * WAVES_PER_BLOCK + wib;
+      const int c = (int)blockIdx.x & ( HEAVY_CLASSES - 1 ), p = ( (int)blockIdx.x >> 3 ) * PA_WAVES + wib;
       if( p >= min( uni( hv[c] ), HEAVY_PER_CLASS ) ) return;
       tile = uni( hv[HEAVY_CLASSES + c * HEAVY_PER_CLASS + p] );
     }
     else
     {
-      tile = natural_tile( (int)blockIdx.x - HEAVY_SLOTS / WAVES_PER_BLOCK );
+      tile = natural_tile( (int)blockIdx.x - HEAVY_SLOTS / PA_WAVES );
       if( tile >= L.src.n_tiles ) return;
       const int flag = uni( hv[HEAVY_CLASSES + HEAVY_SLOTS + tile] );
       if( flag == 1 ) return;                                            // a front slot has it
@@ -1456,7 +1456,7 @@ __global__ __launch_bounds__( BLOCK, BOUNDED_ONLY ? RS_ICP_WARM_OCC : RS_ICP_OCC
   const Match init = icp_warm_start( L, prob, i, active, qx, qy, qz, nx, ny, nz );
   const bool search = active & !icp_certificate( L, prob, i, active & !init.found, qx, qy, qz, nx, ny, nz );
   Match m = tile_search<true, true, BOUNDED_ONLY>( L.tgt, search, qx, qy, qz, nx, ny, nz, L.radius, L.radius_sq, L.gate_tmin, L.K,
-                               lds[wib], lane, L.solo_stages, &handoff, DBG( L ) ? unsettled : nullptr, init, &sweeps, L.by_rows != 0, &streamed, L.heavy_longest, L.heavy_total );
+                               lds[wib], lane, L.solo_stages, &handoff, DBG( L ) ? unsettled : nullptr, init, &sweeps, L.by_rows != 0, &streamed, L.heavy_total );
   if( L.heavy_out && lane == 0 )
   {
     int* hv = L.heavy_out + (size_t)prob * heavy_stride( L.src.n_tiles );
@@ -1469,9 +1469,9 @@ __global__ __launch_bounds__( BLOCK, BOUNDED_ONLY ? RS_ICP_WARM_OCC : RS_ICP_OCC
     else if( slow )
     {
 #if RS_XCD_MAP
-      const int c = min( ( tile / WAVES_PER_BLOCK ) / icp_blocks_per_xcd( L.src.n_tiles ), HEAVY_CLASSES - 1 );      // the class whose natural range holds the tile
+      const int c = min( ( tile / PA_WAVES ) / icp_blocks_per_xcd( L.src.n_tiles ), HEAVY_CLASSES - 1 );      // the class whose natural range holds the tile
 #else
-      const int c = ( tile / WAVES_PER_BLOCK ) & ( HEAVY_CLASSES - 1 );
+      const int c = ( tile / PA_WAVES ) & ( HEAVY_CLASSES - 1 );
 #endif
       const int pos = atomicAdd( hv + c, 1 );
       if( pos < HEAVY_PER_CLASS ) { hv[HEAVY_CLASSES + c * HEAVY_PER_CLASS + pos] = tile; listed = 1; }
@@ -2462,12 +2462,12 @@ void launch_icp_corr( const IcpLaunch& L, hipStream_t st )
   // queue_count is zero on entry: cleared once by the host, then by the workgroup that ends every iteration (icp_iteration_reset)
   // A launch of a few hundred tiles leaves every wave alone on its SIMD, i.e. latency-bound, and phase A's slowest tile
   // sets its time: such launches skip phase A and give every tile a workgroup straight away (coop_all).
-  static_assert( HEAVY_SLOTS % ( 8 * WAVES_PER_BLOCK ) == 0, "the front slots must not shift the XCD class of the natural part" );
-  dim3 grid( ( L.heavy_in ? HEAVY_SLOTS / WAVES_PER_BLOCK : 0 ) + 8 * icp_blocks_per_xcd( L.src.n_tiles ), L.n_prob );
+  static_assert( HEAVY_SLOTS % ( 8 * PA_WAVES ) == 0, "the front slots must not shift the XCD class of the natural part" );
+  dim3 grid( ( L.heavy_in ? HEAVY_SLOTS / PA_WAVES : 0 ) + 8 * icp_blocks_per_xcd( L.src.n_tiles ), L.n_prob );
   if( !L.coop_all )
   {
-    if( L.warm && L.bounded_only ) hipLaunchKernelGGL( k_icp_corr<true>, grid, dim3( BLOCK ), 0, st, L );
-    else                           hipLaunchKernelGGL( k_icp_corr<false>, grid, dim3( BLOCK ), 0, st, L );
+    if( L.warm && L.bounded_only ) hipLaunchKernelGGL( k_icp_corr<true>, grid, dim3( PA_WAVES * WAVE ), 0, st, L );
+    else                           hipLaunchKernelGGL( k_icp_corr<false>, grid, dim3( PA_WAVES * WAVE ), 0, st, L );
   }
   // the queue length is only known on the device: a fixed grid strides over it
   int coop_blocks = L.src.n_tiles < 2048 ? L.src.n_tiles : 2048;
