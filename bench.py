@@ -116,11 +116,116 @@ def _pool():
 
 
 _ROLE_POOLS = None
+_ROLE_TIMES = [] if os.environ.get("RS_BENCH_PRINT_STEPS") else None      # per step: host-side ms of the three consumers' calls
 
 
-def _role_pools():
-    """One single-thread executor per consumer (ICP chain, score batch, label pass): a consumer always runs on the same host
-    thread, i.e. on the same HIP stream — and the streams are confined to disjoint sets of CUs (rs_hip_stream_cu_mask).  A bit
+class RoleRunner:
+    """Runs the three consumers of a step side by side, each always on the same host thread (i.e. on the same HIP stream and CU
+    set), and joins them.
+
+    spin (default): the score batch — the longest of the three — runs on the CALLING thread, the ICP chain and the label pass on
+    two worker threads that never sleep: between steps they busy-wait inside the library (rs_hip_spin_wait, no interpreter
+    lock held) for a flag the caller's next library call stores on entry (rs_hip_post_on_next_call), and the caller busy-waits
+    for theirs.  With executors every step is three submissions and three future waits, i.e. six wake-ups of sleeping
+    threads by the host scheduler — usually tens of microseconds each, but on the shared 256-thread hosts of this pool one
+    step in ~35 lost 1.5-3 ms there while all three library calls took their usual time (tools/throttle_check.sh: no cgroup
+    throttling in the region; the time is between the calls).  RS_BENCH_SPIN=0: three single-thread executors as before."""
+
+    ICP, SCORE, LABEL = 0, 1, 2
+
+    def __init__(self, masks, spin):
+        import threading
+        from concurrent.futures import ThreadPoolExecutor
+        from rescan_amd import capi
+        self.capi, self.spin, self.k, self.stop = capi, spin, 0, False
+        self.fns, self.out, self.dt = [None] * 3, [None] * 3, [0.0] * 3
+        if not spin:
+            self.pools = [ThreadPoolExecutor(max_workers=1) for _ in range(3)]
+            if masks:
+                for ex, m in zip(self.pools, masks):
+                    ex.submit(capi.stream_cu_mask, m).result()
+            return
+        self.flags = np.zeros(16, np.int32)           # [0..2] go, [4..6] done, [8..10] ready
+        self.addr = lambda kind, r: self.flags.ctypes.data + 4 * (4 * kind + r)
+        self.failed = None
+        if masks:
+            capi.stream_cu_mask(masks[self.SCORE])    # the calling thread's stream takes the score batch
+        self.threads = [threading.Thread(target=self._worker, args=(r, masks[r] if masks else None), daemon=True) for r in (self.ICP, self.LABEL)]
+        for t in self.threads:
+            t.start()
+        for r in (self.ICP, self.LABEL):
+            capi.spin_wait(self.addr(2, r), 1, 60.0)
+        if self.failed is not None:
+            raise self.failed
+
+    def _worker(self, r, mask):
+        capi = self.capi
+        try:
+            if mask:
+                capi.stream_cu_mask(mask)
+        except Exception as e:               # a runtime without CU masks
+            self.failed = e
+        capi.spin_post(self.addr(2, r), 1)
+        k = 0
+        while True:
+            k += 1
+            capi.spin_wait(self.addr(0, r), k, 0.0)
+            if self.stop:
+                return
+            if r == self.ICP:
+                capi.post_on_next_call(self.addr(0, self.LABEL), k)       # the label thread goes once this one is inside the library
+            t = time.perf_counter()
+            try:
+                out = self.fns[r]()
+            except BaseException as e:        # handed to the caller
+                out = e
+            capi.post_pending()
+            self.out[r], self.dt[r] = out, time.perf_counter() - t
+            capi.spin_post(self.addr(1, r), k)
+
+    def run3(self, icp, score, label):
+        """-> (icp(), score(), label()), run concurrently."""
+        fns = (icp, score, label)
+        if not self.spin:
+            def timed(r):
+                def run():
+                    t = time.perf_counter(); o = fns[r](); self.dt[r] = time.perf_counter() - t
+                    return o
+                return run
+            f = [ex.submit(timed(r)) for r, ex in enumerate(self.pools)]
+            outs = [x.result() for x in f]
+        else:
+            capi = self.capi
+            self.k += 1
+            self.fns = fns
+            capi.post_on_next_call(self.addr(0, self.ICP), self.k)          # the ICP thread goes once this one is inside the library
+            t = time.perf_counter()
+            try:
+                mine = score()
+            finally:
+                capi.post_pending()
+            self.dt[self.SCORE] = time.perf_counter() - t
+            capi.spin_wait(self.addr(1, self.ICP), self.k, 120.0)
+            capi.spin_wait(self.addr(1, self.LABEL), self.k, 120.0)
+            outs = [self.out[self.ICP], mine, self.out[self.LABEL]]
+            for o in outs:
+                if isinstance(o, BaseException):
+                    raise o
+        if _ROLE_TIMES is not None:
+            _ROLE_TIMES.append([x * 1e3 for x in self.dt])
+        return outs
+
+    def close(self):
+        """Parks the spinning workers (they would otherwise keep two cores busy)."""
+        if self.spin and not self.stop:
+            self.stop = True
+            for r in (self.ICP, self.LABEL):
+                self.capi.spin_post(self.addr(0, r), 1 << 30)
+
+
+def _roles():
+    """The RoleRunner of this process.  A consumer (ICP chain, score batch, label pass) always runs on the same host thread,
+    i.e. on the same HIP stream — and the streams are confined to disjoint sets of CUs (rs_hip_stream_cu_mask).  A bit
     of the mask is not "a CU of the chip in order": bit i is CU slot i / 8 of XCD i % 8 and slot j is a CU of shader engine
     j % 4 (tools/cu_mask_probe.py, profiles/r02/cu_mask_probe.txt), so bits [0,160) | [160,256) give the ICP chain 5 CUs of every
     shader engine of every XCD and the score batch the other 3; the shader engines hand out workgroups evenly, so splits that
@@ -131,30 +236,30 @@ def _role_pools():
     RS_BENCH_CU_SPLIT=<fraction of the mask bits for the chain> overrides (0 = no partition); RS_BENCH_LABEL_ON=chain|batch|all."""
     global _ROLE_POOLS
     if _ROLE_POOLS is None:
-        from concurrent.futures import ThreadPoolExecutor
         from rescan_amd import capi
         import torch
-        _ROLE_POOLS = [ThreadPoolExecutor(max_workers=1) for _ in range(3)]
         n_cu = int(torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count)
         split = float(os.environ.get("RS_BENCH_CU_SPLIT", "0.625" if n_cu == 256 else "0"))
+        spin = os.environ.get("RS_BENCH_SPIN", "1") != "0"
+        masks, note = None, "none"
         if split > 0.0:
             k = int(round(split * n_cu))
             lo = int(round(float(os.environ.get("RS_BENCH_CU_BATCH_LO", split)) * n_cu))     # experiment: overlapping partitions
             label_on = os.environ.get("RS_BENCH_LABEL_ON", "chain")
             chain, batch = [1] * k + [0] * (n_cu - k), [0] * lo + [1] * (n_cu - lo)
             masks = [chain, batch, {"chain": chain, "batch": batch, "all": [1] * n_cu}[label_on]]
-            try:
-                for ex, m in zip(_ROLE_POOLS, masks):
-                    ex.submit(capi.stream_cu_mask, m).result()
-                f_chain, f_batch = k / n_cu, (n_cu - lo) / n_cu
-                f_label = {"chain": f_chain, "batch": f_batch, "all": 1.0}[label_on]
+            f_chain, f_batch = k / n_cu, (n_cu - lo) / n_cu
+            f_label = {"chain": f_chain, "batch": f_batch, "all": 1.0}[label_on]
+            note = "CU mask bits [0,%d) (%d CUs of every shader engine of every XCD) ICP chain%s, [%d,%d) score batch%s" % (
+                k, k // 32, " + label pass" if label_on == "chain" else "", lo, n_cu, " + label pass" if label_on == "batch" else "")
+        try:
+            runner = RoleRunner(masks, spin)
+            if masks:
                 _CU_SHARES.update({"nn_icp": f_chain, "icp_moments": f_chain, "nn_score": f_batch, "nn_label": f_label})
-                _ROLE_POOLS.append("CU mask bits [0,%d) (%d CUs of every shader engine of every XCD) ICP chain%s, [%d,%d) score batch%s" % (k, k // 32, " + label pass" if label_on == "chain" else "", lo, n_cu, " + label pass" if label_on == "batch" else ""))
-            except Exception as e:       # a runtime without CU masks: the streams stay as they are
-                _ROLE_POOLS.append("none (%s)" % e)
-        else:
-            _ROLE_POOLS.append("none")
-    return _ROLE_POOLS[:3]
+        except Exception as e:               # a runtime without CU masks: plain streams
+            runner, note = RoleRunner(None, spin), "none (%s)" % e
+        _ROLE_POOLS = [runner, note + ("; consumers joined by spinning (score batch on the calling thread)" if spin else "; consumers on three executors")]
+    return _ROLE_POOLS[0]
 
 
 def host_cpu_stat():
@@ -170,7 +275,7 @@ def host_cpu_stat():
 
 
 def cu_partition_note():
-    return _ROLE_POOLS[3] if _ROLE_POOLS else "none"
+    return _ROLE_POOLS[1] if _ROLE_POOLS else "none"
 
 
 _CU_SHARES = {}
@@ -201,8 +306,7 @@ def run_step(w, dist_ctx=None, concurrent=True):
                                           [0] * len(w["plc"]), [p["cls"] for p in w["plc"]], 0.05, False)
 
     if concurrent:
-        f = [ex.submit(fn) for ex, fn in zip(_role_pools(), (icp, score, label))]
-        (err, T, it), scores, res = f[0].result(), f[1].result(), f[2].result()
+        (err, T, it), scores, res = _roles().run3(icp, score, label)
     else:
         (err, T, it), scores, res = icp(), score(), label()
     if dist_ctx is not None:
@@ -335,7 +439,7 @@ class Sharded:
         b = self.bufs[self.step_index & 1]
         self.step_index += 1
         t0 = time.perf_counter()
-        rd.shard_compute(capi, self.lay, self.rank, self.units, b[0], b[2], threads=_role_pools() if concurrent else None)
+        rd.shard_compute(capi, self.lay, self.rank, self.units, b[0], b[2], threads=_roles() if concurrent else None)
         t1 = time.perf_counter()
         prev = exchange_wait()                          # at most one exchange in flight, so the other buffer set is free again
         _XCH["pending"] = _exchange_pool().submit(self.exchange, b)
@@ -537,8 +641,15 @@ def main():
     gc.enable()
     step_ms = np.diff(np.array([t0] + marks)) * 1e3
     if os.environ.get("RS_BENCH_PRINT_STEPS") and rank == 0:
-        print("slow steps (index, ms):", [(int(k), round(float(v), 2)) for k, v in enumerate(step_ms) if v > 1.3 * np.median(step_ms)], file=sys.stderr)
+        slow = [int(k) for k, v in enumerate(step_ms) if v > 1.3 * np.median(step_ms)]
+        print("slow steps (index, ms):", [(k, round(float(step_ms[k]), 2)) for k in slow], file=sys.stderr)
+        if _ROLE_TIMES:
+            rt = np.array(_ROLE_TIMES[-len(step_ms):])
+            print("  consumers' calls, ms (icp, score, label): median", np.round(np.median(rt, axis=0), 2).tolist(),
+                  "| slow steps:", [(k, np.round(rt[k], 2).tolist()) for k in slow if k < len(rt)], file=sys.stderr)
     capi.profile_enable(False)
+    if _ROLE_POOLS:
+        _ROLE_POOLS[0].close()
 
     pairs_unit = sum(w["pairs"].values())
     pairs_total = float(pairs_unit * args.steps * (world if not sharded else units))

@@ -25,6 +25,10 @@ SIGNATURES = {
     "rs_hip_synchronize": (C.c_int, []),
     "rs_hip_stream_cu_mask": (C.c_int, [np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS"), C.c_int32]),
     "rs_hip_probe_placement": (C.c_int, [np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS"), C.c_int32]),
+    "rs_hip_spin_post": (C.c_int, [C.c_void_p, C.c_int32]),
+    "rs_hip_spin_wait": (C.c_int, [C.c_void_p, C.c_int32, C.c_double]),
+    "rs_hip_post_on_next_call": (C.c_int, [C.c_void_p, C.c_int32]),
+    "rs_hip_post_pending": (C.c_int, []),
     "rs_hip_version": (C.c_char_p, []),
     "rs_hip_profile_enable": (C.c_int, [C.c_int]),
     "rs_hip_profile_reset": (C.c_int, []),
@@ -126,6 +130,25 @@ def stream_cu_mask(bits):
         if v:
             words[k // 32] |= np.uint32(1 << (k % 32))
     _check(load().rs_hip_stream_cu_mask(words, len(words)))
+
+
+def spin_post(flag_addr, value):
+    """*flag = value (flag_addr: address of an aligned int32, e.g. a numpy int32 array's .ctypes.data + 4 * k)."""
+    _check(load().rs_hip_spin_post(flag_addr, int(value)))
+
+
+def spin_wait(flag_addr, at_least, timeout_s=60.0):
+    """Busy-waits (outside the interpreter lock) until *flag >= at_least."""
+    _check(load().rs_hip_spin_wait(flag_addr, int(at_least), float(timeout_s)))
+
+
+def post_on_next_call(flag_addr, value):
+    """*flag = value at the calling thread's next entry into the library (i.e. once the interpreter lock has been released)."""
+    _check(load().rs_hip_post_on_next_call(flag_addr, int(value)))
+
+
+def post_pending():
+    _check(load().rs_hip_post_pending())
 
 
 def probe_placement(n_blocks=4096):

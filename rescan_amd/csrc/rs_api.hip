@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <string>
@@ -52,8 +53,17 @@ void set_err( const char* fmt, ... )
        if( e_ != hipSuccess ) { set_err( "%s failed: %s (%s:%d)", #expr, hipGetErrorString( e_ ), __FILE__, __LINE__ ); \
                                 return code_on_fail; } } while( 0 )
 
+// rs_hip_post_on_next_call: a flag this thread stores at its next entry into the library (see include/rescan_hip.h)
+thread_local volatile int32_t* g_post_flag = nullptr;
+thread_local int32_t g_post_value = 0;
+static inline void post_pending()
+{
+  if( g_post_flag ) { __atomic_store_n( (int32_t*)g_post_flag, g_post_value, __ATOMIC_RELEASE ); g_post_flag = nullptr; }
+}
+
 int ensure_ready()
 {
+  post_pending();
   if( !g_ready ) { int rc = rs_hip_init( g_device >= 0 ? g_device : 0 ); if( rc ) return rc; }
   if( !g_own_stream )       // first call from this host thread
   {
@@ -321,6 +331,35 @@ int rs_hip_probe_placement( uint32_t* out_host, int32_t n_blocks )
   HIP_TRY( e, RS_HIP_E_RUNTIME );
   return RS_HIP_OK;
 }
+
+// Host-side spin primitives for callers that issue independent operators from several threads and join them thousands of
+// times per second (bench.py): a thread that sleeps in a queue or on a condition variable pays the host scheduler's wake-up
+// latency at every hand-off — on a shared, busy host occasionally milliseconds, more than a whole step.
+int rs_hip_spin_post( volatile int32_t* flag, int32_t value )
+{
+  if( !flag ) return RS_HIP_E_ARG;
+  __atomic_store_n( (int32_t*)flag, value, __ATOMIC_RELEASE );
+  return RS_HIP_OK;
+}
+int rs_hip_spin_wait( const volatile int32_t* flag, int32_t at_least, double timeout_s )
+{
+  if( !flag ) return RS_HIP_E_ARG;
+  const auto t0 = std::chrono::steady_clock::now();
+  for( unsigned n = 0; ; ++n )
+  {
+    if( __atomic_load_n( (const int32_t*)flag, __ATOMIC_ACQUIRE ) >= at_least ) return RS_HIP_OK;
+    __builtin_ia32_pause();
+    if( ( n & 0xffff ) == 0xffff && timeout_s > 0.0 &&
+        std::chrono::duration<double>( std::chrono::steady_clock::now() - t0 ).count() > timeout_s ) { set_err( "spin_wait: timed out" ); return RS_HIP_E_RUNTIME; }
+  }
+}
+int rs_hip_post_on_next_call( volatile int32_t* flag, int32_t value )
+{
+  post_pending();                     // (one pending post per thread; an older one goes out now)
+  g_post_flag = flag; g_post_value = value;
+  return RS_HIP_OK;
+}
+int rs_hip_post_pending( void ) { post_pending(); return RS_HIP_OK; }
 
 int rs_hip_synchronize( void )
 {

@@ -163,7 +163,9 @@ def shard_compute(capi, lay, rank, units, send, small_host, threads=None):
             capi.label_rows(lscene, lposes[p0:p1], lclouds[p0:p1], lradii[p0:p1], out_device_ptr=send.data_ptr() + 4 * lay.off_rows, query_order=True)
             capi.synchronize()            # the rows are complete before the collective (another stream) reads them
 
-    if threads is not None:            # three executors, one per consumer (bench.py: each with its own stream / CU partition), or one pool
+    if threads is not None and hasattr(threads, "run3"):      # bench.py's RoleRunner: each consumer on its own thread / stream / CU partition
+        threads.run3(icp, score, label)
+    elif threads is not None:          # three executors, one per consumer, or one pool
         subs = [ex.submit(fn) for ex, fn in zip(threads, (icp, score, label))] if isinstance(threads, (list, tuple)) else [threads.submit(fn) for fn in (icp, score, label)]
         for f in subs:
             f.result()
