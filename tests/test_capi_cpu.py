@@ -112,6 +112,41 @@ def test_fails_loudly_without_gpu(lib):
     assert rc == -1 and b"no HIP device" in lib.rs_hip_last_error()
 
 
+def test_spin_flags_hand_work_between_threads(lib):
+    """rs_hip_spin_post / _wait / _post_on_next_call / _post_pending (bench.py's RoleRunner joins its consumers with them): a
+    worker thread and the caller ping-pong through two int32 flags without ever sleeping in a queue; a deferred post goes out
+    at the thread's next entry into the library (or with post_pending), not before; a wait that cannot succeed times out."""
+    import threading
+    from rescan_amd import capi
+    flags = np.zeros(4, np.int32)
+    addr = lambda k: flags.ctypes.data + 4 * k          # noqa: E731
+    seen = []
+
+    def worker():
+        for k in range(1, 201):
+            capi.spin_wait(addr(0), k, 30.0)
+            seen.append(k)
+            capi.spin_post(addr(1), k)
+
+    t = threading.Thread(target=worker)
+    t.start()
+    for k in range(1, 201):
+        capi.spin_post(addr(0), k)
+        capi.spin_wait(addr(1), k, 30.0)
+        assert seen[-1] == k
+    t.join()
+    capi.post_on_next_call(addr(2), 7)
+    assert flags[2] == 0                                  # deferred
+    lib.rs_hip_last_error()                               # (not an entry that posts: a plain accessor)
+    capi.post_pending()
+    assert flags[2] == 7
+    capi.post_on_next_call(addr(3), 9)
+    lib.rs_hip_synchronize()                              # any operator entry posts first (and then fails or not, GPU or no GPU)
+    assert flags[3] == 9
+    with pytest.raises(capi.RescanHipError):
+        capi.spin_wait(addr(0), 10 ** 6, 0.05)
+
+
 def test_missing_extension_is_an_error(monkeypatch, tmp_path):
     from rescan_amd import capi
     monkeypatch.setattr(capi, "_lib", None)
