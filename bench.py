@@ -240,7 +240,16 @@ def _roles():
         import torch
         n_cu = int(torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count)
         split = float(os.environ.get("RS_BENCH_CU_SPLIT", "0.625" if n_cu == 256 else "0"))
-        spin = os.environ.get("RS_BENCH_SPIN", "1") != "0"
+        # spinning threads need their cores: 3 busy threads per rank; a container whose CPU quota does not cover that for all the
+        # node's ranks would be throttled (every thread of the cgroup stalls for the rest of the 100 ms period)
+        st = host_cpu_stat()
+        cpus = None
+        if st and st[0] and st[0].split()[0] != "max":
+            q, per = st[0].split()
+            cpus = float(q) / float(per)
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+        spin_default = "0" if (cpus is not None and cpus < 4.0 * local_world) else "1"
+        spin = os.environ.get("RS_BENCH_SPIN", spin_default) != "0"
         masks, note = None, "none"
         if split > 0.0:
             k = int(round(split * n_cu))
