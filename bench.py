@@ -137,7 +137,7 @@ class RoleRunner:
         import threading
         from concurrent.futures import ThreadPoolExecutor
         from rescan_amd import capi
-        self.capi, self.spin, self.k, self.stop = capi, spin, 0, False
+        self.capi, self.spin, self.k, self.stop, self.masked = capi, spin, 0, False, bool(masks)
         self.fns, self.out, self.dt = [None] * 3, [None] * 3, [0.0] * 3
         if not spin:
             self.pools = [ThreadPoolExecutor(max_workers=1) for _ in range(3)]
@@ -171,6 +171,9 @@ class RoleRunner:
             k += 1
             capi.spin_wait(self.addr(0, r), k, 0.0)
             if self.stop:
+                if mask:
+                    capi.stream_cu_mask(None)         # (a profiler's finalisation does not survive masked streams)
+                capi.spin_post(self.addr(1, r), 1 << 30)
                 return
             if r == self.ICP:
                 capi.post_on_next_call(self.addr(0, self.LABEL), k)       # the label thread goes once this one is inside the library
@@ -216,11 +219,21 @@ class RoleRunner:
         return outs
 
     def close(self):
-        """Parks the spinning workers (they would otherwise keep two cores busy)."""
-        if self.spin and not self.stop:
-            self.stop = True
-            for r in (self.ICP, self.LABEL):
-                self.capi.spin_post(self.addr(0, r), 1 << 30)
+        """Parks the spinning workers (they would otherwise keep two cores busy) and gives every thread an unmasked stream again."""
+        if self.stop:
+            return
+        self.stop = True
+        if not self.spin:
+            if self.masked:
+                for ex in self.pools:
+                    ex.submit(self.capi.stream_cu_mask, None).result()
+            return
+        for r in (self.ICP, self.LABEL):
+            self.capi.spin_post(self.addr(0, r), 1 << 30)
+        for r in (self.ICP, self.LABEL):
+            self.capi.spin_wait(self.addr(1, r), 1 << 30, 30.0)
+        if self.masked:
+            self.capi.stream_cu_mask(None)
 
 
 def _roles():

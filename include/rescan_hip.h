@@ -37,7 +37,9 @@ int         rs_hip_set_stream( void* hip_stream );
 int         rs_hip_synchronize( void );
 /* Restrict the calling thread's own stream to the compute units whose bits are set in mask (n_words x 32 bits, CU 0 = bit 0 of
  * word 0): independent operators issued from different threads can be kept off each other's CUs (a latency-bound chain beside
- * a throughput-bound batch).  Replaces the thread's stream; pending work on the old one is waited for. */
+ * a throughput-bound batch).  Replaces the thread's stream; pending work on the old one is waited for.  (NULL, 0) goes back to an
+ * unrestricted stream — do that before the process exits when a profiler is attached: rocprofv3 crashes in its finalisation when
+ * masked streams are still alive. */
 int         rs_hip_stream_cu_mask( const uint32_t* mask, int32_t n_words );
 /* Diagnostic: out[b] = XCC_ID | HW_ID << 8 of workgroup b of a probe launch on the calling thread's stream (which CUs a
  * CU mask really selects: tools/cu_mask_probe.py). */

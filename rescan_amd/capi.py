@@ -23,7 +23,7 @@ SIGNATURES = {
     "rs_hip_last_error": (C.c_char_p, []),
     "rs_hip_set_stream": (C.c_int, [C.c_void_p]),
     "rs_hip_synchronize": (C.c_int, []),
-    "rs_hip_stream_cu_mask": (C.c_int, [np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS"), C.c_int32]),
+    "rs_hip_stream_cu_mask": (C.c_int, [C.c_void_p, C.c_int32]),
     "rs_hip_probe_placement": (C.c_int, [np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS"), C.c_int32]),
     "rs_hip_spin_post": (C.c_int, [C.c_void_p, C.c_int32]),
     "rs_hip_spin_wait": (C.c_int, [C.c_void_p, C.c_int32, C.c_double]),
@@ -123,13 +123,17 @@ def synchronize():
 
 
 def stream_cu_mask(bits):
-    """Restrict the calling thread's stream to the CUs whose entries in `bits` (sequence of 0/1, CU 0 first) are set."""
+    """Restrict the calling thread's stream to the CUs whose entries in `bits` (sequence of 0/1, CU 0 first) are set; None: back
+    to an unrestricted stream."""
+    if bits is None:
+        _check(load().rs_hip_stream_cu_mask(None, 0))
+        return
     b = np.asarray(bits, np.uint8)
     words = np.zeros((len(b) + 31) // 32, np.uint32)
     for k, v in enumerate(b):
         if v:
             words[k // 32] |= np.uint32(1 << (k % 32))
-    _check(load().rs_hip_stream_cu_mask(words, len(words)))
+    _check(load().rs_hip_stream_cu_mask(words.ctypes.data, len(words)))
 
 
 def spin_post(flag_addr, value):

@@ -296,9 +296,10 @@ int rs_hip_set_stream( void* s )
 int rs_hip_stream_cu_mask( const uint32_t* mask, int32_t n_words )
 {
   int rc = ensure_ready(); if( rc ) return rc;
-  if( !mask || n_words <= 0 ) { set_err( "stream_cu_mask: bad arguments" ); return RS_HIP_E_ARG; }
+  if( ( !mask ) != ( n_words <= 0 ) ) { set_err( "stream_cu_mask: bad arguments" ); return RS_HIP_E_ARG; }
   hipStream_t s = nullptr;
-  HIP_TRY( hipExtStreamCreateWithCUMask( &s, (uint32_t)n_words, mask ), RS_HIP_E_RUNTIME );
+  if( mask ) HIP_TRY( hipExtStreamCreateWithCUMask( &s, (uint32_t)n_words, mask ), RS_HIP_E_RUNTIME );
+  else       HIP_TRY( hipStreamCreateWithFlags( &s, hipStreamNonBlocking ), RS_HIP_E_RUNTIME );          // (null, 0): back to an unrestricted stream
   if( g_own_stream ) { (void)hipStreamSynchronize( g_own_stream ); (void)hipStreamDestroy( g_own_stream ); }
   const bool was_own = g_stream == g_own_stream || !g_stream;
   g_own_stream = s;

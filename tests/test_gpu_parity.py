@@ -675,6 +675,9 @@ def test_cu_masked_stream_keeps_to_its_cus_and_changes_no_result(capi):
         pool.submit(capi.stream_cu_mask, [1] * (n_cu // 2) + [0] * (n_cu - n_cu // 2)).result()
         half = pool.submit(placement).result()
         masked = key(pool.submit(run).result())
+        pool.submit(capi.stream_cu_mask, None).result()             # back to an unrestricted stream
+        again = pool.submit(placement).result()
+    assert again == everywhere
     assert len(everywhere) == n_cu
     assert half < everywhere and len(half) == n_cu // 2
     assert len({x for x, _, _, _ in half}) == len({x for x, _, _, _ in everywhere})     # every XCD keeps CUs: the mask is per XCD
