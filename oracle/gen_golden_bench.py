@@ -2,7 +2,7 @@
 ICP runs against oracle/_ref — the real reference compiled in place from /root/reference.  Run in the build
 container only; the fixtures are committed so the GPU box, which has no /root/reference, can check against them.
 
-  tests/golden/bench_seed11.npz   for bench.build_inputs(1_000_000, seed=11):
+  tests/golden/bench_seed11.npz, bench_seed23.npz   for bench.build_inputs(1_000_000, seed=11 | 23) (11 is what bench.py runs):
         icp_pose / icp_err / icp_n_corrs[10] / icp_errs[10]   10 FIXED iterations composed from the reference's own
               icp_find_corrs + icp_estimate_rigid_xform_pt2pl (lib/rs/icp.h:306-412,210-298) with the loop of
               icp_align (:433-497, radius schedule :493) minus the stop test (oracle/ref_driver.cpp: ref_icp_iterate)
@@ -17,7 +17,7 @@ container only; the fixtures are committed so the GPU box, which has no /root/re
         reference's own icp_align (stop test included): final pose, error; iteration counts from ref_icp_iterate
         with the stop test on (same loop; asserted to end at the same pose bit for bit)
 
-Usage:  python oracle/gen_golden_bench.py [--bench-only | --sweep-only]
+Usage:  python oracle/gen_golden_bench.py [--bench-only [--seed N] | --sweep-only]
 """
 import ctypes as C
 import hashlib
@@ -34,6 +34,7 @@ from rescan_amd import synth  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
 I4 = np.eye(4, dtype=np.float32).ravel()
+BENCH_SEEDS = [11, 23]            # 11: the bench's own workload; 23: a second room of the same size
 SWEEP_SEEDS = list(range(1, 25))
 SWEEP_POINTS = 120_000
 
@@ -65,10 +66,10 @@ def sweep_inputs(seed):
     return s0, s1, T0, np.float32(max_dist), np.float32(np.deg2rad(max_angle))
 
 
-def gen_bench(R, O):
+def gen_bench(R, O, seed=11):
     import bench
     t = time.time()
-    w = bench.build_inputs(1_000_000, seed=11)
+    w = bench.build_inputs(1_000_000, seed=seed)
     s0, s1 = w["s0"], w["s1"]
     print(f"inputs: {w['n_scan0']} / {w['n_scan1']} scan points, {w['n_obj']} object points ({time.time()-t:.1f} s)", flush=True)
     t = time.time()
@@ -86,8 +87,8 @@ def gen_bench(R, O):
     lab = O.arrangement_to_labels(s1["points"], s1["normals"], objs, plcs, 0.05, 0, 0)
     print(f"labels: {int((lab['labels'] > 0).sum())} labelled ({time.time()-t:.1f} s)", flush=True)
     np.savez_compressed(
-        os.path.join(OUT, "bench_seed11.npz"),
-        n_points=1_000_000, seed=11, n_scan0=w["n_scan0"], n_scan1=w["n_scan1"], n_obj=w["n_obj"],
+        os.path.join(OUT, "bench_seed%d.npz" % seed),
+        n_points=1_000_000, seed=seed, n_scan0=w["n_scan0"], n_scan1=w["n_scan1"], n_obj=w["n_obj"],
         in_sha=np.array([sha(s0["points"]), sha(s0["normals"]), sha(s1["points"]), sha(s1["normals"]), sha(op), sha(on),
                          sha(w["score_poses"]), sha(w["plc_poses"]), sha(w["icp_T0"])]),
         icp_T0=w["icp_T0"], icp_pose=T, icp_err=err, icp_n_corrs=nc, icp_errs=errs,
@@ -115,6 +116,8 @@ if __name__ == "__main__":
     build(ref=True)
     R, O = Ref(), Oracle()
     if "--sweep-only" not in sys.argv:
-        gen_bench(R, O)
+        for seed in BENCH_SEEDS:
+            if "--seed" not in sys.argv or str(seed) == sys.argv[sys.argv.index("--seed") + 1]:
+                gen_bench(R, O, seed)
     if "--bench-only" not in sys.argv:
         gen_sweep(R)

@@ -1,6 +1,7 @@
 """GPU parity of the HEADLINE workload and of the multi-GPU route, through the C ABI.
 
-* bench.py's 1 M-point step (BASELINE.json configs[1]) against tests/golden/bench_seed11.npz — what the compiled reference
+* bench.py's 1 M-point step (BASELINE.json configs[1]) against tests/golden/bench_seed11.npz, and the same step on a second
+  synthetic room against bench_seed23.npz — what the compiled reference
   computes for the same inputs (oracle/gen_golden_bench.py): pose / error after the 10 fixed ICP iterations, per-iteration
   correspondence counts, the 256 alignment scores; labels / min_dists against the C restatement's (the reference's label TU
   needs the un-vendored gco header).
@@ -43,10 +44,11 @@ def bench_mod():
     return bench
 
 
-@pytest.fixture(scope="module")
-def headline(capi, bench_mod):
-    """The bench workload, uploaded once for this module, and the fixture that pins it."""
-    g = load_golden("bench_seed11.npz")
+@pytest.fixture(scope="module", params=[11, 23], ids=["seed11-the-bench-workload", "seed23"])
+def headline(request, capi, bench_mod):
+    """The bench workload (seed 11) and a second room of the same size (seed 23), each uploaded once for this module, and
+    the fixture that pins it."""
+    g = load_golden("bench_seed%d.npz" % request.param)
     w = bench_mod.build_workload(int(g["n_points"]), seed=int(g["seed"]), knn="hash")
     s0, s1 = w["s0"], w["s1"]
     op, on = w["obj_score_np"]

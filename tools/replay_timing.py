@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 from rescan_amd import capi, synth
 capi.init(0)
 I4 = np.eye(4, dtype=np.float32).ravel()
-for n in (20_000, 60_000, 134_000, 260_000, 500_000, 1_000_000):
+for n in (5_000, 10_000, 20_000, 40_000, 60_000, 134_000, 260_000, 500_000):
     s0 = synth.scene_for_point_count(int(n * 0.84), seed=3, timestep=0); s1 = synth.scene_for_point_count(int(n * 0.84), seed=3, timestep=1)
     a, b = capi.Cloud(s0["points"], s0["normals"]), capi.Cloud(s1["points"], s1["normals"])
     T0 = synth.perturbed_pose(I4, np.random.default_rng(1), 0.01, 0.01)
