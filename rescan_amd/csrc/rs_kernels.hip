@@ -1371,15 +1371,16 @@ constexpr int PA_WAVES = RS_PA_WAVES;
 __host__ __device__ inline int icp_blocks_per_xcd( int n_tiles ) { return ( ( n_tiles + PA_WAVES - 1 ) / PA_WAVES + 7 ) / 8; }
 
 // Phase A: one wave per tile, first shell(s) only; unsettled tiles are queued.
-// Waves per SIMD the register allocation aims at.  6 = 80 VGPRs: the warm instantiation (no shell loop) then keeps 16 B of
-// scratch per lane, the cold one (iteration 0 only) 36 B; 5 = 87-95 VGPRs, no scratch at all.  Measured on the bench
-// (interleaved repeats, profiles/r02/ab_*.txt): 6 waves are 2.4 % faster per concurrent step, 5 waves move ~15 MB less per
-// search (HBM-side traffic 1.7x instead of 1.9x the algorithmic bytes).  `value` is the metric: 6.
+// Waves per SIMD the register allocation aims at.  5 = 83 / 95 VGPRs (warm / cold instantiation), no scratch; 6 = 80 VGPRs with
+// 16 / 40 B of scratch per lane.  Round 1 and most of round 2 ran 6: 2.4 % faster per concurrent step while the ICP chain was the
+// step's critical path, for ~25 MB more HBM-side traffic per search.  Since the consumers run on disjoint CUs and the score batch
+// is the longer side, the chain's 1.4 % (serial) / 3 % (concurrent) hide behind it: 5 waves, 122 MB per search
+// instead of 148 (1.7x instead of 2.1x the algorithmic bytes), same step time (profiles/r02/ab_*experiments.txt).
 #ifndef RS_ICP_WARM_OCC
-#define RS_ICP_WARM_OCC 6
+#define RS_ICP_WARM_OCC 5
 #endif
 #ifndef RS_ICP_OCC
-#define RS_ICP_OCC 6
+#define RS_ICP_OCC 5
 #endif
 template <bool BOUNDED_ONLY>
 __global__ __launch_bounds__( PA_WAVES * WAVE, BOUNDED_ONLY ? RS_ICP_WARM_OCC : RS_ICP_OCC ) void k_icp_corr( IcpLaunch L )
