@@ -1372,12 +1372,12 @@ __host__ __device__ inline int icp_blocks_per_xcd( int n_tiles ) { return ( ( n_
 
 // Phase A: one wave per tile, first shell(s) only; unsettled tiles are queued.
 // Waves per SIMD the register allocation aims at.  5 = 83 / 95 VGPRs (warm / cold instantiation), no scratch; 6 = 80 VGPRs with
-// 16 / 40 B of scratch per lane.  Round 1 and most of round 2 ran 6: 2.4 % faster per concurrent step while the ICP chain was the
-// step's critical path, for ~25 MB more HBM-side traffic per search.  Since the consumers run on disjoint CUs and the score batch
-// is the longer side, the chain's 1.4 % (serial) / 3 % (concurrent) hide behind it: 5 waves, 122 MB per search
-// instead of 148 (1.7x instead of 2.1x the algorithmic bytes), same step time (profiles/r02/ab_*experiments.txt).
+// 16 / 40 B of scratch per lane.  Measured on the bench with the consumers on disjoint CUs (interleaved repeats,
+// profiles/r02/ab_*experiments.txt), step time / HBM-side traffic per search: both 6: 2.53-2.55 ms, 148 MB; warm 6, cold 5:
+// 2.55-2.59 ms, 134 MB; both 5: 2.61-2.62 ms, 122 MB (70.5 MB are algorithmic).  The ICP chain is the step's critical path, so
+// the warm launches (nine of ten) keep their sixth wave; the cold one, whose scratch is the larger, does without.
 #ifndef RS_ICP_WARM_OCC
-#define RS_ICP_WARM_OCC 5
+#define RS_ICP_WARM_OCC 6
 #endif
 #ifndef RS_ICP_OCC
 #define RS_ICP_OCC 5
@@ -2525,16 +2525,23 @@ __device__ __forceinline__ void score_emit( const ScoreLaunch& L, int pose, int 
 #define RS_SCORE_ROWS_OCC 5
 #endif
 // RB = 0: the tile-wide search (with hand-off to k_score_coop); RB = 16: the cold search row by row, RB candidates per row and round
+// Waves per workgroup of the score batch's search.  As for phase A of the ICP search: a workgroup's slots are released when its
+// last wave ends, and the four tiles of a workgroup do not take equally long (~180 us each, +-30 %): one tile per workgroup is
+// 1.21 -> 1.09 ms for the batch alone and 2.60 -> 2.29 ms on its 3/8 of the CUs beside the ICP chain.
+#ifndef RS_SC_WAVES
+#define RS_SC_WAVES 1
+#endif
+constexpr int SC_WAVES = RS_SC_WAVES;
 template <int RB>
-__global__ __launch_bounds__( BLOCK, RB ? RS_SCORE_ROWS_OCC : RS_SCORE_OCC ) void k_score( ScoreLaunch L )
+__global__ __launch_bounds__( SC_WAVES * WAVE, RB ? RS_SCORE_ROWS_OCC : RS_SCORE_OCC ) void k_score( ScoreLaunch L )
 {
   typedef WaveLdsT<( RB ? 4 * RB : WAVE )> Lds;
-  __shared__ Lds lds[WAVES_PER_BLOCK];
+  __shared__ Lds lds[SC_WAVES];
   const int pose = blockIdx.y;
   const int lane = threadIdx.x & ( WAVE - 1 );
   const int wib = threadIdx.x / WAVE;
   EvalScope eval_scope( L.scene.evals, lds[wib], lane );
-  const int tile = blockIdx.x * WAVES_PER_BLOCK + wib;
+  const int tile = blockIdx.x * SC_WAVES + wib;
   if( tile >= L.obj.n_tiles ) return;
   const int i = (int)L.obj.tiles[tile] + lane;
   const bool active = i < (int)L.obj.tiles[tile + 1];
@@ -2604,11 +2611,11 @@ __global__ __launch_bounds__( BLOCK ) void k_score_final( ScoreLaunch L )
 void launch_score( const ScoreLaunch& L, hipStream_t st )
 {
   (void)hipMemsetAsync( L.queue_count, 0, sizeof(int), st );
-  dim3 grid( ( L.obj.n_tiles + WAVES_PER_BLOCK - 1 ) / WAVES_PER_BLOCK, L.n_poses );
+  dim3 grid( ( L.obj.n_tiles + SC_WAVES - 1 ) / SC_WAVES, L.n_poses );
   // by_rows: big batches on a cell grid only — nothing is handed off there.  (16 candidates per row and round; 32 and 64 were
   // measured too: 1.70 and 2.15 ms against 1.53 — rows of unequal length evaluate sentinels up to the longest one's count.)
-  if( L.by_rows && L.solo_stages == 0x7fffffff && L.scene.inv_cell > 0.0f ) hipLaunchKernelGGL( k_score<16>, grid, dim3( BLOCK ), 0, st, L );
-  else hipLaunchKernelGGL( k_score<0>, grid, dim3( BLOCK ), 0, st, L );
+  if( L.by_rows && L.solo_stages == 0x7fffffff && L.scene.inv_cell > 0.0f ) hipLaunchKernelGGL( k_score<16>, grid, dim3( SC_WAVES * WAVE ), 0, st, L );
+  else hipLaunchKernelGGL( k_score<0>, grid, dim3( SC_WAVES * WAVE ), 0, st, L );
   long long items = (long long)L.obj.n_tiles * L.n_poses;
   hipLaunchKernelGGL( k_score_coop, dim3( items < 4096 ? (int)( items > 0 ? items : 1 ) : 4096 ), dim3( COOP_BLOCK ), 0, st, L );
   hipLaunchKernelGGL( k_score_final, dim3( L.n_poses ), dim3( BLOCK ), 0, st, L );
