@@ -57,10 +57,13 @@ if __name__ == "__main__":
     elif len(sys.argv) > 2 and sys.argv[1] == "--trace":
         rows = sorted(csv.DictReader(open(sys.argv[2])), key=lambda r: int(r["Start_Timestamp"]))
         rows = [r for r in rows if "rs::" in r["Kernel_Name"]]
-        # bench.py --steps 1 --warmup 1 --serial: cloud construction, then two identical steps; show the second
+        # bench.py --steps 2 --warmup 1 --serial with RS_HIP_PROF_EVERY=1000: cloud construction, then three identical steps; show the
+        # LAST one — the first timed step carries the live profile's event records between its kernels (a ~6 us bubble each: what
+        # round 1's trace showed as "launch gaps"), the later ones do not
         last_build = max([k for k, r in enumerate(rows) if "k_build_" in r["Kernel_Name"]], default=-1)
         rows = rows[last_build + 1:]
-        start = len(rows) // 2
+        n_steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+        start = len(rows) * (n_steps - 1) // n_steps
         lines = []
         for r in rows[start:]:
             s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])

@@ -25,7 +25,7 @@ traffic)
   python tools/pmc_summary.py --traffic ;;
 trace)   # per-dispatch timeline of one serial step: which ICP iteration costs what
   rm -rf gpurun_out/prof_trace
-  rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_trace -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --serial > /dev/null 2> gpurun_out/prof_trace.err
-  python tools/pmc_summary.py --trace "$(find gpurun_out/prof_trace -name '*kernel_trace.csv' | head -1)" ;;
+  RS_HIP_PROF_EVERY=1000 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_trace -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --serial > /dev/null 2> gpurun_out/prof_trace.err
+  python tools/pmc_summary.py --trace "$(find gpurun_out/prof_trace -name '*kernel_trace.csv' | head -1)" 3 ;;
 *) echo "usage: $0 stats|pmc|traffic|trace" ;;
 esac
