@@ -1463,9 +1463,29 @@ int rs_hip_radius_search( const rs_hip_cloud_t* target, const float* query, int6
     static const size_t zero_copy_below = getenv( "RS_HIP_ROWS_ZERO_COPY_BELOW" ) ? (size_t)atoll( getenv( "RS_HIP_ROWS_ZERO_COPY_BELOW" ) ) : ( 256u << 10 );
     if( down_words * 4 <= zero_copy_below )
     {
+      // ... and the synchronisation is the host polling the counts: every wave stores its row, then (after a system-scope fence)
+      // the row's count, which the host pre-set to a sentinel; the runtime's own completion wait costs more than the kernel
+      // (RS_HIP_ROWS_NO_POLL=1: hipStreamSynchronize; it is also what a poll of 2 ms without an answer falls back to)
+      static const bool poll = !getenv( "RS_HIP_ROWS_NO_POLL" );
+      const int pending = INT_MIN;
+      if( poll ) for( int i = 0; i < nq; ++i ) ( (volatile int*)h_nn )[i] = pending;
       { ProfScope ps( "nn_rows" );
         launch_rows_wave( g, h_up, nq, k, radius, radius_sq_of( radius ), (float*)( h_nn + nn + 1 ), h_nn + nn + 1 + nk, h_nn, h_nn + nq, g_stream ); }
-      HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
+      bool done = false;
+      if( poll )
+      {
+        const auto t0 = std::chrono::steady_clock::now();
+        int i = 0;
+        for( unsigned spins = 0; ; ++spins )
+        {
+          while( i < nq && ( (volatile int*)h_nn )[i] != pending ) ++i;
+          if( i == nq ) { done = true; break; }
+          __builtin_ia32_pause();
+          if( ( spins & 1023 ) == 1023 && std::chrono::duration<double>( std::chrono::steady_clock::now() - t0 ).count() > 2e-3 ) break;
+        }
+        std::atomic_thread_fence( std::memory_order_acquire );
+      }
+      if( !done ) HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
     }
     else
     {

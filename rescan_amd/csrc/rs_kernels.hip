@@ -2981,7 +2981,7 @@ __global__ __launch_bounds__( ROWS_WAVES * WAVE ) void k_rows_wave( GridView g, 
     }
     wave_lds_fence();
   }
-  if( count > ROWS_CAP ) { if( lane == 0 ) { atomicExch( overflow, 1 ); out_nn[qi] = -1; } return; }
+  if( count > ROWS_CAP ) { if( lane == 0 ) { *(volatile int*)overflow = 1; out_nn[qi] = -1; } return; }      // (plain stores: the words may live in host memory)
   // (Ordering a row by counting — every hit counts the hits that precede it and stores itself at that position — instead of
   //  sorting was tried: 128 hits cost about the same as the 28 LDS round trips of the bitonic network, more hits cost more.)
   const uint32_t n_out = count < (uint32_t)K ? count : (uint32_t)K;
@@ -2991,6 +2991,8 @@ __global__ __launch_bounds__( ROWS_WAVES * WAVE ) void k_rows_wave( GridView g, 
     if( count <= WAVE )          rows_sort_emit<1>( L, count, n_out, lane, od, oi );
     else if( count <= 2 * WAVE ) rows_sort_emit<2>( L, count, n_out, lane, od, oi );
     else                         rows_sort_emit<4>( L, count, n_out, lane, od, oi );
+    // the count is the row's "ready" flag for a host that polls it (rows and counts in host memory): rows first, system-wide
+    __threadfence_system();
     if( lane == 0 ) out_nn[qi] = (int)n_out;
     return;
   }
@@ -3013,6 +3015,7 @@ __global__ __launch_bounds__( ROWS_WAVES * WAVE ) void k_rows_wave( GridView g, 
       wave_lds_fence();
     }
   for( uint32_t t = lane; t < n_out; t += WAVE ) { out_d2[(size_t)qi * K + t] = L.d2[t]; out_idx[(size_t)qi * K + t] = L.idx[t]; }
+  __threadfence_system();
   if( lane == 0 ) out_nn[qi] = (int)n_out;
 }
 
