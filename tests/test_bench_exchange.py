@@ -48,3 +48,38 @@ def test_exchange_world2_gloo():
         p.join(60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res), res
+
+
+def test_role_runner_joins_three_consumers_without_sleeping():
+    """bench.py's RoleRunner in its spinning form (no GPU needed: the hand-off flags are host memory): 200 steps of three
+    callables, each always on its own thread, results in order; an exception raised by a worker's callable reaches the caller; a
+    callable that never enters the library still releases the next thread (post_pending); close() parks the workers."""
+    import threading
+    sys.path.insert(0, ROOT)
+    import bench
+    from rescan_amd import build
+    build.build()
+    r = bench.RoleRunner(None, True)
+    names = {}
+
+    def fn(tag, k):
+        def run():
+            names.setdefault(tag, set()).add(threading.current_thread().name)
+            return (tag, k)
+        return run
+
+    for k in range(200):
+        out = r.run3(fn("icp", k), fn("score", k), fn("label", k))
+        assert out == [("icp", k), ("score", k), ("label", k)]
+    assert all(len(v) == 1 for v in names.values()) and len({next(iter(v)) for v in names.values()}) == 3
+    assert next(iter(names["score"])) == threading.current_thread().name          # the longest consumer runs on the caller
+
+    def boom():
+        raise ValueError("from the label thread")
+    with pytest.raises(ValueError):
+        r.run3(fn("icp", -1), fn("score", -1), boom)
+    assert r.run3(fn("icp", 7), fn("score", 7), fn("label", 7))[2] == ("label", 7)   # still usable
+    r.close()
+    for t in r.threads:
+        t.join(10.0)
+        assert not t.is_alive()
