@@ -447,7 +447,7 @@ class Sharded:
             self.bufs.append((send, recv, small, out))
         # the exchange thread's stream: non-blocking (see exchange) and of high priority — its few kernels (copy, collective, fold) are
         # dispatched ahead of the next step's tens of thousands of queued workgroups instead of behind them
-        self.xs = torch.cuda.Stream(device=dev, priority=-1)
+        self.xs = torch.cuda.Stream(device=dev, priority=-1) if not os.environ.get("RS_BENCH_XCH_DEFAULT_STREAM") else torch.cuda.default_stream(dev)   # (the variable: A/B of the above)
         self.xs_bound = False
         self.step_index = 0
         self.stat_from = 0
