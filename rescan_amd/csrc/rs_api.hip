@@ -806,8 +806,15 @@ void icp_debug_after( IcpCtx& cx, int n_src, int n, int i, float max_dist )
   size_t unm = 0, cert = 0;
   for( int v : ms ) unm += v < 0;
   for( float v : cr ) cert += v > 0.0f;
-  fprintf( stderr, "[rs_hip icp] it %d (max_dist %g, coop waves %d): prob 0 queued tiles %d of %d, unmatched %zu of %d, certificates %zu\n",
-           i, (double)max_dist, cx.L.coop_waves, qc[0], cx.n_waves, unm, n_src, cert );
+  long long st_sum = 0, st_cnt = 0;
+  if( cx.L.heavy_out )
+  {
+    std::vector<int> words( (size_t)cx.n_waves );
+    (void)hipMemcpy( words.data(), cx.L.heavy_out + HEAVY_HDR + HEAVY_SLOTS, words.size() * 4, hipMemcpyDeviceToHost );
+    for( int v : words ) if( (unsigned)v >> 2 ) { st_sum += (unsigned)v >> 2; ++st_cnt; }
+  }
+  fprintf( stderr, "[rs_hip icp] it %d (max_dist %g, coop waves %d): prob 0 queued tiles %d of %d, unmatched %zu of %d, certificates %zu, candidates streamed per tile of phase A %lld\n",
+           i, (double)max_dist, cx.L.coop_waves, qc[0], cx.n_waves, unm, n_src, cert, st_cnt ? st_sum / st_cnt : 0ll );
   if( !cx.L.dbg ) return;
   std::vector<unsigned long long> h( (size_t)cx.n_waves * 2 );
   (void)hipMemcpy( h.data(), cx.L.dbg, h.size() * 8, hipMemcpyDeviceToHost );

@@ -56,7 +56,10 @@ enum { ICP_NMOM = 35,     // raw moments reduced per ICP iteration (see k_icp_mo
 constexpr int HEAVY_SLOTS = 2048;   // wave slots at the front of phase A's grid reserved for the previous iteration's slow tiles
 constexpr int HEAVY_CLASSES = 8;     // one list per XCD class of the natural order: a listed tile stays on the XCD whose L2 holds its part of the target
 constexpr int HEAVY_PER_CLASS = HEAVY_SLOTS / HEAVY_CLASSES;
-__host__ __device__ inline size_t heavy_stride( int n_tiles ) { return (size_t)n_tiles + HEAVY_SLOTS + HEAVY_CLASSES; }
+constexpr int HEAVY_MEAN = HEAVY_CLASSES;                             // word: mean candidates streamed per tile of the launch (a sample) / HEAVY_MEAN_REF, in 1/256ths, written when the iteration ends
+constexpr int HEAVY_HDR = HEAVY_CLASSES + 8;                         // header words before the lists
+constexpr int HEAVY_MEAN_REF = 320;  // mean up to which the thresholds below apply as they are (the 1 M-point headline: 300 after the cold launch, 200 later); beyond, they grow with it
+__host__ __device__ inline size_t heavy_stride( int n_tiles ) { return (size_t)n_tiles + HEAVY_SLOTS + HEAVY_HDR; }
 
 struct IcpLaunch
 {
@@ -106,7 +109,8 @@ struct IcpLaunch
   unsigned long long* dbg;   // diagnostic builds only: per-tile {cycles, candidates} of phase A (null otherwise)
   const float* w_explicit;   // if non-null: weights given per query (estimate-only entry point)
   // slowest-first start of phase A's tiles: every iteration lists its slow tiles for the next one (null: off)
-  //   per problem (heavy_stride words): HEAVY_CLASSES counts | HEAVY_CLASSES x HEAVY_PER_CLASS tile ids | n_tiles x (1: a front slot has it; 2: handed to the cooperative kernel at once; 0)
+  //   per problem (heavy_stride words): HEAVY_CLASSES counts | mean candidates streamed per tile | pad |
+  //   HEAVY_CLASSES x HEAVY_PER_CLASS tile ids | n_tiles x (bits 0-1: 1 a front slot has it, 2 handed to the cooperative kernel at once; bits 2..: candidates it streamed)
   const int* heavy_in;
   int*    heavy_out;
   int     heavy_streamed;   // a tile that streamed at least this many candidates is listed

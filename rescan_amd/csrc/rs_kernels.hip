@@ -1350,10 +1350,32 @@ __device__ __forceinline__ void icp_iteration_reset( const IcpLaunch& L, int pro
   {
     if( L.queued ) L.queued[prob] = L.queue_count[prob];       // tiles phase A handed off (diagnostics)
     L.queue_count[prob] = 0;                                   // ready for the next iteration's phase A
-    if( L.heavy_in ) for( int c = 0; c < HEAVY_CLASSES; ++c ) const_cast<int*>( L.heavy_in )[(size_t)prob * heavy_stride( L.src.n_tiles ) + c] = 0;   // consumed: it is the next iteration's output buffer
+  }
+  const int stat_wave = blockDim.x >= 2 * WAVE ? WAVE : 0;      // (not the wave whose first thread goes on to solve: its time is the iteration's)
+  if( L.heavy_out && (int)threadIdx.x >= stat_wave && (int)threadIdx.x < stat_wave + WAVE )
+  {
+    const int sl = (int)threadIdx.x - stat_wave;
+    // What this iteration's phase A streamed per tile, on average (a sample of 256 tiles, by the first wave): the next launch's
+    // "slow tile" thresholds are absolute numbers of candidates (a lone wave's time) up to a mean of HEAVY_MEAN_REF and scale with
+    // the mean beyond — on a target four times as dense EVERY tile streams four times as many, and a third of them went to the
+    // cooperative kernel (2x the search time at 4 M points per scan).
+    int* ho = L.heavy_out + (size_t)prob * heavy_stride( L.src.n_tiles );
+    const int n_t = L.src.n_tiles, step = max( 1, n_t / ( 4 * WAVE ) );
+    unsigned long long acc = 0;                          // sum << 32 | count
+#pragma unroll
+    for( int q = 0; q < 4; ++q )
+    {
+      const int t = ( q * WAVE + sl ) * step;
+      const unsigned w = t < n_t ? (unsigned)ho[HEAVY_HDR + HEAVY_SLOTS + t] >> 2 : 0u;
+      if( w ) acc += ( (unsigned long long)w << 32 ) | 1ull;
+    }
+    acc = wave_sum_u64( acc );
+    if( sl == 0 ) { const unsigned cnt = (unsigned)acc; const unsigned mean = cnt ? (unsigned)( ( acc >> 32 ) / cnt ) : 0u; ho[HEAVY_MEAN] = (int)( mean * 256u / HEAVY_MEAN_REF ); }      // (x 256)
   }
   if( L.stat_acc )
     for( int k = threadIdx.x; k < STAT_SHARDS * 4; k += blockDim.x ) L.stat_acc[(size_t)prob * STAT_SHARDS * 4 + k] = 0ull;
+  if( L.heavy_in )      // consumed: it is the next iteration's output buffer
+    for( int k = threadIdx.x; k < HEAVY_CLASSES; k += blockDim.x ) const_cast<int*>( L.heavy_in )[(size_t)prob * heavy_stride( L.src.n_tiles ) + k] = 0;
 }
 
 #ifndef RS_XCD_MAP
@@ -1418,13 +1440,13 @@ __global__ __launch_bounds__( PA_WAVES * WAVE, BOUNDED_ONLY ? RS_ICP_WARM_OCC : 
       // front block b serves XCD class b mod 8 (it runs on the XCD the class's natural blocks run on), entry (b / 8) * 4 + wave
       const int c = (int)blockIdx.x & ( HEAVY_CLASSES - 1 ), p = ( (int)blockIdx.x >> 3 ) * PA_WAVES + wib;
       if( p >= min( uni( hv[c] ), HEAVY_PER_CLASS ) ) return;
-      tile = uni( hv[HEAVY_CLASSES + c * HEAVY_PER_CLASS + p] );
+      tile = uni( hv[HEAVY_HDR + c * HEAVY_PER_CLASS + p] );
     }
     else
     {
       tile = natural_tile( (int)blockIdx.x - HEAVY_SLOTS / PA_WAVES );
       if( tile >= L.src.n_tiles ) return;
-      const int flag = uni( hv[HEAVY_CLASSES + HEAVY_SLOTS + tile] );
+      const int flag = uni( hv[HEAVY_HDR + HEAVY_SLOTS + tile] ) & 3;
       if( flag == 1 ) return;                                            // a front slot has it
       if( BOUNDED_ONLY && flag == 2 )
       {
@@ -1433,7 +1455,7 @@ __global__ __launch_bounds__( PA_WAVES * WAVE, BOUNDED_ONLY ? RS_ICP_WARM_OCC : 
         if( lane == 0 )
         {
           int q = atomicAdd( L.queue_count + prob, 1 ); L.queue[(size_t)prob * L.src.n_tiles + q] = tile;
-          if( L.heavy_out ) L.heavy_out[(size_t)prob * heavy_stride( L.src.n_tiles ) + HEAVY_CLASSES + HEAVY_SLOTS + tile] = 2;
+          if( L.heavy_out ) L.heavy_out[(size_t)prob * heavy_stride( L.src.n_tiles ) + HEAVY_HDR + HEAVY_SLOTS + tile] = 2;
           if( DBG( L ) ) { DBG( L )[2 * tile] = wall_clock64(); DBG( L )[2 * tile + 1] = 1ull << 20; }      // (handed off, no time spent)
         }
         return;
@@ -1456,8 +1478,15 @@ __global__ __launch_bounds__( PA_WAVES * WAVE, BOUNDED_ONLY ? RS_ICP_WARM_OCC : 
   int unsettled[4] = { 0, 0, 0, 0 };
   const Match init = icp_warm_start( L, prob, i, active, qx, qy, qz, nx, ny, nz );
   const bool search = active & !icp_certificate( L, prob, i, active & !init.found, qx, qy, qz, nx, ny, nz );
+  // thresholds in candidates: as given up to a mean of HEAVY_MEAN_REF candidates per tile in the previous launch, growing with it
+  // beyond (the factor, in 1/256ths, was worked out when that iteration ended: icp_iteration_reset)
+  const unsigned scale_q8 = L.heavy_in ? (unsigned)uni( L.heavy_in[(size_t)prob * heavy_stride( L.src.n_tiles ) + HEAVY_MEAN] ) : 256u;
+  const unsigned sq8 = scale_q8 < 256u ? 256u : ( scale_q8 > 65536u ? 65536u : scale_q8 );
+  const int thr_total = (int)( ( (unsigned)min( L.heavy_total, 0xffff ) * sq8 ) >> 8 );
+  const uint32_t thr_streamed = ( (unsigned)min( L.heavy_streamed, 0xffff ) * sq8 ) >> 8;
+  const uint32_t thr_handoff = ( (unsigned)min( L.heavy_handoff, 0xffff ) * sq8 ) >> 8;
   Match m = tile_search<true, true, BOUNDED_ONLY>( L.tgt, search, qx, qy, qz, nx, ny, nz, L.radius, L.radius_sq, L.gate_tmin, L.K,
-                               lds[wib], lane, L.solo_stages, &handoff, DBG( L ) ? unsettled : nullptr, init, &sweeps, L.by_rows != 0, &streamed, L.heavy_total );
+                               lds[wib], lane, L.solo_stages, &handoff, DBG( L ) ? unsettled : nullptr, init, &sweeps, L.by_rows != 0, &streamed, thr_total );
   if( L.heavy_out && lane == 0 )
   {
     int* hv = L.heavy_out + (size_t)prob * heavy_stride( L.src.n_tiles );
@@ -1465,8 +1494,8 @@ __global__ __launch_bounds__( PA_WAVES * WAVE, BOUNDED_ONLY ? RS_ICP_WARM_OCC : 
     // What will be slow next time.  A warm launch hands its unbounded tiles off at once — they cost it nothing — and its slow
     // tiles are the ones that stream many candidates in their one sweep (p50 150 candidates / 12 us, p99.9 750 / 40 us: left in
     // natural order those start half way through the launch and ARE its tail); the cold launch's are its multi-shell tiles.
-    const bool slow = BOUNDED_ONLY ? ( !handoff && streamed >= (uint32_t)L.heavy_streamed ) : ( handoff || sweeps >= 2 || streamed >= (uint32_t)L.heavy_streamed );
-    if( BOUNDED_ONLY && !handoff && streamed >= (uint32_t)L.heavy_handoff ) listed = 2;
+    const bool slow = BOUNDED_ONLY ? ( !handoff && streamed >= thr_streamed ) : ( handoff || sweeps >= 2 || streamed >= thr_streamed );
+    if( BOUNDED_ONLY && !handoff && streamed >= thr_handoff ) listed = 2;
     else if( slow )
     {
 #if RS_XCD_MAP
@@ -1475,9 +1504,11 @@ __global__ __launch_bounds__( PA_WAVES * WAVE, BOUNDED_ONLY ? RS_ICP_WARM_OCC : 
       const int c = ( tile / PA_WAVES ) & ( HEAVY_CLASSES - 1 );
 #endif
       const int pos = atomicAdd( hv + c, 1 );
-      if( pos < HEAVY_PER_CLASS ) { hv[HEAVY_CLASSES + c * HEAVY_PER_CLASS + pos] = tile; listed = 1; }
+      if( pos < HEAVY_PER_CLASS ) { hv[HEAVY_HDR + c * HEAVY_PER_CLASS + pos] = tile; listed = 1; }
     }
-    hv[HEAVY_CLASSES + HEAVY_SLOTS + tile] = listed;
+    // per tile: flag (bits 0-1) | candidates streamed by this launch (handed off: 0, not counted) — one store; the mean over a sample
+    // of these words is the next launch's yardstick (icp_iteration_reset).  (Summing them with atomics cost 33 us per launch.)
+    hv[HEAVY_HDR + HEAVY_SLOTS + tile] = listed | ( handoff ? 0 : (int)( min( streamed, 0x0fffffffu ) << 2 ) );
   }
   if( DBG( L ) && lane == 0 )
   {
