@@ -98,7 +98,12 @@ def load():
             "(there is no CPU fallback for the hot path)")
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            if "RS_HIP_LIB" in os.environ:        # an A/B build of an older tree may predate an entry point
+                continue
+            raise
         fn.restype = res
         fn.argtypes = args
     _lib = lib

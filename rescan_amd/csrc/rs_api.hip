@@ -1470,10 +1470,11 @@ int rs_hip_radius_search( const rs_hip_cloud_t* target, const float* query, int6
     static const size_t zero_copy_below = getenv( "RS_HIP_ROWS_ZERO_COPY_BELOW" ) ? (size_t)atoll( getenv( "RS_HIP_ROWS_ZERO_COPY_BELOW" ) ) : ( 256u << 10 );
     if( down_words * 4 <= zero_copy_below )
     {
-      // ... and the synchronisation is the host polling the counts: every wave stores its row, then (after a system-scope fence)
-      // the row's count, which the host pre-set to a sentinel; the runtime's own completion wait costs more than the kernel
-      // (RS_HIP_ROWS_NO_POLL=1: hipStreamSynchronize; it is also what a poll of 2 ms without an answer falls back to)
-      static const bool poll = !getenv( "RS_HIP_ROWS_NO_POLL" );
+      // (RS_HIP_ROWS_POLL=1, off by default: instead of synchronising the stream the host polls the counts — every wave stores its
+      //  row, then, after a system-scope fence, the row's count, which the host pre-set to a sentinel.  3 us less per call, and not
+      //  safe: in one of ~60 suite runs a row was read before it had arrived — writes to host memory over PCIe may pass each
+      //  other, a fence on the device does not order their ARRIVAL; only the runtime's completion signal does.)
+      static const bool poll = getenv( "RS_HIP_ROWS_POLL" ) != nullptr;
       const int pending = INT_MIN;
       if( poll ) for( int i = 0; i < nq; ++i ) ( (volatile int*)h_nn )[i] = pending;
       { ProfScope ps( "nn_rows" );

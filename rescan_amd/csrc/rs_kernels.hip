@@ -1344,6 +1344,7 @@ __device__ __forceinline__ void icp_emit( const IcpLaunch& L, int prob, int tile
 }
 
 // What has to be reset between two searches of a problem (done by the workgroup that ends the iteration).
+// Called by EVERY thread of the workgroup that ends an iteration (at least one full wave).
 __device__ __forceinline__ void icp_iteration_reset( const IcpLaunch& L, int prob )
 {
   if( threadIdx.x == 0 )
@@ -1374,8 +1375,8 @@ __device__ __forceinline__ void icp_iteration_reset( const IcpLaunch& L, int pro
   }
   if( L.stat_acc )
     for( int k = threadIdx.x; k < STAT_SHARDS * 4; k += blockDim.x ) L.stat_acc[(size_t)prob * STAT_SHARDS * 4 + k] = 0ull;
-  if( L.heavy_in )      // consumed: it is the next iteration's output buffer
-    for( int k = threadIdx.x; k < HEAVY_CLASSES; k += blockDim.x ) const_cast<int*>( L.heavy_in )[(size_t)prob * heavy_stride( L.src.n_tiles ) + k] = 0;
+  if( L.heavy_in && threadIdx.x == 0 )      // consumed: it is the next iteration's output buffer
+    for( int k = 0; k < HEAVY_CLASSES; ++k ) const_cast<int*>( L.heavy_in )[(size_t)prob * heavy_stride( L.src.n_tiles ) + k] = 0;
 }
 
 #ifndef RS_XCD_MAP
@@ -2441,8 +2442,9 @@ __global__ __launch_bounds__( WAVE ) void k_replay_walk( IcpLaunch L, ReplayBufs
 __global__ __launch_bounds__( WAVE ) void k_replay_finish( IcpLaunch L, ReplayBufs B )
 {
   const int prob = blockIdx.x;
-  if( L.active[prob] == 0 || threadIdx.x != 0 ) return;
-  if( L.solve ) icp_iteration_reset( L, prob );
+  if( L.active[prob] == 0 ) return;
+  if( L.solve ) icp_iteration_reset( L, prob );            // (by the whole wave: it averages a sample of per-tile counts)
+  if( threadIdx.x != 0 ) return;
   const double* totals = B.totals + (size_t)prob * 3 * ICP_NMOM;
   FaithPar P;
   const bool ok = replay_params( L, prob, 3, totals, P );
