@@ -123,22 +123,26 @@ class RoleRunner:
     """Runs the three consumers of a step side by side, each always on the same host thread (i.e. on the same HIP stream and CU
     set), and joins them.
 
-    spin (default): the score batch — the longest of the three — runs on the CALLING thread, the ICP chain and the label pass on
-    two worker threads that never sleep: between steps they busy-wait inside the library (rs_hip_spin_wait, no interpreter
-    lock held) for a flag the caller's next library call stores on entry (rs_hip_post_on_next_call), and the caller busy-waits
-    for theirs.  With executors every step is three submissions and three future waits, i.e. six wake-ups of sleeping
+    spin (default): the longest of the three — the ICP chain (RS_BENCH_MAIN_ROLE=icp|score|label; it was the score batch
+    until that got single-wave workgroups) — runs on the CALLING thread, the two others on worker threads that never sleep:
+    between steps they busy-wait inside the library (rs_hip_spin_wait, no interpreter lock held) for a flag the caller's next
+    library call stores on entry (rs_hip_post_on_next_call: the longest consumer is under way before the others are released,
+    the second-longest first), and the caller busy-waits for theirs.  With executors every step is three submissions and three future waits, i.e. six wake-ups of sleeping
     threads by the host scheduler — usually tens of microseconds each, but on the shared 256-thread hosts of this pool one
     step in ~35 lost 1.5-3 ms there while all three library calls took their usual time (tools/throttle_check.sh: no cgroup
     throttling in the region; the time is between the calls).  RS_BENCH_SPIN=0: three single-thread executors as before."""
 
     ICP, SCORE, LABEL = 0, 1, 2
 
-    def __init__(self, masks, spin):
+    def __init__(self, masks, spin, main_role=0):
         import threading
         from concurrent.futures import ThreadPoolExecutor
         from rescan_amd import capi
         self.capi, self.spin, self.k, self.stop, self.masked = capi, spin, 0, False, bool(masks)
         self.fns, self.out, self.dt = [None] * 3, [None] * 3, [0.0] * 3
+        self.main = main_role
+        # release order of the workers: the score batch before the label pass
+        self.workers = [r for r in (self.SCORE, self.ICP, self.LABEL) if r != main_role]
         if not spin:
             self.pools = [ThreadPoolExecutor(max_workers=1) for _ in range(3)]
             if masks:
@@ -149,11 +153,11 @@ class RoleRunner:
         self.addr = lambda kind, r: self.flags.ctypes.data + 4 * (4 * kind + r)
         self.failed = None
         if masks:
-            capi.stream_cu_mask(masks[self.SCORE])    # the calling thread's stream takes the score batch
-        self.threads = [threading.Thread(target=self._worker, args=(r, masks[r] if masks else None), daemon=True) for r in (self.ICP, self.LABEL)]
+            capi.stream_cu_mask(masks[self.main])     # the calling thread's stream takes the main role's CUs
+        self.threads = [threading.Thread(target=self._worker, args=(r, masks[r] if masks else None), daemon=True) for r in self.workers]
         for t in self.threads:
             t.start()
-        for r in (self.ICP, self.LABEL):
+        for r in self.workers:
             capi.spin_wait(self.addr(2, r), 1, 60.0)
         if self.failed is not None:
             raise self.failed
@@ -175,8 +179,8 @@ class RoleRunner:
                     capi.stream_cu_mask(None)         # (a profiler's finalisation does not survive masked streams)
                 capi.spin_post(self.addr(1, r), 1 << 30)
                 return
-            if r == self.ICP:
-                capi.post_on_next_call(self.addr(0, self.LABEL), k)       # the label thread goes once this one is inside the library
+            if r == self.workers[0]:
+                capi.post_on_next_call(self.addr(0, self.workers[1]), k)  # the second worker goes once this one is inside the library
             t = time.perf_counter()
             try:
                 out = self.fns[r]()
@@ -201,16 +205,16 @@ class RoleRunner:
             capi = self.capi
             self.k += 1
             self.fns = fns
-            capi.post_on_next_call(self.addr(0, self.ICP), self.k)          # the ICP thread goes once this one is inside the library
+            capi.post_on_next_call(self.addr(0, self.workers[0]), self.k)   # the first worker goes once this thread is inside the library
             t = time.perf_counter()
             try:
-                mine = score()
+                mine = fns[self.main]()
             finally:
                 capi.post_pending()
-            self.dt[self.SCORE] = time.perf_counter() - t
-            capi.spin_wait(self.addr(1, self.ICP), self.k, 120.0)
-            capi.spin_wait(self.addr(1, self.LABEL), self.k, 120.0)
-            outs = [self.out[self.ICP], mine, self.out[self.LABEL]]
+            self.dt[self.main] = time.perf_counter() - t
+            for r in self.workers:
+                capi.spin_wait(self.addr(1, r), self.k, 120.0)
+            outs = [mine if r == self.main else self.out[r] for r in range(3)]
             for o in outs:
                 if isinstance(o, BaseException):
                     raise o
@@ -228,9 +232,9 @@ class RoleRunner:
                 for ex in self.pools:
                     ex.submit(self.capi.stream_cu_mask, None).result()
             return
-        for r in (self.ICP, self.LABEL):
+        for r in self.workers:
             self.capi.spin_post(self.addr(0, r), 1 << 30)
-        for r in (self.ICP, self.LABEL):
+        for r in self.workers:
             self.capi.spin_wait(self.addr(1, r), 1 << 30, 30.0)
         if self.masked:
             self.capi.stream_cu_mask(None)
@@ -275,12 +279,13 @@ def _roles():
             note = "CU mask bits [0,%d) (%d CUs of every shader engine of every XCD) ICP chain%s, [%d,%d) score batch%s" % (
                 k, k // 32, " + label pass" if label_on == "chain" else "", lo, n_cu, " + label pass" if label_on == "batch" else "")
         try:
-            runner = RoleRunner(masks, spin)
+            main_role = {"icp": 0, "score": 1, "label": 2}[os.environ.get("RS_BENCH_MAIN_ROLE", "icp")]
+            runner = RoleRunner(masks, spin, main_role)
             if masks:
                 _CU_SHARES.update({"nn_icp": f_chain, "icp_moments": f_chain, "nn_score": f_batch, "nn_label": f_label})
         except Exception as e:               # a runtime without CU masks: plain streams
-            runner, note = RoleRunner(None, spin), "none (%s)" % e
-        _ROLE_POOLS = [runner, note + ("; consumers joined by spinning (score batch on the calling thread)" if spin else "; consumers on three executors")]
+            runner, note = RoleRunner(None, spin, main_role), "none (%s)" % e
+        _ROLE_POOLS = [runner, note + ("; consumers joined by spinning (%s on the calling thread)" % os.environ.get("RS_BENCH_MAIN_ROLE", "icp") if spin else "; consumers on three executors")]
     return _ROLE_POOLS[0]
 
 

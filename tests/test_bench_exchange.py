@@ -60,6 +60,7 @@ def test_role_runner_joins_three_consumers_without_sleeping():
     from rescan_amd import build
     build.build()
     r = bench.RoleRunner(None, True)
+    assert r.workers == [bench.RoleRunner.SCORE, bench.RoleRunner.LABEL]        # released in this order
     names = {}
 
     def fn(tag, k):
@@ -72,7 +73,7 @@ def test_role_runner_joins_three_consumers_without_sleeping():
         out = r.run3(fn("icp", k), fn("score", k), fn("label", k))
         assert out == [("icp", k), ("score", k), ("label", k)]
     assert all(len(v) == 1 for v in names.values()) and len({next(iter(v)) for v in names.values()}) == 3
-    assert next(iter(names["score"])) == threading.current_thread().name          # the longest consumer runs on the caller
+    assert next(iter(names["icp"])) == threading.current_thread().name            # the longest consumer (role 0 by default) runs on the caller
 
     def boom():
         raise ValueError("from the label thread")
