@@ -278,8 +278,8 @@ def _roles():
             f_label = {"chain": f_chain, "batch": f_batch, "all": 1.0}[label_on]
             note = "CU mask bits [0,%d) (%d CUs of every shader engine of every XCD) ICP chain%s, [%d,%d) score batch%s" % (
                 k, k // 32, " + label pass" if label_on == "chain" else "", lo, n_cu, " + label pass" if label_on == "batch" else "")
+        main_role = {"icp": 0, "score": 1, "label": 2}.get(os.environ.get("RS_BENCH_MAIN_ROLE", "icp"), 0)
         try:
-            main_role = {"icp": 0, "score": 1, "label": 2}[os.environ.get("RS_BENCH_MAIN_ROLE", "icp")]
             runner = RoleRunner(masks, spin, main_role)
             if masks:
                 _CU_SHARES.update({"nn_icp": f_chain, "icp_moments": f_chain, "nn_score": f_batch, "nn_label": f_label})
@@ -287,6 +287,14 @@ def _roles():
             runner, note = RoleRunner(None, spin, main_role), "none (%s)" % e
         _ROLE_POOLS = [runner, note + ("; consumers joined by spinning (%s on the calling thread)" % os.environ.get("RS_BENCH_MAIN_ROLE", "icp") if spin else "; consumers on three executors")]
     return _ROLE_POOLS[0]
+
+
+def close_roles():
+    """Parks the process's RoleRunner (its spinning workers, its CU-masked streams); the next concurrent step makes a new one."""
+    global _ROLE_POOLS
+    if _ROLE_POOLS:
+        _ROLE_POOLS[0].close()
+        _ROLE_POOLS = None
 
 
 def host_cpu_stat():

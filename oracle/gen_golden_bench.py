@@ -17,7 +17,13 @@ container only; the fixtures are committed so the GPU box, which has no /root/re
         reference's own icp_align (stop test included): final pose, error; iteration counts from ref_icp_iterate
         with the stop test on (same loop; asserted to end at the same pose bit for bit)
 
-Usage:  python oracle/gen_golden_bench.py [--bench-only [--seed N] | --sweep-only]
+  tests/golden/bench_seed31.npz … bench_seed38.npz   (round 3) eight more rooms of the headline's size, the same
+        fields — labels as a sha256 + a strided sample instead of whole, to keep the files at a few KB — plus
+        stop_pose / stop_err / stop_iters / stop_params: the reference's own icp_align, STOP TEST ON (lib/rs/icp.h:489),
+        on the same two ~0.98 M-point scans, the three call sites' parameter sets in turn and start poses from
+        5 mm / 0.3 deg to 3 cm / 2 deg (MORE_SEEDS, more_stop_case)
+
+Usage:  python oracle/gen_golden_bench.py [--bench-only [--seed N] | --sweep-only | --more [--seed N]]
 """
 import ctypes as C
 import hashlib
@@ -35,6 +41,7 @@ from rescan_amd import synth  # noqa: E402
 OUT = os.path.join(ROOT, "tests", "golden")
 I4 = np.eye(4, dtype=np.float32).ravel()
 BENCH_SEEDS = [11, 23]            # 11: the bench's own workload; 23: a second room of the same size
+MORE_SEEDS = list(range(31, 39))  # round 3: further rooms of the headline's size, with a stop-test-on icp_align run each
 SWEEP_SEEDS = list(range(1, 25))
 SWEEP_POINTS = 120_000
 
@@ -66,7 +73,16 @@ def sweep_inputs(seed):
     return s0, s1, T0, np.float32(max_dist), np.float32(np.deg2rad(max_angle))
 
 
-def gen_bench(R, O, seed=11):
+def more_stop_case(seed):
+    """The stop-test-on icp_align case of room `seed`: parameters of the reference's three call sites in turn
+     and a start pose whose size cycles independently."""
+    rng = np.random.default_rng(7000 + seed)
+    max_dist, max_angle = [(0.10, 60.0), (0.075, 50.0), (0.05, 10.0)][seed % 3]
+    T0 = synth.perturbed_pose(I4, rng, [0.005, 0.015, 0.03][(seed // 2) % 3], [0.005, 0.01, 0.03][(seed // 3) % 3])
+    return T0, np.float32(max_dist), np.float32(np.deg2rad(max_angle))
+
+
+def gen_bench(R, O, seed=11, more=False):
     import bench
     t = time.time()
     w = bench.build_inputs(1_000_000, seed=seed)
@@ -86,13 +102,23 @@ def gen_bench(R, O, seed=11):
     plcs = [dict(pose=p["pose"], object_idx=k, uidx=k) for k, p in enumerate(w["plc"])]
     lab = O.arrangement_to_labels(s1["points"], s1["normals"], objs, plcs, 0.05, 0, 0)
     print(f"labels: {int((lab['labels'] > 0).sum())} labelled ({time.time()-t:.1f} s)", flush=True)
+    extra = dict(labels=lab["labels"])
+    if more:
+        t = time.time()
+        T0s, md, ma = more_stop_case(seed)
+        e, Ts, _ = R.icp_align(s1["points"], s1["normals"], s0["points"], s0["normals"], T0s, I4, md, ma)
+        Ts2, e2, sdone, _, _ = ref_iterate(R, s1["points"], s1["normals"], s0["points"], s0["normals"], T0s, I4, md, ma, 100, 1)
+        assert (Ts2 == Ts).all() and np.float32(e) == e2, "ref_icp_iterate (stop test on) must BE icp_align"
+        print(f"icp_align (stop test on): r {md:.3f} iters {sdone} err {e:.6f} ({time.time()-t:.1f} s)", flush=True)
+        extra = dict(labels_sha=sha(lab["labels"]), labels_sample=lab["labels"][::257].copy(), n_labelled=int((lab["labels"] > 0).sum()),
+                     stop_T0=T0s, stop_pose=Ts, stop_err=np.float32(e), stop_iters=np.int32(sdone), stop_params=np.array([md, ma], np.float32))
     np.savez_compressed(
-        os.path.join(OUT, "bench_seed%d.npz" % seed),
+        os.path.join(OUT, "bench_seed%d.npz" % seed), **extra,
         n_points=1_000_000, seed=seed, n_scan0=w["n_scan0"], n_scan1=w["n_scan1"], n_obj=w["n_obj"],
         in_sha=np.array([sha(s0["points"]), sha(s0["normals"]), sha(s1["points"]), sha(s1["normals"]), sha(op), sha(on),
                          sha(w["score_poses"]), sha(w["plc_poses"]), sha(w["icp_T0"])]),
         icp_T0=w["icp_T0"], icp_pose=T, icp_err=err, icp_n_corrs=nc, icp_errs=errs,
-        scores=scores, labels=lab["labels"], order=lab["order"],
+        scores=scores, order=lab["order"],
         min_dists_sha=sha(lab["min_dists"]), min_dists_sample=lab["min_dists"][::257].copy())
 
 
@@ -115,6 +141,11 @@ def gen_sweep(R):
 if __name__ == "__main__":
     build(ref=True)
     R, O = Ref(), Oracle()
+    if "--more" in sys.argv:
+        for seed in MORE_SEEDS:
+            if "--seed" not in sys.argv or str(seed) == sys.argv[sys.argv.index("--seed") + 1]:
+                gen_bench(R, O, seed, more=True)
+        sys.exit(0)
     if "--sweep-only" not in sys.argv:
         for seed in BENCH_SEEDS:
             if "--seed" not in sys.argv or str(seed) == sys.argv[sys.argv.index("--seed") + 1]:

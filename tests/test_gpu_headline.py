@@ -127,6 +127,50 @@ def test_headline_sharded_route_is_bit_identical(capi, bench_mod, headline):
         assert (labels == lab0["labels"]).all() and (mind == lab0["min_dists"]).all(), f"world {world}: labels"
 
 
+MORE_SEEDS = list(range(31, 39))
+
+
+def _close_workload(w):
+    for c in [w["scan0"], w["scan1"], w["obj_score"]] + [p["cloud"] for p in w["plc"]]:
+        c.close()
+
+
+@pytest.mark.parametrize("seed", MORE_SEEDS)
+def test_more_headline_rooms_vs_reference(capi, bench_mod, seed):
+    """Eight more rooms of the headline's size (round 3: oracle/gen_golden_bench.py --more), each through the DEFAULT path
+    at that size.  Every one must hold north_star's bar — no budget of exceptions: the step's ICP (10 fixed iterations) and
+    the reference's own icp_align WITH its stop test (lib/rs/icp.h:489; the three call sites' parameters in turn, start poses
+    from 5 mm / 0.3 deg to 3 cm / 2 deg) end within 1e-4 Frobenius of the reference's pose, the 256 scores within 2e-6,
+    labels / min_dists bit for bit."""
+    g = load_golden("bench_seed%d.npz" % seed)
+    w = bench_mod.build_workload(int(g["n_points"]), seed=int(g["seed"]), knn="hash")
+    try:
+        s0, s1 = w["s0"], w["s1"]
+        op, on = w["obj_score_np"]
+        got = [sha(s0["points"]), sha(s0["normals"]), sha(s1["points"]), sha(s1["normals"]), sha(op), sha(on),
+               sha(w["score_poses"]), sha(w["plc_poses"]), sha(w["icp_T0"])]
+        assert got == [str(x) for x in g["in_sha"]], "the generator no longer produces the inputs the fixture was made for"
+        err, T, it = capi.icp_align(w["scan1"], w["scan0"], w["icp_T0"], I4, 0.10, np.deg2rad(60.0), max_iter=bench_mod.ICP_ITERS, fixed_iters=True)
+        d_fixed = np.linalg.norm(T.astype(np.float64) - g["icp_pose"].astype(np.float64))
+        md, ma = float(g["stop_params"][0]), float(g["stop_params"][1])
+        e2, T2, it2 = capi.icp_align(w["scan1"], w["scan0"], g["stop_T0"], I4, md, ma)
+        d_stop = np.linalg.norm(T2.astype(np.float64) - g["stop_pose"].astype(np.float64))
+        sc = capi.alignment_scores(w["obj_score"], w["scan1"], w["score_poses"], 0.1, 64)
+        d_sc = np.abs(sc.astype(np.float64) - g["scores"].astype(np.float64)).max()
+        res = capi.arrangement_to_labels(w["scan1"], w["plc_poses"], [p["cloud"] for p in w["plc"]], [0] * len(w["plc"]),
+                                         [p["cls"] for p in w["plc"]], 0.05, False)
+        print(f"seed {seed}: 10 fixed iterations {d_fixed:.3e} from the reference (err {err:.7f} vs {float(g['icp_err']):.7f}); "
+              f"icp_align r {md:.3f}: {d_stop:.3e}, {it2} vs {int(g['stop_iters'])} iterations, err {e2:.7f} vs {float(g['stop_err']):.7f}; "
+              f"scores max abs {d_sc:.2e}, {int((sc == g['scores']).sum())} of {len(sc)} bit-identical")
+        assert it == bench_mod.ICP_ITERS and d_fixed < POSE_TOL and abs(err - float(g["icp_err"])) < 1e-5
+        assert d_stop < POSE_TOL, f"icp_align with the stop test: {d_stop:.3e} from the reference ({it2} vs {int(g['stop_iters'])} iterations)"
+        assert d_sc < SCORE_TOL
+        assert (res["order"] == g["order"]).all()
+        assert sha(res["labels"]) == str(g["labels_sha"]) and sha(res["min_dists"]) == str(g["min_dists_sha"])
+    finally:
+        _close_workload(w)
+
+
 def test_label_rows_in_all_three_forms(capi, headline):
     """rs_hip_label_rows: host rows (input order), device rows in input order, device rows in the scene's query order — the
     last folded by rs_hip_fold_label_rows_device with the scene cloud — all give the rows / labels of the placement loop."""
@@ -201,4 +245,8 @@ def test_scan_sized_icp_sweep_vs_reference(capi):
     print(f"fp64 moments: {len(over)} of {len(g['seeds'])} runs end >= 1e-4 from the reference (worst {worst:.2e}); {iter_diff} stop an iteration apart")
     print(f"reference order: {exact} of {len(g['seeds'])} bit-identical (pose, error, iterations)")
     assert exact >= len(g["seeds"]) - 1              # (an exact fp32 distance tie may cost one run a few 1e-5)
-    assert len(over) <= 4 and worst < 5e-4, over    # the policy data: see DESIGN.md §4 for what follows from it
+    # The DEFAULT estimator for sources of this size (65 537 .. 262 144 points) is the parallel reference order, held to the
+    # reference bit for bit above (and to north_star's 1e-4 in every run: `dr < POSE_TOL` for the sequential chains, whose
+    # bits it shares: replay_exact == exact).  The fp64 moments are NOT the default here; their distances are data for
+    # DESIGN.md §4's policy (where the default IS the fp64 moments — sources above 262 144 points — every fixture is held
+    # to 1e-4 without exception: test_more_headline_rooms_vs_reference, test_headline_icp_vs_reference).

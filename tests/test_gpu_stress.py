@@ -1,0 +1,141 @@
+"""Repeat / stress tests of the places where a bit-exact contract can break only sometimes (round 2 found a 1-in-25 race in
+the parallel reference-order estimator and withdrew a polled zero-copy path whose rows arrived late once in ~60 suite runs):
+a single pass of the suite cannot see such failures, so these run the same inputs many times — from one thread and from
+several — and demand identical bits every time.  Sized to finish within about a minute on the GPU box.
+
+* the batched ICP with the parallel reference-order estimator ("replay") against the one-problem-at-a-time runs, 32 times;
+* replay against the sequential chains on a scan-sized source, 32 times;
+* small radius searches through the zero-copy (pinned-block) route of k_rows_wave from three host threads at once, each
+  thread with its own queries, 300 calls per thread, every call compared with the first answer;
+* the three consumers of bench.py's step issued from three threads against the same step issued serially.
+"""
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+I4 = np.eye(4, dtype=np.float32).ravel()
+REPEATS = 32
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from rescan_amd import capi
+    capi.init(0)
+    return capi
+
+
+@pytest.fixture(scope="module")
+def clouds(capi, gscene):
+    scn = capi.Cloud(gscene["points"], gscene["normals"], cell_size=0.2)
+    objs = [capi.Cloud(o["pos"], o["nor"], cell_size=0.1) for o in gscene["objects"]]
+    return scn, objs
+
+
+def _key(err, T, it):
+    return np.float32(err).tobytes() + np.asarray(T, np.float32).tobytes() + np.int32(it).tobytes()
+
+
+def test_parallel_chains_batch_matches_single_repeatedly(capi, gscene, clouds):
+    """tests/test_gpu_parity.py::test_icp_batch_matches_single[parallel chains], REPEATS times: the batch, whose problems
+    advance side by side through the replay kernels, returns the bits of the problems run alone — every time."""
+    from rescan_amd import synth
+    scn, objs = clouds
+    o = gscene["objects"][1]
+    rng = np.random.default_rng(3)
+    T0s = np.stack([synth.perturbed_pose(o["pose"], rng) for _ in range(5)])
+    prev, prev_r = capi.icp_reference_order_below(-1), capi.icp_replay_below(-1)
+    try:
+        capi.icp_reference_order_below(0); capi.icp_replay_below(1 << 30)
+        single = [_key(*capi.icp_align(objs[1], scn, T0s[k], I4, 0.1, np.deg2rad(60.0))) for k in range(5)]
+        bad = []
+        for rep in range(REPEATS):
+            errs, Ts, its = capi.icp_align_batch(objs[1], scn, T0s, I4, 0.1, np.deg2rad(60.0))
+            bad += [(rep, k) for k in range(5) if _key(errs[k], Ts[k], its[k]) != single[k]]
+            if rep % 8 == 7:                                     # the single runs must not drift either
+                bad += [(rep, -1 - k) for k in range(5) if _key(*capi.icp_align(objs[1], scn, T0s[k], I4, 0.1, np.deg2rad(60.0))) != single[k]]
+        assert not bad, f"(repeat, problem) pairs that differ: {bad}"
+        capi.icp_reference_order_below(1 << 30)                  # and they are the sequential chains' bits
+        assert [_key(*capi.icp_align(objs[1], scn, T0s[k], I4, 0.1, np.deg2rad(60.0))) for k in range(5)] == single
+    finally:
+        capi.icp_reference_order_below(prev); capi.icp_replay_below(prev_r)
+
+
+def test_replay_matches_sequential_chains_repeatedly(capi):
+    """A scan-sized source (the replay's own regime: thousands of segments, hundreds of superblocks per accumulator):
+    REPEATS runs of the parallel chains return the one result of the sequential chains."""
+    from rescan_amd import synth
+    s0 = synth.scene_for_point_count(90_000, seed=29, timestep=0)
+    s1 = synth.scene_for_point_count(90_000, seed=29, timestep=1)
+    a, b = capi.Cloud(s0["points"], s0["normals"]), capi.Cloud(s1["points"], s1["normals"])
+    T0 = synth.perturbed_pose(I4, np.random.default_rng(4), 0.02, 0.02)
+    prev, prev_r = capi.icp_reference_order_below(-1), capi.icp_replay_below(-1)
+    try:
+        capi.icp_reference_order_below(1 << 30)
+        ref = _key(*capi.icp_align(b, a, T0, I4, 0.1, np.deg2rad(60.0), max_iter=8, fixed_iters=True))
+        capi.icp_reference_order_below(0); capi.icp_replay_below(1 << 30)
+        bad = [rep for rep in range(REPEATS) if _key(*capi.icp_align(b, a, T0, I4, 0.1, np.deg2rad(60.0), max_iter=8, fixed_iters=True)) != ref]
+        assert not bad, f"repeats that differ from the sequential chains: {bad}"
+    finally:
+        capi.icp_reference_order_below(prev); capi.icp_replay_below(prev_r)
+        a.close(); b.close()
+
+
+def test_small_searches_from_three_threads(capi, gscene):
+    """The unchanged apps' call pattern (~130 queries per call, K = 64: one launch on device-visible pinned blocks, one
+    synchronisation — DESIGN.md §3 k_rows_wave) from three host threads at once, each with its own stream, pinned blocks
+    and queries: 300 calls per thread, every answer identical to the thread's first, and the first identical to the same
+    call made alone."""
+    scn = capi.Cloud(gscene["points"], None, cell_size=0.1)
+    rng = np.random.default_rng(12)
+    n_threads, n_calls = 3, 300
+    queries = []
+    for t in range(n_threads):
+        base = gscene["points"][rng.integers(0, len(gscene["points"]), 130)]
+        queries.append(np.ascontiguousarray(base + rng.normal(0, 0.01, base.shape).astype(np.float32), np.float32))
+    alone = [capi.radius_search(scn, q, 0.1, 64) for q in queries]
+    errors = []
+
+    def worker(t):
+        try:
+            for c in range(n_calls):
+                d, i, nn, _ = capi.radius_search(scn, queries[t], 0.1, 64)
+                if not (np.array_equal(nn, alone[t][2]) and np.array_equal(d, alone[t][0]) and np.array_equal(i, alone[t][1])):
+                    errors.append((t, c)); return
+        except Exception as e:                                  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    scn.close()
+    assert not errors, f"(thread, call) that differed: {errors}"
+
+
+def test_three_consumers_side_by_side_repeatedly(capi):
+    """tools/concurrency_check.py as a test, at a size that keeps it short: bench.py's step (ICP chain, score batch, label
+    pass) issued from three threads returns the bits of the step issued serially, 12 times in a row."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    w = bench.build_workload(200_000, 11, "hash")
+    ref = bench.run_step(w, concurrent=False)
+
+    def same(got):
+        return (np.float32(got["err"]) == np.float32(ref["err"]) and (np.asarray(got["T"]) == np.asarray(ref["T"])).all()
+                and (got["scores"] == ref["scores"]).all() and (got["labels"] == ref["labels"]).all()
+                and (got["min_dists"] == ref["min_dists"]).all())
+
+    try:
+        bad = [k for k in range(12) if not same(bench.run_step(w, concurrent=True))]
+        bad += [-1 - k for k in range(2) if not same(bench.run_step(w, concurrent=False))]
+    finally:
+        bench.close_roles()                                      # (the runner's worker threads busy-wait between steps)
+    assert not bad, f"steps that differ: {bad}"
