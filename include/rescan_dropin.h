@@ -144,13 +144,21 @@ int rsd_rsdb_format_pose_line( char* out, size_t capacity, int32_t uidx, int32_t
 int rsd_rsdb_parse_pose_line( const char* line, int32_t* uidx, int32_t* arrangement_idx, int32_t* object_idx,
                               float* score, rsd_mat4_t* pose );
 
-/* The shim caches device uploads of host arrays by (pointers, count, sampled fingerprint) — SURVEY.md §8b's
- * "(pointer, n, generation)" key.  msh_hash_grid_term() invalidates what was built from its grid's array (the reference
- * terminates a level's grid right before it frees or rebuilds the level, lib/rs/rs_pointcloud.h:879-901);
- * rsd_cache_invalidate does the same for an array the caller is about to free or edit in place; rsd_cache_clear drops
- * everything.  RS_DROPIN_FULL_HASH=1 (environment) hashes whole arrays on every call instead of sampling them. */
+/* The shim caches device uploads of host arrays by (pointers, count, content hash) — SURVEY.md §8b's "(pointer, n,
+ * generation)" key.  Arrays of up to 4 MB each (RS_DROPIN_FULL_HASH_BELOW, bytes) are hashed whole on every call: an in-place
+ * edit of any byte is seen.  Larger arrays are keyed by a ~1 KB sample and their full hash is re-checked on the first and then
+ * every 16th hit: a caller that edits a LARGE array in place (same pointer, same count) MUST call rsd_cache_invalidate( ptr )
+ * before the next call that passes it — or set RS_DROPIN_FULL_HASH=1 (environment: whole arrays hashed on every call, 40 us
+ * per MB).  msh_hash_grid_term() invalidates what was built from its grid's array (the reference terminates a level's grid
+ * right before it frees or rebuilds the level, lib/rs/rs_pointcloud.h:879-901); rsd_cache_clear drops everything.  A cached
+ * cloud that a call is using stays alive until that call returns, whatever is evicted or invalidated meanwhile. */
 void  rsd_cache_clear( void );
 void  rsd_cache_invalidate( const void* host_array );
+
+/* msh_hash_grid_radius_search calls that hit a HIP error on an initialised grid and were therefore answered from the grid's
+ * host copy (the reference's search always fills its rows and counts, lib/msh/msh_hash_grid.h:1090-1259, and its callers
+ * walk them; the first such call complains on stderr).  0 in a healthy run: tests assert it. */
+unsigned long long rsd_device_failures( void );
 
 #ifdef __cplusplus
 }

@@ -3,7 +3,12 @@
 //
 // Error behaviour follows the reference: no error codes on this path.  A failing
 // HIP call prints to stderr and leaves the caller's data untouched (icp_align returns the 1e6 it
-// would have returned had it never iterated, lib/rs/icp.h:441-442).  There is no CPU fallback.
+// would have returned had it never iterated, lib/rs/icp.h:441-442).  There is no CPU fallback for
+// compute: without a usable HIP device a grid is not even initialised.  The one exception is a HIP
+// error DURING a batched msh_hash_grid_radius_search on an initialised grid: the reference's search
+// always fills n_neighbors and the rows (lib/msh/msh_hash_grid.h:1090-1259) and its callers walk
+// them unconditionally, so such a call is answered from the grid's own host copy (the one that
+// serves one-query calls), loudly: a complaint on stderr and a count in rsd_device_failures().
 
 #include "../../include/rescan_dropin.h"
 #include "../../include/rescan_hip.h"
@@ -15,7 +20,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <list>
+#include <memory>
 #include <mutex>
 #include <vector>
 
@@ -65,15 +72,22 @@ struct Timed
 // built on (the reference terminates a level's grid right before it frees or rebuilds the level's arrays,
 // lib/rs/rs_pointcloud.h:879-901), rsd_cache_invalidate( ptr ) does the same for a caller's own arrays, rsd_cache_clear()
 // for everything; RS_DROPIN_FULL_HASH=1 brings the full hash back.
+struct CloudDeleter { void operator()( rs_hip_cloud_t* c ) const { if( c ) rs_hip_cloud_destroy( c ); } };
+// A cached cloud is handed out as a shared reference: the caller keeps it for the duration of its call, so an eviction (a
+// call with more placements than the cache has entries) or an invalidation from another thread can drop the cache's entry
+// at any time — the device memory goes when the last holder lets go.
+typedef std::shared_ptr<rs_hip_cloud_t> CloudRef;
 struct Entry
 {
   const void* pos; const void* nor; int32_t n; float cell; uint64_t hash; uint64_t generation;
-  rs_hip_cloud_t* cloud;
+  uint64_t full; bool sampled; unsigned hits;      // sampled keys: the arrays' full hash when the entry was made, re-checked every kVerifyEvery hits
+  CloudRef cloud;
 };
 std::list<Entry> g_cache;
 std::mutex g_cache_mutex;
 uint64_t g_generation = 1;          // bumped by every invalidation; an entry remembers the generation it was made in
 const size_t kMaxEntries = 64;
+const unsigned kVerifyEvery = 16;
 
 inline uint64_t mix( uint64_t h, uint64_t w ) { h = ( h ^ w ) * 0xff51afd7ed558ccdull; return h ^ ( h >> 29 ); }
 
@@ -102,10 +116,18 @@ uint64_t full_hash( const void* a, const void* b, size_t bytes )
   return h;
 }
 
-uint64_t fingerprint( const void* a, const void* b, size_t bytes )
+// Arrays of up to RS_DROPIN_FULL_HASH_BELOW bytes each (default 4 MB: ~0.15 ms) are keyed by their FULL content hash — every
+// object level and every level-2 scan the reference's call sites pass; an in-place edit of any byte is seen.  Larger arrays are
+// keyed by a sample (first and last 64 bytes plus 62 blocks spread over the rest) and the full hash is re-checked on the first
+// and then every kVerifyEvery-th hit; RS_DROPIN_FULL_HASH=1 hashes everything on every call.
+size_t full_hash_below()
 {
-  static const bool full = getenv( "RS_DROPIN_FULL_HASH" ) != nullptr;
-  if( full || bytes <= 2048 ) return full_hash( a, b, bytes );
+  static const size_t v = getenv( "RS_DROPIN_FULL_HASH" ) ? ~(size_t)0 : getenv( "RS_DROPIN_FULL_HASH_BELOW" ) ? (size_t)atoll( getenv( "RS_DROPIN_FULL_HASH_BELOW" ) ) : ( (size_t)4 << 20 );
+  return v;
+}
+
+uint64_t sampled_hash( const void* a, const void* b, size_t bytes )
+{
   uint64_t h = 0x9e3779b97f4a7c15ull ^ bytes;
   for( const void* src : { a, b } )
   {
@@ -120,21 +142,39 @@ uint64_t fingerprint( const void* a, const void* b, size_t bytes )
   return h;
 }
 
-rs_hip_cloud_t* cached_cloud( const rsd_vec3_t* pos, const rsd_vec3_t* nor, int32_t n, float cell )
+CloudRef cached_cloud( const rsd_vec3_t* pos, const rsd_vec3_t* nor, int32_t n, float cell )
 {
-  const uint64_t h = fingerprint( pos, nor, (size_t)( n > 0 ? n : 0 ) * 12 );
-  std::lock_guard<std::mutex> lock( g_cache_mutex );
-  for( auto it = g_cache.begin(); it != g_cache.end(); ++it )
-    if( it->pos == pos && it->nor == nor && it->n == n && it->cell == cell && it->hash == h )
-    {
-      g_cache.splice( g_cache.begin(), g_cache, it );
-      return g_cache.front().cloud;
-    }
+  const size_t bytes = (size_t)( n > 0 ? n : 0 ) * 12;
+  const bool sampled = bytes > full_hash_below() && bytes > 2048;
+  const uint64_t h = sampled ? sampled_hash( pos, nor, bytes ) : full_hash( pos, nor, bytes );
+  {
+    std::unique_lock<std::mutex> lock( g_cache_mutex );
+    for( auto it = g_cache.begin(); it != g_cache.end(); ++it )
+      if( it->pos == pos && it->nor == nor && it->n == n && it->cell == cell && it->sampled == sampled && it->hash == h )
+      {
+        if( sampled && ( it->hits++ % kVerifyEvery ) == 0 )
+        {
+          const uint64_t expect = it->full;
+          lock.unlock();                                    // (hashing tens of MB: not under the lock)
+          const bool same = full_hash( pos, nor, bytes ) == expect;
+          lock.lock();
+          it = g_cache.begin();
+          while( it != g_cache.end() && !( it->pos == pos && it->nor == nor && it->n == n && it->cell == cell && it->sampled && it->hash == h ) ) ++it;
+          if( it == g_cache.end() ) break;                  // gone meanwhile: rebuild
+          if( !same ) { g_cache.erase( it ); break; }       // edited in place where the sample does not look: rebuild
+        }
+        g_cache.splice( g_cache.begin(), g_cache, it );
+        return g_cache.front().cloud;
+      }
+  }
+  const uint64_t full = sampled ? full_hash( pos, nor, bytes ) : h;
   rs_hip_cloud_t* c = rs_hip_cloud_create( (const float*)pos, (const float*)nor, n, cell );
-  if( !c ) { complain( "cloud upload" ); return nullptr; }
-  g_cache.push_front( Entry{ pos, nor, n, cell, h, g_generation, c } );
-  while( g_cache.size() > kMaxEntries ) { rs_hip_cloud_destroy( g_cache.back().cloud ); g_cache.pop_back(); }
-  return c;
+  if( !c ) { complain( "cloud upload" ); return CloudRef(); }
+  CloudRef ref( c, CloudDeleter() );
+  std::lock_guard<std::mutex> lock( g_cache_mutex );
+  g_cache.push_front( Entry{ pos, nor, n, cell, h, g_generation, full, sampled, 1u, ref } );
+  while( g_cache.size() > kMaxEntries ) g_cache.pop_back();        // (holders of the evicted cloud keep it alive)
+  return ref;
 }
 
 void invalidate_pointer( const void* p )
@@ -143,7 +183,7 @@ void invalidate_pointer( const void* p )
   std::lock_guard<std::mutex> lock( g_cache_mutex );
   ++g_generation;
   for( auto it = g_cache.begin(); it != g_cache.end(); )
-    if( it->pos == p || it->nor == p ) { rs_hip_cloud_destroy( it->cloud ); it = g_cache.erase( it ); } else ++it;
+    if( it->pos == p || it->nor == p ) it = g_cache.erase( it ); else ++it;
 }
 
 // ---- host side of a grid -------------------------------------------------------------------
@@ -280,7 +320,6 @@ void rsd_cache_clear( void )
 {
   std::lock_guard<std::mutex> lock( g_cache_mutex );
   ++g_generation;
-  for( auto& e : g_cache ) rs_hip_cloud_destroy( e.cloud );
   g_cache.clear();
 }
 
@@ -296,7 +335,10 @@ void msh_hash_grid_init_3d( rsd_hash_grid_t* hg, const float* pts, const int32_t
   hg->bin_table = nullptr; hg->offsets = nullptr; hg->data_buffer = nullptr;
   hg->cell_size = cell; hg->_inv_cell_size = 1.0 / cell;
   hg->_pts_dim = 3; hg->_num_threads = 1; hg->_n_pts = (size_t)( n_pts > 0 ? n_pts : 0 );
-  if( rs_hip_synchronize() != RS_HIP_OK ) { complain( "msh_hash_grid_init_3d" ); return; }     // no HIP device: no grid (there is no CPU fallback)
+  // No HIP device: no grid (there is no CPU fallback; every search on it returns 0 neighbours).  RS_DROPIN_INIT_WITHOUT_DEVICE=1
+  // is for tests of the failure path on a machine without a GPU: the grid is initialised, and every batched search then
+  // fails on the device side exactly as after a runtime error.
+  if( rs_hip_synchronize() != RS_HIP_OK && !getenv( "RS_DROPIN_INIT_WITHOUT_DEVICE" ) ) { complain( "msh_hash_grid_init_3d" ); return; }
   GridHandle* h = new GridHandle();
   h->src = pts;
   { Timed t( 0, (unsigned long long)( n_pts > 0 ? n_pts : 0 ) ); h->host.build( pts, n_pts, cell ); }
@@ -316,31 +358,58 @@ void msh_hash_grid_term( rsd_hash_grid_t* hg )
   std::memset( hg, 0, sizeof(*hg) );                     // the reference zeroes what it owns (:558-573)
 }
 
+static std::atomic<unsigned long long> g_device_failures{ 0 };
+unsigned long long rsd_device_failures( void ) { return g_device_failures.load(); }
+
+// all queries of a call from the grid's host copy (the reference's own contract: every row and every count is written)
+static size_t host_search_all( const GridHandle* h, rsd_search_desc_t* d )
+{
+  size_t total = 0;
+  for( size_t i = 0; i < d->n_query_pts; ++i )
+  {
+    const size_t c = h->host.search( d->query_pts + 3 * i, d->radius, d->max_n_neigh, d->distances_sq + i * d->max_n_neigh, d->indices + i * d->max_n_neigh );
+    if( d->n_neighbors ) d->n_neighbors[i] = c;
+    total += c;
+  }
+  return total;
+}
+
 size_t msh_hash_grid_radius_search( const rsd_hash_grid_t* hg, rsd_search_desc_t* d )
 {
-  if( !hg || !hg->data_buffer || !d || !d->query_pts || !d->distances_sq || !d->indices || d->max_n_neigh == 0 || !( d->radius > 0.0f ) ) return 0;
+  if( !hg || !d || !d->query_pts || !d->distances_sq || !d->indices || d->max_n_neigh == 0 ) return 0;
+  // the reference writes n_neighbors[i] for every query (msh_hash_grid.h:1242) and its callers read them unconditionally:
+  // a call that finds nothing — no grid, a non-positive radius — still says so per query
+  if( !hg->data_buffer || !( d->radius > 0.0f ) )
+  {
+    if( d->n_neighbors ) for( size_t i = 0; i < d->n_query_pts; ++i ) d->n_neighbors[i] = 0;
+    return 0;
+  }
   GridHandle* h = (GridHandle*)hg->data_buffer;
   const size_t host_queries = getenv( "RS_DROPIN_HOST_QUERIES" ) ? (size_t)atoll( getenv( "RS_DROPIN_HOST_QUERIES" ) ) : 4;      // (read per call: tests switch it)
   if( d->n_query_pts <= host_queries )
   {
     Timed t( 2, d->n_query_pts );
-    size_t total = 0;
-    for( size_t i = 0; i < d->n_query_pts; ++i )
-    {
-      const size_t c = h->host.search( d->query_pts + 3 * i, d->radius, d->max_n_neigh, d->distances_sq + i * d->max_n_neigh, d->indices + i * d->max_n_neigh );
-      if( d->n_neighbors ) d->n_neighbors[i] = c;
-      total += c;
-    }
-    return total;
+    return host_search_all( h, d );
   }
   rs_hip_cloud_t* c = device_cloud_of( h );
-  if( !c ) return 0;
-  Timed t( 3, d->n_query_pts );
+  int rc = RS_HIP_E_RUNTIME;
   uint64_t total = 0;
-  int rc = rs_hip_radius_search( c, d->query_pts, (int64_t)d->n_query_pts, d->radius,
-                                 (int32_t)d->max_n_neigh, d->distances_sq, d->indices, d->n_neighbors, &total );
-  if( rc ) { complain( "msh_hash_grid_radius_search" ); return 0; }
-  return (size_t)total;
+  if( c )
+  {
+    Timed t( 3, d->n_query_pts );
+    rc = rs_hip_radius_search( c, d->query_pts, (int64_t)d->n_query_pts, d->radius,
+                               (int32_t)d->max_n_neigh, d->distances_sq, d->indices, d->n_neighbors, &total );
+    if( rc ) complain( "msh_hash_grid_radius_search" );
+  }
+  if( rc == RS_HIP_OK ) return (size_t)total;
+  // A HIP error in the middle of an app run ("print to stderr ... never abort the app"): the caller's rows may be
+  // half written and its loops will walk them whatever we return, so the call is answered from the grid's host copy — the same
+  // arithmetic and order as the one-query route (tests/test_dropin.py pins it against the reference's rows) — and counted.
+  if( g_device_failures.fetch_add( 1 ) == 0 )
+    fprintf( stderr, "[rescan_hip] msh_hash_grid_radius_search: the device path failed; this call and any later failing one are answered "
+                     "from the grid's host copy (slow).  rsd_device_failures() counts them.\n" );
+  Timed t( 2, d->n_query_pts );
+  return host_search_all( h, d );
 }
 
 // ---- icp ----------------------------------------------------------------------------------
@@ -352,12 +421,12 @@ float icp_align( rsd_vec3_t* pts1, rsd_vec3_t* nor1, int32_t n_pts1, rsd_vec3_t*
   // change results here, so the clouds use the density-derived cell (fastest, and shared with the
   // score / label entry points through the cache)
   Timed timed( 4, (unsigned long long)( n_pts1 > 0 ? n_pts1 : 0 ) );
-  rs_hip_cloud_t* src = cached_cloud( pts1, nor1, n_pts1, -1.0f );
-  rs_hip_cloud_t* tgt = cached_cloud( pts2, nor2, n_pts2, -1.0f );
+  const CloudRef src = cached_cloud( pts1, nor1, n_pts1, -1.0f );      // (held until the call returns: see CloudRef)
+  const CloudRef tgt = cached_cloud( pts2, nor2, n_pts2, -1.0f );
   float err = 1e6f; int32_t iters = 0;
   if( !src || !tgt ) return err;
   rsd_mat4_t t = *T1;
-  int rc = rs_hip_icp_align( src, tgt, t.data, T2.data, max_dist, max_angle, 100, 0, &err, &iters );
+  int rc = rs_hip_icp_align( src.get(), tgt.get(), t.data, T2.data, max_dist, max_angle, 100, 0, &err, &iters );
   if( rc ) { complain( "icp_align" ); return 1e6f; }
   *T1 = t;
   if( verbose ) printf( " ICP: %d iterations on the GPU, final error %7.5f\n", iters, err );
@@ -394,10 +463,10 @@ void icp_find_corrs( rsd_vec3_t* pts1, rsd_vec3_t* nor1, int32_t n_pts1, rsd_has
   *weights   = (float*)malloc( cap * sizeof(float) );
   *n_corrs = 0;
   (void)idx2;
-  rs_hip_cloud_t* src = cached_cloud( pts1, nor1, n_pts1, -1.0f );
-  rs_hip_cloud_t* tgt = cached_cloud( pts2, nor2, n_pts2, -1.0f );
+  const CloudRef src = cached_cloud( pts1, nor1, n_pts1, -1.0f );
+  const CloudRef tgt = cached_cloud( pts2, nor2, n_pts2, -1.0f );
   if( !src || !tgt ) return;
-  if( rs_hip_icp_find_corrs( src, tgt, T1.data, T2.data, max_dist, max_angle, (float*)*corr_pts1, (float*)*corr_nor1,
+  if( rs_hip_icp_find_corrs( src.get(), tgt.get(), T1.data, T2.data, max_dist, max_angle, (float*)*corr_pts1, (float*)*corr_nor1,
                              (float*)*corr_pts2, (float*)*corr_nor2, *weights, n_corrs ) )
   { complain( "icp_find_corrs" ); *n_corrs = 0; }
 }
@@ -409,10 +478,10 @@ int rsd_alignment_scores( const rsd_vec3_t* obj_pos, const rsd_vec3_t* obj_nor, 
                           const rsd_mat4_t* xforms, int32_t n_poses, float search_radius, int32_t max_n_neigh, float* scores )
 {
   // (the reference's level grids use radius 0.05 -> cell 0.10, lib/rs/rs_pointcloud.h:862)
-  rs_hip_cloud_t* obj = cached_cloud( obj_pos, obj_nor, n_obj, -1.0f );
-  rs_hip_cloud_t* scn = cached_cloud( scn_pos, scn_nor, n_scn, -1.0f );
+  const CloudRef obj = cached_cloud( obj_pos, obj_nor, n_obj, -1.0f );
+  const CloudRef scn = cached_cloud( scn_pos, scn_nor, n_scn, -1.0f );
   if( !obj || !scn ) return RS_HIP_E_RUNTIME;
-  int rc = rs_hip_alignment_scores( obj, scn, (const float*)xforms, n_poses, search_radius, max_n_neigh, scores );
+  int rc = rs_hip_alignment_scores( obj.get(), scn.get(), (const float*)xforms, n_poses, search_radius, max_n_neigh, scores );
   if( rc ) complain( "alignment_scores" );
   return rc;
 }
@@ -431,16 +500,20 @@ int rsd_arrangement_to_labels( const rsd_vec3_t* scn_pos, const rsd_vec3_t* scn_
                                const rsd_mat4_t* poses, const int32_t* is_static, const int32_t* class_idx, int32_t n_plc,
                                float radius, bool prioritize_static, int8_t* labels, int32_t* sorted_order )
 {
-  rs_hip_cloud_t* scn = cached_cloud( scn_pos, scn_nor, n_scn, -1.0f );
+  const CloudRef scn = cached_cloud( scn_pos, scn_nor, n_scn, -1.0f );
   if( !scn ) return RS_HIP_E_RUNTIME;
-  std::vector<const rs_hip_cloud_t*> objs( (size_t)( n_plc > 0 ? n_plc : 0 ) );
+  // every placement's cloud is HELD for the call: an arrangement may have more distinct objects than the cache has entries
+  // (the library takes up to 127 placements), and evicting one of them — or the scene — must not free what the call is using
+  std::vector<CloudRef> held( (size_t)( n_plc > 0 ? n_plc : 0 ) );
+  std::vector<const rs_hip_cloud_t*> objs( held.size() );
   for( int i = 0; i < n_plc; ++i )
   {
-    objs[i] = cached_cloud( obj_pos[i], obj_nor[i], obj_n[i], -1.0f );
-    if( !objs[i] ) return RS_HIP_E_RUNTIME;
+    held[i] = cached_cloud( obj_pos[i], obj_nor[i], obj_n[i], -1.0f );
+    if( !held[i] ) return RS_HIP_E_RUNTIME;
+    objs[i] = held[i].get();
   }
   std::vector<float> min_dists( (size_t)( n_scn > 0 ? n_scn : 0 ) );
-  int rc = rs_hip_arrangement_to_labels( scn, (const float*)poses, objs.data(), is_static, class_idx, n_plc, radius,
+  int rc = rs_hip_arrangement_to_labels( scn.get(), (const float*)poses, objs.data(), is_static, class_idx, n_plc, radius,
                                          prioritize_static ? 1 : 0, labels, min_dists.data(), sorted_order );
   if( rc ) complain( "arrangement_to_labels" );
   return rc;
@@ -452,15 +525,19 @@ int rsd_arrangement_to_ids( const rsd_vec3_t* scn_pos, const rsd_vec3_t* scn_nor
                             float radius, bool prioritize_static, int32_t unlabelled_class_idx,
                             int32_t* class_ids, int32_t* instance_ids )
 {
-  rs_hip_cloud_t* scn = cached_cloud( scn_pos, scn_nor, n_scn, -1.0f );
+  const CloudRef scn = cached_cloud( scn_pos, scn_nor, n_scn, -1.0f );
   if( !scn ) return RS_HIP_E_RUNTIME;
-  std::vector<const rs_hip_cloud_t*> objs( (size_t)( n_plc > 0 ? n_plc : 0 ) );
+  // every placement's cloud is HELD for the call: an arrangement may have more distinct objects than the cache has entries
+  // (the library takes up to 127 placements), and evicting one of them — or the scene — must not free what the call is using
+  std::vector<CloudRef> held( (size_t)( n_plc > 0 ? n_plc : 0 ) );
+  std::vector<const rs_hip_cloud_t*> objs( held.size() );
   for( int i = 0; i < n_plc; ++i )
   {
-    objs[i] = cached_cloud( obj_pos[i], obj_nor[i], obj_n[i], -1.0f );
-    if( !objs[i] ) return RS_HIP_E_RUNTIME;
+    held[i] = cached_cloud( obj_pos[i], obj_nor[i], obj_n[i], -1.0f );
+    if( !held[i] ) return RS_HIP_E_RUNTIME;
+    objs[i] = held[i].get();
   }
-  int rc = rs_hip_arrangement_to_ids( scn, (const float*)poses, objs.data(), is_static, class_idx, uidx, n_plc, radius,
+  int rc = rs_hip_arrangement_to_ids( scn.get(), (const float*)poses, objs.data(), is_static, class_idx, uidx, n_plc, radius,
                                       prioritize_static ? 1 : 0, unlabelled_class_idx, class_ids, instance_ids, nullptr, nullptr, nullptr );
   if( rc ) complain( "arrangement_to_ids" );
   return rc;
@@ -470,10 +547,10 @@ int64_t rsd_compute_neighborhood( const rsd_vec3_t* pos, const rsd_vec3_t* nor, 
                                   int32_t max_nn, float radius_sq, float dist_exp, float angle_exp,
                                   int32_t* idx1, int32_t* idx2, float* weight )
 {
-  rs_hip_cloud_t* c = cached_cloud( pos, nor, n, -1.0f );
+  const CloudRef c = cached_cloud( pos, nor, n, -1.0f );
   if( !c ) return RS_HIP_E_RUNTIME;
   int64_t n_edges = 0;
-  int rc = rs_hip_compute_neighborhood( c, max_nn, radius_sq, dist_exp, angle_exp, idx1, idx2, weight,
+  int rc = rs_hip_compute_neighborhood( c.get(), max_nn, radius_sq, dist_exp, angle_exp, idx1, idx2, weight,
                                         (int64_t)n * max_nn, &n_edges );
   if( rc ) { complain( "compute_neighborhood" ); return rc; }
   return n_edges;
@@ -481,12 +558,12 @@ int64_t rsd_compute_neighborhood( const rsd_vec3_t* pos, const rsd_vec3_t* nor, 
 
 int32_t rsd_level_poisson( const rsd_vec3_t* pos, int32_t n, float voxel_size, int32_t level, int32_t* sample_idx )
 {
-  rs_hip_cloud_t* c = cached_cloud( pos, nullptr, n, -1.0f );
+  const CloudRef c = cached_cloud( pos, nullptr, n, -1.0f );
   if( !c ) return RS_HIP_E_RUNTIME;
   size_t max_n_neigh = (size_t)( 1024 * ( ( level ) / (float)( 5 - 1 ) ) );      // rs_pointcloud.h:995 (RSPC_N_LEVELS = 5)
   if( !max_n_neigh ) max_n_neigh = 256;                                           // :996
   int32_t n_samples = 0;
-  int rc = rs_hip_level_samples( c, voxel_size, (int32_t)max_n_neigh, sample_idx, &n_samples, nullptr );
+  int rc = rs_hip_level_samples( c.get(), voxel_size, (int32_t)max_n_neigh, sample_idx, &n_samples, nullptr );
   if( rc ) { complain( "level_poisson" ); return rc; }
   return n_samples;
 }
@@ -503,10 +580,12 @@ void* rsd_coverage_create( const rsd_vec3_t* bbox_min, const rsd_vec3_t* bbox_ma
 float rsd_coverage_score( void* coverage, const rsd_vec3_t* const* obj_pos, const int32_t* obj_n,
                           const rsd_mat4_t* poses, const int32_t* is_static, int32_t n_plc )
 {
-  std::vector<const rs_hip_cloud_t*> objs( (size_t)( n_plc > 0 ? n_plc : 0 ) );
+  std::vector<CloudRef> held( (size_t)( n_plc > 0 ? n_plc : 0 ) );
+  std::vector<const rs_hip_cloud_t*> objs( held.size() );
   for( int i = 0; i < n_plc; ++i )
   {
-    objs[i] = is_static[i] ? nullptr : cached_cloud( obj_pos[i], nullptr, obj_n[i], -1.0f );
+    if( !is_static[i] ) held[i] = cached_cloud( obj_pos[i], nullptr, obj_n[i], -1.0f );
+    objs[i] = held[i].get();
     if( !is_static[i] && !objs[i] ) return -1.0f;
   }
   const int32_t first[2] = { 0, n_plc };

@@ -65,6 +65,9 @@ namespace rs {
 // ------------------------------------------------------------------------------------------
 
 __device__ __forceinline__ int uni( int v ) { return __builtin_amdgcn_readfirstlane( v ); }
+// "does any lane ...": a compare of the wave's lane mask with zero on the scalar unit (HIP's __any goes through a VGPR: two VALU
+// instructions per question, and the candidate step asks up to six per group of four candidates)
+__device__ __forceinline__ bool wave_any( bool p ) { return __builtin_amdgcn_ballot_w64( p ) != 0ull; }
 
 // Order LDS traffic of one wave: the LDS executes a wave's DS instructions in issue order,
 // so a store by one lane is visible to a later load by another lane of the SAME wave; the
@@ -284,7 +287,7 @@ __device__ __forceinline__ float box_cover( const GridView& g, const CellBox& cu
 
 // Per-wave LDS.  CAP = staged candidates per round (the per-row cold search of the score batch stages more than a wave's worth).
 template <int CAP>
-struct WaveLdsT
+struct __attribute__(( aligned( 16 ) )) WaveLdsT      // (aligned: the compiler splits the 128-bit reads into pairs of 64-bit ones otherwise)
 {
   float    px[CAP], py[CAP], pz[CAP];      // staged candidates, one array per coordinate so that four
   int      pidx[CAP];                      // consecutive candidates load as one ds_read_b128 per coordinate
@@ -536,6 +539,18 @@ __device__ __forceinline__ void dist2x4( const float4& X, const float4& Y, const
 // Three levels: (1) distances only — most groups end here; (2) some lane has a candidate inside its
 // bound (lanes without a match see that for everything within the radius): the gate of all four,
 // packed like the distances; (3) a candidate passed both: settle it one by one.
+// (Questions about the whole wave — "is any lane ...?" — are asked of LANE MASKS: ballot( compare ) is the compare's own SGPR
+//  result, and and / or / "!= 0" of such masks are scalar instructions.  HIP's __any( a | b ) goes through a VGPR instead,
+//  two VALU instructions per question, six questions per group of four candidates.)
+typedef unsigned long long lanemask;
+#define RS_BALLOT( c ) __builtin_amdgcn_ballot_w64( c )
+// cnt += 1 in the lanes of `mask`: one v_addc (the mask is the carry-in), not a select and an add
+__device__ __forceinline__ void count_lanes( int& cnt, lanemask mask )
+{
+  lanemask carry_out;
+  asm( "v_addc_co_u32 %0, %1, 0, %0, %2" : "+v"( cnt ), "=s"( carry_out ) : "s"( mask ) );
+}
+
 template <bool GATED, bool SELF, class LDS>
 __device__ __forceinline__ void consider4( const float4& X, const float4& Y, const float4& Z, int k, const LDS& L,
                                            float qx, float qy, float qz, float nx, float ny, float nz,
@@ -543,8 +558,10 @@ __device__ __forceinline__ void consider4( const float4& X, const float4& Y, con
 {
   float d[4];
   dist2x4( X, Y, Z, qx, qy, qz, d[0], d[1], d[2], d[3] );
-  bool in0 = d[0] < bound, in1 = d[1] < bound, in2 = d[2] < bound, in3 = d[3] < bound;
-  if( !__any( in0 | in1 | in2 | in3 ) ) return;
+  lanemask in[4];
+#pragma unroll
+  for( int i = 0; i < 4; ++i ) in[i] = RS_BALLOT( d[i] < bound );
+  if( ( in[0] | in[1] | in[2] | in[3] ) == 0ull ) return;
   int4 I = make_int4( 0, 0, 0, 0 );
   if( SELF )
   {
@@ -552,12 +569,13 @@ __device__ __forceinline__ void consider4( const float4& X, const float4& Y, con
     // stream exactly once (d == its dist² < bound) — that is most of what gets here once the bounds are
     // tight, and it is no news
     I = *reinterpret_cast<const int4*>( &L.pidx[k] );
-    in0 &= I.x != m.idx; in1 &= I.y != m.idx; in2 &= I.z != m.idx; in3 &= I.w != m.idx;
-    if( !__any( in0 | in1 | in2 | in3 ) ) return;
+    in[0] &= RS_BALLOT( I.x != m.idx ); in[1] &= RS_BALLOT( I.y != m.idx ); in[2] &= RS_BALLOT( I.z != m.idx ); in[3] &= RS_BALLOT( I.w != m.idx );
+    if( ( in[0] | in[1] | in[2] | in[3] ) == 0ull ) return;
   }
-  seen_closer += ( in0 ? 1 : 0 ) + ( in1 ? 1 : 0 ) + ( in2 ? 1 : 0 ) + ( in3 ? 1 : 0 );
-  float dc[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
-  bool p0 = in0, p1 = in1, p2 = in2, p3 = in3;
+#pragma unroll
+  for( int i = 0; i < 4; ++i ) count_lanes( seen_closer, in[i] );
+  float dot[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+  lanemask pass[4] = { in[0], in[1], in[2], in[3] };
   if( GATED )
   {
     const float4 NX = *reinterpret_cast<const float4*>( &L.nx[k] );
@@ -566,31 +584,44 @@ __device__ __forceinline__ void consider4( const float4& X, const float4& Y, con
     const f32x2 n_x = { nx, nx }, n_y = { ny, ny }, n_z = { nz, nz };
     const f32x2 a = f32x2{ NX.x, NX.y } * n_x + f32x2{ NY.x, NY.y } * n_y + f32x2{ NZ.x, NZ.y } * n_z;   // msh_vec3_dot( m, n )
     const f32x2 b = f32x2{ NX.z, NX.w } * n_x + f32x2{ NY.z, NY.w } * n_y + f32x2{ NZ.z, NZ.w } * n_z;
-    dc[0] = a.x > 0.0f ? a.x : 0.0f; dc[1] = a.y > 0.0f ? a.y : 0.0f;                                    // msh_max( dot, 0.0f )
-    dc[2] = b.x > 0.0f ? b.x : 0.0f; dc[3] = b.y > 0.0f ? b.y : 0.0f;
-    p0 &= ( dc[0] >= tmin ) & ( dc[0] <= 1.0f ); p1 &= ( dc[1] >= tmin ) & ( dc[1] <= 1.0f );
-    p2 &= ( dc[2] >= tmin ) & ( dc[2] <= 1.0f ); p3 &= ( dc[3] >= tmin ) & ( dc[3] <= 1.0f );
-    if( SELF )     // only the ICP instantiation issues certificates (icp_emit); the score batch has no use for fail_max
+    dot[0] = a.x; dot[1] = a.y; dot[2] = b.x; dot[3] = b.y;
+    if( SELF )     // only the ICP instantiation issues certificates (icp_emit); it needs the exact gate of every in-bound candidate
     {
-      m.fail_max = fmaxf( fmaxf( m.fail_max, ( in0 & !p0 ) ? dc[0] : 0.0f ), ( in1 & !p1 ) ? dc[1] : 0.0f );
-      m.fail_max = fmaxf( fmaxf( m.fail_max, ( in2 & !p2 ) ? dc[2] : 0.0f ), ( in3 & !p3 ) ? dc[3] : 0.0f );
+      const lanemask lane_bit = 1ull << ( threadIdx.x & ( WAVE - 1 ) );
+#pragma unroll
+      for( int i = 0; i < 4; ++i )
+      {
+        const float dc = dot[i] > 0.0f ? dot[i] : 0.0f;                                                   // msh_max( dot, 0.0f )
+        pass[i] &= RS_BALLOT( dc >= tmin ) & RS_BALLOT( dc <= 1.0f );
+        m.fail_max = fmaxf( m.fail_max, ( ( in[i] & ~pass[i] ) & lane_bit ) ? dc : 0.0f );
+      }
+    }
+    else
+    {
+      // One compare per candidate here, the exact gate  tmin <= max(dot,0) <= 1  only for what survives it (below): with
+      // tmin > 0, max(dot,0) >= tmin implies !(dot < tmin) (NaN included); a gate that lets max(dot,0) = 0 pass (tmin <= 0)
+      // filters nothing at this stage.
+      const float pre = tmin > 0.0f ? tmin : -INFINITY;
+#pragma unroll
+      for( int i = 0; i < 4; ++i ) pass[i] &= RS_BALLOT( !( dot[i] < pre ) );
     }
   }
-  if( __any( p0 | p1 | p2 | p3 ) )
-  {
-    const bool pass[4] = { p0, p1, p2, p3 };
+  if( ( pass[0] | pass[1] | pass[2] | pass[3] ) == 0ull ) return;
 #pragma unroll
-    for( int i = 0; i < 4; ++i )
+  for( int i = 0; i < 4; ++i )
+  {
+    if( pass[i] != 0ull )
     {
-      if( __any( pass[i] ) )
+      const int idx = SELF ? ( i == 0 ? I.x : i == 1 ? I.y : i == 2 ? I.z : I.w ) : L.pidx[k + i];
+      const float dc = dot[i] > 0.0f ? dot[i] : 0.0f;                                                   // msh_max( dot, 0.0f )
+      // (the lane's bit of pass[i] is implied by the tests below but for the gate's prefilter and SELF's own-match skip: the exact
+      //  gate re-checks the former, d < bound with the match at its own bound the latter — a match never beats itself in lex_less)
+      const bool gate = !GATED | ( ( dc >= tmin ) & ( dc <= 1.0f ) );
+      const bool take = gate & ( d[i] < bound ) & lex_less( d[i], idx, m.d2, m.idx );   // the bound may have tightened within the group
+      if( take )
       {
-        const int idx = SELF ? ( i == 0 ? I.x : i == 1 ? I.y : i == 2 ? I.z : I.w ) : L.pidx[k + i];
-        const bool take = pass[i] & ( d[i] < bound ) & lex_less( d[i], idx, m.d2, m.idx );   // the bound may have tightened within the group
-        if( take )
-        {
-          m.d2 = d[i]; m.idx = idx; m.dot = dc[i]; m.slot = (int)L.slot[k + i]; m.found = true;
-          bound = __int_as_float( __float_as_int( d[i] ) + 1 );   // next float above d2 (d2 >= 0, finite, < radius²)
-        }
+        m.d2 = d[i]; m.idx = idx; m.dot = dc; m.slot = (int)L.slot[k + i]; m.found = true;
+        bound = __int_as_float( __float_as_int( d[i] ) + 1 );   // next float above d2 (d2 >= 0, finite, < radius²)
       }
     }
   }

@@ -61,6 +61,57 @@ def test_layout_matches_the_reference_headers():
     assert [lib.ref_layout(i) for i in range(9)] == want
 
 
+def _bind_grid(lib):
+    lib.msh_hash_grid_init_3d.restype = None
+    lib.msh_hash_grid_init_3d.argtypes = [C.POINTER(HashGrid), C.c_void_p, C.c_int32, C.c_float]
+    lib.msh_hash_grid_term.restype = None
+    lib.msh_hash_grid_term.argtypes = [C.POINTER(HashGrid)]
+    lib.msh_hash_grid_radius_search.restype = C.c_size_t
+    lib.msh_hash_grid_radius_search.argtypes = [C.POINTER(HashGrid), C.POINTER(SearchDesc)]
+    lib.rsd_device_failures.restype = C.c_ulonglong
+    lib.rsd_device_failures.argtypes = []
+    return lib
+
+
+def _no_gpu():
+    import torch
+    return not torch.cuda.is_available()
+
+
+@pytest.mark.skipif(not _no_gpu(), reason="forces the device path to fail by running where there is no device")
+@pytest.mark.parametrize("fname", ["rows_k16_r010.npz", "rows_k1_r005.npz"])
+def test_search_survives_a_device_failure(gscene, fname, monkeypatch, capfd):
+    """a GPU failure inside the shim must never leave the unchanged app walking unwritten rows
+    (lib/msh/msh_hash_grid.h:1090-1259 always fills n_neighbors).  Without a device a grid is not initialised at all and every
+    search reports zero neighbours per query; with RS_DROPIN_INIT_WITHOUT_DEVICE=1 (this test's hook) the grid exists and
+    every batched search fails on the device side, as after a HIP runtime error: it is then answered from the grid's own host
+    copy — the reference's rows — with a complaint on stderr and a count in rsd_device_failures()."""
+    from conftest import rows_equal_up_to_ties
+    from rescan_amd import build
+    build.build()
+    lib = _bind_grid(C.CDLL(DROPIN))
+    g = load_golden(fname)
+    pts, q, k = gscene["points"], g["query"], int(g["k"])
+    hg = HashGrid()
+    lib.msh_hash_grid_init_3d(C.byref(hg), pts.ctypes.data, len(pts), float(g["grid_radius"]))
+    assert not hg.data_buffer                                     # no device, no grid ...
+    d = np.full((len(q), k), -1, np.float32); i = np.full((len(q), k), -1, np.int32); nn = np.full(len(q), 77, np.uint64)
+    sd = SearchDesc(q.ctypes.data, len(q), d.ctypes.data, i.ctypes.data, nn.ctypes.data, float(g["radius"]), k, 1)
+    assert lib.msh_hash_grid_radius_search(C.byref(hg), C.byref(sd)) == 0 and (nn == 0).all()      # ... and the counts say so
+    lib.msh_hash_grid_term(C.byref(hg))
+    monkeypatch.setenv("RS_DROPIN_INIT_WITHOUT_DEVICE", "1")
+    before = lib.rsd_device_failures()
+    lib.msh_hash_grid_init_3d(C.byref(hg), pts.ctypes.data, len(pts), float(g["grid_radius"]))
+    assert hg.data_buffer
+    capfd.readouterr()
+    d, i, nn, tot = _search(lib, hg, q, g["radius"], k)
+    err = capfd.readouterr().err
+    assert tot == int(g["total"])
+    rows_equal_up_to_ties(d, i, nn, g["dists"], g["inds"], g["nn"])
+    assert lib.rsd_device_failures() == before + 1 and "[rescan_hip]" in err
+    lib.msh_hash_grid_term(C.byref(hg))
+
+
 @pytest.fixture(scope="module")
 def dropin():
     from rescan_amd import capi
@@ -78,7 +129,10 @@ def dropin():
     lib.rsd_alignment_scores.restype = C.c_int
     lib.rsd_alignment_scores.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                          C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_void_p]
-    return lib
+    lib.rsd_device_failures.restype = C.c_ulonglong
+    lib.rsd_device_failures.argtypes = []
+    yield lib
+    assert lib.rsd_device_failures() == 0, "a search of this module was answered from a grid's host copy after a HIP error"
 
 
 @pytest.mark.gpu
@@ -99,6 +153,7 @@ def test_icp_align_by_reference_name(dropin, gscene, fname):
 
 
 def _search(dropin, hg, q, radius, k, sort=1):
+    # (defined before its first use at run time; test_search_survives_a_device_failure above calls it too)
     q = np.ascontiguousarray(q, np.float32).reshape(-1, 3)
     d = np.zeros((len(q), k), np.float32); i = np.zeros((len(q), k), np.int32); nn = np.zeros(len(q), np.uint64)
     sd = SearchDesc(q.ctypes.data, len(q), d.ctypes.data, i.ctypes.data, nn.ctypes.data, float(radius), k, sort)
@@ -167,8 +222,9 @@ def test_level_builder_loop_through_the_shim(dropin, gscene):
 
 @pytest.mark.gpu
 def test_upload_cache_follows_the_arrays(dropin, gscene):
-    """The shim's device-cloud cache: same arrays -> same result (cached upload); arrays rebuilt in place -> noticed by the
-    sampled fingerprint; a few points edited in place -> noticed after rsd_cache_invalidate (the explicit route)."""
+    """The shim's device-cloud cache: same arrays -> same result (cached upload); arrays rebuilt in place, or ONE point edited
+    in place -> noticed (arrays of this size are keyed by their full content hash); rsd_cache_invalidate is the explicit
+    route.  test_upload_cache_large_arrays covers the sampled keys of arrays above 4 MB."""
     g = load_golden(golden_files("icp_")[0])
     o = gscene["objects"][int(g["obj"])]
     pos, nor = o["pos"].copy(), o["nor"].copy()
@@ -191,12 +247,80 @@ def test_upload_cache_follows_the_arrays(dropin, gscene):
     assert not (b == a).all()
     pos[:] = saved
     assert (run() == a).all()
-    pos[len(pos) // 3] += np.float32(0.05)                       # one point: invisible to a sample, so the caller says so
-    dropin.rsd_cache_invalidate(pos.ctypes.data)
+    pos[len(pos) // 3] += np.float32(0.05)                       # one point, no invalidation: the full hash sees it
     c = run()
     pos[:] = saved
-    dropin.rsd_cache_invalidate(pos.ctypes.data)
     assert (run() == a).all() and not (c == a).all()
+    pos[len(pos) // 3] += np.float32(0.05)
+    dropin.rsd_cache_invalidate(pos.ctypes.data)                 # the explicit route still works
+    c2 = run()
+    pos[:] = saved
+    dropin.rsd_cache_invalidate(pos.ctypes.data)
+    assert (c2 == c).all() and (run() == a).all()
+
+
+@pytest.mark.gpu
+def test_upload_cache_large_arrays(dropin):
+    """Arrays above RS_DROPIN_FULL_HASH_BELOW (4 MB) are keyed by a ~1 KB sample: a point edited in place where the sample does
+    not look is seen at the latest at the 16th later hit (the periodic full-hash check), immediately after
+    rsd_cache_invalidate, and always under a lowered threshold."""
+    from rescan_amd import synth
+    s0 = synth.scene_for_point_count(400_000, seed=5, timestep=0)          # > 4 MB of positions
+    s1 = synth.scene_for_point_count(400_000, seed=5, timestep=1)
+    pos, nor = s1["points"].copy(), s1["normals"].copy()
+    assert pos.nbytes > (4 << 20)
+    T2 = Mat4(); T2.data[:] = [1.0 if k % 5 == 0 else 0.0 for k in range(16)]
+    dropin.rsd_cache_invalidate.restype = None
+    dropin.rsd_cache_invalidate.argtypes = [C.c_void_p]
+
+    def run():
+        T = Mat4(); T.data[:] = T2.data[:]
+        dropin.icp_align(pos.ctypes.data, nor.ctypes.data, len(pos), s0["points"].ctypes.data, s0["normals"].ctypes.data,
+                         len(s0["points"]), C.byref(T), T2, 0.1, float(np.deg2rad(60.0)), False)
+        return np.array(T.data[:], np.float32)
+
+    a = run()
+    assert (run() == a).all()
+    saved = pos.copy()
+    pos[len(pos) // 3 + 7] += np.float32(0.5)                    # between two sampled blocks
+    seen_after = next((k for k in range(1, 40) if not (run() == a).all()), None)
+    assert seen_after is not None and seen_after <= 16, seen_after
+    pos[:] = saved
+    dropin.rsd_cache_invalidate(pos.ctypes.data)
+    assert (run() == a).all()
+
+
+@pytest.mark.gpu
+def test_more_placements_than_cache_entries(dropin, gscene):
+    """rsd_arrangement_to_ids with 100 DISTINCT object arrays (the cache keeps 64 entries; the library takes up to 127
+    placements): every cloud of the call stays alive until the call returns — the ids are those of the native entry point on
+    clouds of its own."""
+    from rescan_amd import capi
+    pts, nor = gscene["points"], gscene["normals"]
+    rng = np.random.default_rng(9)
+    n_plc = 100
+    objs = []
+    for k in range(n_plc):
+        o = gscene["objects"][k % len(gscene["objects"])]
+        sel = np.sort(rng.choice(len(o["pos"]), size=max(64, len(o["pos"]) // 8), replace=False))
+        objs.append((np.ascontiguousarray(o["pos"][sel]), np.ascontiguousarray(o["nor"][sel]), o["pose"]))
+    poses = np.ascontiguousarray(np.stack([o[2] for o in objs]), np.float32)
+    is_static = np.zeros(n_plc, np.int32); cls = (np.arange(n_plc) % 7).astype(np.int32); uidx = np.arange(n_plc, dtype=np.int32)
+    pp = (C.c_void_p * n_plc)(*[o[0].ctypes.data for o in objs]); pn = (C.c_void_p * n_plc)(*[o[1].ctypes.data for o in objs])
+    ns = np.array([len(o[0]) for o in objs], np.int32)
+    cid = np.zeros(len(pts), np.int32); iid = np.zeros(len(pts), np.int32)
+    dropin.rsd_arrangement_to_ids.restype = C.c_int
+    dropin.rsd_arrangement_to_ids.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_bool, C.c_int32, C.c_void_p, C.c_void_p]
+    for _ in range(2):
+        rc = dropin.rsd_arrangement_to_ids(pts.ctypes.data, nor.ctypes.data, len(pts), C.addressof(pp), C.addressof(pn), ns.ctypes.data,
+                                           poses.ctypes.data, is_static.ctypes.data, cls.ctypes.data, uidx.ctypes.data, n_plc, 0.05, False, 40,
+                                           cid.ctypes.data, iid.ctypes.data)
+        assert rc == 0
+    scn = capi.Cloud(pts, nor)
+    clouds = [capi.Cloud(o[0], o[1]) for o in objs]
+    want = capi.arrangement_to_ids(scn, poses, clouds, is_static.tolist(), cls.tolist(), uidx.tolist(), 0.05, False, 40)
+    assert (cid == want["class_ids"]).all() and (iid == want["instance_ids"]).all()
 
 
 @pytest.mark.gpu
