@@ -126,6 +126,14 @@ int32_t rs_hip_icp_reference_order_below( int32_t n_points );
  * after the other (a diagnostic: binade crossings, chain starts). */
 int32_t rs_hip_icp_replay_below( int32_t n_points );
 int32_t rs_hip_icp_replay_redone( void );
+/* Sources above both thresholds (whole million-point scans): the parallel fp64 reduction, centred on the REFERENCE'S centroids —
+ * the seven sums behind icp__compute_weighted_centroid (icp.h:136-148: Σw, Σw·p, Σw·q) are computed as the reference's own
+ * sequential fp32 chains, bit for bit.  Those chains carry a systematic rounding drift (parts in a thousand of Σw once the running
+ * sum's grid is coarser than the spread of the addends) that moves the reference's converged pose by up to 3e-4 from the exact
+ * least-squares one; with its centroids the fp64 step lands within ~1e-6 of the reference's pose.  on = 0: plain fp64
+ * moments (faster by the chains' cost, within 1e-4 of the reference in most runs only); on < 0 only reads; environment
+ * RS_HIP_EXACT_CENTROIDS.  Returns the previous setting. */
+int32_t rs_hip_icp_exact_centroids( int32_t on );
 
 /* Many independent icp_align problems of one (source, target) pair, one per start pose
  * (apps/pose_proposal/main.cpp:190-202 runs exactly this loop): T1s is float[16*n], errs

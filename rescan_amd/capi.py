@@ -44,6 +44,7 @@ SIGNATURES = {
     "rs_hip_icp_reference_order_below": (C.c_int32, [C.c_int32]),
     "rs_hip_icp_replay_below": (C.c_int32, [C.c_int32]),
     "rs_hip_icp_replay_redone": (C.c_int32, []),
+    "rs_hip_icp_exact_centroids": (C.c_int32, [C.c_int32]),
     "rs_hip_icp_align_batch": (C.c_int, [C.c_void_p, C.c_void_p, f32p, C.c_int32, f32p, C.c_float, C.c_float,
                                          C.c_int32, C.c_int32, f32p, i32p]),
     "rs_hip_icp_find_corrs": (C.c_int, [C.c_void_p, C.c_void_p, f32p, f32p, C.c_float, C.c_float,
@@ -258,6 +259,12 @@ def icp_replay_below(n_points=-1):
     """Threshold up to which sources above the reference-order threshold get the reference's sums computed in parallel
     (same bits); -1 only reads.  Returns the previous threshold."""
     return int(load().rs_hip_icp_replay_below(int(n_points)))
+
+
+def icp_exact_centroids(on=-1):
+    """Sources above both thresholds: centre the fp64 step on the reference's own fp32 centroid chains (default on); -1 only
+    reads.  Returns the previous setting."""
+    return int(load().rs_hip_icp_exact_centroids(int(on)))
 
 
 def icp_replay_redone():

@@ -133,6 +133,9 @@ std::atomic<int> g_ref_order_below{ getenv( "RS_HIP_REF_ORDER_BELOW" ) ? atoi( g
 // bits again, two to three times as fast as the sequential chains on scan-sized sources, still ten times the fp64 moments);
 // beyond — whole million-point scans, where a bit-exact iteration would cost 2.4 ms instead of 0.2 — the fp64 moments, whose
 // distance from the reference is measured (4.7e-5 on the headline workload, 23 of 24 sweep runs under 1e-4).
+// Sources above both thresholds: the fp64 moments, centred on the reference's own fp32 centroid chains (rs_kernels.hip:
+// launch_icp_exact_centroids; rs_math.h: icp_solve).  RS_HIP_EXACT_CENTROIDS=0: plain fp64 moments.
+std::atomic<int> g_exact_centroids{ getenv( "RS_HIP_EXACT_CENTROIDS" ) ? atoi( getenv( "RS_HIP_EXACT_CENTROIDS" ) ) : 1 };
 std::atomic<int> g_replay_below{ getenv( "RS_HIP_REPLAY_BELOW" ) ? atoi( getenv( "RS_HIP_REPLAY_BELOW" ) ) : 262144 };
 std::mutex g_prof_mutex;
 struct ProfEntry { std::vector<std::pair<hipEvent_t, hipEvent_t>> spans; int64_t launches = 0; double ms = 0.0; };
@@ -892,14 +895,16 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
   if( ( rc = icp_upload_state( cx, T1s, (size_t)n ) ) ) return rc;
   const bool ref_order = source->n <= g_ref_order_below.load();
   const bool replay = !ref_order && source->n <= g_replay_below.load();
+  const bool exact_centroids = !ref_order && !replay && g_exact_centroids.load() != 0;
   ReplayBufs RB{};
-  if( ref_order || replay )
+  if( ref_order || replay || exact_centroids )
   {
     if( ( rc = g_ws.faith.ensure( (size_t)n * FAITH_REC * (size_t)source->n * 4 ) ) ) return rc;
     cx.L.faith = g_ws.faith.as<float>();
-    if( replay && ( rc = replay_prepare( RB, n, source->n ) ) ) return rc;
+    if( ( replay || exact_centroids ) && ( rc = replay_prepare( RB, n, source->n ) ) ) return rc;
   }
-  else
+  if( exact_centroids ) { cx.L.exact_centroids = 1; cx.L.centroid_totals = RB.totals; }
+  if( !ref_order && !replay )
   {
     HIP_TRY( hipMemsetAsync( g_ws.stat_acc.p, 0, (size_t)n * STAT_SHARDS * 4 * 8, g_stream ), RS_HIP_E_RUNTIME );
     cx.L.stat_acc = g_ws.stat_acc.as<unsigned long long>();
@@ -952,6 +957,7 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
       if( debug ) icp_debug_after( cx, source->n, n, i, max_dist );
       prof.mark( "icp_moments" );
       if( replay ) launch_icp_replay( cx.L, RB, g_stream );
+      else if( exact_centroids ) launch_icp_exact_centroids( cx.L, RB, g_stream );
       else if( cx.L.faith ) launch_icp_faithful( cx.L, g_stream ); else launch_icp_moments( cx.L, g_stream );
       double nd = max_dist * 0.95;                                      // icp.h:493
       max_dist = (float)( nd > 0.05 ? nd : 0.05 );
@@ -979,6 +985,13 @@ int32_t rs_hip_icp_replay_below( int32_t n_points )
 {
   const int prev = g_replay_below.load();
   if( n_points >= 0 ) g_replay_below.store( n_points );
+  return prev;
+}
+
+int32_t rs_hip_icp_exact_centroids( int32_t on )
+{
+  const int prev = g_exact_centroids.load();
+  if( on >= 0 ) g_exact_centroids.store( on ? 1 : 0 );
   return prev;
 }
 

@@ -119,6 +119,10 @@ struct IcpLaunch
   // reference-order estimator (rs_kernels.hip: k_icp_faithful); faith == null: fp64 moments
   const int* by_orig;   // original source index -> query slot (null: identity)
   float*  faith;        // n_prob x FAITH_REC x nq: the correspondences in the source's own order
+  // "exact centroids" estimator (large sources): the fp64 moments, but the seven sums behind the two weighted centroids
+  // (icp.h:136-148: Σw, Σw·p, Σw·q) as the reference's own sequential fp32 chains — see launch_icp_exact_centroids
+  int     exact_centroids;
+  const double* centroid_totals;   // n_prob x 3 x ICP_NMOM (ReplayBufs::totals): [ICP_NMOM + 0..6] = the seven chain totals
 };
 void launch_icp_corr( const IcpLaunch& L, hipStream_t st );     // phase A, phase B (the tiles add their dist² statistics to L.stat_acc)
 void launch_icp_moments( const IcpLaunch& L, hipStream_t st );  // weights + moments (+ solve and loop-state update if L.solve)
@@ -138,6 +142,8 @@ struct ReplayBufs
   int*    redone;       // n_prob: segments re-added sequentially (diagnostics; may be null)
 };
 void   launch_icp_replay( const IcpLaunch& L, const ReplayBufs& B, hipStream_t st );
+// fp64 moments + the reference's own fp32 chains for Σw, Σw·p, Σw·q (pass 2 of the replay) + solve with those centroids
+void   launch_icp_exact_centroids( const IcpLaunch& L, const ReplayBufs& B, hipStream_t st );
 int    replay_segments( int n_source );
 int    replay_superblocks( int n_source );
 size_t replay_seg_bytes();

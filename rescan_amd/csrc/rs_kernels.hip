@@ -1759,7 +1759,17 @@ __global__ __launch_bounds__( UPDATE_WAVES * WAVE ) void k_icp_update( IcpLaunch
   Mat4 T;
   for( int k = 0; k < 16; ++k ) { T.m[k] = L.T1[prob * 16 + k]; L.T1_prev[prob * 16 + k] = T.m[k]; }
   float e;
-  if( !icp_solve( res, T, e ) ) { L.active[prob] = 0; return; }         // icp.h:466-470: weights vanished
+  float cen[6];
+  if( L.exact_centroids )
+  {
+    // the reference's own centroids: c = Σw·p * ( 1.0f / Σw ), every sum its sequential fp32 chain (icp.h:136-148)
+    const double* t2 = L.centroid_totals + ( (size_t)prob * 3 + 1 ) * ICP_NMOM;
+    const float total = (float)t2[0];
+    if( total <= 1e-7 ) { L.active[prob] = 0; return; }                 // icp.h:466-470
+    const float inv = __fdiv_rn( 1.0f, total );
+    for( int a = 0; a < 6; ++a ) cen[a] = (float)t2[1 + a] * inv;
+  }
+  if( !icp_solve( res, T, e, L.exact_centroids ? cen : nullptr ) ) { L.active[prob] = 0; return; }         // icp.h:466-470: weights vanished
   for( int k = 0; k < 16; ++k ) L.T1[prob * 16 + k] = T.m[k];           // icp.h:295
   L.err[prob] = e;
   const float delta = fabsf( L.prev_err[prob] - e );
@@ -2090,7 +2100,16 @@ __device__ __forceinline__ bool replay_params( const IcpLaunch& L, int prob, int
 {
   P.w_explicit = L.w_explicit != nullptr; P.use_sd = false; P.max_dist = L.radius; P.cut = 0.0f;
   P.c1[0] = P.c1[1] = P.c1[2] = P.c2[0] = P.c2[1] = P.c2[2] = 0.0f;
-  if( pass >= 2 && !P.w_explicit )
+  if( pass >= 2 && !P.w_explicit && L.exact_centroids )
+  {
+    // the cut of k_icp_moments (same expressions, same bits: both take n, mean, stddev from the integer statistics of the search)
+    const double* st = L.res + (size_t)prob * ICP_NRES + ICP_NMOM;
+    if( st[0] == 0.0 ) return false;
+    const float sd = (float)st[2];
+    P.use_sd = sd > 0.000001;
+    P.cut = 2.5f * sd;
+  }
+  else if( pass >= 2 && !P.w_explicit )
   {
     const double* t1 = totals;                                         // pass 1: Σd², Σd⁴, count (floats kept in doubles)
     const float cnt = (float)t1[2];
@@ -2517,6 +2536,15 @@ void launch_icp_replay( const IcpLaunch& L, const ReplayBufs& B, hipStream_t st 
   launch_replay_pass<2>( L, B, st );
   launch_replay_pass<3>( L, B, st );
   hipLaunchKernelGGL( k_replay_finish, dim3( L.n_prob ), dim3( WAVE ), 0, st, L, B );
+}
+// Large sources: k_icp_moments (parallel fp64) for everything but the two weighted centroids, whose seven sums run as the
+// reference's sequential fp32 chains (pass 2 of the replay, with the moments' own 2.5-sigma cut); k_icp_update centres on them.
+void launch_icp_exact_centroids( const IcpLaunch& L, const ReplayBufs& B, hipStream_t st )
+{
+  hipLaunchKernelGGL( k_icp_moments, dim3( L.n_mom_blocks, L.n_prob ), dim3( BLOCK ), 0, st, L );      // (also leaves n, mean, stddev in L.res)
+  hipLaunchKernelGGL( k_icp_faith_gather, dim3( ( L.src.n + BLOCK - 1 ) / BLOCK, L.n_prob ), dim3( BLOCK ), 0, st, L );
+  launch_replay_pass<2>( L, B, st );
+  hipLaunchKernelGGL( k_icp_update, dim3( L.n_prob ), dim3( UPDATE_WAVES * WAVE ), 0, st, L );
 }
 int replay_segments( int n_source ) { return ( n_source + REPLAY_SEG - 1 ) / REPLAY_SEG; }
 int replay_superblocks( int n_source ) { return ( replay_segments( n_source ) + REPLAY_SUPER - 1 ) / REPLAY_SUPER; }

@@ -213,12 +213,18 @@ RS_HD inline void ldlt6_solve( double A[6][6], const double b[6], double x[6] )
 
 // Finish lib/rs/icp.h:210-298 from the 35 uncentred fp64 moments (layout: rs_kernels.hip, k_icp_moments).
 // Returns false when the reference would have stopped before estimating (Σw <= 1e-7, icp.h:466).
-RS_HD inline bool icp_solve( const double* M, Mat4& T1, float& err )
+// cen (may be null): the two weighted centroids c1, c2 to centre on (6 floats) instead of the moments' own Σw·p / Σw, Σw·q / Σw.
+// The reference's centroids are sequential fp32 sums (icp.h:136-148) and carry a SYSTEMATIC rounding error: once the running
+// sum's grid (its ulp) is coarser than the spread of the addends — Σw of 7 x 10^5 weights near 0.97 advances on a grid of
+// 1/16 and every addend rounds UP to 1.0 — the sum drifts by parts in a thousand (Σw + 0.27 %, the centroids by a
+// centimetre, their difference c1 - c2 by a millimetre at a far start pose), and the residuals d = (p - c1) - (q - c2) inherit
+// c1 - c2.  An estimator that wants the reference's pose for a million-point source must centre where the reference centres.
+RS_HD inline bool icp_solve( const double* M, Mat4& T1, float& err, const float* cen = nullptr )
 {
   const double W = M[0];
   if( (float)W <= 1e-7 ) return false;
-  const float c1f[3] = { (float)( M[1] / W ), (float)( M[2] / W ), (float)( M[3] / W ) };
-  const float c2f[3] = { (float)( M[4] / W ), (float)( M[5] / W ), (float)( M[6] / W ) };
+  const float c1f[3] = { cen ? cen[0] : (float)( M[1] / W ), cen ? cen[1] : (float)( M[2] / W ), cen ? cen[2] : (float)( M[3] / W ) };
+  const float c2f[3] = { cen ? cen[3] : (float)( M[4] / W ), cen ? cen[4] : (float)( M[5] / W ), cen ? cen[5] : (float)( M[6] / W ) };
   const double c1[3] = { c1f[0], c1f[1], c1f[2] }, dl[3] = { (double)c1f[0] - c2f[0], (double)c1f[1] - c2f[1], (double)c1f[2] - c2f[2] };
   const double Maa[3][3] = { { M[7], M[8], M[9] }, { M[8], M[10], M[11] }, { M[9], M[11], M[12] } };
   double Man[3][3];
