@@ -119,6 +119,7 @@ struct Workspace
   DevBuf lvl_pos, lvl_nor, lvl_cnt, lvl_within, lvl_offset, lvl_adj, lvl_state, lvl_misc, lvl_flags, lvl_scan, lvl_samples, lvl_tmp, lvl_cursor, lvl_work_a, lvl_work_b;   // level builder
   DevBuf faith;                                                                 // reference-order estimator: correspondences in source order
   DevBuf rp_segsum, rp_guess, rp_seg, rp_super, rp_totals, rp_redone;                     // ... its parallel form (replay)
+  DevBuf ch_rec, ch_segsum, ch_prefix, ch_seg, ch_blk, ch_dbg;                                    // the centroid chains of large sources (grid chains)
   PinBuf h_a, h_b, h_c;
 };
 thread_local Workspace g_ws;
@@ -897,13 +898,37 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
   const bool replay = !ref_order && source->n <= g_replay_below.load();
   const bool exact_centroids = !ref_order && !replay && g_exact_centroids.load() != 0;
   ReplayBufs RB{};
-  if( ref_order || replay || exact_centroids )
+  ChainBufs CB{};
+  const bool chains = exact_centroids && g_exact_centroids.load() == 1;      // (2: the same sums through pass 2 of the replay — the cross-check)
+  if( ref_order || replay || ( exact_centroids && !chains ) )
   {
     if( ( rc = g_ws.faith.ensure( (size_t)n * FAITH_REC * (size_t)source->n * 4 ) ) ) return rc;
     cx.L.faith = g_ws.faith.as<float>();
     if( ( replay || exact_centroids ) && ( rc = replay_prepare( RB, n, source->n ) ) ) return rc;
   }
+  if( chains )
+  {
+    if( ( rc = g_ws.rp_totals.ensure( (size_t)n * 3 * ICP_NMOM * 8 ) ) || ( rc = g_ws.rp_redone.ensure( (size_t)n * 4 + 64 ) ) ) return rc;
+    RB.totals = g_ws.rp_totals.as<double>(); RB.redone = g_ws.rp_redone.as<int>();
+    HIP_TRY( hipMemsetAsync( g_ws.rp_redone.p, 0, (size_t)n * 4 + 64, g_stream ), RS_HIP_E_RUNTIME );
+  }
   if( exact_centroids ) { cx.L.exact_centroids = 1; cx.L.centroid_totals = RB.totals; }
+  if( chains )
+  {
+    CB.n_seg = chain_segments( source->n ); CB.n_blk = chain_blocks( source->n );
+    const size_t rows = (size_t)n * CH_ROWS;
+    if( ( rc = g_ws.ch_rec.ensure( (size_t)n * (size_t)source->n * 64 ) ) || ( rc = g_ws.ch_segsum.ensure( rows * CB.n_seg * 8 ) ) ||
+        ( rc = g_ws.ch_prefix.ensure( rows * CB.n_seg * 8 ) ) || ( rc = g_ws.ch_seg.ensure( rows * CB.n_seg * sizeof( ChainRec ) ) ) ||
+        ( rc = g_ws.ch_blk.ensure( rows * CB.n_blk * sizeof( ChainRec ) ) ) ) return rc;
+    CB.segsum = g_ws.ch_segsum.as<double>(); CB.prefix = g_ws.ch_prefix.as<double>(); CB.seg = (ChainRec*)g_ws.ch_seg.p; CB.blk = (ChainRec*)g_ws.ch_blk.p;
+    CB.totals = RB.totals; CB.resolved = RB.redone;
+    if( getenv( "RS_HIP_CHAIN_DEBUG" ) )
+    {
+      if( ( rc = g_ws.ch_dbg.ensure( rows * ( 1 + 64 * 8 ) * 4 ) ) ) return rc;
+      CB.dbg = g_ws.ch_dbg.as<int>();
+    }
+    cx.L.rec = (float4*)g_ws.ch_rec.p;
+  }
   if( !ref_order && !replay )
   {
     HIP_TRY( hipMemsetAsync( g_ws.stat_acc.p, 0, (size_t)n * STAT_SHARDS * 4 * 8, g_stream ), RS_HIP_E_RUNTIME );
@@ -957,6 +982,7 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
       if( debug ) icp_debug_after( cx, source->n, n, i, max_dist );
       prof.mark( "icp_moments" );
       if( replay ) launch_icp_replay( cx.L, RB, g_stream );
+      else if( chains ) launch_icp_chain_centroids( cx.L, CB, g_stream );
       else if( exact_centroids ) launch_icp_exact_centroids( cx.L, RB, g_stream );
       else if( cx.L.faith ) launch_icp_faithful( cx.L, g_stream ); else launch_icp_moments( cx.L, g_stream );
       double nd = max_dist * 0.95;                                      // icp.h:493
@@ -968,6 +994,22 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
     int n_active = 0;
     for( int p = 0; p < n; ++p ) n_active += hActive[p] ? 1 : 0;
     if( n_active == 0 ) break;
+  }
+  if( CB.dbg )      // RS_HIP_CHAIN_DEBUG: which segments the last iteration's chain walks added up addend by addend, and why their record did not fit
+  {
+    std::vector<int> d( (size_t)CH_ROWS * ( 1 + 64 * 8 ) );
+    (void)hipMemcpy( d.data(), CB.dbg, d.size() * 4, hipMemcpyDeviceToHost );
+    for( int r = 0; r < CH_ROWS; ++r )
+    {
+      const int* q = d.data() + (size_t)r * ( 1 + 64 * 8 );
+      fprintf( stderr, "[rs_hip chains] chain %d: %d segments added one by one\n", r, q[0] );
+      for( int k = 0; k < std::min( q[0], 64 ); ++k )
+      {
+        const int* e = q + 1 + 8 * k; const unsigned sb = (unsigned)e[1];
+        fprintf( stderr, "   segment %6d (block %4d): value exp %3u mantissa %8u sign %u | guess exp %3d sign %d -> class %d: lo %8d hi %8d D %8d\n", e[0], e[7], ( sb >> 23 ) & 255u,
+                 ( sb & 0x7fffffu ) | 0x800000u, sb >> 31, e[2] & 255, e[2] >> 8, e[3], e[4], e[5], e[6] );
+      }
+    }
   }
   const int* hIters = (const int*)( hS + np * 33 );
   for( int p = 0; p < n; ++p ) { std::memcpy( T1s + 16 * p, hS + 16 * p, 64 ); errs[p] = hS[np * 34 + p]; if( iters ) iters[p] = hIters[p]; }
@@ -991,7 +1033,7 @@ int32_t rs_hip_icp_replay_below( int32_t n_points )
 int32_t rs_hip_icp_exact_centroids( int32_t on )
 {
   const int prev = g_exact_centroids.load();
-  if( on >= 0 ) g_exact_centroids.store( on ? 1 : 0 );
+  if( on >= 0 ) g_exact_centroids.store( on > 2 ? 1 : on );
   return prev;
 }
 

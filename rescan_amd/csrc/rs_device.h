@@ -123,7 +123,30 @@ struct IcpLaunch
   // (icp.h:136-148: Σw, Σw·p, Σw·q) as the reference's own sequential fp32 chains — see launch_icp_exact_centroids
   int     exact_centroids;
   const double* centroid_totals;   // n_prob x 3 x ICP_NMOM (ReplayBufs::totals): [ICP_NMOM + 0..6] = the seven chain totals
+  // ... and their fast form (rs_kernels.hip: "grid chains"): every search writes one 64-byte record per source point at the point's
+  // ORIGINAL index — {p.xyz, dist² (< 0: no match)} {q.xyz, dot} {n.xyz, -} {-} — which the estimator's kernels then read in the
+  // reference's own order, coalesced (null: not wanted)
+  float4* rec;                     // n_prob x n x 4
 };
+
+// The seven centroid chains (Σw, Σw·p, Σw·q: icp.h:136-148) as sequential fp32 sums, computed on the integer grid of the
+// running sum's binade (rs_kernels.hip: "grid chains").  Segments of 64 source points (original order), blocks of 64 segments.
+constexpr int CH_ROWS = 7, CH_SEG = 64, CH_BLK = 64;
+struct ChainRec { int e_sign; int lo[3], hi[3], D[3]; };   // exponent guess | sign << 8; per exponent e-1, e, e+1: the start mantissas it holds for and the advance
+struct ChainBufs
+{
+  int       n_seg, n_blk;
+  double*   segsum;     // n_prob x CH_ROWS x n_seg : fp64 sums of the segments' addends
+  double*   prefix;     // n_prob x CH_ROWS x n_seg : their exclusive prefix — the guess of the running sum at a segment's start
+  ChainRec* seg;        // n_prob x CH_ROWS x n_seg
+  ChainRec* blk;        // n_prob x CH_ROWS x n_blk : 64 segments composed
+  double*   totals;     // n_prob x 3 x ICP_NMOM (the layout of ReplayBufs::totals; the chains fill [ICP_NMOM + 0..6])
+  int*      resolved;   // n_prob: segments the walks had to add up one addend after the other (diagnostics)
+  int*      dbg;        // RS_HIP_CHAIN_DEBUG: per chain 1 + 64 x 8 words — count, then {segment, value bits, guess, lo / hi / D of the class tried} of the first 64 such segments
+};
+void   launch_icp_chain_centroids( const IcpLaunch& L, const ChainBufs& B, hipStream_t st );
+inline int chain_segments( int n ) { return ( n + CH_SEG - 1 ) / CH_SEG; }
+inline int chain_blocks( int n ) { return ( chain_segments( n ) + CH_BLK - 1 ) / CH_BLK; }
 void launch_icp_corr( const IcpLaunch& L, hipStream_t st );     // phase A, phase B (the tiles add their dist² statistics to L.stat_acc)
 void launch_icp_moments( const IcpLaunch& L, hipStream_t st );  // weights + moments (+ solve and loop-state update if L.solve)
 constexpr int FAITH_REC = 11;   // per correspondence: dist² (< 0: none), dot | weight, p, q, n

@@ -1336,7 +1336,26 @@ __device__ __forceinline__ void icp_emit( const IcpLaunch& L, int prob, int tile
                                           bool skipped )
 {
   const size_t o = (size_t)prob * L.src.n + i;
-  if( active ) { L.m_slot[o] = m.found ? m.slot : -1; L.m_d2[o] = m.d2; L.m_dot[o] = m.dot; }
+  if( active ) { L.m_slot[o] = m.found ? m.slot : -1; if( !L.rec ) { L.m_d2[o] = m.d2; L.m_dot[o] = m.dot; } }
+  if( active && L.rec )
+  {
+    // the correspondence as the estimator wants it, at the source point's ORIGINAL index: one full 64-byte line per point, so the
+    // scattered store is a whole memory transaction (the estimator's kernels then read the reference's order coalesced, instead
+    // of gathering slot / dist² / dot / source / target point / target normal at random: 5 transactions per point)
+    Xform T1;
+#pragma unroll
+    for( int k = 0; k < 16; ++k ) T1.m[k] = L.T1[prob * 16 + k];
+    float qx, qy, qz, nx, ny, nz;
+    icp_query( L, T1, i, true, qx, qy, qz, nx, ny, nz );           // (the same float operations the search used)
+    float4 P = make_float4( 0.0f, 0.0f, 0.0f, 0.0f ), N = P;
+    if( m.found ) { P = L.tgt.pos[m.slot]; N = L.tgt.nor[m.slot]; }
+    const int orig = __float_as_int( L.src.pos[i].w );
+    float4* R = L.rec + ( (size_t)prob * L.src.n + orig ) * 4;
+    R[0] = make_float4( qx, qy, qz, m.found ? m.d2 : -1.0f );
+    R[1] = make_float4( P.x, P.y, P.z, m.dot );
+    R[2] = make_float4( N.x, N.y, N.z, 0.0f );
+    R[3] = make_float4( 0.0f, 0.0f, 0.0f, 0.0f );
+  }
   if( active && L.cert_r && !skipped )
   {
     // fresh certificate (m.idx != INT_MAX: a gated candidate exists at dist² m.d2, even if its rank rejected it)
@@ -2546,6 +2565,394 @@ void launch_icp_exact_centroids( const IcpLaunch& L, const ReplayBufs& B, hipStr
   launch_replay_pass<2>( L, B, st );
   hipLaunchKernelGGL( k_icp_update, dim3( L.n_prob ), dim3( UPDATE_WAVES * WAVE ), 0, st, L );
 }
+// ------------------------------------------------------------------------------------------
+// Grid chains: the reference's seven centroid sums (icp.h:136-148), bit for bit, at the cost of a reduction
+//
+// A sequential fp32 sum  s <- RN( s + x )  is an INTEGER sum while s stays inside one binade: with u = ulp( s ), s = M u,
+// RN( s + x ) = ( M + rndne( x / u ) ) u  unless x / u sits exactly half way between two integers (then the parity of M decides) —
+// and integer addition is associative.  So for a stretch of addends and an exponent E the whole effect on the chain is three
+// integers: D = Σ rndne( x_i / u ) and the smallest / largest partial sum, which say for which start mantissas M the chain stays
+// inside the binade all the way (a margin of one grid step at the ends keeps clear of the neighbouring binades' grids).  Such
+// records compose (intervals intersect, advances add).  The only sequential part left is the handful of places where the chain
+// really changes binade (~20 times on the way from 0 to 2^21), a tie, or a sign change: there the addends of one segment are
+// added one after the other in fp32.
+//
+//   the searches    leave one 64-byte record per source point at the point's ORIGINAL index (icp_emit);
+//   k_chain_moments the fp64 moments of k_icp_moments, read from those records in the reference's order, + per segment of 64
+//                   points the fp64 sums of the seven chains' addends;
+//   k_chain_scan    their exclusive prefix per chain: a guess of the running sum at every segment's start — good enough for
+//                   its EXPONENT (the fp32 chain itself drifts by parts in a thousand; records are made for e-1, e, e+1);
+//   k_chain_records one record per (segment, chain), and 64 of them composed per block;
+//   k_chain_walk    one wave per chain walks the blocks with the exact value: a wave-wide scan composes 64 block records at a
+//                   time and finds the first one the value does not fit; that block is walked by its segments the same way, the
+//                   segment that does not fit is added up addend by addend.  Then the same workgroup finishes the iteration
+//                   (icp.h:253-295,455-493) like k_icp_update, centred on the chains' centroids.
+// ------------------------------------------------------------------------------------------
+struct ChainPar { bool use_sd; float cut, max_dist; };
+
+// the seven addends of one source point (faith_terms<2>: icp.h:141-142, weights icp.h:387,396-401)
+__device__ __forceinline__ void chain_addends( const float4& A, const float4& Bq, const ChainPar& P, float x[CH_ROWS], float& w )
+{
+  const bool m = A.w >= 0.0f;
+  w = 0.0f;
+  if( m )
+  {
+    w = ( 1.0f - __fdiv_rn( A.w, P.max_dist ) ) * Bq.w;
+    if( P.use_sd && A.w > P.cut ) w = 0.0f;
+  }
+  x[0] = w;
+  x[1] = m ? A.x * w : 0.0f;  x[2] = m ? A.y * w : 0.0f;  x[3] = m ? A.z * w : 0.0f;
+  x[4] = m ? Bq.x * w : 0.0f; x[5] = m ? Bq.y * w : 0.0f; x[6] = m ? Bq.z * w : 0.0f;
+}
+
+// n_corr, mean, stddev of dist² from the searches' integer statistics (as k_icp_moments); every thread of the block gets the same bits
+__device__ __forceinline__ float chain_stats( const IcpLaunch& L, int prob, unsigned long long ( *s_stat )[3], double* st_out )
+{
+  static_assert( STAT_SHARDS == BLOCK, "one shard per thread" );
+  const unsigned long long* a = L.stat_acc + ( (size_t)prob * STAT_SHARDS + ( threadIdx.x & ( BLOCK - 1 ) ) ) * 4;
+  const bool mine = threadIdx.x < BLOCK;
+  const unsigned long long c0 = wave_sum_u64( mine ? a[0] : 0ull ), c1 = wave_sum_u64( mine ? a[1] : 0ull ), c2 = wave_sum_u64( mine ? a[2] : 0ull );
+  if( mine && ( threadIdx.x & ( WAVE - 1 ) ) == 0 ) { unsigned long long* o = s_stat[threadIdx.x / WAVE]; o[0] = c0; o[1] = c1; o[2] = c2; }
+  __syncthreads();
+  unsigned long long t0 = 0, t1 = 0, t2 = 0;
+#pragma unroll
+  for( int w = 0; w < WAVES_PER_BLOCK; ++w ) { t0 += s_stat[w][0]; t1 += s_stat[w][1]; t2 += s_stat[w][2]; }
+  const double n = (double)t0;
+  const float mean = (float)( (double)t1 * L.stat_i1 / n );           // sum / (float)n
+  const float sqm = (float)( (double)t2 * L.stat_i2 / n );            // sq_sum / (float)n
+  const float var = sqm - mean * mean;
+  const float sd = (float)sqrt( (double)var );                        // (float)sqrt( ... ), msh_std.h:1824
+  if( st_out ) { st_out[0] = n; st_out[1] = mean; st_out[2] = sd; st_out[3] = (double)L.queue_count[prob]; }
+  return sd;
+}
+
+__global__ __launch_bounds__( BLOCK ) void k_chain_moments( IcpLaunch L, ChainBufs B )
+{
+  __shared__ double red[WAVES_PER_BLOCK][ICP_NMOM];
+  __shared__ unsigned long long s_stat[WAVES_PER_BLOCK][3];
+  const int prob = blockIdx.y;
+  if( L.active[prob] == 0 ) return;
+  const float sd = chain_stats( L, prob, s_stat, ( blockIdx.x == 0 && threadIdx.x == 0 ) ? L.res + (size_t)prob * ICP_NRES + ICP_NMOM : nullptr );
+  ChainPar P; P.use_sd = sd > 0.000001; P.cut = 2.5f * sd; P.max_dist = L.radius;
+  const int lane = threadIdx.x & ( WAVE - 1 ), wib = threadIdx.x / WAVE;
+  const float4* R = L.rec + (size_t)prob * L.src.n * 4;
+
+  double acc[ICP_NMOM];
+#pragma unroll
+  for( int k = 0; k < ICP_NMOM; ++k ) acc[k] = 0.0;
+  const int n_pad = B.n_seg * CH_SEG;
+  for( int i = blockIdx.x * BLOCK + threadIdx.x; i < n_pad; i += gridDim.x * BLOCK )     // a wave's 64 lanes = one segment
+  {
+    float4 A = make_float4( 0.0f, 0.0f, 0.0f, -1.0f ), Q = make_float4( 0.0f, 0.0f, 0.0f, 0.0f ), N4 = Q;
+    if( i < L.src.n ) { A = R[(size_t)i * 4]; Q = R[(size_t)i * 4 + 1]; N4 = R[(size_t)i * 4 + 2]; }
+    float x[CH_ROWS], w;
+    chain_addends( A, Q, P, x, w );
+    const int seg = i / CH_SEG;
+#pragma unroll
+    for( int r = 0; r < CH_ROWS; ++r )
+    {
+      const double v = wave_sum( (double)x[r] );
+      if( lane == 0 ) B.segsum[( (size_t)prob * CH_ROWS + r ) * B.n_seg + seg] = v;
+    }
+    if( A.w < 0.0f ) continue;
+    const double W = w, p[3] = { A.x, A.y, A.z }, q[3] = { Q.x, Q.y, Q.z }, n[3] = { N4.x, N4.y, N4.z };
+    const double a[3] = { p[1] * n[2] - p[2] * n[1], p[2] * n[0] - p[0] * n[2], p[0] * n[1] - p[1] * n[0] };
+    const double e = ( p[0] - q[0] ) * n[0] + ( p[1] - q[1] ) * n[1] + ( p[2] - q[2] ) * n[2];
+    acc[0] += W;
+    acc[1] += W * p[0]; acc[2] += W * p[1]; acc[3] += W * p[2];
+    acc[4] += W * q[0]; acc[5] += W * q[1]; acc[6] += W * q[2];
+    acc[7]  += W * a[0] * a[0]; acc[8]  += W * a[0] * a[1]; acc[9]  += W * a[0] * a[2];
+    acc[10] += W * a[1] * a[1]; acc[11] += W * a[1] * a[2]; acc[12] += W * a[2] * a[2];
+#pragma unroll
+    for( int r = 0; r < 3; ++r )
+#pragma unroll
+      for( int c = 0; c < 3; ++c ) acc[13 + 3 * r + c] += W * a[r] * n[c];
+    acc[22] += W * n[0] * n[0]; acc[23] += W * n[0] * n[1]; acc[24] += W * n[0] * n[2];
+    acc[25] += W * n[1] * n[1]; acc[26] += W * n[1] * n[2]; acc[27] += W * n[2] * n[2];
+    acc[28] += W * a[0] * e; acc[29] += W * a[1] * e; acc[30] += W * a[2] * e;
+    acc[31] += W * n[0] * e; acc[32] += W * n[1] * e; acc[33] += W * n[2] * e;
+    acc[34] += W * e * e;
+  }
+#pragma unroll
+  for( int k = 0; k < ICP_NMOM; ++k ) { double v = wave_sum( acc[k] ); if( lane == 0 ) red[wib][k] = v; }
+  __syncthreads();
+  if( threadIdx.x < ICP_NMOM )
+  {
+    double v = 0.0;
+    for( int w = 0; w < WAVES_PER_BLOCK; ++w ) v += red[w][threadIdx.x];
+    L.mom_part[( (size_t)prob * L.n_mom_blocks + blockIdx.x ) * ICP_NMOM + threadIdx.x] = v;
+  }
+}
+
+// exclusive prefix of the segment sums, per chain (a guess: any association will do)
+__global__ __launch_bounds__( BLOCK ) void k_chain_scan( IcpLaunch L, ChainBufs B )
+{
+  __shared__ double part[BLOCK];
+  const int prob = blockIdx.y, row = blockIdx.x;
+  if( L.active[prob] == 0 ) return;
+  const double* in = B.segsum + ( (size_t)prob * CH_ROWS + row ) * B.n_seg;
+  double* out = B.prefix + ( (size_t)prob * CH_ROWS + row ) * B.n_seg;
+  const int per = ( B.n_seg + BLOCK - 1 ) / BLOCK, g0 = threadIdx.x * per, g1 = min( g0 + per, B.n_seg );
+  double a = 0.0;
+  for( int g = g0; g < g1; ++g ) a += in[g];
+  part[threadIdx.x] = a;
+  __syncthreads();
+  if( threadIdx.x == 0 ) { double run = 0.0; for( int t = 0; t < BLOCK; ++t ) { const double v = part[t]; part[t] = run; run += v; } }
+  __syncthreads();
+  double run = part[threadIdx.x];
+  for( int g = g0; g < g1; ++g ) { out[g] = run; run += in[g]; }
+}
+
+#define CH_M_LO ( 1 << 23 )
+#define CH_M_HI ( ( 1 << 24 ) - 1 )
+// a record's three functions  M -> M + D  (valid for lo <= M <= hi), kept normalised: lo, hi inside the mantissa range, lo > hi = never
+struct ChainFn { int lo, hi, D; };
+__device__ __forceinline__ ChainFn chain_never() { ChainFn f; f.lo = CH_M_HI; f.hi = CH_M_LO; f.D = 0; return f; }
+__device__ __forceinline__ ChainFn chain_identity() { ChainFn f; f.lo = CH_M_LO; f.hi = CH_M_HI; f.D = 0; return f; }
+// first f, then g
+__device__ __forceinline__ ChainFn chain_then( const ChainFn& f, const ChainFn& g )
+{
+  if( f.lo > f.hi || g.lo > g.hi ) return chain_never();
+  ChainFn h;                                    // (|D| < 2^24 and lo, hi in [2^23, 2^24) for valid records: no overflow)
+  h.lo = max( f.lo, g.lo - f.D ); h.hi = min( f.hi, g.hi - f.D ); h.D = f.D + g.D;
+  if( h.lo > h.hi ) return chain_never();
+  return h;
+}
+// the function of a record for the (biased) exponent E and sign bit sg of the running value
+__device__ __forceinline__ ChainFn chain_select( const ChainRec& r, int E, int sg )
+{
+  const int c = E - ( r.e_sign & 255 ) + 1;
+  ChainFn f = chain_never();
+  if( ( r.e_sign >> 8 ) == sg )
+  {
+    if( c == 0 ) { f.lo = r.lo[0]; f.hi = r.hi[0]; f.D = r.D[0]; }
+    if( c == 1 ) { f.lo = r.lo[1]; f.hi = r.hi[1]; f.D = r.D[1]; }
+    if( c == 2 ) { f.lo = r.lo[2]; f.hi = r.hi[2]; f.D = r.D[2]; }
+  }
+  return f;
+}
+// inclusive scan over the lanes, in lane order (the composition is not commutative): lane l ends with f_0 then f_1 ... then f_l
+__device__ __forceinline__ ChainFn chain_wave_scan( ChainFn f, int lane )
+{
+#pragma unroll
+  for( int d = 1; d < WAVE; d <<= 1 )
+  {
+    ChainFn e; e.lo = __shfl_up( f.lo, d ); e.hi = __shfl_up( f.hi, d ); e.D = __shfl_up( f.D, d );
+    if( lane >= d ) f = chain_then( e, f );
+  }
+  return f;
+}
+
+#define CHAIN_REC_WAVES 16
+__global__ __launch_bounds__( CHAIN_REC_WAVES * WAVE ) void k_chain_records( IcpLaunch L, ChainBufs B )
+{
+  __shared__ ChainRec s_rec[CH_ROWS][CH_BLK];
+  __shared__ unsigned long long s_stat[WAVES_PER_BLOCK][3];
+  const int prob = blockIdx.y, blk = blockIdx.x;
+  if( L.active[prob] == 0 ) return;
+  const float sd = chain_stats( L, prob, s_stat, nullptr );
+  ChainPar P; P.use_sd = sd > 0.000001; P.cut = 2.5f * sd; P.max_dist = L.radius;
+  const int lane = threadIdx.x & ( WAVE - 1 ), wib = threadIdx.x / WAVE;
+  const float4* R = L.rec + (size_t)prob * L.src.n * 4;
+  for( int sb = wib; sb < CH_BLK; sb += CHAIN_REC_WAVES )
+  {
+    const int seg = blk * CH_BLK + sb;
+    if( seg >= B.n_seg )
+    {
+      // past the end of the cloud: nothing is added
+      if( lane < CH_ROWS ) { ChainRec r; r.e_sign = -1; for( int c = 0; c < 3; ++c ) { r.lo[c] = CH_M_LO; r.hi[c] = CH_M_HI; r.D[c] = 0; } s_rec[lane][sb] = r; }
+      continue;
+    }
+    const int i = seg * CH_SEG + lane;
+    float4 A = make_float4( 0.0f, 0.0f, 0.0f, -1.0f ), Q = make_float4( 0.0f, 0.0f, 0.0f, 0.0f );
+    if( i < L.src.n ) { A = R[(size_t)i * 4]; Q = R[(size_t)i * 4 + 1]; }
+    float x[CH_ROWS], w;
+    chain_addends( A, Q, P, x, w );
+#pragma unroll
+    for( int r = 0; r < CH_ROWS; ++r )
+    {
+      const double guess = B.prefix[( (size_t)prob * CH_ROWS + r ) * B.n_seg + seg];
+      const uint32_t gb = __float_as_uint( (float)guess );
+      const int eg = (int)( ( gb >> 23 ) & 255u ), sg = (int)( gb >> 31 );
+      ChainRec rec; rec.e_sign = eg | ( sg << 8 );
+      const float xs = sg ? -x[r] : x[r];                                  // the chain of |s|: s + x = -( |s| + (-x) ) for negative s
+#pragma unroll
+      for( int c = 0; c < 3; ++c )
+      {
+        const int E = eg - 1 + c;                                          // s = M * 2^(E - 150), M in [2^23, 2^24)
+        const float y = ldexpf( xs, 150 - E );                             // x / ulp( s ): exact (a power of two), or 0 / inf at the ends
+        const float rn = rintf( y );                                       // to nearest, ties to even
+        const bool bad = !( fabsf( y ) < 8388608.0f ) || fabsf( y - rn ) == 0.5f;     // too big for this binade (or NaN), or a tie: M's parity would decide
+        const int ri = bad ? 0 : (int)rn;
+        const uint32_t incl = wave_scan( (uint32_t)ri, lane );             // partial sums (two's complement)
+        int pmin = min( (int)incl, 0 ), pmax = max( (int)incl, 0 );         // ... including the start itself
+        for( int d = 1; d < WAVE; d <<= 1 ) { pmin = min( pmin, __shfl_xor( pmin, d ) ); pmax = max( pmax, __shfl_xor( pmax, d ) ); }
+        const int D = __builtin_amdgcn_readlane( (int)incl, WAVE - 1 );
+        const bool any_bad = wave_any( bad ) || E < 1 || E > 254;
+        // every value on the way, the start included, at least one grid step inside the binade: the neighbouring binades' grids
+        // (half / twice as fine) then play no part in any of the roundings
+        long long lo = (long long)CH_M_LO + 1 - pmin, hi = (long long)CH_M_HI - 1 - pmax;
+        lo = lo < CH_M_LO ? CH_M_LO : lo; hi = hi > CH_M_HI ? CH_M_HI : hi;
+        const bool ok = !any_bad && lo <= hi;
+        rec.lo[c] = ok ? (int)lo : CH_M_HI; rec.hi[c] = ok ? (int)hi : CH_M_LO; rec.D[c] = ok ? D : 0;
+      }
+      if( lane == 0 ) { B.seg[( (size_t)prob * CH_ROWS + r ) * B.n_seg + seg] = rec; s_rec[r][sb] = rec; }
+    }
+  }
+  __syncthreads();
+  // the block's 64 segments composed, per chain and exponent around the block's first guess
+  for( int job = wib; job < CH_ROWS * 3; job += CHAIN_REC_WAVES )
+  {
+    const int r = job / 3, c = job % 3;
+    const int first = s_rec[r][0].e_sign;
+    const int E = ( first & 255 ) - 1 + c, sg = first >> 8;
+    const ChainRec mine = s_rec[r][lane];
+    ChainFn f = mine.e_sign == -1 ? chain_identity() : chain_select( mine, E, sg );
+    f = chain_wave_scan( f, lane );
+    if( lane == WAVE - 1 )
+    {
+      ChainRec* out = B.blk + ( (size_t)prob * CH_ROWS + r ) * B.n_blk + blk;
+      if( c == 0 ) out->e_sign = first;
+      out->lo[c] = f.lo; out->hi[c] = f.hi; out->D[c] = f.D;
+    }
+  }
+}
+
+// One chain walked by one wave.  `s` (uniform) is the exact running value.
+__device__ __forceinline__ float chain_walk( const IcpLaunch& L, const ChainBufs& B, int prob, int row, const ChainPar& P, int lane, int* n_resolved )
+{
+  const ChainRec* blks = B.blk + ( (size_t)prob * CH_ROWS + row ) * B.n_blk;
+  const ChainRec* segs = B.seg + ( (size_t)prob * CH_ROWS + row ) * B.n_seg;
+  const float4* R = L.rec + (size_t)prob * L.src.n * 4;
+  float s = 0.0f;
+  int resolved = 0;
+  // advance over the records held by the lanes [from, count): as far as the value fits; returns the first lane that does not (count: all done)
+  auto advance = [&]( const ChainRec& mine, int from, int count ) -> int
+  {
+    const uint32_t sb = __float_as_uint( s );
+    const int E = (int)( ( sb >> 23 ) & 255u ), sg = (int)( sb >> 31 ), M = (int)( sb & 0x7fffffu ) | CH_M_LO;
+    ChainFn f = ( lane < from || lane >= count ) ? chain_identity() : chain_select( mine, E, sg );
+    if( E == 0 || E == 255 ) f = ( lane < from || lane >= count ) ? chain_identity() : chain_never();      // zero, denormal, inf, NaN: one by one
+    f = chain_wave_scan( f, lane );
+    const bool fits = f.lo <= f.hi && M >= f.lo && M <= f.hi;
+    const unsigned long long good = RS_BALLOT( fits ) | ( from > 0 ? ( ( 1ull << from ) - 1ull ) : 0ull );
+    const int stop = good == ~0ull ? WAVE : __builtin_ctzll( ~good );       // the fitting lanes are a prefix: the intervals only shrink
+    const int last = min( stop, count ) - 1;
+    if( last >= from )
+    {
+      const int D = __builtin_amdgcn_readlane( f.D, last );
+      s = __uint_as_float( ( sb & 0xff800000u ) | ( (uint32_t)( M + D ) & 0x7fffffu ) );
+    }
+    return min( stop, count );
+  };
+  for( int b0 = 0; b0 < B.n_blk; b0 += WAVE )
+  {
+    const int nb = min( WAVE, B.n_blk - b0 );
+    ChainRec mine; mine.e_sign = -1;
+    if( lane < nb ) mine = blks[b0 + lane];
+    int at = 0;
+    while( at < nb )
+    {
+      at = advance( mine, at, nb );
+      if( at >= nb ) break;
+      // block b0 + at does not fit as a whole: by its segments
+      const int g0 = ( b0 + at ) * CH_BLK, ns = min( CH_BLK, B.n_seg - g0 );
+      ChainRec smine; smine.e_sign = -1;
+      if( lane < ns ) smine = segs[g0 + lane];
+      int sat = 0;
+      while( sat < ns )
+      {
+        sat = advance( smine, sat, ns );
+        if( sat >= ns ) break;
+        // segment g0 + sat: its 64 addends one after the other, in fp32 — the reference's own operations
+        if( B.dbg && resolved < 64 )
+        {
+          const ChainRec why = segs[g0 + sat];
+          const uint32_t sb = __float_as_uint( s );
+          const int c = (int)( ( sb >> 23 ) & 255u ) - ( why.e_sign & 255 ) + 1;
+          int* d = B.dbg + ( (size_t)prob * CH_ROWS + row ) * ( 1 + 64 * 8 ) + 1 + resolved * 8;
+          if( lane == 0 ) { d[0] = g0 + sat; d[1] = (int)sb; d[2] = why.e_sign; d[3] = c; d[4] = ( c >= 0 && c < 3 ) ? why.lo[c] : 0; d[5] = ( c >= 0 && c < 3 ) ? why.hi[c] : 0; d[6] = ( c >= 0 && c < 3 ) ? why.D[c] : 0; d[7] = at + b0; }
+        }
+        const int i = ( g0 + sat ) * CH_SEG + lane;
+        float4 A = make_float4( 0.0f, 0.0f, 0.0f, -1.0f ), Q = make_float4( 0.0f, 0.0f, 0.0f, 0.0f );
+        if( i < L.src.n ) { A = R[(size_t)i * 4]; Q = R[(size_t)i * 4 + 1]; }
+        float x[CH_ROWS], w;
+        chain_addends( A, Q, P, x, w );
+        float xr = x[0];
+#pragma unroll
+        for( int r = 1; r < CH_ROWS; ++r ) xr = row == r ? x[r] : xr;
+#pragma unroll 8
+        for( int j = 0; j < CH_SEG; ++j ) s = s + __int_as_float( __builtin_amdgcn_readlane( __float_as_int( xr ), j ) );
+        s = __int_as_float( uni( __float_as_int( s ) ) );
+        ++resolved; ++sat;
+      }
+      ++at;
+    }
+  }
+  if( n_resolved ) *n_resolved = resolved;
+  if( B.dbg && lane == 0 ) B.dbg[( (size_t)prob * CH_ROWS + row ) * ( 1 + 64 * 8 )] = resolved;
+  return s;
+}
+
+// One workgroup per problem: the moments' tree (as k_icp_update), the seven chains (waves 0-6), then the rest of the iteration.
+__global__ __launch_bounds__( UPDATE_WAVES * WAVE ) void k_chain_walk_update( IcpLaunch L, ChainBufs B )
+{
+  __shared__ unsigned long long s_stat[WAVES_PER_BLOCK][3];
+  const int prob = blockIdx.x;
+  if( L.active[prob] == 0 ) return;
+  const int lane = threadIdx.x & ( WAVE - 1 ), wib = threadIdx.x / WAVE;
+  const float sd = chain_stats( L, prob, s_stat, nullptr );
+  ChainPar P; P.use_sd = sd > 0.000001; P.cut = 2.5f * sd; P.max_dist = L.radius;
+  double* res = L.res + (size_t)prob * ICP_NRES;
+  if( wib < CH_ROWS )
+  {
+    int resolved = 0;
+    const float v = chain_walk( L, B, prob, wib, P, lane, &resolved );
+    if( lane == 0 ) { B.totals[( (size_t)prob * 3 + 1 ) * ICP_NMOM + wib] = (double)v; if( B.resolved ) atomicAdd( B.resolved + prob, resolved ); }
+  }
+  else
+  {
+    const double* in = L.mom_part + (size_t)prob * L.n_mom_blocks * ICP_NMOM;
+    for( int k = wib - CH_ROWS; k < ICP_NMOM; k += UPDATE_WAVES - CH_ROWS )
+    {
+      double v = 0.0;
+      for( int b = lane; b < L.n_mom_blocks; b += WAVE ) v += in[(size_t)b * ICP_NMOM + k];
+      v = wave_sum( v );
+      if( lane == 0 ) res[k] = v;
+    }
+  }
+  __syncthreads();
+  if( !L.solve ) return;
+  icp_iteration_reset( L, prob );
+  if( threadIdx.x != 0 ) return;
+  // ---- icp.h:455-493 for this problem (as k_icp_update) ----
+  L.prev_err[prob] = L.err[prob];
+  L.iters[prob] += 1;
+  if( res[ICP_NMOM] == 0.0 ) { L.active[prob] = 0; return; }            // icp.h:455-459: no correspondences
+  Mat4 T;
+  for( int k = 0; k < 16; ++k ) { T.m[k] = L.T1[prob * 16 + k]; L.T1_prev[prob * 16 + k] = T.m[k]; }
+  const double* t2 = B.totals + ( (size_t)prob * 3 + 1 ) * ICP_NMOM;
+  const float total = (float)t2[0];
+  if( total <= 1e-7 ) { L.active[prob] = 0; return; }                   // icp.h:466-470
+  const float inv = __fdiv_rn( 1.0f, total );
+  float cen[6];
+  for( int a = 0; a < 6; ++a ) cen[a] = (float)t2[1 + a] * inv;         // c = Σw·p * ( 1.0f / Σw ), icp.h:145-146
+  float e;
+  if( !icp_solve( res, T, e, cen ) ) { L.active[prob] = 0; return; }
+  for( int k = 0; k < 16; ++k ) L.T1[prob * 16 + k] = T.m[k];           // icp.h:295
+  L.err[prob] = e;
+  const float delta = fabsf( L.prev_err[prob] - e );
+  if( !L.fixed_iters && L.iter_index > 5 && delta < 1e-5 ) L.active[prob] = 0;   // icp.h:489
+}
+
+void launch_icp_chain_centroids( const IcpLaunch& L, const ChainBufs& B, hipStream_t st )
+{
+  hipLaunchKernelGGL( k_chain_moments, dim3( L.n_mom_blocks, L.n_prob ), dim3( BLOCK ), 0, st, L, B );
+  hipLaunchKernelGGL( k_chain_scan, dim3( CH_ROWS, L.n_prob ), dim3( BLOCK ), 0, st, L, B );
+  hipLaunchKernelGGL( k_chain_records, dim3( B.n_blk, L.n_prob ), dim3( CHAIN_REC_WAVES * WAVE ), 0, st, L, B );
+  hipLaunchKernelGGL( k_chain_walk_update, dim3( L.n_prob ), dim3( UPDATE_WAVES * WAVE ), 0, st, L, B );
+}
+
 int replay_segments( int n_source ) { return ( n_source + REPLAY_SEG - 1 ) / REPLAY_SEG; }
 int replay_superblocks( int n_source ) { return ( replay_segments( n_source ) + REPLAY_SUPER - 1 ) / REPLAY_SUPER; }
 size_t replay_seg_bytes() { return sizeof( ReplaySeg ); }
