@@ -119,7 +119,7 @@ struct Workspace
   DevBuf lvl_pos, lvl_nor, lvl_cnt, lvl_within, lvl_offset, lvl_adj, lvl_state, lvl_misc, lvl_flags, lvl_scan, lvl_samples, lvl_tmp, lvl_cursor, lvl_work_a, lvl_work_b;   // level builder
   DevBuf faith;                                                                 // reference-order estimator: correspondences in source order
   DevBuf rp_segsum, rp_guess, rp_seg, rp_super, rp_totals, rp_redone;                     // ... its parallel form (replay)
-  DevBuf ch_rec, ch_segsum, ch_prefix, ch_seg, ch_blk, ch_dbg;                                    // the centroid chains of large sources (grid chains)
+  DevBuf ch_rec, ch_segsum, ch_prefix, ch_seg, ch_blk, ch_x0, ch_dbg;                                    // the centroid chains of large sources (grid chains)
   PinBuf h_a, h_b, h_c;
 };
 thread_local Workspace g_ws;
@@ -918,16 +918,19 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
     CB.n_seg = chain_segments( source->n ); CB.n_blk = chain_blocks( source->n );
     const size_t rows = (size_t)n * CH_ROWS;
     if( ( rc = g_ws.ch_rec.ensure( (size_t)n * (size_t)source->n * 64 ) ) || ( rc = g_ws.ch_segsum.ensure( rows * CB.n_seg * 8 ) ) ||
-        ( rc = g_ws.ch_prefix.ensure( rows * CB.n_seg * 8 ) ) || ( rc = g_ws.ch_seg.ensure( rows * CB.n_seg * sizeof( ChainRec ) ) ) ||
-        ( rc = g_ws.ch_blk.ensure( rows * CB.n_blk * sizeof( ChainRec ) ) ) ) return rc;
-    CB.segsum = g_ws.ch_segsum.as<double>(); CB.prefix = g_ws.ch_prefix.as<double>(); CB.seg = (ChainRec*)g_ws.ch_seg.p; CB.blk = (ChainRec*)g_ws.ch_blk.p;
+        ( rc = g_ws.ch_prefix.ensure( rows * CB.n_blk * 4 * 8 ) ) || ( rc = g_ws.ch_seg.ensure( rows * CB.n_seg * sizeof( ChainRec ) ) ) ||
+        ( rc = g_ws.ch_blk.ensure( rows * CB.n_blk * sizeof( ChainRec ) ) ) || ( rc = g_ws.ch_x0.ensure( rows * CH_BLK * CH_SEG * 4 ) ) ) return rc;
+    CB.segsum = g_ws.ch_segsum.as<double>(); CB.blksum = g_ws.ch_prefix.as<double>(); CB.seg = (ChainRec*)g_ws.ch_seg.p; CB.blk = (ChainRec*)g_ws.ch_blk.p; CB.x0 = g_ws.ch_x0.as<float>();
     CB.totals = RB.totals; CB.resolved = RB.redone;
     if( getenv( "RS_HIP_CHAIN_DEBUG" ) )
     {
-      if( ( rc = g_ws.ch_dbg.ensure( rows * ( 1 + 64 * 8 ) * 4 ) ) ) return rc;
+      if( ( rc = g_ws.ch_dbg.ensure( rows * ( 4 + 64 * 8 ) * 4 ) ) ) return rc;
       CB.dbg = g_ws.ch_dbg.as<int>();
     }
     cx.L.rec = (float4*)g_ws.ch_rec.p;
+    cx.L.n_mom_blocks = CB.n_blk * 4;              // k_chain_moments: one workgroup, one partial, per quarter block (1 024 source points)
+    if( ( rc = g_ws.mom_part.ensure( (size_t)n * CB.n_blk * 4 * ICP_NMOM * 8 ) ) ) return rc;
+    cx.L.mom_part = g_ws.mom_part.as<double>();
   }
   if( !ref_order && !replay )
   {
@@ -997,16 +1000,16 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
   }
   if( CB.dbg )      // RS_HIP_CHAIN_DEBUG: which segments the last iteration's chain walks added up addend by addend, and why their record did not fit
   {
-    std::vector<int> d( (size_t)CH_ROWS * ( 1 + 64 * 8 ) );
+    std::vector<int> d( (size_t)CH_ROWS * ( 4 + 64 * 8 ) );
     (void)hipMemcpy( d.data(), CB.dbg, d.size() * 4, hipMemcpyDeviceToHost );
     for( int r = 0; r < CH_ROWS; ++r )
     {
-      const int* q = d.data() + (size_t)r * ( 1 + 64 * 8 );
-      fprintf( stderr, "[rs_hip chains] chain %d: %d segments added one by one\n", r, q[0] );
-      for( int k = 0; k < std::min( q[0], 64 ); ++k )
+      const int* q = d.data() + (size_t)r * ( 4 + 64 * 8 );
+      fprintf( stderr, "[rs_hip chains] chain %d: %d segments added one by one%s; block 0 in LDS + cut after %.2f us, walk done after %.2f us\n", r, q[0] & 0xffff, ( q[0] >> 30 ) ? " (STUCK)" : "", q[1] / 100.0, q[3] / 100.0 );
+      for( int k = 0; k < std::min( q[0] & 0xffff, 64 ); ++k )
       {
-        const int* e = q + 1 + 8 * k; const unsigned sb = (unsigned)e[1];
-        fprintf( stderr, "   segment %6d (block %4d): value exp %3u mantissa %8u sign %u | guess exp %3d sign %d -> class %d: lo %8d hi %8d D %8d\n", e[0], e[7], ( sb >> 23 ) & 255u,
+        const int* e = q + 4 + 8 * k; const unsigned sb = (unsigned)e[1];
+        fprintf( stderr, "   segment %6d (at %6.2f us): value exp %3u mantissa %8u sign %u | guess exp %3d sign %d -> class %d: lo %8d hi %8d D %8d\n", e[0], e[7] / 100.0, ( sb >> 23 ) & 255u,
                  ( sb & 0x7fffffu ) | 0x800000u, sb >> 31, e[2] & 255, e[2] >> 8, e[3], e[4], e[5], e[6] );
       }
     }

@@ -1763,7 +1763,8 @@ __global__ __launch_bounds__( UPDATE_WAVES * WAVE ) void k_icp_update( IcpLaunch
   for( int k = wib; k < ICP_NMOM; k += UPDATE_WAVES )
   {
     double v = 0.0;
-    for( int b = lane; b < L.n_mom_blocks; b += WAVE ) v += in[(size_t)b * ICP_NMOM + k];
+    if( L.rec ) for( int b = lane; b < L.n_mom_blocks; b += WAVE ) v += in[(size_t)k * L.n_mom_blocks + b];      // k_chain_moments' layout (moment-major)
+    else        for( int b = lane; b < L.n_mom_blocks; b += WAVE ) v += in[(size_t)b * ICP_NMOM + k];
     v = wave_sum( v );
     if( lane == 0 ) res[k] = v;
   }
@@ -2578,15 +2579,15 @@ void launch_icp_exact_centroids( const IcpLaunch& L, const ReplayBufs& B, hipStr
 // added one after the other in fp32.
 //
 //   the searches    leave one 64-byte record per source point at the point's ORIGINAL index (icp_emit);
-//   k_chain_moments the fp64 moments of k_icp_moments, read from those records in the reference's order, + per segment of 64
-//                   points the fp64 sums of the seven chains' addends;
-//   k_chain_scan    their exclusive prefix per chain: a guess of the running sum at every segment's start — good enough for
-//                   its EXPONENT (the fp32 chain itself drifts by parts in a thousand; records are made for e-1, e, e+1);
-//   k_chain_records one record per (segment, chain), and 64 of them composed per block;
+//   k_chain_moments the fp64 moments of k_icp_moments, read from those records in the reference's order, + the fp64 sums of the
+//                   seven chains' addends per segment of 64 points and per block of 64 segments;
+//   k_chain_records the fp64 prefix at a segment's start is a guess of the running sum there — good enough for its EXPONENT (the
+//                   fp32 chain itself drifts by parts in a thousand; records are made for e-1, e, e+1): one record per
+//                   (segment, chain), and the block's 64 composed;
 //   k_chain_walk    one wave per chain walks the blocks with the exact value: a wave-wide scan composes 64 block records at a
 //                   time and finds the first one the value does not fit; that block is walked by its segments the same way, the
-//                   segment that does not fit is added up addend by addend.  Then the same workgroup finishes the iteration
-//                   (icp.h:253-295,455-493) like k_icp_update, centred on the chains' centroids.
+//                   segment that does not fit is added up addend by addend;
+//   k_icp_update    finishes the iteration (icp.h:253-295,455-493), centred on the chains' centroids.
 // ------------------------------------------------------------------------------------------
 struct ChainPar { bool use_sd; float cut, max_dist; };
 
@@ -2626,32 +2627,42 @@ __device__ __forceinline__ float chain_stats( const IcpLaunch& L, int prob, unsi
   return sd;
 }
 
+// One workgroup per QUARTER of a block of 64 segments (1 024 source points in the reference's order): the fp64 moments' partials, the
+// seven chains' fp64 sums per segment, and per quarter block.  Block 0 of the launch leaves n, mean, stddev and the cut's stddev
+// in L.res for the kernels that follow.
+#define CH_QUARTERS 4
 __global__ __launch_bounds__( BLOCK ) void k_chain_moments( IcpLaunch L, ChainBufs B )
 {
   __shared__ double red[WAVES_PER_BLOCK][ICP_NMOM];
+  __shared__ double bsum[WAVES_PER_BLOCK][CH_ROWS];
   __shared__ unsigned long long s_stat[WAVES_PER_BLOCK][3];
-  const int prob = blockIdx.y;
+  const int prob = blockIdx.y, qb = blockIdx.x;                     // quarter block: segments [16 qb, 16 qb + 16)
   if( L.active[prob] == 0 ) return;
   const float sd = chain_stats( L, prob, s_stat, ( blockIdx.x == 0 && threadIdx.x == 0 ) ? L.res + (size_t)prob * ICP_NRES + ICP_NMOM : nullptr );
   ChainPar P; P.use_sd = sd > 0.000001; P.cut = 2.5f * sd; P.max_dist = L.radius;
   const int lane = threadIdx.x & ( WAVE - 1 ), wib = threadIdx.x / WAVE;
   const float4* R = L.rec + (size_t)prob * L.src.n * 4;
 
-  double acc[ICP_NMOM];
+  double acc[ICP_NMOM], bs[CH_ROWS];
 #pragma unroll
   for( int k = 0; k < ICP_NMOM; ++k ) acc[k] = 0.0;
-  const int n_pad = B.n_seg * CH_SEG;
-  for( int i = blockIdx.x * BLOCK + threadIdx.x; i < n_pad; i += gridDim.x * BLOCK )     // a wave's 64 lanes = one segment
+#pragma unroll
+  for( int r = 0; r < CH_ROWS; ++r ) bs[r] = 0.0;
+  constexpr int SEGS = CH_BLK / CH_QUARTERS;
+  for( int sb = wib; sb < SEGS; sb += WAVES_PER_BLOCK )              // a wave's 64 lanes = one segment
   {
+    const int seg = qb * SEGS + sb;
+    if( seg >= B.n_seg ) break;
+    const int i = seg * CH_SEG + lane;
     float4 A = make_float4( 0.0f, 0.0f, 0.0f, -1.0f ), Q = make_float4( 0.0f, 0.0f, 0.0f, 0.0f ), N4 = Q;
     if( i < L.src.n ) { A = R[(size_t)i * 4]; Q = R[(size_t)i * 4 + 1]; N4 = R[(size_t)i * 4 + 2]; }
     float x[CH_ROWS], w;
     chain_addends( A, Q, P, x, w );
-    const int seg = i / CH_SEG;
 #pragma unroll
     for( int r = 0; r < CH_ROWS; ++r )
     {
       const double v = wave_sum( (double)x[r] );
+      bs[r] += v;
       if( lane == 0 ) B.segsum[( (size_t)prob * CH_ROWS + r ) * B.n_seg + seg] = v;
     }
     if( A.w < 0.0f ) continue;
@@ -2675,49 +2686,32 @@ __global__ __launch_bounds__( BLOCK ) void k_chain_moments( IcpLaunch L, ChainBu
   }
 #pragma unroll
   for( int k = 0; k < ICP_NMOM; ++k ) { double v = wave_sum( acc[k] ); if( lane == 0 ) red[wib][k] = v; }
+  if( lane == 0 ) { for( int r = 0; r < CH_ROWS; ++r ) bsum[wib][r] = bs[r]; }
   __syncthreads();
   if( threadIdx.x < ICP_NMOM )
   {
     double v = 0.0;
     for( int w = 0; w < WAVES_PER_BLOCK; ++w ) v += red[w][threadIdx.x];
-    L.mom_part[( (size_t)prob * L.n_mom_blocks + blockIdx.x ) * ICP_NMOM + threadIdx.x] = v;
+    L.mom_part[( (size_t)prob * ICP_NMOM + threadIdx.x ) * L.n_mom_blocks + blockIdx.x] = v;      // (moment-major: k_icp_update reads a moment's partials coalesced)
   }
-}
-
-// exclusive prefix of the segment sums, per chain (a guess: any association will do)
-__global__ __launch_bounds__( BLOCK ) void k_chain_scan( IcpLaunch L, ChainBufs B )
-{
-  __shared__ double part[BLOCK];
-  const int prob = blockIdx.y, row = blockIdx.x;
-  if( L.active[prob] == 0 ) return;
-  const double* in = B.segsum + ( (size_t)prob * CH_ROWS + row ) * B.n_seg;
-  double* out = B.prefix + ( (size_t)prob * CH_ROWS + row ) * B.n_seg;
-  const int per = ( B.n_seg + BLOCK - 1 ) / BLOCK, g0 = threadIdx.x * per, g1 = min( g0 + per, B.n_seg );
-  double a = 0.0;
-  for( int g = g0; g < g1; ++g ) a += in[g];
-  part[threadIdx.x] = a;
-  __syncthreads();
-  if( threadIdx.x == 0 ) { double run = 0.0; for( int t = 0; t < BLOCK; ++t ) { const double v = part[t]; part[t] = run; run += v; } }
-  __syncthreads();
-  double run = part[threadIdx.x];
-  for( int g = g0; g < g1; ++g ) { out[g] = run; run += in[g]; }
+  if( threadIdx.x >= WAVE && threadIdx.x < WAVE + CH_ROWS )
+  {
+    double v = 0.0;
+    for( int w = 0; w < WAVES_PER_BLOCK; ++w ) v += bsum[w][threadIdx.x - WAVE];
+    B.blksum[( (size_t)prob * CH_ROWS + ( threadIdx.x - WAVE ) ) * ( B.n_blk * CH_QUARTERS ) + qb] = v;
+  }
 }
 
 #define CH_M_LO ( 1 << 23 )
 #define CH_M_HI ( ( 1 << 24 ) - 1 )
-// a record's three functions  M -> M + D  (valid for lo <= M <= hi), kept normalised: lo, hi inside the mantissa range, lo > hi = never
+// A record's function for one exponent is  M -> M + D, valid for lo <= M <= hi  (lo > hi: never).  A run of records f_0 .. f_l
+// applies to a start mantissa M iff  lo_j <= M + D_0 + .. + D_(j-1) <= hi_j  for every j, i.e. iff
+//     max_j ( lo_j - Dex_j )  <=  M  <=  min_j ( hi_j - Dex_j ),      Dex_j = the advance of the records before j,
+// and then advances it by D_0 + .. + D_l: three integer prefix scans over the lanes (sum, max, min), each six DPP instructions.
+// (A never-record has lo - Dex > hi - Dex, so the max passes the min from its lane on: nothing fits any more.)
 struct ChainFn { int lo, hi, D; };
 __device__ __forceinline__ ChainFn chain_never() { ChainFn f; f.lo = CH_M_HI; f.hi = CH_M_LO; f.D = 0; return f; }
 __device__ __forceinline__ ChainFn chain_identity() { ChainFn f; f.lo = CH_M_LO; f.hi = CH_M_HI; f.D = 0; return f; }
-// first f, then g
-__device__ __forceinline__ ChainFn chain_then( const ChainFn& f, const ChainFn& g )
-{
-  if( f.lo > f.hi || g.lo > g.hi ) return chain_never();
-  ChainFn h;                                    // (|D| < 2^24 and lo, hi in [2^23, 2^24) for valid records: no overflow)
-  h.lo = max( f.lo, g.lo - f.D ); h.hi = min( f.hi, g.hi - f.D ); h.D = f.D + g.D;
-  if( h.lo > h.hi ) return chain_never();
-  return h;
-}
 // the function of a record for the (biased) exponent E and sign bit sg of the running value
 __device__ __forceinline__ ChainFn chain_select( const ChainRec& r, int E, int sg )
 {
@@ -2731,76 +2725,137 @@ __device__ __forceinline__ ChainFn chain_select( const ChainRec& r, int E, int s
   }
   return f;
 }
-// inclusive scan over the lanes, in lane order (the composition is not commutative): lane l ends with f_0 then f_1 ... then f_l
-__device__ __forceinline__ ChainFn chain_wave_scan( ChainFn f, int lane )
+// inclusive prefix max / min over the 64 lanes (signed), like wave_scan: lanes without a source lane keep their own value
+#define RS_DPP_PREFIX( OP, v )                                                              \
+  asm volatile( "s_nop 4\n\t"                                                               \
+                OP " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"        \
+                OP " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"        \
+                OP " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"        \
+                OP " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"        \
+                OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"     \
+                OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"         \
+                : "+v"( v ) )
+// Lane l ends with the run f_0 .. f_l as one function (normalised like a record; the caller's M test is  lo <= M <= hi).
+__device__ __forceinline__ ChainFn chain_prefix( const ChainFn& f, int lane )
 {
-#pragma unroll
-  for( int d = 1; d < WAVE; d <<= 1 )
-  {
-    ChainFn e; e.lo = __shfl_up( f.lo, d ); e.hi = __shfl_up( f.hi, d ); e.D = __shfl_up( f.D, d );
-    if( lane >= d ) f = chain_then( e, f );
-  }
-  return f;
+  const int incl = (int)wave_scan( (uint32_t)f.D, lane );
+  const int ex = incl - f.D;
+  int a = f.lo - ex, b = f.hi - ex;                 // (|D| < 2^24 per valid record, 0 for a never-record: no overflow over 64 lanes)
+  RS_DPP_PREFIX( "v_max_i32_dpp", a );
+  RS_DPP_PREFIX( "v_min_i32_dpp", b );
+  ChainFn g;
+  g.lo = max( a, CH_M_LO ); g.hi = min( b, CH_M_HI ); g.D = incl;
+  const bool never = g.lo > g.hi;
+  g.lo = never ? CH_M_HI : g.lo; g.hi = never ? CH_M_LO : g.hi; g.D = never ? 0 : g.D;
+  return g;
 }
 
-#define CHAIN_REC_WAVES 16
+// One workgroup per block of 64 segments.  The guesses: every chain's fp64 prefix at each of the block's segments (the blocks
+// before from the block sums, then a scan of the block's own 64 segment sums).  The records: a wave stages THREE segments' addends
+// in LDS (lane = point), then lane = (segment, exponent class, chain) runs down its segment's 64 addends in integers — no cross-lane
+// traffic, 63 records at once.  Then the block's 64 segments composed per chain and exponent.
+#define CHAIN_REC_WAVES 8
+#define CHAIN_REC_TASK 3          // segments per wave and round
 __global__ __launch_bounds__( CHAIN_REC_WAVES * WAVE ) void k_chain_records( IcpLaunch L, ChainBufs B )
 {
   __shared__ ChainRec s_rec[CH_ROWS][CH_BLK];
-  __shared__ unsigned long long s_stat[WAVES_PER_BLOCK][3];
+  __shared__ float s_x[CHAIN_REC_WAVES][CHAIN_REC_TASK][CH_ROWS][CH_SEG];
   const int prob = blockIdx.y, blk = blockIdx.x;
   if( L.active[prob] == 0 ) return;
-  const float sd = chain_stats( L, prob, s_stat, nullptr );
+  const float sd = (float)L.res[(size_t)prob * ICP_NRES + ICP_NMOM + 2];      // (left there by k_chain_moments: the same bits in every kernel of the iteration)
   ChainPar P; P.use_sd = sd > 0.000001; P.cut = 2.5f * sd; P.max_dist = L.radius;
   const int lane = threadIdx.x & ( WAVE - 1 ), wib = threadIdx.x / WAVE;
   const float4* R = L.rec + (size_t)prob * L.src.n * 4;
-  for( int sb = wib; sb < CH_BLK; sb += CHAIN_REC_WAVES )
+  if( wib < CH_ROWS )
   {
-    const int seg = blk * CH_BLK + sb;
-    if( seg >= B.n_seg )
+    const int r = wib;
+    const double* bsum = B.blksum + ( (size_t)prob * CH_ROWS + r ) * ( B.n_blk * CH_QUARTERS );
+    double before = 0.0;
+    for( int b = lane; b < blk * CH_QUARTERS; b += WAVE ) before += bsum[b];
+    before = wave_sum( before );
+    const int seg = blk * CH_BLK + lane;
+    const double v = seg < B.n_seg ? B.segsum[( (size_t)prob * CH_ROWS + r ) * B.n_seg + seg] : 0.0;
+    double incl = v;
+#pragma unroll
+    for( int d = 1; d < WAVE; d <<= 1 ) { const double up = __shfl_up( incl, d ); if( lane >= d ) incl += up; }
+    const uint32_t gb = __float_as_uint( (float)( before + ( incl - v ) ) );
+    s_rec[r][lane].e_sign = seg < B.n_seg ? (int)( ( ( gb >> 23 ) & 255u ) | ( ( gb >> 31 ) << 8 ) ) : -1;
+  }
+  __syncthreads();
+  constexpr int N_TASKS = ( CH_BLK + CHAIN_REC_TASK - 1 ) / CHAIN_REC_TASK;
+  for( int task = wib; task < N_TASKS; task += CHAIN_REC_WAVES )
+  {
+    float4 A[CHAIN_REC_TASK], Q[CHAIN_REC_TASK];
+#pragma unroll
+    for( int q = 0; q < CHAIN_REC_TASK; ++q )
     {
-      // past the end of the cloud: nothing is added
-      if( lane < CH_ROWS ) { ChainRec r; r.e_sign = -1; for( int c = 0; c < 3; ++c ) { r.lo[c] = CH_M_LO; r.hi[c] = CH_M_HI; r.D[c] = 0; } s_rec[lane][sb] = r; }
-      continue;
+      const int sb = task * CHAIN_REC_TASK + q, i = ( blk * CH_BLK + sb ) * CH_SEG + lane;
+      A[q] = make_float4( 0.0f, 0.0f, 0.0f, -1.0f ); Q[q] = make_float4( 0.0f, 0.0f, 0.0f, 0.0f );
+      if( sb < CH_BLK && i < L.src.n ) { A[q] = R[(size_t)i * 4]; Q[q] = R[(size_t)i * 4 + 1]; }
     }
-    const int i = seg * CH_SEG + lane;
-    float4 A = make_float4( 0.0f, 0.0f, 0.0f, -1.0f ), Q = make_float4( 0.0f, 0.0f, 0.0f, 0.0f );
-    if( i < L.src.n ) { A = R[(size_t)i * 4]; Q = R[(size_t)i * 4 + 1]; }
-    float x[CH_ROWS], w;
-    chain_addends( A, Q, P, x, w );
 #pragma unroll
-    for( int r = 0; r < CH_ROWS; ++r )
+    for( int q = 0; q < CHAIN_REC_TASK; ++q )
     {
-      const double guess = B.prefix[( (size_t)prob * CH_ROWS + r ) * B.n_seg + seg];
-      const uint32_t gb = __float_as_uint( (float)guess );
-      const int eg = (int)( ( gb >> 23 ) & 255u ), sg = (int)( gb >> 31 );
-      ChainRec rec; rec.e_sign = eg | ( sg << 8 );
-      const float xs = sg ? -x[r] : x[r];                                  // the chain of |s|: s + x = -( |s| + (-x) ) for negative s
+      float x[CH_ROWS], w;
+      chain_addends( A[q], Q[q], P, x, w );
+      const int sb = task * CHAIN_REC_TASK + q;
 #pragma unroll
-      for( int c = 0; c < 3; ++c )
+      for( int r = 0; r < CH_ROWS; ++r )
       {
-        const int E = eg - 1 + c;                                          // s = M * 2^(E - 150), M in [2^23, 2^24)
-        const float y = ldexpf( xs, 150 - E );                             // x / ulp( s ): exact (a power of two), or 0 / inf at the ends
-        const float rn = rintf( y );                                       // to nearest, ties to even
-        const bool bad = !( fabsf( y ) < 8388608.0f ) || fabsf( y - rn ) == 0.5f;     // too big for this binade (or NaN), or a tie: M's parity would decide
-        const int ri = bad ? 0 : (int)rn;
-        const uint32_t incl = wave_scan( (uint32_t)ri, lane );             // partial sums (two's complement)
-        int pmin = min( (int)incl, 0 ), pmax = max( (int)incl, 0 );         // ... including the start itself
-        for( int d = 1; d < WAVE; d <<= 1 ) { pmin = min( pmin, __shfl_xor( pmin, d ) ); pmax = max( pmax, __shfl_xor( pmax, d ) ); }
-        const int D = __builtin_amdgcn_readlane( (int)incl, WAVE - 1 );
-        const bool any_bad = wave_any( bad ) || E < 1 || E > 254;
+        s_x[wib][q][r][lane] = x[r];
+        // block 0's addends also go to memory: the walks serve that block from LDS (k_chain_walk)
+        if( blk == 0 && sb < CH_BLK ) B.x0[( (size_t)prob * CH_ROWS + r ) * ( CH_BLK * CH_SEG ) + sb * CH_SEG + lane] = x[r];
+      }
+    }
+    wave_lds_fence();
+    {
+      const int q = min( lane / ( CH_ROWS * 3 ), CHAIN_REC_TASK - 1 ), combo = lane % ( CH_ROWS * 3 );
+      const int r = combo % CH_ROWS, c = combo / CH_ROWS;
+      const int sb = task * CHAIN_REC_TASK + q;
+      const bool mine = lane < CHAIN_REC_TASK * CH_ROWS * 3 && sb < CH_BLK;
+      const int es = mine ? s_rec[r][sb].e_sign : -1;
+      if( mine && es != -1 )
+      {
+        const int eg = es & 255, sg = es >> 8;
+        const int E = eg - 1 + c;                                            // s = M * 2^(E - 150), M in [2^23, 2^24)
+        int Pj = 0, pmin = 0, pmax = 0;                                      // partial sums, the start included
+        bool bad = E < 1 || E > 254;
+        const float* xs = &s_x[wib][q][r][0];
+#pragma unroll 8
+        for( int j = 0; j < CH_SEG; ++j )
+        {
+          const float xv = xs[j];
+          const float y = ldexpf( sg ? -xv : xv, 150 - E );                  // x / ulp( s ): exact (a power of two), or 0 / inf at the ends; the chain of |s| for negative s
+          const float rn = rintf( y );                                       // to nearest, ties to even
+          bad |= !( fabsf( y ) < 8388608.0f ) | ( fabsf( y - rn ) == 0.5f );  // too big for this binade (or NaN), or a tie: M's parity would decide
+          Pj += (int)rn;
+          pmin = min( pmin, Pj ); pmax = max( pmax, Pj );
+        }
         // every value on the way, the start included, at least one grid step inside the binade: the neighbouring binades' grids
         // (half / twice as fine) then play no part in any of the roundings
         long long lo = (long long)CH_M_LO + 1 - pmin, hi = (long long)CH_M_HI - 1 - pmax;
         lo = lo < CH_M_LO ? CH_M_LO : lo; hi = hi > CH_M_HI ? CH_M_HI : hi;
-        const bool ok = !any_bad && lo <= hi;
-        rec.lo[c] = ok ? (int)lo : CH_M_HI; rec.hi[c] = ok ? (int)hi : CH_M_LO; rec.D[c] = ok ? D : 0;
+        const bool ok = !bad && lo <= hi;
+        ChainRec& out = s_rec[r][sb];
+        out.lo[c] = ok ? (int)lo : CH_M_HI; out.hi[c] = ok ? (int)hi : CH_M_LO; out.D[c] = ok ? Pj : 0;
       }
-      if( lane == 0 ) { B.seg[( (size_t)prob * CH_ROWS + r ) * B.n_seg + seg] = rec; s_rec[r][sb] = rec; }
+      else if( mine )      // past the end of the cloud: nothing is added
+      { ChainRec& out = s_rec[r][sb]; out.lo[c] = CH_M_LO; out.hi[c] = CH_M_HI; out.D[c] = 0; }
     }
+    wave_lds_fence();
   }
   __syncthreads();
-  // the block's 64 segments composed, per chain and exponent around the block's first guess
+  // the segment records to memory (coalesced words), and the block's 64 segments composed per chain and exponent
+  {
+    constexpr int WORDS = sizeof( ChainRec ) / 4;
+    const int n_here = min( CH_BLK, B.n_seg - blk * CH_BLK );
+    for( int r = 0; r < CH_ROWS; ++r )
+    {
+      int* dst = reinterpret_cast<int*>( B.seg + ( (size_t)prob * CH_ROWS + r ) * B.n_seg + (size_t)blk * CH_BLK );
+      const int* src = reinterpret_cast<const int*>( &s_rec[r][0] );
+      for( int k = threadIdx.x; k < n_here * WORDS; k += blockDim.x ) dst[k] = src[k];
+    }
+  }
   for( int job = wib; job < CH_ROWS * 3; job += CHAIN_REC_WAVES )
   {
     const int r = job / 3, c = job % 3;
@@ -2808,7 +2863,7 @@ __global__ __launch_bounds__( CHAIN_REC_WAVES * WAVE ) void k_chain_records( Icp
     const int E = ( first & 255 ) - 1 + c, sg = first >> 8;
     const ChainRec mine = s_rec[r][lane];
     ChainFn f = mine.e_sign == -1 ? chain_identity() : chain_select( mine, E, sg );
-    f = chain_wave_scan( f, lane );
+    f = chain_prefix( f, lane );
     if( lane == WAVE - 1 )
     {
       ChainRec* out = B.blk + ( (size_t)prob * CH_ROWS + r ) * B.n_blk + blk;
@@ -2818,24 +2873,57 @@ __global__ __launch_bounds__( CHAIN_REC_WAVES * WAVE ) void k_chain_records( Icp
   }
 }
 
-// One chain walked by one wave.  `s` (uniform) is the exact running value.
-__device__ __forceinline__ float chain_walk( const IcpLaunch& L, const ChainBufs& B, int prob, int row, const ChainPar& P, int lane, int* n_resolved )
+// One chain walked by one wave (a workgroup of its own).  `s` (uniform) is the exact running value.  Block 0 — where the chain
+// climbs from zero through a dozen binades, and where addends as large as the sum make ties likely — is served from LDS: its
+// 4 096 addends (left in memory by k_chain_records) are fetched when the kernel starts, all loads in flight together, so none of
+// its ~14 segments that have to be added up addend by addend waits for memory.
+__global__ __launch_bounds__( WAVE ) void k_chain_walk( IcpLaunch L, ChainBufs B )
 {
+  __shared__ float s_x0[CH_BLK][CH_SEG];
+  const int prob = blockIdx.y, row = blockIdx.x;
+  if( L.active[prob] == 0 ) return;
+  const int lane = threadIdx.x;
+  const unsigned long long t_start = B.dbg ? wall_clock64() : 0ull;
+  {
+    const float* x0 = B.x0 + ( (size_t)prob * CH_ROWS + row ) * ( CH_BLK * CH_SEG );
+    const int ns0 = min( CH_BLK, B.n_seg );
+    float v[CH_BLK];
+#pragma unroll
+    for( int g = 0; g < CH_BLK; ++g ) v[g] = g < ns0 ? x0[g * CH_SEG + lane] : 0.0f;
+#pragma unroll
+    for( int g = 0; g < CH_BLK; ++g ) s_x0[g][lane] = v[g];
+  }
+  const float sd = (float)L.res[(size_t)prob * ICP_NRES + ICP_NMOM + 2];      // the cut's stddev, as k_chain_moments left it
+  ChainPar P; P.use_sd = sd > 0.000001; P.cut = 2.5f * sd; P.max_dist = L.radius;
   const ChainRec* blks = B.blk + ( (size_t)prob * CH_ROWS + row ) * B.n_blk;
   const ChainRec* segs = B.seg + ( (size_t)prob * CH_ROWS + row ) * B.n_seg;
   const float4* R = L.rec + (size_t)prob * L.src.n * 4;
+  auto addend = [&]( int i ) -> float
+  {
+    float4 A = make_float4( 0.0f, 0.0f, 0.0f, -1.0f ), Q = make_float4( 0.0f, 0.0f, 0.0f, 0.0f );
+    if( i < L.src.n ) { A = R[(size_t)i * 4]; Q = R[(size_t)i * 4 + 1]; }
+    float x[CH_ROWS], w;
+    chain_addends( A, Q, P, x, w );
+    float xr = x[0];
+#pragma unroll
+    for( int r = 1; r < CH_ROWS; ++r ) xr = row == r ? x[r] : xr;
+    return xr;
+  };
+  wave_lds_fence();
+  if( B.dbg && lane == 0 ) B.dbg[( (size_t)prob * CH_ROWS + row ) * ( 4 + 64 * 8 ) + 1] = (int)( wall_clock64() - t_start );
+
   float s = 0.0f;
-  int resolved = 0;
+  int resolved = 0, stuck = 0, steps = 0;
   // advance over the records held by the lanes [from, count): as far as the value fits; returns the first lane that does not (count: all done)
   auto advance = [&]( const ChainRec& mine, int from, int count ) -> int
   {
     const uint32_t sb = __float_as_uint( s );
     const int E = (int)( ( sb >> 23 ) & 255u ), sg = (int)( sb >> 31 ), M = (int)( sb & 0x7fffffu ) | CH_M_LO;
-    ChainFn f = ( lane < from || lane >= count ) ? chain_identity() : chain_select( mine, E, sg );
-    if( E == 0 || E == 255 ) f = ( lane < from || lane >= count ) ? chain_identity() : chain_never();      // zero, denormal, inf, NaN: one by one
-    f = chain_wave_scan( f, lane );
+    const bool mine_in = lane >= from && lane < count;
+    ChainFn f = !mine_in ? chain_identity() : ( ( E == 0 || E == 255 ) ? chain_never() : chain_select( mine, E, sg ) );      // zero, denormal, inf, NaN: one by one
+    f = chain_prefix( f, lane );
     const bool fits = f.lo <= f.hi && M >= f.lo && M <= f.hi;
-    const unsigned long long good = RS_BALLOT( fits ) | ( from > 0 ? ( ( 1ull << from ) - 1ull ) : 0ull );
+    const unsigned long long good = RS_BALLOT( fits );
     const int stop = good == ~0ull ? WAVE : __builtin_ctzll( ~good );       // the fitting lanes are a prefix: the intervals only shrink
     const int last = min( stop, count ) - 1;
     if( last >= from )
@@ -2845,15 +2933,18 @@ __device__ __forceinline__ float chain_walk( const IcpLaunch& L, const ChainBufs
     }
     return min( stop, count );
   };
-  for( int b0 = 0; b0 < B.n_blk; b0 += WAVE )
+  for( int b0 = 0; b0 < B.n_blk && !( stuck & 2 ); b0 += WAVE )
   {
     const int nb = min( WAVE, B.n_blk - b0 );
     ChainRec mine; mine.e_sign = -1;
     if( lane < nb ) mine = blks[b0 + lane];
     int at = 0;
-    while( at < nb )
+    while( at < nb && !( stuck & 2 ) )
     {
+      const int at_was = at;
+      if( ++steps > 8 * B.n_seg + 4096 ) { stuck |= 2; break; }       // (a walk takes at most one step per block + two per segment: guards against a loop that does not end)
       at = advance( mine, at, nb );
+      if( at < at_was ) { stuck |= 1; at = at_was; }      // (cannot happen: the lanes before `at` hold the identity — guards the loop against a wrong scan)
       if( at >= nb ) break;
       // block b0 + at does not fit as a whole: by its segments
       const int g0 = ( b0 + at ) * CH_BLK, ns = min( CH_BLK, B.n_seg - g0 );
@@ -2862,7 +2953,10 @@ __device__ __forceinline__ float chain_walk( const IcpLaunch& L, const ChainBufs
       int sat = 0;
       while( sat < ns )
       {
+        const int sat_was = sat;
+        if( ++steps > 8 * B.n_seg + 4096 ) { stuck |= 2; break; }
         sat = advance( smine, sat, ns );
+        if( sat < sat_was ) { stuck |= 1; sat = sat_was; }
         if( sat >= ns ) break;
         // segment g0 + sat: its 64 addends one after the other, in fp32 — the reference's own operations
         if( B.dbg && resolved < 64 )
@@ -2870,18 +2964,11 @@ __device__ __forceinline__ float chain_walk( const IcpLaunch& L, const ChainBufs
           const ChainRec why = segs[g0 + sat];
           const uint32_t sb = __float_as_uint( s );
           const int c = (int)( ( sb >> 23 ) & 255u ) - ( why.e_sign & 255 ) + 1;
-          int* d = B.dbg + ( (size_t)prob * CH_ROWS + row ) * ( 1 + 64 * 8 ) + 1 + resolved * 8;
-          if( lane == 0 ) { d[0] = g0 + sat; d[1] = (int)sb; d[2] = why.e_sign; d[3] = c; d[4] = ( c >= 0 && c < 3 ) ? why.lo[c] : 0; d[5] = ( c >= 0 && c < 3 ) ? why.hi[c] : 0; d[6] = ( c >= 0 && c < 3 ) ? why.D[c] : 0; d[7] = at + b0; }
+          int* d = B.dbg + ( (size_t)prob * CH_ROWS + row ) * ( 4 + 64 * 8 ) + 4 + resolved * 8;
+          if( lane == 0 ) { d[0] = g0 + sat; d[1] = (int)sb; d[2] = why.e_sign; d[3] = c; d[4] = ( c >= 0 && c < 3 ) ? why.lo[c] : 0; d[5] = ( c >= 0 && c < 3 ) ? why.hi[c] : 0; d[6] = ( c >= 0 && c < 3 ) ? why.D[c] : 0; d[7] = (int)( wall_clock64() - t_start ); }
         }
-        const int i = ( g0 + sat ) * CH_SEG + lane;
-        float4 A = make_float4( 0.0f, 0.0f, 0.0f, -1.0f ), Q = make_float4( 0.0f, 0.0f, 0.0f, 0.0f );
-        if( i < L.src.n ) { A = R[(size_t)i * 4]; Q = R[(size_t)i * 4 + 1]; }
-        float x[CH_ROWS], w;
-        chain_addends( A, Q, P, x, w );
-        float xr = x[0];
-#pragma unroll
-        for( int r = 1; r < CH_ROWS; ++r ) xr = row == r ? x[r] : xr;
-#pragma unroll 8
+        const float xr = ( g0 == 0 ) ? s_x0[sat][lane] : addend( ( g0 + sat ) * CH_SEG + lane );
+#pragma unroll 16
         for( int j = 0; j < CH_SEG; ++j ) s = s + __int_as_float( __builtin_amdgcn_readlane( __float_as_int( xr ), j ) );
         s = __int_as_float( uni( __float_as_int( s ) ) );
         ++resolved; ++sat;
@@ -2889,68 +2976,20 @@ __device__ __forceinline__ float chain_walk( const IcpLaunch& L, const ChainBufs
       ++at;
     }
   }
-  if( n_resolved ) *n_resolved = resolved;
-  if( B.dbg && lane == 0 ) B.dbg[( (size_t)prob * CH_ROWS + row ) * ( 1 + 64 * 8 )] = resolved;
-  return s;
-}
-
-// One workgroup per problem: the moments' tree (as k_icp_update), the seven chains (waves 0-6), then the rest of the iteration.
-__global__ __launch_bounds__( UPDATE_WAVES * WAVE ) void k_chain_walk_update( IcpLaunch L, ChainBufs B )
-{
-  __shared__ unsigned long long s_stat[WAVES_PER_BLOCK][3];
-  const int prob = blockIdx.x;
-  if( L.active[prob] == 0 ) return;
-  const int lane = threadIdx.x & ( WAVE - 1 ), wib = threadIdx.x / WAVE;
-  const float sd = chain_stats( L, prob, s_stat, nullptr );
-  ChainPar P; P.use_sd = sd > 0.000001; P.cut = 2.5f * sd; P.max_dist = L.radius;
-  double* res = L.res + (size_t)prob * ICP_NRES;
-  if( wib < CH_ROWS )
+  if( lane == 0 )
   {
-    int resolved = 0;
-    const float v = chain_walk( L, B, prob, wib, P, lane, &resolved );
-    if( lane == 0 ) { B.totals[( (size_t)prob * 3 + 1 ) * ICP_NMOM + wib] = (double)v; if( B.resolved ) atomicAdd( B.resolved + prob, resolved ); }
+    B.totals[( (size_t)prob * 3 + 1 ) * ICP_NMOM + row] = (double)s;
+    if( B.resolved ) atomicAdd( B.resolved + prob, resolved );
+    if( B.dbg ) { int* h = B.dbg + ( (size_t)prob * CH_ROWS + row ) * ( 4 + 64 * 8 ); h[0] = resolved | ( stuck << 30 ); h[3] = (int)( wall_clock64() - t_start ); }
   }
-  else
-  {
-    const double* in = L.mom_part + (size_t)prob * L.n_mom_blocks * ICP_NMOM;
-    for( int k = wib - CH_ROWS; k < ICP_NMOM; k += UPDATE_WAVES - CH_ROWS )
-    {
-      double v = 0.0;
-      for( int b = lane; b < L.n_mom_blocks; b += WAVE ) v += in[(size_t)b * ICP_NMOM + k];
-      v = wave_sum( v );
-      if( lane == 0 ) res[k] = v;
-    }
-  }
-  __syncthreads();
-  if( !L.solve ) return;
-  icp_iteration_reset( L, prob );
-  if( threadIdx.x != 0 ) return;
-  // ---- icp.h:455-493 for this problem (as k_icp_update) ----
-  L.prev_err[prob] = L.err[prob];
-  L.iters[prob] += 1;
-  if( res[ICP_NMOM] == 0.0 ) { L.active[prob] = 0; return; }            // icp.h:455-459: no correspondences
-  Mat4 T;
-  for( int k = 0; k < 16; ++k ) { T.m[k] = L.T1[prob * 16 + k]; L.T1_prev[prob * 16 + k] = T.m[k]; }
-  const double* t2 = B.totals + ( (size_t)prob * 3 + 1 ) * ICP_NMOM;
-  const float total = (float)t2[0];
-  if( total <= 1e-7 ) { L.active[prob] = 0; return; }                   // icp.h:466-470
-  const float inv = __fdiv_rn( 1.0f, total );
-  float cen[6];
-  for( int a = 0; a < 6; ++a ) cen[a] = (float)t2[1 + a] * inv;         // c = Σw·p * ( 1.0f / Σw ), icp.h:145-146
-  float e;
-  if( !icp_solve( res, T, e, cen ) ) { L.active[prob] = 0; return; }
-  for( int k = 0; k < 16; ++k ) L.T1[prob * 16 + k] = T.m[k];           // icp.h:295
-  L.err[prob] = e;
-  const float delta = fabsf( L.prev_err[prob] - e );
-  if( !L.fixed_iters && L.iter_index > 5 && delta < 1e-5 ) L.active[prob] = 0;   // icp.h:489
 }
 
 void launch_icp_chain_centroids( const IcpLaunch& L, const ChainBufs& B, hipStream_t st )
 {
-  hipLaunchKernelGGL( k_chain_moments, dim3( L.n_mom_blocks, L.n_prob ), dim3( BLOCK ), 0, st, L, B );
-  hipLaunchKernelGGL( k_chain_scan, dim3( CH_ROWS, L.n_prob ), dim3( BLOCK ), 0, st, L, B );
+  hipLaunchKernelGGL( k_chain_moments, dim3( B.n_blk * CH_QUARTERS, L.n_prob ), dim3( BLOCK ), 0, st, L, B );           // (L.n_mom_blocks == 4 B.n_blk)
   hipLaunchKernelGGL( k_chain_records, dim3( B.n_blk, L.n_prob ), dim3( CHAIN_REC_WAVES * WAVE ), 0, st, L, B );
-  hipLaunchKernelGGL( k_chain_walk_update, dim3( L.n_prob ), dim3( UPDATE_WAVES * WAVE ), 0, st, L, B );
+  hipLaunchKernelGGL( k_chain_walk, dim3( CH_ROWS, L.n_prob ), dim3( WAVE ), 0, st, L, B );
+  hipLaunchKernelGGL( k_icp_update, dim3( L.n_prob ), dim3( UPDATE_WAVES * WAVE ), 0, st, L );                           // (centred on the chains' totals: L.exact_centroids)
 }
 
 int replay_segments( int n_source ) { return ( n_source + REPLAY_SEG - 1 ) / REPLAY_SEG; }
