@@ -1763,8 +1763,19 @@ __global__ __launch_bounds__( UPDATE_WAVES * WAVE ) void k_icp_update( IcpLaunch
   for( int k = wib; k < ICP_NMOM; k += UPDATE_WAVES )
   {
     double v = 0.0;
-    if( L.rec ) for( int b = lane; b < L.n_mom_blocks; b += WAVE ) v += in[(size_t)k * L.n_mom_blocks + b];      // k_chain_moments' layout (moment-major)
-    else        for( int b = lane; b < L.n_mom_blocks; b += WAVE ) v += in[(size_t)b * ICP_NMOM + k];
+    if( L.rec )
+    {
+      // k_chain_moments' layout (moment-major: coalesced), eight loads in flight per lane; the order of the additions is fixed
+      for( int b0 = lane; b0 < L.n_mom_blocks; b0 += 8 * WAVE )
+      {
+        double t[8];
+#pragma unroll
+        for( int j = 0; j < 8; ++j ) { const int b = b0 + j * WAVE; t[j] = b < L.n_mom_blocks ? in[(size_t)k * L.n_mom_blocks + b] : 0.0; }
+#pragma unroll
+        for( int j = 0; j < 8; ++j ) v += t[j];
+      }
+    }
+    else for( int b = lane; b < L.n_mom_blocks; b += WAVE ) v += in[(size_t)b * ICP_NMOM + k];
     v = wave_sum( v );
     if( lane == 0 ) res[k] = v;
   }
@@ -2877,9 +2888,11 @@ __global__ __launch_bounds__( CHAIN_REC_WAVES * WAVE ) void k_chain_records( Icp
 // climbs from zero through a dozen binades, and where addends as large as the sum make ties likely — is served from LDS: its
 // 4 096 addends (left in memory by k_chain_records) are fetched when the kernel starts, all loads in flight together, so none of
 // its ~14 segments that have to be added up addend by addend waits for memory.
+#define CH_PREFETCH 8
 __global__ __launch_bounds__( WAVE ) void k_chain_walk( IcpLaunch L, ChainBufs B )
 {
   __shared__ float s_x0[CH_BLK][CH_SEG];
+  __shared__ ChainRec s_seg[CH_PREFETCH][CH_SEG];
   const int prob = blockIdx.y, row = blockIdx.x;
   if( L.active[prob] == 0 ) return;
   const int lane = threadIdx.x;
@@ -2938,6 +2951,31 @@ __global__ __launch_bounds__( WAVE ) void k_chain_walk( IcpLaunch L, ChainBufs B
     const int nb = min( WAVE, B.n_blk - b0 );
     ChainRec mine; mine.e_sign = -1;
     if( lane < nb ) mine = blks[b0 + lane];
+    // Where will the chain change binade?  Where the GUESS does: in a block whose successor's guess has another exponent (and in
+    // block 0).  The segment records of up to CH_PREFETCH such blocks of this chunk are fetched now, all loads in flight together,
+    // so that the walk does not wait for them when it gets there (a block that fails for another reason — a tie — is loaded then).
+    unsigned long long pre_mask;
+    {
+      const int next = __shfl_down( mine.e_sign, 1 );
+      const bool flag = lane < nb && ( lane + 1 >= nb ? true : next != mine.e_sign );
+      unsigned long long m = RS_BALLOT( flag ) | ( b0 == 0 ? 1ull : 0ull );
+      pre_mask = 0ull;
+      ChainRec got[CH_PREFETCH];
+#pragma unroll
+      for( int k = 0; k < CH_PREFETCH; ++k )
+      {
+        got[k].e_sign = -1;
+        if( m )
+        {
+          const int b = __builtin_ctzll( m ); m &= m - 1ull; pre_mask |= 1ull << b;
+          const int g0 = ( b0 + b ) * CH_BLK;
+          if( g0 + lane < B.n_seg ) got[k] = segs[g0 + lane];
+        }
+      }
+#pragma unroll
+      for( int k = 0; k < CH_PREFETCH; ++k ) s_seg[k][lane] = got[k];
+      wave_lds_fence();
+    }
     int at = 0;
     while( at < nb && !( stuck & 2 ) )
     {
@@ -2949,7 +2987,8 @@ __global__ __launch_bounds__( WAVE ) void k_chain_walk( IcpLaunch L, ChainBufs B
       // block b0 + at does not fit as a whole: by its segments
       const int g0 = ( b0 + at ) * CH_BLK, ns = min( CH_BLK, B.n_seg - g0 );
       ChainRec smine; smine.e_sign = -1;
-      if( lane < ns ) smine = segs[g0 + lane];
+      if( ( pre_mask >> at ) & 1ull ) smine = s_seg[__builtin_popcountll( pre_mask & ( ( 1ull << at ) - 1ull ) )][lane];
+      else if( lane < ns ) smine = segs[g0 + lane];
       int sat = 0;
       while( sat < ns )
       {
@@ -2968,8 +3007,8 @@ __global__ __launch_bounds__( WAVE ) void k_chain_walk( IcpLaunch L, ChainBufs B
           if( lane == 0 ) { d[0] = g0 + sat; d[1] = (int)sb; d[2] = why.e_sign; d[3] = c; d[4] = ( c >= 0 && c < 3 ) ? why.lo[c] : 0; d[5] = ( c >= 0 && c < 3 ) ? why.hi[c] : 0; d[6] = ( c >= 0 && c < 3 ) ? why.D[c] : 0; d[7] = (int)( wall_clock64() - t_start ); }
         }
         const float xr = ( g0 == 0 ) ? s_x0[sat][lane] : addend( ( g0 + sat ) * CH_SEG + lane );
-#pragma unroll 16
-        for( int j = 0; j < CH_SEG; ++j ) s = s + __int_as_float( __builtin_amdgcn_readlane( __float_as_int( xr ), j ) );
+#pragma unroll
+        for( int j = 0; j < CH_SEG; ++j ) s = s + __int_as_float( __builtin_amdgcn_readlane( __float_as_int( xr ), j ) );      // (fully unrolled: lane numbers as immediates, the reads ahead of the chain of adds)
         s = __int_as_float( uni( __float_as_int( s ) ) );
         ++resolved; ++sat;
       }
