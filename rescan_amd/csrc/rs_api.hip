@@ -119,7 +119,7 @@ struct Workspace
   DevBuf lvl_pos, lvl_nor, lvl_cnt, lvl_within, lvl_offset, lvl_adj, lvl_state, lvl_misc, lvl_flags, lvl_scan, lvl_samples, lvl_tmp, lvl_cursor, lvl_work_a, lvl_work_b;   // level builder
   DevBuf faith;                                                                 // reference-order estimator: correspondences in source order
   DevBuf rp_segsum, rp_guess, rp_seg, rp_super, rp_totals, rp_redone;                     // ... its parallel form (replay)
-  DevBuf ch_rec, ch_segsum, ch_prefix, ch_seg, ch_blk, ch_x0, ch_dbg;                                    // the centroid chains of large sources (grid chains)
+  DevBuf ch_rec, ch_segsum, ch_prefix, ch_seg, ch_blk, ch_x0, ch_guess, ch_dbg;                                    // the centroid chains of large sources (grid chains)
   PinBuf h_a, h_b, h_c;
 };
 thread_local Workspace g_ws;
@@ -919,8 +919,9 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
     const size_t rows = (size_t)n * CH_ROWS;
     if( ( rc = g_ws.ch_rec.ensure( (size_t)n * (size_t)source->n * 64 ) ) || ( rc = g_ws.ch_segsum.ensure( rows * CB.n_seg * 8 ) ) ||
         ( rc = g_ws.ch_prefix.ensure( rows * CB.n_blk * 4 * 8 ) ) || ( rc = g_ws.ch_seg.ensure( rows * CB.n_seg * sizeof( ChainRec ) ) ) ||
-        ( rc = g_ws.ch_blk.ensure( rows * CB.n_blk * sizeof( ChainRec ) ) ) || ( rc = g_ws.ch_x0.ensure( rows * CH_BLK * CH_SEG * 4 ) ) ) return rc;
-    CB.segsum = g_ws.ch_segsum.as<double>(); CB.blksum = g_ws.ch_prefix.as<double>(); CB.seg = (ChainRec*)g_ws.ch_seg.p; CB.blk = (ChainRec*)g_ws.ch_blk.p; CB.x0 = g_ws.ch_x0.as<float>();
+        ( rc = g_ws.ch_blk.ensure( rows * CB.n_blk * sizeof( ChainRec ) ) ) || ( rc = g_ws.ch_x0.ensure( rows * CH_BLK * CH_SEG * 4 ) ) ||
+        ( rc = g_ws.ch_guess.ensure( rows * CB.n_seg * 4 ) ) ) return rc;
+    CB.segsum = g_ws.ch_segsum.as<double>(); CB.blksum = g_ws.ch_prefix.as<double>(); CB.seg = (ChainRec*)g_ws.ch_seg.p; CB.blk = (ChainRec*)g_ws.ch_blk.p; CB.x0 = g_ws.ch_x0.as<float>(); CB.guess = g_ws.ch_guess.as<int>();
     CB.totals = RB.totals; CB.resolved = RB.redone;
     if( getenv( "RS_HIP_CHAIN_DEBUG" ) )
     {
@@ -958,6 +959,7 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
   const long long total_tiles = (long long)cx.n_waves * n;
   static const long long coop_all_below = getenv( "RS_HIP_COOP_ALL_BELOW" ) ? atoll( getenv( "RS_HIP_COOP_ALL_BELOW" ) ) : 4096;
   static const int coop_waves_forced = getenv( "RS_HIP_COOP_WAVES" ) ? atoi( getenv( "RS_HIP_COOP_WAVES" ) ) : 0;
+  static const int chain_refresh = std::max( 1, getenv( "RS_HIP_CHAIN_REFRESH" ) ? atoi( getenv( "RS_HIP_CHAIN_REFRESH" ) ) : 8 );
   cx.L.solve = 1; cx.L.fixed_iters = fixed_iters ? 1 : 0;
   ProfChain prof;
   for( int i = 0; i < max_iter; )                                       // icp.h:444
@@ -985,7 +987,13 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
       if( debug ) icp_debug_after( cx, source->n, n, i, max_dist );
       prof.mark( "icp_moments" );
       if( replay ) launch_icp_replay( cx.L, RB, g_stream );
-      else if( chains ) launch_icp_chain_centroids( cx.L, CB, g_stream );
+      else if( chains )
+      {
+        // the binade guesses of the chains' records are made from this iteration's sums every chain_refresh-th iteration and kept in
+        // between (then the records and the walks do not wait for the moments: one launch does both)
+        CB.refresh = ( i % chain_refresh ) == 0 ? 1 : 0;
+        launch_icp_chain_centroids( cx.L, CB, g_stream );
+      }
       else if( exact_centroids ) launch_icp_exact_centroids( cx.L, RB, g_stream );
       else if( cx.L.faith ) launch_icp_faithful( cx.L, g_stream ); else launch_icp_moments( cx.L, g_stream );
       double nd = max_dist * 0.95;                                      // icp.h:493

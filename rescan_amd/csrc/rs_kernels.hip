@@ -2642,14 +2642,11 @@ __device__ __forceinline__ float chain_stats( const IcpLaunch& L, int prob, unsi
 // seven chains' fp64 sums per segment, and per quarter block.  Block 0 of the launch leaves n, mean, stddev and the cut's stddev
 // in L.res for the kernels that follow.
 #define CH_QUARTERS 4
-__global__ __launch_bounds__( BLOCK ) void k_chain_moments( IcpLaunch L, ChainBufs B )
+struct ChainMomLds { double red[WAVES_PER_BLOCK][ICP_NMOM]; double bsum[WAVES_PER_BLOCK][CH_ROWS]; unsigned long long stat[WAVES_PER_BLOCK][3]; };
+__device__ __forceinline__ void chain_moments_block( const IcpLaunch& L, const ChainBufs& B, int prob, int qb, ChainMomLds& S )
 {
-  __shared__ double red[WAVES_PER_BLOCK][ICP_NMOM];
-  __shared__ double bsum[WAVES_PER_BLOCK][CH_ROWS];
-  __shared__ unsigned long long s_stat[WAVES_PER_BLOCK][3];
-  const int prob = blockIdx.y, qb = blockIdx.x;                     // quarter block: segments [16 qb, 16 qb + 16)
-  if( L.active[prob] == 0 ) return;
-  const float sd = chain_stats( L, prob, s_stat, ( blockIdx.x == 0 && threadIdx.x == 0 ) ? L.res + (size_t)prob * ICP_NRES + ICP_NMOM : nullptr );
+  // quarter block qb: segments [16 qb, 16 qb + 16)
+  const float sd = chain_stats( L, prob, S.stat, ( qb == 0 && threadIdx.x == 0 ) ? L.res + (size_t)prob * ICP_NRES + ICP_NMOM : nullptr );
   ChainPar P; P.use_sd = sd > 0.000001; P.cut = 2.5f * sd; P.max_dist = L.radius;
   const int lane = threadIdx.x & ( WAVE - 1 ), wib = threadIdx.x / WAVE;
   const float4* R = L.rec + (size_t)prob * L.src.n * 4;
@@ -2669,12 +2666,15 @@ __global__ __launch_bounds__( BLOCK ) void k_chain_moments( IcpLaunch L, ChainBu
     if( i < L.src.n ) { A = R[(size_t)i * 4]; Q = R[(size_t)i * 4 + 1]; N4 = R[(size_t)i * 4 + 2]; }
     float x[CH_ROWS], w;
     chain_addends( A, Q, P, x, w );
-#pragma unroll
-    for( int r = 0; r < CH_ROWS; ++r )
+    if( B.refresh )
     {
-      const double v = wave_sum( (double)x[r] );
-      bs[r] += v;
-      if( lane == 0 ) B.segsum[( (size_t)prob * CH_ROWS + r ) * B.n_seg + seg] = v;
+#pragma unroll
+      for( int r = 0; r < CH_ROWS; ++r )
+      {
+        const double v = wave_sum( (double)x[r] );
+        bs[r] += v;
+        if( lane == 0 ) B.segsum[( (size_t)prob * CH_ROWS + r ) * B.n_seg + seg] = v;
+      }
     }
     if( A.w < 0.0f ) continue;
     const double W = w, p[3] = { A.x, A.y, A.z }, q[3] = { Q.x, Q.y, Q.z }, n[3] = { N4.x, N4.y, N4.z };
@@ -2696,21 +2696,28 @@ __global__ __launch_bounds__( BLOCK ) void k_chain_moments( IcpLaunch L, ChainBu
     acc[34] += W * e * e;
   }
 #pragma unroll
-  for( int k = 0; k < ICP_NMOM; ++k ) { double v = wave_sum( acc[k] ); if( lane == 0 ) red[wib][k] = v; }
-  if( lane == 0 ) { for( int r = 0; r < CH_ROWS; ++r ) bsum[wib][r] = bs[r]; }
+  for( int k = 0; k < ICP_NMOM; ++k ) { double v = wave_sum( acc[k] ); if( lane == 0 ) S.red[wib][k] = v; }
+  if( lane == 0 ) { for( int r = 0; r < CH_ROWS; ++r ) S.bsum[wib][r] = bs[r]; }
   __syncthreads();
   if( threadIdx.x < ICP_NMOM )
   {
     double v = 0.0;
-    for( int w = 0; w < WAVES_PER_BLOCK; ++w ) v += red[w][threadIdx.x];
-    L.mom_part[( (size_t)prob * ICP_NMOM + threadIdx.x ) * L.n_mom_blocks + blockIdx.x] = v;      // (moment-major: k_icp_update reads a moment's partials coalesced)
+    for( int w = 0; w < WAVES_PER_BLOCK; ++w ) v += S.red[w][threadIdx.x];
+    L.mom_part[( (size_t)prob * ICP_NMOM + threadIdx.x ) * L.n_mom_blocks + qb] = v;      // (moment-major: k_icp_update reads a moment's partials coalesced)
   }
-  if( threadIdx.x >= WAVE && threadIdx.x < WAVE + CH_ROWS )
+  if( B.refresh && threadIdx.x >= WAVE && threadIdx.x < WAVE + CH_ROWS )
   {
     double v = 0.0;
-    for( int w = 0; w < WAVES_PER_BLOCK; ++w ) v += bsum[w][threadIdx.x - WAVE];
+    for( int w = 0; w < WAVES_PER_BLOCK; ++w ) v += S.bsum[w][threadIdx.x - WAVE];
     B.blksum[( (size_t)prob * CH_ROWS + ( threadIdx.x - WAVE ) ) * ( B.n_blk * CH_QUARTERS ) + qb] = v;
   }
+}
+__global__ __launch_bounds__( BLOCK ) void k_chain_moments( IcpLaunch L, ChainBufs B )
+{
+  __shared__ ChainMomLds S;
+  const int prob = blockIdx.y;
+  if( L.active[prob] == 0 ) return;
+  chain_moments_block( L, B, prob, blockIdx.x, S );
 }
 
 #define CH_M_LO ( 1 << 23 )
@@ -2771,13 +2778,21 @@ __global__ __launch_bounds__( CHAIN_REC_WAVES * WAVE ) void k_chain_records( Icp
 {
   __shared__ ChainRec s_rec[CH_ROWS][CH_BLK];
   __shared__ float s_x[CHAIN_REC_WAVES][CHAIN_REC_TASK][CH_ROWS][CH_SEG];
+  __shared__ unsigned long long s_stat[WAVES_PER_BLOCK][3];
   const int prob = blockIdx.y, blk = blockIdx.x;
   if( L.active[prob] == 0 ) return;
-  const float sd = (float)L.res[(size_t)prob * ICP_NRES + ICP_NMOM + 2];      // (left there by k_chain_moments: the same bits in every kernel of the iteration)
+  const float sd = chain_stats( L, prob, s_stat, nullptr );                  // (its own: in the iterations that keep their guesses this kernel runs BEFORE the moments)
   ChainPar P; P.use_sd = sd > 0.000001; P.cut = 2.5f * sd; P.max_dist = L.radius;
   const int lane = threadIdx.x & ( WAVE - 1 ), wib = threadIdx.x / WAVE;
   const float4* R = L.rec + (size_t)prob * L.src.n * 4;
-  if( wib < CH_ROWS )
+  if( wib < CH_ROWS && !B.refresh )
+  {
+    // The guesses of the last refresh serve again: between two ICP iterations the sums move by a few per cent at most (the radius
+    // shrinks by 5 %, a per cent of the correspondences change), far less than the factor of two a record's three exponents cover.
+    const int seg = blk * CH_BLK + lane;
+    s_rec[wib][lane].e_sign = seg < B.n_seg ? B.guess[( (size_t)prob * CH_ROWS + wib ) * B.n_seg + seg] : -1;
+  }
+  if( wib < CH_ROWS && B.refresh )
   {
     const int r = wib;
     const double* bsum = B.blksum + ( (size_t)prob * CH_ROWS + r ) * ( B.n_blk * CH_QUARTERS );
@@ -2790,7 +2805,9 @@ __global__ __launch_bounds__( CHAIN_REC_WAVES * WAVE ) void k_chain_records( Icp
 #pragma unroll
     for( int d = 1; d < WAVE; d <<= 1 ) { const double up = __shfl_up( incl, d ); if( lane >= d ) incl += up; }
     const uint32_t gb = __float_as_uint( (float)( before + ( incl - v ) ) );
-    s_rec[r][lane].e_sign = seg < B.n_seg ? (int)( ( ( gb >> 23 ) & 255u ) | ( ( gb >> 31 ) << 8 ) ) : -1;
+    const int es = seg < B.n_seg ? (int)( ( ( gb >> 23 ) & 255u ) | ( ( gb >> 31 ) << 8 ) ) : -1;
+    s_rec[r][lane].e_sign = es;
+    if( seg < B.n_seg ) B.guess[( (size_t)prob * CH_ROWS + r ) * B.n_seg + seg] = es;
   }
   __syncthreads();
   constexpr int N_TASKS = ( CH_BLK + CHAIN_REC_TASK - 1 ) / CHAIN_REC_TASK;
@@ -2889,13 +2906,10 @@ __global__ __launch_bounds__( CHAIN_REC_WAVES * WAVE ) void k_chain_records( Icp
 // 4 096 addends (left in memory by k_chain_records) are fetched when the kernel starts, all loads in flight together, so none of
 // its ~14 segments that have to be added up addend by addend waits for memory.
 #define CH_PREFETCH 8
-__global__ __launch_bounds__( WAVE ) void k_chain_walk( IcpLaunch L, ChainBufs B )
+struct ChainWalkLds { float x0[CH_BLK][CH_SEG]; ChainRec seg[CH_PREFETCH][CH_SEG]; };
+__device__ __forceinline__ void chain_walk_row( const IcpLaunch& L, const ChainBufs& B, int prob, int row, int lane, ChainWalkLds& S )
 {
-  __shared__ float s_x0[CH_BLK][CH_SEG];
-  __shared__ ChainRec s_seg[CH_PREFETCH][CH_SEG];
-  const int prob = blockIdx.y, row = blockIdx.x;
-  if( L.active[prob] == 0 ) return;
-  const int lane = threadIdx.x;
+  auto& s_x0 = S.x0; auto& s_seg = S.seg;
   const unsigned long long t_start = B.dbg ? wall_clock64() : 0ull;
   {
     const float* x0 = B.x0 + ( (size_t)prob * CH_ROWS + row ) * ( CH_BLK * CH_SEG );
@@ -2906,7 +2920,21 @@ __global__ __launch_bounds__( WAVE ) void k_chain_walk( IcpLaunch L, ChainBufs B
 #pragma unroll
     for( int g = 0; g < CH_BLK; ++g ) s_x0[g][lane] = v[g];
   }
-  const float sd = (float)L.res[(size_t)prob * ICP_NRES + ICP_NMOM + 2];      // the cut's stddev, as k_chain_moments left it
+  // the cut (as chain_stats; one wave takes the 256 shards in four rounds)
+  float sd;
+  {
+    unsigned long long t0 = 0, t1 = 0, t2 = 0;
+    for( int q = 0; q < STAT_SHARDS / WAVE; ++q )
+    {
+      const unsigned long long* a = L.stat_acc + ( (size_t)prob * STAT_SHARDS + q * WAVE + lane ) * 4;
+      t0 += wave_sum_u64( a[0] ); t1 += wave_sum_u64( a[1] ); t2 += wave_sum_u64( a[2] );
+    }
+    const double n = (double)t0;
+    const float mean = (float)( (double)t1 * L.stat_i1 / n );
+    const float sqm = (float)( (double)t2 * L.stat_i2 / n );
+    const float var = sqm - mean * mean;
+    sd = (float)sqrt( (double)var );
+  }
   ChainPar P; P.use_sd = sd > 0.000001; P.cut = 2.5f * sd; P.max_dist = L.radius;
   const ChainRec* blks = B.blk + ( (size_t)prob * CH_ROWS + row ) * B.n_blk;
   const ChainRec* segs = B.seg + ( (size_t)prob * CH_ROWS + row ) * B.n_seg;
@@ -3023,11 +3051,42 @@ __global__ __launch_bounds__( WAVE ) void k_chain_walk( IcpLaunch L, ChainBufs B
   }
 }
 
+__global__ __launch_bounds__( WAVE ) void k_chain_walk( IcpLaunch L, ChainBufs B )
+{
+  __shared__ ChainWalkLds S;
+  const int prob = blockIdx.y;
+  if( L.active[prob] == 0 ) return;
+  chain_walk_row( L, B, prob, blockIdx.x, threadIdx.x, S );
+}
+// The walks and the moments in ONE launch (the iterations that keep their guesses: neither needs the other): workgroups 0-6 walk a
+// chain each with their first wave, the others take a quarter block of the moments each.
+__global__ __launch_bounds__( BLOCK ) void k_chain_walk_and_moments( IcpLaunch L, ChainBufs B )
+{
+  __shared__ union U { ChainWalkLds w; ChainMomLds m; __device__ U() {} } S;
+  const int prob = blockIdx.y;
+  if( L.active[prob] == 0 ) return;
+  if( blockIdx.x < CH_ROWS )
+  {
+    if( threadIdx.x < WAVE ) chain_walk_row( L, B, prob, blockIdx.x, threadIdx.x, S.w );
+    return;
+  }
+  chain_moments_block( L, B, prob, (int)blockIdx.x - CH_ROWS, S.m );
+}
+
 void launch_icp_chain_centroids( const IcpLaunch& L, const ChainBufs& B, hipStream_t st )
 {
-  hipLaunchKernelGGL( k_chain_moments, dim3( B.n_blk * CH_QUARTERS, L.n_prob ), dim3( BLOCK ), 0, st, L, B );           // (L.n_mom_blocks == 4 B.n_blk)
-  hipLaunchKernelGGL( k_chain_records, dim3( B.n_blk, L.n_prob ), dim3( CHAIN_REC_WAVES * WAVE ), 0, st, L, B );
-  hipLaunchKernelGGL( k_chain_walk, dim3( CH_ROWS, L.n_prob ), dim3( WAVE ), 0, st, L, B );
+  if( B.refresh )
+  {
+    // the guesses anew: this iteration's fp64 sums first
+    hipLaunchKernelGGL( k_chain_moments, dim3( B.n_blk * CH_QUARTERS, L.n_prob ), dim3( BLOCK ), 0, st, L, B );         // (L.n_mom_blocks == 4 B.n_blk)
+    hipLaunchKernelGGL( k_chain_records, dim3( B.n_blk, L.n_prob ), dim3( CHAIN_REC_WAVES * WAVE ), 0, st, L, B );
+    hipLaunchKernelGGL( k_chain_walk, dim3( CH_ROWS, L.n_prob ), dim3( WAVE ), 0, st, L, B );
+  }
+  else
+  {
+    hipLaunchKernelGGL( k_chain_records, dim3( B.n_blk, L.n_prob ), dim3( CHAIN_REC_WAVES * WAVE ), 0, st, L, B );
+    hipLaunchKernelGGL( k_chain_walk_and_moments, dim3( CH_ROWS + B.n_blk * CH_QUARTERS, L.n_prob ), dim3( BLOCK ), 0, st, L, B );
+  }
   hipLaunchKernelGGL( k_icp_update, dim3( L.n_prob ), dim3( UPDATE_WAVES * WAVE ), 0, st, L );                           // (centred on the chains' totals: L.exact_centroids)
 }
 
