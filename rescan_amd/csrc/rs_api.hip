@@ -1229,6 +1229,12 @@ int rs_hip_alignment_scores( const rs_hip_cloud_t* object, const rs_hip_cloud_t*
   // opt-in: the cold search row by row (16 lanes) with a K-stop per lane.  Same bits, 383 instead of 841 candidate evaluations per
   // point pair — and slower: 564 M VALU instructions per launch instead of 471 M, 1.53 ms instead of 1.16
   L.by_rows = getenv( "RS_HIP_SCORE_ROWS" ) ? 1 : 0;
+  // K-cap (opt-in, RS_HIP_SCORE_KCAP=<fraction of radius², e.g. 0.5>): a lane that has met K candidates within sqrt( kcap ) x radius
+  // stops caring about anything beyond.  Exact (same 256 bits) and measured useless on the bench's poses: 424 M VALU instructions per
+  // launch against 406 M without, 0.89 against 0.91 ms — the box a tile sweeps is set by its matched lanes' shells as much as by
+  // the unmatched ones' reach, and the counting costs what the smaller boxes save (profiles/r03/score_kcap.txt).
+  static const float kcap = getenv( "RS_HIP_SCORE_KCAP" ) ? (float)atof( getenv( "RS_HIP_SCORE_KCAP" ) ) : 0.0f;
+  L.kcap_frac = ( kcap > 0.0f && kcap < 1.0f ) ? kcap : 0.0f;
   // the launch grid's y dimension is limited to 65535 poses per launch
   for( int p0 = 0; p0 < n_poses; p0 += 65535 )
   {

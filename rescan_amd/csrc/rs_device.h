@@ -189,6 +189,7 @@ struct ScoreLaunch
   int*         queue_count;
   int          solo_stages;
   int          by_rows;    // launches that hand nothing off: the row-wise cold search (rs_kernels.hip: tile_search_rows)
+  float        kcap_frac;  // K-cap distance² as a fraction of radius² (rs_kernels.hip: KCap); 0: off
 };
 void launch_score( const ScoreLaunch& L, hipStream_t st );
 

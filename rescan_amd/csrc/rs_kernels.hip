@@ -551,10 +551,17 @@ __device__ __forceinline__ void count_lanes( int& cnt, lanemask mask )
   asm( "v_addc_co_u32 %0, %1, 0, %0, %2" : "+v"( cnt ), "=s"( carry_out ) : "s"( mask ) );
 }
 
-template <bool GATED, bool SELF, class LDS>
+// K-cap of a cold gated search (KCAP; the score batch): the consumers only walk the K NEAREST candidates, so once a lane has met K
+// candidates closer than some distance, nothing at or beyond that distance can ever be its match (its rank would be >= K).  One
+// such distance is tested, tau2 = a fixed fraction of radius²: a lane counts what it meets below it (cap_count) and, at K, lowers
+// its bound to it — a match it may hold beyond is dropped (rank >= K, proven).  Exact, and it turns the lanes that have nothing
+// compatible nearby — whose bound otherwise stays at the radius, which keeps the whole wave gating every candidate and sweeping
+// the full box — into lanes with the reach of their K-th neighbour.
+struct KCap { float tau2; int count; };
+template <bool GATED, bool SELF, bool KCAP = false, class LDS>
 __device__ __forceinline__ void consider4( const float4& X, const float4& Y, const float4& Z, int k, const LDS& L,
                                            float qx, float qy, float qz, float nx, float ny, float nz,
-                                           float tmin, float& bound, Match& m, int& seen_closer )
+                                           float tmin, float& bound, Match& m, int& seen_closer, KCap* cap = nullptr, int K = 0 )
 {
   float d[4];
   dist2x4( X, Y, Z, qx, qy, qz, d[0], d[1], d[2], d[3] );
@@ -562,6 +569,23 @@ __device__ __forceinline__ void consider4( const float4& X, const float4& Y, con
 #pragma unroll
   for( int i = 0; i < 4; ++i ) in[i] = RS_BALLOT( d[i] < bound );
   if( ( in[0] | in[1] | in[2] | in[3] ) == 0ull ) return;
+  if( KCAP )
+  {
+    // (a candidate below tau2 that is not below the lane's bound any more is closer than nothing the lane still cares about:
+    //  not counting it only delays the cap)
+#pragma unroll
+    for( int i = 0; i < 4; ++i ) count_lanes( cap->count, in[i] & RS_BALLOT( d[i] < cap->tau2 ) );
+    const bool capit = cap->count >= K && bound > cap->tau2;
+    if( RS_BALLOT( capit ) != 0ull )                     // (uniform: the lane masks below are taken with every lane present)
+    {
+      const bool drop = capit && m.found && !( m.d2 < cap->tau2 );
+      bound = capit ? cap->tau2 : bound;
+      m.found = drop ? false : m.found; m.slot = drop ? -1 : m.slot; m.d2 = drop ? INFINITY : m.d2; m.idx = drop ? INT_MAX : m.idx;
+#pragma unroll
+      for( int i = 0; i < 4; ++i ) in[i] = RS_BALLOT( d[i] < bound );
+      if( ( in[0] | in[1] | in[2] | in[3] ) == 0ull ) return;
+    }
+  }
   int4 I = make_int4( 0, 0, 0, 0 );
   if( SELF )
   {
@@ -627,16 +651,25 @@ __device__ __forceinline__ void consider4( const float4& X, const float4& Y, con
   }
 }
 
-// count, among four candidates, those that precede (bd2, bidx) within the radius
+// count, among four candidates, those that precede (bd2, bidx) within the radius.  bd2 < radius² (it is a match's dist²), so
+// "within the radius" is implied by "closer than the match"; a candidate AT the match's distance precedes it by its index — a
+// tie, looked at only when some lane has one.
 template <class LDS>
 __device__ __forceinline__ int precede4( const float4& X, const float4& Y, const float4& Z, int k, const LDS& L,
                                          float qx, float qy, float qz, float radius_sq, float bd2, int bidx )
 {
+  (void)radius_sq;
   float d[4];
   dist2x4( X, Y, Z, qx, qy, qz, d[0], d[1], d[2], d[3] );
   int c = 0;
 #pragma unroll
-  for( int i = 0; i < 4; ++i ) c += ( ( d[i] < radius_sq ) & lex_less( d[i], L.pidx[k + i], bd2, bidx ) ) ? 1 : 0;
+  for( int i = 0; i < 4; ++i ) count_lanes( c, RS_BALLOT( d[i] < bd2 ) );
+  const lanemask eq = RS_BALLOT( d[0] == bd2 ) | RS_BALLOT( d[1] == bd2 ) | RS_BALLOT( d[2] == bd2 ) | RS_BALLOT( d[3] == bd2 );
+  if( eq != 0ull )
+  {
+#pragma unroll
+    for( int i = 0; i < 4; ++i ) c += ( ( d[i] == bd2 ) & ( L.pidx[k + i] < bidx ) ) ? 1 : 0;
+  }
   return c;
 }
 
@@ -739,7 +772,7 @@ __device__ __forceinline__ CellBox box_clip( const CellBox& a, const CellBox& c 
 // any other tile is handed off at once (*handoff) — the cooperative kernel gives it a workgroup straight away instead of
 // after a lone wave's first shells, and this instantiation carries no shell loop (registers: phase A then fits 6 waves per
 // SIMD without scratch).
-template <bool GATED, bool WARM = false, bool BOUNDED_ONLY = false>
+template <bool GATED, bool WARM = false, bool BOUNDED_ONLY = false, bool KCAP = false>
 __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
                                               float qx, float qy, float qz, float nx, float ny, float nz,
                                               float radius, float radius_sq, float tmin, int K,
@@ -748,13 +781,17 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
                                               int* n_sweeps = nullptr /* out: shells swept + rank pass: the tile's cost class */,
                                               bool by_rows = false /* WARM: sweep_by_rows for tiles whose lanes all start from a candidate */,
                                               uint32_t* n_streamed = nullptr /* out: candidates streamed, rank pass included */,
-                                              int bounded_give_up_total = 0 /* BOUNDED_ONLY: hand a bounded tile off too when, swept tile-wide, the first 64 cell rows of its box hold this many candidates (0: never) */ )
+                                              int bounded_give_up_total = 0 /* BOUNDED_ONLY: hand a bounded tile off too when, swept tile-wide, the first 64 cell rows of its box hold this many candidates (0: never) */,
+                                              float kcap_frac = 0.5f /* KCAP: tau² / radius² */ )
 {
   if( handoff ) *handoff = false;
   int sweeps = 0;
   if( !__any( active ) ) return m;
   int seen_closer = 0;   // candidates that were no farther than the best-so-far when they were met
   float bound = bound_of( active, radius_sq, m );
+  KCap cap; cap.tau2 = radius_sq * kcap_frac; cap.count = 0;
+  // how far a lane still has to look: to its match, or — without one — as far as its bound lets anything in (the radius, or the K-cap)
+  auto reach = [&]() -> float { return ( KCAP && !m.found && active ) ? sqrtf( bound ) * 1.0001f + 1e-5f : reach_of( m, radius ); };
   uint32_t streamed = 0;
   const bool grid = g.inv_cell > 0.0f;
   const bool all_bounded = WARM && grid && !__any( active & !m.found );
@@ -808,17 +845,18 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
   for( int k = 0; ; k = k ? 2 * k : 1 )
   {
     cur = grid ? box_grow( core, k, full ) : full;
-    const CellBox out = grid ? reach_box( g, cur, unsettled, reach_of( m, radius ), qx, qy, qz ) : full;
+    const CellBox out = grid ? reach_box( g, cur, unsettled, reach(), qx, qy, qz ) : full;
     if( !box_empty( out ) )
       streamed += sweep_shell<GATED>( g, out, prev, have_prev, L, lane, 0, 1, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
-      { consider4<GATED, WARM>( X, Y, Z, k4, L, qx, qy, qz, nx, ny, nz, tmin, bound, m, seen_closer ); } );
+      { consider4<GATED, WARM, KCAP>( X, Y, Z, k4, L, qx, qy, qz, nx, ny, nz, tmin, bound, m, seen_closer, &cap, K ); } );
     if( dbg_unsettled ) dbg_unsettled[1] = (int)streamed;
     ++sweeps;
     if( n_sweeps ) *n_sweeps = sweeps;
     if( box_same( cur, full ) ) break;
-    // a lane is settled when nothing outside `cur` can precede its match (or reach it at all)
+    // a lane is settled when nothing outside `cur` can precede its match (or reach it at all: beyond the radius, or beyond its K-cap)
     const float cov = box_cover( g, cur, full, qx, qy, qz );
-    const bool settled = !active | ( cov >= radius ) | ( m.found & ( cov > 0.0f ) & ( m.d2 < cov * cov ) );
+    const bool settled = !active | ( cov >= radius ) | ( m.found & ( cov > 0.0f ) & ( m.d2 < cov * cov ) ) |
+                         ( KCAP & !m.found & ( cov > 0.0f ) & ( bound <= cov * cov ) );
     unsettled = !settled;
     if( dbg_unsettled ) { if( k == 1 ) dbg_unsettled[0] = __popcll( __ballot( !settled ) ); dbg_unsettled[1] = (int)streamed; dbg_unsettled[3] += 1; }
     if( !__any( !settled ) ) break;
@@ -3193,8 +3231,14 @@ __global__ __launch_bounds__( SC_WAVES * WAVE, RB ? RS_SCORE_ROWS_OCC : RS_SCORE
   if constexpr( RB > 0 )
   { handoff = false; m = tile_search_rows<true, RB>( L.scene, active, qx, qy, qz, nx, ny, nz, (float)L.sigma, L.radius_sq, L.gate_tmin, L.K, lds[wib], lane ); }
   else
-    m = tile_search<true>( L.scene, active, qx, qy, qz, nx, ny, nz, (float)L.sigma, L.radius_sq, L.gate_tmin, L.K,
-                           lds[wib], lane, L.solo_stages, &handoff, nullptr, no_match() );
+  {
+    if( L.kcap_frac > 0.0f )
+      m = tile_search<true, false, false, true>( L.scene, active, qx, qy, qz, nx, ny, nz, (float)L.sigma, L.radius_sq, L.gate_tmin, L.K,
+                             lds[wib], lane, L.solo_stages, &handoff, nullptr, no_match(), nullptr, false, nullptr, 0, L.kcap_frac );
+    else
+      m = tile_search<true>( L.scene, active, qx, qy, qz, nx, ny, nz, (float)L.sigma, L.radius_sq, L.gate_tmin, L.K,
+                             lds[wib], lane, L.solo_stages, &handoff, nullptr, no_match() );
+  }
   if( handoff )
   {
     if( lane == 0 ) { int q = atomicAdd( L.queue_count, 1 ); L.queue[q] = pose * L.obj.n_tiles + tile; }
