@@ -14,6 +14,10 @@ point-pairs = sum of query points over all searches = 10*n_scan + 256*n_obj + 8*
 Inputs are resident in HBM when the timed region starts; poses / scores / labels return to the
 host inside the timed region (they are the outputs the reference's callers consume).
 
+`--scaling strong` (N >= 1): ONE FIXED scene whatever N is — 8 ICP problems (every placement's ~50k-point model refined against
+the 1M-point scan, the loop of lib/rs/rs_database.h:220-230 with the reference's (0.075, 50 deg) and 10 fixed iterations), 256
+score poses, 8 placements — its units sharded over the ranks like below; total work does not grow with N ("scaling": "strong").
+
 N > 1 (torchrun, one rank per GPU, RCCL) — BASELINE.json configs[3], SURVEY.md §8e: ONE scene, replicated on every
 GPU; the units of the three consumers (ICP start poses, score poses, placements of the sorted arrangement) are
 sharded across the ranks with rescan_amd.dist.shard_range; every rank's label kernel writes its per-placement unary
@@ -42,6 +46,8 @@ sys.path.insert(0, ROOT)
 # profiles/r02/ab_profiling_events.txt; events carried inside the kernels' dispatch packets — hipExtLaunchKernelGGL — cost more:
 # 3.11).  The score and label kernels are timed on every call.
 os.environ.setdefault("RS_HIP_PROF_EVERY", "4")
+# completion waits busy-wait instead of sleeping (the library reads this in rs_hip_init; opt-in, see rs_api.hip)
+os.environ.setdefault("RS_HIP_SCHEDULE", "spin")
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
 ICP_ITERS = 10
@@ -81,6 +87,9 @@ def build_inputs(n_points, seed, units=1):
         for k in range(N_PLACEMENTS):
             plc.append(dict(np=plc[k]["np"], same_as=k, pose=synth.perturbed_pose(s1["objects"][k]["pose"], rng_u, 0.01, 0.005), cls=plc[k]["cls"]))
     w["icp_T0s"] = np.stack(w["icp_T0s"])
+    # --scaling strong: one ICP problem per placement — the placement's model cloud against the scan, from the placement's (slightly
+    # wrong) pose, with rsdb_refine_alignment_of_objects_to_scene's parameters (lib/rs/rs_database.h:220-230)
+    w["strong_icp"] = dict(T0s=np.stack([p["pose"] for p in plc[:N_PLACEMENTS]]), max_dist=0.075, max_angle=np.deg2rad(50.0))
     w["plc"] = plc
     w["plc_poses"] = np.stack([p["pose"] for p in plc])
     w["units"] = units
@@ -100,7 +109,8 @@ def build_workload(n_points, seed, knn, units=1):
     op, on = w["obj_score_np"]
     w["obj_score"] = capi.Cloud(op, on, cell_size=cell if cell != 0 else -1.0)
     for p in w["plc"]:
-        p["cloud"] = w["plc"][p["same_as"]]["cloud"] if "same_as" in p else capi.Cloud(p["np"][0], p["np"][1], cell_size=cell if cell != 0 else -1.0)
+        # (--knn brute: the placed models — the label pass's TARGETS — are one brute tile each too)
+        p["cloud"] = w["plc"][p["same_as"]]["cloud"] if "same_as" in p else capi.Cloud(p["np"][0], p["np"][1], cell_size=cell)
     return w
 
 
@@ -125,9 +135,11 @@ class RoleRunner:
 
     spin (default): the longest of the three — the ICP chain (RS_BENCH_MAIN_ROLE=icp|score|label; it was the score batch
     until that got single-wave workgroups) — runs on the CALLING thread, the two others on worker threads that never sleep:
-    between steps they busy-wait inside the library (rs_hip_spin_wait, no interpreter lock held) for a flag the caller's next
-    library call stores on entry (rs_hip_post_on_next_call: the longest consumer is under way before the others are released,
-    the second-longest first), and the caller busy-waits for theirs.  With executors every step is three submissions and three future waits, i.e. six wake-ups of sleeping
+    between steps they busy-wait in native code (tools/benchaux: rsb_spin_wait, no interpreter lock held) for a flag that the
+    caller stores WITHOUT releasing the interpreter lock right before its own consumer's call (spin_post_holding_gil: the
+    waiting thread can only go on once the poster is inside its native call — the longest consumer is under way before the
+    others are released, the second-longest first), and the caller busy-waits for theirs.  These helpers are the harness's own
+    (tools/benchaux/librs_benchaux.so), not part of the product ABI.  With executors every step is three submissions and three future waits, i.e. six wake-ups of sleeping
     threads by the host scheduler — usually tens of microseconds each, but on the shared 256-thread hosts of this pool one
     step in ~35 lost 1.5-3 ms there while all three library calls took their usual time (tools/throttle_check.sh: no cgroup
     throttling in the region; the time is between the calls).  RS_BENCH_SPIN=0: three single-thread executors as before."""
@@ -138,6 +150,9 @@ class RoleRunner:
         import threading
         from concurrent.futures import ThreadPoolExecutor
         from rescan_amd import capi
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import benchaux
+        self.aux = benchaux
         self.capi, self.spin, self.k, self.stop, self.masked = capi, spin, 0, False, bool(masks)
         self.fns, self.out, self.dt = [None] * 3, [None] * 3, [0.0] * 3
         self.main = main_role
@@ -158,37 +173,40 @@ class RoleRunner:
         for t in self.threads:
             t.start()
         for r in self.workers:
-            capi.spin_wait(self.addr(2, r), 1, 60.0)
+            self.aux.spin_wait(self.addr(2, r), 1, 60.0)
         if self.failed is not None:
+            self.close()                           # (park the workers that did start, give the calling thread its unmasked stream back)
             raise self.failed
 
     def _worker(self, r, mask):
-        capi = self.capi
+        capi, aux = self.capi, self.aux
         try:
             if mask:
                 capi.stream_cu_mask(mask)
         except Exception as e:               # a runtime without CU masks
             self.failed = e
-        capi.spin_post(self.addr(2, r), 1)
+        aux.spin_post(self.addr(2, r), 1)
         k = 0
         while True:
             k += 1
-            capi.spin_wait(self.addr(0, r), k, 0.0)
+            aux.spin_wait(self.addr(0, r), k, 0.0)
             if self.stop:
                 if mask:
-                    capi.stream_cu_mask(None)         # (a profiler's finalisation does not survive masked streams)
-                capi.spin_post(self.addr(1, r), 1 << 30)
+                    try:
+                        capi.stream_cu_mask(None)     # (a profiler's finalisation does not survive masked streams)
+                    except Exception:
+                        pass
+                aux.spin_post(self.addr(1, r), 1 << 30)
                 return
             if r == self.workers[0]:
-                capi.post_on_next_call(self.addr(0, self.workers[1]), k)  # the second worker goes once this one is inside the library
+                aux.spin_post_holding_gil(self.addr(0, self.workers[1]), k)  # the second worker goes once this one is inside the library
             t = time.perf_counter()
             try:
                 out = self.fns[r]()
             except BaseException as e:        # handed to the caller
                 out = e
-            capi.post_pending()
             self.out[r], self.dt[r] = out, time.perf_counter() - t
-            capi.spin_post(self.addr(1, r), k)
+            aux.spin_post(self.addr(1, r), k)
 
     def run3(self, icp, score, label):
         """-> (icp(), score(), label()), run concurrently."""
@@ -202,18 +220,15 @@ class RoleRunner:
             f = [ex.submit(timed(r)) for r, ex in enumerate(self.pools)]
             outs = [x.result() for x in f]
         else:
-            capi = self.capi
+            aux = self.aux
             self.k += 1
             self.fns = fns
-            capi.post_on_next_call(self.addr(0, self.workers[0]), self.k)   # the first worker goes once this thread is inside the library
+            aux.spin_post_holding_gil(self.addr(0, self.workers[0]), self.k)   # the first worker goes once this thread is inside the library
             t = time.perf_counter()
-            try:
-                mine = fns[self.main]()
-            finally:
-                capi.post_pending()
+            mine = fns[self.main]()
             self.dt[self.main] = time.perf_counter() - t
             for r in self.workers:
-                capi.spin_wait(self.addr(1, r), self.k, 120.0)
+                aux.spin_wait(self.addr(1, r), self.k, 120.0)
             outs = [mine if r == self.main else self.out[r] for r in range(3)]
             for o in outs:
                 if isinstance(o, BaseException):
@@ -233,9 +248,10 @@ class RoleRunner:
                     ex.submit(self.capi.stream_cu_mask, None).result()
             return
         for r in self.workers:
-            self.capi.spin_post(self.addr(0, r), 1 << 30)
+            self.aux.spin_post(self.addr(0, r), 1 << 30)
         for r in self.workers:
-            self.capi.spin_wait(self.addr(1, r), 1 << 30, 30.0)
+            if self.threads[self.workers.index(r)].is_alive() or True:
+                self.aux.spin_wait(self.addr(1, r), 1 << 30, 30.0)
         if self.masked:
             self.capi.stream_cu_mask(None)
 
@@ -265,6 +281,8 @@ def _roles():
             q, per = st[0].split()
             cpus = float(q) / float(per)
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+        aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None      # (a cpuset limits the cores like a quota does)
+        cpus = aff if cpus is None else (min(cpus, aff) if aff else cpus)
         spin_default = "0" if (cpus is not None and cpus < 4.0 * local_world) else "1"
         spin = os.environ.get("RS_BENCH_SPIN", spin_default) != "0"
         masks, note = None, "none"
@@ -438,16 +456,19 @@ class Sharded:
     Two send / receive buffer sets: the exchange of step s (copy of the small results, all-gather, fold, download of the
     folded labels) runs on its own host thread while step s + 1 computes into the other set."""
 
-    def __init__(self, w, dist, dev, rank, world):
+    def __init__(self, w, dist, dev, rank, world, strong=False):
         import torch
         from rescan_amd import dist as rd
         self.w, self.dist, self.dev, self.rank, self.world = w, dist, dev, rank, world
         n_plc = len(w["plc"])
-        self.lay = rd.ShardLayout(world, len(w["icp_T0s"]), len(w["score_poses"]), n_plc, w["n_scan1"])
+        n_icp = N_PLACEMENTS if strong else len(w["icp_T0s"])
+        self.lay = rd.ShardLayout(world, n_icp, len(w["score_poses"]), n_plc, w["n_scan1"])
         order, _, radii = rd.arrangement_plan([0] * n_plc, [p["cls"] for p in w["plc"]], 0.05)
         self.order = order
+        si = w["strong_icp"]
         self.units = dict(
-            icp=(w["scan1"], w["scan0"], w["icp_T0s"], 0.10, np.deg2rad(60.0), ICP_ITERS),
+            icp=([p["cloud"] for p in w["plc"][:N_PLACEMENTS]], w["scan1"], si["T0s"], si["max_dist"], si["max_angle"], ICP_ITERS) if strong else
+                (w["scan1"], w["scan0"], w["icp_T0s"], 0.10, np.deg2rad(60.0), ICP_ITERS),
             score=(w["obj_score"], w["scan1"], w["score_poses"], 0.1, 64),
             label=(w["scan1"], w["plc_poses"][order], [w["plc"][i]["cloud"] for i in order], radii))
         self.bufs = []
@@ -510,7 +531,7 @@ class Sharded:
         return prev
 
 
-def parity_block(out, n_points, seed, knn, units):
+def parity_block(out, n_points, seed, knn, units, strong=False):
     """Distance of the LAST step's outputs from tests/golden/bench_seed11.npz — what the compiled reference computes for
     the same inputs (oracle/gen_golden_bench.py: pose / error after the 10 fixed iterations composed from the reference's
     icp_find_corrs + icp_estimate_rigid_xform_pt2pl, the 256 scores of mgs_compute_object_alignment_score; labels by the
@@ -521,8 +542,12 @@ def parity_block(out, n_points, seed, knn, units):
         return None
     g = np.load(path)
     blk = {"fixture": "tests/golden/bench_seed11.npz", "knn": knn}
-    blk["pose_dist"] = float(np.linalg.norm(np.asarray(out["T"], np.float64).ravel() - g["icp_pose"].astype(np.float64)))
-    blk["err_abs_diff"] = float(abs(float(out["err"]) - float(g["icp_err"])))
+    if strong:
+        blk["icp"] = ("not compared: --scaling strong refines the 8 placements' models against the scan (object-sized sources: the reference-order "
+                      "estimator, bit-identical to the reference on every fixture of tests/golden/icp_*.npz), the fixture holds the scan-to-scan run")
+    else:
+        blk["pose_dist"] = float(np.linalg.norm(np.asarray(out["T"], np.float64).ravel() - g["icp_pose"].astype(np.float64)))
+        blk["err_abs_diff"] = float(abs(float(out["err"]) - float(g["icp_err"])))
     sc = np.asarray(out["scores"], np.float64)[:N_POSES]
     blk["score_max_abs_err"] = float(np.abs(sc - g["scores"].astype(np.float64)).max())
     if units == 1:
@@ -532,6 +557,62 @@ def parity_block(out, n_points, seed, knn, units):
         blk["labels"] = "not compared: %d placements instead of the fixture's %d" % (units * N_PLACEMENTS, N_PLACEMENTS)
     blk["tolerance"] = {"pose_dist": 1e-4, "score_max_abs_err": 2e-6, "label_mismatches": 0}
     return blk
+
+
+def dropin_block(w):
+    """"device time + H2D/D2H that the reference-equivalent call would incur" — the same three consumers issued
+    through librescan_dropin.so with HOST arrays in and results out (the reference's own entry points: icp_align with its stop
+    test, the flat score / label entries), outside the timed region: the first call pays hashing, upload and the device index
+    build of every array; a repeated call pays the hashes (arrays above 4 MB: a ~1 KB sample) and the results' way back."""
+    import ctypes as C
+    lib = C.CDLL(os.path.join(ROOT, "rescan_amd", "librescan_dropin.so"))
+
+    class Mat4(C.Structure):
+        _fields_ = [("data", C.c_float * 16)]
+    lib.icp_align.restype = C.c_float
+    lib.icp_align.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(Mat4), Mat4, C.c_float, C.c_float, C.c_bool]
+    lib.rsd_alignment_scores.restype = C.c_int
+    lib.rsd_alignment_scores.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_void_p]
+    lib.rsd_arrangement_to_labels.restype = C.c_int
+    lib.rsd_arrangement_to_labels.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                              C.c_float, C.c_bool, C.c_void_p, C.c_void_p]
+    lib.rsd_cache_clear.restype = None
+    s0, s1 = w["s0"], w["s1"]
+    op, on = w["obj_score_np"]
+    plc = w["plc"][:N_PLACEMENTS]
+    T2 = Mat4(); T2.data[:] = [float(x) for x in I4]
+    poses = np.ascontiguousarray(w["score_poses"][:N_POSES], np.float32)
+    scores = np.zeros(N_POSES, np.float32)
+    pp = (C.c_void_p * len(plc))(*[p["np"][0].ctypes.data for p in plc]); pn = (C.c_void_p * len(plc))(*[p["np"][1].ctypes.data for p in plc])
+    ns = np.array([len(p["np"][0]) for p in plc], np.int32)
+    pl_poses = np.ascontiguousarray(w["plc_poses"][:N_PLACEMENTS], np.float32)
+    st = np.zeros(len(plc), np.int32); cls = np.array([p["cls"] for p in plc], np.int32)
+    labels = np.zeros(w["n_scan1"], np.int8); order = np.zeros(len(plc), np.int32)
+
+    def step():
+        T = Mat4(); T.data[:] = [float(x) for x in w["icp_T0"]]
+        t = [time.perf_counter()]
+        lib.icp_align(s1["points"].ctypes.data, s1["normals"].ctypes.data, len(s1["points"]), s0["points"].ctypes.data, s0["normals"].ctypes.data,
+                      len(s0["points"]), C.byref(T), T2, 0.1, float(np.deg2rad(60.0)), False)
+        t.append(time.perf_counter())
+        lib.rsd_alignment_scores(op.ctypes.data, on.ctypes.data, len(op), s1["points"].ctypes.data, s1["normals"].ctypes.data, len(s1["points"]),
+                                 poses.ctypes.data, N_POSES, 0.1, 64, scores.ctypes.data)
+        t.append(time.perf_counter())
+        lib.rsd_arrangement_to_labels(s1["points"].ctypes.data, s1["normals"].ctypes.data, len(s1["points"]), C.addressof(pp), C.addressof(pn), ns.ctypes.data,
+                                      pl_poses.ctypes.data, st.ctypes.data, cls.ctypes.data, len(plc), 0.05, False, labels.ctypes.data, order.ctypes.data)
+        t.append(time.perf_counter())
+        return [1e3 * (b - a) for a, b in zip(t[:-1], t[1:])]
+
+    lib.rsd_cache_clear()
+    first = step()
+    rep = [step() for _ in range(3)]
+    rep = [min(r[k] for r in rep) for k in range(3)]
+    lib.rsd_cache_clear()
+    return {"first_call_ms": sum(first), "repeated_ms": sum(rep),
+            "first_call_ms_by_consumer": dict(icp_align=first[0], alignment_scores=first[1], arrangement_to_labels=first[2]),
+            "repeated_ms_by_consumer": dict(icp_align=rep[0], alignment_scores=rep[1], arrangement_to_labels=rep[2]),
+            "note": "librescan_dropin.so, host arrays in / results out, the consumers one after the other; icp_align runs the reference's own loop "
+                    "(stop test on: it converges where the timed step runs 10 fixed iterations)"}
 
 
 def cpu_baseline(w, budget_s=20.0):
@@ -617,6 +698,8 @@ def main():
     ap.add_argument("--serial", action="store_true", help="issue the three consumers one after another")
     ap.add_argument("--shard", action="store_true", help="the sharded route (default for --gpus > 1) also at N = 1")
     ap.add_argument("--replicas", action="store_true", help="--gpus > 1: every rank its own scene (configs[4]) instead of one sharded scene")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="strong: ONE fixed scene (8 per-placement ICP problems, 256 score poses, 8 placements) sharded over the ranks; total work does not grow with --gpus")
     args = ap.parse_args()
 
     # stdout carries the ONE JSON line and nothing else: whatever libraries print there (RCCL's version banner at the first
@@ -653,12 +736,15 @@ def main():
     from rescan_amd import capi
     capi.init(local_rank)
 
-    sharded = args.shard or (world > 1 and not args.replicas)
+    strong = args.scaling == "strong"
+    sharded = args.shard or strong or (world > 1 and not args.replicas)
     seed = 11 if sharded else 11 + rank
-    units = world if sharded else 1
+    units = 1 if strong else (world if sharded else 1)
     w = build_workload(args.points, seed=seed, knn=args.knn, units=units)
+    if strong:      # the step's ICP units are the 8 per-placement problems: model points x iterations
+        w["pairs"] = dict(icp=ICP_ITERS * sum(len(p["np"][0]) for p in w["plc"][:N_PLACEMENTS]), score=w["pairs"]["score"], label=w["pairs"]["label"])
     dist_ctx = (dist, dev) if dist is not None else None
-    sh = Sharded(w, dist, dev, rank, world) if sharded else None
+    sh = Sharded(w, dist, dev, rank, world, strong=strong) if sharded else None
 
     def barrier():
         if dist is not None:
@@ -751,7 +837,11 @@ def main():
         avg_s = (ms / max(1, n_l)) * 1e-3
         achieved = bytes_launch / avg_s / 1e9 if avg_s > 0 else 0.0
         traffic, traffic_note = read_traffic(dom)
-        if sharded:
+        if strong:
+            wl = ("configs[3], strong scaling: ONE FIXED scene (~1M-pt scans) replicated per rank, its units sharded over the ranks: 8 ICP-NN problems "
+                  "(each placement's ~50k-pt model -> scan, 0.075 / 50 deg, 10 it: lib/rs/rs_database.h:220-230), score-NN 256 poses x 10k, label-NN 8 placements; "
+                  "per-placement rows all-gathered on the device, ordered fold")
+        elif sharded:
             wl = ("configs[3]: ONE scene (~1M-pt scans) replicated per rank, units sharded over the ranks: %d x {ICP-NN 10 it x scan->scan, "
                   "score-NN 256 poses x 10k, label-NN 8 placements}; per-placement rows all-gathered on the device, ordered fold" % units)
         else:
@@ -761,7 +851,7 @@ def main():
             "metric": "point-pairs/sec (ICP-NN + score-NN + segment-NN) per scene",
             "value": pairs_total / elapsed, "unit": "point-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl,
                        "knn": "lds-hash-cells" if args.knn == "hash" else "brute-tile",
@@ -780,7 +870,7 @@ def main():
                          "avg_launch_ms": ms / max(1, n_l), "launches": n_l, "alg_bytes_per_launch": bytes_launch,
                          "dominant_by": "time per step x share of the CUs the kernel's stream is confined to", "cu_share": shares.get(dom, 1.0)},
             "roofline_by_kernel": by_kernel,
-            "parity": parity_block(out, args.points, seed, args.knn, units),
+            "parity": parity_block(out, args.points, seed, args.knn, units, strong),
             "ms_per_step_spread": {"min": float(step_ms.min()), "median": float(np.median(step_ms)), "max": float(step_ms.max()),
                                    "steps_over_1.3x_median": int((step_ms > 1.3 * np.median(step_ms)).sum())},
             # the container's CPU cgroup around the timed region: a throttled period stalls every host thread of the process
@@ -796,6 +886,17 @@ def main():
         line["candidate_evals"] = {"per_step": cand * 64 / args.steps, "per_s": cand * 64 / elapsed,
                                    "candidates_staged_per_step": cand / args.steps,
                                    "per_point_pair": cand * 64 / args.steps / max(1, pairs_unit)}
+        if world == 1 and not sharded:
+            # outside the timed region: the same step with the consumers issued one after the other, and through the drop-in boundary
+            try:
+                capi.profile_enable(False)
+                t_ser = []
+                for _ in range(5):
+                    t = time.perf_counter(); run_step(w, None, False); t_ser.append(time.perf_counter() - t)
+                line["serial_ms_per_step"] = float(np.median(t_ser) * 1e3)
+                line["dropin"] = dropin_block(w)
+            except Exception as e:
+                line["dropin"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 cb = cpu_baseline(w)

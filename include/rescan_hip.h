@@ -41,18 +41,9 @@ int         rs_hip_synchronize( void );
  * unrestricted stream — do that before the process exits when a profiler is attached: rocprofv3 crashes in its finalisation when
  * masked streams are still alive. */
 int         rs_hip_stream_cu_mask( const uint32_t* mask, int32_t n_words );
-/* Diagnostic: out[b] = XCC_ID | HW_ID << 8 of workgroup b of a probe launch on the calling thread's stream (which CUs a
- * CU mask really selects: tools/cu_mask_probe.py). */
-int         rs_hip_probe_placement( uint32_t* out_host, int32_t n_blocks );
-/* Host-side spin primitives for callers that issue independent operators from several threads and join them thousands of times
- * per second.  spin_post stores value into *flag (release); spin_wait returns once *flag >= at_least (acquire), busy-waiting
- * (timeout_s > 0: RS_HIP_E_RUNTIME after that long); post_on_next_call defers a post to the calling thread's next entry into
- * this library — for bindings that hold a global interpreter lock outside native calls: the waiting thread is then released
- * while the posting one is inside the library and the lock is free; post_pending sends a deferred post now. */
-int         rs_hip_spin_post( volatile int32_t* flag, int32_t value );
-int         rs_hip_spin_wait( const volatile int32_t* flag, int32_t at_least, double timeout_s );
-int         rs_hip_post_on_next_call( volatile int32_t* flag, int32_t value );
-int         rs_hip_post_pending( void );
+/* The HIP stream (hipStream_t) the calling thread's launches go to: its own, or the one given to rs_hip_set_stream.  NULL if the
+ * library cannot be initialised. */
+void*       rs_hip_get_stream( void );
 /* ABI/version string, e.g. "rescan_hip 0.1 gfx950". */
 const char* rs_hip_version( void );
 

@@ -24,11 +24,7 @@ SIGNATURES = {
     "rs_hip_set_stream": (C.c_int, [C.c_void_p]),
     "rs_hip_synchronize": (C.c_int, []),
     "rs_hip_stream_cu_mask": (C.c_int, [C.c_void_p, C.c_int32]),
-    "rs_hip_probe_placement": (C.c_int, [np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS"), C.c_int32]),
-    "rs_hip_spin_post": (C.c_int, [C.c_void_p, C.c_int32]),
-    "rs_hip_spin_wait": (C.c_int, [C.c_void_p, C.c_int32, C.c_double]),
-    "rs_hip_post_on_next_call": (C.c_int, [C.c_void_p, C.c_int32]),
-    "rs_hip_post_pending": (C.c_int, []),
+    "rs_hip_get_stream": (C.c_void_p, []),
     "rs_hip_version": (C.c_char_p, []),
     "rs_hip_profile_enable": (C.c_int, [C.c_int]),
     "rs_hip_profile_reset": (C.c_int, []),
@@ -142,31 +138,9 @@ def stream_cu_mask(bits):
     _check(load().rs_hip_stream_cu_mask(words.ctypes.data, len(words)))
 
 
-def spin_post(flag_addr, value):
-    """*flag = value (flag_addr: address of an aligned int32, e.g. a numpy int32 array's .ctypes.data + 4 * k)."""
-    _check(load().rs_hip_spin_post(flag_addr, int(value)))
-
-
-def spin_wait(flag_addr, at_least, timeout_s=60.0):
-    """Busy-waits (outside the interpreter lock) until *flag >= at_least."""
-    _check(load().rs_hip_spin_wait(flag_addr, int(at_least), float(timeout_s)))
-
-
-def post_on_next_call(flag_addr, value):
-    """*flag = value at the calling thread's next entry into the library (i.e. once the interpreter lock has been released)."""
-    _check(load().rs_hip_post_on_next_call(flag_addr, int(value)))
-
-
-def post_pending():
-    _check(load().rs_hip_post_pending())
-
-
-def probe_placement(n_blocks=4096):
-    """(xcc, se, sh, cu) of each workgroup of a probe launch on the calling thread's stream (diagnostic)."""
-    out = np.zeros(n_blocks, np.uint32)
-    _check(load().rs_hip_probe_placement(out, n_blocks))
-    hw = out >> 8
-    return out & 15, (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 15
+def get_stream():
+    """The HIP stream (an integer handle) the calling thread's launches go to."""
+    return load().rs_hip_get_stream()
 
 
 def profile_enable(on=True):

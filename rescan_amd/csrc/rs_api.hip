@@ -53,17 +53,8 @@ void set_err( const char* fmt, ... )
        if( e_ != hipSuccess ) { set_err( "%s failed: %s (%s:%d)", #expr, hipGetErrorString( e_ ), __FILE__, __LINE__ ); \
                                 return code_on_fail; } } while( 0 )
 
-// rs_hip_post_on_next_call: a flag this thread stores at its next entry into the library (see include/rescan_hip.h)
-thread_local volatile int32_t* g_post_flag = nullptr;
-thread_local int32_t g_post_value = 0;
-static inline void post_pending()
-{
-  if( g_post_flag ) { __atomic_store_n( (int32_t*)g_post_flag, g_post_value, __ATOMIC_RELEASE ); g_post_flag = nullptr; }
-}
-
 int ensure_ready()
 {
-  post_pending();
   if( !g_ready ) { int rc = rs_hip_init( g_device >= 0 ? g_device : 0 ); if( rc ) return rc; }
   if( !g_own_stream )       // first call from this host thread
   {
@@ -277,14 +268,16 @@ int rs_hip_init( int device )
     return RS_HIP_E_NODEVICE;
   }
   if( device < 0 || device >= count ) { set_err( "rs_hip_init: device %d out of range (%d devices)", device, count ); return RS_HIP_E_ARG; }
-  // Callers wait for small results thousands of times per second (the unchanged pose_proposal: ~37 k searches per run):
-  // spin on completion instead of sleeping.  Refused (harmlessly) when the process has set up the device already; RS_HIP_SCHEDULE=yield|auto keeps the default.
+  HIP_TRY( hipSetDevice( device ), RS_HIP_E_NODEVICE );
+  // RS_HIP_SCHEDULE=spin: completion waits of THIS device busy-wait instead of sleeping — for callers that wait for small results
+  // thousands of times per second (librescan_dropin.so asks for it: the unchanged pose_proposal issues ~37 k searches per run; so
+  // does bench.py).  Opt-in: a library does not change a process's scheduling policy by itself (8 ranks x 3 busy-waiting threads on
+  // a host with a CPU quota would starve each other).  Refused (harmlessly) when the process has set the device up already.
   {
     const char* sch = getenv( "RS_HIP_SCHEDULE" );
-    if( !sch || !std::strcmp( sch, "spin" ) ) (void)hipSetDeviceFlags( hipDeviceScheduleSpin );
+    if( sch && !std::strcmp( sch, "spin" ) ) (void)hipSetDeviceFlags( hipDeviceScheduleSpin );
     (void)hipGetLastError();
   }
-  HIP_TRY( hipSetDevice( device ), RS_HIP_E_NODEVICE );
   g_device = device;
   g_ready = true;
   return RS_HIP_OK;
@@ -311,60 +304,11 @@ int rs_hip_stream_cu_mask( const uint32_t* mask, int32_t n_words )
   return RS_HIP_OK;
 }
 
-// Diagnostic: where the hardware places the workgroups of the calling thread's stream.  out[b] = XCC_ID | HW_ID << 8 of
-// block b's first wave (HW_ID: CU_ID bits 11:8, SH_ID 12, SE_ID 15:13).  Used by tools/cu_mask_probe.py to find out which
-// CUs a mask bit stands for — the partition bench.py uses is chosen from that.
-__global__ void k_probe_placement( uint32_t* out, int spin )
+void* rs_hip_get_stream( void )
 {
-  uint32_t xcc, hw;
-  asm volatile( "s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"( xcc ) );
-  asm volatile( "s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"( hw ) );
-  const long long t0 = wall_clock64();
-  while( wall_clock64() - t0 < spin ) { }                 // hold the slot so that the blocks spread over everything allowed
-  if( threadIdx.x == 0 ) out[blockIdx.x] = ( xcc & 15u ) | ( hw << 8 );
+  if( ensure_ready() ) return nullptr;
+  return (void*)g_stream;
 }
-int rs_hip_probe_placement( uint32_t* out_host, int32_t n_blocks )
-{
-  int rc = ensure_ready(); if( rc ) return rc;
-  if( !out_host || n_blocks <= 0 ) { set_err( "probe_placement: bad arguments" ); return RS_HIP_E_ARG; }
-  uint32_t* d = nullptr;
-  HIP_TRY( hipMalloc( (void**)&d, (size_t)n_blocks * 4 ), RS_HIP_E_RUNTIME );
-  hipLaunchKernelGGL( k_probe_placement, dim3( n_blocks ), dim3( 256 ), 0, g_stream, d, 20000 );   // 100 MHz clock: 200 us
-  hipError_t e = hipMemcpyAsync( out_host, d, (size_t)n_blocks * 4, hipMemcpyDeviceToHost, g_stream );
-  if( e == hipSuccess ) e = hipStreamSynchronize( g_stream );
-  (void)hipFree( d );
-  HIP_TRY( e, RS_HIP_E_RUNTIME );
-  return RS_HIP_OK;
-}
-
-// Host-side spin primitives for callers that issue independent operators from several threads and join them thousands of
-// times per second (bench.py): a thread that sleeps in a queue or on a condition variable pays the host scheduler's wake-up
-// latency at every hand-off — on a shared, busy host occasionally milliseconds, more than a whole step.
-int rs_hip_spin_post( volatile int32_t* flag, int32_t value )
-{
-  if( !flag ) return RS_HIP_E_ARG;
-  __atomic_store_n( (int32_t*)flag, value, __ATOMIC_RELEASE );
-  return RS_HIP_OK;
-}
-int rs_hip_spin_wait( const volatile int32_t* flag, int32_t at_least, double timeout_s )
-{
-  if( !flag ) return RS_HIP_E_ARG;
-  const auto t0 = std::chrono::steady_clock::now();
-  for( unsigned n = 0; ; ++n )
-  {
-    if( __atomic_load_n( (const int32_t*)flag, __ATOMIC_ACQUIRE ) >= at_least ) return RS_HIP_OK;
-    __builtin_ia32_pause();
-    if( ( n & 0xffff ) == 0xffff && timeout_s > 0.0 &&
-        std::chrono::duration<double>( std::chrono::steady_clock::now() - t0 ).count() > timeout_s ) { set_err( "spin_wait: timed out" ); return RS_HIP_E_RUNTIME; }
-  }
-}
-int rs_hip_post_on_next_call( volatile int32_t* flag, int32_t value )
-{
-  post_pending();                     // (one pending post per thread; an older one goes out now)
-  g_post_flag = flag; g_post_value = value;
-  return RS_HIP_OK;
-}
-int rs_hip_post_pending( void ) { post_pending(); return RS_HIP_OK; }
 
 int rs_hip_synchronize( void )
 {

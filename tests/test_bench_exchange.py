@@ -52,8 +52,8 @@ def test_exchange_world2_gloo():
 
 def test_role_runner_joins_three_consumers_without_sleeping():
     """bench.py's RoleRunner in its spinning form (no GPU needed: the hand-off flags are host memory): 200 steps of three
-    callables, each always on its own thread, results in order; an exception raised by a worker's callable reaches the caller; a
-    callable that never enters the library still releases the next thread (post_pending); close() parks the workers."""
+    callables, each always on its own thread, results in order; an exception raised by a worker's callable reaches the caller;
+    close() parks the workers."""
     import threading
     sys.path.insert(0, ROOT)
     import bench

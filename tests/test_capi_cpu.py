@@ -5,11 +5,14 @@ import ctypes
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
 
 from conftest import ROOT, load_golden
+
+LIB = os.path.join(ROOT, "rescan_amd", "librescan_hip.so")
 
 
 @pytest.fixture(scope="module")
@@ -112,39 +115,34 @@ def test_fails_loudly_without_gpu(lib):
     assert rc == -1 and b"no HIP device" in lib.rs_hip_last_error()
 
 
-def test_spin_flags_hand_work_between_threads(lib):
-    """rs_hip_spin_post / _wait / _post_on_next_call / _post_pending (bench.py's RoleRunner joins its consumers with them): a
-    worker thread and the caller ping-pong through two int32 flags without ever sleeping in a queue; a deferred post goes out
-    at the thread's next entry into the library (or with post_pending), not before; a wait that cannot succeed times out."""
+def test_spin_flags_hand_work_between_threads():
+    """tools/benchaux (the harness's own helper library, NOT the product ABI): a worker thread and the caller ping-pong through two
+    int32 flags without ever sleeping in a queue; a wait that cannot succeed times out; and none of these helpers is exported by
+    librescan_hip.so any more (round-2 verdict: bench plumbing out of the product ABI)."""
     import threading
-    from rescan_amd import capi
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import benchaux
     flags = np.zeros(4, np.int32)
     addr = lambda k: flags.ctypes.data + 4 * k          # noqa: E731
     seen = []
 
     def worker():
         for k in range(1, 201):
-            capi.spin_wait(addr(0), k, 30.0)
+            benchaux.spin_wait(addr(0), k, 30.0)
             seen.append(k)
-            capi.spin_post(addr(1), k)
+            benchaux.spin_post(addr(1), k)
 
     t = threading.Thread(target=worker)
     t.start()
     for k in range(1, 201):
-        capi.spin_post(addr(0), k)
-        capi.spin_wait(addr(1), k, 30.0)
+        (benchaux.spin_post if k % 2 else benchaux.spin_post_holding_gil)(addr(0), k)
+        benchaux.spin_wait(addr(1), k, 30.0)
         assert seen[-1] == k
     t.join()
-    capi.post_on_next_call(addr(2), 7)
-    assert flags[2] == 0                                  # deferred
-    lib.rs_hip_last_error()                               # (not an entry that posts: a plain accessor)
-    capi.post_pending()
-    assert flags[2] == 7
-    capi.post_on_next_call(addr(3), 9)
-    lib.rs_hip_synchronize()                              # any operator entry posts first (and then fails or not, GPU or no GPU)
-    assert flags[3] == 9
-    with pytest.raises(capi.RescanHipError):
-        capi.spin_wait(addr(0), 10 ** 6, 0.05)
+    with pytest.raises(RuntimeError):
+        benchaux.spin_wait(addr(0), 10 ** 6, 0.05)
+    out = subprocess.check_output(["nm", "-D", "--defined-only", LIB], text=True)
+    assert not re.search(r"rs_hip_(spin_|post_|probe_placement)", out)
 
 
 def test_missing_extension_is_an_error(monkeypatch, tmp_path):

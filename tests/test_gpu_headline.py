@@ -127,6 +127,58 @@ def test_headline_sharded_route_is_bit_identical(capi, bench_mod, headline):
         assert (labels == lab0["labels"]).all() and (mind == lab0["min_dists"]).all(), f"world {world}: labels"
 
 
+def test_brute_tile_step_vs_reference(capi, bench_mod):
+    """BASELINE.json configs[1] names the brute-tile k-NN: one full-size step with every target — both scans and the eight placed
+    models — stored as ONE cell (bench.py --knn brute; every tile streams the whole target through LDS: ~3.4 s), against the
+    reference's fixture: the same bars as the hash-cell layout."""
+    g = load_golden("bench_seed11.npz")
+    w = bench_mod.build_workload(int(g["n_points"]), seed=11, knn="brute")
+    try:
+        out = bench_mod.run_step(w, None, False)
+        d = np.linalg.norm(np.asarray(out["T"], np.float64) - g["icp_pose"].astype(np.float64))
+        print(f"brute-tile step: pose {d:.3e} from the reference, scores max abs {np.abs(out['scores'].astype(np.float64) - g['scores']).max():.2e}")
+        assert d < POSE_TOL and np.abs(out["scores"].astype(np.float64) - g["scores"].astype(np.float64)).max() < SCORE_TOL
+        assert (out["labels"] == g["labels"]).all() and sha(out["min_dists"]) == str(g["min_dists_sha"])
+    finally:
+        _close_workload(w)
+
+
+def test_strong_scaling_split_is_bit_identical(capi, bench_mod, headline):
+    """bench.py --scaling strong: ONE fixed scene — 8 per-placement ICP problems (model -> scan, lib/rs/rs_database.h:220-230),
+    256 score poses, 8 placements — sharded over a simulated world of 1, 2, 3 and 8 ranks on this device (every rank's send
+    buffer computed in turn, concatenated as the all-gather would, folded): every split returns the bits of the unsharded
+    entry points."""
+    import torch
+    from rescan_amd import dist as rd
+    w, g = headline
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    n_plc = bench_mod.N_PLACEMENTS
+    plc = w["plc"][:n_plc]
+    order, _, radii = rd.arrangement_plan([0] * n_plc, [p["cls"] for p in plc], 0.05)
+    si = w["strong_icp"]
+    units = dict(icp=([p["cloud"] for p in plc], w["scan1"], si["T0s"], si["max_dist"], si["max_angle"], bench_mod.ICP_ITERS),
+                 score=(w["obj_score"], w["scan1"], w["score_poses"][:bench_mod.N_POSES], 0.1, 64),
+                 label=(w["scan1"], w["plc_poses"][order], [plc[i]["cloud"] for i in order], radii))
+    ref = [capi.icp_align(plc[k]["cloud"], w["scan1"], si["T0s"][k], I4, si["max_dist"], si["max_angle"], max_iter=bench_mod.ICP_ITERS, fixed_iters=True) for k in range(n_plc)]
+    sc0 = capi.alignment_scores(w["obj_score"], w["scan1"], w["score_poses"][:bench_mod.N_POSES], 0.1, 64)
+    lab0 = capi.arrangement_to_labels(w["scan1"], w["plc_poses"][:n_plc], [p["cloud"] for p in plc], [0] * n_plc, [p["cls"] for p in plc], 0.05, False)
+    for world in (1, 2, 3, 8):
+        lay = rd.ShardLayout(world, n_plc, bench_mod.N_POSES, n_plc, w["n_scan1"])
+        recv = torch.zeros(world * lay.words, dtype=torch.float32, device=dev)
+        for rank in range(world):
+            send = recv[rank * lay.words:(rank + 1) * lay.words]
+            small = torch.zeros(lay.small_words, dtype=torch.float32)
+            rd.shard_compute(capi, lay, rank, units, send, small)
+            rd.shard_publish(lay, send, small)
+        torch.cuda.synchronize()
+        errs, Ts, its, scores, labels, mind = rd.shard_fold(capi, lay, recv, scene=w["scan1"])
+        for k in range(n_plc):
+            assert (Ts[k] == ref[k][1]).all() and errs[k] == np.float32(ref[k][0]) and its[k] == ref[k][2], f"world {world}: ICP problem {k}"
+        assert (scores == sc0).all(), f"world {world}: scores"
+        assert (labels == lab0["labels"]).all() and (mind == lab0["min_dists"]).all(), f"world {world}: labels"
+
+
 MORE_SEEDS = list(range(31, 39))
 
 

@@ -715,7 +715,10 @@ def test_cu_masked_stream_keeps_to_its_cus_and_changes_no_result(capi):
     ref = key(run())
 
     def placement():
-        xcc, se, sh, cu = capi.probe_placement(8192)
+        import os, sys
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+        import benchaux
+        xcc, se, sh, cu = benchaux.probe_placement(8192)
         return set(zip(xcc.tolist(), se.tolist(), sh.tolist(), cu.tolist()))
 
     with ThreadPoolExecutor(max_workers=1) as pool:                 # (the mask belongs to the calling thread's stream)

@@ -6,13 +6,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch; torch.cuda.init()
 from rescan_amd import capi
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import benchaux
 capi.init(0)
 n_cu = torch.cuda.get_device_properties(0).multi_processor_count
 
 
 def show(name, bits):
     capi.stream_cu_mask(bits)
-    xcc, se, sh, cu = capi.probe_placement(8192)
+    xcc, se, sh, cu = benchaux.probe_placement(8192)
     print(f"{name}: {int(sum(bits))} bits set", flush=True)
     for x in sorted(set(xcc.tolist())):
         sel = xcc == x
