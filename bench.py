@@ -462,7 +462,9 @@ class Sharded:
         self.w, self.dist, self.dev, self.rank, self.world = w, dist, dev, rank, world
         n_plc = len(w["plc"])
         n_icp = N_PLACEMENTS if strong else len(w["icp_T0s"])
-        self.lay = rd.ShardLayout(world, n_icp, len(w["score_poses"]), n_plc, w["n_scan1"])
+        # every rank sends the (min_dist, label) partial of its own run of the sorted arrangement (5 B per scene point) instead of its unary
+        # rows (4 B per point and placement: 31 MB per rank at 8 placements); RS_BENCH_PREFOLD=0 sends the rows.  Same bits either way.
+        self.lay = rd.ShardLayout(world, n_icp, len(w["score_poses"]), n_plc, w["n_scan1"], prefold=os.environ.get("RS_BENCH_PREFOLD", "1") != "0")
         order, _, radii = rd.arrangement_plan([0] * n_plc, [p["cls"] for p in w["plc"]], 0.05)
         self.order = order
         si = w["strong_icp"]
@@ -804,6 +806,11 @@ def main():
 
     pairs_unit = sum(w["pairs"].values())
     pairs_total = float(pairs_unit * args.steps * (world if not sharded else units))
+    if dist is not None and not sharded:
+        # --replicas: every rank has its own scene (its own seed, its own point counts): the pairs of all ranks, summed
+        tp = torch.tensor([float(pairs_unit * args.steps)], device=dev if dist.get_backend() != "gloo" else "cpu", dtype=torch.float64)
+        dist.all_reduce(tp, op=dist.ReduceOp.SUM)
+        pairs_total = float(tp.item())
     if dist is not None:
         t = torch.tensor([elapsed], device=dev if dist.get_backend() != "gloo" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -831,7 +838,8 @@ def main():
             avg = (ms_k / max(1, n_k)) * 1e-3
             by_kernel[k] = {"avg_launch_ms": avg * 1e3, "launches": n_k, "alg_bytes_per_launch": alg_bytes[k], "cu_share": shares.get(k, 1.0),
                             "achieved_GBs": alg_bytes[k] / avg / 1e9 if avg > 0 else 0.0, "frac": (alg_bytes[k] / avg / 1e9 / HBM_PEAK_GBS) if avg > 0 else 0.0}
-        dom = max(per_step, key=lambda k: per_step[k] * shares.get(k, 1.0))
+        dom = max(per_step, key=lambda k: per_step[k])              # the kernel that takes the most TIME per step (its CU share is reported next to it)
+        dom_by_cu_time = max(per_step, key=lambda k: per_step[k] * shares.get(k, 1.0))
         n_l, ms = prof[dom]
         bytes_launch = alg_bytes[dom]
         avg_s = (ms / max(1, n_l)) * 1e-3
@@ -859,7 +867,7 @@ def main():
                        "n_scan0": w["n_scan0"], "n_scan1": w["n_scan1"], "n_obj": w["n_obj"],
                        "pairs_per_step": pairs_unit * (units if sharded else world), "pairs_split_per_unit": w["pairs"],
                        "issue": ("3 host threads / 3 HIP streams (ICP chain | score batch | label pass); CU partition: " + cu_partition_note()) if conc else "serial",
-                       "exchange": ("one all_gather of the per-rank send buffers (poses, errors, scores, per-placement rows: %.1f MB per rank) per step, "
+                       "exchange": ("one all_gather of the per-rank send buffers (poses, errors, scores, " + ("the rank's (min_dist, label) partial of its own run" if sh.lay.prefold else "per-placement rows") + ": %.1f MB per rank) per step, "
                                     "overlapped with the next step; ordered fold of the rows on the device; on the exchange thread: publish + all_gather %.3f ms, "
                                     "fold + download of poses / scores / labels %.3f ms per step; main thread: compute %.3f ms, waiting for the previous exchange %.3f ms per step"
                                     % (sh.lay.words * 4 / 1e6, sh.t_gather / max(1, sh.n_exchanges) * 1e3, sh.t_fold / max(1, sh.n_exchanges) * 1e3,
@@ -868,7 +876,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                          "avg_launch_ms": ms / max(1, n_l), "launches": n_l, "alg_bytes_per_launch": bytes_launch,
-                         "dominant_by": "time per step x share of the CUs the kernel's stream is confined to", "cu_share": shares.get(dom, 1.0)},
+                         "dominant_by": "time per step", "cu_share": shares.get(dom, 1.0),
+                         "note": "achieved / frac compare a kernel confined to cu_share of the CUs with the whole chip's peak; roofline_by_kernel has every domain",
+                         "dominant_by_cu_time": dom_by_cu_time},
             "roofline_by_kernel": by_kernel,
             "parity": parity_block(out, args.points, seed, args.knn, units, strong),
             "ms_per_step_spread": {"min": float(step_ms.min()), "median": float(np.median(step_ms)), "max": float(step_ms.max()),

@@ -49,6 +49,9 @@ SIGNATURES = {
     "rs_hip_assign_labels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, i8p, f32p]),
     "rs_hip_label_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int]),
     "rs_hip_combine_label_rows": (None, [f32p, C.c_int32, C.c_int64, C.c_int32, i8p, f32p]),
+    "rs_hip_label_partial_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "rs_hip_fold_label_partials_device": (C.c_int, [C.c_void_p, np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS"), np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS"),
+                                                    C.c_int32, C.c_int64, i8p, f32p, C.c_void_p]),
     "rs_hip_fold_label_rows_device": (C.c_int, [C.c_void_p, np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS"), C.c_int32,
                                                 C.c_int64, C.c_int32, i8p, f32p, C.c_int32, C.c_void_p]),
     "rs_hip_arrangement_to_labels": (C.c_int, [C.c_void_p, f32p, C.c_void_p, i32p, i32p, C.c_int32, C.c_float,
@@ -320,6 +323,22 @@ def label_rows(scene, poses, objects, radii, out_device_ptr=None, query_order=Fa
     rows = np.zeros((n, scene.n), np.float32)
     _check(load().rs_hip_label_rows(scene.handle, C.addressof(arr), n, rows.ctypes.data_as(C.c_void_p), 0))
     return rows
+
+
+def label_partial_device(scene, poses, objects, radii, label_base, min_dists_ptr, labels_ptr):
+    """The (min_dist, label) partial of a contiguous run of the sorted arrangement, written to device memory (query order)."""
+    arr = _placements(poses, objects, radii)
+    _check(load().rs_hip_label_partial_device(scene.handle, C.addressof(arr), len(objects), int(label_base), C.c_void_p(min_dists_ptr), C.c_void_p(labels_ptr)))
+
+
+def fold_label_partials_device(base_ptr, min_offsets, label_offsets, scene_n, labels=None, min_dists=None, query_order_of=None):
+    """Ordered fold of gathered per-rank partials (min_dists at base + 4*min_offsets[r], int8 labels at base + label_offsets[r])."""
+    mo = np.ascontiguousarray(min_offsets, np.int64); lo = np.ascontiguousarray(label_offsets, np.int64)
+    if labels is None or min_dists is None:
+        labels = np.empty(int(scene_n), np.int8); min_dists = np.empty(int(scene_n), np.float32)
+    _check(load().rs_hip_fold_label_partials_device(C.c_void_p(base_ptr), mo, lo, len(mo), int(scene_n), labels, min_dists,
+                                                    query_order_of.handle if query_order_of is not None else None))
+    return labels, min_dists
 
 
 def combine_label_rows(rows, labels, min_dists, label_base=0):

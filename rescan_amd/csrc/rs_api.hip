@@ -1290,6 +1290,47 @@ int rs_hip_label_rows( const rs_hip_cloud_t* scene, const rs_hip_placement_t* pl
   return RS_HIP_OK;
 }
 
+int rs_hip_label_partial_device( const rs_hip_cloud_t* scene, const rs_hip_placement_t* placements, int32_t n, int32_t label_base,
+                                 float* min_dists_device, int8_t* labels_device )
+{
+  int rc = ensure_ready(); if( rc ) return rc;
+  if( !scene || ( n > 0 && !scene->has_nor ) || !min_dists_device || !labels_device || n < 0 || ( n > 0 && !placements ) ) { set_err( "label_partial_device: bad arguments" ); return RS_HIP_E_ARG; }
+  if( label_base + n > 127 ) { set_err( "label_partial_device: more than 127 placements do not fit the reference's int8 labels" ); return RS_HIP_E_CAPACITY; }
+  if( scene->n == 0 ) return RS_HIP_OK;
+  if( n > 0 && ( rc = label_upload_placements( placements, n ) ) ) return rc;
+  // the placement loop over this run, from the loop's initial state, its running (min_dist, label) written where the caller wants
+  // them — in the scene cloud's query order, the order the kernel works in
+  LabelLaunch L{};
+  L.scene = scene->qview; L.pl = g_ws.plc.as<PlacementDev>(); L.n_pl = n;
+  L.label_base = label_base; L.gate_tmin = label_gate_threshold(); L.labels = labels_device; L.min_d = min_dists_device; L.rows = nullptr; L.fresh = 1;
+  { ProfScope ps( "nn_label" ); launch_label( L, g_stream ); }
+  return RS_HIP_OK;
+}
+
+int rs_hip_fold_label_partials_device( const float* base_device, const int64_t* min_offsets, const int64_t* label_offsets, int32_t n_parts, int64_t scene_n,
+                                       int8_t* labels, float* min_dists, const rs_hip_cloud_t* in_query_order_of )
+{
+  int rc = ensure_ready(); if( rc ) return rc;
+  if( n_parts < 0 || scene_n < 0 || !labels || !min_dists || ( n_parts > 0 && ( !base_device || !min_offsets || !label_offsets ) ) ) { set_err( "fold_label_partials_device: bad arguments" ); return RS_HIP_E_ARG; }
+  const rs_hip_cloud_t* qc = in_query_order_of;
+  if( qc && qc->n != scene_n ) { set_err( "fold_label_partials_device: the cloud has %d points, the partials %lld", qc->n, (long long)scene_n ); return RS_HIP_E_ARG; }
+  if( scene_n == 0 ) return RS_HIP_OK;
+  const size_t ns = (size_t)scene_n;
+  if( ( rc = g_ws.labels.ensure( ns ) ) || ( rc = g_ws.mind.ensure( ns * 4 ) ) || ( rc = g_ws.fold_off.ensure( (size_t)std::max( 1, n_parts ) * 16 ) ) ) return rc;
+  std::vector<int64_t> off( (size_t)std::max( 1, n_parts ) * 2 );
+  for( int r = 0; r < n_parts; ++r ) { off[r] = min_offsets[r]; off[(size_t)n_parts + r] = label_offsets[r]; }
+  HIP_TRY( hipMemcpyAsync( g_ws.fold_off.p, off.data(), (size_t)std::max( 1, n_parts ) * 16, hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );          // (off is a local)
+  { ProfScope ps( "label_fold" );
+    launch_label_fold_partials( base_device, g_ws.fold_off.as<long long>(), g_ws.fold_off.as<long long>() + n_parts, n_parts, (long long)scene_n,
+                                g_ws.labels.as<int8_t>(), g_ws.mind.as<float>(), g_stream ); }
+  if( qc ) return label_state_download( qc, labels, min_dists );
+  HIP_TRY( hipMemcpyAsync( labels, g_ws.labels.p, ns, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipMemcpyAsync( min_dists, g_ws.mind.p, ns * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
+  return RS_HIP_OK;
+}
+
 void rs_hip_combine_label_rows( const float* rows, int32_t n_rows, int64_t scene_n, int32_t label_base,
                                 int8_t* labels, float* min_dists )
 {

@@ -213,6 +213,8 @@ void launch_label_ids_to_input_order( const int* by_orig, long long n, const int
 void launch_gather_words( const uint32_t* src, const int* idx, long long count, int words, uint32_t* dst, hipStream_t st );
 // ordered fold of device-resident rows (row k at rows + offsets[k], n floats each; offsets is a device array)
 void launch_label_fold( const float* rows, const long long* offsets, int n_rows, long long n, int label_base, int8_t* labels, float* min_d, bool fresh, hipStream_t st );
+// ordered fold of per-rank partials (min_dists at base + min_off[r] floats, int8 labels at (int8*)base + lab_off[r] bytes; device arrays of offsets)
+void launch_label_fold_partials( const float* base, const long long* min_off, const long long* lab_off, int n_parts, long long n, int8_t* labels, float* min_d, hipStream_t st );
 
 struct RowsLaunch
 {

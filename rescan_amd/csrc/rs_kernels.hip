@@ -3451,6 +3451,26 @@ __global__ __launch_bounds__( BLOCK ) void k_label_fold( const float* rows, cons
   }
   min_d[j] = best; labels[j] = (int8_t)label;
 }
+// The same over per-RANK partials of the loop — rank r's (min_dist, label) after its own contiguous run of the sorted arrangement,
+// labels already carrying the run's base — folded in rank order with the same strict `<`: a later run only takes a point it is
+// strictly closer to, exactly as the sequential loop would have.
+__global__ __launch_bounds__( BLOCK ) void k_label_fold_partials( const float* base, const long long* min_off, const long long* lab_off, int n_parts, long long n,
+                                                                  int8_t* labels, float* min_d )
+{
+  const long long j = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if( j >= n ) return;
+  float best = 1e9f; int label = 0;                                            // :799-802,820
+  for( int r = 0; r < n_parts; ++r )
+  {
+    const float v = base[min_off[r] + j];
+    if( v < best ) { best = v; label = reinterpret_cast<const int8_t*>( base )[lab_off[r] + j]; }
+  }
+  min_d[j] = best; labels[j] = (int8_t)label;
+}
+void launch_label_fold_partials( const float* base, const long long* min_off, const long long* lab_off, int n_parts, long long n, int8_t* labels, float* min_d, hipStream_t st )
+{
+  hipLaunchKernelGGL( k_label_fold_partials, dim3( (unsigned)( ( n + BLOCK - 1 ) / BLOCK ) ), dim3( BLOCK ), 0, st, base, min_off, lab_off, n_parts, n, labels, min_d );
+}
 void launch_label_fold( const float* rows, const long long* offsets, int n_rows, long long n, int label_base, int8_t* labels, float* min_d, bool fresh, hipStream_t st )
 {
   hipLaunchKernelGGL( k_label_fold, dim3( (unsigned)( ( n + BLOCK - 1 ) / BLOCK ) ), dim3( BLOCK ), 0, st, rows, offsets, n_rows, n, label_base, labels, min_d, fresh );

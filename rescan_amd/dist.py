@@ -117,14 +117,17 @@ class ShardLayout:
          [ icp: n_icp_max x 18 (pose 16, err, iterations) | scores: n_score_max | rows: n_plc_max x n_scene ]
     n_*_max = the largest slice any rank owns, so the all-gather is one fixed-size collective."""
 
-    def __init__(self, world, n_icp, n_score, n_plc, n_scene):
+    def __init__(self, world, n_icp, n_score, n_plc, n_scene, prefold=False):
         self.world, self.n_icp, self.n_score, self.n_plc, self.n_scene = int(world), int(n_icp), int(n_score), int(n_plc), int(n_scene)
         cap = lambda n: max(shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world))  # noqa: E731
         self.icp_cap, self.score_cap, self.plc_cap = cap(n_icp), cap(n_score), cap(n_plc)
         self.off_icp = 0
         self.off_score = self.off_icp + 18 * self.icp_cap
         self.off_rows = (self.off_score + self.score_cap + 63) // 64 * 64          # rows start 256-byte aligned
-        self.words = self.off_rows + self.plc_cap * self.n_scene
+        # prefold: instead of one row per placement, the rank's PARTIAL of the loop over its own run — min_dists float32[n_scene],
+        # then labels int8[n_scene] — 5 bytes per scene point whatever the number of placements (rs_hip_label_partial_device)
+        self.prefold = bool(prefold)
+        self.words = self.off_rows + ((self.n_scene + (self.n_scene + 3) // 4 + 63) // 64 * 64 if self.prefold else self.plc_cap * self.n_scene)
         self.small_words = self.off_rows
 
     def slices(self, rank):
@@ -163,7 +166,12 @@ def shard_compute(capi, lay, rank, units, send, small_host, threads=None):
             sh[lay.off_score: lay.off_score + (s1 - s0)] = capi.alignment_scores(obj, scn, poses[s0:s1], radius, K)
 
     def label():
-        if p1 > p0:
+        if lay.prefold:
+            # (every rank sends a partial, an empty run's being the loop's initial state)
+            base = send.data_ptr() + 4 * lay.off_rows
+            capi.label_partial_device(lscene, lposes[p0:p1], lclouds[p0:p1], lradii[p0:p1], p0, base, base + 4 * lay.n_scene)
+            capi.synchronize()
+        elif p1 > p0:
             # rows in the scene cloud's query order: what the kernel writes (coalesced); every rank builds the same cloud from
             # the same scene, so the gathered rows share that order and shard_fold hands the cloud to the fold
             capi.label_rows(lscene, lposes[p0:p1], lclouds[p0:p1], lradii[p0:p1], out_device_ptr=send.data_ptr() + 4 * lay.off_rows, query_order=True)
@@ -199,6 +207,11 @@ def shard_fold(capi, lay, recv, out=None, scene=None):
         Ts.append(blk[:, :16]); errs.append(blk[:, 16]); its.append(blk[:, 17].astype(np.int32))
         scores.append(small[r, lay.off_score: lay.off_score + (s1 - s0)])
         offsets += [r * W + lay.off_rows + k * lay.n_scene for k in range(p1 - p0)]
+    if lay.prefold:
+        mo = [r * W + lay.off_rows for r in range(lay.world)]
+        lo = [4 * (r * W + lay.off_rows + lay.n_scene) for r in range(lay.world)]
+        labels, mind = capi.fold_label_partials_device(recv.data_ptr(), mo, lo, lay.n_scene, *(out if out is not None else (None, None)), query_order_of=scene)
+        return (np.concatenate(errs), np.concatenate(Ts).copy(), np.concatenate(its), np.concatenate(scores), labels, mind)
     # from (0, 1e9): rs_pointcloud_filters.cpp:799-802,820; out = (labels int8[n_scene], min_dists float32[n_scene]) to receive the result
     # scene: the Cloud in whose query order shard_compute wrote the rows
     labels, mind = capi.fold_label_rows_device(recv.data_ptr(), offsets, lay.n_scene, *(out if out is not None else (None, None)), fresh=True,

@@ -163,8 +163,9 @@ def test_strong_scaling_split_is_bit_identical(capi, bench_mod, headline):
     ref = [capi.icp_align(plc[k]["cloud"], w["scan1"], si["T0s"][k], I4, si["max_dist"], si["max_angle"], max_iter=bench_mod.ICP_ITERS, fixed_iters=True) for k in range(n_plc)]
     sc0 = capi.alignment_scores(w["obj_score"], w["scan1"], w["score_poses"][:bench_mod.N_POSES], 0.1, 64)
     lab0 = capi.arrangement_to_labels(w["scan1"], w["plc_poses"][:n_plc], [p["cloud"] for p in plc], [0] * n_plc, [p["cls"] for p in plc], 0.05, False)
-    for world in (1, 2, 3, 8):
-        lay = rd.ShardLayout(world, n_plc, bench_mod.N_POSES, n_plc, w["n_scan1"])
+    for world, prefold in ((1, False), (2, False), (3, False), (8, False), (1, True), (3, True), (8, True), (12, True)):
+        # (prefold: every rank sends the partial of its own run — 5 B per scene point — instead of its rows; 12 ranks: some without a placement)
+        lay = rd.ShardLayout(world, n_plc, bench_mod.N_POSES, n_plc, w["n_scan1"], prefold=prefold)
         recv = torch.zeros(world * lay.words, dtype=torch.float32, device=dev)
         for rank in range(world):
             send = recv[rank * lay.words:(rank + 1) * lay.words]
@@ -176,7 +177,7 @@ def test_strong_scaling_split_is_bit_identical(capi, bench_mod, headline):
         for k in range(n_plc):
             assert (Ts[k] == ref[k][1]).all() and errs[k] == np.float32(ref[k][0]) and its[k] == ref[k][2], f"world {world}: ICP problem {k}"
         assert (scores == sc0).all(), f"world {world}: scores"
-        assert (labels == lab0["labels"]).all() and (mind == lab0["min_dists"]).all(), f"world {world}: labels"
+        assert (labels == lab0["labels"]).all() and (mind == lab0["min_dists"]).all(), f"world {world} prefold {prefold}: labels"
 
 
 MORE_SEEDS = list(range(31, 39))
