@@ -272,7 +272,10 @@ def _roles():
         from rescan_amd import capi
         import torch
         n_cu = int(torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count)
-        split = float(os.environ.get("RS_BENCH_CU_SPLIT", "0.625" if n_cu == 256 else "0"))
+        # (round 3: 0.75 — 6 + 2 CUs of every shader engine.  With the reference's centroid chains the ICP chain is the longer side by a
+        #  millisecond (3.25 ms against a 1.97 ms score batch at 5 + 3), so it gets the sixth CU: 3.03 ms, the batch 2.85 ms; at 7 + 1 the
+        #  batch would take 5.7 ms — profiles/r03/ab_cu_split.txt)
+        split = float(os.environ.get("RS_BENCH_CU_SPLIT", "0.75" if n_cu == 256 else "0"))
         # spinning threads need their cores: 3 busy threads per rank; a container whose CPU quota does not cover that for all the
         # node's ranks would be throttled (every thread of the cgroup stalls for the rest of the 100 ms period)
         st = host_cpu_stat()
