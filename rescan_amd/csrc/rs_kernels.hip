@@ -2630,9 +2630,10 @@ void launch_icp_exact_centroids( const IcpLaunch& L, const ReplayBufs& B, hipStr
 //   the searches    leave one 64-byte record per source point at the point's ORIGINAL index (icp_emit);
 //   k_chain_moments the fp64 moments of k_icp_moments, read from those records in the reference's order, + the fp64 sums of the
 //                   seven chains' addends per segment of 64 points and per block of 64 segments;
-//   k_chain_records the fp64 prefix at a segment's start is a guess of the running sum there — good enough for its EXPONENT (the
-//                   fp32 chain itself drifts by parts in a thousand; records are made for e-1, e, e+1): one record per
-//                   (segment, chain), and the block's 64 composed;
+//   k_chain_guess   the fp64 prefix at a segment's start is a guess of the running sum there — good enough for its EXPONENT (the
+//                   fp32 chain itself drifts by parts in a thousand; records are made for e-1, e, e+1); made every 8th
+//                   iteration and kept in between (then nothing below waits for the moments);
+//   k_chain_segrecs one record per (segment, chain);  k_chain_compose: a block's 64 composed;
 //   k_chain_walk    one wave per chain walks the blocks with the exact value: a wave-wide scan composes 64 block records at a
 //                   time and finds the first one the value does not fit; that block is walked by its segments the same way, the
 //                   segment that does not fit is added up addend by addend;
@@ -2806,123 +2807,115 @@ __device__ __forceinline__ ChainFn chain_prefix( const ChainFn& f, int lane )
   return g;
 }
 
-// One workgroup per block of 64 segments.  The guesses: every chain's fp64 prefix at each of the block's segments (the blocks
-// before from the block sums, then a scan of the block's own 64 segment sums).  The records: a wave stages THREE segments' addends
-// in LDS (lane = point), then lane = (segment, exponent class, chain) runs down its segment's 64 addends in integers — no cross-lane
-// traffic, 63 records at once.  Then the block's 64 segments composed per chain and exponent.
-#define CHAIN_REC_WAVES 8
-#define CHAIN_REC_TASK 3          // segments per wave and round
-__global__ __launch_bounds__( CHAIN_REC_WAVES * WAVE ) void k_chain_records( IcpLaunch L, ChainBufs B )
+// The guesses (refresh iterations): every chain's fp64 prefix at each segment's start — the quarter blocks before from their sums,
+// then a scan of the block's own 64 segment sums — kept as exponent | sign << 8 per (chain, segment).  One workgroup per block.
+__global__ __launch_bounds__( CH_ROWS * WAVE ) void k_chain_guess( IcpLaunch L, ChainBufs B )
 {
-  __shared__ ChainRec s_rec[CH_ROWS][CH_BLK];
-  __shared__ float s_x[CHAIN_REC_WAVES][CHAIN_REC_TASK][CH_ROWS][CH_SEG];
-  __shared__ unsigned long long s_stat[WAVES_PER_BLOCK][3];
   const int prob = blockIdx.y, blk = blockIdx.x;
   if( L.active[prob] == 0 ) return;
+  const int lane = threadIdx.x & ( WAVE - 1 ), r = threadIdx.x / WAVE;
+  const double* bsum = B.blksum + ( (size_t)prob * CH_ROWS + r ) * ( B.n_blk * CH_QUARTERS );
+  double before = 0.0;
+  for( int b = lane; b < blk * CH_QUARTERS; b += WAVE ) before += bsum[b];
+  before = wave_sum( before );
+  const int seg = blk * CH_BLK + lane;
+  const double v = seg < B.n_seg ? B.segsum[( (size_t)prob * CH_ROWS + r ) * B.n_seg + seg] : 0.0;
+  double incl = v;
+#pragma unroll
+  for( int d = 1; d < WAVE; d <<= 1 ) { const double up = __shfl_up( incl, d ); if( lane >= d ) incl += up; }
+  const uint32_t gb = __float_as_uint( (float)( before + ( incl - v ) ) );
+  if( seg < B.n_seg ) B.guess[( (size_t)prob * CH_ROWS + r ) * B.n_seg + seg] = (int)( ( ( gb >> 23 ) & 255u ) | ( ( gb >> 31 ) << 8 ) );
+}
+
+// The segment records: a wave stages THREE consecutive segments' addends in LDS (lane = point), then lane = (segment, exponent
+// class, chain) runs down its segment's 64 addends in integers — no cross-lane traffic, 63 records at once.  The guesses are the
+// kept ones (k_chain_guess): between two ICP iterations the sums move by a few per cent at most (the radius shrinks by 5 %, a per
+// cent of the correspondences change), far less than the factor of two a record's three exponents cover.
+#define CHAIN_REC_TASK 3          // segments per wave
+__global__ __launch_bounds__( BLOCK ) void k_chain_segrecs( IcpLaunch L, ChainBufs B )
+{
+  __shared__ float s_x[WAVES_PER_BLOCK][CHAIN_REC_TASK][CH_ROWS][CH_SEG];
+  __shared__ unsigned long long s_stat[WAVES_PER_BLOCK][3];
+  const int prob = blockIdx.y;
+  if( L.active[prob] == 0 ) return;
+  const int lane = threadIdx.x & ( WAVE - 1 ), wib = threadIdx.x / WAVE;
+  const int task = blockIdx.x * WAVES_PER_BLOCK + wib, seg0 = task * CHAIN_REC_TASK;
+  const float4* R = L.rec + (size_t)prob * L.src.n * 4;
+  float4 A[CHAIN_REC_TASK], Q[CHAIN_REC_TASK];
+#pragma unroll
+  for( int q = 0; q < CHAIN_REC_TASK; ++q )               // (the loads first: the cut's reduction below runs while they are in flight)
+  {
+    const int i = ( seg0 + q ) * CH_SEG + lane;
+    A[q] = make_float4( 0.0f, 0.0f, 0.0f, -1.0f ); Q[q] = make_float4( 0.0f, 0.0f, 0.0f, 0.0f );
+    if( seg0 + q < B.n_seg && i < L.src.n ) { A[q] = R[(size_t)i * 4]; Q[q] = R[(size_t)i * 4 + 1]; }
+  }
   const float sd = chain_stats( L, prob, s_stat, nullptr );                  // (its own: in the iterations that keep their guesses this kernel runs BEFORE the moments)
   ChainPar P; P.use_sd = sd > 0.000001; P.cut = 2.5f * sd; P.max_dist = L.radius;
-  const int lane = threadIdx.x & ( WAVE - 1 ), wib = threadIdx.x / WAVE;
-  const float4* R = L.rec + (size_t)prob * L.src.n * 4;
-  if( wib < CH_ROWS && !B.refresh )
-  {
-    // The guesses of the last refresh serve again: between two ICP iterations the sums move by a few per cent at most (the radius
-    // shrinks by 5 %, a per cent of the correspondences change), far less than the factor of two a record's three exponents cover.
-    const int seg = blk * CH_BLK + lane;
-    s_rec[wib][lane].e_sign = seg < B.n_seg ? B.guess[( (size_t)prob * CH_ROWS + wib ) * B.n_seg + seg] : -1;
-  }
-  if( wib < CH_ROWS && B.refresh )
-  {
-    const int r = wib;
-    const double* bsum = B.blksum + ( (size_t)prob * CH_ROWS + r ) * ( B.n_blk * CH_QUARTERS );
-    double before = 0.0;
-    for( int b = lane; b < blk * CH_QUARTERS; b += WAVE ) before += bsum[b];
-    before = wave_sum( before );
-    const int seg = blk * CH_BLK + lane;
-    const double v = seg < B.n_seg ? B.segsum[( (size_t)prob * CH_ROWS + r ) * B.n_seg + seg] : 0.0;
-    double incl = v;
 #pragma unroll
-    for( int d = 1; d < WAVE; d <<= 1 ) { const double up = __shfl_up( incl, d ); if( lane >= d ) incl += up; }
-    const uint32_t gb = __float_as_uint( (float)( before + ( incl - v ) ) );
-    const int es = seg < B.n_seg ? (int)( ( ( gb >> 23 ) & 255u ) | ( ( gb >> 31 ) << 8 ) ) : -1;
-    s_rec[r][lane].e_sign = es;
-    if( seg < B.n_seg ) B.guess[( (size_t)prob * CH_ROWS + r ) * B.n_seg + seg] = es;
-  }
-  __syncthreads();
-  constexpr int N_TASKS = ( CH_BLK + CHAIN_REC_TASK - 1 ) / CHAIN_REC_TASK;
-  for( int task = wib; task < N_TASKS; task += CHAIN_REC_WAVES )
+  for( int q = 0; q < CHAIN_REC_TASK; ++q )
   {
-    float4 A[CHAIN_REC_TASK], Q[CHAIN_REC_TASK];
+    float x[CH_ROWS], w;
+    chain_addends( A[q], Q[q], P, x, w );
+    const int seg = seg0 + q;
 #pragma unroll
-    for( int q = 0; q < CHAIN_REC_TASK; ++q )
+    for( int r = 0; r < CH_ROWS; ++r )
     {
-      const int sb = task * CHAIN_REC_TASK + q, i = ( blk * CH_BLK + sb ) * CH_SEG + lane;
-      A[q] = make_float4( 0.0f, 0.0f, 0.0f, -1.0f ); Q[q] = make_float4( 0.0f, 0.0f, 0.0f, 0.0f );
-      if( sb < CH_BLK && i < L.src.n ) { A[q] = R[(size_t)i * 4]; Q[q] = R[(size_t)i * 4 + 1]; }
+      s_x[wib][q][r][lane] = x[r];
+      // block 0's addends also go to memory: the walks serve that block from LDS (k_chain_walk)
+      if( seg < CH_BLK ) B.x0[( (size_t)prob * CH_ROWS + r ) * ( CH_BLK * CH_SEG ) + seg * CH_SEG + lane] = x[r];
     }
-#pragma unroll
-    for( int q = 0; q < CHAIN_REC_TASK; ++q )
-    {
-      float x[CH_ROWS], w;
-      chain_addends( A[q], Q[q], P, x, w );
-      const int sb = task * CHAIN_REC_TASK + q;
-#pragma unroll
-      for( int r = 0; r < CH_ROWS; ++r )
-      {
-        s_x[wib][q][r][lane] = x[r];
-        // block 0's addends also go to memory: the walks serve that block from LDS (k_chain_walk)
-        if( blk == 0 && sb < CH_BLK ) B.x0[( (size_t)prob * CH_ROWS + r ) * ( CH_BLK * CH_SEG ) + sb * CH_SEG + lane] = x[r];
-      }
-    }
-    wave_lds_fence();
-    {
-      const int q = min( lane / ( CH_ROWS * 3 ), CHAIN_REC_TASK - 1 ), combo = lane % ( CH_ROWS * 3 );
-      const int r = combo % CH_ROWS, c = combo / CH_ROWS;
-      const int sb = task * CHAIN_REC_TASK + q;
-      const bool mine = lane < CHAIN_REC_TASK * CH_ROWS * 3 && sb < CH_BLK;
-      const int es = mine ? s_rec[r][sb].e_sign : -1;
-      if( mine && es != -1 )
-      {
-        const int eg = es & 255, sg = es >> 8;
-        const int E = eg - 1 + c;                                            // s = M * 2^(E - 150), M in [2^23, 2^24)
-        int Pj = 0, pmin = 0, pmax = 0;                                      // partial sums, the start included
-        bool bad = E < 1 || E > 254;
-        const float* xs = &s_x[wib][q][r][0];
+  }
+  wave_lds_fence();
+  const int q = lane / ( CH_ROWS * 3 ), combo = lane % ( CH_ROWS * 3 );
+  const int r = combo % CH_ROWS, c = combo / CH_ROWS;
+  const int seg = seg0 + q;
+  if( q >= CHAIN_REC_TASK || seg >= B.n_seg ) return;
+  const int es = B.guess[( (size_t)prob * CH_ROWS + r ) * B.n_seg + seg];
+  const int eg = es & 255, sg = es >> 8;
+  const int E = eg - 1 + c;                                            // s = M * 2^(E - 150), M in [2^23, 2^24)
+  int Pj = 0, pmin = 0, pmax = 0;                                      // partial sums, the start included
+  bool bad = E < 1 || E > 254;
+  const float* xs = &s_x[wib][q][r][0];
 #pragma unroll 8
-        for( int j = 0; j < CH_SEG; ++j )
-        {
-          const float xv = xs[j];
-          const float y = ldexpf( sg ? -xv : xv, 150 - E );                  // x / ulp( s ): exact (a power of two), or 0 / inf at the ends; the chain of |s| for negative s
-          const float rn = rintf( y );                                       // to nearest, ties to even
-          bad |= !( fabsf( y ) < 8388608.0f ) | ( fabsf( y - rn ) == 0.5f );  // too big for this binade (or NaN), or a tie: M's parity would decide
-          Pj += (int)rn;
-          pmin = min( pmin, Pj ); pmax = max( pmax, Pj );
-        }
-        // every value on the way, the start included, at least one grid step inside the binade: the neighbouring binades' grids
-        // (half / twice as fine) then play no part in any of the roundings
-        long long lo = (long long)CH_M_LO + 1 - pmin, hi = (long long)CH_M_HI - 1 - pmax;
-        lo = lo < CH_M_LO ? CH_M_LO : lo; hi = hi > CH_M_HI ? CH_M_HI : hi;
-        const bool ok = !bad && lo <= hi;
-        ChainRec& out = s_rec[r][sb];
-        out.lo[c] = ok ? (int)lo : CH_M_HI; out.hi[c] = ok ? (int)hi : CH_M_LO; out.D[c] = ok ? Pj : 0;
-      }
-      else if( mine )      // past the end of the cloud: nothing is added
-      { ChainRec& out = s_rec[r][sb]; out.lo[c] = CH_M_LO; out.hi[c] = CH_M_HI; out.D[c] = 0; }
-    }
-    wave_lds_fence();
+  for( int j = 0; j < CH_SEG; ++j )
+  {
+    const float xv = xs[j];
+    const float y = ldexpf( sg ? -xv : xv, 150 - E );                  // x / ulp( s ): exact (a power of two), or 0 / inf at the ends; the chain of |s| for negative s
+    const float rn = rintf( y );                                       // to nearest, ties to even
+    bad |= !( fabsf( y ) < 8388608.0f ) | ( fabsf( y - rn ) == 0.5f );  // too big for this binade (or NaN), or a tie: M's parity would decide
+    Pj += (int)rn;
+    pmin = min( pmin, Pj ); pmax = max( pmax, Pj );
   }
-  __syncthreads();
-  // the segment records to memory (coalesced words), and the block's 64 segments composed per chain and exponent
+  // every value on the way, the start included, at least one grid step inside the binade: the neighbouring binades' grids
+  // (half / twice as fine) then play no part in any of the roundings
+  long long lo = (long long)CH_M_LO + 1 - pmin, hi = (long long)CH_M_HI - 1 - pmax;
+  lo = lo < CH_M_LO ? CH_M_LO : lo; hi = hi > CH_M_HI ? CH_M_HI : hi;
+  const bool ok = !bad && lo <= hi;
+  ChainRec* out = B.seg + ( (size_t)prob * CH_ROWS + r ) * B.n_seg + seg;
+  if( c == 0 ) out->e_sign = es;
+  out->lo[c] = ok ? (int)lo : CH_M_HI; out->hi[c] = ok ? (int)hi : CH_M_LO; out->D[c] = ok ? Pj : 0;
+}
+
+// The block records: a block's 64 segment records composed per chain and exponent (around the block's first guess).
+#define CHAIN_CMP_WAVES 8
+__global__ __launch_bounds__( CHAIN_CMP_WAVES * WAVE ) void k_chain_compose( IcpLaunch L, ChainBufs B )
+{
+  __shared__ ChainRec s_rec[CH_ROWS][CH_BLK];
+  const int prob = blockIdx.y, blk = blockIdx.x;
+  if( L.active[prob] == 0 ) return;
+  const int lane = threadIdx.x & ( WAVE - 1 ), wib = threadIdx.x / WAVE;
   {
     constexpr int WORDS = sizeof( ChainRec ) / 4;
     const int n_here = min( CH_BLK, B.n_seg - blk * CH_BLK );
     for( int r = 0; r < CH_ROWS; ++r )
     {
-      int* dst = reinterpret_cast<int*>( B.seg + ( (size_t)prob * CH_ROWS + r ) * B.n_seg + (size_t)blk * CH_BLK );
-      const int* src = reinterpret_cast<const int*>( &s_rec[r][0] );
-      for( int k = threadIdx.x; k < n_here * WORDS; k += blockDim.x ) dst[k] = src[k];
+      const int* src = reinterpret_cast<const int*>( B.seg + ( (size_t)prob * CH_ROWS + r ) * B.n_seg + (size_t)blk * CH_BLK );
+      int* dst = reinterpret_cast<int*>( &s_rec[r][0] );
+      for( int k = threadIdx.x; k < CH_BLK * WORDS; k += blockDim.x ) dst[k] = k < n_here * WORDS ? src[k] : -1;      // (e_sign -1: past the end of the cloud)
     }
   }
-  for( int job = wib; job < CH_ROWS * 3; job += CHAIN_REC_WAVES )
+  __syncthreads();
+  for( int job = wib; job < CH_ROWS * 3; job += CHAIN_CMP_WAVES )
   {
     const int r = job / 3, c = job % 3;
     const int first = s_rec[r][0].e_sign;
@@ -3113,16 +3106,21 @@ __global__ __launch_bounds__( BLOCK ) void k_chain_walk_and_moments( IcpLaunch L
 
 void launch_icp_chain_centroids( const IcpLaunch& L, const ChainBufs& B, hipStream_t st )
 {
+  const int n_tasks = ( B.n_seg + CHAIN_REC_TASK - 1 ) / CHAIN_REC_TASK;
+  const dim3 rec_grid( ( n_tasks + WAVES_PER_BLOCK - 1 ) / WAVES_PER_BLOCK, L.n_prob );
   if( B.refresh )
   {
     // the guesses anew: this iteration's fp64 sums first
     hipLaunchKernelGGL( k_chain_moments, dim3( B.n_blk * CH_QUARTERS, L.n_prob ), dim3( BLOCK ), 0, st, L, B );         // (L.n_mom_blocks == 4 B.n_blk)
-    hipLaunchKernelGGL( k_chain_records, dim3( B.n_blk, L.n_prob ), dim3( CHAIN_REC_WAVES * WAVE ), 0, st, L, B );
+    hipLaunchKernelGGL( k_chain_guess, dim3( B.n_blk, L.n_prob ), dim3( CH_ROWS * WAVE ), 0, st, L, B );
+    hipLaunchKernelGGL( k_chain_segrecs, rec_grid, dim3( BLOCK ), 0, st, L, B );
+    hipLaunchKernelGGL( k_chain_compose, dim3( B.n_blk, L.n_prob ), dim3( CHAIN_CMP_WAVES * WAVE ), 0, st, L, B );
     hipLaunchKernelGGL( k_chain_walk, dim3( CH_ROWS, L.n_prob ), dim3( WAVE ), 0, st, L, B );
   }
   else
   {
-    hipLaunchKernelGGL( k_chain_records, dim3( B.n_blk, L.n_prob ), dim3( CHAIN_REC_WAVES * WAVE ), 0, st, L, B );
+    hipLaunchKernelGGL( k_chain_segrecs, rec_grid, dim3( BLOCK ), 0, st, L, B );
+    hipLaunchKernelGGL( k_chain_compose, dim3( B.n_blk, L.n_prob ), dim3( CHAIN_CMP_WAVES * WAVE ), 0, st, L, B );
     hipLaunchKernelGGL( k_chain_walk_and_moments, dim3( CH_ROWS + B.n_blk * CH_QUARTERS, L.n_prob ), dim3( BLOCK ), 0, st, L, B );
   }
   hipLaunchKernelGGL( k_icp_update, dim3( L.n_prob ), dim3( UPDATE_WAVES * WAVE ), 0, st, L );                           // (centred on the chains' totals: L.exact_centroids)
