@@ -861,7 +861,7 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
   {
     CB.n_seg = chain_segments( source->n ); CB.n_blk = chain_blocks( source->n );
     const size_t rows = (size_t)n * CH_ROWS;
-    if( ( rc = g_ws.ch_rec.ensure( (size_t)n * (size_t)source->n * 64 ) ) || ( rc = g_ws.ch_segsum.ensure( rows * CB.n_seg * 8 ) ) ||
+    if( ( rc = g_ws.ch_rec.ensure( (size_t)n * (size_t)source->n * REC_F4 * 16 ) ) || ( rc = g_ws.ch_segsum.ensure( rows * CB.n_seg * 8 ) ) ||
         ( rc = g_ws.ch_prefix.ensure( rows * CB.n_blk * 4 * 8 ) ) || ( rc = g_ws.ch_seg.ensure( rows * CB.n_seg * sizeof( ChainRec ) ) ) ||
         ( rc = g_ws.ch_blk.ensure( rows * CB.n_blk * sizeof( ChainRec ) ) ) || ( rc = g_ws.ch_x0.ensure( rows * CH_BLK * CH_SEG * 4 ) ) ||
         ( rc = g_ws.ch_guess.ensure( rows * CB.n_seg * 4 ) ) ) return rc;

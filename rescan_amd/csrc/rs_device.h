@@ -123,15 +123,16 @@ struct IcpLaunch
   // (icp.h:136-148: Σw, Σw·p, Σw·q) as the reference's own sequential fp32 chains — see launch_icp_exact_centroids
   int     exact_centroids;
   const double* centroid_totals;   // n_prob x 3 x ICP_NMOM (ReplayBufs::totals): [ICP_NMOM + 0..6] = the seven chain totals
-  // ... and their fast form (rs_kernels.hip: "grid chains"): every search writes one 64-byte record per source point at the point's
-  // ORIGINAL index — {p.xyz, dist² (< 0: no match)} {q.xyz, dot} {n.xyz, -} {-} — which the estimator's kernels then read in the
+  // ... and their fast form (rs_kernels.hip: "grid chains"): every search writes one 48-byte record per source point at the point's
+  // ORIGINAL index — {p.xyz, dist² (< 0: no match)} {q.xyz, dot} {n.xyz, -} — which the estimator's kernels then read in the
   // reference's own order, coalesced (null: not wanted)
-  float4* rec;                     // n_prob x n x 4
+  float4* rec;                     // n_prob x n x REC_F4
 };
 
 // The seven centroid chains (Σw, Σw·p, Σw·q: icp.h:136-148) as sequential fp32 sums, computed on the integer grid of the
 // running sum's binade (rs_kernels.hip: "grid chains").  Segments of 64 source points (original order), blocks of 64 segments.
 constexpr int CH_ROWS = 7, CH_SEG = 64, CH_BLK = 64;
+constexpr int REC_F4 = 3;        // float4 per correspondence record
 struct ChainRec { int e_sign; int lo[3], hi[3], D[3]; };   // exponent guess | sign << 8; per exponent e-1, e, e+1: the start mantissas it holds for and the advance
 struct ChainBufs
 {

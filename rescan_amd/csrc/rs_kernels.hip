@@ -1377,9 +1377,9 @@ __device__ __forceinline__ void icp_emit( const IcpLaunch& L, int prob, int tile
   if( active ) { L.m_slot[o] = m.found ? m.slot : -1; if( !L.rec ) { L.m_d2[o] = m.d2; L.m_dot[o] = m.dot; } }
   if( active && L.rec )
   {
-    // the correspondence as the estimator wants it, at the source point's ORIGINAL index: one full 64-byte line per point, so the
-    // scattered store is a whole memory transaction (the estimator's kernels then read the reference's order coalesced, instead
-    // of gathering slot / dist² / dot / source / target point / target normal at random: 5 transactions per point)
+    // the correspondence as the estimator wants it, at the source point's ORIGINAL index: three 16-byte stores into one 48-byte
+    // record (the estimator's kernels then read the reference's order coalesced, instead of gathering slot / dist² / dot /
+    // source / target point / target normal at random: 5 transactions per point)
     Xform T1;
 #pragma unroll
     for( int k = 0; k < 16; ++k ) T1.m[k] = L.T1[prob * 16 + k];
@@ -1388,11 +1388,10 @@ __device__ __forceinline__ void icp_emit( const IcpLaunch& L, int prob, int tile
     float4 P = make_float4( 0.0f, 0.0f, 0.0f, 0.0f ), N = P;
     if( m.found ) { P = L.tgt.pos[m.slot]; N = L.tgt.nor[m.slot]; }
     const int orig = __float_as_int( L.src.pos[i].w );
-    float4* R = L.rec + ( (size_t)prob * L.src.n + orig ) * 4;
+    float4* R = L.rec + ( (size_t)prob * L.src.n + orig ) * REC_F4;
     R[0] = make_float4( qx, qy, qz, m.found ? m.d2 : -1.0f );
     R[1] = make_float4( P.x, P.y, P.z, m.dot );
     R[2] = make_float4( N.x, N.y, N.z, 0.0f );
-    R[3] = make_float4( 0.0f, 0.0f, 0.0f, 0.0f );
   }
   if( active && L.cert_r && !skipped )
   {
@@ -2688,7 +2687,7 @@ __device__ __forceinline__ void chain_moments_block( const IcpLaunch& L, const C
   const float sd = chain_stats( L, prob, S.stat, ( qb == 0 && threadIdx.x == 0 ) ? L.res + (size_t)prob * ICP_NRES + ICP_NMOM : nullptr );
   ChainPar P; P.use_sd = sd > 0.000001; P.cut = 2.5f * sd; P.max_dist = L.radius;
   const int lane = threadIdx.x & ( WAVE - 1 ), wib = threadIdx.x / WAVE;
-  const float4* R = L.rec + (size_t)prob * L.src.n * 4;
+  const float4* R = L.rec + (size_t)prob * L.src.n * REC_F4;
 
   double acc[ICP_NMOM], bs[CH_ROWS];
 #pragma unroll
@@ -2702,7 +2701,7 @@ __device__ __forceinline__ void chain_moments_block( const IcpLaunch& L, const C
     if( seg >= B.n_seg ) break;
     const int i = seg * CH_SEG + lane;
     float4 A = make_float4( 0.0f, 0.0f, 0.0f, -1.0f ), Q = make_float4( 0.0f, 0.0f, 0.0f, 0.0f ), N4 = Q;
-    if( i < L.src.n ) { A = R[(size_t)i * 4]; Q = R[(size_t)i * 4 + 1]; N4 = R[(size_t)i * 4 + 2]; }
+    if( i < L.src.n ) { A = R[(size_t)i * REC_F4]; Q = R[(size_t)i * REC_F4 + 1]; N4 = R[(size_t)i * REC_F4 + 2]; }
     float x[CH_ROWS], w;
     chain_addends( A, Q, P, x, w );
     if( B.refresh )
@@ -2840,14 +2839,14 @@ __global__ __launch_bounds__( BLOCK ) void k_chain_segrecs( IcpLaunch L, ChainBu
   if( L.active[prob] == 0 ) return;
   const int lane = threadIdx.x & ( WAVE - 1 ), wib = threadIdx.x / WAVE;
   const int task = blockIdx.x * WAVES_PER_BLOCK + wib, seg0 = task * CHAIN_REC_TASK;
-  const float4* R = L.rec + (size_t)prob * L.src.n * 4;
+  const float4* R = L.rec + (size_t)prob * L.src.n * REC_F4;
   float4 A[CHAIN_REC_TASK], Q[CHAIN_REC_TASK];
 #pragma unroll
   for( int q = 0; q < CHAIN_REC_TASK; ++q )               // (the loads first: the cut's reduction below runs while they are in flight)
   {
     const int i = ( seg0 + q ) * CH_SEG + lane;
     A[q] = make_float4( 0.0f, 0.0f, 0.0f, -1.0f ); Q[q] = make_float4( 0.0f, 0.0f, 0.0f, 0.0f );
-    if( seg0 + q < B.n_seg && i < L.src.n ) { A[q] = R[(size_t)i * 4]; Q[q] = R[(size_t)i * 4 + 1]; }
+    if( seg0 + q < B.n_seg && i < L.src.n ) { A[q] = R[(size_t)i * REC_F4]; Q[q] = R[(size_t)i * REC_F4 + 1]; }
   }
   const float sd = chain_stats( L, prob, s_stat, nullptr );                  // (its own: in the iterations that keep their guesses this kernel runs BEFORE the moments)
   ChainPar P; P.use_sd = sd > 0.000001; P.cut = 2.5f * sd; P.max_dist = L.radius;
@@ -2969,11 +2968,11 @@ __device__ __forceinline__ void chain_walk_row( const IcpLaunch& L, const ChainB
   ChainPar P; P.use_sd = sd > 0.000001; P.cut = 2.5f * sd; P.max_dist = L.radius;
   const ChainRec* blks = B.blk + ( (size_t)prob * CH_ROWS + row ) * B.n_blk;
   const ChainRec* segs = B.seg + ( (size_t)prob * CH_ROWS + row ) * B.n_seg;
-  const float4* R = L.rec + (size_t)prob * L.src.n * 4;
+  const float4* R = L.rec + (size_t)prob * L.src.n * REC_F4;
   auto addend = [&]( int i ) -> float
   {
     float4 A = make_float4( 0.0f, 0.0f, 0.0f, -1.0f ), Q = make_float4( 0.0f, 0.0f, 0.0f, 0.0f );
-    if( i < L.src.n ) { A = R[(size_t)i * 4]; Q = R[(size_t)i * 4 + 1]; }
+    if( i < L.src.n ) { A = R[(size_t)i * REC_F4]; Q = R[(size_t)i * REC_F4 + 1]; }
     float x[CH_ROWS], w;
     chain_addends( A, Q, P, x, w );
     float xr = x[0];
@@ -3204,7 +3203,7 @@ __device__ __forceinline__ void score_emit( const ScoreLaunch& L, int pose, int 
 #define RS_SC_WAVES 1
 #endif
 constexpr int SC_WAVES = RS_SC_WAVES;
-template <int RB>
+template <int RB, bool KCAP = false>
 __global__ __launch_bounds__( SC_WAVES * WAVE, RB ? RS_SCORE_ROWS_OCC : RS_SCORE_OCC ) void k_score( ScoreLaunch L )
 {
   typedef WaveLdsT<( RB ? 4 * RB : WAVE )> Lds;
@@ -3230,7 +3229,7 @@ __global__ __launch_bounds__( SC_WAVES * WAVE, RB ? RS_SCORE_ROWS_OCC : RS_SCORE
   { handoff = false; m = tile_search_rows<true, RB>( L.scene, active, qx, qy, qz, nx, ny, nz, (float)L.sigma, L.radius_sq, L.gate_tmin, L.K, lds[wib], lane ); }
   else
   {
-    if( L.kcap_frac > 0.0f )
+    if constexpr( KCAP )
       m = tile_search<true, false, false, true>( L.scene, active, qx, qy, qz, nx, ny, nz, (float)L.sigma, L.radius_sq, L.gate_tmin, L.K,
                              lds[wib], lane, L.solo_stages, &handoff, nullptr, no_match(), nullptr, false, nullptr, 0, L.kcap_frac );
     else
@@ -3293,7 +3292,8 @@ void launch_score( const ScoreLaunch& L, hipStream_t st )
   // by_rows: big batches on a cell grid only — nothing is handed off there.  (16 candidates per row and round; 32 and 64 were
   // measured too: 1.70 and 2.15 ms against 1.53 — rows of unequal length evaluate sentinels up to the longest one's count.)
   if( L.by_rows && L.solo_stages == 0x7fffffff && L.scene.inv_cell > 0.0f ) hipLaunchKernelGGL( k_score<16>, grid, dim3( SC_WAVES * WAVE ), 0, st, L );
-  else hipLaunchKernelGGL( k_score<0>, grid, dim3( SC_WAVES * WAVE ), 0, st, L );
+  else if( L.kcap_frac > 0.0f ) hipLaunchKernelGGL( ( k_score<0, true> ), grid, dim3( SC_WAVES * WAVE ), 0, st, L );      // (opt-in experiment: RS_HIP_SCORE_KCAP)
+  else hipLaunchKernelGGL( ( k_score<0, false> ), grid, dim3( SC_WAVES * WAVE ), 0, st, L );
   long long items = (long long)L.obj.n_tiles * L.n_poses;
   hipLaunchKernelGGL( k_score_coop, dim3( items < 4096 ? (int)( items > 0 ? items : 1 ) : 4096 ), dim3( COOP_BLOCK ), 0, st, L );
   hipLaunchKernelGGL( k_score_final, dim3( L.n_poses ), dim3( BLOCK ), 0, st, L );

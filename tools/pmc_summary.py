@@ -39,7 +39,7 @@ if __name__ == "__main__":
         def total(names):
             return sum((2 * F[k][0] + W.get(k, (0, 0))[0]) * F[k][1] for k in F if any(n in k for n in names)) * 1024
         # domain -> (kernels that belong to it, kernels whose launches count as ONE unit of it)
-        doms = {"nn_icp": (["k_icp_corr"], ["k_icp_corr<"]), "icp_moments": (["k_icp_moments", "k_icp_update"], ["k_icp_moments"]),
+        doms = {"nn_icp": (["k_icp_corr"], ["k_icp_corr<"]), "icp_moments": (["k_icp_moments", "k_icp_update", "k_chain_"], ["k_icp_update"]),       # the estimator: one k_icp_update per iteration (round 3: + the centroid chains' kernels)
                 "nn_score": (["k_score"], ["rs::k_score<"]), "nn_label": (["k_label"], ["rs::k_label("])}
         out = {"_note": "HBM-side bytes per launch from rocprofv3 PMC (separate FETCH_SIZE and WRITE_SIZE passes of `bench.py --steps 2 "
                         "--warmup 1 --serial`, tools/profile.sh traffic, folded by tools/pmc_summary.py --fold), FETCH_SIZE doubled as "
