@@ -110,7 +110,7 @@ struct Workspace
   DevBuf lvl_pos, lvl_nor, lvl_cnt, lvl_within, lvl_offset, lvl_adj, lvl_state, lvl_misc, lvl_flags, lvl_scan, lvl_samples, lvl_tmp, lvl_cursor, lvl_work_a, lvl_work_b;   // level builder
   DevBuf faith;                                                                 // reference-order estimator: correspondences in source order
   DevBuf rp_segsum, rp_guess, rp_seg, rp_super, rp_totals, rp_redone;                     // ... its parallel form (replay)
-  DevBuf ch_rec, ch_segsum, ch_prefix, ch_seg, ch_blk, ch_x0, ch_guess, ch_dbg;                                    // the centroid chains of large sources (grid chains)
+  DevBuf ch_rec, ch_segsum, ch_prefix, ch_seg, ch_blk, ch_x0, ch_guess, ch_dbg, ch_done;                                    // the centroid chains of large sources (grid chains)
   PinBuf h_a, h_b, h_c;
 };
 thread_local Workspace g_ws;
@@ -867,10 +867,13 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
         ( rc = g_ws.ch_guess.ensure( rows * CB.n_seg * 4 ) ) ) return rc;
     CB.segsum = g_ws.ch_segsum.as<double>(); CB.blksum = g_ws.ch_prefix.as<double>(); CB.seg = (ChainRec*)g_ws.ch_seg.p; CB.blk = (ChainRec*)g_ws.ch_blk.p; CB.x0 = g_ws.ch_x0.as<float>(); CB.guess = g_ws.ch_guess.as<int>();
     CB.totals = RB.totals; CB.resolved = RB.redone;
+    if( ( rc = g_ws.ch_done.ensure( (size_t)n * 4 ) ) ) return rc;
+    HIP_TRY( hipMemsetAsync( g_ws.ch_done.p, 0, (size_t)n * 4, g_stream ), RS_HIP_E_RUNTIME );
+    CB.done = g_ws.ch_done.as<int>();
     if( getenv( "RS_HIP_CHAIN_DEBUG" ) )
     {
       if( ( rc = g_ws.ch_dbg.ensure( rows * ( 4 + 64 * 8 ) * 4 ) ) ) return rc;
-      CB.dbg = g_ws.ch_dbg.as<int>();
+      CB.dbg = g_ws.ch_dbg.as<int>(); CB.dbg_reps = std::max( 1, atoi( getenv( "RS_HIP_CHAIN_DEBUG" ) ) );
     }
     cx.L.rec = (float4*)g_ws.ch_rec.p;
     cx.L.n_mom_blocks = CB.n_blk * 4;              // k_chain_moments: one workgroup, one partial, per quarter block (1 024 source points)
@@ -903,7 +906,7 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
   const long long total_tiles = (long long)cx.n_waves * n;
   static const long long coop_all_below = getenv( "RS_HIP_COOP_ALL_BELOW" ) ? atoll( getenv( "RS_HIP_COOP_ALL_BELOW" ) ) : 4096;
   static const int coop_waves_forced = getenv( "RS_HIP_COOP_WAVES" ) ? atoi( getenv( "RS_HIP_COOP_WAVES" ) ) : 0;
-  static const int chain_refresh = std::max( 1, getenv( "RS_HIP_CHAIN_REFRESH" ) ? atoi( getenv( "RS_HIP_CHAIN_REFRESH" ) ) : 8 );
+  static const int chain_refresh = std::max( 0, getenv( "RS_HIP_CHAIN_REFRESH" ) ? atoi( getenv( "RS_HIP_CHAIN_REFRESH" ) ) : 0 );
   cx.L.solve = 1; cx.L.fixed_iters = fixed_iters ? 1 : 0;
   ProfChain prof;
   for( int i = 0; i < max_iter; )                                       // icp.h:444
@@ -933,9 +936,9 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
       if( replay ) launch_icp_replay( cx.L, RB, g_stream );
       else if( chains )
       {
-        // the binade guesses of the chains' records are made from this iteration's sums every chain_refresh-th iteration and kept in
-        // between (then the records and the walks do not wait for the moments: one launch does both)
-        CB.refresh = ( i % chain_refresh ) == 0 ? 1 : 0;
+        // the binade guesses of the chains' records: made from the sums of the iteration before (k_chain_walk_and_moments) — in the first
+        // iteration from its own, so the records and the walks wait for the moments there (RS_HIP_CHAIN_REFRESH=k: in every k-th as well)
+        CB.refresh = ( i == 0 || ( chain_refresh > 0 && ( i % chain_refresh ) == 0 ) ) ? 1 : 0;
         launch_icp_chain_centroids( cx.L, CB, g_stream );
       }
       else if( exact_centroids ) launch_icp_exact_centroids( cx.L, RB, g_stream );
@@ -957,12 +960,15 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
     for( int r = 0; r < CH_ROWS; ++r )
     {
       const int* q = d.data() + (size_t)r * ( 4 + 64 * 8 );
-      fprintf( stderr, "[rs_hip chains] chain %d: %d segments added one by one%s; block 0 in LDS + cut after %.2f us, walk done after %.2f us\n", r, q[0] & 0xffff, ( q[0] >> 30 ) ? " (STUCK)" : "", q[1] / 100.0, q[3] / 100.0 );
-      for( int k = 0; k < std::min( q[0] & 0xffff, 64 ); ++k )
+      fprintf( stderr, "[rs_hip chains] chain %d: %d segments added one by one (%d with their addends fetched ahead)%s; fetches done after %.2f us, walk after %.2f us\n", r, q[0] & 0xffff, q[2],
+               ( q[0] >> 30 ) ? " (STUCK)" : "", q[1] / 100.0, q[3] / 100.0 );
+      fprintf( stderr, "   cut + block 0 after %.2f us, block forecasts after %.2f us, segment records + forecasts after %.2f us\n", q[4 + 63 * 8] / 100.0, q[4 + 63 * 8 + 1] / 100.0, q[4 + 63 * 8 + 2] / 100.0 );
+      for( int k = 0; k < std::min( q[0] & 0xffff, 63 ); ++k )
       {
         const int* e = q + 4 + 8 * k; const unsigned sb = (unsigned)e[1];
-        fprintf( stderr, "   segment %6d (at %6.2f us): value exp %3u mantissa %8u sign %u | guess exp %3d sign %d -> class %d: lo %8d hi %8d D %8d\n", e[0], e[7] / 100.0, ( sb >> 23 ) & 255u,
-                 ( sb & 0x7fffffu ) | 0x800000u, sb >> 31, e[2] & 255, e[2] >> 8, e[3], e[4], e[5], e[6] );
+        fprintf( stderr, "   segment %6d (at %6.2f us): value exp %3u mantissa %8u sign %u | class %d lo %8d hi %8d%s | %s, %s\n", e[0], e[7] / 100.0, ( sb >> 23 ) & 255u,
+                 ( sb & 0x7fffffu ) | 0x800000u, sb >> 31, e[3], e[4], e[5], e[4] > e[5] ? " (no record: tie / too big)" : "",
+                 ( e[2] & 2 ) ? "block forecast" : "block NOT forecast", ( e[2] & 1 ) ? "addends ahead" : "addends fetched now" );
       }
     }
   }

@@ -1785,6 +1785,37 @@ __global__ __launch_bounds__( BLOCK ) void k_icp_moments( IcpLaunch L )
 
 }
 
+// The rest of an iteration once the moments are summed in L.res (the whole workgroup comes in; thread 0 solves).
+__device__ __forceinline__ void icp_update_tail( const IcpLaunch& L, int prob )
+{
+  double* res = L.res + (size_t)prob * ICP_NRES;
+  if( !L.solve ) return;
+  icp_iteration_reset( L, prob );
+  if( threadIdx.x != 0 ) return;
+  // ---- icp.h:455-493 for this problem ----
+  L.prev_err[prob] = L.err[prob];
+  L.iters[prob] += 1;
+  if( res[ICP_NMOM] == 0.0 ) { L.active[prob] = 0; return; }            // icp.h:455-459: no correspondences
+  Mat4 T;
+  for( int k = 0; k < 16; ++k ) { T.m[k] = L.T1[prob * 16 + k]; L.T1_prev[prob * 16 + k] = T.m[k]; }
+  float e;
+  float cen[6];
+  if( L.exact_centroids )
+  {
+    // the reference's own centroids: c = Σw·p * ( 1.0f / Σw ), every sum its sequential fp32 chain (icp.h:136-148)
+    const double* t2 = L.centroid_totals + ( (size_t)prob * 3 + 1 ) * ICP_NMOM;
+    const float total = (float)t2[0];
+    if( total <= 1e-7 ) { L.active[prob] = 0; return; }                 // icp.h:466-470
+    const float inv = __fdiv_rn( 1.0f, total );
+    for( int a = 0; a < 6; ++a ) cen[a] = (float)t2[1 + a] * inv;
+  }
+  if( !icp_solve( res, T, e, L.exact_centroids ? cen : nullptr ) ) { L.active[prob] = 0; return; }         // icp.h:466-470: weights vanished
+  for( int k = 0; k < 16; ++k ) L.T1[prob * 16 + k] = T.m[k];           // icp.h:295
+  L.err[prob] = e;
+  const float delta = fabsf( L.prev_err[prob] - e );
+  if( !L.fixed_iters && L.iter_index > 5 && delta < 1e-5 ) L.active[prob] = 0;   // icp.h:489
+}
+
 // One workgroup per problem: fixed-order sum of the per-workgroup partials (moment k by wave k mod 16;
 // lane l adds partials l, l+64, l+128, ..., then the wave tree) and — inside the ICP loop — the
 // rest of the iteration (icp.h:455-493), which the reference runs on the CPU: 6x6 solve, pose
@@ -1817,31 +1848,39 @@ __global__ __launch_bounds__( UPDATE_WAVES * WAVE ) void k_icp_update( IcpLaunch
     if( lane == 0 ) res[k] = v;
   }
   __syncthreads();
-  if( !L.solve ) return;
-  icp_iteration_reset( L, prob );
-  if( threadIdx.x != 0 ) return;
-  // ---- icp.h:455-493 for this problem ----
-  L.prev_err[prob] = L.err[prob];
-  L.iters[prob] += 1;
-  if( res[ICP_NMOM] == 0.0 ) { L.active[prob] = 0; return; }            // icp.h:455-459: no correspondences
-  Mat4 T;
-  for( int k = 0; k < 16; ++k ) { T.m[k] = L.T1[prob * 16 + k]; L.T1_prev[prob * 16 + k] = T.m[k]; }
-  float e;
-  float cen[6];
-  if( L.exact_centroids )
+  icp_update_tail( L, prob );
+}
+
+// The same for the chains' estimator, whose partials come by the thousand (one per 1 024 source points, moment-major): one
+// workgroup per MOMENT sums its row (a single workgroup took 14 us over the 400 KB of a 1 M-point scan), the last one to finish
+// does the rest of the iteration.  Fixed order throughout: thread t adds partials t, t + 256, ..., then the wave tree, then the
+// four waves in turn.
+__global__ __launch_bounds__( BLOCK ) void k_icp_update_wide( IcpLaunch L, int* done )
+{
+  __shared__ double s_part[WAVES_PER_BLOCK];
+  __shared__ int s_last;
+  const int prob = blockIdx.y, k = blockIdx.x;
+  if( L.active[prob] == 0 ) return;
+  const int lane = threadIdx.x & ( WAVE - 1 ), wib = threadIdx.x / WAVE;
+  const double* in = L.mom_part + ( (size_t)prob * ICP_NMOM + k ) * L.n_mom_blocks;
+  double v = 0.0;
+  for( int b = threadIdx.x; b < L.n_mom_blocks; b += BLOCK ) v += in[b];
+  v = wave_sum( v );
+  if( lane == 0 ) s_part[wib] = v;
+  __syncthreads();
+  if( threadIdx.x == 0 )
   {
-    // the reference's own centroids: c = Σw·p * ( 1.0f / Σw ), every sum its sequential fp32 chain (icp.h:136-148)
-    const double* t2 = L.centroid_totals + ( (size_t)prob * 3 + 1 ) * ICP_NMOM;
-    const float total = (float)t2[0];
-    if( total <= 1e-7 ) { L.active[prob] = 0; return; }                 // icp.h:466-470
-    const float inv = __fdiv_rn( 1.0f, total );
-    for( int a = 0; a < 6; ++a ) cen[a] = (float)t2[1 + a] * inv;
+    double t = 0.0;
+    for( int w = 0; w < WAVES_PER_BLOCK; ++w ) t += s_part[w];
+    L.res[(size_t)prob * ICP_NRES + k] = t;
+    __threadfence();
+    s_last = atomicAdd( done + prob, 1 ) == ICP_NMOM - 1 ? 1 : 0;
   }
-  if( !icp_solve( res, T, e, L.exact_centroids ? cen : nullptr ) ) { L.active[prob] = 0; return; }         // icp.h:466-470: weights vanished
-  for( int k = 0; k < 16; ++k ) L.T1[prob * 16 + k] = T.m[k];           // icp.h:295
-  L.err[prob] = e;
-  const float delta = fabsf( L.prev_err[prob] - e );
-  if( !L.fixed_iters && L.iter_index > 5 && delta < 1e-5 ) L.active[prob] = 0;   // icp.h:489
+  __syncthreads();
+  if( !s_last ) return;
+  __threadfence();                                       // (the other workgroups' sums)
+  if( threadIdx.x == 0 ) done[prob] = 0;
+  icp_update_tail( L, prob );
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2765,9 +2804,17 @@ __global__ __launch_bounds__( BLOCK ) void k_chain_moments( IcpLaunch L, ChainBu
 //     max_j ( lo_j - Dex_j )  <=  M  <=  min_j ( hi_j - Dex_j ),      Dex_j = the advance of the records before j,
 // and then advances it by D_0 + .. + D_l: three integer prefix scans over the lanes (sum, max, min), each six DPP instructions.
 // (A never-record has lo - Dex > hi - Dex, so the max passes the min from its lane on: nothing fits any more.)
-struct ChainFn { int lo, hi, D; };
-__device__ __forceinline__ ChainFn chain_never() { ChainFn f; f.lo = CH_M_HI; f.hi = CH_M_LO; f.D = 0; return f; }
-__device__ __forceinline__ ChainFn chain_identity() { ChainFn f; f.lo = CH_M_LO; f.hi = CH_M_HI; f.D = 0; return f; }
+//
+// Ties.  An addend that lands exactly half way between two grid points is rounded to the EVEN one: M + k + ( ( M + k ) & 1 ) — what
+// it adds depends on the parity of the value it meets, i.e. on the parity of the record's start mantissa.  After it the value is
+// even, whatever it was: later ties of the same record are decided.  So a record with ties is  M -> M + D + tau[ M & 1 ]  with two
+// small numbers tau[0], tau[1] (a segment: { c, 1 - c }; a block: composed, chain_compose) — kept in the low four bits of the D
+// word — and its interval is narrowed by max tau.  The scans below take D alone; whoever applies a run of records adds, in order,
+// the tau each start's parity picks (advance in chain_walk_row, k_chain_compose), having left room for the most they can add.
+struct ChainFn { int lo, hi, D, tau; };
+__device__ __forceinline__ ChainFn chain_never() { ChainFn f; f.lo = CH_M_HI; f.hi = CH_M_LO; f.D = 0; f.tau = 0; return f; }
+__device__ __forceinline__ ChainFn chain_identity() { ChainFn f; f.lo = CH_M_LO; f.hi = CH_M_HI; f.D = 0; f.tau = 0; return f; }
+__device__ __forceinline__ int chain_tau( int tau, int parity ) { return ( tau >> ( 2 * ( parity & 1 ) ) ) & 3; }
 // the function of a record for the (biased) exponent E and sign bit sg of the running value
 __device__ __forceinline__ ChainFn chain_select( const ChainRec& r, int E, int sg )
 {
@@ -2775,9 +2822,11 @@ __device__ __forceinline__ ChainFn chain_select( const ChainRec& r, int E, int s
   ChainFn f = chain_never();
   if( ( r.e_sign >> 8 ) == sg )
   {
-    if( c == 0 ) { f.lo = r.lo[0]; f.hi = r.hi[0]; f.D = r.D[0]; }
-    if( c == 1 ) { f.lo = r.lo[1]; f.hi = r.hi[1]; f.D = r.D[1]; }
-    if( c == 2 ) { f.lo = r.lo[2]; f.hi = r.hi[2]; f.D = r.D[2]; }
+    int d = 0;
+    if( c == 0 ) { f.lo = r.lo[0]; f.hi = r.hi[0]; d = r.D[0]; }
+    if( c == 1 ) { f.lo = r.lo[1]; f.hi = r.hi[1]; d = r.D[1]; }
+    if( c == 2 ) { f.lo = r.lo[2]; f.hi = r.hi[2]; d = r.D[2]; }
+    f.D = d >> 4; f.tau = d & 15;
   }
   return f;
 }
@@ -2800,7 +2849,7 @@ __device__ __forceinline__ ChainFn chain_prefix( const ChainFn& f, int lane )
   RS_DPP_PREFIX( "v_max_i32_dpp", a );
   RS_DPP_PREFIX( "v_min_i32_dpp", b );
   ChainFn g;
-  g.lo = max( a, CH_M_LO ); g.hi = min( b, CH_M_HI ); g.D = incl;
+  g.lo = max( a, CH_M_LO ); g.hi = min( b, CH_M_HI ); g.D = incl; g.tau = f.tau;
   const bool never = g.lo > g.hi;
   g.lo = never ? CH_M_HI : g.lo; g.hi = never ? CH_M_LO : g.hi; g.D = never ? 0 : g.D;
   return g;
@@ -2808,22 +2857,33 @@ __device__ __forceinline__ ChainFn chain_prefix( const ChainFn& f, int lane )
 
 // The guesses (refresh iterations): every chain's fp64 prefix at each segment's start — the quarter blocks before from their sums,
 // then a scan of the block's own 64 segment sums — kept as exponent | sign << 8 per (chain, segment).  One workgroup per block.
+__device__ __forceinline__ double wave_scan_f64( double v, int lane )      // inclusive
+{
+#pragma unroll
+  for( int d = 1; d < WAVE; d <<= 1 ) { const double up = __shfl_up( v, d ); if( lane >= d ) v += up; }
+  return v;
+}
+__device__ __forceinline__ void chain_guess_block( const IcpLaunch& L, const ChainBufs& B, int prob, int blk, int n_waves )
+{
+  const int lane = threadIdx.x & ( WAVE - 1 );
+  for( int r = threadIdx.x / WAVE; r < CH_ROWS; r += n_waves )
+  {
+    const double* bsum = B.blksum + ( (size_t)prob * CH_ROWS + r ) * ( B.n_blk * CH_QUARTERS );
+    double before = 0.0;
+    for( int b = lane; b < blk * CH_QUARTERS; b += WAVE ) before += bsum[b];
+    before = wave_sum( before );
+    const int seg = blk * CH_BLK + lane;
+    const double v = seg < B.n_seg ? B.segsum[( (size_t)prob * CH_ROWS + r ) * B.n_seg + seg] : 0.0;
+    const double incl = wave_scan_f64( v, lane );
+    const uint32_t gb = __float_as_uint( (float)( before + ( incl - v ) ) );
+    if( seg < B.n_seg ) B.guess[( (size_t)prob * CH_ROWS + r ) * B.n_seg + seg] = (int)( ( ( gb >> 23 ) & 255u ) | ( ( gb >> 31 ) << 8 ) );
+  }
+}
 __global__ __launch_bounds__( CH_ROWS * WAVE ) void k_chain_guess( IcpLaunch L, ChainBufs B )
 {
-  const int prob = blockIdx.y, blk = blockIdx.x;
+  const int prob = blockIdx.y;
   if( L.active[prob] == 0 ) return;
-  const int lane = threadIdx.x & ( WAVE - 1 ), r = threadIdx.x / WAVE;
-  const double* bsum = B.blksum + ( (size_t)prob * CH_ROWS + r ) * ( B.n_blk * CH_QUARTERS );
-  double before = 0.0;
-  for( int b = lane; b < blk * CH_QUARTERS; b += WAVE ) before += bsum[b];
-  before = wave_sum( before );
-  const int seg = blk * CH_BLK + lane;
-  const double v = seg < B.n_seg ? B.segsum[( (size_t)prob * CH_ROWS + r ) * B.n_seg + seg] : 0.0;
-  double incl = v;
-#pragma unroll
-  for( int d = 1; d < WAVE; d <<= 1 ) { const double up = __shfl_up( incl, d ); if( lane >= d ) incl += up; }
-  const uint32_t gb = __float_as_uint( (float)( before + ( incl - v ) ) );
-  if( seg < B.n_seg ) B.guess[( (size_t)prob * CH_ROWS + r ) * B.n_seg + seg] = (int)( ( ( gb >> 23 ) & 255u ) | ( ( gb >> 31 ) << 8 ) );
+  chain_guess_block( L, B, prob, blockIdx.x, CH_ROWS );
 }
 
 // The segment records: a wave stages THREE consecutive segments' addends in LDS (lane = point), then lane = (segment, exponent
@@ -2873,7 +2933,9 @@ __global__ __launch_bounds__( BLOCK ) void k_chain_segrecs( IcpLaunch L, ChainBu
   const int eg = es & 255, sg = es >> 8;
   const int E = eg - 1 + c;                                            // s = M * 2^(E - 150), M in [2^23, 2^24)
   int Pj = 0, pmin = 0, pmax = 0;                                      // partial sums, the start included
-  bool bad = E < 1 || E > 254;
+  const bool bad_e = E < 1 || E > 254;
+  bool odd = bad_e, big = bad_e, seen = false;
+  int cpar = 0;
   const float* xs = &s_x[wib][q][r][0];
 #pragma unroll 8
   for( int j = 0; j < CH_SEG; ++j )
@@ -2881,10 +2943,39 @@ __global__ __launch_bounds__( BLOCK ) void k_chain_segrecs( IcpLaunch L, ChainBu
     const float xv = xs[j];
     const float y = ldexpf( sg ? -xv : xv, 150 - E );                  // x / ulp( s ): exact (a power of two), or 0 / inf at the ends; the chain of |s| for negative s
     const float rn = rintf( y );                                       // to nearest, ties to even
-    bad |= !( fabsf( y ) < 8388608.0f ) | ( fabsf( y - rn ) == 0.5f );  // too big for this binade (or NaN), or a tie: M's parity would decide
+    odd |= (int)!( fabsf( y ) < 8388608.0f ) | (int)( fabsf( y - rn ) == 0.5f );  // too big for this binade (or NaN), or a tie: M's parity decides
     Pj += (int)rn;
     pmin = min( pmin, Pj ); pmax = max( pmax, Pj );
   }
+  float fsum = 0.0f;
+  if( odd )        // one segment in a few hundred: again, telling the two apart and taking the ties as they fall (see ChainFn)
+  {
+    Pj = 0; pmin = 0; pmax = 0;
+    int Pfa = 0;
+    for( int j = 0; j < CH_SEG; ++j )
+    {
+      const float xv = xs[j];
+      const float y = ldexpf( sg ? -xv : xv, 150 - E );
+      const float rn = rintf( y );
+      big |= !( fabsf( y ) < 8388608.0f );
+      if( fabsf( y - rn ) == 0.5f )                                    // to the even neighbour
+      {
+        const int kl = (int)floorf( y );
+        if( !seen ) { seen = true; cpar = ( Pj + kl ) & 1; Pj += kl; Pfa = Pj; }      // M + Pj + ( ( M + cpar ) & 1 ): even from here on, = "M' + ( Pj - Pfa )"
+        else Pj += kl + ( ( Pj - Pfa + kl ) & 1 );
+      }
+      else Pj += (int)rn;
+      pmin = min( pmin, Pj ); pmax = max( pmax, Pj );
+      fsum += xv;
+    }
+    pmax += seen ? 1 : 0;
+  }
+  const bool bad = big;
+  // What the segment adds to the chain, for the walks' forecasts of where the chain changes binade (chain_walk_row) and for the
+  // next iteration's guesses: the guessed binade's own advance — D grid steps, i.e. the CHAIN's sum, its rounding drift included —
+  // or, where the addends do not fit that grid, their plain sum.
+  if( c == 1 )
+    B.segsum[( (size_t)prob * CH_ROWS + r ) * B.n_seg + seg] = big ? (double)fsum : ldexp( (double)( sg ? -Pj : Pj ), E - 150 );
   // every value on the way, the start included, at least one grid step inside the binade: the neighbouring binades' grids
   // (half / twice as fine) then play no part in any of the roundings
   long long lo = (long long)CH_M_LO + 1 - pmin, hi = (long long)CH_M_HI - 1 - pmax;
@@ -2892,7 +2983,7 @@ __global__ __launch_bounds__( BLOCK ) void k_chain_segrecs( IcpLaunch L, ChainBu
   const bool ok = !bad && lo <= hi;
   ChainRec* out = B.seg + ( (size_t)prob * CH_ROWS + r ) * B.n_seg + seg;
   if( c == 0 ) out->e_sign = es;
-  out->lo[c] = ok ? (int)lo : CH_M_HI; out->hi[c] = ok ? (int)hi : CH_M_LO; out->D[c] = ok ? Pj : 0;
+  out->lo[c] = ok ? (int)lo : CH_M_HI; out->hi[c] = ok ? (int)hi : CH_M_LO; out->D[c] = ok ? Pj * 16 + ( seen ? ( cpar ? 1 : 4 ) : 0 ) : 0;      // tau = { cpar, 1 - cpar }
 }
 
 // The block records: a block's 64 segment records composed per chain and exponent (around the block's first guess).
@@ -2913,6 +3004,16 @@ __global__ __launch_bounds__( CHAIN_CMP_WAVES * WAVE ) void k_chain_compose( Icp
       for( int k = threadIdx.x; k < CH_BLK * WORDS; k += blockDim.x ) dst[k] = k < n_here * WORDS ? src[k] : -1;      // (e_sign -1: past the end of the cloud)
     }
   }
+  // ... and the quarter blocks' sums of the segments' (the walks' forecasts, the next guesses)
+  if( threadIdx.x < CH_ROWS * CH_QUARTERS )
+  {
+    const int r = threadIdx.x / CH_QUARTERS, q = threadIdx.x % CH_QUARTERS;
+    const double* ss = B.segsum + ( (size_t)prob * CH_ROWS + r ) * B.n_seg;
+    constexpr int SEGS = CH_BLK / CH_QUARTERS;
+    double v = 0.0;
+    for( int k = 0; k < SEGS; ++k ) { const int seg = blk * CH_BLK + q * SEGS + k; if( seg < B.n_seg ) v += ss[seg]; }
+    B.blksum[( (size_t)prob * CH_ROWS + r ) * ( B.n_blk * CH_QUARTERS ) + blk * CH_QUARTERS + q] = v;
+  }
   __syncthreads();
   for( int job = wib; job < CH_ROWS * 3; job += CHAIN_CMP_WAVES )
   {
@@ -2920,176 +3021,349 @@ __global__ __launch_bounds__( CHAIN_CMP_WAVES * WAVE ) void k_chain_compose( Icp
     const int first = s_rec[r][0].e_sign;
     const int E = ( first & 255 ) - 1 + c, sg = first >> 8;
     const ChainRec mine = s_rec[r][lane];
-    ChainFn f = mine.e_sign == -1 ? chain_identity() : chain_select( mine, E, sg );
-    f = chain_prefix( f, lane );
+    const ChainFn f0 = mine.e_sign == -1 ? chain_identity() : chain_select( mine, E, sg );
+    ChainFn f = chain_prefix( f0, lane );
+    // the ties inside, in order: what the block adds for an even / an odd start (each record's tau picked by the parity of ITS start)
+    unsigned long long tm = RS_BALLOT( f0.tau != 0 );
+    const int ex = f.D - f0.D;
+    int t0 = 0, t1 = 0, tmax = 0;
+    while( tm != 0ull )
+    {
+      const int k = __builtin_ctzll( tm ); tm &= tm - 1ull;
+      const int exk = __builtin_amdgcn_readlane( ex, k ), tk = __builtin_amdgcn_readlane( f0.tau, k );
+      t0 += chain_tau( tk, exk + t0 ); t1 += chain_tau( tk, 1 + exk + t1 ); tmax += max( tk & 3, tk >> 2 );
+    }
     if( lane == WAVE - 1 )
     {
       ChainRec* out = B.blk + ( (size_t)prob * CH_ROWS + r ) * B.n_blk + blk;
       if( c == 0 ) out->e_sign = first;
-      out->lo[c] = f.lo; out->hi[c] = f.hi; out->D[c] = f.D;
+      const int hi = f.hi - tmax;
+      const bool ok = f.lo <= hi && t0 <= 3 && t1 <= 3;                   // (a never-record has lo > hi already)
+      out->lo[c] = ok ? f.lo : CH_M_HI; out->hi[c] = ok ? hi : CH_M_LO; out->D[c] = ok ? f.D * 16 + t0 + 4 * t1 : 0;
     }
   }
 }
 
-// One chain walked by one wave (a workgroup of its own).  `s` (uniform) is the exact running value.  Block 0 — where the chain
-// climbs from zero through a dozen binades, and where addends as large as the sum make ties likely — is served from LDS: its
-// 4 096 addends (left in memory by k_chain_records) are fetched when the kernel starts, all loads in flight together, so none of
-// its ~14 segments that have to be added up addend by addend waits for memory.
-#define CH_PREFETCH 8
-struct ChainWalkLds { float x0[CH_BLK][CH_SEG]; ChainRec seg[CH_PREFETCH][CH_SEG]; };
-__device__ __forceinline__ void chain_walk_row( const IcpLaunch& L, const ChainBufs& B, int prob, int row, int lane, ChainWalkLds& S )
+// One chain walked by one wave.  `s` (uniform) is the exact running value.  What costs time in a walk is not arithmetic but memory
+// latency — a block that does not fit needs its segments' records, the segment that does not fit its 64 addends: two dependent
+// round trips of ~2 us, ~20 times per chain.  So the walk FORECASTS where the chain will change binade and fetches ahead, every
+// load of a round in flight together, three rounds per 512 blocks:
+//   1  the blocks' sums (quarter sums: k_chain_compose), block 0's addends (4 096: the chain climbs through a dozen binades there,
+//      and addends as large as the sum make ties likely), the first 64 block records;
+//   2  the forecast of the chain at every block's start = the exact value so far + the prefix of the blocks' sums (those are the
+//      records' own advances, the rounding drift included: chain_segrecs); the segment records and sums of the first CH_PRE_BLKS
+//      blocks inside which the forecast comes within CH_EPS of a power of two (or of zero);
+//   3  the same forecast by segments inside those blocks, and the addends of the first CH_PRE_SEGS segments it points at.
+// A block or segment that fails without having been forecast (a tie, a forecast off by more than CH_EPS) is fetched when the walk
+// gets there, as before.  Block records: 64 at a time, the next 64 on their way while the walk is in the current ones.
+#define CH_PRE_BLKS 8
+#define CH_PRE_SEGS 24
+#define CH_SUPER 8                 // chunks of 64 blocks per round of forecasts (512 blocks: 2 M source points)
+#define CH_EPS ( 1.0f / 2048.0f )
+struct ChainWalkLds
 {
-  auto& s_x0 = S.x0; auto& s_seg = S.seg;
+  float x0[CH_BLK][CH_SEG]; ChainRec seg[CH_PRE_BLKS][CH_SEG]; float xs[CH_PRE_SEGS][CH_SEG];
+  unsigned long long stat[WAVES_PER_BLOCK][3], want[CH_PRE_BLKS]; int pblk[CH_PRE_BLKS], at_seg[CH_PRE_SEGS]; float pst[CH_PRE_BLKS];
+};
+// does a chain that goes from a to b (forecasts) change binade on the way, give or take a relative eps?
+__device__ __forceinline__ bool chain_crosses( float a, float b, float eps )
+{
+  if( !( a * b > 0.0f ) ) return true;                   // zero, a sign change, NaN
+  const float lo = fminf( fabsf( a ), fabsf( b ) ) * ( 1.0f - eps ), hi = fmaxf( fabsf( a ), fabsf( b ) ) * ( 1.0f + eps );
+  return ( __float_as_uint( lo ) >> 23 ) != ( __float_as_uint( hi ) >> 23 );
+}
+// (a forecast needs four digits, not sixteen: fp32 prefix sums, six DPP adds each)
+__device__ __forceinline__ float wave_scan_f32( float v ) { RS_DPP_PREFIX( "v_add_f32_dpp", v ); return v; }
+__device__ __forceinline__ float rl( float v, int lane ) { return __int_as_float( __builtin_amdgcn_readlane( __float_as_int( v ), lane ) ); }
+__device__ __forceinline__ unsigned long long below( int bit ) { return ( 1ull << bit ) - 1ull; }
+// (field by field: a conditional copy of the whole struct is a memcpy through private memory, which then stays in scratch)
+__device__ __forceinline__ void chain_rec_copy( ChainRec& d, const ChainRec& r )
+{
+  d.e_sign = r.e_sign;
+#pragma unroll
+  for( int c = 0; c < 3; ++c ) { d.lo[c] = r.lo[c]; d.hi[c] = r.hi[c]; d.D[c] = r.D[c]; }
+}
+// A workgroup of BLOCK threads per chain: ONE wave issues ~500 instructions per microsecond, so the fetches — a few thousand
+// instructions — are shared by the four waves (and every round's loads are unconditional, from clamped indices, masked afterwards:
+// a load inside a branch is waited for there, one round trip after the other); the walk itself is wave 0's.
+__device__ __forceinline__ void chain_walk_row( const IcpLaunch& L, const ChainBufs& B, int prob, int row, ChainWalkLds& S )
+{
+  const int lane = threadIdx.x & ( WAVE - 1 ), wib = threadIdx.x / WAVE;
+  const bool walker = wib == 0;
   const unsigned long long t_start = B.dbg ? wall_clock64() : 0ull;
-  {
-    const float* x0 = B.x0 + ( (size_t)prob * CH_ROWS + row ) * ( CH_BLK * CH_SEG );
-    const int ns0 = min( CH_BLK, B.n_seg );
-    float v[CH_BLK];
-#pragma unroll
-    for( int g = 0; g < CH_BLK; ++g ) v[g] = g < ns0 ? x0[g * CH_SEG + lane] : 0.0f;
-#pragma unroll
-    for( int g = 0; g < CH_BLK; ++g ) s_x0[g][lane] = v[g];
-  }
-  // the cut (as chain_stats; one wave takes the 256 shards in four rounds)
-  float sd;
-  {
-    unsigned long long t0 = 0, t1 = 0, t2 = 0;
-    for( int q = 0; q < STAT_SHARDS / WAVE; ++q )
-    {
-      const unsigned long long* a = L.stat_acc + ( (size_t)prob * STAT_SHARDS + q * WAVE + lane ) * 4;
-      t0 += wave_sum_u64( a[0] ); t1 += wave_sum_u64( a[1] ); t2 += wave_sum_u64( a[2] );
-    }
-    const double n = (double)t0;
-    const float mean = (float)( (double)t1 * L.stat_i1 / n );
-    const float sqm = (float)( (double)t2 * L.stat_i2 / n );
-    const float var = sqm - mean * mean;
-    sd = (float)sqrt( (double)var );
-  }
-  ChainPar P; P.use_sd = sd > 0.000001; P.cut = 2.5f * sd; P.max_dist = L.radius;
   const ChainRec* blks = B.blk + ( (size_t)prob * CH_ROWS + row ) * B.n_blk;
   const ChainRec* segs = B.seg + ( (size_t)prob * CH_ROWS + row ) * B.n_seg;
-  const float4* R = L.rec + (size_t)prob * L.src.n * REC_F4;
-  auto addend = [&]( int i ) -> float
+  const double* ssum = B.segsum + ( (size_t)prob * CH_ROWS + row ) * B.n_seg;
+  const double* qsum = B.blksum + ( (size_t)prob * CH_ROWS + row ) * ( B.n_blk * CH_QUARTERS );
+  const float* Rf = reinterpret_cast<const float*>( L.rec + (size_t)prob * L.src.n * REC_F4 );
+  const int comp = row == 0 ? 3 : ( row <= 3 ? row - 1 : row );      // a record's words: p.xyz at 0..2, dist² at 3, q.xyz at 4..6, dot at 7
+  int* dbg = ( B.dbg && threadIdx.x == 0 ) ? B.dbg + ( (size_t)prob * CH_ROWS + row ) * ( 4 + 64 * 8 ) : nullptr;
+  auto stamp = [&]( int k ) { if( dbg ) dbg[4 + 63 * 8 + k] = (int)( wall_clock64() - t_start ); };
+  auto load_blocks = [&]( int b0 ) -> ChainRec { ChainRec m; chain_rec_copy( m, blks[min( b0 + lane, B.n_blk - 1 )] ); if( b0 + lane >= B.n_blk ) m.e_sign = -1; return m; };
+  auto load_bsum = [&]( int b ) -> float
   {
-    float4 A = make_float4( 0.0f, 0.0f, 0.0f, -1.0f ), Q = make_float4( 0.0f, 0.0f, 0.0f, 0.0f );
-    if( i < L.src.n ) { A = R[(size_t)i * REC_F4]; Q = R[(size_t)i * REC_F4 + 1]; }
-    float x[CH_ROWS], w;
-    chain_addends( A, Q, P, x, w );
-    float xr = x[0];
-#pragma unroll
-    for( int r = 1; r < CH_ROWS; ++r ) xr = row == r ? x[r] : xr;
-    return xr;
+    const double2* q = reinterpret_cast<const double2*>( qsum + (size_t)min( b, B.n_blk - 1 ) * CH_QUARTERS );
+    const double2 u = q[0], v = q[1];
+    return b < B.n_blk ? (float)( ( u.x + u.y ) + ( v.x + v.y ) ) : 0.0f;
   };
-  wave_lds_fence();
-  if( B.dbg && lane == 0 ) B.dbg[( (size_t)prob * CH_ROWS + row ) * ( 4 + 64 * 8 ) + 1] = (int)( wall_clock64() - t_start );
+
+  // ---- round 1: block 0's addends, the first 512 blocks' sums and first 64 records, the cut (chain_stats: its loads go out with these)
+  constexpr int X0_PER_WAVE = CH_BLK / WAVES_PER_BLOCK;
+  float v0[X0_PER_WAVE];
+  {
+    const float* x0 = B.x0 + ( (size_t)prob * CH_ROWS + row ) * ( CH_BLK * CH_SEG );
+#pragma unroll
+    for( int g = 0; g < X0_PER_WAVE; ++g ) v0[g] = x0[( wib * X0_PER_WAVE + g ) * CH_SEG + lane];        // (the buffer holds 4 096; what lies past the cloud's end is not used)
+  }
+  float bs[CH_SUPER];
+  ChainRec cur; cur.e_sign = -1;
+  if( walker )
+  {
+#pragma unroll
+    for( int c = 0; c < CH_SUPER; ++c ) bs[c] = load_bsum( c * WAVE + lane );
+    cur = load_blocks( 0 );
+  }
+  const float sd = chain_stats( L, prob, S.stat, nullptr );
+  ChainPar P; P.use_sd = sd > 0.000001; P.cut = 2.5f * sd; P.max_dist = L.radius;
+#pragma unroll
+  for( int g = 0; g < X0_PER_WAVE; ++g ) S.x0[wib * X0_PER_WAVE + g][lane] = v0[g];
+  stamp( 0 );
+
+  auto addend = [&]( int i ) -> float                 // (of a segment that was not fetched ahead)
+  {
+    const float* rp = Rf + (size_t)min( i, L.src.n - 1 ) * ( REC_F4 * 4 );
+    const float d2 = rp[3], dt = rp[7], cv = rp[comp];
+    const bool mt = d2 >= 0.0f && i < L.src.n;
+    float w = 0.0f;                                     // chain_addends
+    if( mt ) { w = ( 1.0f - __fdiv_rn( d2, P.max_dist ) ) * dt; if( P.use_sd && d2 > P.cut ) w = 0.0f; }
+    return row == 0 ? w : ( mt ? cv * w : 0.0f );
+  };
 
   float s = 0.0f;
-  int resolved = 0, stuck = 0, steps = 0;
+  int resolved = 0, stuck = 0, steps = 0, hits = 0;
   // advance over the records held by the lanes [from, count): as far as the value fits; returns the first lane that does not (count: all done)
   auto advance = [&]( const ChainRec& mine, int from, int count ) -> int
   {
     const uint32_t sb = __float_as_uint( s );
     const int E = (int)( ( sb >> 23 ) & 255u ), sg = (int)( sb >> 31 ), M = (int)( sb & 0x7fffffu ) | CH_M_LO;
     const bool mine_in = lane >= from && lane < count;
-    ChainFn f = !mine_in ? chain_identity() : ( ( E == 0 || E == 255 ) ? chain_never() : chain_select( mine, E, sg ) );      // zero, denormal, inf, NaN: one by one
-    f = chain_prefix( f, lane );
-    const bool fits = f.lo <= f.hi && M >= f.lo && M <= f.hi;
+    const ChainFn f0 = !mine_in ? chain_identity() : ( ( E == 0 || E == 255 ) ? chain_never() : chain_select( mine, E, sg ) );      // zero, denormal, inf, NaN: one by one
+    const ChainFn f = chain_prefix( f0, lane );
+    // records with ties inside (ChainFn): each adds the tau its own start's parity picks — until those are known the most they can add
+    const unsigned long long tl = RS_BALLOT( f0.tau != 0 );
+    int taumax = 0;
+    for( unsigned long long t = tl; t != 0ull; t &= t - 1ull ) { const int tk = __builtin_amdgcn_readlane( f0.tau, __builtin_ctzll( t ) ); taumax += max( tk & 3, tk >> 2 ); }
+    const bool fits = f.lo <= f.hi && M >= f.lo && M + taumax <= f.hi;
     const unsigned long long good = RS_BALLOT( fits );
     const int stop = good == ~0ull ? WAVE : __builtin_ctzll( ~good );       // the fitting lanes are a prefix: the intervals only shrink
     const int last = min( stop, count ) - 1;
     if( last >= from )
     {
-      const int D = __builtin_amdgcn_readlane( f.D, last );
+      int extra = 0;
+      for( unsigned long long t = tl & ( last >= WAVE - 1 ? ~0ull : below( last + 1 ) ); t != 0ull; t &= t - 1ull )
+      {
+        const int k = __builtin_ctzll( t );
+        const int exk = __builtin_amdgcn_readlane( f.D, k ) - __builtin_amdgcn_readlane( f0.D, k );
+        extra += chain_tau( __builtin_amdgcn_readlane( f0.tau, k ), M + exk + extra );
+      }
+      const int D = __builtin_amdgcn_readlane( f.D, last ) + extra;
       s = __uint_as_float( ( sb & 0xff800000u ) | ( (uint32_t)( M + D ) & 0x7fffffu ) );
     }
     return min( stop, count );
   };
-  for( int b0 = 0; b0 < B.n_blk && !( stuck & 2 ); b0 += WAVE )
+
+  for( int B0 = 0; B0 < B.n_blk; B0 += CH_SUPER * WAVE )
   {
-    const int nb = min( WAVE, B.n_blk - b0 );
-    ChainRec mine; mine.e_sign = -1;
-    if( lane < nb ) mine = blks[b0 + lane];
-    // Where will the chain change binade?  Where the GUESS does: in a block whose successor's guess has another exponent (and in
-    // block 0).  The segment records of up to CH_PREFETCH such blocks of this chunk are fetched now, all loads in flight together,
-    // so that the walk does not wait for them when it gets there (a block that fails for another reason — a tie — is loaded then).
-    unsigned long long pre_mask;
+    const int n_chunks = min( CH_SUPER, ( B.n_blk - B0 + WAVE - 1 ) / WAVE );
+    unsigned long long l_pre = 0ull;      // (wave 0) lane c: the blocks of chunk c whose segment records are in S.seg
+    if( walker )
     {
-      const int next = __shfl_down( mine.e_sign, 1 );
-      const bool flag = lane < nb && ( lane + 1 >= nb ? true : next != mine.e_sign );
-      unsigned long long m = RS_BALLOT( flag ) | ( b0 == 0 ? 1ull : 0ull );
-      pre_mask = 0ull;
-      ChainRec got[CH_PREFETCH];
-#pragma unroll
-      for( int k = 0; k < CH_PREFETCH; ++k )
+      if( B0 > 0 )
       {
-        got[k].e_sign = -1;
-        if( m )
+#pragma unroll
+        for( int c = 0; c < CH_SUPER; ++c ) bs[c] = load_bsum( B0 + c * WAVE + lane );
+        cur = load_blocks( B0 );
+      }
+      // ---- forecasts at the blocks' starts; the blocks to fetch ahead (lane k: block k's number and the forecast at its start)
+      int l_pblk = -1, n_pre = 0;
+      float l_pst = 0.0f, base = s;
+#pragma unroll
+      for( int c = 0; c < CH_SUPER; ++c )
+        if( c < n_chunks )
         {
-          const int b = __builtin_ctzll( m ); m &= m - 1ull; pre_mask |= 1ull << b;
-          const int g0 = ( b0 + b ) * CH_BLK;
-          if( g0 + lane < B.n_seg ) got[k] = segs[g0 + lane];
+          const float incl = wave_scan_f32( bs[c] );
+          const float st = base + ( incl - bs[c] ), en = base + incl;
+          const int b = B0 + c * WAVE + lane;
+          unsigned long long m = RS_BALLOT( b < B.n_blk && ( b == 0 || chain_crosses( st, en, CH_EPS ) ) );
+          unsigned long long keep = 0ull;
+          while( m != 0ull && n_pre < CH_PRE_BLKS )
+          {
+            const int bit = __builtin_ctzll( m ); m &= m - 1ull; keep |= 1ull << bit;
+            const float pst = rl( st, bit );
+            if( lane == n_pre ) { l_pblk = B0 + c * WAVE + bit; l_pst = pst; }
+            ++n_pre;
+          }
+          if( lane == c ) l_pre = keep;
+          base += rl( incl, WAVE - 1 );
         }
+      if( lane < CH_PRE_BLKS ) { S.pblk[lane] = l_pblk; S.pst[lane] = l_pst; }
+    }
+    __syncthreads();                                                      // (S.x0, S.pblk, S.pst)
+    stamp( 1 );
+    // ---- round 2: those blocks' segment records and sums, the forecast by segments inside them (block 0: all of it is in S.x0)
+    {
+      constexpr int PER = CH_PRE_BLKS / WAVES_PER_BLOCK;
+      ChainRec got[PER]; float sv[PER]; int pb[PER];
+#pragma unroll
+      for( int i = 0; i < PER; ++i )
+      {
+        pb[i] = uni( S.pblk[wib * PER + i] );
+        const int sg = max( pb[i], 0 ) * CH_BLK + lane, sgc = min( sg, B.n_seg - 1 );
+        chain_rec_copy( got[i], segs[sgc] ); sv[i] = (float)ssum[sgc];
+        if( pb[i] < 0 || sg >= B.n_seg ) { got[i].e_sign = -1; sv[i] = 0.0f; }
       }
 #pragma unroll
-      for( int k = 0; k < CH_PREFETCH; ++k ) s_seg[k][lane] = got[k];
-      wave_lds_fence();
-    }
-    int at = 0;
-    while( at < nb && !( stuck & 2 ) )
-    {
-      const int at_was = at;
-      if( ++steps > 8 * B.n_seg + 4096 ) { stuck |= 2; break; }       // (a walk takes at most one step per block + two per segment: guards against a loop that does not end)
-      at = advance( mine, at, nb );
-      if( at < at_was ) { stuck |= 1; at = at_was; }      // (cannot happen: the lanes before `at` hold the identity — guards the loop against a wrong scan)
-      if( at >= nb ) break;
-      // block b0 + at does not fit as a whole: by its segments
-      const int g0 = ( b0 + at ) * CH_BLK, ns = min( CH_BLK, B.n_seg - g0 );
-      ChainRec smine; smine.e_sign = -1;
-      if( ( pre_mask >> at ) & 1ull ) smine = s_seg[__builtin_popcountll( pre_mask & ( ( 1ull << at ) - 1ull ) )][lane];
-      else if( lane < ns ) smine = segs[g0 + lane];
-      int sat = 0;
-      while( sat < ns )
+      for( int i = 0; i < PER; ++i )
       {
-        const int sat_was = sat;
-        if( ++steps > 8 * B.n_seg + 4096 ) { stuck |= 2; break; }
-        sat = advance( smine, sat, ns );
-        if( sat < sat_was ) { stuck |= 1; sat = sat_was; }
-        if( sat >= ns ) break;
-        // segment g0 + sat: its 64 addends one after the other, in fp32 — the reference's own operations
-        if( B.dbg && resolved < 64 )
-        {
-          const ChainRec why = segs[g0 + sat];
-          const uint32_t sb = __float_as_uint( s );
-          const int c = (int)( ( sb >> 23 ) & 255u ) - ( why.e_sign & 255 ) + 1;
-          int* d = B.dbg + ( (size_t)prob * CH_ROWS + row ) * ( 4 + 64 * 8 ) + 4 + resolved * 8;
-          if( lane == 0 ) { d[0] = g0 + sat; d[1] = (int)sb; d[2] = why.e_sign; d[3] = c; d[4] = ( c >= 0 && c < 3 ) ? why.lo[c] : 0; d[5] = ( c >= 0 && c < 3 ) ? why.hi[c] : 0; d[6] = ( c >= 0 && c < 3 ) ? why.D[c] : 0; d[7] = (int)( wall_clock64() - t_start ); }
-        }
-        const float xr = ( g0 == 0 ) ? s_x0[sat][lane] : addend( ( g0 + sat ) * CH_SEG + lane );
-#pragma unroll
-        for( int j = 0; j < CH_SEG; ++j ) s = s + __int_as_float( __builtin_amdgcn_readlane( __float_as_int( xr ), j ) );      // (fully unrolled: lane numbers as immediates, the reads ahead of the chain of adds)
-        s = __int_as_float( uni( __float_as_int( s ) ) );
-        ++resolved; ++sat;
+        const int k = wib * PER + i;
+        chain_rec_copy( S.seg[k][lane], got[i] );
+        const float incl = wave_scan_f32( sv[i] ), st0 = S.pst[k];
+        const unsigned long long m = RS_BALLOT( pb[i] > 0 && pb[i] * CH_BLK + lane < B.n_seg && chain_crosses( st0 + ( incl - sv[i] ), st0 + incl, CH_EPS ) );
+        if( lane == 0 ) S.want[k] = m;
       }
-      ++at;
     }
+    __syncthreads();                                                      // (S.seg, S.want)
+    stamp( 2 );
+    // ---- the first CH_PRE_SEGS of the segments the forecasts point at, in order (lane k: those of block k, and their first slot in S.xs)
+    unsigned long long l_segs = 0ull;
+    int l_sbase = 0;
+    if( walker )
+    {
+      const unsigned long long l_want = lane < CH_PRE_BLKS ? S.want[lane] : 0ull;
+      int my_seg = 0, k = 0;                                                // lane j: the segment for slot j (none: segment 0, not used)
+      unsigned long long m = rl( l_want, 0 );
+      for( int j = 0; j < CH_PRE_SEGS; ++j )
+      {
+        while( m == 0ull && k < CH_PRE_BLKS - 1 ) { ++k; m = rl( l_want, k ); }
+        if( m == 0ull ) break;
+        const int bit = __builtin_ctzll( m ); m &= m - 1ull;
+        if( lane == k ) l_segs |= 1ull << bit;
+        if( lane == j ) my_seg = uni( S.pblk[k] ) * CH_BLK + bit;
+      }
+      if( lane < CH_PRE_SEGS ) S.at_seg[lane] = my_seg;
+      const uint32_t cnt = (uint32_t)__builtin_popcountll( l_segs );
+      l_sbase = (int)( wave_scan( cnt, lane ) - cnt );
+    }
+    __syncthreads();                                                      // (S.at_seg)
+    // ---- round 3: their addends
+    {
+      constexpr int PER = CH_PRE_SEGS / WAVES_PER_BLOCK;
+      float xd[PER], xw[PER], xc[PER]; int at[PER];
+#pragma unroll
+      for( int i = 0; i < PER; ++i )
+      {
+        at[i] = uni( S.at_seg[wib * PER + i] ) * CH_SEG + lane;
+        const float* rp = Rf + (size_t)min( at[i], L.src.n - 1 ) * ( REC_F4 * 4 );
+        xd[i] = rp[3]; xw[i] = rp[7]; xc[i] = rp[comp];
+      }
+#pragma unroll
+      for( int i = 0; i < PER; ++i )
+      {
+        const bool mt = xd[i] >= 0.0f && at[i] < L.src.n;
+        float w = 0.0f;                                                   // chain_addends
+        if( mt ) { w = ( 1.0f - __fdiv_rn( xd[i], P.max_dist ) ) * xw[i]; if( P.use_sd && xd[i] > P.cut ) w = 0.0f; }
+        S.xs[wib * PER + i][lane] = row == 0 ? w : ( mt ? xc[i] * w : 0.0f );
+      }
+    }
+    __syncthreads();                                                      // (S.xs)
+    if( B0 == 0 && dbg ) dbg[1] = (int)( wall_clock64() - t_start );
+
+    // ---- the walk
+    if( walker && !( stuck & 2 ) )
+    {
+      int pre_before = 0;                   // blocks in S.seg from the chunks before this one
+      for( int c = 0; c < n_chunks && !( stuck & 2 ); ++c )
+      {
+        const int b0 = B0 + c * WAVE, nb = min( WAVE, B.n_blk - b0 );
+        ChainRec mine; chain_rec_copy( mine, cur );
+        if( c + 1 < n_chunks ) { const ChainRec nx = load_blocks( b0 + WAVE ); chain_rec_copy( cur, nx ); }      // (on its way while this chunk is walked)
+        const unsigned long long pre_mask = rl( l_pre, c );
+        int at = 0;
+        while( at < nb && !( stuck & 2 ) )
+        {
+          const int at_was = at;
+          if( ++steps > 8 * B.n_seg + 4096 ) { stuck |= 2; break; }       // (a walk takes at most one step per block + two per segment: guards against a loop that does not end)
+          at = advance( mine, at, nb );
+          if( at < at_was ) { stuck |= 1; at = at_was; }      // (cannot happen: the lanes before `at` hold the identity — guards the loop against a wrong scan)
+          if( at >= nb ) break;
+          // block b0 + at does not fit as a whole: by its segments
+          const int g0 = ( b0 + at ) * CH_BLK, ns = min( CH_BLK, B.n_seg - g0 );
+          ChainRec smine; smine.e_sign = -1;
+          unsigned long long have = 0ull; int sbase = 0;
+          const bool ahead = ( pre_mask >> at ) & 1ull;
+          if( ahead )
+          {
+            const int k = pre_before + __builtin_popcountll( pre_mask & below( at ) );
+            chain_rec_copy( smine, S.seg[k][lane] ); have = rl( l_segs, k ); sbase = __builtin_amdgcn_readlane( l_sbase, k );
+          }
+          else if( lane < ns ) chain_rec_copy( smine, segs[g0 + lane] );
+          int sat = 0;
+          while( sat < ns )
+          {
+            const int sat_was = sat;
+            if( ++steps > 8 * B.n_seg + 4096 ) { stuck |= 2; break; }
+            sat = advance( smine, sat, ns );
+            if( sat < sat_was ) { stuck |= 1; sat = sat_was; }
+            if( sat >= ns ) break;
+            // segment g0 + sat: its 64 addends one after the other, in fp32 — the reference's own operations
+            const bool in_lds = g0 == 0 || ( ( have >> sat ) & 1ull );
+            if( B.dbg && resolved < 63 )
+            {
+              const uint32_t sb = __float_as_uint( s );
+              const int cls = (int)( ( sb >> 23 ) & 255u ) - ( __builtin_amdgcn_readlane( smine.e_sign, sat ) & 255 ) + 1;
+              const int lo = __builtin_amdgcn_readlane( cls == 0 ? smine.lo[0] : ( cls == 1 ? smine.lo[1] : smine.lo[2] ), sat );
+              const int hi = __builtin_amdgcn_readlane( cls == 0 ? smine.hi[0] : ( cls == 1 ? smine.hi[1] : smine.hi[2] ), sat );
+              if( dbg )
+              {
+                int* d = dbg + 4 + resolved * 8;
+                d[0] = g0 + sat; d[1] = (int)sb; d[2] = ( in_lds ? 1 : 0 ) | ( ahead ? 2 : 0 ); d[3] = cls; d[4] = lo; d[5] = hi; d[7] = (int)( wall_clock64() - t_start );
+              }
+            }
+            float xr;
+            if( g0 == 0 ) xr = S.x0[sat][lane];
+            else if( in_lds ) xr = S.xs[sbase + __builtin_popcountll( have & below( sat ) )][lane];
+            else xr = addend( ( g0 + sat ) * CH_SEG + lane );
+            hits += in_lds ? 1 : 0;
+#pragma unroll
+            for( int j = 0; j < CH_SEG; ++j ) s = s + __int_as_float( __builtin_amdgcn_readlane( __float_as_int( xr ), j ) );      // (fully unrolled: lane numbers as immediates, the reads ahead of the chain of adds)
+            s = __int_as_float( uni( __float_as_int( s ) ) );
+            ++resolved; ++sat;
+          }
+          ++at;
+        }
+        pre_before += __builtin_popcountll( pre_mask );
+      }
+    }
+    if( B0 + CH_SUPER * WAVE < B.n_blk ) __syncthreads();                   // (the next round overwrites what this walk read)
   }
-  if( lane == 0 )
+  if( threadIdx.x == 0 )
   {
     B.totals[( (size_t)prob * 3 + 1 ) * ICP_NMOM + row] = (double)s;
     if( B.resolved ) atomicAdd( B.resolved + prob, resolved );
-    if( B.dbg ) { int* h = B.dbg + ( (size_t)prob * CH_ROWS + row ) * ( 4 + 64 * 8 ); h[0] = resolved | ( stuck << 30 ); h[3] = (int)( wall_clock64() - t_start ); }
+    if( dbg ) { dbg[0] = resolved | ( stuck << 30 ); dbg[2] = hits; dbg[3] = (int)( wall_clock64() - t_start ); }
   }
 }
 
-__global__ __launch_bounds__( WAVE ) void k_chain_walk( IcpLaunch L, ChainBufs B )
+__global__ __launch_bounds__( BLOCK ) void k_chain_walk( IcpLaunch L, ChainBufs B )
 {
   __shared__ ChainWalkLds S;
   const int prob = blockIdx.y;
   if( L.active[prob] == 0 ) return;
-  chain_walk_row( L, B, prob, blockIdx.x, threadIdx.x, S );
+  for( int rep = 0; rep < ( B.dbg ? B.dbg_reps : 1 ); ++rep ) { chain_walk_row( L, B, prob, blockIdx.x, S ); __syncthreads(); }
 }
-// The walks and the moments in ONE launch (the iterations that keep their guesses: neither needs the other): workgroups 0-6 walk a
-// chain each with their first wave, the others take a quarter block of the moments each.
+// The walks, the moments and the next iteration's guesses in ONE launch (none needs another's results): workgroups 0-6 walk a chain
+// each with their first wave, the next 4 n_blk take a quarter block of the moments each, the last n_blk a block of the guesses (from
+// the sums k_chain_segrecs and k_chain_compose have just left: read by the NEXT iteration's k_chain_segrecs).
 __global__ __launch_bounds__( BLOCK ) void k_chain_walk_and_moments( IcpLaunch L, ChainBufs B )
 {
   __shared__ union U { ChainWalkLds w; ChainMomLds m; __device__ U() {} } S;
@@ -3097,10 +3371,12 @@ __global__ __launch_bounds__( BLOCK ) void k_chain_walk_and_moments( IcpLaunch L
   if( L.active[prob] == 0 ) return;
   if( blockIdx.x < CH_ROWS )
   {
-    if( threadIdx.x < WAVE ) chain_walk_row( L, B, prob, blockIdx.x, threadIdx.x, S.w );
+    chain_walk_row( L, B, prob, blockIdx.x, S.w );
     return;
   }
-  chain_moments_block( L, B, prob, (int)blockIdx.x - CH_ROWS, S.m );
+  const int qb = (int)blockIdx.x - CH_ROWS;
+  if( qb < B.n_blk * CH_QUARTERS ) chain_moments_block( L, B, prob, qb, S.m );
+  else chain_guess_block( L, B, prob, qb - B.n_blk * CH_QUARTERS, WAVES_PER_BLOCK );
 }
 
 void launch_icp_chain_centroids( const IcpLaunch& L, const ChainBufs& B, hipStream_t st )
@@ -3114,15 +3390,15 @@ void launch_icp_chain_centroids( const IcpLaunch& L, const ChainBufs& B, hipStre
     hipLaunchKernelGGL( k_chain_guess, dim3( B.n_blk, L.n_prob ), dim3( CH_ROWS * WAVE ), 0, st, L, B );
     hipLaunchKernelGGL( k_chain_segrecs, rec_grid, dim3( BLOCK ), 0, st, L, B );
     hipLaunchKernelGGL( k_chain_compose, dim3( B.n_blk, L.n_prob ), dim3( CHAIN_CMP_WAVES * WAVE ), 0, st, L, B );
-    hipLaunchKernelGGL( k_chain_walk, dim3( CH_ROWS, L.n_prob ), dim3( WAVE ), 0, st, L, B );
+    hipLaunchKernelGGL( k_chain_walk, dim3( CH_ROWS, L.n_prob ), dim3( BLOCK ), 0, st, L, B );
   }
   else
   {
     hipLaunchKernelGGL( k_chain_segrecs, rec_grid, dim3( BLOCK ), 0, st, L, B );
     hipLaunchKernelGGL( k_chain_compose, dim3( B.n_blk, L.n_prob ), dim3( CHAIN_CMP_WAVES * WAVE ), 0, st, L, B );
-    hipLaunchKernelGGL( k_chain_walk_and_moments, dim3( CH_ROWS + B.n_blk * CH_QUARTERS, L.n_prob ), dim3( BLOCK ), 0, st, L, B );
+    hipLaunchKernelGGL( k_chain_walk_and_moments, dim3( CH_ROWS + B.n_blk * ( CH_QUARTERS + 1 ), L.n_prob ), dim3( BLOCK ), 0, st, L, B );
   }
-  hipLaunchKernelGGL( k_icp_update, dim3( L.n_prob ), dim3( UPDATE_WAVES * WAVE ), 0, st, L );                           // (centred on the chains' totals: L.exact_centroids)
+  hipLaunchKernelGGL( k_icp_update_wide, dim3( ICP_NMOM, L.n_prob ), dim3( BLOCK ), 0, st, L, B.done );                // (centred on the chains' totals: L.exact_centroids)
 }
 
 int replay_segments( int n_source ) { return ( n_source + REPLAY_SEG - 1 ) / REPLAY_SEG; }
