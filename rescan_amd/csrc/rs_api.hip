@@ -110,7 +110,7 @@ struct Workspace
   DevBuf lvl_pos, lvl_nor, lvl_cnt, lvl_within, lvl_offset, lvl_adj, lvl_state, lvl_misc, lvl_flags, lvl_scan, lvl_samples, lvl_tmp, lvl_cursor, lvl_work_a, lvl_work_b;   // level builder
   DevBuf faith;                                                                 // reference-order estimator: correspondences in source order
   DevBuf rp_segsum, rp_guess, rp_seg, rp_super, rp_totals, rp_redone;                     // ... its parallel form (replay)
-  DevBuf ch_rec, ch_segsum, ch_prefix, ch_seg, ch_blk, ch_x0, ch_guess, ch_dbg, ch_done;                                    // the centroid chains of large sources (grid chains)
+  DevBuf ch_rec, ch_segsum, ch_prefix, ch_seg, ch_blk, ch_guess, ch_dbg, ch_done;                                    // the centroid chains of large sources (grid chains)
   PinBuf h_a, h_b, h_c;
 };
 thread_local Workspace g_ws;
@@ -863,9 +863,9 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
     const size_t rows = (size_t)n * CH_ROWS;
     if( ( rc = g_ws.ch_rec.ensure( (size_t)n * (size_t)source->n * REC_F4 * 16 ) ) || ( rc = g_ws.ch_segsum.ensure( rows * CB.n_seg * 8 ) ) ||
         ( rc = g_ws.ch_prefix.ensure( rows * CB.n_blk * 4 * 8 ) ) || ( rc = g_ws.ch_seg.ensure( rows * CB.n_seg * sizeof( ChainRec ) ) ) ||
-        ( rc = g_ws.ch_blk.ensure( rows * CB.n_blk * sizeof( ChainRec ) ) ) || ( rc = g_ws.ch_x0.ensure( rows * CH_BLK * CH_SEG * 4 ) ) ||
+        ( rc = g_ws.ch_blk.ensure( rows * CB.n_blk * sizeof( ChainRec ) ) ) ||
         ( rc = g_ws.ch_guess.ensure( rows * CB.n_seg * 4 ) ) ) return rc;
-    CB.segsum = g_ws.ch_segsum.as<double>(); CB.blksum = g_ws.ch_prefix.as<double>(); CB.seg = (ChainRec*)g_ws.ch_seg.p; CB.blk = (ChainRec*)g_ws.ch_blk.p; CB.x0 = g_ws.ch_x0.as<float>(); CB.guess = g_ws.ch_guess.as<int>();
+    CB.segsum = g_ws.ch_segsum.as<double>(); CB.blksum = g_ws.ch_prefix.as<double>(); CB.seg = (ChainRec*)g_ws.ch_seg.p; CB.blk = (ChainRec*)g_ws.ch_blk.p; CB.guess = g_ws.ch_guess.as<int>();
     CB.totals = RB.totals; CB.resolved = RB.redone;
     if( ( rc = g_ws.ch_done.ensure( (size_t)n * 4 ) ) ) return rc;
     HIP_TRY( hipMemsetAsync( g_ws.ch_done.p, 0, (size_t)n * 4, g_stream ), RS_HIP_E_RUNTIME );
@@ -960,14 +960,14 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
     for( int r = 0; r < CH_ROWS; ++r )
     {
       const int* q = d.data() + (size_t)r * ( 4 + 64 * 8 );
-      fprintf( stderr, "[rs_hip chains] chain %d: %d segments added one by one (%d with their addends fetched ahead)%s; fetches done after %.2f us, walk after %.2f us\n", r, q[0] & 0xffff, q[2],
+      fprintf( stderr, "[rs_hip chains] chain %d: %d segments added one by one (%d with their addends fetched ahead), %d pieces taken whole, %d wave-wide scans%s; fetches done after %.2f us, walk after %.2f us\n", r, q[0] & 0xffff, q[2] & 0xffff, q[2] >> 16, ( q[0] >> 16 ) & 0x3fff,
                ( q[0] >> 30 ) ? " (STUCK)" : "", q[1] / 100.0, q[3] / 100.0 );
-      fprintf( stderr, "   cut + block 0 after %.2f us, block forecasts after %.2f us, segment records + forecasts after %.2f us\n", q[4 + 63 * 8] / 100.0, q[4 + 63 * 8 + 1] / 100.0, q[4 + 63 * 8 + 2] / 100.0 );
+      fprintf( stderr, "   cut + block 0 after %.2f us, block forecasts after %.2f us, segment records + forecasts after %.2f us; shader cycles: %d the whole walk, %d in the pieces' steps, %d in the crossing blocks (%d of them in their crossing segments' record checks)\n", q[4 + 63 * 8] / 100.0, q[4 + 63 * 8 + 1] / 100.0, q[4 + 63 * 8 + 2] / 100.0, q[4 + 63 * 8 + 6], q[4 + 63 * 8 + 3], q[4 + 63 * 8 + 4], q[4 + 63 * 8 + 5] );
       for( int k = 0; k < std::min( q[0] & 0xffff, 63 ); ++k )
       {
         const int* e = q + 4 + 8 * k; const unsigned sb = (unsigned)e[1];
-        fprintf( stderr, "   segment %6d (at %6.2f us): value exp %3u mantissa %8u sign %u | class %d lo %8d hi %8d%s | %s, %s\n", e[0], e[7] / 100.0, ( sb >> 23 ) & 255u,
-                 ( sb & 0x7fffffu ) | 0x800000u, sb >> 31, e[3], e[4], e[5], e[4] > e[5] ? " (no record: tie / too big)" : "",
+        fprintf( stderr, "   segment %6d (at %6.2f us): value exp %3u mantissa %8u sign %u | %d cycles for the 64 adds | %s, %s\n", e[0], e[7] / 100.0, ( sb >> 23 ) & 255u,
+                 ( sb & 0x7fffffu ) | 0x800000u, sb >> 31, e[3],
                  ( e[2] & 2 ) ? "block forecast" : "block NOT forecast", ( e[2] & 1 ) ? "addends ahead" : "addends fetched now" );
       }
     }

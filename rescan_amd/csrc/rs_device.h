@@ -139,7 +139,6 @@ struct ChainBufs
   int       n_seg, n_blk;
   double*   segsum;     // n_prob x CH_ROWS x n_seg : fp64 sums of the segments' addends
   double*   blksum;     // n_prob x CH_ROWS x 4 n_blk : ... and of the quarter blocks' (the guess of the running sum at a segment's start = their prefix)
-  float*    x0;         // n_prob x CH_ROWS x 4096 : the addends of block 0
   ChainRec* seg;        // n_prob x CH_ROWS x n_seg
   ChainRec* blk;        // n_prob x CH_ROWS x n_blk : 64 segments composed
   double*   totals;     // n_prob x 3 x ICP_NMOM (the layout of ReplayBufs::totals; the chains fill [ICP_NMOM + 0..6])

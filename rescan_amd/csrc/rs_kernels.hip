@@ -2915,13 +2915,10 @@ __global__ __launch_bounds__( BLOCK ) void k_chain_segrecs( IcpLaunch L, ChainBu
   {
     float x[CH_ROWS], w;
     chain_addends( A[q], Q[q], P, x, w );
-    const int seg = seg0 + q;
 #pragma unroll
     for( int r = 0; r < CH_ROWS; ++r )
     {
       s_x[wib][q][r][lane] = x[r];
-      // block 0's addends also go to memory: the walks serve that block from LDS (k_chain_walk)
-      if( seg < CH_BLK ) B.x0[( (size_t)prob * CH_ROWS + r ) * ( CH_BLK * CH_SEG ) + seg * CH_SEG + lane] = x[r];
     }
   }
   wave_lds_fence();
@@ -3044,26 +3041,44 @@ __global__ __launch_bounds__( CHAIN_CMP_WAVES * WAVE ) void k_chain_compose( Icp
   }
 }
 
-// One chain walked by one wave.  `s` (uniform) is the exact running value.  What costs time in a walk is not arithmetic but memory
-// latency — a block that does not fit needs its segments' records, the segment that does not fit its 64 addends: two dependent
-// round trips of ~2 us, ~20 times per chain.  So the walk FORECASTS where the chain will change binade and fetches ahead, every
-// load of a round in flight together, three rounds per 512 blocks:
-//   1  the blocks' sums (quarter sums: k_chain_compose), block 0's addends (4 096: the chain climbs through a dozen binades there,
-//      and addends as large as the sum make ties likely), the first 64 block records;
-//   2  the forecast of the chain at every block's start = the exact value so far + the prefix of the blocks' sums (those are the
-//      records' own advances, the rounding drift included: chain_segrecs); the segment records and sums of the first CH_PRE_BLKS
-//      blocks inside which the forecast comes within CH_EPS of a power of two (or of zero);
-//   3  the same forecast by segments inside those blocks, and the addends of the first CH_PRE_SEGS segments it points at.
-// A block or segment that fails without having been forecast (a tie, a forecast off by more than CH_EPS) is fetched when the walk
-// gets there, as before.  Block records: 64 at a time, the next 64 on their way while the walk is in the current ones.
-#define CH_PRE_BLKS 8
-#define CH_PRE_SEGS 24
-#define CH_SUPER 8                 // chunks of 64 blocks per round of forecasts (512 blocks: 2 M source points)
+// One chain walked by a workgroup of four waves.  `s` (wave 0's, uniform) is the exact running value.
+//
+// What a walk costs is set by two things.  Memory latency: a block that does not fit needs its segments' records, the segment that
+// does not fit its 64 addends — two dependent round trips of ~2 us, ~20 times per chain.  And instruction issue: ONE wave issues
+// ~250 instructions per microsecond, a wave-wide scan of 64 records is ~130.  So the walk FORECASTS where the chain will change
+// binade, fetches ahead — every load of a round in flight together, the work of a round shared by the four waves — and has
+// everything around a forecast crossing composed into single records beforehand.  Per 512 blocks (2 M source points):
+//   1  the blocks' sums (quarter sums: k_chain_compose) and records.  The forecast of the chain at every block's start = the exact
+//      value so far + the prefix of the blocks' sums (the records' own advances, their rounding drift included: k_chain_segrecs);
+//      of each block record only the function for the forecast's binade is kept (S.ones); the first CH_PRE_BLKS blocks inside which
+//      the forecast comes within CH_EPS of a power of two (or of zero) are the "fetched" blocks;
+//   2  their segment records and sums: the same forecast by segments; the runs of segments between two forecast crossings composed
+//      into one record each, for the binade the forecast has there (S.piece: one segmented scan per block);
+//   3  the addends and the records of the first CH_PRE_SEGS segments the forecasts point at (S.xs, S.fseg).
+// The walk then: a wave-wide scan over 64 block functions at a time; a fetched block piece by piece and crossing by crossing, one
+// record each; a segment whose record does not hold the value is added up addend by addend (the reference's own operations).
+// Whatever was not forecast (off by more than CH_EPS, more crossings than fit) is fetched when the walk gets there and scanned.
+#define CH_PRE_BLKS 12
+#define CH_PRE_SEGS 32
+#define CH_SUPER 8                 // chunks of 64 blocks per round of forecasts
 #define CH_EPS ( 1.0f / 2048.0f )
+#define CH_PIECES 16               // pieces of a fetched block
+#define CH_PIECE_BIG ( 1 << 27 )
+struct ChainPiece { int es, lo, hi, D; };      // exponent | sign << 8 it is made for; M -> M + D [+ tau: ptau / bptau] for lo <= M <= hi
+struct ChainOne { int es, lo, hi, Dt; };       // a block record's function for one binade: Dt = D * 16 + tau
 struct ChainWalkLds
 {
-  float x0[CH_BLK][CH_SEG]; ChainRec seg[CH_PRE_BLKS][CH_SEG]; float xs[CH_PRE_SEGS][CH_SEG];
-  unsigned long long stat[WAVES_PER_BLOCK][3], want[CH_PRE_BLKS]; int pblk[CH_PRE_BLKS], at_seg[CH_PRE_SEGS]; float pst[CH_PRE_BLKS];
+  ChainOne ones[CH_SUPER * WAVE];               // the block records' functions for the forecast binade
+  ChainPiece bpiece[CH_SUPER * WAVE];           // [c * 64 + l]: blocks (the forecast's last crossing block before l, l] of chunk c as one record
+  int bptau[CH_SUPER][CH_PIECES];               // per piece: tau[0] | tau[1] << 4 | max tau << 8
+  float bst[CH_SUPER * WAVE];                   // the forecast at the blocks' starts
+  ChainPiece piece[CH_PRE_BLKS][CH_SEG];        // the same by segments inside fetched block k
+  int ptau[CH_PRE_BLKS][CH_PIECES];
+  ChainRec fseg[CH_PRE_SEGS];                   // the records of the segments the forecasts point at ...
+  float xs[CH_PRE_SEGS + 1][CH_SEG];            // ... and their addends (the last row: those of a segment fetched on the way)
+  unsigned long long stat[WAVES_PER_BLOCK][3], flag[CH_PRE_BLKS], fmask[CH_SUPER];
+  int pblk[CH_PRE_BLKS], at_seg[CH_PRE_SEGS], mode[CH_PRE_BLKS], bmode[CH_SUPER];
+  float pst[CH_PRE_BLKS], tot[CH_SUPER], s0;
 };
 // does a chain that goes from a to b (forecasts) change binade on the way, give or take a relative eps?
 __device__ __forceinline__ bool chain_crosses( float a, float b, float eps )
@@ -3076,6 +3091,12 @@ __device__ __forceinline__ bool chain_crosses( float a, float b, float eps )
 __device__ __forceinline__ float wave_scan_f32( float v ) { RS_DPP_PREFIX( "v_add_f32_dpp", v ); return v; }
 __device__ __forceinline__ float rl( float v, int lane ) { return __int_as_float( __builtin_amdgcn_readlane( __float_as_int( v ), lane ) ); }
 __device__ __forceinline__ unsigned long long below( int bit ) { return ( 1ull << bit ) - 1ull; }
+// the lowest n set bits of m
+__device__ __forceinline__ unsigned long long lowest_bits( unsigned long long m, int n )
+{
+  for( int c = __builtin_popcountll( m ); c > n && m != 0ull; --c ) m &= ~( 1ull << ( 63 - __builtin_clzll( m ) ) );
+  return n > 0 ? m : 0ull;
+}
 // (field by field: a conditional copy of the whole struct is a memcpy through private memory, which then stays in scratch)
 __device__ __forceinline__ void chain_rec_copy( ChainRec& d, const ChainRec& r )
 {
@@ -3083,12 +3104,49 @@ __device__ __forceinline__ void chain_rec_copy( ChainRec& d, const ChainRec& r )
 #pragma unroll
   for( int c = 0; c < 3; ++c ) { d.lo[c] = r.lo[c]; d.hi[c] = r.hi[c]; d.D[c] = r.D[c]; }
 }
-// A workgroup of BLOCK threads per chain: ONE wave issues ~500 instructions per microsecond, so the fetches — a few thousand
-// instructions — are shared by the four waves (and every round's loads are unconditional, from clamped indices, masked afterwards:
-// a load inside a branch is waited for there, one round trip after the other); the walk itself is wave 0's.
+__device__ __forceinline__ ChainFn chain_one_fn( const ChainOne& p, int E, int sg )
+{
+  ChainFn f = chain_never();
+  if( p.es == ( E | ( sg << 8 ) ) ) { f.lo = p.lo; f.hi = p.hi; f.D = p.Dt >> 4; f.tau = p.Dt & 15; }
+  return f;
+}
+// The runs of records between the forecast's crossings (the set bits of m; f0 there: the identity), each composed into ONE record
+// for the binade `es` the forecast has there: one segmented scan makes them all — the exclusive prefix of D restarts after every
+// crossing, the prefix max / min carry the piece number in the high bits — and lane l ends up with the record of (the last
+// crossing before l, l].  The ties inside, piece by piece, as k_chain_compose.  (m has fewer than CH_PIECES bits.)
+__device__ __forceinline__ void chain_pieces( const ChainFn& f0, int es, unsigned long long m, int lane, ChainPiece* out, int* ptau )
+{
+  const unsigned long long before = m & below( lane );
+  const int pid = __builtin_popcountll( before );
+  const int incD = (int)wave_scan( (uint32_t)f0.D, lane ), ex = incD - f0.D;
+  const int first = before != 0ull ? 64 - __builtin_clzll( before ) : 0;       // my piece starts after the last crossing before me
+  const int exs = ex - __shfl( ex, first );
+  const bool wild = abs( exs ) > ( 1 << 25 );                                   // (no valid run adds that much inside one binade; keeps the sums below in range)
+  int a = ( wild ? CH_M_HI : f0.lo - exs ) + pid * CH_PIECE_BIG, b = ( wild ? CH_M_LO : f0.hi - exs ) - pid * CH_PIECE_BIG;
+  RS_DPP_PREFIX( "v_max_i32_dpp", a );
+  RS_DPP_PREFIX( "v_min_i32_dpp", b );
+  ChainPiece pc;
+  pc.es = es; pc.lo = max( a - pid * CH_PIECE_BIG, CH_M_LO ); pc.hi = min( b + pid * CH_PIECE_BIG, CH_M_HI ); pc.D = exs + f0.D;
+  out[lane] = pc;
+  if( lane < CH_PIECES ) ptau[lane] = 0;
+  wave_lds_fence();
+  int cur = -1, t0 = 0, t1 = 0, tmax = 0;
+  for( unsigned long long tm = RS_BALLOT( f0.tau != 0 ); tm != 0ull; tm &= tm - 1ull )
+  {
+    const int kk = __builtin_ctzll( tm );
+    const int pk = __builtin_amdgcn_readlane( pid, kk ), exk = __builtin_amdgcn_readlane( exs, kk ), tk = __builtin_amdgcn_readlane( f0.tau, kk );
+    if( pk != cur ) { if( cur >= 0 && lane == 0 ) ptau[cur] = min( t0, 15 ) | ( min( t1, 15 ) << 4 ) | ( tmax << 8 ); cur = pk; t0 = 0; t1 = 0; tmax = 0; }
+    t0 += chain_tau( tk, exk + t0 ); t1 += chain_tau( tk, 1 + exk + t1 ); tmax += max( tk & 3, tk >> 2 );
+  }
+  if( cur >= 0 && lane == 0 ) ptau[cur] = min( t0, 15 ) | ( min( t1, 15 ) << 4 ) | ( tmax << 8 );
+}
+// (every round's loads are unconditional, from clamped indices, masked afterwards: a load inside a branch is waited for there,
+//  one round trip after the other)
 __device__ __forceinline__ void chain_walk_row( const IcpLaunch& L, const ChainBufs& B, int prob, int row, ChainWalkLds& S )
 {
-  const int lane = threadIdx.x & ( WAVE - 1 ), wib = threadIdx.x / WAVE;
+  // (the wave's number through readfirstlane: the compiler then KNOWS that "wave 0 only" is uniform control flow — otherwise every
+  //  loop of the walk is compiled as divergent, its counters in vector registers and an exec-mask dance around every branch)
+  const int lane = threadIdx.x & ( WAVE - 1 ), wib = uni( (int)threadIdx.x / WAVE );
   const bool walker = wib == 0;
   const unsigned long long t_start = B.dbg ? wall_clock64() : 0ull;
   const ChainRec* blks = B.blk + ( (size_t)prob * CH_ROWS + row ) * B.n_blk;
@@ -3099,56 +3157,49 @@ __device__ __forceinline__ void chain_walk_row( const IcpLaunch& L, const ChainB
   const int comp = row == 0 ? 3 : ( row <= 3 ? row - 1 : row );      // a record's words: p.xyz at 0..2, dist² at 3, q.xyz at 4..6, dot at 7
   int* dbg = ( B.dbg && threadIdx.x == 0 ) ? B.dbg + ( (size_t)prob * CH_ROWS + row ) * ( 4 + 64 * 8 ) : nullptr;
   auto stamp = [&]( int k ) { if( dbg ) dbg[4 + 63 * 8 + k] = (int)( wall_clock64() - t_start ); };
-  auto load_blocks = [&]( int b0 ) -> ChainRec { ChainRec m; chain_rec_copy( m, blks[min( b0 + lane, B.n_blk - 1 )] ); if( b0 + lane >= B.n_blk ) m.e_sign = -1; return m; };
-  auto load_bsum = [&]( int b ) -> float
-  {
-    const double2* q = reinterpret_cast<const double2*>( qsum + (size_t)min( b, B.n_blk - 1 ) * CH_QUARTERS );
-    const double2 u = q[0], v = q[1];
-    return b < B.n_blk ? (float)( ( u.x + u.y ) + ( v.x + v.y ) ) : 0.0f;
-  };
+  constexpr int CHUNKS_PER_WAVE = CH_SUPER / WAVES_PER_BLOCK, BLKS_PER_WAVE = CH_PRE_BLKS / WAVES_PER_BLOCK, SEGS_PER_WAVE = CH_PRE_SEGS / WAVES_PER_BLOCK;
+  static_assert( CH_SUPER % WAVES_PER_BLOCK == 0 && CH_PRE_BLKS % WAVES_PER_BLOCK == 0 && CH_PRE_SEGS % WAVES_PER_BLOCK == 0, "the rounds' work is dealt to the waves" );
+  static_assert( CH_PRE_BLKS <= WAVE && CH_SUPER <= WAVE, "one lane per fetched block / per chunk" );
 
-  // ---- round 1: block 0's addends, the first 512 blocks' sums and first 64 records, the cut (chain_stats: its loads go out with these)
-  constexpr int X0_PER_WAVE = CH_BLK / WAVES_PER_BLOCK;
-  float v0[X0_PER_WAVE];
-  {
-    const float* x0 = B.x0 + ( (size_t)prob * CH_ROWS + row ) * ( CH_BLK * CH_SEG );
-#pragma unroll
-    for( int g = 0; g < X0_PER_WAVE; ++g ) v0[g] = x0[( wib * X0_PER_WAVE + g ) * CH_SEG + lane];        // (the buffer holds 4 096; what lies past the cloud's end is not used)
-  }
-  float bs[CH_SUPER];
-  ChainRec cur; cur.e_sign = -1;
-  if( walker )
+  float bsl[CHUNKS_PER_WAVE]; ChainRec rc[CHUNKS_PER_WAVE];
+  auto round1_loads = [&]( int B0 )
   {
 #pragma unroll
-    for( int c = 0; c < CH_SUPER; ++c ) bs[c] = load_bsum( c * WAVE + lane );
-    cur = load_blocks( 0 );
-  }
-  const float sd = chain_stats( L, prob, S.stat, nullptr );
+    for( int i = 0; i < CHUNKS_PER_WAVE; ++i )
+    {
+      const int b = B0 + ( wib + i * WAVES_PER_BLOCK ) * WAVE + lane, bc = min( b, B.n_blk - 1 );
+      const double2* q = reinterpret_cast<const double2*>( qsum + (size_t)bc * CH_QUARTERS );
+      const double2 u = q[0], v = q[1];
+      chain_rec_copy( rc[i], blks[bc] );
+      bsl[i] = b < B.n_blk ? (float)( ( u.x + u.y ) + ( v.x + v.y ) ) : 0.0f;
+      if( b >= B.n_blk ) rc[i].e_sign = -1;
+    }
+  };
+  round1_loads( 0 );
+  const float sd = chain_stats( L, prob, S.stat, nullptr );                  // (its loads go out with round 1's)
   ChainPar P; P.use_sd = sd > 0.000001; P.cut = 2.5f * sd; P.max_dist = L.radius;
-#pragma unroll
-  for( int g = 0; g < X0_PER_WAVE; ++g ) S.x0[wib * X0_PER_WAVE + g][lane] = v0[g];
   stamp( 0 );
 
-  auto addend = [&]( int i ) -> float                 // (of a segment that was not fetched ahead)
+  auto addend_of = [&]( float d2, float dt, float cv, bool inside ) -> float        // chain_addends, this chain's
   {
-    const float* rp = Rf + (size_t)min( i, L.src.n - 1 ) * ( REC_F4 * 4 );
-    const float d2 = rp[3], dt = rp[7], cv = rp[comp];
-    const bool mt = d2 >= 0.0f && i < L.src.n;
-    float w = 0.0f;                                     // chain_addends
+    const bool mt = d2 >= 0.0f && inside;
+    float w = 0.0f;
     if( mt ) { w = ( 1.0f - __fdiv_rn( d2, P.max_dist ) ) * dt; if( P.use_sd && d2 > P.cut ) w = 0.0f; }
     return row == 0 ? w : ( mt ? cv * w : 0.0f );
   };
 
   float s = 0.0f;
-  int resolved = 0, stuck = 0, steps = 0, hits = 0;
+  int resolved = 0, stuck = 0, steps = 0, hits = 0, piece_steps = 0, scans = 0;
   // advance over the records held by the lanes [from, count): as far as the value fits; returns the first lane that does not (count: all done)
-  auto advance = [&]( const ChainRec& mine, int from, int count ) -> int
+  // (select( E, sign ): the lane's record as a function for that binade)
+  auto advance = [&]( auto&& select, int from, int count ) -> int
   {
-    const uint32_t sb = __float_as_uint( s );
+    const uint32_t sb = (uint32_t)uni( __float_as_int( s ) );             // (uniform, and the compiler is told so: everything derived from it is scalar work)
     const int E = (int)( ( sb >> 23 ) & 255u ), sg = (int)( sb >> 31 ), M = (int)( sb & 0x7fffffu ) | CH_M_LO;
     const bool mine_in = lane >= from && lane < count;
-    const ChainFn f0 = !mine_in ? chain_identity() : ( ( E == 0 || E == 255 ) ? chain_never() : chain_select( mine, E, sg ) );      // zero, denormal, inf, NaN: one by one
+    const ChainFn f0 = !mine_in ? chain_identity() : ( ( E == 0 || E == 255 ) ? chain_never() : select( E, sg ) );      // zero, denormal, inf, NaN: one by one
     const ChainFn f = chain_prefix( f0, lane );
+    ++scans;
     // records with ties inside (ChainFn): each adds the tau its own start's parity picks — until those are known the most they can add
     const unsigned long long tl = RS_BALLOT( f0.tau != 0 );
     int taumax = 0;
@@ -3171,178 +3222,303 @@ __device__ __forceinline__ void chain_walk_row( const IcpLaunch& L, const ChainB
     }
     return min( stop, count );
   };
+  // one record applied to the value, if it holds it (uniform)
+  auto apply = [&]( const ChainFn& f, int t0, int t1, int tmax ) -> bool
+  {
+    const uint32_t sb = (uint32_t)uni( __float_as_int( s ) );
+    const int M = (int)( sb & 0x7fffffu ) | CH_M_LO;
+    if( !( f.lo <= f.hi && M >= f.lo && M + tmax <= f.hi ) ) return false;
+    s = __uint_as_float( ( sb & 0xff800000u ) | ( (uint32_t)( M + f.D + ( ( M & 1 ) ? t1 : t0 ) ) & 0x7fffffu ) );
+    return true;
+  };
+  long long piece_cycles = 0, seg_cycles = 0, flag_cycles = 0, walk_cycles = 0;
+  auto apply_piece = [&]( const ChainPiece& pc, int tp ) -> bool
+  {
+    const long long c0 = dbg ? clock64() : 0;
+    const uint32_t sb = (uint32_t)uni( __float_as_int( s ) );
+    ChainFn f = chain_never();
+    if( pc.es == (int)( sb >> 23 ) ) { f.lo = pc.lo; f.hi = pc.hi; f.D = pc.D; }       // (exponent | sign << 8 = the value's bits >> 23)
+    const bool ok = apply( f, tp & 15, ( tp >> 4 ) & 15, tp >> 8 );
+    if( dbg ) { s = __int_as_float( uni( __float_as_int( s ) ) ); piece_cycles += clock64() - c0; }
+    return ok;
+  };
 
   for( int B0 = 0; B0 < B.n_blk; B0 += CH_SUPER * WAVE )
   {
     const int n_chunks = min( CH_SUPER, ( B.n_blk - B0 + WAVE - 1 ) / WAVE );
-    unsigned long long l_pre = 0ull;      // (wave 0) lane c: the blocks of chunk c whose segment records are in S.seg
-    if( walker )
+    if( B0 > 0 ) round1_loads( B0 );
+    // ---- the forecasts at the blocks' starts: the chunks' totals first ...
+    float incl[CHUNKS_PER_WAVE];
+#pragma unroll
+    for( int i = 0; i < CHUNKS_PER_WAVE; ++i ) { incl[i] = wave_scan_f32( bsl[i] ); if( lane == WAVE - 1 ) S.tot[wib + i * WAVES_PER_BLOCK] = incl[i]; }
+    if( threadIdx.x == 0 ) S.s0 = s;
+    __syncthreads();
+    unsigned long long fm_mine[CHUNKS_PER_WAVE]; float st_mine[CHUNKS_PER_WAVE];
+#pragma unroll
+    for( int i = 0; i < CHUNKS_PER_WAVE; ++i )
     {
-      if( B0 > 0 )
-      {
-#pragma unroll
-        for( int c = 0; c < CH_SUPER; ++c ) bs[c] = load_bsum( B0 + c * WAVE + lane );
-        cur = load_blocks( B0 );
-      }
-      // ---- forecasts at the blocks' starts; the blocks to fetch ahead (lane k: block k's number and the forecast at its start)
-      int l_pblk = -1, n_pre = 0;
-      float l_pst = 0.0f, base = s;
-#pragma unroll
-      for( int c = 0; c < CH_SUPER; ++c )
-        if( c < n_chunks )
-        {
-          const float incl = wave_scan_f32( bs[c] );
-          const float st = base + ( incl - bs[c] ), en = base + incl;
-          const int b = B0 + c * WAVE + lane;
-          unsigned long long m = RS_BALLOT( b < B.n_blk && ( b == 0 || chain_crosses( st, en, CH_EPS ) ) );
-          unsigned long long keep = 0ull;
-          while( m != 0ull && n_pre < CH_PRE_BLKS )
-          {
-            const int bit = __builtin_ctzll( m ); m &= m - 1ull; keep |= 1ull << bit;
-            const float pst = rl( st, bit );
-            if( lane == n_pre ) { l_pblk = B0 + c * WAVE + bit; l_pst = pst; }
-            ++n_pre;
-          }
-          if( lane == c ) l_pre = keep;
-          base += rl( incl, WAVE - 1 );
-        }
-      if( lane < CH_PRE_BLKS ) { S.pblk[lane] = l_pblk; S.pst[lane] = l_pst; }
+      const int c = wib + i * WAVES_PER_BLOCK;
+      float base = S.s0;
+      for( int q = 0; q < c; ++q ) base += S.tot[q];
+      const float st = base + ( incl[i] - bsl[i] ), en = base + incl[i];
+      const int b = B0 + c * WAVE + lane;
+      // ... of a block's record the function for the binade the forecast has at its start (if the value gets there in another: by its segments)
+      const uint32_t vb = __float_as_uint( st );
+      const int El = (int)( ( vb >> 23 ) & 255u ), sgl = (int)( vb >> 31 );
+      const ChainFn f = ( rc[i].e_sign == -1 || El == 0 || El == 255 ) ? chain_never() : chain_select( rc[i], El, sgl );
+      ChainOne one; one.es = (int)( vb >> 23 ); one.lo = f.lo; one.hi = f.hi; one.Dt = f.D * 16 + f.tau;
+      S.ones[c * WAVE + lane] = one; S.bst[c * WAVE + lane] = st;
+      const unsigned long long m = RS_BALLOT( b < B.n_blk && ( b == 0 || chain_crosses( st, en, CH_EPS ) ) );
+      fm_mine[i] = m; st_mine[i] = st;
+      // ... and the runs of blocks between the forecast's crossing blocks as one record each
+      const bool pieces = __builtin_popcountll( m ) < CH_PIECES;
+      if( lane == 0 ) { S.fmask[c] = m; S.bmode[c] = pieces ? 1 : 0; }
+      if( pieces ) chain_pieces( ( b >= B.n_blk || ( ( m >> lane ) & 1ull ) ) ? chain_identity() : f, (int)( vb >> 23 ), m, lane, &S.bpiece[c * WAVE], S.bptau[c] );
     }
-    __syncthreads();                                                      // (S.x0, S.pblk, S.pst)
-    stamp( 1 );
-    // ---- round 2: those blocks' segment records and sums, the forecast by segments inside them (block 0: all of it is in S.x0)
+    __syncthreads();
+    // ---- the blocks to fetch: the first CH_PRE_BLKS of those, in order — every lane knows its block's rank (wave 0's lane c keeps chunk c's)
+    unsigned long long l_pre = 0ull;
     {
-      constexpr int PER = CH_PRE_BLKS / WAVES_PER_BLOCK;
-      ChainRec got[PER]; float sv[PER]; int pb[PER];
+      int before_chunk[CHUNKS_PER_WAVE];
 #pragma unroll
-      for( int i = 0; i < PER; ++i )
+      for( int i = 0; i < CHUNKS_PER_WAVE; ++i )
       {
-        pb[i] = uni( S.pblk[wib * PER + i] );
+        const int c = wib + i * WAVES_PER_BLOCK;
+        int n = 0;
+        for( int q = 0; q < c; ++q ) n += __builtin_popcountll( S.fmask[q] );
+        before_chunk[i] = n;
+        const int rank = n + __builtin_popcountll( fm_mine[i] & below( lane ) );
+        if( ( ( fm_mine[i] >> lane ) & 1ull ) && rank < CH_PRE_BLKS ) { S.pblk[rank] = B0 + c * WAVE + lane; S.pst[rank] = st_mine[i]; }
+      }
+      if( walker )
+      {
+        int n = 0, total = 0;
+        for( int q = 0; q < n_chunks; ++q ) { const int cnt = __builtin_popcountll( S.fmask[q] ); if( q < lane ) n += cnt; total += cnt; }
+        l_pre = lane < n_chunks ? lowest_bits( S.fmask[min( lane, CH_SUPER - 1 )], CH_PRE_BLKS - n ) : 0ull;
+        if( lane >= total && lane < CH_PRE_BLKS ) { S.pblk[lane] = -1; S.pst[lane] = 0.0f; }
+      }
+    }
+    __syncthreads();
+    stamp( 1 );
+    // ---- round 2: those blocks' segment records and sums; the forecast by segments; the pieces
+    {
+      ChainRec got[BLKS_PER_WAVE]; float sv[BLKS_PER_WAVE]; int pb[BLKS_PER_WAVE];
+#pragma unroll
+      for( int i = 0; i < BLKS_PER_WAVE; ++i )
+      {
+        pb[i] = uni( S.pblk[wib * BLKS_PER_WAVE + i] );
         const int sg = max( pb[i], 0 ) * CH_BLK + lane, sgc = min( sg, B.n_seg - 1 );
         chain_rec_copy( got[i], segs[sgc] ); sv[i] = (float)ssum[sgc];
         if( pb[i] < 0 || sg >= B.n_seg ) { got[i].e_sign = -1; sv[i] = 0.0f; }
       }
 #pragma unroll
-      for( int i = 0; i < PER; ++i )
+      for( int i = 0; i < BLKS_PER_WAVE; ++i )
       {
-        const int k = wib * PER + i;
-        chain_rec_copy( S.seg[k][lane], got[i] );
-        const float incl = wave_scan_f32( sv[i] ), st0 = S.pst[k];
-        const unsigned long long m = RS_BALLOT( pb[i] > 0 && pb[i] * CH_BLK + lane < B.n_seg && chain_crosses( st0 + ( incl - sv[i] ), st0 + incl, CH_EPS ) );
-        if( lane == 0 ) S.want[k] = m;
+        const int k = wib * BLKS_PER_WAVE + i;
+        const float incs = wave_scan_f32( sv[i] ), st0 = S.pst[k];
+        const float vst = st0 + ( incs - sv[i] );
+        const bool in = pb[i] >= 0 && pb[i] * CH_BLK + lane < B.n_seg;
+        const unsigned long long m = RS_BALLOT( in && chain_crosses( vst, st0 + incs, CH_EPS ) );
+        const bool pieces = pb[i] >= 0 && __builtin_popcountll( m ) < CH_PIECES;
+        if( lane == 0 ) { S.flag[k] = m; S.mode[k] = pieces ? 1 : 0; }
+        if( pieces )
+        {
+          const uint32_t vb = __float_as_uint( vst );
+          const int El = (int)( ( vb >> 23 ) & 255u ), sgl = (int)( vb >> 31 );
+          const ChainFn f0 = ( !in || ( ( m >> lane ) & 1ull ) ) ? chain_identity() : ( ( El == 0 || El == 255 ) ? chain_never() : chain_select( got[i], El, sgl ) );
+          chain_pieces( f0, (int)( vb >> 23 ), m, lane, S.piece[k], S.ptau[k] );
+        }
       }
     }
-    __syncthreads();                                                      // (S.seg, S.want)
+    __syncthreads();                                                      // (S.flag, S.piece)
     stamp( 2 );
-    // ---- the first CH_PRE_SEGS of the segments the forecasts point at, in order (lane k: those of block k, and their first slot in S.xs)
-    unsigned long long l_segs = 0ull;
+    // ---- the first CH_PRE_SEGS of the segments the forecasts point at, in order: lane k (of every wave) works out block k's share
+    unsigned long long l_segs = 0ull;     // lane k: the segments of fetched block k whose addends and records are in S.xs / S.fseg, from slot l_sbase on
     int l_sbase = 0;
-    if( walker )
     {
-      const unsigned long long l_want = lane < CH_PRE_BLKS ? S.want[lane] : 0ull;
-      int my_seg = 0, k = 0;                                                // lane j: the segment for slot j (none: segment 0, not used)
-      unsigned long long m = rl( l_want, 0 );
-      for( int j = 0; j < CH_PRE_SEGS; ++j )
-      {
-        while( m == 0ull && k < CH_PRE_BLKS - 1 ) { ++k; m = rl( l_want, k ); }
-        if( m == 0ull ) break;
-        const int bit = __builtin_ctzll( m ); m &= m - 1ull;
-        if( lane == k ) l_segs |= 1ull << bit;
-        if( lane == j ) my_seg = uni( S.pblk[k] ) * CH_BLK + bit;
-      }
-      if( lane < CH_PRE_SEGS ) S.at_seg[lane] = my_seg;
-      const uint32_t cnt = (uint32_t)__builtin_popcountll( l_segs );
+      const unsigned long long mine = lane < CH_PRE_BLKS ? S.flag[lane] : 0ull;
+      const uint32_t cnt = (uint32_t)__builtin_popcountll( mine );
       l_sbase = (int)( wave_scan( cnt, lane ) - cnt );
+      l_segs = lowest_bits( mine, CH_PRE_SEGS - l_sbase );
+      if( walker )
+      {
+        const int pbk = lane < CH_PRE_BLKS ? S.pblk[lane] : 0;
+        int slot = l_sbase;
+        for( unsigned long long m = l_segs; m != 0ull; m &= m - 1ull ) S.at_seg[slot++] = pbk * CH_BLK + __builtin_ctzll( m );
+        const int total = __builtin_amdgcn_readlane( l_sbase + (int)__builtin_popcountll( l_segs ), CH_PRE_BLKS - 1 );
+        if( lane >= total && lane < CH_PRE_SEGS ) S.at_seg[lane] = 0;       // (none: segment 0's, not used)
+      }
     }
     __syncthreads();                                                      // (S.at_seg)
-    // ---- round 3: their addends
+    // ---- round 3: their addends and records
     {
-      constexpr int PER = CH_PRE_SEGS / WAVES_PER_BLOCK;
-      float xd[PER], xw[PER], xc[PER]; int at[PER];
+      float xd[SEGS_PER_WAVE], xw[SEGS_PER_WAVE], xc[SEGS_PER_WAVE]; int at[SEGS_PER_WAVE], rw[SEGS_PER_WAVE];
+      constexpr int WORDS = sizeof( ChainRec ) / 4;
 #pragma unroll
-      for( int i = 0; i < PER; ++i )
+      for( int i = 0; i < SEGS_PER_WAVE; ++i )
       {
-        at[i] = uni( S.at_seg[wib * PER + i] ) * CH_SEG + lane;
+        const int sgm = uni( S.at_seg[wib * SEGS_PER_WAVE + i] );
+        at[i] = sgm * CH_SEG + lane;
         const float* rp = Rf + (size_t)min( at[i], L.src.n - 1 ) * ( REC_F4 * 4 );
         xd[i] = rp[3]; xw[i] = rp[7]; xc[i] = rp[comp];
+        rw[i] = reinterpret_cast<const int*>( segs + min( sgm, B.n_seg - 1 ) )[min( lane, WORDS - 1 )];
       }
 #pragma unroll
-      for( int i = 0; i < PER; ++i )
+      for( int i = 0; i < SEGS_PER_WAVE; ++i )
       {
-        const bool mt = xd[i] >= 0.0f && at[i] < L.src.n;
-        float w = 0.0f;                                                   // chain_addends
-        if( mt ) { w = ( 1.0f - __fdiv_rn( xd[i], P.max_dist ) ) * xw[i]; if( P.use_sd && xd[i] > P.cut ) w = 0.0f; }
-        S.xs[wib * PER + i][lane] = row == 0 ? w : ( mt ? xc[i] * w : 0.0f );
+        S.xs[wib * SEGS_PER_WAVE + i][lane] = addend_of( xd[i], xw[i], xc[i], at[i] < L.src.n );
+        if( lane < WORDS ) reinterpret_cast<int*>( &S.fseg[wib * SEGS_PER_WAVE + i] )[lane] = rw[i];
       }
     }
-    __syncthreads();                                                      // (S.xs)
+    __syncthreads();                                                      // (S.xs, S.fseg)
     if( B0 == 0 && dbg ) dbg[1] = (int)( wall_clock64() - t_start );
 
     // ---- the walk
     if( walker && !( stuck & 2 ) )
     {
-      int pre_before = 0;                   // blocks in S.seg from the chunks before this one
+      const long long c_walk = dbg ? clock64() : 0;
+      int pre_before = 0;                   // fetched blocks from the chunks before this one
       for( int c = 0; c < n_chunks && !( stuck & 2 ); ++c )
       {
         const int b0 = B0 + c * WAVE, nb = min( WAVE, B.n_blk - b0 );
-        ChainRec mine; chain_rec_copy( mine, cur );
-        if( c + 1 < n_chunks ) { const ChainRec nx = load_blocks( b0 + WAVE ); chain_rec_copy( cur, nx ); }      // (on its way while this chunk is walked)
+        const ChainOne mine = S.ones[c * WAVE + lane];
         const unsigned long long pre_mask = rl( l_pre, c );
-        int at = 0;
-        while( at < nb && !( stuck & 2 ) )
+        // block b0 + at, which does not fit as a whole (or where the forecast has a crossing): by its segments
+        auto by_segments = [&]( int at )
         {
-          const int at_was = at;
-          if( ++steps > 8 * B.n_seg + 4096 ) { stuck |= 2; break; }       // (a walk takes at most one step per block + two per segment: guards against a loop that does not end)
-          at = advance( mine, at, nb );
-          if( at < at_was ) { stuck |= 1; at = at_was; }      // (cannot happen: the lanes before `at` hold the identity — guards the loop against a wrong scan)
-          if( at >= nb ) break;
-          // block b0 + at does not fit as a whole: by its segments
           const int g0 = ( b0 + at ) * CH_BLK, ns = min( CH_BLK, B.n_seg - g0 );
-          ChainRec smine; smine.e_sign = -1;
-          unsigned long long have = 0ull; int sbase = 0;
+          unsigned long long have = 0ull; int sbase = 0, k = -1;
           const bool ahead = ( pre_mask >> at ) & 1ull;
-          if( ahead )
+          if( ahead ) { k = pre_before + __builtin_popcountll( pre_mask & below( at ) ); have = rl( l_segs, k ); sbase = __builtin_amdgcn_readlane( l_sbase, k ); }
+          // segment g0 + sat: its 64 addends one after the other, in fp32 — the reference's own operations.  From LDS, four at a
+          // time, every lane the same address: 16 reads + 64 adds (by readlane from a register: 64 + 64).
+          auto one_by_one = [&]( int sat )
           {
-            const int k = pre_before + __builtin_popcountll( pre_mask & below( at ) );
-            chain_rec_copy( smine, S.seg[k][lane] ); have = rl( l_segs, k ); sbase = __builtin_amdgcn_readlane( l_sbase, k );
-          }
-          else if( lane < ns ) chain_rec_copy( smine, segs[g0 + lane] );
-          int sat = 0;
-          while( sat < ns )
-          {
-            const int sat_was = sat;
-            if( ++steps > 8 * B.n_seg + 4096 ) { stuck |= 2; break; }
-            sat = advance( smine, sat, ns );
-            if( sat < sat_was ) { stuck |= 1; sat = sat_was; }
-            if( sat >= ns ) break;
-            // segment g0 + sat: its 64 addends one after the other, in fp32 — the reference's own operations
-            const bool in_lds = g0 == 0 || ( ( have >> sat ) & 1ull );
-            if( B.dbg && resolved < 63 )
+            const bool in_lds = ( have >> sat ) & 1ull;
+            if( dbg && resolved < 63 )
             {
-              const uint32_t sb = __float_as_uint( s );
-              const int cls = (int)( ( sb >> 23 ) & 255u ) - ( __builtin_amdgcn_readlane( smine.e_sign, sat ) & 255 ) + 1;
-              const int lo = __builtin_amdgcn_readlane( cls == 0 ? smine.lo[0] : ( cls == 1 ? smine.lo[1] : smine.lo[2] ), sat );
-              const int hi = __builtin_amdgcn_readlane( cls == 0 ? smine.hi[0] : ( cls == 1 ? smine.hi[1] : smine.hi[2] ), sat );
-              if( dbg )
+              int* d = dbg + 4 + resolved * 8;
+              d[0] = g0 + sat; d[1] = __float_as_int( s ); d[2] = ( in_lds ? 1 : 0 ) | ( ahead ? 2 : 0 ); d[3] = 0; d[4] = 0; d[5] = 0; d[7] = (int)( wall_clock64() - t_start );
+            }
+            int slot = sbase + __builtin_popcountll( have & below( sat ) );
+            if( !in_lds )
+            {
+              const int i = ( g0 + sat ) * CH_SEG + lane;
+              const float* rp = Rf + (size_t)min( i, L.src.n - 1 ) * ( REC_F4 * 4 );
+              slot = CH_PRE_SEGS;
+              S.xs[slot][lane] = addend_of( rp[3], rp[7], rp[comp], i < L.src.n );
+              wave_lds_fence();
+            }
+            hits += in_lds ? 1 : 0;
+            const long long c_seq = dbg ? clock64() : 0;
+            const float4* xp = reinterpret_cast<const float4*>( &S.xs[slot][0] );
+            float4 xa[4], xb[4];                                          // (two sets of 16 addends in turn: 32 registers)
+            auto add4 = [&]( const float4* x ) {
+#pragma unroll
+              for( int j = 0; j < 4; ++j ) { s = s + x[j].x; s = s + x[j].y; s = s + x[j].z; s = s + x[j].w; } };
+#pragma unroll
+            for( int j = 0; j < 4; ++j ) { xa[j] = xp[j]; xb[j] = xp[4 + j]; }
+            add4( xa );
+#pragma unroll
+            for( int j = 0; j < 4; ++j ) xa[j] = xp[8 + j];
+            add4( xb );
+#pragma unroll
+            for( int j = 0; j < 4; ++j ) xb[j] = xp[12 + j];
+            add4( xa );
+            add4( xb );
+            if( dbg && resolved < 63 ) { s = __int_as_float( uni( __float_as_int( s ) ) ); dbg[4 + resolved * 8 + 3] = (int)( clock64() - c_seq ); }
+            ++resolved;
+          };
+          // the segments [sat, to) by wave-wide scans of their records (fetched now)
+          auto by_scans = [&]( int sat, int to )
+          {
+            ChainRec smine; smine.e_sign = -1;
+            if( lane < ns ) chain_rec_copy( smine, segs[g0 + lane] );
+            while( sat < to )
+            {
+              const int sat_was = sat;
+              if( ++steps > 8 * B.n_seg + 4096 ) { stuck |= 2; break; }
+              sat = advance( [&]( int E, int sg ) -> ChainFn { return chain_select( smine, E, sg ); }, sat, to );
+              if( sat < sat_was ) { stuck |= 1; sat = sat_was; }
+              if( sat >= to ) break;
+              one_by_one( sat );
+              ++sat;
+            }
+          };
+          int pos = 0;
+          if( ahead && S.mode[k] )
+          {
+            // ... a fetched block: piece by piece, crossing by crossing, one record each
+            const unsigned long long fm = S.flag[k];
+            int pid = 0;
+            while( pos < ns && !( stuck & 2 ) )
+            {
+              if( ++steps > 8 * B.n_seg + 4096 ) { stuck |= 2; break; }
+              if( ( fm >> pos ) & 1ull )
               {
-                int* d = dbg + 4 + resolved * 8;
-                d[0] = g0 + sat; d[1] = (int)sb; d[2] = ( in_lds ? 1 : 0 ) | ( ahead ? 2 : 0 ); d[3] = cls; d[4] = lo; d[5] = hi; d[7] = (int)( wall_clock64() - t_start );
+                if( !( ( have >> pos ) & 1ull ) ) break;                    // (more crossings than S.fseg holds: the rest of the block by scans)
+                const long long c0 = dbg ? clock64() : 0;
+                const uint32_t sb = (uint32_t)uni( __float_as_int( s ) );
+                const int E = (int)( ( sb >> 23 ) & 255u ), sg = (int)( sb >> 31 );
+                ChainRec r; chain_rec_copy( r, S.fseg[sbase + __builtin_popcountll( have & below( pos ) )] );
+                const ChainFn f = ( E == 0 || E == 255 ) ? chain_never() : chain_select( r, E, sg );
+                const bool held = apply( f, chain_tau( f.tau, 0 ), chain_tau( f.tau, 1 ), max( f.tau & 3, f.tau >> 2 ) );
+                if( dbg ) { s = __int_as_float( uni( __float_as_int( s ) ) ); flag_cycles += clock64() - c0; }
+                if( !held ) one_by_one( pos );
+                ++pos; ++pid;
+              }
+              else
+              {
+                const unsigned long long rest = fm >> pos;
+                const int end = min( ns, rest != 0ull ? pos + __builtin_ctzll( rest ) : CH_BLK );
+                if( apply_piece( S.piece[k][end - 1], S.ptau[k][pid] ) ) ++piece_steps; else by_scans( pos, end );
+                pos = end;
               }
             }
-            float xr;
-            if( g0 == 0 ) xr = S.x0[sat][lane];
-            else if( in_lds ) xr = S.xs[sbase + __builtin_popcountll( have & below( sat ) )][lane];
-            else xr = addend( ( g0 + sat ) * CH_SEG + lane );
-            hits += in_lds ? 1 : 0;
-#pragma unroll
-            for( int j = 0; j < CH_SEG; ++j ) s = s + __int_as_float( __builtin_amdgcn_readlane( __float_as_int( xr ), j ) );      // (fully unrolled: lane numbers as immediates, the reads ahead of the chain of adds)
-            s = __int_as_float( uni( __float_as_int( s ) ) );
-            ++resolved; ++sat;
           }
-          ++at;
+          if( pos < ns ) by_scans( pos, ns );
+        };
+        // the blocks [at, to) by wave-wide scans of their functions
+        auto blocks_by_scans = [&]( int at, int to )
+        {
+          while( at < to && !( stuck & 2 ) )
+          {
+            const int at_was = at;
+            if( ++steps > 8 * B.n_seg + 4096 ) { stuck |= 2; break; }       // (a walk takes at most one step per block + two per segment: guards against a loop that does not end)
+            at = advance( [&]( int E, int sg ) -> ChainFn { return chain_one_fn( mine, E, sg ); }, at, to );
+            if( at < at_was ) { stuck |= 1; at = at_was; }      // (cannot happen: the lanes before `at` hold the identity — guards the loop against a wrong scan)
+            if( at >= to ) break;
+            by_segments( at );
+            ++at;
+          }
+        };
+        if( S.bmode[c] )
+        {
+          // the chunk run by run, crossing block by crossing block
+          const unsigned long long fm = S.fmask[c];
+          int pos = 0, pid = 0;
+          while( pos < nb && !( stuck & 2 ) )
+          {
+            if( ++steps > 8 * B.n_seg + 4096 ) { stuck |= 2; break; }
+            if( ( fm >> pos ) & 1ull )
+            {
+              const long long c0 = dbg ? clock64() : 0;
+              by_segments( pos ); ++pos; ++pid;
+              if( dbg ) { s = __int_as_float( uni( __float_as_int( s ) ) ); seg_cycles += clock64() - c0; }
+            }
+            else
+            {
+              const unsigned long long rest = fm >> pos;
+              const int end = min( nb, rest != 0ull ? pos + __builtin_ctzll( rest ) : WAVE );
+              if( apply_piece( S.bpiece[c * WAVE + end - 1], S.bptau[c][pid] ) ) ++piece_steps; else blocks_by_scans( pos, end );
+              pos = end;
+            }
+          }
         }
+        else blocks_by_scans( 0, nb );
         pre_before += __builtin_popcountll( pre_mask );
       }
+      if( dbg ) { s = __int_as_float( uni( __float_as_int( s ) ) ); walk_cycles += clock64() - c_walk; }
     }
     if( B0 + CH_SUPER * WAVE < B.n_blk ) __syncthreads();                   // (the next round overwrites what this walk read)
   }
@@ -3350,7 +3526,7 @@ __device__ __forceinline__ void chain_walk_row( const IcpLaunch& L, const ChainB
   {
     B.totals[( (size_t)prob * 3 + 1 ) * ICP_NMOM + row] = (double)s;
     if( B.resolved ) atomicAdd( B.resolved + prob, resolved );
-    if( dbg ) { dbg[0] = resolved | ( stuck << 30 ); dbg[2] = hits; dbg[3] = (int)( wall_clock64() - t_start ); }
+    if( dbg ) { dbg[0] = resolved | ( stuck << 30 ) | ( scans << 16 ); dbg[2] = hits | ( piece_steps << 16 ); dbg[3] = (int)( wall_clock64() - t_start ); dbg[4 + 63 * 8 + 3] = (int)piece_cycles; dbg[4 + 63 * 8 + 4] = (int)seg_cycles; dbg[4 + 63 * 8 + 5] = (int)flag_cycles; dbg[4 + 63 * 8 + 6] = (int)walk_cycles; }
   }
 }
 
