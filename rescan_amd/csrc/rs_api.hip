@@ -960,9 +960,9 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
     for( int r = 0; r < CH_ROWS; ++r )
     {
       const int* q = d.data() + (size_t)r * ( 4 + 64 * 8 );
-      fprintf( stderr, "[rs_hip chains] chain %d: %d segments added one by one (%d with their addends fetched ahead), %d pieces taken whole, %d wave-wide scans%s; fetches done after %.2f us, walk after %.2f us\n", r, q[0] & 0xffff, q[2] & 0xffff, q[2] >> 16, ( q[0] >> 16 ) & 0x3fff,
+      fprintf( stderr, "[rs_hip chains] chain %d: %d segments added one by one (%d with their addends fetched ahead), %d steps by one record, %d wave-wide scans%s; fetches done after %.2f us, walk after %.2f us\n", r, q[0] & 0xffff, q[2] & 0xffff, q[2] >> 16, ( q[0] >> 16 ) & 0x3fff,
                ( q[0] >> 30 ) ? " (STUCK)" : "", q[1] / 100.0, q[3] / 100.0 );
-      fprintf( stderr, "   cut + block 0 after %.2f us, block forecasts after %.2f us, segment records + forecasts after %.2f us; shader cycles: %d the whole walk, %d in the pieces' steps, %d in the crossing blocks (%d of them in their crossing segments' record checks)\n", q[4 + 63 * 8] / 100.0, q[4 + 63 * 8 + 1] / 100.0, q[4 + 63 * 8 + 2] / 100.0, q[4 + 63 * 8 + 6], q[4 + 63 * 8 + 3], q[4 + 63 * 8 + 4], q[4 + 63 * 8 + 5] );
+      fprintf( stderr, "   cut + block 0 after %.2f us, block forecasts after %.2f us, segment records + forecasts after %.2f us; %d shader cycles in the walk itself\n", q[4 + 63 * 8] / 100.0, q[4 + 63 * 8 + 1] / 100.0, q[4 + 63 * 8 + 2] / 100.0, q[4 + 63 * 8 + 3] );
       for( int k = 0; k < std::min( q[0] & 0xffff, 63 ); ++k )
       {
         const int* e = q + 4 + 8 * k; const unsigned sb = (unsigned)e[1];

@@ -160,6 +160,42 @@ __device__ __forceinline__ double wave_sum( double v ) {
   const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane( (int)(uint32_t)( (unsigned long long)r >> 32 ), 63 );
   return __longlong_as_double( (long long)( ( (unsigned long long)hi << 32 ) | lo ) );
 }
+// N sums over the 64 lanes at once, as a butterfly: at every level a lane keeps HALF of its values — lanes with the level's bit clear
+// the even ones, the others the odd ones — and adds its partner's copies of the same; after six levels lane l holds the total of
+// value l (lanes >= N: nothing).  N / 2 + N / 4 + ... exchanges instead of 6 N: a third of the instructions of N wave_sum()s, which
+// was half of all the moments' kernel executed.  Fixed association (partner order 1, 2, 4, 8, 16, 32).
+template <int XOR> __device__ __forceinline__ double lane_xor_d( double v )
+{
+  if( XOR == 1 ) return dpp_d<RS_DPP_QUAD_XOR1, 0xf>( 0.0, v );
+  if( XOR == 2 ) return dpp_d<RS_DPP_QUAD_XOR2, 0xf>( 0.0, v );
+  if( XOR == 32 ) return __shfl_xor( v, 32 );
+  const long long x = __double_as_longlong( v );
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_swizzle( (int)(uint32_t)x, ( XOR << 10 ) | 0x1f );
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_swizzle( (int)(uint32_t)( (unsigned long long)x >> 32 ), ( XOR << 10 ) | 0x1f );
+  return __longlong_as_double( (long long)( ( (unsigned long long)hi << 32 ) | lo ) );
+}
+template <int XOR, int N>
+__device__ __forceinline__ void wave_sums_level( const double ( &a )[N], double ( &o )[( N + 1 ) / 2], int lane )
+{
+  const bool upper = ( lane & XOR ) != 0;
+#pragma unroll
+  for( int j = 0; j < ( N + 1 ) / 2; ++j )
+  {
+    const double lo = a[2 * j], hi = 2 * j + 1 < N ? a[2 * j + 1] : 0.0;
+    const double keep = upper ? hi : lo, send = upper ? lo : hi;
+    o[j] = keep + lane_xor_d<XOR>( send );
+  }
+}
+template <int N>
+__device__ __forceinline__ double wave_sums( const double ( &a )[N], int lane )
+{
+  static_assert( N <= WAVE && N > 32, "six levels" );
+  constexpr int N1 = ( N + 1 ) / 2, N2 = ( N1 + 1 ) / 2, N3 = ( N2 + 1 ) / 2, N4 = ( N3 + 1 ) / 2, N5 = ( N4 + 1 ) / 2;
+  double b[N1], c[N2], d[N3], e[N4], f[N5], g[1];
+  wave_sums_level<1>( a, b, lane ); wave_sums_level<2>( b, c, lane ); wave_sums_level<4>( c, d, lane );
+  wave_sums_level<8>( d, e, lane ); wave_sums_level<16>( e, f, lane ); wave_sums_level<32>( f, g, lane );
+  return g[0];
+}
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ unsigned long long dpp_u64( unsigned long long v )
 {
@@ -2772,8 +2808,7 @@ __device__ __forceinline__ void chain_moments_block( const IcpLaunch& L, const C
     acc[31] += W * n[0] * e; acc[32] += W * n[1] * e; acc[33] += W * n[2] * e;
     acc[34] += W * e * e;
   }
-#pragma unroll
-  for( int k = 0; k < ICP_NMOM; ++k ) { double v = wave_sum( acc[k] ); if( lane == 0 ) S.red[wib][k] = v; }
+  { const double v = wave_sums( acc, lane ); if( lane < ICP_NMOM ) S.red[wib][lane] = v; }
   if( lane == 0 ) { for( int r = 0; r < CH_ROWS; ++r ) S.bsum[wib][r] = bs[r]; }
   __syncthreads();
   if( threadIdx.x < ICP_NMOM )
@@ -2810,7 +2845,7 @@ __global__ __launch_bounds__( BLOCK ) void k_chain_moments( IcpLaunch L, ChainBu
 // even, whatever it was: later ties of the same record are decided.  So a record with ties is  M -> M + D + tau[ M & 1 ]  with two
 // small numbers tau[0], tau[1] (a segment: { c, 1 - c }; a block: composed, chain_compose) — kept in the low four bits of the D
 // word — and its interval is narrowed by max tau.  The scans below take D alone; whoever applies a run of records adds, in order,
-// the tau each start's parity picks (advance in chain_walk_row, k_chain_compose), having left room for the most they can add.
+// the tau each start's parity picks (advance in chain_walk_row, chain_compose_block), having left room for the most they can add.
 struct ChainFn { int lo, hi, D, tau; };
 __device__ __forceinline__ ChainFn chain_never() { ChainFn f; f.lo = CH_M_HI; f.hi = CH_M_LO; f.D = 0; f.tau = 0; return f; }
 __device__ __forceinline__ ChainFn chain_identity() { ChainFn f; f.lo = CH_M_LO; f.hi = CH_M_HI; f.D = 0; f.tau = 0; return f; }
@@ -2886,35 +2921,103 @@ __global__ __launch_bounds__( CH_ROWS * WAVE ) void k_chain_guess( IcpLaunch L, 
   chain_guess_block( L, B, prob, blockIdx.x, CH_ROWS );
 }
 
+// The block records: a block's 64 segment records composed per chain and exponent (around the block's first guess), and the quarter
+// blocks' sums of the segments' (the walks' forecasts, the next guesses).
+typedef ChainRec ChainBlockLds[CH_ROWS][CH_BLK];
+__device__ __forceinline__ void chain_compose_block( const ChainBufs& B, int prob, int blk, ChainBlockLds& s_rec )
+{
+  const int lane = threadIdx.x & ( WAVE - 1 ), wib = uni( (int)threadIdx.x / WAVE ), n_waves = blockDim.x / WAVE;
+  {
+    constexpr int WORDS = sizeof( ChainRec ) / 4;
+    const int n_here = min( CH_BLK, B.n_seg - blk * CH_BLK );
+    for( int r = 0; r < CH_ROWS; ++r )
+    {
+      const int* src = reinterpret_cast<const int*>( B.seg + ( (size_t)prob * CH_ROWS + r ) * B.n_seg + (size_t)blk * CH_BLK );
+      int* dst = reinterpret_cast<int*>( &s_rec[r][0] );
+      for( int k = threadIdx.x; k < CH_BLK * WORDS; k += blockDim.x ) dst[k] = k < n_here * WORDS ? src[k] : -1;      // (e_sign -1: past the end of the cloud)
+    }
+  }
+  if( threadIdx.x < CH_ROWS * CH_QUARTERS )
+  {
+    const int r = threadIdx.x / CH_QUARTERS, q = threadIdx.x % CH_QUARTERS;
+    const double* ss = B.segsum + ( (size_t)prob * CH_ROWS + r ) * B.n_seg;
+    constexpr int SEGS = CH_BLK / CH_QUARTERS;
+    double v = 0.0;
+    for( int k = 0; k < SEGS; ++k ) { const int seg = blk * CH_BLK + q * SEGS + k; if( seg < B.n_seg ) v += ss[seg]; }
+    B.blksum[( (size_t)prob * CH_ROWS + r ) * ( B.n_blk * CH_QUARTERS ) + blk * CH_QUARTERS + q] = v;
+  }
+  __syncthreads();
+  for( int job = wib; job < CH_ROWS * 3; job += n_waves )
+  {
+    const int r = job / 3, c = job % 3;
+    const int first = s_rec[r][0].e_sign;
+    const int E = ( first & 255 ) - 1 + c, sg = first >> 8;
+    const ChainRec mine = s_rec[r][lane];
+    const ChainFn f0 = mine.e_sign == -1 ? chain_identity() : chain_select( mine, E, sg );
+    ChainFn f = chain_prefix( f0, lane );
+    // the ties inside, in order: what the block adds for an even / an odd start (each record's tau picked by the parity of ITS start)
+    unsigned long long tm = RS_BALLOT( f0.tau != 0 );
+    const int ex = f.D - f0.D;
+    int t0 = 0, t1 = 0, tmax = 0;
+    while( tm != 0ull )
+    {
+      const int k = __builtin_ctzll( tm ); tm &= tm - 1ull;
+      const int exk = __builtin_amdgcn_readlane( ex, k ), tk = __builtin_amdgcn_readlane( f0.tau, k );
+      t0 += chain_tau( tk, exk + t0 ); t1 += chain_tau( tk, 1 + exk + t1 ); tmax += max( tk & 3, tk >> 2 );
+    }
+    if( lane == WAVE - 1 )
+    {
+      ChainRec* out = B.blk + ( (size_t)prob * CH_ROWS + r ) * B.n_blk + blk;
+      if( c == 0 ) out->e_sign = first;
+      const int hi = f.hi - tmax;
+      const bool ok = f.lo <= hi && t0 <= 3 && t1 <= 3;                   // (a never-record has lo > hi already)
+      out->lo[c] = ok ? f.lo : CH_M_HI; out->hi[c] = ok ? hi : CH_M_LO; out->D[c] = ok ? f.D * 16 + t0 + 4 * t1 : 0;
+    }
+  }
+}
+
 // The segment records: a wave stages THREE consecutive segments' addends in LDS (lane = point), then lane = (segment, exponent
 // class, chain) runs down its segment's 64 addends in integers — no cross-lane traffic, 63 records at once.  The guesses are the
 // kept ones (k_chain_guess): between two ICP iterations the sums move by a few per cent at most (the radius shrinks by 5 %, a per
 // cent of the correspondences change), far less than the factor of two a record's three exponents cover.
-#define CHAIN_REC_TASK 3          // segments per wave
+#define CHAIN_REC_TASK 3          // segments per wave and round
+#define CHAIN_REC_ROUNDS 1
 __global__ __launch_bounds__( BLOCK ) void k_chain_segrecs( IcpLaunch L, ChainBufs B )
 {
-  __shared__ float s_x[WAVES_PER_BLOCK][CHAIN_REC_TASK][CH_ROWS][CH_SEG];
+  // (rows of 65: lane = (segment, class, chain) reads row (segment, chain) at column j — with rows of 64 all 21 rows' column j sit in
+  //  ONE bank, a 21-way conflict on every read of the loop below)
+  __shared__ float s_x[WAVES_PER_BLOCK][CHAIN_REC_TASK][CH_ROWS][CH_SEG + 1];
   __shared__ unsigned long long s_stat[WAVES_PER_BLOCK][3];
   const int prob = blockIdx.y;
   if( L.active[prob] == 0 ) return;
   const int lane = threadIdx.x & ( WAVE - 1 ), wib = threadIdx.x / WAVE;
-  const int task = blockIdx.x * WAVES_PER_BLOCK + wib, seg0 = task * CHAIN_REC_TASK;
+  // (CHAIN_REC_ROUNDS tasks per wave, the loads of all first.  One: with two — the second's loads in flight while the first is worked on,
+  //  half as many waves — the launch took 29 us instead of 25: the kernel is bound by its ~1 100 vector instructions per task, not by
+  //  the loads.)
   const float4* R = L.rec + (size_t)prob * L.src.n * REC_F4;
-  float4 A[CHAIN_REC_TASK], Q[CHAIN_REC_TASK];
+  float4 A2[CHAIN_REC_ROUNDS][CHAIN_REC_TASK], Q2[CHAIN_REC_ROUNDS][CHAIN_REC_TASK];
 #pragma unroll
-  for( int q = 0; q < CHAIN_REC_TASK; ++q )               // (the loads first: the cut's reduction below runs while they are in flight)
-  {
-    const int i = ( seg0 + q ) * CH_SEG + lane;
-    A[q] = make_float4( 0.0f, 0.0f, 0.0f, -1.0f ); Q[q] = make_float4( 0.0f, 0.0f, 0.0f, 0.0f );
-    if( seg0 + q < B.n_seg && i < L.src.n ) { A[q] = R[(size_t)i * REC_F4]; Q[q] = R[(size_t)i * REC_F4 + 1]; }
-  }
+  for( int t = 0; t < CHAIN_REC_ROUNDS; ++t )
+#pragma unroll
+    for( int q = 0; q < CHAIN_REC_TASK; ++q )               // (the loads first: the cut's reduction below runs while they are in flight)
+    {
+      const int sg = ( ( blockIdx.x * CHAIN_REC_ROUNDS + t ) * WAVES_PER_BLOCK + wib ) * CHAIN_REC_TASK + q, i = sg * CH_SEG + lane;
+      const size_t ic = (size_t)min( i, L.src.n - 1 );
+      A2[t][q] = R[ic * REC_F4]; Q2[t][q] = R[ic * REC_F4 + 1];
+      if( sg >= B.n_seg || i >= L.src.n ) { A2[t][q] = make_float4( 0.0f, 0.0f, 0.0f, -1.0f ); Q2[t][q] = make_float4( 0.0f, 0.0f, 0.0f, 0.0f ); }
+    }
   const float sd = chain_stats( L, prob, s_stat, nullptr );                  // (its own: in the iterations that keep their guesses this kernel runs BEFORE the moments)
   ChainPar P; P.use_sd = sd > 0.000001; P.cut = 2.5f * sd; P.max_dist = L.radius;
+#pragma unroll
+  for( int t = 0; t < CHAIN_REC_ROUNDS; ++t )
+  {
+  const int task = ( blockIdx.x * CHAIN_REC_ROUNDS + t ) * WAVES_PER_BLOCK + wib, seg0 = task * CHAIN_REC_TASK;
+  if( t > 0 ) wave_lds_fence();                                              // (the round before has read its rows)
 #pragma unroll
   for( int q = 0; q < CHAIN_REC_TASK; ++q )
   {
     float x[CH_ROWS], w;
-    chain_addends( A[q], Q[q], P, x, w );
+    chain_addends( A2[t][q], Q2[t][q], P, x, w );
 #pragma unroll
     for( int r = 0; r < CH_ROWS; ++r )
     {
@@ -2925,7 +3028,8 @@ __global__ __launch_bounds__( BLOCK ) void k_chain_segrecs( IcpLaunch L, ChainBu
   const int q = lane / ( CH_ROWS * 3 ), combo = lane % ( CH_ROWS * 3 );
   const int r = combo % CH_ROWS, c = combo / CH_ROWS;
   const int seg = seg0 + q;
-  if( q >= CHAIN_REC_TASK || seg >= B.n_seg ) return;
+  if( q < CHAIN_REC_TASK && seg < B.n_seg )
+  {
   const int es = B.guess[( (size_t)prob * CH_ROWS + r ) * B.n_seg + seg];
   const int eg = es & 255, sg = es >> 8;
   const int E = eg - 1 + c;                                            // s = M * 2^(E - 150), M in [2^23, 2^24)
@@ -2981,64 +3085,19 @@ __global__ __launch_bounds__( BLOCK ) void k_chain_segrecs( IcpLaunch L, ChainBu
   ChainRec* out = B.seg + ( (size_t)prob * CH_ROWS + r ) * B.n_seg + seg;
   if( c == 0 ) out->e_sign = es;
   out->lo[c] = ok ? (int)lo : CH_M_HI; out->hi[c] = ok ? (int)hi : CH_M_LO; out->D[c] = ok ? Pj * 16 + ( seen ? ( cpar ? 1 : 4 ) : 0 ) : 0;      // tau = { cpar, 1 - cpar }
+  }
+  }
 }
 
-// The block records: a block's 64 segment records composed per chain and exponent (around the block's first guess).
-#define CHAIN_CMP_WAVES 8
-__global__ __launch_bounds__( CHAIN_CMP_WAVES * WAVE ) void k_chain_compose( IcpLaunch L, ChainBufs B )
+// (One launch per block.  Having the k_chain_segrecs workgroup that completes a block compose it — a counter per block, the last of
+//  its six or seven to arrive — was tried: correct, and 300 us per launch instead of 25 + 11, because the 1 500 workgroups' release
+//  fences each write back their XCD's L2, which the search has just filled with dirty records.)
+__global__ __launch_bounds__( 2 * BLOCK ) void k_chain_compose( IcpLaunch L, ChainBufs B )
 {
-  __shared__ ChainRec s_rec[CH_ROWS][CH_BLK];
-  const int prob = blockIdx.y, blk = blockIdx.x;
+  __shared__ ChainBlockLds s_rec;
+  const int prob = blockIdx.y;
   if( L.active[prob] == 0 ) return;
-  const int lane = threadIdx.x & ( WAVE - 1 ), wib = threadIdx.x / WAVE;
-  {
-    constexpr int WORDS = sizeof( ChainRec ) / 4;
-    const int n_here = min( CH_BLK, B.n_seg - blk * CH_BLK );
-    for( int r = 0; r < CH_ROWS; ++r )
-    {
-      const int* src = reinterpret_cast<const int*>( B.seg + ( (size_t)prob * CH_ROWS + r ) * B.n_seg + (size_t)blk * CH_BLK );
-      int* dst = reinterpret_cast<int*>( &s_rec[r][0] );
-      for( int k = threadIdx.x; k < CH_BLK * WORDS; k += blockDim.x ) dst[k] = k < n_here * WORDS ? src[k] : -1;      // (e_sign -1: past the end of the cloud)
-    }
-  }
-  // ... and the quarter blocks' sums of the segments' (the walks' forecasts, the next guesses)
-  if( threadIdx.x < CH_ROWS * CH_QUARTERS )
-  {
-    const int r = threadIdx.x / CH_QUARTERS, q = threadIdx.x % CH_QUARTERS;
-    const double* ss = B.segsum + ( (size_t)prob * CH_ROWS + r ) * B.n_seg;
-    constexpr int SEGS = CH_BLK / CH_QUARTERS;
-    double v = 0.0;
-    for( int k = 0; k < SEGS; ++k ) { const int seg = blk * CH_BLK + q * SEGS + k; if( seg < B.n_seg ) v += ss[seg]; }
-    B.blksum[( (size_t)prob * CH_ROWS + r ) * ( B.n_blk * CH_QUARTERS ) + blk * CH_QUARTERS + q] = v;
-  }
-  __syncthreads();
-  for( int job = wib; job < CH_ROWS * 3; job += CHAIN_CMP_WAVES )
-  {
-    const int r = job / 3, c = job % 3;
-    const int first = s_rec[r][0].e_sign;
-    const int E = ( first & 255 ) - 1 + c, sg = first >> 8;
-    const ChainRec mine = s_rec[r][lane];
-    const ChainFn f0 = mine.e_sign == -1 ? chain_identity() : chain_select( mine, E, sg );
-    ChainFn f = chain_prefix( f0, lane );
-    // the ties inside, in order: what the block adds for an even / an odd start (each record's tau picked by the parity of ITS start)
-    unsigned long long tm = RS_BALLOT( f0.tau != 0 );
-    const int ex = f.D - f0.D;
-    int t0 = 0, t1 = 0, tmax = 0;
-    while( tm != 0ull )
-    {
-      const int k = __builtin_ctzll( tm ); tm &= tm - 1ull;
-      const int exk = __builtin_amdgcn_readlane( ex, k ), tk = __builtin_amdgcn_readlane( f0.tau, k );
-      t0 += chain_tau( tk, exk + t0 ); t1 += chain_tau( tk, 1 + exk + t1 ); tmax += max( tk & 3, tk >> 2 );
-    }
-    if( lane == WAVE - 1 )
-    {
-      ChainRec* out = B.blk + ( (size_t)prob * CH_ROWS + r ) * B.n_blk + blk;
-      if( c == 0 ) out->e_sign = first;
-      const int hi = f.hi - tmax;
-      const bool ok = f.lo <= hi && t0 <= 3 && t1 <= 3;                   // (a never-record has lo > hi already)
-      out->lo[c] = ok ? f.lo : CH_M_HI; out->hi[c] = ok ? hi : CH_M_LO; out->D[c] = ok ? f.D * 16 + t0 + 4 * t1 : 0;
-    }
-  }
+  chain_compose_block( B, prob, blockIdx.x, s_rec );
 }
 
 // One chain walked by a workgroup of four waves.  `s` (wave 0's, uniform) is the exact running value.
@@ -3066,6 +3125,13 @@ __global__ __launch_bounds__( CHAIN_CMP_WAVES * WAVE ) void k_chain_compose( Icp
 #define CH_PIECE_BIG ( 1 << 27 )
 struct ChainPiece { int es, lo, hi, D; };      // exponent | sign << 8 it is made for; M -> M + D [+ tau: ptau / bptau] for lo <= M <= hi
 struct ChainOne { int es, lo, hi, Dt; };       // a block record's function for one binade: Dt = D * 16 + tau
+// One step of the walk, made ahead: the record of a run of blocks / of a run of segments / of a segment the forecast has a crossing
+// in, for the binade the forecast has there (tp: ChainWalkLds::ptau's form) — and what to fall back on when it does not hold the value:
+// kind = type | chunk << 2 | block in chunk << 5 | from (or the segment) << 11 | to << 17 | slot in S.xs << 24 (63: not fetched)
+enum { CH_IT_BLOCKS = 0, CH_IT_SEGS = 1, CH_IT_SEG = 2, CH_IT_BLOCK = 3 };       // a run of blocks, a run of segments, one segment, one whole block by its segments
+struct ChainItem { int es, lo, hi, D, tp, kind; };
+#define CH_ITEMS 192
+__device__ __forceinline__ int chain_item_kind( int type, int c, int at, int from, int to, int slot ) { return type | ( c << 2 ) | ( at << 5 ) | ( from << 11 ) | ( to << 17 ) | ( slot << 24 ); }
 struct ChainWalkLds
 {
   ChainOne ones[CH_SUPER * WAVE];               // the block records' functions for the forecast binade
@@ -3079,6 +3145,8 @@ struct ChainWalkLds
   unsigned long long stat[WAVES_PER_BLOCK][3], flag[CH_PRE_BLKS], fmask[CH_SUPER];
   int pblk[CH_PRE_BLKS], at_seg[CH_PRE_SEGS], mode[CH_PRE_BLKS], bmode[CH_SUPER];
   float pst[CH_PRE_BLKS], tot[CH_SUPER], s0;
+  ChainItem items[CH_ITEMS];                    // the walk's steps, in order
+  int ctot[CH_SUPER], kbase[CH_PRE_BLKS];       // items per chunk; a fetched block's first item
 };
 // does a chain that goes from a to b (forecasts) change binade on the way, give or take a relative eps?
 __device__ __forceinline__ bool chain_crosses( float a, float b, float eps )
@@ -3113,7 +3181,7 @@ __device__ __forceinline__ ChainFn chain_one_fn( const ChainOne& p, int E, int s
 // The runs of records between the forecast's crossings (the set bits of m; f0 there: the identity), each composed into ONE record
 // for the binade `es` the forecast has there: one segmented scan makes them all — the exclusive prefix of D restarts after every
 // crossing, the prefix max / min carry the piece number in the high bits — and lane l ends up with the record of (the last
-// crossing before l, l].  The ties inside, piece by piece, as k_chain_compose.  (m has fewer than CH_PIECES bits.)
+// crossing before l, l].  The ties inside, piece by piece, as chain_compose_block.  (m has fewer than CH_PIECES bits.)
 __device__ __forceinline__ void chain_pieces( const ChainFn& f0, int es, unsigned long long m, int lane, ChainPiece* out, int* ptau )
 {
   const unsigned long long before = m & below( lane );
@@ -3222,27 +3290,7 @@ __device__ __forceinline__ void chain_walk_row( const IcpLaunch& L, const ChainB
     }
     return min( stop, count );
   };
-  // one record applied to the value, if it holds it (uniform)
-  auto apply = [&]( const ChainFn& f, int t0, int t1, int tmax ) -> bool
-  {
-    const uint32_t sb = (uint32_t)uni( __float_as_int( s ) );
-    const int M = (int)( sb & 0x7fffffu ) | CH_M_LO;
-    if( !( f.lo <= f.hi && M >= f.lo && M + tmax <= f.hi ) ) return false;
-    s = __uint_as_float( ( sb & 0xff800000u ) | ( (uint32_t)( M + f.D + ( ( M & 1 ) ? t1 : t0 ) ) & 0x7fffffu ) );
-    return true;
-  };
-  long long piece_cycles = 0, seg_cycles = 0, flag_cycles = 0, walk_cycles = 0;
-  auto apply_piece = [&]( const ChainPiece& pc, int tp ) -> bool
-  {
-    const long long c0 = dbg ? clock64() : 0;
-    const uint32_t sb = (uint32_t)uni( __float_as_int( s ) );
-    ChainFn f = chain_never();
-    if( pc.es == (int)( sb >> 23 ) ) { f.lo = pc.lo; f.hi = pc.hi; f.D = pc.D; }       // (exponent | sign << 8 = the value's bits >> 23)
-    const bool ok = apply( f, tp & 15, ( tp >> 4 ) & 15, tp >> 8 );
-    if( dbg ) { s = __int_as_float( uni( __float_as_int( s ) ) ); piece_cycles += clock64() - c0; }
-    return ok;
-  };
-
+  long long walk_cycles = 0;
   for( int B0 = 0; B0 < B.n_blk; B0 += CH_SUPER * WAVE )
   {
     const int n_chunks = min( CH_SUPER, ( B.n_blk - B0 + WAVE - 1 ) / WAVE );
@@ -3254,12 +3302,13 @@ __device__ __forceinline__ void chain_walk_row( const IcpLaunch& L, const ChainB
     if( threadIdx.x == 0 ) S.s0 = s;
     __syncthreads();
     unsigned long long fm_mine[CHUNKS_PER_WAVE]; float st_mine[CHUNKS_PER_WAVE];
+    float tot_before;                      // lane c: what the chunks before c add (one read, one scan: a loop of dependent LDS reads costs ~100 cycles a turn)
+    { const float t = lane < CH_SUPER ? S.tot[lane] : 0.0f; tot_before = wave_scan_f32( t ) - t; }
 #pragma unroll
     for( int i = 0; i < CHUNKS_PER_WAVE; ++i )
     {
       const int c = wib + i * WAVES_PER_BLOCK;
-      float base = S.s0;
-      for( int q = 0; q < c; ++q ) base += S.tot[q];
+      const float base = S.s0 + rl( tot_before, c );
       const float st = base + ( incl[i] - bsl[i] ), en = base + incl[i];
       const int b = B0 + c * WAVE + lane;
       // ... of a block's record the function for the binade the forecast has at its start (if the value gets there in another: by its segments)
@@ -3276,27 +3325,20 @@ __device__ __forceinline__ void chain_walk_row( const IcpLaunch& L, const ChainB
       if( pieces ) chain_pieces( ( b >= B.n_blk || ( ( m >> lane ) & 1ull ) ) ? chain_identity() : f, (int)( vb >> 23 ), m, lane, &S.bpiece[c * WAVE], S.bptau[c] );
     }
     __syncthreads();
-    // ---- the blocks to fetch: the first CH_PRE_BLKS of those, in order — every lane knows its block's rank (wave 0's lane c keeps chunk c's)
-    unsigned long long l_pre = 0ull;
+    // ---- the blocks to fetch: the first CH_PRE_BLKS of those, in order — every lane knows its block's rank
+    int flagged_before, flagged_total;     // lane c: the crossing blocks in the chunks before c
     {
-      int before_chunk[CHUNKS_PER_WAVE];
+      const uint32_t cnt = lane < CH_SUPER ? (uint32_t)__builtin_popcountll( S.fmask[lane] ) : 0u;
+      const uint32_t inc = wave_scan( cnt, lane );
+      flagged_before = (int)( inc - cnt ); flagged_total = __builtin_amdgcn_readlane( (int)inc, WAVE - 1 );
 #pragma unroll
       for( int i = 0; i < CHUNKS_PER_WAVE; ++i )
       {
         const int c = wib + i * WAVES_PER_BLOCK;
-        int n = 0;
-        for( int q = 0; q < c; ++q ) n += __builtin_popcountll( S.fmask[q] );
-        before_chunk[i] = n;
-        const int rank = n + __builtin_popcountll( fm_mine[i] & below( lane ) );
+        const int rank = __builtin_amdgcn_readlane( flagged_before, c ) + __builtin_popcountll( fm_mine[i] & below( lane ) );
         if( ( ( fm_mine[i] >> lane ) & 1ull ) && rank < CH_PRE_BLKS ) { S.pblk[rank] = B0 + c * WAVE + lane; S.pst[rank] = st_mine[i]; }
       }
-      if( walker )
-      {
-        int n = 0, total = 0;
-        for( int q = 0; q < n_chunks; ++q ) { const int cnt = __builtin_popcountll( S.fmask[q] ); if( q < lane ) n += cnt; total += cnt; }
-        l_pre = lane < n_chunks ? lowest_bits( S.fmask[min( lane, CH_SUPER - 1 )], CH_PRE_BLKS - n ) : 0ull;
-        if( lane >= total && lane < CH_PRE_BLKS ) { S.pblk[lane] = -1; S.pst[lane] = 0.0f; }
-      }
+      if( walker && lane >= flagged_total && lane < CH_PRE_BLKS ) { S.pblk[lane] = -1; S.pst[lane] = 0.0f; }
     }
     __syncthreads();
     stamp( 1 );
@@ -3350,174 +3392,235 @@ __device__ __forceinline__ void chain_walk_row( const IcpLaunch& L, const ChainB
       }
     }
     __syncthreads();                                                      // (S.at_seg)
-    // ---- round 3: their addends and records
+    // ---- round 3: their addends and records (the loads now; what they bring is put away after the items below, which do not need it)
+    float xd[SEGS_PER_WAVE], xw[SEGS_PER_WAVE], xc[SEGS_PER_WAVE]; int at3[SEGS_PER_WAVE], rw[SEGS_PER_WAVE];
+    constexpr int REC_WORDS = sizeof( ChainRec ) / 4;
+#pragma unroll
+    for( int i = 0; i < SEGS_PER_WAVE; ++i )
     {
-      float xd[SEGS_PER_WAVE], xw[SEGS_PER_WAVE], xc[SEGS_PER_WAVE]; int at[SEGS_PER_WAVE], rw[SEGS_PER_WAVE];
-      constexpr int WORDS = sizeof( ChainRec ) / 4;
+      const int sgm = uni( S.at_seg[wib * SEGS_PER_WAVE + i] );
+      at3[i] = sgm * CH_SEG + lane;
+      const float* rp = Rf + (size_t)min( at3[i], L.src.n - 1 ) * ( REC_F4 * 4 );
+      xd[i] = rp[3]; xw[i] = rp[7]; xc[i] = rp[comp];
+      rw[i] = reinterpret_cast<const int*>( segs + min( sgm, B.n_seg - 1 ) )[min( lane, REC_WORDS - 1 )];
+    }
+    // ---- the walk's steps, in order, one item each (ChainItem): how many per chunk ...
+    auto lanes_below = [&]( int n ) -> unsigned long long { return n >= WAVE ? ~0ull : below( n ); };
+    int it_cnt[CHUNKS_PER_WAVE], it_off[CHUNKS_PER_WAVE], it_k[CHUNKS_PER_WAVE];
 #pragma unroll
-      for( int i = 0; i < SEGS_PER_WAVE; ++i )
+    for( int i = 0; i < CHUNKS_PER_WAVE; ++i )
+    {
+      const int c = wib + i * WAVES_PER_BLOCK, nb = min( WAVE, B.n_blk - ( B0 + c * WAVE ) );
+      const unsigned long long fm = fm_mine[i];
+      const int rank = __builtin_amdgcn_readlane( flagged_before, c ) + __builtin_popcountll( fm & below( lane ) );
+      const bool flagged = ( fm >> lane ) & 1ull, mine_in = lane < nb;
+      int cnt = 0; it_k[i] = -1;
+      if( c < n_chunks && mine_in )
       {
-        const int sgm = uni( S.at_seg[wib * SEGS_PER_WAVE + i] );
-        at[i] = sgm * CH_SEG + lane;
-        const float* rp = Rf + (size_t)min( at[i], L.src.n - 1 ) * ( REC_F4 * 4 );
-        xd[i] = rp[3]; xw[i] = rp[7]; xc[i] = rp[comp];
-        rw[i] = reinterpret_cast<const int*>( segs + min( sgm, B.n_seg - 1 ) )[min( lane, WORDS - 1 )];
+        if( !S.bmode[c] ) cnt = lane == 0 ? 1 : 0;                           // (too many crossings for pieces: the whole chunk by scans)
+        else if( flagged )
+        {
+          cnt = 1;
+          if( rank < CH_PRE_BLKS && S.mode[rank] )
+          {
+            // a fetched block: its crossing segments and the runs between them
+            const int ns = min( CH_BLK, B.n_seg - ( B0 + c * WAVE + lane ) * CH_BLK );
+            const unsigned long long m = S.flag[rank], in = lanes_below( ns );
+            cnt = __builtin_popcountll( m & in ) + __builtin_popcountll( ~m & ( ( m << 1 ) | 1ull ) & in );
+            it_k[i] = rank;
+          }
+        }
+        else cnt = ( lane == nb - 1 || ( ( fm >> ( lane + 1 ) ) & 1ull ) ) ? 1 : 0;     // the last block of a run
       }
+      it_cnt[i] = cnt;
+      const int inc = (int)wave_scan( (uint32_t)cnt, lane );
+      it_off[i] = inc - cnt;
+      if( lane == WAVE - 1 ) S.ctot[c] = inc;
+    }
+    __syncthreads();
+    // ... the runs of blocks and the blocks taken whole; where a fetched block's items start
+    int n_items, items_before;             // lane c: the items of the chunks before c
+    {
+      const uint32_t cnt = lane < CH_SUPER ? (uint32_t)S.ctot[lane] : 0u;
+      const uint32_t inc = wave_scan( cnt, lane );
+      items_before = (int)( inc - cnt ); n_items = __builtin_amdgcn_readlane( (int)inc, WAVE - 1 );
+    }
 #pragma unroll
-      for( int i = 0; i < SEGS_PER_WAVE; ++i )
+    for( int i = 0; i < CHUNKS_PER_WAVE; ++i )
+    {
+      const int c = wib + i * WAVES_PER_BLOCK, nb = min( WAVE, B.n_blk - ( B0 + c * WAVE ) );
+      const int at = __builtin_amdgcn_readlane( items_before, c ) + it_off[i];
+      if( it_cnt[i] > 0 && at < CH_ITEMS )
       {
-        S.xs[wib * SEGS_PER_WAVE + i][lane] = addend_of( xd[i], xw[i], xc[i], at[i] < L.src.n );
-        if( lane < WORDS ) reinterpret_cast<int*>( &S.fseg[wib * SEGS_PER_WAVE + i] )[lane] = rw[i];
+        const unsigned long long fm = fm_mine[i];
+        ChainItem it; it.es = -1; it.lo = CH_M_HI; it.hi = CH_M_LO; it.D = 0; it.tp = 0;
+        if( !S.bmode[c] ) { it.kind = chain_item_kind( CH_IT_BLOCKS, c, 0, 0, nb, 63 ); S.items[at] = it; }
+        else if( ( fm >> lane ) & 1ull )
+        {
+          if( it_k[i] >= 0 ) S.kbase[it_k[i]] = at;
+          else { it.kind = chain_item_kind( CH_IT_BLOCK, c, lane, 0, 0, 63 ); S.items[at] = it; }
+        }
+        else
+        {
+          const unsigned long long before = fm & below( lane );
+          const int from = before != 0ull ? 64 - __builtin_clzll( before ) : 0;
+          const ChainPiece pc = S.bpiece[c * WAVE + lane];
+          it.es = pc.es; it.lo = pc.lo; it.hi = pc.hi; it.D = pc.D; it.tp = S.bptau[c][__builtin_popcountll( before )];
+          it.kind = chain_item_kind( CH_IT_BLOCKS, c, 0, from, lane + 1, 63 );
+          S.items[at] = it;
+        }
       }
     }
-    __syncthreads();                                                      // (S.xs, S.fseg)
+#pragma unroll
+    for( int i = 0; i < SEGS_PER_WAVE; ++i )
+    {
+      S.xs[wib * SEGS_PER_WAVE + i][lane] = addend_of( xd[i], xw[i], xc[i], at3[i] < L.src.n );
+      if( lane < REC_WORDS ) reinterpret_cast<int*>( &S.fseg[wib * SEGS_PER_WAVE + i] )[lane] = rw[i];
+    }
+    __syncthreads();                                                      // (S.xs, S.fseg, S.kbase)
+    // ... and the fetched blocks' own
+#pragma unroll
+    for( int i = 0; i < BLKS_PER_WAVE; ++i )
+    {
+      const int k = wib * BLKS_PER_WAVE + i, pbk = S.pblk[k];
+      if( pbk < 0 || !S.mode[k] ) continue;
+      const int ns = min( CH_BLK, B.n_seg - pbk * CH_BLK ), c = ( pbk - B0 ) / WAVE, at_blk = ( pbk - B0 ) % WAVE;
+      const unsigned long long m = S.flag[k];
+      const bool flagged = ( m >> lane ) & 1ull;
+      const bool run_end = !flagged && ( lane == ns - 1 || ( ( m >> ( lane + 1 ) ) & 1ull ) );
+      const unsigned long long ends = RS_BALLOT( lane < ns && ( flagged || run_end ) );
+      const int at = S.kbase[k] + __builtin_popcountll( ends & below( lane ) );
+      if( ( ( ends >> lane ) & 1ull ) && at < CH_ITEMS )
+      {
+        const unsigned long long have = rl( l_segs, k );
+        const int sbase = __builtin_amdgcn_readlane( l_sbase, k );
+        const ChainPiece pc = S.piece[k][lane];
+        ChainItem it; it.es = pc.es; it.lo = CH_M_HI; it.hi = CH_M_LO; it.D = 0; it.tp = 0;
+        if( flagged )
+        {
+          int slot = 63;
+          if( ( have >> lane ) & 1ull )
+          {
+            slot = sbase + __builtin_popcountll( have & below( lane ) );
+            ChainRec r; chain_rec_copy( r, S.fseg[slot] );
+            const int El = pc.es & 255, sgl = pc.es >> 8;
+            const ChainFn f = ( El == 0 || El == 255 ) ? chain_never() : chain_select( r, El, sgl );
+            it.lo = f.lo; it.hi = f.hi; it.D = f.D; it.tp = chain_tau( f.tau, 0 ) | ( chain_tau( f.tau, 1 ) << 4 ) | ( max( f.tau & 3, f.tau >> 2 ) << 8 );
+          }
+          it.kind = chain_item_kind( CH_IT_SEG, c, at_blk, lane, lane + 1, slot );
+        }
+        else
+        {
+          const unsigned long long before = m & below( lane );
+          const int from = before != 0ull ? 64 - __builtin_clzll( before ) : 0;
+          it.lo = pc.lo; it.hi = pc.hi; it.D = pc.D; it.tp = S.ptau[k][__builtin_popcountll( before )];
+          it.kind = chain_item_kind( CH_IT_SEGS, c, at_blk, from, lane + 1, 63 );
+        }
+        S.items[at] = it;
+      }
+    }
+    __syncthreads();
     if( B0 == 0 && dbg ) dbg[1] = (int)( wall_clock64() - t_start );
 
-    // ---- the walk
+    // ---- the walk: item after item, 64 of them in wave 0's registers at a time; an item that does not hold the value (the forecast
+    // was off, or it is the segment where the chain changes binade) falls back on its own range — addend by addend for a segment,
+    // wave-wide scans of the records for a run
     if( walker && !( stuck & 2 ) )
     {
       const long long c_walk = dbg ? clock64() : 0;
-      int pre_before = 0;                   // fetched blocks from the chunks before this one
-      for( int c = 0; c < n_chunks && !( stuck & 2 ); ++c )
+      // segment g: its 64 addends one after the other, in fp32 — the reference's own operations.  From LDS, four at a time, every
+      // lane the same address: 16 reads + 64 adds (by readlane from a register: 64 + 64).
+      auto one_by_one = [&]( int g, int slot )
       {
-        const int b0 = B0 + c * WAVE, nb = min( WAVE, B.n_blk - b0 );
-        const ChainOne mine = S.ones[c * WAVE + lane];
-        const unsigned long long pre_mask = rl( l_pre, c );
-        // block b0 + at, which does not fit as a whole (or where the forecast has a crossing): by its segments
-        auto by_segments = [&]( int at )
+        if( dbg && resolved < 63 )
         {
-          const int g0 = ( b0 + at ) * CH_BLK, ns = min( CH_BLK, B.n_seg - g0 );
-          unsigned long long have = 0ull; int sbase = 0, k = -1;
-          const bool ahead = ( pre_mask >> at ) & 1ull;
-          if( ahead ) { k = pre_before + __builtin_popcountll( pre_mask & below( at ) ); have = rl( l_segs, k ); sbase = __builtin_amdgcn_readlane( l_sbase, k ); }
-          // segment g0 + sat: its 64 addends one after the other, in fp32 — the reference's own operations.  From LDS, four at a
-          // time, every lane the same address: 16 reads + 64 adds (by readlane from a register: 64 + 64).
-          auto one_by_one = [&]( int sat )
-          {
-            const bool in_lds = ( have >> sat ) & 1ull;
-            if( dbg && resolved < 63 )
-            {
-              int* d = dbg + 4 + resolved * 8;
-              d[0] = g0 + sat; d[1] = __float_as_int( s ); d[2] = ( in_lds ? 1 : 0 ) | ( ahead ? 2 : 0 ); d[3] = 0; d[4] = 0; d[5] = 0; d[7] = (int)( wall_clock64() - t_start );
-            }
-            int slot = sbase + __builtin_popcountll( have & below( sat ) );
-            if( !in_lds )
-            {
-              const int i = ( g0 + sat ) * CH_SEG + lane;
-              const float* rp = Rf + (size_t)min( i, L.src.n - 1 ) * ( REC_F4 * 4 );
-              slot = CH_PRE_SEGS;
-              S.xs[slot][lane] = addend_of( rp[3], rp[7], rp[comp], i < L.src.n );
-              wave_lds_fence();
-            }
-            hits += in_lds ? 1 : 0;
-            const long long c_seq = dbg ? clock64() : 0;
-            const float4* xp = reinterpret_cast<const float4*>( &S.xs[slot][0] );
-            float4 xa[4], xb[4];                                          // (two sets of 16 addends in turn: 32 registers)
-            auto add4 = [&]( const float4* x ) {
-#pragma unroll
-              for( int j = 0; j < 4; ++j ) { s = s + x[j].x; s = s + x[j].y; s = s + x[j].z; s = s + x[j].w; } };
-#pragma unroll
-            for( int j = 0; j < 4; ++j ) { xa[j] = xp[j]; xb[j] = xp[4 + j]; }
-            add4( xa );
-#pragma unroll
-            for( int j = 0; j < 4; ++j ) xa[j] = xp[8 + j];
-            add4( xb );
-#pragma unroll
-            for( int j = 0; j < 4; ++j ) xb[j] = xp[12 + j];
-            add4( xa );
-            add4( xb );
-            if( dbg && resolved < 63 ) { s = __int_as_float( uni( __float_as_int( s ) ) ); dbg[4 + resolved * 8 + 3] = (int)( clock64() - c_seq ); }
-            ++resolved;
-          };
-          // the segments [sat, to) by wave-wide scans of their records (fetched now)
-          auto by_scans = [&]( int sat, int to )
-          {
-            ChainRec smine; smine.e_sign = -1;
-            if( lane < ns ) chain_rec_copy( smine, segs[g0 + lane] );
-            while( sat < to )
-            {
-              const int sat_was = sat;
-              if( ++steps > 8 * B.n_seg + 4096 ) { stuck |= 2; break; }
-              sat = advance( [&]( int E, int sg ) -> ChainFn { return chain_select( smine, E, sg ); }, sat, to );
-              if( sat < sat_was ) { stuck |= 1; sat = sat_was; }
-              if( sat >= to ) break;
-              one_by_one( sat );
-              ++sat;
-            }
-          };
-          int pos = 0;
-          if( ahead && S.mode[k] )
-          {
-            // ... a fetched block: piece by piece, crossing by crossing, one record each
-            const unsigned long long fm = S.flag[k];
-            int pid = 0;
-            while( pos < ns && !( stuck & 2 ) )
-            {
-              if( ++steps > 8 * B.n_seg + 4096 ) { stuck |= 2; break; }
-              if( ( fm >> pos ) & 1ull )
-              {
-                if( !( ( have >> pos ) & 1ull ) ) break;                    // (more crossings than S.fseg holds: the rest of the block by scans)
-                const long long c0 = dbg ? clock64() : 0;
-                const uint32_t sb = (uint32_t)uni( __float_as_int( s ) );
-                const int E = (int)( ( sb >> 23 ) & 255u ), sg = (int)( sb >> 31 );
-                ChainRec r; chain_rec_copy( r, S.fseg[sbase + __builtin_popcountll( have & below( pos ) )] );
-                const ChainFn f = ( E == 0 || E == 255 ) ? chain_never() : chain_select( r, E, sg );
-                const bool held = apply( f, chain_tau( f.tau, 0 ), chain_tau( f.tau, 1 ), max( f.tau & 3, f.tau >> 2 ) );
-                if( dbg ) { s = __int_as_float( uni( __float_as_int( s ) ) ); flag_cycles += clock64() - c0; }
-                if( !held ) one_by_one( pos );
-                ++pos; ++pid;
-              }
-              else
-              {
-                const unsigned long long rest = fm >> pos;
-                const int end = min( ns, rest != 0ull ? pos + __builtin_ctzll( rest ) : CH_BLK );
-                if( apply_piece( S.piece[k][end - 1], S.ptau[k][pid] ) ) ++piece_steps; else by_scans( pos, end );
-                pos = end;
-              }
-            }
-          }
-          if( pos < ns ) by_scans( pos, ns );
-        };
-        // the blocks [at, to) by wave-wide scans of their functions
-        auto blocks_by_scans = [&]( int at, int to )
-        {
-          while( at < to && !( stuck & 2 ) )
-          {
-            const int at_was = at;
-            if( ++steps > 8 * B.n_seg + 4096 ) { stuck |= 2; break; }       // (a walk takes at most one step per block + two per segment: guards against a loop that does not end)
-            at = advance( [&]( int E, int sg ) -> ChainFn { return chain_one_fn( mine, E, sg ); }, at, to );
-            if( at < at_was ) { stuck |= 1; at = at_was; }      // (cannot happen: the lanes before `at` hold the identity — guards the loop against a wrong scan)
-            if( at >= to ) break;
-            by_segments( at );
-            ++at;
-          }
-        };
-        if( S.bmode[c] )
-        {
-          // the chunk run by run, crossing block by crossing block
-          const unsigned long long fm = S.fmask[c];
-          int pos = 0, pid = 0;
-          while( pos < nb && !( stuck & 2 ) )
-          {
-            if( ++steps > 8 * B.n_seg + 4096 ) { stuck |= 2; break; }
-            if( ( fm >> pos ) & 1ull )
-            {
-              const long long c0 = dbg ? clock64() : 0;
-              by_segments( pos ); ++pos; ++pid;
-              if( dbg ) { s = __int_as_float( uni( __float_as_int( s ) ) ); seg_cycles += clock64() - c0; }
-            }
-            else
-            {
-              const unsigned long long rest = fm >> pos;
-              const int end = min( nb, rest != 0ull ? pos + __builtin_ctzll( rest ) : WAVE );
-              if( apply_piece( S.bpiece[c * WAVE + end - 1], S.bptau[c][pid] ) ) ++piece_steps; else blocks_by_scans( pos, end );
-              pos = end;
-            }
-          }
+          int* d = dbg + 4 + resolved * 8;
+          d[0] = g; d[1] = __float_as_int( s ); d[2] = slot < CH_PRE_SEGS ? 3 : 0; d[3] = 0; d[7] = (int)( wall_clock64() - t_start );
         }
-        else blocks_by_scans( 0, nb );
-        pre_before += __builtin_popcountll( pre_mask );
+        hits += slot < CH_PRE_SEGS ? 1 : 0;
+        if( slot >= CH_PRE_SEGS )
+        {
+          const int i = g * CH_SEG + lane;
+          const float* rp = Rf + (size_t)min( i, L.src.n - 1 ) * ( REC_F4 * 4 );
+          slot = CH_PRE_SEGS;
+          S.xs[slot][lane] = addend_of( rp[3], rp[7], rp[comp], i < L.src.n );
+          wave_lds_fence();
+        }
+        const float4* xp = reinterpret_cast<const float4*>( &S.xs[slot][0] );
+        float4 xa[4], xb[4];                                          // (two sets of 16 addends in turn: 32 registers)
+        auto add4 = [&]( const float4* x ) {
+#pragma unroll
+          for( int j = 0; j < 4; ++j ) { s = s + x[j].x; s = s + x[j].y; s = s + x[j].z; s = s + x[j].w; } };
+#pragma unroll
+        for( int j = 0; j < 4; ++j ) { xa[j] = xp[j]; xb[j] = xp[4 + j]; }
+        add4( xa );
+#pragma unroll
+        for( int j = 0; j < 4; ++j ) xa[j] = xp[8 + j];
+        add4( xb );
+#pragma unroll
+        for( int j = 0; j < 4; ++j ) xb[j] = xp[12 + j];
+        add4( xa );
+        add4( xb );
+        ++resolved;
+      };
+      // the segments [sat, to) of the block that starts at segment g0 by wave-wide scans of their records (fetched now)
+      auto segs_by_scans = [&]( int g0, int sat, int to )
+      {
+        const int ns = min( CH_BLK, B.n_seg - g0 );
+        ChainRec smine; smine.e_sign = -1;
+        if( lane < ns ) chain_rec_copy( smine, segs[g0 + lane] );
+        while( sat < to )
+        {
+          const int sat_was = sat;
+          if( ++steps > 8 * B.n_seg + 4096 ) { stuck |= 2; break; }       // (a walk takes at most one step per block + two per segment: guards against a loop that does not end)
+          sat = advance( [&]( int E, int sg ) -> ChainFn { return chain_select( smine, E, sg ); }, sat, to );
+          if( sat < sat_was ) { stuck |= 1; sat = sat_was; }              // (cannot happen: the lanes before `sat` hold the identity — guards the loop against a wrong scan)
+          if( sat >= to ) break;
+          one_by_one( g0 + sat, 63 );
+          ++sat;
+        }
+      };
+      // the blocks [at, to) of chunk c by wave-wide scans of their functions
+      auto blocks_by_scans = [&]( int c, int at, int to )
+      {
+        const ChainOne mine = S.ones[c * WAVE + lane];
+        while( at < to && !( stuck & 2 ) )
+        {
+          const int at_was = at;
+          if( ++steps > 8 * B.n_seg + 4096 ) { stuck |= 2; break; }
+          at = advance( [&]( int E, int sg ) -> ChainFn { return chain_one_fn( mine, E, sg ); }, at, to );
+          if( at < at_was ) { stuck |= 1; at = at_was; }
+          if( at >= to ) break;
+          const int g0 = ( B0 + c * WAVE + at ) * CH_BLK;
+          segs_by_scans( g0, 0, min( CH_BLK, B.n_seg - g0 ) );
+          ++at;
+        }
+      };
+      for( int i0 = 0; i0 < min( n_items, CH_ITEMS ) && !( stuck & 2 ); i0 += WAVE )
+      {
+        const ChainItem mine = S.items[min( i0 + lane, CH_ITEMS - 1 )];
+        const int n_here = min( WAVE, min( n_items, CH_ITEMS ) - i0 );
+        for( int i = 0; i < n_here && !( stuck & 2 ); ++i )
+        {
+          const uint32_t sb = (uint32_t)uni( __float_as_int( s ) );
+          const int M = (int)( sb & 0x7fffffu ) | CH_M_LO;
+          const int es = __builtin_amdgcn_readlane( mine.es, i ), lo = __builtin_amdgcn_readlane( mine.lo, i ), hi = __builtin_amdgcn_readlane( mine.hi, i );
+          const int D = __builtin_amdgcn_readlane( mine.D, i ), tp = __builtin_amdgcn_readlane( mine.tp, i ), kind = __builtin_amdgcn_readlane( mine.kind, i );
+          if( es == (int)( sb >> 23 ) && lo <= hi && M >= lo && M + ( tp >> 8 ) <= hi )
+          {
+            s = __uint_as_float( ( sb & 0xff800000u ) | ( (uint32_t)( M + D + ( ( M & 1 ) ? ( tp >> 4 ) & 15 : tp & 15 ) ) & 0x7fffffu ) );
+            ++piece_steps;
+            continue;
+          }
+          const int type = kind & 3, c = ( kind >> 2 ) & 7, at = ( kind >> 5 ) & 63, from = ( kind >> 11 ) & 63, to = ( kind >> 17 ) & 127, slot = ( kind >> 24 ) & 63;
+          const int g0 = ( B0 + c * WAVE + at ) * CH_BLK;
+          if( type == CH_IT_SEG ) one_by_one( g0 + from, slot );
+          else if( type == CH_IT_SEGS ) segs_by_scans( g0, from, to );
+          else if( type == CH_IT_BLOCK ) segs_by_scans( g0, 0, min( CH_BLK, B.n_seg - g0 ) );
+          else blocks_by_scans( c, from, to );
+        }
       }
+      if( n_items > CH_ITEMS ) stuck |= 2;                                   // (cannot happen: at most 8 x ( 16 + 16 ) + 12 x 31 ... see the static_assert)
       if( dbg ) { s = __int_as_float( uni( __float_as_int( s ) ) ); walk_cycles += clock64() - c_walk; }
     }
     if( B0 + CH_SUPER * WAVE < B.n_blk ) __syncthreads();                   // (the next round overwrites what this walk read)
@@ -3526,7 +3629,7 @@ __device__ __forceinline__ void chain_walk_row( const IcpLaunch& L, const ChainB
   {
     B.totals[( (size_t)prob * 3 + 1 ) * ICP_NMOM + row] = (double)s;
     if( B.resolved ) atomicAdd( B.resolved + prob, resolved );
-    if( dbg ) { dbg[0] = resolved | ( stuck << 30 ) | ( scans << 16 ); dbg[2] = hits | ( piece_steps << 16 ); dbg[3] = (int)( wall_clock64() - t_start ); dbg[4 + 63 * 8 + 3] = (int)piece_cycles; dbg[4 + 63 * 8 + 4] = (int)seg_cycles; dbg[4 + 63 * 8 + 5] = (int)flag_cycles; dbg[4 + 63 * 8 + 6] = (int)walk_cycles; }
+    if( dbg ) { dbg[0] = resolved | ( stuck << 30 ) | ( scans << 16 ); dbg[2] = hits | ( piece_steps << 16 ); dbg[3] = (int)( wall_clock64() - t_start ); dbg[4 + 63 * 8 + 3] = (int)walk_cycles; }
   }
 }
 
@@ -3558,20 +3661,20 @@ __global__ __launch_bounds__( BLOCK ) void k_chain_walk_and_moments( IcpLaunch L
 void launch_icp_chain_centroids( const IcpLaunch& L, const ChainBufs& B, hipStream_t st )
 {
   const int n_tasks = ( B.n_seg + CHAIN_REC_TASK - 1 ) / CHAIN_REC_TASK;
-  const dim3 rec_grid( ( n_tasks + WAVES_PER_BLOCK - 1 ) / WAVES_PER_BLOCK, L.n_prob );
+  const dim3 rec_grid( ( n_tasks + WAVES_PER_BLOCK * CHAIN_REC_ROUNDS - 1 ) / ( WAVES_PER_BLOCK * CHAIN_REC_ROUNDS ), L.n_prob );
   if( B.refresh )
   {
     // the guesses anew: this iteration's fp64 sums first
     hipLaunchKernelGGL( k_chain_moments, dim3( B.n_blk * CH_QUARTERS, L.n_prob ), dim3( BLOCK ), 0, st, L, B );         // (L.n_mom_blocks == 4 B.n_blk)
     hipLaunchKernelGGL( k_chain_guess, dim3( B.n_blk, L.n_prob ), dim3( CH_ROWS * WAVE ), 0, st, L, B );
     hipLaunchKernelGGL( k_chain_segrecs, rec_grid, dim3( BLOCK ), 0, st, L, B );
-    hipLaunchKernelGGL( k_chain_compose, dim3( B.n_blk, L.n_prob ), dim3( CHAIN_CMP_WAVES * WAVE ), 0, st, L, B );
+    hipLaunchKernelGGL( k_chain_compose, dim3( B.n_blk, L.n_prob ), dim3( 2 * BLOCK ), 0, st, L, B );
     hipLaunchKernelGGL( k_chain_walk, dim3( CH_ROWS, L.n_prob ), dim3( BLOCK ), 0, st, L, B );
   }
   else
   {
     hipLaunchKernelGGL( k_chain_segrecs, rec_grid, dim3( BLOCK ), 0, st, L, B );
-    hipLaunchKernelGGL( k_chain_compose, dim3( B.n_blk, L.n_prob ), dim3( CHAIN_CMP_WAVES * WAVE ), 0, st, L, B );
+    hipLaunchKernelGGL( k_chain_compose, dim3( B.n_blk, L.n_prob ), dim3( 2 * BLOCK ), 0, st, L, B );
     hipLaunchKernelGGL( k_chain_walk_and_moments, dim3( CH_ROWS + B.n_blk * ( CH_QUARTERS + 1 ), L.n_prob ), dim3( BLOCK ), 0, st, L, B );
   }
   hipLaunchKernelGGL( k_icp_update_wide, dim3( ICP_NMOM, L.n_prob ), dim3( BLOCK ), 0, st, L, B.done );                // (centred on the chains' totals: L.exact_centroids)
