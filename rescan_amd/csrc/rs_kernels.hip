@@ -2697,21 +2697,22 @@ void launch_icp_exact_centroids( const IcpLaunch& L, const ReplayBufs& B, hipStr
 // and integer addition is associative.  So for a stretch of addends and an exponent E the whole effect on the chain is three
 // integers: D = Σ rndne( x_i / u ) and the smallest / largest partial sum, which say for which start mantissas M the chain stays
 // inside the binade all the way (a margin of one grid step at the ends keeps clear of the neighbouring binades' grids).  Such
-// records compose (intervals intersect, advances add).  The only sequential part left is the handful of places where the chain
-// really changes binade (~20 times on the way from 0 to 2^21), a tie, or a sign change: there the addends of one segment are
-// added one after the other in fp32.
+// records compose (intervals intersect, advances add).  A tie is part of the record too (ChainFn below: what it adds depends on the
+// parity of the start alone).  The only sequential part left is the handful of places where the chain really changes binade (~15
+// times on the way from 0 to 2^21) or sign: there the addends of one segment are added one after the other in fp32.
 //
-//   the searches    leave one 64-byte record per source point at the point's ORIGINAL index (icp_emit);
-//   k_chain_moments the fp64 moments of k_icp_moments, read from those records in the reference's order, + the fp64 sums of the
-//                   seven chains' addends per segment of 64 points and per block of 64 segments;
-//   k_chain_guess   the fp64 prefix at a segment's start is a guess of the running sum there — good enough for its EXPONENT (the
-//                   fp32 chain itself drifts by parts in a thousand; records are made for e-1, e, e+1); made every 8th
-//                   iteration and kept in between (then nothing below waits for the moments);
-//   k_chain_segrecs one record per (segment, chain);  k_chain_compose: a block's 64 composed;
-//   k_chain_walk    one wave per chain walks the blocks with the exact value: a wave-wide scan composes 64 block records at a
-//                   time and finds the first one the value does not fit; that block is walked by its segments the same way, the
-//                   segment that does not fit is added up addend by addend;
-//   k_icp_update    finishes the iteration (icp.h:253-295,455-493), centred on the chains' centroids.
+//   the searches    leave one 48-byte record per source point at the point's ORIGINAL index (icp_emit);
+//   k_chain_segrecs one record per (segment of 64 points, chain): the functions for the binades e-1, e, e+1 around a guess e of the
+//                   running sum's exponent there, and what the segment adds (the guessed binade's own advance, i.e. the chain's sum
+//                   with its rounding drift — what the walks forecast with);
+//   k_chain_compose a block's 64 segment records composed (per chain and binade), the quarter blocks' sums;
+//   k_chain_walk_and_moments   ONE launch for three things that do not need each other:
+//       the walks   one workgroup per chain (chain_walk_row: forecasts, fetches, the walk proper — ~35 us for a 1 M-point scan);
+//       the moments the fp64 moments of k_icp_moments, read from the records in the reference's order (a quarter block per workgroup);
+//       the guesses for the NEXT iteration's records, from this iteration's sums (k_chain_guess's work, a block per workgroup);
+//   k_icp_update_wide   finishes the iteration (icp.h:253-295,455-493), centred on the chains' centroids.
+// The first iteration has no guesses yet: k_chain_moments (with the segments' fp64 sums) and k_chain_guess run before the records,
+// k_chain_walk alone after them.
 // ------------------------------------------------------------------------------------------
 struct ChainPar { bool use_sd; float cut, max_dist; };
 
