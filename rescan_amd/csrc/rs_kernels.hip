@@ -2856,7 +2856,7 @@ __device__ __forceinline__ ChainFn chain_select( const ChainRec& r, int E, int s
 {
   const int c = E - ( r.e_sign & 255 ) + 1;
   ChainFn f = chain_never();
-  if( ( r.e_sign >> 8 ) == sg )
+  if( ( ( r.e_sign >> 8 ) & 1 ) == sg )
   {
     int d = 0;
     if( c == 0 ) { f.lo = r.lo[0]; f.hi = r.hi[0]; d = r.D[0]; }
@@ -2865,6 +2865,17 @@ __device__ __forceinline__ ChainFn chain_select( const ChainRec& r, int E, int s
     f.D = d >> 4; f.tau = d & 15;
   }
   return f;
+}
+// ... for the binade of the value with the bits vb.  A value of exactly zero has no binade: it stays zero through a stretch whose
+// addends are ALL zero (bit 16 of e_sign — the unmatched points a scan may well begin with; without it every such segment would be
+// added up addend by addend), anything else from there is added one by one (as are denormals, inf and NaN).
+#define CH_ALL_ZERO ( 1 << 16 )
+__device__ __forceinline__ ChainFn chain_fn_for( const ChainRec& r, uint32_t vb )
+{
+  const int E = (int)( ( vb >> 23 ) & 255u ), sg = (int)( vb >> 31 );
+  if( E == 0 ) return ( ( vb << 1 ) == 0u && ( r.e_sign & CH_ALL_ZERO ) ) ? chain_identity() : chain_never();
+  if( E == 255 ) return chain_never();
+  return chain_select( r, E, sg );
 }
 // inclusive prefix max / min over the 64 lanes (signed), like wave_scan: lanes without a source lane keep their own value
 #define RS_DPP_PREFIX( OP, v )                                                              \
@@ -2952,8 +2963,9 @@ __device__ __forceinline__ void chain_compose_block( const ChainBufs& B, int pro
   {
     const int r = job / 3, c = job % 3;
     const int first = s_rec[r][0].e_sign;
-    const int E = ( first & 255 ) - 1 + c, sg = first >> 8;
+    const int E = ( first & 255 ) - 1 + c, sg = ( first >> 8 ) & 1;
     const ChainRec mine = s_rec[r][lane];
+    const bool all_zero = RS_BALLOT( mine.e_sign != -1 && !( mine.e_sign & CH_ALL_ZERO ) ) == 0ull;
     const ChainFn f0 = mine.e_sign == -1 ? chain_identity() : chain_select( mine, E, sg );
     ChainFn f = chain_prefix( f0, lane );
     // the ties inside, in order: what the block adds for an even / an odd start (each record's tau picked by the parity of ITS start)
@@ -2969,7 +2981,7 @@ __device__ __forceinline__ void chain_compose_block( const ChainBufs& B, int pro
     if( lane == WAVE - 1 )
     {
       ChainRec* out = B.blk + ( (size_t)prob * CH_ROWS + r ) * B.n_blk + blk;
-      if( c == 0 ) out->e_sign = first;
+      if( c == 0 ) out->e_sign = ( first & 0x1ff ) | ( all_zero ? CH_ALL_ZERO : 0 );
       const int hi = f.hi - tmax;
       const bool ok = f.lo <= hi && t0 <= 3 && t1 <= 3;                   // (a never-record has lo > hi already)
       out->lo[c] = ok ? f.lo : CH_M_HI; out->hi[c] = ok ? hi : CH_M_LO; out->D[c] = ok ? f.D * 16 + t0 + 4 * t1 : 0;
@@ -2988,6 +3000,7 @@ __global__ __launch_bounds__( BLOCK ) void k_chain_segrecs( IcpLaunch L, ChainBu
   // (rows of 65: lane = (segment, class, chain) reads row (segment, chain) at column j — with rows of 64 all 21 rows' column j sit in
   //  ONE bank, a 21-way conflict on every read of the loop below)
   __shared__ float s_x[WAVES_PER_BLOCK][CHAIN_REC_TASK][CH_ROWS][CH_SEG + 1];
+  __shared__ int s_zero[WAVES_PER_BLOCK][CHAIN_REC_TASK][CH_ROWS];           // all 64 addends of (segment, chain) are zero
   __shared__ unsigned long long s_stat[WAVES_PER_BLOCK][3];
   const int prob = blockIdx.y;
   if( L.active[prob] == 0 ) return;
@@ -3023,6 +3036,8 @@ __global__ __launch_bounds__( BLOCK ) void k_chain_segrecs( IcpLaunch L, ChainBu
     for( int r = 0; r < CH_ROWS; ++r )
     {
       s_x[wib][q][r][lane] = x[r];
+      const unsigned long long nz = RS_BALLOT( x[r] != 0.0f );
+      if( lane == 0 ) s_zero[wib][q][r] = nz == 0ull ? CH_ALL_ZERO : 0;
     }
   }
   wave_lds_fence();
@@ -3084,7 +3099,7 @@ __global__ __launch_bounds__( BLOCK ) void k_chain_segrecs( IcpLaunch L, ChainBu
   lo = lo < CH_M_LO ? CH_M_LO : lo; hi = hi > CH_M_HI ? CH_M_HI : hi;
   const bool ok = !bad && lo <= hi;
   ChainRec* out = B.seg + ( (size_t)prob * CH_ROWS + r ) * B.n_seg + seg;
-  if( c == 0 ) out->e_sign = es;
+  if( c == 0 ) out->e_sign = es | s_zero[wib][q][r];
   out->lo[c] = ok ? (int)lo : CH_M_HI; out->hi[c] = ok ? (int)hi : CH_M_LO; out->D[c] = ok ? Pj * 16 + ( seen ? ( cpar ? 1 : 4 ) : 0 ) : 0;      // tau = { cpar, 1 - cpar }
   }
   }
@@ -3152,6 +3167,7 @@ struct ChainWalkLds
 // does a chain that goes from a to b (forecasts) change binade on the way, give or take a relative eps?
 __device__ __forceinline__ bool chain_crosses( float a, float b, float eps )
 {
+  if( a == 0.0f && b == 0.0f ) return false;             // (a chain that has not left zero yet)
   if( !( a * b > 0.0f ) ) return true;                   // zero, a sign change, NaN
   const float lo = fminf( fabsf( a ), fabsf( b ) ) * ( 1.0f - eps ), hi = fmaxf( fabsf( a ), fabsf( b ) ) * ( 1.0f + eps );
   return ( __float_as_uint( lo ) >> 23 ) != ( __float_as_uint( hi ) >> 23 );
@@ -3173,10 +3189,10 @@ __device__ __forceinline__ void chain_rec_copy( ChainRec& d, const ChainRec& r )
 #pragma unroll
   for( int c = 0; c < 3; ++c ) { d.lo[c] = r.lo[c]; d.hi[c] = r.hi[c]; d.D[c] = r.D[c]; }
 }
-__device__ __forceinline__ ChainFn chain_one_fn( const ChainOne& p, int E, int sg )
+__device__ __forceinline__ ChainFn chain_one_fn( const ChainOne& p, uint32_t vb )
 {
   ChainFn f = chain_never();
-  if( p.es == ( E | ( sg << 8 ) ) ) { f.lo = p.lo; f.hi = p.hi; f.D = p.Dt >> 4; f.tau = p.Dt & 15; }
+  if( p.es == (int)( vb >> 23 ) ) { f.lo = p.lo; f.hi = p.hi; f.D = p.Dt >> 4; f.tau = p.Dt & 15; }
   return f;
 }
 // The runs of records between the forecast's crossings (the set bits of m; f0 there: the identity), each composed into ONE record
@@ -3260,13 +3276,13 @@ __device__ __forceinline__ void chain_walk_row( const IcpLaunch& L, const ChainB
   float s = 0.0f;
   int resolved = 0, stuck = 0, steps = 0, hits = 0, piece_steps = 0, scans = 0;
   // advance over the records held by the lanes [from, count): as far as the value fits; returns the first lane that does not (count: all done)
-  // (select( E, sign ): the lane's record as a function for that binade)
+  // (select( value bits ): the lane's record as a function for that value's binade)
   auto advance = [&]( auto&& select, int from, int count ) -> int
   {
     const uint32_t sb = (uint32_t)uni( __float_as_int( s ) );             // (uniform, and the compiler is told so: everything derived from it is scalar work)
-    const int E = (int)( ( sb >> 23 ) & 255u ), sg = (int)( sb >> 31 ), M = (int)( sb & 0x7fffffu ) | CH_M_LO;
+    const int M = (int)( sb & 0x7fffffu ) | CH_M_LO;
     const bool mine_in = lane >= from && lane < count;
-    const ChainFn f0 = !mine_in ? chain_identity() : ( ( E == 0 || E == 255 ) ? chain_never() : select( E, sg ) );      // zero, denormal, inf, NaN: one by one
+    const ChainFn f0 = !mine_in ? chain_identity() : select( sb );
     const ChainFn f = chain_prefix( f0, lane );
     ++scans;
     // records with ties inside (ChainFn): each adds the tau its own start's parity picks — until those are known the most they can add
@@ -3314,8 +3330,7 @@ __device__ __forceinline__ void chain_walk_row( const IcpLaunch& L, const ChainB
       const int b = B0 + c * WAVE + lane;
       // ... of a block's record the function for the binade the forecast has at its start (if the value gets there in another: by its segments)
       const uint32_t vb = __float_as_uint( st );
-      const int El = (int)( ( vb >> 23 ) & 255u ), sgl = (int)( vb >> 31 );
-      const ChainFn f = ( rc[i].e_sign == -1 || El == 0 || El == 255 ) ? chain_never() : chain_select( rc[i], El, sgl );
+      const ChainFn f = rc[i].e_sign == -1 ? chain_never() : chain_fn_for( rc[i], vb );
       ChainOne one; one.es = (int)( vb >> 23 ); one.lo = f.lo; one.hi = f.hi; one.Dt = f.D * 16 + f.tau;
       S.ones[c * WAVE + lane] = one; S.bst[c * WAVE + lane] = st;
       const unsigned long long m = RS_BALLOT( b < B.n_blk && ( b == 0 || chain_crosses( st, en, CH_EPS ) ) );
@@ -3367,8 +3382,7 @@ __device__ __forceinline__ void chain_walk_row( const IcpLaunch& L, const ChainB
         if( pieces )
         {
           const uint32_t vb = __float_as_uint( vst );
-          const int El = (int)( ( vb >> 23 ) & 255u ), sgl = (int)( vb >> 31 );
-          const ChainFn f0 = ( !in || ( ( m >> lane ) & 1ull ) ) ? chain_identity() : ( ( El == 0 || El == 255 ) ? chain_never() : chain_select( got[i], El, sgl ) );
+          const ChainFn f0 = ( !in || ( ( m >> lane ) & 1ull ) ) ? chain_identity() : chain_fn_for( got[i], vb );
           chain_pieces( f0, (int)( vb >> 23 ), m, lane, S.piece[k], S.ptau[k] );
         }
       }
@@ -3504,8 +3518,7 @@ __device__ __forceinline__ void chain_walk_row( const IcpLaunch& L, const ChainB
           {
             slot = sbase + __builtin_popcountll( have & below( lane ) );
             ChainRec r; chain_rec_copy( r, S.fseg[slot] );
-            const int El = pc.es & 255, sgl = pc.es >> 8;
-            const ChainFn f = ( El == 0 || El == 255 ) ? chain_never() : chain_select( r, El, sgl );
+            const ChainFn f = chain_fn_for( r, (uint32_t)pc.es << 23 );
             it.lo = f.lo; it.hi = f.hi; it.D = f.D; it.tp = chain_tau( f.tau, 0 ) | ( chain_tau( f.tau, 1 ) << 4 ) | ( max( f.tau & 3, f.tau >> 2 ) << 8 );
           }
           it.kind = chain_item_kind( CH_IT_SEG, c, at_blk, lane, lane + 1, slot );
@@ -3574,7 +3587,7 @@ __device__ __forceinline__ void chain_walk_row( const IcpLaunch& L, const ChainB
         {
           const int sat_was = sat;
           if( ++steps > 8 * B.n_seg + 4096 ) { stuck |= 2; break; }       // (a walk takes at most one step per block + two per segment: guards against a loop that does not end)
-          sat = advance( [&]( int E, int sg ) -> ChainFn { return chain_select( smine, E, sg ); }, sat, to );
+          sat = advance( [&]( uint32_t vb ) -> ChainFn { return smine.e_sign == -1 ? chain_never() : chain_fn_for( smine, vb ); }, sat, to );
           if( sat < sat_was ) { stuck |= 1; sat = sat_was; }              // (cannot happen: the lanes before `sat` hold the identity — guards the loop against a wrong scan)
           if( sat >= to ) break;
           one_by_one( g0 + sat, 63 );
@@ -3589,7 +3602,7 @@ __device__ __forceinline__ void chain_walk_row( const IcpLaunch& L, const ChainB
         {
           const int at_was = at;
           if( ++steps > 8 * B.n_seg + 4096 ) { stuck |= 2; break; }
-          at = advance( [&]( int E, int sg ) -> ChainFn { return chain_one_fn( mine, E, sg ); }, at, to );
+          at = advance( [&]( uint32_t vb ) -> ChainFn { return chain_one_fn( mine, vb ); }, at, to );
           if( at < at_was ) { stuck |= 1; at = at_was; }
           if( at >= to ) break;
           const int g0 = ( B0 + c * WAVE + at ) * CH_BLK;

@@ -223,6 +223,9 @@ def test_icp_batch_matches_single(capi, gscene, scene_clouds, estimator):
         capi.icp_reference_order_below(prev); capi.icp_replay_below(prev_r)
 
 
+CH_ROWS_TEST = 7
+
+
 def test_exact_centroid_chains_are_the_sequential_sums(capi, gscene, scene_clouds):
     """Sources above the replay threshold centre the fp64 step on the reference's own centroid sums (Σw, Σw·p, Σw·q as
     sequential fp32 chains, icp.h:136-148).  Two implementations of those seven chains — pass 2 of the replay (itself held
@@ -268,6 +271,23 @@ def test_exact_centroid_chains_are_the_sequential_sums(capi, gscene, scene_cloud
                     print(f"{b.n} source points: segments the chain walks added one addend after the other in the last iteration: {capi.icp_replay_redone()}")
             assert (out[1][1] == out[2][1]).all() and out[1][0] == out[2][0] and out[1][2] == out[2][2], n_pts
             a.close(); b.close()
+        # a scan that BEGINS with points that match nothing (a fifth of it moved 50 m away): its chains stay at exactly zero — no
+        # binade — through 1 200 segments; they must be walked through as records, not added up addend by addend
+        s0 = synth.scene_for_point_count(330_000, seed=21, timestep=0)
+        s1 = synth.scene_for_point_count(330_000, seed=21, timestep=1)
+        p1 = s1["points"].copy(); p1[: len(p1) // 5] += np.array([50.0, 0.0, 0.0], np.float32)
+        a, b = capi.Cloud(s0["points"], s0["normals"]), capi.Cloud(p1, s1["normals"])
+        T0 = synth.perturbed_pose(I4, rng, 0.02, 0.01)
+        out = {}
+        for mode in (1, 2):
+            capi.icp_exact_centroids(mode)
+            out[mode] = capi.icp_align(b, a, T0, I4, 0.1, np.deg2rad(60.0), max_iter=6, fixed_iters=True)
+            if mode == 1:
+                redone = capi.icp_replay_redone()
+        assert (out[1][1] == out[2][1]).all() and out[1][0] == out[2][0] and out[1][2] == out[2][2]
+        print(f"{b.n} source points, the first fifth unmatched: segments added one addend after the other over the six iterations: {redone}")
+        assert redone < 6 * CH_ROWS_TEST * 60, redone
+        a.close(); b.close()
     finally:
         capi.icp_reference_order_below(prev); capi.icp_replay_below(prev_r); capi.icp_exact_centroids(prev_c)
 
