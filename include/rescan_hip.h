@@ -125,6 +125,9 @@ int32_t rs_hip_icp_replay_redone( void );
  * moments (faster by the chains' cost, within 1e-4 of the reference in most runs only); on < 0 only reads; environment
  * RS_HIP_EXACT_CENTROIDS.  Returns the previous setting. */
 int32_t rs_hip_icp_exact_centroids( int32_t on );
+/* How many rs_hip_icp_align[_batch] calls the grid chains gave up so far (sums that keep changing binade — coordinates that straddle
+ * the origin in a cancelling order) and ran again with the centroid sums by pass 2 of the replay: same result, ~10x the estimator time. */
+int32_t rs_hip_icp_chains_gave_up( void );
 
 /* Many independent icp_align problems of one (source, target) pair, one per start pose
  * (apps/pose_proposal/main.cpp:190-202 runs exactly this loop): T1s is float[16*n], errs

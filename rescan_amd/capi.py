@@ -41,6 +41,7 @@ SIGNATURES = {
     "rs_hip_icp_replay_below": (C.c_int32, [C.c_int32]),
     "rs_hip_icp_replay_redone": (C.c_int32, []),
     "rs_hip_icp_exact_centroids": (C.c_int32, [C.c_int32]),
+    "rs_hip_icp_chains_gave_up": (C.c_int32, []),
     "rs_hip_icp_align_batch": (C.c_int, [C.c_void_p, C.c_void_p, f32p, C.c_int32, f32p, C.c_float, C.c_float,
                                          C.c_int32, C.c_int32, f32p, i32p]),
     "rs_hip_icp_find_corrs": (C.c_int, [C.c_void_p, C.c_void_p, f32p, f32p, C.c_float, C.c_float,
@@ -242,6 +243,11 @@ def icp_exact_centroids(on=-1):
     """Sources above both thresholds: centre the fp64 step on the reference's own fp32 centroid chains (default on); -1 only
     reads.  Returns the previous setting."""
     return int(load().rs_hip_icp_exact_centroids(int(on)))
+
+
+def icp_chains_gave_up():
+    """Calls the grid chains gave up and the replay's pass 2 redid (include/rescan_hip.h)."""
+    return int(load().rs_hip_icp_chains_gave_up())
 
 
 def icp_replay_redone():

@@ -127,6 +127,7 @@ std::atomic<int> g_ref_order_below{ getenv( "RS_HIP_REF_ORDER_BELOW" ) ? atoi( g
 // distance from the reference is measured (4.7e-5 on the headline workload, 23 of 24 sweep runs under 1e-4).
 // Sources above both thresholds: the fp64 moments, centred on the reference's own fp32 centroid chains (rs_kernels.hip:
 // launch_icp_exact_centroids; rs_math.h: icp_solve).  RS_HIP_EXACT_CENTROIDS=0: plain fp64 moments.
+std::atomic<int> g_chains_gave_up{ 0 };
 std::atomic<int> g_exact_centroids{ getenv( "RS_HIP_EXACT_CENTROIDS" ) ? atoi( getenv( "RS_HIP_EXACT_CENTROIDS" ) ) : 1 };
 std::atomic<int> g_replay_below{ getenv( "RS_HIP_REPLAY_BELOW" ) ? atoi( getenv( "RS_HIP_REPLAY_BELOW" ) ) : 262144 };
 std::mutex g_prof_mutex;
@@ -826,9 +827,14 @@ void icp_set_radius( IcpCtx& cx, float max_dist, float tmin )
 
 extern "C" {
 
-int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* target,
-                            float* T1s, int32_t n, const float* T2, float max_dist, float max_angle,
-                            int32_t max_iter, int32_t fixed_iters, float* errs, int32_t* iters )
+} // extern "C"
+
+namespace {
+enum { ICP_CHAINS_GAVE_UP = -1000 };      // (internal) a centroid chain's walk gave the problem up: again, the seven sums by pass 2 of the replay
+
+int icp_align_batch_impl( const rs_hip_cloud_t* source, const rs_hip_cloud_t* target,
+                          float* T1s, int32_t n, const float* T2, float max_dist, float max_angle,
+                          int32_t max_iter, int32_t fixed_iters, float* errs, int32_t* iters, int centroid_mode )
 {
   int rc = ensure_ready(); if( rc ) return rc;
   if( !T1s || !T2 || !errs ) { set_err( "icp_align: null argument" ); return RS_HIP_E_ARG; }
@@ -840,10 +846,10 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
   if( ( rc = icp_upload_state( cx, T1s, (size_t)n ) ) ) return rc;
   const bool ref_order = source->n <= g_ref_order_below.load();
   const bool replay = !ref_order && source->n <= g_replay_below.load();
-  const bool exact_centroids = !ref_order && !replay && g_exact_centroids.load() != 0;
+  const bool exact_centroids = !ref_order && !replay && centroid_mode != 0;
   ReplayBufs RB{};
   ChainBufs CB{};
-  const bool chains = exact_centroids && g_exact_centroids.load() == 1;      // (2: the same sums through pass 2 of the replay — the cross-check)
+  const bool chains = exact_centroids && centroid_mode == 1;      // (2: the same sums through pass 2 of the replay — the cross-check, and what a problem the chains give up is run with)
   if( ref_order || replay || ( exact_centroids && !chains ) )
   {
     if( ( rc = g_ws.faith.ensure( (size_t)n * FAITH_REC * (size_t)source->n * 4 ) ) ) return rc;
@@ -867,9 +873,9 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
         ( rc = g_ws.ch_guess.ensure( rows * CB.n_seg * 4 ) ) ) return rc;
     CB.segsum = g_ws.ch_segsum.as<double>(); CB.blksum = g_ws.ch_prefix.as<double>(); CB.seg = (ChainRec*)g_ws.ch_seg.p; CB.blk = (ChainRec*)g_ws.ch_blk.p; CB.guess = g_ws.ch_guess.as<int>();
     CB.totals = RB.totals; CB.resolved = RB.redone;
-    if( ( rc = g_ws.ch_done.ensure( (size_t)n * 4 ) ) ) return rc;
-    HIP_TRY( hipMemsetAsync( g_ws.ch_done.p, 0, (size_t)n * 4, g_stream ), RS_HIP_E_RUNTIME );
-    CB.done = g_ws.ch_done.as<int>();
+    if( ( rc = g_ws.ch_done.ensure( (size_t)n * 8 ) ) ) return rc;
+    HIP_TRY( hipMemsetAsync( g_ws.ch_done.p, 0, (size_t)n * 8, g_stream ), RS_HIP_E_RUNTIME );
+    CB.done = g_ws.ch_done.as<int>(); CB.failed = CB.done + n;
     if( getenv( "RS_HIP_CHAIN_DEBUG" ) )
     {
       if( ( rc = g_ws.ch_dbg.ensure( rows * ( 4 + 64 * 8 ) * 4 ) ) ) return rc;
@@ -972,10 +978,33 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
       }
     }
   }
+  if( chains )
+  {
+    std::vector<int> failed( (size_t)n );
+    HIP_TRY( hipMemcpy( failed.data(), CB.failed, (size_t)n * 4, hipMemcpyDeviceToHost ), RS_HIP_E_RUNTIME );
+    for( int p = 0; p < n; ++p ) if( failed[p] ) { g_chains_gave_up.fetch_add( 1 ); return ICP_CHAINS_GAVE_UP; }      // (nothing written to the caller's arrays yet)
+  }
   const int* hIters = (const int*)( hS + np * 33 );
   for( int p = 0; p < n; ++p ) { std::memcpy( T1s + 16 * p, hS + 16 * p, 64 ); errs[p] = hS[np * 34 + p]; if( iters ) iters[p] = hIters[p]; }
   return RS_HIP_OK;
 }
+} // namespace
+
+extern "C" {
+
+int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* target,
+                            float* T1s, int32_t n, const float* T2, float max_dist, float max_angle,
+                            int32_t max_iter, int32_t fixed_iters, float* errs, int32_t* iters )
+{
+  // Scan-sized sources: the reference's centroid sums by the grid chains — which give a problem up when a sum keeps changing
+  // binade (coordinates that straddle the origin in a cancelling order: rs_kernels.hip, chain_walk_row); the batch is then run
+  // again with those sums by pass 2 of the replay: the same bits, 0.9 ms per iteration at a million points instead of 0.09.
+  int rc = icp_align_batch_impl( source, target, T1s, n, T2, max_dist, max_angle, max_iter, fixed_iters, errs, iters, g_exact_centroids.load() );
+  if( rc == ICP_CHAINS_GAVE_UP ) rc = icp_align_batch_impl( source, target, T1s, n, T2, max_dist, max_angle, max_iter, fixed_iters, errs, iters, 2 );
+  return rc;
+}
+
+int32_t rs_hip_icp_chains_gave_up( void ) { return g_chains_gave_up.load(); }
 
 int32_t rs_hip_icp_reference_order_below( int32_t n_points )
 {

@@ -144,6 +144,7 @@ struct ChainBufs
   double*   totals;     // n_prob x 3 x ICP_NMOM (the layout of ReplayBufs::totals; the chains fill [ICP_NMOM + 0..6])
   int*      guess;      // n_prob x CH_ROWS x n_seg : exponent | sign << 8 of the guess at every segment's start, kept from the last refresh
   int       refresh;    // 1: the guesses are made anew from this iteration's fp64 sums (moments before records); 0: the kept ones serve again
+  int*      failed;     // n_prob: a walk gave up (too many binade changes for this method: chain_walk_row) — the host runs the problem again another way
   int*      done;       // n_prob, zero between launches: k_icp_update_wide's count of finished workgroups
   int*      resolved;   // n_prob: segments the walks had to add up one addend after the other (diagnostics)
   int       dbg_reps;   // (RS_HIP_CHAIN_DEBUG=n: k_chain_walk walks n times, the stamps are the last walk's — warm caches)

@@ -3137,6 +3137,7 @@ __global__ __launch_bounds__( 2 * BLOCK ) void k_chain_compose( IcpLaunch L, Cha
 #define CH_PRE_SEGS 32
 #define CH_SUPER 8                 // chunks of 64 blocks per round of forecasts
 #define CH_EPS ( 1.0f / 2048.0f )
+#define CH_BUDGET 192              // segments a walk may add up addend by addend before it gives the problem up (ChainBufs::failed)
 #define CH_PIECES 16               // pieces of a fetched block
 #define CH_PIECE_BIG ( 1 << 27 )
 struct ChainPiece { int es, lo, hi, D; };      // exponent | sign << 8 it is made for; M -> M + D [+ tau: ptau / bptau] for lo <= M <= hi
@@ -3575,7 +3576,7 @@ __device__ __forceinline__ void chain_walk_row( const IcpLaunch& L, const ChainB
         for( int j = 0; j < 4; ++j ) xb[j] = xp[12 + j];
         add4( xa );
         add4( xb );
-        ++resolved;
+        if( ++resolved > CH_BUDGET ) stuck |= 2;
       };
       // the segments [sat, to) of the block that starts at segment g0 by wave-wide scans of their records (fetched now)
       auto segs_by_scans = [&]( int g0, int sat, int to )
@@ -3583,7 +3584,7 @@ __device__ __forceinline__ void chain_walk_row( const IcpLaunch& L, const ChainB
         const int ns = min( CH_BLK, B.n_seg - g0 );
         ChainRec smine; smine.e_sign = -1;
         if( lane < ns ) chain_rec_copy( smine, segs[g0 + lane] );
-        while( sat < to )
+        while( sat < to && !( stuck & 2 ) )
         {
           const int sat_was = sat;
           if( ++steps > 8 * B.n_seg + 4096 ) { stuck |= 2; break; }       // (a walk takes at most one step per block + two per segment: guards against a loop that does not end)
@@ -3634,11 +3635,17 @@ __device__ __forceinline__ void chain_walk_row( const IcpLaunch& L, const ChainB
           else blocks_by_scans( c, from, to );
         }
       }
-      if( n_items > CH_ITEMS ) stuck |= 2;                                   // (cannot happen: at most 8 x ( 16 + 16 ) + 12 x 31 ... see the static_assert)
+      if( n_items > CH_ITEMS ) stuck |= 2;                                   // (more steps than the list holds: hundreds of binade changes in one round)
       if( dbg ) { s = __int_as_float( uni( __float_as_int( s ) ) ); walk_cycles += clock64() - c_walk; }
     }
     if( B0 + CH_SUPER * WAVE < B.n_blk ) __syncthreads();                   // (the next round overwrites what this walk read)
   }
+  // A chain that wanders around zero — coordinates that straddle the origin, summed in an order that keeps cancelling — changes binade
+  // not fifteen times but thousands of times, and every such segment is 64 dependent additions on this one wave: milliseconds.  The
+  // walk gives up after CH_BUDGET of them (or when its list of steps overflows, or a loop guard fires): the problem is marked failed
+  // and inactive — every later launch of the call is a no-op for it — and the host runs it again with the seven sums by pass 2 of
+  // the replay (rs_hip_icp_align_batch), whose speculative segments do not mind.
+  if( threadIdx.x == 0 && ( stuck & 2 ) && B.failed ) { B.failed[prob] = 1; L.active[prob] = 0; }
   if( threadIdx.x == 0 )
   {
     B.totals[( (size_t)prob * 3 + 1 ) * ICP_NMOM + row] = (double)s;

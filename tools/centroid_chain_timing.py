@@ -7,8 +7,14 @@ sys.path.insert(0, ROOT)
 from rescan_amd import capi, synth
 capi.init(0)
 I4 = np.eye(4, dtype=np.float32).ravel()
-for n in [int(a) for a in sys.argv[1:]] or [300_000, 1_170_000]:
+# `centred` as an argument: both scans shifted so that the coordinates straddle zero (the median point at the origin) — chains that wander
+# around zero change binade, and sign, far more often than those of a room in the positive octant
+centred = "centred" in sys.argv[1:]
+for n in [int(a) for a in sys.argv[1:] if a.isdigit()] or [300_000, 1_170_000]:
     s0 = synth.scene_for_point_count(int(n * 0.84), seed=11, timestep=0); s1 = synth.scene_for_point_count(int(n * 0.84), seed=11, timestep=1)
+    if centred:
+        shift = -np.median(s1["points"], axis=0).astype(np.float32)
+        s0["points"] = s0["points"] + shift; s1["points"] = s1["points"] + shift
     a, b = capi.Cloud(s0["points"], s0["normals"]), capi.Cloud(s1["points"], s1["normals"])
     T0 = synth.perturbed_pose(I4, np.random.default_rng(1), 0.01, 0.01)
     capi.icp_reference_order_below(0)
