@@ -84,6 +84,12 @@ __device__ __forceinline__ void wave_lds_fence()
 //   quad_perm [1,0,3,2] / [2,3,0,1]: lane ^ 1, lane ^ 2;  row_half_mirror / row_mirror: reversed within 8 / 16 lanes
 //   (after the quad steps every lane of a row of 16 holds the row's result);  row_bcast:15 into rows 1 and 3, then
 //   row_bcast:31 into rows 2 and 3: lane 63 ends with the whole wave's result and is read back as a scalar.
+// (experiment: -DRS_CHAIN_PRIO=3 raises the issue priority of the ICP chain's waves over a batch kernel's that share their CUs)
+#ifdef RS_CHAIN_PRIO
+#define RS_CHAIN_SETPRIO() __builtin_amdgcn_s_setprio( RS_CHAIN_PRIO )
+#else
+#define RS_CHAIN_SETPRIO()
+#endif
 #define RS_DPP_QUAD_XOR1   0xB1
 #define RS_DPP_QUAD_XOR2   0x4E
 #define RS_DPP_ROW_SHR( n ) ( 0x110 + ( n ) )
@@ -1531,6 +1537,7 @@ __host__ __device__ inline int icp_blocks_per_xcd( int n_tiles ) { return ( ( n_
 template <bool BOUNDED_ONLY>
 __global__ __launch_bounds__( PA_WAVES * WAVE, BOUNDED_ONLY ? RS_ICP_WARM_OCC : RS_ICP_OCC ) void k_icp_corr( IcpLaunch L )
 {
+  RS_CHAIN_SETPRIO();
   __shared__ WaveLds lds[PA_WAVES];
   const int prob = blockIdx.y;
   if( L.active[prob] == 0 ) return;
@@ -1701,6 +1708,7 @@ __device__ __forceinline__ bool icp_coop_tile( const IcpLaunch& L, const Xform& 
 template <int NW>
 __global__ __launch_bounds__( NW * WAVE, RS_COOP_OCC ) void k_icp_corr_coop( IcpLaunch L )
 {
+  RS_CHAIN_SETPRIO();
   __shared__ WaveLds lds[NW];
   __shared__ CoopLds<NW> coop;
   __shared__ unsigned long long s_skip;
@@ -1893,6 +1901,7 @@ __global__ __launch_bounds__( UPDATE_WAVES * WAVE ) void k_icp_update( IcpLaunch
 // four waves in turn.
 __global__ __launch_bounds__( BLOCK ) void k_icp_update_wide( IcpLaunch L, int* done )
 {
+  RS_CHAIN_SETPRIO();
   __shared__ double s_part[WAVES_PER_BLOCK];
   __shared__ int s_last;
   const int prob = blockIdx.y, k = blockIdx.x;
@@ -2827,6 +2836,7 @@ __device__ __forceinline__ void chain_moments_block( const IcpLaunch& L, const C
 }
 __global__ __launch_bounds__( BLOCK ) void k_chain_moments( IcpLaunch L, ChainBufs B )
 {
+  RS_CHAIN_SETPRIO();
   __shared__ ChainMomLds S;
   const int prob = blockIdx.y;
   if( L.active[prob] == 0 ) return;
@@ -2928,6 +2938,7 @@ __device__ __forceinline__ void chain_guess_block( const IcpLaunch& L, const Cha
 }
 __global__ __launch_bounds__( CH_ROWS * WAVE ) void k_chain_guess( IcpLaunch L, ChainBufs B )
 {
+  RS_CHAIN_SETPRIO();
   const int prob = blockIdx.y;
   if( L.active[prob] == 0 ) return;
   chain_guess_block( L, B, prob, blockIdx.x, CH_ROWS );
@@ -2997,6 +3008,7 @@ __device__ __forceinline__ void chain_compose_block( const ChainBufs& B, int pro
 #define CHAIN_REC_ROUNDS 1
 __global__ __launch_bounds__( BLOCK ) void k_chain_segrecs( IcpLaunch L, ChainBufs B )
 {
+  RS_CHAIN_SETPRIO();
   // (rows of 65: lane = (segment, class, chain) reads row (segment, chain) at column j — with rows of 64 all 21 rows' column j sit in
   //  ONE bank, a 21-way conflict on every read of the loop below)
   __shared__ float s_x[WAVES_PER_BLOCK][CHAIN_REC_TASK][CH_ROWS][CH_SEG + 1];
@@ -3110,6 +3122,7 @@ __global__ __launch_bounds__( BLOCK ) void k_chain_segrecs( IcpLaunch L, ChainBu
 //  fences each write back their XCD's L2, which the search has just filled with dirty records.)
 __global__ __launch_bounds__( 2 * BLOCK ) void k_chain_compose( IcpLaunch L, ChainBufs B )
 {
+  RS_CHAIN_SETPRIO();
   __shared__ ChainBlockLds s_rec;
   const int prob = blockIdx.y;
   if( L.active[prob] == 0 ) return;
@@ -3656,6 +3669,7 @@ __device__ __forceinline__ void chain_walk_row( const IcpLaunch& L, const ChainB
 
 __global__ __launch_bounds__( BLOCK ) void k_chain_walk( IcpLaunch L, ChainBufs B )
 {
+  RS_CHAIN_SETPRIO();
   __shared__ ChainWalkLds S;
   const int prob = blockIdx.y;
   if( L.active[prob] == 0 ) return;
@@ -3666,6 +3680,7 @@ __global__ __launch_bounds__( BLOCK ) void k_chain_walk( IcpLaunch L, ChainBufs 
 // the sums k_chain_segrecs and k_chain_compose have just left: read by the NEXT iteration's k_chain_segrecs).
 __global__ __launch_bounds__( BLOCK ) void k_chain_walk_and_moments( IcpLaunch L, ChainBufs B )
 {
+  RS_CHAIN_SETPRIO();
   __shared__ union U { ChainWalkLds w; ChainMomLds m; __device__ U() {} } S;
   const int prob = blockIdx.y;
   if( L.active[prob] == 0 ) return;
@@ -3869,7 +3884,14 @@ void launch_score( const ScoreLaunch& L, hipStream_t st )
   // measured too: 1.70 and 2.15 ms against 1.53 — rows of unequal length evaluate sentinels up to the longest one's count.)
   if( L.by_rows && L.solo_stages == 0x7fffffff && L.scene.inv_cell > 0.0f ) hipLaunchKernelGGL( k_score<16>, grid, dim3( SC_WAVES * WAVE ), 0, st, L );
   else if( L.kcap_frac > 0.0f ) hipLaunchKernelGGL( ( k_score<0, true> ), grid, dim3( SC_WAVES * WAVE ), 0, st, L );      // (opt-in experiment: RS_HIP_SCORE_KCAP)
-  else hipLaunchKernelGGL( ( k_score<0, false> ), grid, dim3( SC_WAVES * WAVE ), 0, st, L );
+  else
+  {
+    // RS_HIP_SCORE_LDS_PAD=<bytes>: dynamic LDS nobody uses — caps how many of this kernel's single-wave workgroups a CU holds, so
+    // that a latency-bound chain of kernels issued beside the batch finds free slots on every CU (bench.py: the alternative to
+    // confining the two to disjoint CUs)
+    static const int pad = getenv( "RS_HIP_SCORE_LDS_PAD" ) ? atoi( getenv( "RS_HIP_SCORE_LDS_PAD" ) ) : 0;
+    hipLaunchKernelGGL( ( k_score<0, false> ), grid, dim3( SC_WAVES * WAVE ), (size_t)( pad > 0 ? pad : 0 ), st, L );
+  }
   long long items = (long long)L.obj.n_tiles * L.n_poses;
   hipLaunchKernelGGL( k_score_coop, dim3( items < 4096 ? (int)( items > 0 ? items : 1 ) : 4096 ), dim3( COOP_BLOCK ), 0, st, L );
   hipLaunchKernelGGL( k_score_final, dim3( L.n_poses ), dim3( BLOCK ), 0, st, L );
