@@ -3150,7 +3150,7 @@ __global__ __launch_bounds__( 2 * BLOCK ) void k_chain_compose( IcpLaunch L, Cha
 #define CH_PRE_SEGS 32
 #define CH_SUPER 8                 // chunks of 64 blocks per round of forecasts
 #define CH_EPS ( 1.0f / 2048.0f )
-#define CH_BUDGET 192              // segments a walk may add up addend by addend before it gives the problem up (ChainBufs::failed)
+#define CH_BUDGET 384              // segments a walk may add up addend by addend before it gives the problem up (ChainBufs::failed)
 #define CH_PIECES 16               // pieces of a fetched block
 #define CH_PIECE_BIG ( 1 << 27 )
 struct ChainPiece { int es, lo, hi, D; };      // exponent | sign << 8 it is made for; M -> M + D [+ tau: ptau / bptau] for lo <= M <= hi
@@ -3175,6 +3175,7 @@ struct ChainWalkLds
   unsigned long long stat[WAVES_PER_BLOCK][3], flag[CH_PRE_BLKS], fmask[CH_SUPER];
   int pblk[CH_PRE_BLKS], at_seg[CH_PRE_SEGS], mode[CH_PRE_BLKS], bmode[CH_SUPER];
   float pst[CH_PRE_BLKS], tot[CH_SUPER], s0;
+  int round_end;                                // the first block this round does not cover
   ChainItem items[CH_ITEMS];                    // the walk's steps, in order
   int ctot[CH_SUPER], kbase[CH_PRE_BLKS];       // items per chunk; a fetched block's first item
 };
@@ -3322,10 +3323,13 @@ __device__ __forceinline__ void chain_walk_row( const IcpLaunch& L, const ChainB
     return min( stop, count );
   };
   long long walk_cycles = 0;
-  for( int B0 = 0; B0 < B.n_blk; B0 += CH_SUPER * WAVE )
+  // A round covers up to 512 blocks — and ends early at the first crossing block its fetch slots do not hold (S.round_end):
+  // the next round starts there, from the exact value, with fresh slots.
+  for( int B0 = 0; B0 < B.n_blk; )
   {
     const int n_chunks = min( CH_SUPER, ( B.n_blk - B0 + WAVE - 1 ) / WAVE );
     if( B0 > 0 ) round1_loads( B0 );
+    if( threadIdx.x == 0 ) S.round_end = min( B0 + CH_SUPER * WAVE, B.n_blk );
     // ---- the forecasts at the blocks' starts: the chunks' totals first ...
     float incl[CHUNKS_PER_WAVE];
 #pragma unroll
@@ -3367,10 +3371,12 @@ __device__ __forceinline__ void chain_walk_row( const IcpLaunch& L, const ChainB
         const int c = wib + i * WAVES_PER_BLOCK;
         const int rank = __builtin_amdgcn_readlane( flagged_before, c ) + __builtin_popcountll( fm_mine[i] & below( lane ) );
         if( ( ( fm_mine[i] >> lane ) & 1ull ) && rank < CH_PRE_BLKS ) { S.pblk[rank] = B0 + c * WAVE + lane; S.pst[rank] = st_mine[i]; }
+        if( ( ( fm_mine[i] >> lane ) & 1ull ) && rank == CH_PRE_BLKS ) S.round_end = B0 + c * WAVE + lane;      // (the first one without a slot)
       }
       if( walker && lane >= flagged_total && lane < CH_PRE_BLKS ) { S.pblk[lane] = -1; S.pst[lane] = 0.0f; }
     }
     __syncthreads();
+    const int round_end = S.round_end;
     stamp( 1 );
     // ---- round 2: those blocks' segment records and sums; the forecast by segments; the pieces
     {
@@ -3439,8 +3445,8 @@ __device__ __forceinline__ void chain_walk_row( const IcpLaunch& L, const ChainB
 #pragma unroll
     for( int i = 0; i < CHUNKS_PER_WAVE; ++i )
     {
-      const int c = wib + i * WAVES_PER_BLOCK, nb = min( WAVE, B.n_blk - ( B0 + c * WAVE ) );
-      const unsigned long long fm = fm_mine[i];
+      const int c = wib + i * WAVES_PER_BLOCK, nb = max( 0, min( WAVE, round_end - ( B0 + c * WAVE ) ) );
+      const unsigned long long fm = fm_mine[i] & lanes_below( nb );
       const int rank = __builtin_amdgcn_readlane( flagged_before, c ) + __builtin_popcountll( fm & below( lane ) );
       const bool flagged = ( fm >> lane ) & 1ull, mine_in = lane < nb;
       int cnt = 0; it_k[i] = -1;
@@ -3477,11 +3483,11 @@ __device__ __forceinline__ void chain_walk_row( const IcpLaunch& L, const ChainB
 #pragma unroll
     for( int i = 0; i < CHUNKS_PER_WAVE; ++i )
     {
-      const int c = wib + i * WAVES_PER_BLOCK, nb = min( WAVE, B.n_blk - ( B0 + c * WAVE ) );
+      const int c = wib + i * WAVES_PER_BLOCK, nb = max( 0, min( WAVE, round_end - ( B0 + c * WAVE ) ) );
       const int at = __builtin_amdgcn_readlane( items_before, c ) + it_off[i];
       if( it_cnt[i] > 0 && at < CH_ITEMS )
       {
-        const unsigned long long fm = fm_mine[i];
+        const unsigned long long fm = fm_mine[i] & lanes_below( nb );
         ChainItem it; it.es = -1; it.lo = CH_M_HI; it.hi = CH_M_LO; it.D = 0; it.tp = 0;
         if( !S.bmode[c] ) { it.kind = chain_item_kind( CH_IT_BLOCKS, c, 0, 0, nb, 63 ); S.items[at] = it; }
         else if( ( fm >> lane ) & 1ull )
@@ -3651,7 +3657,8 @@ __device__ __forceinline__ void chain_walk_row( const IcpLaunch& L, const ChainB
       if( n_items > CH_ITEMS ) stuck |= 2;                                   // (more steps than the list holds: hundreds of binade changes in one round)
       if( dbg ) { s = __int_as_float( uni( __float_as_int( s ) ) ); walk_cycles += clock64() - c_walk; }
     }
-    if( B0 + CH_SUPER * WAVE < B.n_blk ) __syncthreads();                   // (the next round overwrites what this walk read)
+    __syncthreads();                                                      // (the next round overwrites what this walk read)
+    B0 = round_end;
   }
   // A chain that wanders around zero — coordinates that straddle the origin, summed in an order that keeps cancelling — changes binade
   // not fifteen times but thousands of times, and every such segment is 64 dependent additions on this one wave: milliseconds.  The
