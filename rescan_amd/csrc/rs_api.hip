@@ -110,7 +110,7 @@ struct Workspace
   DevBuf lvl_pos, lvl_nor, lvl_cnt, lvl_within, lvl_offset, lvl_adj, lvl_state, lvl_misc, lvl_flags, lvl_scan, lvl_samples, lvl_tmp, lvl_cursor, lvl_work_a, lvl_work_b;   // level builder
   DevBuf faith;                                                                 // reference-order estimator: correspondences in source order
   DevBuf rp_segsum, rp_guess, rp_seg, rp_super, rp_totals, rp_redone;                     // ... its parallel form (replay)
-  DevBuf ch_rec, ch_segsum, ch_prefix, ch_seg, ch_blk, ch_guess, ch_dbg, ch_done;                                    // the centroid chains of large sources (grid chains)
+  DevBuf ch_rec, ch_segsum, ch_prefix, ch_seg, ch_blk, ch_guess, ch_dbg, ch_done, ch_chk;                                    // the centroid chains of large sources (grid chains)
   PinBuf h_a, h_b, h_c;
 };
 thread_local Workspace g_ws;
@@ -880,6 +880,9 @@ int icp_align_batch_impl( const rs_hip_cloud_t* source, const rs_hip_cloud_t* ta
     {
       if( ( rc = g_ws.ch_dbg.ensure( rows * ( 4 + 64 * 8 ) * 4 ) ) ) return rc;
       CB.dbg = g_ws.ch_dbg.as<int>(); CB.dbg_reps = std::max( 1, atoi( getenv( "RS_HIP_CHAIN_DEBUG" ) ) );
+      if( ( rc = g_ws.ch_chk.ensure( rows * ( 4 + 3 * 4096 ) * 4 ) ) ) return rc;
+      HIP_TRY( hipMemsetAsync( g_ws.ch_chk.p, 0, rows * ( 4 + 3 * 4096 ) * 4, g_stream ), RS_HIP_E_RUNTIME );
+      CB.chk = g_ws.ch_chk.as<int>();
     }
     cx.L.rec = (float4*)g_ws.ch_rec.p;
     cx.L.n_mom_blocks = CB.n_blk * 4;              // k_chain_moments: one workgroup, one partial, per quarter block (1 024 source points)
@@ -959,6 +962,17 @@ int icp_align_batch_impl( const rs_hip_cloud_t* source, const rs_hip_cloud_t* ta
     for( int p = 0; p < n; ++p ) n_active += hActive[p] ? 1 : 0;
     if( n_active == 0 ) break;
   }
+  if( exact_centroids && getenv( "RS_HIP_DEBUG_TOTALS" ) )      // the seven centroid sums of the last iteration, as the estimator used them (bits)
+  {
+    std::vector<double> t( (size_t)n * 3 * ICP_NMOM );
+    (void)hipMemcpy( t.data(), RB.totals, t.size() * 8, hipMemcpyDeviceToHost );
+    for( int p = 0; p < n; ++p )
+    {
+      fprintf( stderr, "[rs_hip totals] mode %d problem %d:", centroid_mode, p );
+      for( int r = 0; r < CH_ROWS; ++r ) { const float f = (float)t[( (size_t)p * 3 + 1 ) * ICP_NMOM + r]; uint32_t u; std::memcpy( &u, &f, 4 ); fprintf( stderr, " %08x", u ); }
+      fprintf( stderr, "\n" );
+    }
+  }
   if( CB.dbg )      // RS_HIP_CHAIN_DEBUG: which segments the last iteration's chain walks added up addend by addend, and why their record did not fit
   {
     std::vector<int> d( (size_t)CH_ROWS * ( 4 + 64 * 8 ) );
@@ -969,7 +983,11 @@ int icp_align_batch_impl( const rs_hip_cloud_t* source, const rs_hip_cloud_t* ta
       fprintf( stderr, "[rs_hip chains] chain %d: %d segments added one by one (%d with their addends fetched ahead), %d steps by one record, %d wave-wide scans%s; fetches done after %.2f us, walk after %.2f us\n", r, q[0] & 0xffff, q[2] & 0xffff, q[2] >> 16, ( q[0] >> 16 ) & 0x3fff,
                ( q[0] >> 30 ) ? " (STUCK)" : "", q[1] / 100.0, q[3] / 100.0 );
       fprintf( stderr, "   cut + block 0 after %.2f us, block forecasts after %.2f us, segment records + forecasts after %.2f us; %d shader cycles in the walk itself\n", q[4 + 63 * 8] / 100.0, q[4 + 63 * 8 + 1] / 100.0, q[4 + 63 * 8 + 2] / 100.0, q[4 + 63 * 8 + 3] );
-      for( int k = 0; k < std::min( q[0] & 0xffff, 63 ); ++k )
+      if( q[4 + 63 * 8 + 4] )
+        fprintf( stderr, "   step %d taken by its record DIFFERS from the same step by scans: record es %x lo %d hi %d D %d tp %x | start %08x -> by scans %08x, by record %08x | kind type %d chunk %d block %d from %d to %d\n",
+                 q[4 + 63 * 8 + 4] - 1, q[4 + 63 * 8 + 5], q[4 + 63 * 8 + 6], q[4 + 63 * 8 + 7], q[4 + 62 * 8], q[4 + 62 * 8 + 1], (unsigned)q[4 + 62 * 8 + 2], (unsigned)q[4 + 62 * 8 + 3], (unsigned)q[4 + 62 * 8 + 4],
+                 q[4 + 62 * 8 + 5] & 3, ( q[4 + 62 * 8 + 5] >> 2 ) & 7, ( q[4 + 62 * 8 + 5] >> 5 ) & 63, ( q[4 + 62 * 8 + 5] >> 11 ) & 63, ( q[4 + 62 * 8 + 5] >> 17 ) & 127 );
+      for( int k = 0; k < std::min( q[0] & 0xffff, 62 ); ++k )
       {
         const int* e = q + 4 + 8 * k; const unsigned sb = (unsigned)e[1];
         fprintf( stderr, "   segment %6d (at %6.2f us): value exp %3u mantissa %8u sign %u | %d cycles for the 64 adds | %s, %s\n", e[0], e[7] / 100.0, ( sb >> 23 ) & 255u,
@@ -983,6 +1001,21 @@ int icp_align_batch_impl( const rs_hip_cloud_t* source, const rs_hip_cloud_t* ta
     std::vector<int> failed( (size_t)n );
     HIP_TRY( hipMemcpy( failed.data(), CB.failed, (size_t)n * 4, hipMemcpyDeviceToHost ), RS_HIP_E_RUNTIME );
     for( int p = 0; p < n; ++p ) if( failed[p] ) { g_chains_gave_up.fetch_add( 1 ); return ICP_CHAINS_GAVE_UP; }      // (nothing written to the caller's arrays yet)
+  }
+  if( CB.chk )
+  {
+    std::vector<int> c( (size_t)CH_ROWS * ( 4 + 3 * 4096 ) );
+    (void)hipMemcpy( c.data(), CB.chk, c.size() * 4, hipMemcpyDeviceToHost );
+    for( int r = 0; r < CH_ROWS; ++r )
+    {
+      const int* q = c.data() + (size_t)r * ( 4 + 3 * 4096 );
+      if( q[1] < 0 ) { fprintf( stderr, "[rs_hip chains] chain %d self-check: %d steps, all as the plain sum (%08x)\n", r, q[0], (unsigned)q[3] ); continue; }
+      const int k = q[1];
+      auto show = [&]( int j ) { const int* e = q + 4 + 3 * j; const int kind = e[2]; fprintf( stderr, "      step %d: ends at segment %d with %08x; type %d chunk %d block %d from %d to %d slot %d, %s\n", j, e[0], (unsigned)e[1], kind & 3, ( kind >> 2 ) & 7, ( kind >> 5 ) & 63, ( kind >> 11 ) & 63, ( kind >> 17 ) & 127, ( kind >> 24 ) & 63, ( kind >> 30 ) & 1 ? "by its record" : "by scans / addend by addend" ); };
+      fprintf( stderr, "[rs_hip chains] chain %d self-check: step %d of %d differs from the plain sum (%08x there)\n", r, k, q[0], (unsigned)q[2] );
+      if( k > 0 ) show( k - 1 );
+      show( k );
+    }
   }
   const int* hIters = (const int*)( hS + np * 33 );
   for( int p = 0; p < n; ++p ) { std::memcpy( T1s + 16 * p, hS + 16 * p, 64 ); errs[p] = hS[np * 34 + p]; if( iters ) iters[p] = hIters[p]; }

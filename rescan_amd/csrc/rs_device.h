@@ -147,6 +147,7 @@ struct ChainBufs
   int*      failed;     // n_prob: a walk gave up (too many binade changes for this method: chain_walk_row) — the host runs the problem again another way
   int*      done;       // n_prob, zero between launches: k_icp_update_wide's count of finished workgroups
   int*      resolved;   // n_prob: segments the walks had to add up one addend after the other (diagnostics)
+  int*      chk;        // (RS_HIP_CHAIN_DEBUG) per chain 4 + 3 x 4096 words: the walk's steps {end segment, value bits, kind}, checked against the plain sum by the walk itself
   int       dbg_reps;   // (RS_HIP_CHAIN_DEBUG=n: k_chain_walk walks n times, the stamps are the last walk's — warm caches)
   int*      dbg;        // RS_HIP_CHAIN_DEBUG: per chain 1 + 64 x 8 words — count, then {segment, value bits, guess, lo / hi / D of the class tried} of the first 64 such segments
 };

@@ -3150,6 +3150,7 @@ __global__ __launch_bounds__( 2 * BLOCK ) void k_chain_compose( IcpLaunch L, Cha
 #define CH_PRE_SEGS 32
 #define CH_SUPER 8                 // chunks of 64 blocks per round of forecasts
 #define CH_EPS ( 1.0f / 2048.0f )
+#define CH_CHK_MAX 4096            // (RS_HIP_CHAIN_DEBUG) steps of a walk logged for the self-check
 #define CH_BUDGET 384              // segments a walk may add up addend by addend before it gives the problem up (ChainBufs::failed)
 #define CH_PIECES 16               // pieces of a fetched block
 #define CH_PIECE_BIG ( 1 << 27 )
@@ -3230,15 +3231,18 @@ __device__ __forceinline__ void chain_pieces( const ChainFn& f0, int es, unsigne
   out[lane] = pc;
   if( lane < CH_PIECES ) ptau[lane] = 0;
   wave_lds_fence();
+  // (taus that outgrow their four bits: a 'max tau' no interval has room for — the piece is then never taken whole.  Clamping them
+  //  instead was wrong by as many grid steps as were cut off: a run of 37 blocks, nine of them with ties, 4 ulps.)
+  auto pack = []( int t0, int t1, int tmax ) -> int { return ( t0 > 15 || t1 > 15 ) ? ( 0x7fffff << 8 ) : ( t0 | ( t1 << 4 ) | ( tmax << 8 ) ); };
   int cur = -1, t0 = 0, t1 = 0, tmax = 0;
   for( unsigned long long tm = RS_BALLOT( f0.tau != 0 ); tm != 0ull; tm &= tm - 1ull )
   {
     const int kk = __builtin_ctzll( tm );
     const int pk = __builtin_amdgcn_readlane( pid, kk ), exk = __builtin_amdgcn_readlane( exs, kk ), tk = __builtin_amdgcn_readlane( f0.tau, kk );
-    if( pk != cur ) { if( cur >= 0 && lane == 0 ) ptau[cur] = min( t0, 15 ) | ( min( t1, 15 ) << 4 ) | ( tmax << 8 ); cur = pk; t0 = 0; t1 = 0; tmax = 0; }
+    if( pk != cur ) { if( cur >= 0 && lane == 0 ) ptau[cur] = pack( t0, t1, tmax ); cur = pk; t0 = 0; t1 = 0; tmax = 0; }
     t0 += chain_tau( tk, exk + t0 ); t1 += chain_tau( tk, 1 + exk + t1 ); tmax += max( tk & 3, tk >> 2 );
   }
-  if( cur >= 0 && lane == 0 ) ptau[cur] = min( t0, 15 ) | ( min( t1, 15 ) << 4 ) | ( tmax << 8 );
+  if( cur >= 0 && lane == 0 ) ptau[cur] = pack( t0, t1, tmax );
 }
 // (every round's loads are unconditional, from clamped indices, masked afterwards: a load inside a branch is waited for there,
 //  one round trip after the other)
@@ -3289,7 +3293,8 @@ __device__ __forceinline__ void chain_walk_row( const IcpLaunch& L, const ChainB
   };
 
   float s = 0.0f;
-  int resolved = 0, stuck = 0, steps = 0, hits = 0, piece_steps = 0, scans = 0;
+  int resolved = 0, stuck = 0, steps = 0, hits = 0, piece_steps = 0, scans = 0, n_chk = 0;
+  int* chk = B.chk ? B.chk + ( (size_t)prob * CH_ROWS + row ) * ( 4 + 3 * CH_CHK_MAX ) : nullptr;
   // advance over the records held by the lanes [from, count): as far as the value fits; returns the first lane that does not (count: all done)
   // (select( value bits ): the lane's record as a function for that value's binade)
   auto advance = [&]( auto&& select, int from, int count ) -> int
@@ -3566,7 +3571,7 @@ __device__ __forceinline__ void chain_walk_row( const IcpLaunch& L, const ChainB
       // lane the same address: 16 reads + 64 adds (by readlane from a register: 64 + 64).
       auto one_by_one = [&]( int g, int slot )
       {
-        if( dbg && resolved < 63 )
+        if( dbg && resolved < 62 )
         {
           int* d = dbg + 4 + resolved * 8;
           d[0] = g; d[1] = __float_as_int( s ); d[2] = slot < CH_PRE_SEGS ? 3 : 0; d[3] = 0; d[7] = (int)( wall_clock64() - t_start );
@@ -3640,18 +3645,39 @@ __device__ __forceinline__ void chain_walk_row( const IcpLaunch& L, const ChainB
           const int M = (int)( sb & 0x7fffffu ) | CH_M_LO;
           const int es = __builtin_amdgcn_readlane( mine.es, i ), lo = __builtin_amdgcn_readlane( mine.lo, i ), hi = __builtin_amdgcn_readlane( mine.hi, i );
           const int D = __builtin_amdgcn_readlane( mine.D, i ), tp = __builtin_amdgcn_readlane( mine.tp, i ), kind = __builtin_amdgcn_readlane( mine.kind, i );
-          if( es == (int)( sb >> 23 ) && lo <= hi && M >= lo && M + ( tp >> 8 ) <= hi )
-          {
-            s = __uint_as_float( ( sb & 0xff800000u ) | ( (uint32_t)( M + D + ( ( M & 1 ) ? ( tp >> 4 ) & 15 : tp & 15 ) ) & 0x7fffffu ) );
-            ++piece_steps;
-            continue;
-          }
           const int type = kind & 3, c = ( kind >> 2 ) & 7, at = ( kind >> 5 ) & 63, from = ( kind >> 11 ) & 63, to = ( kind >> 17 ) & 127, slot = ( kind >> 24 ) & 63;
           const int g0 = ( B0 + c * WAVE + at ) * CH_BLK;
-          if( type == CH_IT_SEG ) one_by_one( g0 + from, slot );
+          const bool whole = es == (int)( sb >> 23 ) && lo <= hi && M >= lo && M + ( tp >> 8 ) <= hi;
+          if( whole )
+          {
+            const float s_rec = __uint_as_float( ( sb & 0xff800000u ) | ( (uint32_t)( M + D + ( ( M & 1 ) ? ( tp >> 4 ) & 15 : tp & 15 ) ) & 0x7fffffu ) );
+            if( chk )      // (RS_HIP_CHAIN_DEBUG: the same step by scans / addend by addend, from the same value)
+            {
+              if( type == CH_IT_SEG ) one_by_one( g0 + from, slot );
+              else if( type == CH_IT_SEGS ) segs_by_scans( g0, from, to );
+              else if( type == CH_IT_BLOCK ) segs_by_scans( g0, 0, min( CH_BLK, B.n_seg - g0 ) );
+              else blocks_by_scans( c, from, to );
+              s = __int_as_float( uni( __float_as_int( s ) ) );
+              if( __float_as_int( s ) != __float_as_int( s_rec ) && dbg && dbg[4 + 63 * 8 + 4] == 0 )
+              {
+                dbg[4 + 63 * 8 + 4] = 1 + n_chk; dbg[4 + 63 * 8 + 5] = es; dbg[4 + 63 * 8 + 6] = lo; dbg[4 + 63 * 8 + 7] = hi;
+                dbg[4 + 62 * 8 + 0] = D; dbg[4 + 62 * 8 + 1] = tp; dbg[4 + 62 * 8 + 2] = (int)sb; dbg[4 + 62 * 8 + 3] = __float_as_int( s ); dbg[4 + 62 * 8 + 4] = __float_as_int( s_rec ); dbg[4 + 62 * 8 + 5] = kind;
+              }
+            }
+            s = s_rec;
+            ++piece_steps;
+          }
+          else if( type == CH_IT_SEG ) one_by_one( g0 + from, slot );
           else if( type == CH_IT_SEGS ) segs_by_scans( g0, from, to );
           else if( type == CH_IT_BLOCK ) segs_by_scans( g0, 0, min( CH_BLK, B.n_seg - g0 ) );
           else blocks_by_scans( c, from, to );
+          if( chk && n_chk < CH_CHK_MAX )       // (RS_HIP_CHAIN_DEBUG: where this step ends and with what — held against the plain sum below)
+          {
+            const int end_seg = type == CH_IT_BLOCKS ? min( ( B0 + c * WAVE + to ) * CH_BLK, B.n_seg ) : ( type == CH_IT_SEGS ? g0 + to : ( type == CH_IT_SEG ? g0 + from + 1 : min( g0 + CH_BLK, B.n_seg ) ) );
+            s = __int_as_float( uni( __float_as_int( s ) ) );
+            if( lane == 0 ) { chk[4 + 3 * n_chk] = end_seg; chk[4 + 3 * n_chk + 1] = __float_as_int( s ); chk[4 + 3 * n_chk + 2] = kind | ( whole ? 1 << 30 : 0 ); }
+            ++n_chk;
+          }
         }
       }
       if( n_items > CH_ITEMS ) stuck |= 2;                                   // (more steps than the list holds: hundreds of binade changes in one round)
@@ -3659,6 +3685,26 @@ __device__ __forceinline__ void chain_walk_row( const IcpLaunch& L, const ChainB
     }
     __syncthreads();                                                      // (the next round overwrites what this walk read)
     B0 = round_end;
+  }
+  if( chk && walker )
+  {
+    // the plain sum, 64 addends at a time, compared with what the walk had where each of its steps ended
+    float sp = 0.0f; int next = 0, bad = -1, bad_bits = 0;
+    for( int g = 0; g < B.n_seg; ++g )
+    {
+      const int i = g * CH_SEG + lane;
+      const float* rp = Rf + (size_t)min( i, L.src.n - 1 ) * ( REC_F4 * 4 );
+      const float xr = addend_of( rp[3], rp[7], rp[comp], i < L.src.n );
+#pragma unroll
+      for( int j = 0; j < CH_SEG; ++j ) sp = sp + __int_as_float( __builtin_amdgcn_readlane( __float_as_int( xr ), j ) );
+      sp = __int_as_float( uni( __float_as_int( sp ) ) );
+      while( next < n_chk && chk[4 + 3 * next] <= g + 1 )
+      {
+        if( chk[4 + 3 * next] == g + 1 && bad < 0 && chk[4 + 3 * next + 1] != __float_as_int( sp ) ) { bad = next; bad_bits = __float_as_int( sp ); }
+        ++next;
+      }
+    }
+    if( lane == 0 ) { chk[0] = n_chk; chk[1] = bad; chk[2] = bad_bits; chk[3] = __float_as_int( sp ); }
   }
   // A chain that wanders around zero — coordinates that straddle the origin, summed in an order that keeps cancelling — changes binade
   // not fifteen times but thousands of times, and every such segment is 64 dependent additions on this one wave: milliseconds.  The

@@ -271,6 +271,14 @@ def test_exact_centroid_chains_are_the_sequential_sums(capi, gscene, scene_cloud
                 if mode == 1:
                     print(f"{b.n} source points: segments the chain walks added one addend after the other in the last iteration: {capi.icp_replay_redone()}")
             assert (out[1][1] == out[2][1]).all() and out[1][0] == out[2][0] and out[1][2] == out[2][2], n_pts
+            if n_pts == 330_000:
+                # ... and as a batch of three start poses on the same scans: every problem its own walks, same bits as alone
+                T0s = np.stack([T0] + [synth.perturbed_pose(I4, rng, 0.02, 0.01) for _ in range(2)])
+                capi.icp_exact_centroids(1)
+                eb, Tb, itb = capi.icp_align_batch(b, a, T0s, I4, 0.1, np.deg2rad(60.0), max_iter=5, fixed_iters=True)
+                for k in range(3):
+                    e1, T1, it1 = capi.icp_align(b, a, T0s[k], I4, 0.1, np.deg2rad(60.0), max_iter=5, fixed_iters=True)
+                    assert (Tb[k] == T1).all() and eb[k] == e1 and itb[k] == it1, k
             # (a room in the positive octant: sums that grow steadily — the chains must not have handed the call to the replay;
             #  the shifted scan's x sums wander around zero: they may)
             assert seed == 3 or capi.icp_chains_gave_up() == gave_up, n_pts

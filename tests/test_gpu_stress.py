@@ -139,3 +139,39 @@ def test_three_consumers_side_by_side_repeatedly(capi):
     finally:
         bench.close_roles()                                      # (the runner's worker threads busy-wait between steps)
     assert not bad, f"steps that differ: {bad}"
+
+
+def test_centroid_chains_sweep_vs_replay(capi):
+    """The grid chains (the default estimator of scan-sized sources) against pass 2 of the replay on whole icp_align runs: two rooms,
+    each as generated (sums that grow) and moved so that its median point is the origin (sums that wander around zero: many
+    more binade changes, ties in long runs of blocks, now and then a walk that gives up and hands the call to the replay), five
+    start poses each.  Bit-identical poses, errors and iteration counts throughout — a run of 37 blocks whose tie corrections
+    outgrew their four bits was once taken whole with the corrections clamped: 4 ulps in one centroid sum, 7e-8 in the pose,
+    in four of five start poses of the centred room and in none of the others."""
+    from rescan_amd import synth
+    prev, prev_r, prev_c = capi.icp_reference_order_below(-1), capi.icp_replay_below(-1), capi.icp_exact_centroids(-1)
+    bad, gave_up = [], 0
+    try:
+        capi.icp_reference_order_below(0); capi.icp_replay_below(0)
+        for seed in (22, 23):
+            s0 = synth.scene_for_point_count(330_000, seed=seed, timestep=0)
+            s1 = synth.scene_for_point_count(330_000, seed=seed, timestep=1)
+            for centred in (True, False):
+                shift = -np.median(s1["points"], axis=0).astype(np.float32) if centred else np.zeros(3, np.float32)
+                a, b = capi.Cloud(s0["points"] + shift, s0["normals"]), capi.Cloud(s1["points"] + shift, s1["normals"])
+                rng = np.random.default_rng(5)
+                for trial in range(5):
+                    T0 = synth.perturbed_pose(I4, rng, 0.02, 0.01)
+                    res = {}
+                    for mode in (2, 1):
+                        capi.icp_exact_centroids(mode)
+                        g = capi.icp_chains_gave_up()
+                        res[mode] = capi.icp_align(b, a, T0, I4, 0.1, np.deg2rad(60.0), max_iter=6, fixed_iters=True)
+                        gave_up += capi.icp_chains_gave_up() - g
+                    if _key(*res[1]) != _key(*res[2]):
+                        bad.append((seed, centred, trial))
+                a.close(); b.close()
+        print(f"calls the chains gave up: {gave_up} of 20")
+        assert not bad, f"(seed, centred, start pose) that differ: {bad}"
+    finally:
+        capi.icp_reference_order_below(prev); capi.icp_replay_below(prev_r); capi.icp_exact_centroids(prev_c)
