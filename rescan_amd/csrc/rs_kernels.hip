@@ -2946,57 +2946,54 @@ __global__ __launch_bounds__( CH_ROWS * WAVE ) void k_chain_guess( IcpLaunch L, 
 
 // The block records: a block's 64 segment records composed per chain and exponent (around the block's first guess), and the quarter
 // blocks' sums of the segments' (the walks' forecasts, the next guesses).
-typedef ChainRec ChainBlockLds[CH_ROWS][CH_BLK];
-__device__ __forceinline__ void chain_compose_block( const ChainBufs& B, int prob, int blk, ChainBlockLds& s_rec )
+__device__ __forceinline__ void chain_rec_copy_fwd( ChainRec& d, const ChainRec& r )
 {
-  const int lane = threadIdx.x & ( WAVE - 1 ), wib = uni( (int)threadIdx.x / WAVE ), n_waves = blockDim.x / WAVE;
+  d.e_sign = r.e_sign;
+#pragma unroll
+  for( int c = 0; c < 3; ++c ) { d.lo[c] = r.lo[c]; d.hi[c] = r.hi[c]; d.D[c] = r.D[c]; }
+}
+// One workgroup per (block, chain): three waves, one per binade; the first also sums the quarters.  (One workgroup per block with all
+// seven chains — 21 scans over 8 waves, 18 KB staged — took 11 us per launch, nearly all of it the latency of that one workgroup's
+// load -> scans -> store; 2 000 small ones take 7.)
+__device__ __forceinline__ void chain_compose_block( const ChainBufs& B, int prob, int blk, int r )
+{
+  const int lane = threadIdx.x & ( WAVE - 1 ), c = uni( (int)threadIdx.x / WAVE );
+  const int seg = blk * CH_BLK + lane;
+  ChainRec mine; mine.e_sign = -1;
+  const ChainRec* src = B.seg + ( (size_t)prob * CH_ROWS + r ) * B.n_seg;
+  chain_rec_copy_fwd( mine, src[min( seg, B.n_seg - 1 )] );
+  if( seg >= B.n_seg ) mine.e_sign = -1;                                  // (past the end of the cloud)
+  if( c == 0 )
   {
-    constexpr int WORDS = sizeof( ChainRec ) / 4;
-    const int n_here = min( CH_BLK, B.n_seg - blk * CH_BLK );
-    for( int r = 0; r < CH_ROWS; ++r )
-    {
-      const int* src = reinterpret_cast<const int*>( B.seg + ( (size_t)prob * CH_ROWS + r ) * B.n_seg + (size_t)blk * CH_BLK );
-      int* dst = reinterpret_cast<int*>( &s_rec[r][0] );
-      for( int k = threadIdx.x; k < CH_BLK * WORDS; k += blockDim.x ) dst[k] = k < n_here * WORDS ? src[k] : -1;      // (e_sign -1: past the end of the cloud)
-    }
+    const double v = seg < B.n_seg ? B.segsum[( (size_t)prob * CH_ROWS + r ) * B.n_seg + seg] : 0.0;
+    // the quarter blocks' sums: a row of 16 lanes each (fixed order: lane 0's quad tree)
+    double q = v;
+    q += dpp_d<RS_DPP_QUAD_XOR1, 0xf>( 0.0, q ); q += dpp_d<RS_DPP_QUAD_XOR2, 0xf>( 0.0, q );
+    q += dpp_d<RS_DPP_HALF_MIRROR, 0xf>( 0.0, q ); q += dpp_d<RS_DPP_ROW_MIRROR, 0xf>( 0.0, q );
+    if( ( lane & 15 ) == 0 ) B.blksum[( (size_t)prob * CH_ROWS + r ) * ( B.n_blk * CH_QUARTERS ) + blk * CH_QUARTERS + ( lane >> 4 )] = q;
   }
-  if( threadIdx.x < CH_ROWS * CH_QUARTERS )
+  const int first = __builtin_amdgcn_readlane( mine.e_sign, 0 );
+  const int E = ( first & 255 ) - 1 + c, sg = ( first >> 8 ) & 1;
+  const bool all_zero = RS_BALLOT( mine.e_sign != -1 && !( mine.e_sign & CH_ALL_ZERO ) ) == 0ull;
+  const ChainFn f0 = mine.e_sign == -1 ? chain_identity() : chain_select( mine, E, sg );
+  ChainFn f = chain_prefix( f0, lane );
+  // the ties inside, in order: what the block adds for an even / an odd start (each record's tau picked by the parity of ITS start)
+  unsigned long long tm = RS_BALLOT( f0.tau != 0 );
+  const int ex = f.D - f0.D;
+  int t0 = 0, t1 = 0, tmax = 0;
+  while( tm != 0ull )
   {
-    const int r = threadIdx.x / CH_QUARTERS, q = threadIdx.x % CH_QUARTERS;
-    const double* ss = B.segsum + ( (size_t)prob * CH_ROWS + r ) * B.n_seg;
-    constexpr int SEGS = CH_BLK / CH_QUARTERS;
-    double v = 0.0;
-    for( int k = 0; k < SEGS; ++k ) { const int seg = blk * CH_BLK + q * SEGS + k; if( seg < B.n_seg ) v += ss[seg]; }
-    B.blksum[( (size_t)prob * CH_ROWS + r ) * ( B.n_blk * CH_QUARTERS ) + blk * CH_QUARTERS + q] = v;
+    const int k = __builtin_ctzll( tm ); tm &= tm - 1ull;
+    const int exk = __builtin_amdgcn_readlane( ex, k ), tk = __builtin_amdgcn_readlane( f0.tau, k );
+    t0 += chain_tau( tk, exk + t0 ); t1 += chain_tau( tk, 1 + exk + t1 ); tmax += max( tk & 3, tk >> 2 );
   }
-  __syncthreads();
-  for( int job = wib; job < CH_ROWS * 3; job += n_waves )
+  if( lane == WAVE - 1 )
   {
-    const int r = job / 3, c = job % 3;
-    const int first = s_rec[r][0].e_sign;
-    const int E = ( first & 255 ) - 1 + c, sg = ( first >> 8 ) & 1;
-    const ChainRec mine = s_rec[r][lane];
-    const bool all_zero = RS_BALLOT( mine.e_sign != -1 && !( mine.e_sign & CH_ALL_ZERO ) ) == 0ull;
-    const ChainFn f0 = mine.e_sign == -1 ? chain_identity() : chain_select( mine, E, sg );
-    ChainFn f = chain_prefix( f0, lane );
-    // the ties inside, in order: what the block adds for an even / an odd start (each record's tau picked by the parity of ITS start)
-    unsigned long long tm = RS_BALLOT( f0.tau != 0 );
-    const int ex = f.D - f0.D;
-    int t0 = 0, t1 = 0, tmax = 0;
-    while( tm != 0ull )
-    {
-      const int k = __builtin_ctzll( tm ); tm &= tm - 1ull;
-      const int exk = __builtin_amdgcn_readlane( ex, k ), tk = __builtin_amdgcn_readlane( f0.tau, k );
-      t0 += chain_tau( tk, exk + t0 ); t1 += chain_tau( tk, 1 + exk + t1 ); tmax += max( tk & 3, tk >> 2 );
-    }
-    if( lane == WAVE - 1 )
-    {
-      ChainRec* out = B.blk + ( (size_t)prob * CH_ROWS + r ) * B.n_blk + blk;
-      if( c == 0 ) out->e_sign = ( first & 0x1ff ) | ( all_zero ? CH_ALL_ZERO : 0 );
-      const int hi = f.hi - tmax;
-      const bool ok = f.lo <= hi && t0 <= 3 && t1 <= 3;                   // (a never-record has lo > hi already)
-      out->lo[c] = ok ? f.lo : CH_M_HI; out->hi[c] = ok ? hi : CH_M_LO; out->D[c] = ok ? f.D * 16 + t0 + 4 * t1 : 0;
-    }
+    ChainRec* out = B.blk + ( (size_t)prob * CH_ROWS + r ) * B.n_blk + blk;
+    if( c == 0 ) out->e_sign = ( first & 0x1ff ) | ( all_zero ? CH_ALL_ZERO : 0 );
+    const int hi = f.hi - tmax;
+    const bool ok = f.lo <= hi && t0 <= 3 && t1 <= 3;                   // (a never-record has lo > hi already)
+    out->lo[c] = ok ? f.lo : CH_M_HI; out->hi[c] = ok ? hi : CH_M_LO; out->D[c] = ok ? f.D * 16 + t0 + 4 * t1 : 0;
   }
 }
 
@@ -3120,13 +3117,12 @@ __global__ __launch_bounds__( BLOCK ) void k_chain_segrecs( IcpLaunch L, ChainBu
 // (One launch per block.  Having the k_chain_segrecs workgroup that completes a block compose it — a counter per block, the last of
 //  its six or seven to arrive — was tried: correct, and 300 us per launch instead of 25 + 11, because the 1 500 workgroups' release
 //  fences each write back their XCD's L2, which the search has just filled with dirty records.)
-__global__ __launch_bounds__( 2 * BLOCK ) void k_chain_compose( IcpLaunch L, ChainBufs B )
+__global__ __launch_bounds__( 3 * WAVE ) void k_chain_compose( IcpLaunch L, ChainBufs B )
 {
   RS_CHAIN_SETPRIO();
-  __shared__ ChainBlockLds s_rec;
   const int prob = blockIdx.y;
   if( L.active[prob] == 0 ) return;
-  chain_compose_block( B, prob, blockIdx.x, s_rec );
+  chain_compose_block( B, prob, blockIdx.x, blockIdx.z );
 }
 
 // One chain walked by a workgroup of four waves.  `s` (wave 0's, uniform) is the exact running value.
@@ -3757,13 +3753,13 @@ void launch_icp_chain_centroids( const IcpLaunch& L, const ChainBufs& B, hipStre
     hipLaunchKernelGGL( k_chain_moments, dim3( B.n_blk * CH_QUARTERS, L.n_prob ), dim3( BLOCK ), 0, st, L, B );         // (L.n_mom_blocks == 4 B.n_blk)
     hipLaunchKernelGGL( k_chain_guess, dim3( B.n_blk, L.n_prob ), dim3( CH_ROWS * WAVE ), 0, st, L, B );
     hipLaunchKernelGGL( k_chain_segrecs, rec_grid, dim3( BLOCK ), 0, st, L, B );
-    hipLaunchKernelGGL( k_chain_compose, dim3( B.n_blk, L.n_prob ), dim3( 2 * BLOCK ), 0, st, L, B );
+    hipLaunchKernelGGL( k_chain_compose, dim3( B.n_blk, L.n_prob, CH_ROWS ), dim3( 3 * WAVE ), 0, st, L, B );
     hipLaunchKernelGGL( k_chain_walk, dim3( CH_ROWS, L.n_prob ), dim3( BLOCK ), 0, st, L, B );
   }
   else
   {
     hipLaunchKernelGGL( k_chain_segrecs, rec_grid, dim3( BLOCK ), 0, st, L, B );
-    hipLaunchKernelGGL( k_chain_compose, dim3( B.n_blk, L.n_prob ), dim3( 2 * BLOCK ), 0, st, L, B );
+    hipLaunchKernelGGL( k_chain_compose, dim3( B.n_blk, L.n_prob, CH_ROWS ), dim3( 3 * WAVE ), 0, st, L, B );
     hipLaunchKernelGGL( k_chain_walk_and_moments, dim3( CH_ROWS + B.n_blk * ( CH_QUARTERS + 1 ), L.n_prob ), dim3( BLOCK ), 0, st, L, B );
   }
   hipLaunchKernelGGL( k_icp_update_wide, dim3( ICP_NMOM, L.n_prob ), dim3( BLOCK ), 0, st, L, B.done );                // (centred on the chains' totals: L.exact_centroids)
