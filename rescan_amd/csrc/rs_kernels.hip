@@ -3829,8 +3829,10 @@ __device__ __forceinline__ void score_emit( const ScoreLaunch& L, int pose, int 
   if( lane == 0 ) L.part[(size_t)pose * L.obj.n_tiles + tile] = s;
 }
 
+// (7 waves per SIMD — 72 VGPRs, 44 B of scratch per lane — since round 3: on its quarter of the CUs the batch is bound by vector issue,
+//  and a seventh wave fills more of it than the spills cost: 2.87 -> 2.77 ms there, four interleaved repeats; 5 waves, no spills: 3.00)
 #ifndef RS_SCORE_OCC
-#define RS_SCORE_OCC 6
+#define RS_SCORE_OCC 7
 #endif
 #ifndef RS_SCORE_ROWS_OCC
 #define RS_SCORE_ROWS_OCC 5
