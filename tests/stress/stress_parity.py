@@ -15,6 +15,12 @@ for seed in seeds:
     rng = np.random.default_rng(seed)
     dens = float(rng.choice([600, 1500, 3000, 5000]))
     s0 = synth.make_scene(seed=seed, density=dens, timestep=0); s1 = synth.make_scene(seed=seed, density=dens, timestep=1)
+    if os.environ.get("STRESS_SHIFT"):          # the whole world moved: "centre" puts the median point at the origin (coordinates of both signs), a number moves it that far along (1, 1, 1)
+        sh = -np.median(s1["points"], axis=0).astype(np.float32) if os.environ["STRESS_SHIFT"] == "centre" else np.full(3, float(os.environ["STRESS_SHIFT"]), np.float32)
+        for sc in (s0, s1):
+            sc["points"] = sc["points"] + sh
+            for q in sc["objects"]:
+                q["pose"] = q["pose"].copy(); q["pose"][12:15] += sh
     a, b = capi.Cloud(s0["points"], s0["normals"]), capi.Cloud(s1["points"], s1["normals"])
     msgs = []
     for trial in range(2):
