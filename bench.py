@@ -175,8 +175,10 @@ class RoleRunner:
         for r in self.workers:
             self.aux.spin_wait(self.addr(2, r), 1, 60.0)
         if self.failed is not None:
-            self.close()                           # (park the workers that did start, give the calling thread its unmasked stream back)
-            raise self.failed
+            try:
+                self.close()                       # (park the workers that did start, give the calling thread its unmasked stream back)
+            finally:
+                raise self.failed                  # the original error, whatever close() ran into
 
     def _worker(self, r, mask):
         capi, aux = self.capi, self.aux
@@ -250,7 +252,7 @@ class RoleRunner:
         for r in self.workers:
             self.aux.spin_post(self.addr(0, r), 1 << 30)
         for r in self.workers:
-            if self.threads[self.workers.index(r)].is_alive() or True:
+            if self.threads[self.workers.index(r)].is_alive():        # a worker that died has nothing to acknowledge
                 self.aux.spin_wait(self.addr(1, r), 1 << 30, 30.0)
         if self.masked:
             self.capi.stream_cu_mask(None)
@@ -539,8 +541,8 @@ class Sharded:
 def parity_block(out, n_points, seed, knn, units, strong=False):
     """Distance of the LAST step's outputs from tests/golden/bench_seed11.npz — what the compiled reference computes for
     the same inputs (oracle/gen_golden_bench.py: pose / error after the 10 fixed iterations composed from the reference's
-    icp_find_corrs + icp_estimate_rigid_xform_pt2pl, the 256 scores of mgs_compute_object_alignment_score; labels by the
-    C restatement, the reference's label TU needs gco).  Computed outside the timed region."""
+    icp_find_corrs + icp_estimate_rigid_xform_pt2pl, the 256 scores of mgs_compute_object_alignment_score; labels and min_dists
+    of rspf_arrangement_to_labels by the reference's own text, oracle/_ref/libref_filters.so).  Computed outside the timed region."""
     import hashlib
     path = os.path.join(ROOT, "tests", "golden", "bench_seed11.npz")
     if not os.path.exists(path) or n_points != 1_000_000 or seed != 11:
@@ -664,28 +666,41 @@ def cpu_baseline(w, budget_s=20.0):
         R.alignment_scores(s1["points"], s1["normals"], op, on, w["score_poses"][:n_p], 64, scene=scn)
         t_score = (time.perf_counter() - t) / (n_p * len(op))
         R.scene_destroy(scn)
-        # label-NN: transform + K=1 search in the object's grid for a sample of scene points, 2 placements
-        # (the reference's label loop itself needs the un-vendored gco header; its gate loop is omitted,
-        #  which favours the CPU)
+        # label-NN: the reference's own placement loop (rspf__assign_temporary_labels, rs_pointcloud_filters.cpp:738-778: transform,
+        # K=1 search in the object's grid, gate, running minimum) for a sample of scene points, 2 placements
+        from oracle.pyoracle import RefFilters
+        from rescan_amd import synth
         n_l = trim(min(len(s1["points"]), 400_000))
         sel = np.sort(rng.choice(len(s1["points"]), n_l, replace=False))
-        sp = np.ascontiguousarray(s1["points"][sel])
+        sp, sn = np.ascontiguousarray(s1["points"][sel]), np.ascontiguousarray(s1["normals"][sel])
         t_label = 0.0
-        for p in w["plc"][:2]:
-            g = R.grid_create(p["np"][0], 0.05)
-            inv = R.mat4_inverse(p["pose"])
+        label_how = "rspf__assign_temporary_labels"
+        if RefFilters.available(omp=omp):
+            RF = RefFilters(synth.CLASS_IDX, omp=omp)
+            plc2 = [dict(pose=p["pose"], object_idx=RF.add_object(p["np"][0], p["np"][1], p["cls"], 1000 + k), uidx=k)
+                    for k, p in enumerate(w["plc"][:2])]
+            lab = np.zeros(n_l, np.int8); mind = np.full(n_l, 1e9, np.float32)
             t = time.perf_counter()
-            q = R.xform_points(inv, sp, 1)
-            R.radius_search(g, q, 0.05, 1, 0)
-            t_label += time.perf_counter() - t
-            R.grid_destroy(g)
+            RF.assign(sp, sn, plc2, 0, 2, 0.05, lab, mind)
+            t_label = time.perf_counter() - t
+            RF.close()
+        else:          # an oracle/_ref from before round 4: the loop's search alone (its gate loop omitted, which favours the CPU)
+            label_how = "transform + K=1 search only"
+            for p in w["plc"][:2]:
+                g = R.grid_create(p["np"][0], 0.05)
+                inv = R.mat4_inverse(p["pose"])
+                t = time.perf_counter()
+                q = R.xform_points(inv, sp, 1)
+                R.radius_search(g, q, 0.05, 1, 0)
+                t_label += time.perf_counter() - t
+                R.grid_destroy(g)
         t_label /= 2 * n_l
         pr = w["pairs"]
         total = pr["icp"] + pr["score"] + pr["label"]
         est = pr["icp"] * t_icp + pr["score"] * t_score + pr["label"] * t_label
         out["omp" if omp else "single"] = dict(
             value=total / est, unit="point-pairs/s", cores=cores, kind="reference",
-            sample=f"1 icp_find_corrs on {n_q} queries + {n_p} score poses x {len(op)} pts + 2 label placements x {n_l} pts; "
+            sample=f"1 icp_find_corrs on {n_q} queries + {n_p} score poses x {len(op)} pts + 2 label placements x {n_l} pts ({label_how}); "
                    f"per-pair times ICP {t_icp*1e9:.0f} ns, score {t_score*1e9:.0f} ns, label {t_label*1e9:.0f} ns, "
                    f"combined in the GPU workload's mix")
     return out

@@ -11,17 +11,18 @@ Each fixture holds the inputs and the reference's outputs for one hot-path funct
   scores_*.npz   mgs_compute_object_alignment_score for a list of poses (pose_proposal.cpp:93-158)
   mat4.npz       msh_mat4_inverse / msh_mat4_mul / msh_translate / msh_rotate samples
   gates.npz      accept/reject of the label normal gate over a sweep of dot values
-  labels_*.npz   rspf_arrangement_to_labels — produced by the C restatement (oracle/rs_oracle.c),
-                 NOT by the reference: lib/rs/rs_pointcloud_filters.cpp needs the un-vendored gco
-                 header and cannot be built here.  Its primitives are pinned by the files above.
+  labels_*.npz   rspf_arrangement_to_labels + rspf__assign_temporary_labels (rs_pointcloud_filters.cpp:738-879) by the
+                 REFERENCE's own text: oracle/_ref/libref_filters.so = that file's lines 1-14 + 16-879 (everything but
+                 the include of the un-vendored gco header and rspf_smooth_labels, its one user), oracle/Makefile
   edge_cost.npz  the neighbourhood edge weight (rs_pointcloud_filters.cpp:706-708) from the
                  reference-toolchain TU oracle/ref_label_gate.cpp
-  neighborhood_*.npz  rspf_compute_neighborhood (:674-722) — by the C restatement, as for labels_*
+  neighborhood_*.npz  rspf_compute_neighborhood (:674-722) — by the same reference build, sorted by pair key
   coverage.npz   rsao__compute_scene_coverage_score + grids (arrangement_optimization.cpp:344-373,1064-1106) from the
                  reference TU compiled in place (oracle/_ref/libref_ao.so)
 
 Usage:  python oracle/gen_golden.py                       (everything)
         python oracle/gen_golden.py --neighborhood-only   (adds those two without rewriting the rest)
+        python oracle/gen_golden.py --labels-only         (labels_*.npz again, from the inputs of scene.npz)
         python oracle/gen_golden.py --coverage-only       (likewise)
         python oracle/gen_golden.py --level-only          (likewise: level.npz)
 """
@@ -32,7 +33,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle.pyoracle import Oracle, Ref, build, edge_digest  # noqa: E402
+from oracle.pyoracle import Oracle, Ref, RefFilters, build, edge_digest  # noqa: E402
 from rescan_amd import synth  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
@@ -121,34 +122,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "gates.npz"), dot=xs,
                         label_accept=np.array([R.label_gate_dot(x) for x in xs], np.int8))
 
-    # ---- labels (restatement; see module docstring) ---------------------------------
-    for tag, with_static in (("mixed", True), ("nostatic", False)):
-        objs = []
-        plcs = []
-        for oi, o in enumerate(s["objects"]):
-            objs.append(dict(pos=o["pos"], nor=o["nor"], class_idx=o["class_idx"], is_static=0))
-            plcs.append(dict(pose=synth.perturbed_pose(o["pose"], rng, 0.02, 0.01), object_idx=oi, uidx=o["uidx"]))
-        if with_static:
-            for cls_name, inst in (("floor", 0), ("wall", 1)):
-                m = s["instance_idx"] == inst
-                sub = rng.permutation(np.nonzero(m)[0])[::2]
-                objs.append(dict(pos=pts[sub], nor=nor[sub], class_idx=synth.CLASS_IDX[cls_name], is_static=1, sub=sub))
-                plcs.append(dict(pose=I4, object_idx=len(objs) - 1, uidx=inst))
-        order = rng.permutation(len(plcs))
-        plcs = [plcs[i] for i in order]
-        res = O.arrangement_to_labels(pts, nor, objs, plcs, 0.05, 0, 0)
-        np.savez_compressed(
-            os.path.join(OUT, f"labels_{tag}.npz"),
-            n_obj=len(objs), n_plc=len(plcs),
-            # objects beyond the scene's own are subsets of the scan, stored as index lists
-            **{f"obj{i}_sub": o["sub"].astype(np.int32) for i, o in enumerate(objs) if "sub" in o},
-            obj_class=np.array([o["class_idx"] for o in objs], np.int32),
-            obj_static=np.array([o["is_static"] for o in objs], np.int32),
-            plc_pose=np.stack([np.asarray(p["pose"], np.float32) for p in plcs]),
-            plc_obj=np.array([p["object_idx"] for p in plcs], np.int32),
-            plc_uidx=np.array([p["uidx"] for p in plcs], np.int32),
-            labels=res["labels"], min_dists=res["min_dists"], order=res["order"],
-            class_ids=res["class_ids"], instance_ids=res["instance_ids"])
+    gen_labels(s)
 
     gen_neighborhood(O, R, s)
     gen_coverage(s)
@@ -158,21 +132,78 @@ def main():
     print(f"wrote {len(os.listdir(OUT))} fixtures, {total/1e6:.2f} MB")
 
 
+LABEL_CASES = (          # tag, static placements, prioritize_static, every dynamic placement three times (one an exact copy)
+    ("mixed", ("floor", "wall"), 0, False),
+    ("nostatic", (), 0, False),                          # first_static = 0: one pass at 1.5 * radius (:830-848)
+    ("prio", ("floor", "wall"), 1, False),               # prioritize_static: min_dists reset, same radius (:841-845)
+    ("ties", ("floor",), 0, True),                       # equal distances between placements: the earlier one wins (strict <)
+    ("multistatic", ("floor", "wall", "wall", "floor"), 0, True),
+)
+
+
+def gen_labels(s):
+    """labels_*.npz from the reference's own label loops (oracle/_ref/libref_filters.so, RefFilters): the temporary labels and
+    min_dists of rspf__assign_temporary_labels, the class / instance ids of rspf_arrangement_to_labels.  Every case has its
+    own generator, so that cases can be added without changing the others."""
+    pts, nor = s["points"], s["normals"]
+    for ci, (tag, statics, prio, dup) in enumerate(LABEL_CASES):
+        rng = np.random.default_rng(4100 + ci)
+        objs, plcs = [], []
+        for oi, o in enumerate(s["objects"]):
+            objs.append(dict(pos=o["pos"], nor=o["nor"], class_idx=o["class_idx"], is_static=0))
+            plcs.append(dict(pose=synth.perturbed_pose(o["pose"], rng, 0.02, 0.01), object_idx=oi, uidx=o["uidx"]))
+            if dup:
+                plcs.append(dict(pose=synth.perturbed_pose(o["pose"], rng, 0.01, 0.005), object_idx=oi, uidx=40 + o["uidx"]))
+                plcs.append(dict(pose=plcs[-2]["pose"], object_idx=oi, uidx=80 + o["uidx"]))
+        for k, cls_name in enumerate(statics):
+            m = s["instance_idx"] == (0 if cls_name == "floor" else 1)
+            sub = rng.permutation(np.nonzero(m)[0])[::2]
+            objs.append(dict(pos=pts[sub], nor=nor[sub], class_idx=synth.CLASS_IDX[cls_name], is_static=1, sub=sub))
+            plcs.append(dict(pose=I4 if k < 2 else synth.perturbed_pose(I4, rng, 0.004, 0.002), object_idx=len(objs) - 1, uidx=120 + k))
+        order = rng.permutation(len(plcs))
+        plcs = [plcs[i] for i in order]
+        RF = RefFilters(synth.CLASS_IDX)
+        res = RF.arrangement_to_labels(pts, nor, objs, plcs, 0.05, prio, synth.CLASS_IDX["unlabelled"])
+        RF.close()
+        np.savez_compressed(
+            os.path.join(OUT, f"labels_{tag}.npz"), source="reference: rs_pointcloud_filters.cpp:738-879 via oracle/_ref/libref_filters.so",
+            n_obj=len(objs), n_plc=len(plcs), prioritize_static=prio,
+            # objects beyond the scene's own are subsets of the scan, stored as index lists
+            **{f"obj{i}_sub": o["sub"].astype(np.int32) for i, o in enumerate(objs) if "sub" in o},
+            obj_class=np.array([o["class_idx"] for o in objs], np.int32),
+            obj_static=np.array([o["is_static"] for o in objs], np.int32),
+            plc_pose=np.stack([np.asarray(p["pose"], np.float32) for p in plcs]),
+            plc_obj=np.array([p["object_idx"] for p in plcs], np.int32),
+            plc_uidx=np.array([p["uidx"] for p in plcs], np.int32),
+            labels=res["labels"], min_dists=res["min_dists"], order=res["order"],
+            class_ids=res["class_ids"], instance_ids=res["instance_ids"])
+        print(f"labels_{tag}: {len(plcs)} placements, {int((res['labels'] > 0).sum())} of {len(pts)} labelled, order {res['order'].tolist()}")
+
+
+def by_pair_key(a, b, w, n):
+    """The reference returns its edges in hash-table order (insertion order); fixtures keep them sorted by the pair key."""
+    o = np.argsort(np.maximum(a, b).astype(np.int64) * n + np.minimum(a, b), kind="stable")
+    return a[o], b[o], w[o]
+
+
 def gen_neighborhood(O, R, s):
     """edge_cost.npz: rs_pointcloud_filters.cpp:706-708 evaluated by the reference-toolchain TU
-    (ref_label_gate.cpp: same math.h preamble).  neighborhood_*.npz: rspf_compute_neighborhood by the
-    C restatement (the TU itself needs gco-v3.0), full edge lists for the object clouds and a digest
-    for the scan."""
+    (ref_label_gate.cpp: same math.h preamble).  neighborhood_*.npz: rspf_compute_neighborhood by the REFERENCE's own text
+    (oracle/_ref/libref_filters.so), full edge lists for the object clouds (below the int32 key wrap, so the pair key is
+    unique) and a digest for the scan."""
     rng = np.random.default_rng(77)
     d2 = np.concatenate([rng.uniform(0, 0.0025, 4000), [0.0, 0.0025, 0.0024999, 1e-12, 0.01]]).astype(np.float32)
     dot = np.concatenate([rng.uniform(-0.2, 1.1, 4000), [1.0, 0.0, -1.0, 0.5, 0.999999]]).astype(np.float32)
     np.savez_compressed(os.path.join(OUT, "edge_cost.npz"), d2=d2, dot=dot,
                         cost=np.array([R.edge_cost(a, b) for a, b in zip(d2, dot)], np.float32))
+    RF = RefFilters(synth.CLASS_IDX)
+    src = "reference: rs_pointcloud_filters.cpp:674-722 via oracle/_ref/libref_filters.so"
     for oi, o in enumerate(s["objects"]):
-        a, b, w = O.compute_neighborhood(o["pos"], o["nor"])
-        np.savez_compressed(os.path.join(OUT, f"neighborhood_obj{oi}.npz"), obj=oi, idx1=a, idx2=b, weight=w)
-    a, b, w = O.compute_neighborhood(s["points"], s["normals"])
-    np.savez_compressed(os.path.join(OUT, "neighborhood_scene.npz"), digest=edge_digest(a, b, w))
+        a, b, w = by_pair_key(*RF.compute_neighborhood(o["pos"], o["nor"]), len(o["pos"]))
+        np.savez_compressed(os.path.join(OUT, f"neighborhood_obj{oi}.npz"), source=src, obj=oi, idx1=a, idx2=b, weight=w)
+    a, b, w = RF.compute_neighborhood(s["points"], s["normals"])
+    np.savez_compressed(os.path.join(OUT, "neighborhood_scene.npz"), source=src, digest=edge_digest(a, b, w))
+    RF.close()
 
 
 def gen_coverage(s):
@@ -228,6 +259,13 @@ def main_coverage_only():
     gen_coverage(s)
 
 
+def scene_from_fixture():
+    d = dict(np.load(os.path.join(OUT, "scene.npz")))
+    return dict(points=d["points"], normals=d["normals"], instance_idx=d["instance_idx"],
+                objects=[dict(pos=d[f"obj{i}_pos"], nor=d[f"obj{i}_nor"], pose=d["obj_pose"][i], class_idx=int(d["obj_class"][i]),
+                              uidx=int(d["obj_uidx"][i])) for i in range(int(d["n_obj"]))])
+
+
 def main_neighborhood_only():
     """Adds the neighbourhood fixtures without rewriting the others (zip timestamps would churn them)."""
     from oracle.pyoracle import Oracle, Ref
@@ -240,6 +278,9 @@ def main_neighborhood_only():
 if __name__ == "__main__":
     if "--neighborhood-only" in sys.argv:
         main_neighborhood_only()
+    elif "--labels-only" in sys.argv:
+        build(ref=True)
+        gen_labels(scene_from_fixture())
     elif "--level-only" in sys.argv:
         main_level_only()
     elif "--coverage-only" in sys.argv:

@@ -7,9 +7,9 @@ container only; the fixtures are committed so the GPU box, which has no /root/re
               icp_find_corrs + icp_estimate_rigid_xform_pt2pl (lib/rs/icp.h:306-412,210-298) with the loop of
               icp_align (:433-497, radius schedule :493) minus the stop test (oracle/ref_driver.cpp: ref_icp_iterate)
         scores[256]                mgs_compute_object_alignment_score (apps/pose_proposal/pose_proposal.cpp:93-158), K = 64
-        labels / min_dists digest  rspf_arrangement_to_labels by the C RESTATEMENT (oracle/rs_oracle.c) — the reference TU
-              needs the un-vendored gco header, SURVEY.md §8c — labels int8[n] stored whole, min_dists as a sha256 +
-              a strided sample
+        labels / min_dists / ids   rspf_arrangement_to_labels + rspf__assign_temporary_labels (lib/rs/rs_pointcloud_filters.cpp:
+              738-879) by the REFERENCE's own text (oracle/_ref/libref_filters.so, round 4; `labels_source` says so) — labels
+              int8[n] stored whole, min_dists / class ids / instance ids as sha256 (+ a strided sample of min_dists)
         input digests              sha256 of the generated inputs, so that a test on another machine notices if the
               generator (numpy, rescan_amd/synth.py) no longer produces the arrays the fixture was made for
 
@@ -23,7 +23,8 @@ container only; the fixtures are committed so the GPU box, which has no /root/re
         on the same two ~0.98 M-point scans, the three call sites' parameter sets in turn and start poses from
         5 mm / 0.3 deg to 3 cm / 2 deg (MORE_SEEDS, more_stop_case)
 
-Usage:  python oracle/gen_golden_bench.py [--bench-only [--seed N] | --sweep-only | --more [--seed N]]
+Usage:  python oracle/gen_golden_bench.py [--bench-only [--seed N] | --sweep-only | --more [--seed N] | --labels-only [--seed N]]
+        --labels-only recomputes the label fields of every bench_seed*.npz from the reference build and leaves the rest as it is
 """
 import ctypes as C
 import hashlib
@@ -35,7 +36,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle.pyoracle import Oracle, Ref, build, f32p, i32p  # noqa: E402
+from oracle.pyoracle import Oracle, Ref, RefFilters, build, f32p, i32p  # noqa: E402
 from rescan_amd import synth  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
@@ -98,9 +99,7 @@ def gen_bench(R, O, seed=11, more=False):
     scores = R.alignment_scores(s1["points"], s1["normals"], op, on, w["score_poses"], 64)
     print(f"scores: mean {scores.mean():.4f} ({time.time()-t:.1f} s)", flush=True)
     t = time.time()
-    objs = [dict(pos=p["np"][0], nor=p["np"][1], class_idx=p["cls"], is_static=0) for p in w["plc"]]
-    plcs = [dict(pose=p["pose"], object_idx=k, uidx=k) for k, p in enumerate(w["plc"])]
-    lab = O.arrangement_to_labels(s1["points"], s1["normals"], objs, plcs, 0.05, 0, 0)
+    lab = ref_labels(w)
     print(f"labels: {int((lab['labels'] > 0).sum())} labelled ({time.time()-t:.1f} s)", flush=True)
     extra = dict(labels=lab["labels"])
     if more:
@@ -118,8 +117,51 @@ def gen_bench(R, O, seed=11, more=False):
         in_sha=np.array([sha(s0["points"]), sha(s0["normals"]), sha(s1["points"]), sha(s1["normals"]), sha(op), sha(on),
                          sha(w["score_poses"]), sha(w["plc_poses"]), sha(w["icp_T0"])]),
         icp_T0=w["icp_T0"], icp_pose=T, icp_err=err, icp_n_corrs=nc, icp_errs=errs,
-        scores=scores, order=lab["order"],
-        min_dists_sha=sha(lab["min_dists"]), min_dists_sample=lab["min_dists"][::257].copy())
+        scores=scores, **label_fields(lab))
+
+
+LABEL_SOURCE = "reference: rs_pointcloud_filters.cpp:738-879 via oracle/_ref/libref_filters.so"
+
+
+def ref_labels(w):
+    """The headline's label transfer (8 placements of ~50 k-point models against the ~0.98 M-point scan, radius 0.05) by the
+    reference's own loops."""
+    objs = [dict(pos=p["np"][0], nor=p["np"][1], class_idx=p["cls"], is_static=0) for p in w["plc"]]
+    plcs = [dict(pose=p["pose"], object_idx=k, uidx=k) for k, p in enumerate(w["plc"])]
+    RF = RefFilters(synth.CLASS_IDX)
+    lab = RF.arrangement_to_labels(w["s1"]["points"], w["s1"]["normals"], objs, plcs, 0.05, 0, synth.CLASS_IDX["unlabelled"])
+    RF.close()
+    return lab
+
+
+def label_fields(lab):
+    return dict(labels_source=LABEL_SOURCE, order=lab["order"], min_dists_sha=sha(lab["min_dists"]),
+                min_dists_sample=lab["min_dists"][::257].copy(), class_ids_sha=sha(lab["class_ids"]),
+                instance_ids_sha=sha(lab["instance_ids"]))
+
+
+def relabel(seed):
+    """--labels-only: the label fields of bench_seed<seed>.npz again, from the reference build; everything else is kept."""
+    import bench
+    path = os.path.join(OUT, "bench_seed%d.npz" % seed)
+    g = dict(np.load(path))
+    w = bench.build_inputs(1_000_000, seed=seed)
+    op, on = w["obj_score_np"]
+    got = [sha(w["s0"]["points"]), sha(w["s0"]["normals"]), sha(w["s1"]["points"]), sha(w["s1"]["normals"]), sha(op), sha(on),
+           sha(w["score_poses"]), sha(w["plc_poses"]), sha(w["icp_T0"])]
+    assert got == [str(x) for x in g["in_sha"]], "the generator no longer produces the inputs the fixture was made for"
+    t = time.time()
+    lab = ref_labels(w)
+    had = (str(g["labels_sha"]) if "labels_sha" in g else sha(g["labels"]), str(g["min_dists_sha"]))
+    now = (sha(lab["labels"]), sha(lab["min_dists"]))
+    print(f"seed {seed}: {int((lab['labels'] > 0).sum())} labelled ({time.time()-t:.1f} s); the fixture's earlier digests "
+          f"{'ARE' if had == now else 'are NOT'} the reference's", flush=True)
+    if "labels_sha" in g:
+        g.update(labels_sha=sha(lab["labels"]), labels_sample=lab["labels"][::257].copy(), n_labelled=int((lab["labels"] > 0).sum()))
+    else:
+        g.update(labels=lab["labels"])
+    g.update(label_fields(lab))
+    np.savez_compressed(path, **g)
 
 
 def gen_sweep(R):
@@ -140,6 +182,11 @@ def gen_sweep(R):
 
 if __name__ == "__main__":
     build(ref=True)
+    if "--labels-only" in sys.argv:
+        for seed in BENCH_SEEDS + MORE_SEEDS:
+            if "--seed" not in sys.argv or str(seed) == sys.argv[sys.argv.index("--seed") + 1]:
+                relabel(seed)
+        sys.exit(0)
     R, O = Ref(), Oracle()
     if "--more" in sys.argv:
         for seed in MORE_SEEDS:

@@ -428,6 +428,134 @@ class RefAO:
         return self._grid("ref_ao_arrangement_grid")
 
 
+class RefFilters:
+    """The reference's label transfer and neighbourhood graph (lib/rs/rs_pointcloud_filters.cpp:674-879, the file's own text
+    compiled by oracle/Makefile -> oracle/_ref/libref_filters.so) behind oracle/ref_filters_driver.cpp.
+    One class table per process (the reference caches class ids in function statics, rs_database.h:260-271)."""
+    PATH = os.path.join(HERE, "_ref", "libref_filters.so")
+    PATH_OMP = os.path.join(HERE, "_ref", "libref_filters_omp.so")     # the same text with the reference's optional OpenMP path
+    _libs = {}
+    _table = None
+
+    @staticmethod
+    def available(omp=False):
+        return os.path.exists(RefFilters.PATH_OMP if omp else RefFilters.PATH)
+
+    def __init__(self, class_table, omp=False):
+        if omp not in RefFilters._libs:
+            RefFilters._libs[omp] = C.CDLL(self.PATH_OMP if omp else self.PATH)
+        if RefFilters._table is None:
+            RefFilters._table = dict(class_table)
+        assert dict(class_table) == RefFilters._table, "one class table per process"
+        self.lib = RefFilters._libs[omp]
+        names = list(class_table)
+        arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+        ids = np.array([class_table[n] for n in names], np.int32)
+        f = self.lib.ref_filters_create
+        f.restype = C.c_void_p
+        f.argtypes = [C.c_void_p, i32p, C.c_int32]
+        self.h = f(C.addressof(arr), ids, len(names))
+        self._keep = []
+        self.unlabelled = int(class_table["unlabelled"])
+
+    def close(self):
+        if self.h:
+            f = self.lib.ref_filters_destroy
+            f.restype = None
+            f.argtypes = [C.c_void_p]
+            f(self.h)
+            self.h = None
+
+    def add_object(self, pos, nor, class_idx, uidx):
+        p, n_ = _f32(pos).copy(), _f32(nor).copy()
+        self._keep += [p, n_]
+        f = self.lib.ref_filters_add_object
+        f.restype = C.c_int32
+        f.argtypes = [C.c_void_p, f32p, f32p, C.c_int64, C.c_int32, C.c_int32]
+        return f(self.h, p, n_, len(p), int(class_idx), int(uidx))
+
+    def is_object_static(self, idx):
+        f = self.lib.ref_filters_is_object_static
+        f.restype = C.c_int32
+        f.argtypes = [C.c_void_p, C.c_int32]
+        return int(f(self.h, int(idx)))
+
+    def _plc_arrays(self, placements):
+        n = len(placements)
+        oi = np.array([int(p["object_idx"]) for p in placements] + [0] * (n == 0), np.int32)
+        ui = np.array([int(p["uidx"]) for p in placements] + [0] * (n == 0), np.int32)
+        po = _f32(np.stack([_f32(p["pose"]).ravel() for p in placements]) if n else np.zeros((1, 16)))
+        return oi, ui, po
+
+    def whole(self, scene_pos, scene_nor, placements, radius=0.05, prioritize_static=0):
+        """rspf_arrangement_to_labels itself -> (class_ids, instance_ids) of the scene's level 1."""
+        sp, sn = _f32(scene_pos).copy(), _f32(scene_nor).copy()
+        oi, ui, po = self._plc_arrays(placements)
+        cls = np.zeros(max(len(sp), 1), np.int32); inst = np.zeros(max(len(sp), 1), np.int32)
+        f = self.lib.ref_filters_arrangement_to_labels
+        f.restype = None
+        f.argtypes = [C.c_void_p, f32p, f32p, C.c_int64, i32p, i32p, f32p, C.c_int32, C.c_float, C.c_int32, i32p, i32p]
+        f(self.h, sp, sn, len(sp), oi, ui, po, len(placements), float(radius), int(prioritize_static), cls, inst)
+        return cls[:len(sp)], inst[:len(sp)]
+
+    def assign(self, scene_pos, scene_nor, placements, start, end, radius, labels, min_dists):
+        """rspf__assign_temporary_labels over placements[start:end] (visited in the order given), in place."""
+        sp, sn = _f32(scene_pos).copy(), _f32(scene_nor).copy()
+        oi, ui, po = self._plc_arrays(placements)
+        f = self.lib.ref_filters_assign_labels
+        f.restype = None
+        f.argtypes = [C.c_void_p, f32p, f32p, C.c_int64, i32p, i32p, f32p, C.c_int32, C.c_int32, C.c_int32, C.c_float, i8p, f32p]
+        f(self.h, sp, sn, len(sp), oi, ui, po, len(placements), int(start), int(end), float(radius), labels, min_dists)
+
+    def arrangement_to_labels(self, scene_pos, scene_nor, objects, placements, radius=0.05, prioritize_static=0,
+                              unlabelled_class_idx=0):
+        """Same arguments and result dict as Oracle.arrangement_to_labels, every array from the reference's compiled text:
+        class / instance ids from rspf_arrangement_to_labels as a whole; labels / min_dists from the reference's
+        rspf__assign_temporary_labels driven the way :837-848 drive it.  The visiting order that second part needs is the
+        stable order of the comparator's key (:724-736; glibc's qsort is a merge sort) and is PROVEN against the whole
+        function: mapping the labels through it must give exactly the whole function's ids."""
+        assert int(unlabelled_class_idx) == self.unlabelled
+        base = len(self._keep)          # object uidx must be unique per database (rsdb_add_object, rs_database.h:648-658); the loops never read it
+        idx = [self.add_object(o["pos"], o["nor"], o["class_idx"], 100000 + base + i) for i, o in enumerate(objects)]
+        for o, k in zip(objects, idx):
+            assert int(o["is_static"]) == self.is_object_static(k), "is_static must follow the class table (rs_database.h:257-288)"
+        plc = [dict(pose=p["pose"], object_idx=idx[int(p["object_idx"])], uidx=p["uidx"]) for p in placements]
+        cls, inst = self.whole(scene_pos, scene_nor, plc, radius, prioritize_static)
+        stat = [self.is_object_static(p["object_idx"]) for p in plc]
+        key = [(s << 10) | int(objects[int(p["object_idx"])]["class_idx"]) for s, p in zip(stat, placements)]
+        order = sorted(range(len(plc)), key=lambda i: key[i])
+        srt = [plc[i] for i in order]
+        first_static = next((i for i, k in enumerate(order) if stat[k]), 0)                      # :830-835
+        n = len(scene_pos)
+        labels = np.zeros(max(n, 1), np.int8); mind = np.full(max(n, 1), 1e9, np.float32)       # :799-802, :820
+        self.assign(scene_pos, scene_nor, srt, 0, first_static, radius, labels, mind)            # :837-839
+        if prioritize_static:
+            mind[:] = 1e9                                                                        # :841-844
+        r2 = np.float32(radius) if prioritize_static else np.float32(1.5) * np.float32(radius)   # :845
+        self.assign(scene_pos, scene_nor, srt, first_static, len(srt), r2, labels, mind)         # :846-848
+        labels, mind = labels[:n], mind[:n]
+        if len(srt):
+            sc = np.array([objects[int(placements[i]["object_idx"])]["class_idx"] for i in order], np.int32)
+            su = np.array([int(placements[i]["uidx"]) for i in order], np.int32)
+            li = np.maximum(labels.astype(np.int64) - 1, 0)
+            want_c = np.where(labels == 0, self.unlabelled, sc[li]); want_i = np.where(labels == 0, 1024, su[li])
+        else:
+            want_c = np.full(n, self.unlabelled); want_i = np.full(n, 1024)
+        assert (want_c == cls).all() and (want_i == inst).all(), "driver order differs from rspf_arrangement_to_labels' own"
+        return dict(labels=labels, min_dists=mind, order=np.array(order, np.int32), class_ids=cls, instance_ids=inst)
+
+    def compute_neighborhood(self, pos, nor, max_nn=8, radius_sq=0.0025, dist_exp=15.0, angle_exp=16.0):
+        """rspf_compute_neighborhood on a bare level-1 cloud -> (idx1, idx2, weight) in the reference's own output order."""
+        p, n_ = _f32(pos).copy(), _f32(nor).copy()
+        cap = max(len(p), 1) * max_nn
+        a = np.zeros(cap, np.int32); b = np.zeros(cap, np.int32); w = np.zeros(cap, np.float32)
+        f = self.lib.ref_filters_compute_neighborhood
+        f.restype = C.c_int64
+        f.argtypes = [f32p, f32p, C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_float, i32p, i32p, f32p]
+        m = f(p, n_, len(p), int(max_nn), float(radius_sq), float(dist_exp), float(angle_exp), a, b, w)
+        return a[:m].copy(), b[:m].copy(), w[:m].copy()
+
+
 def ref_level_poisson(pos, level, voxel_size=0.0):
     """The REAL reference's level builder (oracle/_ref/libref_ao.so: ref_level_poisson) -> sample indices."""
     lib = C.CDLL(RefAO.PATH)

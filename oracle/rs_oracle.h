@@ -8,14 +8,19 @@
  * Parity status: PINNED.  tests/test_oracle_vs_ref.py checks every function
  * here bit-for-bit against oracle/_ref (the real reference compiled in place)
  * on seeded inputs when /root/reference is present, and tests/golden/ holds
- * vectors generated from oracle/_ref by oracle/gen_golden.py.  One exception:
- * the *composition* of the label loop (lib/rs/rs_pointcloud_filters.cpp:738-879)
- * is restated but not run against the reference, because that TU needs the
- * un-vendored gco-v3.0 header; all primitives it calls (K=1 radius search,
- * mat4 inverse/transpose/mat·vec, normalise, the acosf gate) are pinned.  The
- * same holds for rspf_compute_neighborhood (:674-722, same TU): its pieces are
- * pinned (unsorted K=8 search; the edge weight compiled in a TU with that file's
- * include preamble) and the composition is checked against those pieces.
+ * vectors generated from oracle/_ref by oracle/gen_golden.py.  That includes
+ * the label loops and the neighbourhood graph (lib/rs/rs_pointcloud_filters.cpp:
+ * 674-879): that TU includes the un-vendored gco-v3.0 header, but only its last
+ * function (rspf_smooth_labels, :881-) uses gco, so oracle/Makefile compiles the
+ * file's own lines 1-14 + 16-879 — every line but the gco include, none edited,
+ * <cassert>/<cstring> force-included — into oracle/_ref/libref_filters.so
+ * (driver: oracle/ref_filters_driver.cpp), and orc_arrangement_to_labels,
+ * orc_assign_labels and orc_compute_neighborhood are held against
+ * rspf_arrangement_to_labels, rspf__assign_temporary_labels and
+ * rspf_compute_neighborhood themselves (tests/test_oracle_vs_ref.py::
+ * test_labels_vs_reference_text, ::test_neighborhood_vs_reference_text; the
+ * labels_*.npz, neighborhood_*.npz and bench_seed*.npz label fields come from
+ * that build).  Post-smoothing labels (gco) are out of scope and unpinned.
  * The scene-coverage term (orc_voxgrid_*, orc_rasterize_*, orc_coverage_score)
  * is pinned against the reference TU itself: apps/segment_transfer/
  * arrangement_optimization.cpp compiles from its own sources (oracle/_ref/libref_ao.so).

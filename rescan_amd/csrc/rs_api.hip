@@ -880,6 +880,8 @@ int icp_align_batch_impl( const rs_hip_cloud_t* source, const rs_hip_cloud_t* ta
     {
       if( ( rc = g_ws.ch_dbg.ensure( rows * ( 4 + 64 * 8 ) * 4 ) ) ) return rc;
       CB.dbg = g_ws.ch_dbg.as<int>(); CB.dbg_reps = std::max( 1, atoi( getenv( "RS_HIP_CHAIN_DEBUG" ) ) );
+      // the walk writes its mismatch marker only where it finds 0: a fresh (or an earlier call's) buffer must not speak for this one
+      HIP_TRY( hipMemsetAsync( g_ws.ch_dbg.p, 0, rows * ( 4 + 64 * 8 ) * 4, g_stream ), RS_HIP_E_RUNTIME );
       if( ( rc = g_ws.ch_chk.ensure( rows * ( 4 + 3 * 4096 ) * 4 ) ) ) return rc;
       HIP_TRY( hipMemsetAsync( g_ws.ch_chk.p, 0, rows * ( 4 + 3 * 4096 ) * 4, g_stream ), RS_HIP_E_RUNTIME );
       CB.chk = g_ws.ch_chk.as<int>();
@@ -1362,7 +1364,8 @@ int rs_hip_label_partial_device( const rs_hip_cloud_t* scene, const rs_hip_place
                                  float* min_dists_device, int8_t* labels_device )
 {
   int rc = ensure_ready(); if( rc ) return rc;
-  if( !scene || ( n > 0 && !scene->has_nor ) || !min_dists_device || !labels_device || n < 0 || ( n > 0 && !placements ) ) { set_err( "label_partial_device: bad arguments" ); return RS_HIP_E_ARG; }
+  // normals are required even for an empty run: the kernel loads a lane's scene normal before it looks at the placement count
+  if( !scene || !scene->has_nor || !min_dists_device || !labels_device || n < 0 || ( n > 0 && !placements ) ) { set_err( "label_partial_device: bad arguments" ); return RS_HIP_E_ARG; }
   if( label_base + n > 127 ) { set_err( "label_partial_device: more than 127 placements do not fit the reference's int8 labels" ); return RS_HIP_E_CAPACITY; }
   if( scene->n == 0 ) return RS_HIP_OK;
   if( n > 0 && ( rc = label_upload_placements( placements, n ) ) ) return rc;

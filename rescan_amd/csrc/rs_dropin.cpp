@@ -176,7 +176,7 @@ CloudRef cached_cloud( const rsd_vec3_t* pos, const rsd_vec3_t* nor, int32_t n, 
   if( !c ) { complain( "cloud upload" ); return CloudRef(); }
   CloudRef ref( c, CloudDeleter() );
   std::lock_guard<std::mutex> lock( g_cache_mutex );
-  g_cache.push_front( Entry{ pos, nor, n, cell, h, g_generation, full, sampled, 1u, ref } );
+  g_cache.push_front( Entry{ pos, nor, n, cell, h, g_generation, full, sampled, 0u, ref } );      // hits = 0: the FIRST hit re-checks the full hash, then every kVerifyEvery-th
   while( g_cache.size() > kMaxEntries ) g_cache.pop_back();        // (holders of the evicted cloud keep it alive)
   return ref;
 }

@@ -3,8 +3,8 @@
 * bench.py's 1 M-point step (BASELINE.json configs[1]) against tests/golden/bench_seed11.npz, and the same step on a second
   synthetic room against bench_seed23.npz — what the compiled reference
   computes for the same inputs (oracle/gen_golden_bench.py): pose / error after the 10 fixed ICP iterations, per-iteration
-  correspondence counts, the 256 alignment scores; labels / min_dists against the C restatement's (the reference's label TU
-  needs the un-vendored gco header).
+  correspondence counts, the 256 alignment scores; labels / min_dists / class and instance ids of the reference's own label
+  loops (rs_pointcloud_filters.cpp:738-879 compiled from its text, oracle/_ref/libref_filters.so).
 * 24 scan-to-scan icp_align runs on >= 100 k-point scans against tests/golden/sweep_icp.npz (the reference's own icp_align):
   the fp64-moment estimator used for sources above RS_HIP_REF_ORDER_BELOW, and the reference-order estimator.
 * the sharded route of bench.py (--shard / --gpus N): world of one, and a 2-way split simulated on one device, bit-identical
@@ -84,13 +84,19 @@ def test_headline_scores_vs_reference(capi, headline):
     assert d < SCORE_TOL
 
 
-def test_headline_labels_vs_restatement(capi, headline):
+def test_headline_labels_vs_reference(capi, headline):
+    """Label transfer at the headline's size against the reference's own loops (rs_pointcloud_filters.cpp:738-879 compiled from
+    its text, oracle/gen_golden_bench.py --labels-only): temporary labels, min_dists, class and instance ids, bit-exact."""
     w, g = headline
+    assert "reference" in str(g["labels_source"])
     res = capi.arrangement_to_labels(w["scan1"], w["plc_poses"], [p["cloud"] for p in w["plc"]], [0] * len(w["plc"]),
                                      [p["cls"] for p in w["plc"]], 0.05, False)
     assert (res["order"] == g["order"]).all()
     assert (res["labels"] == g["labels"]).all()
     assert sha(res["min_dists"]) == str(g["min_dists_sha"])
+    ids = capi.arrangement_to_ids(w["scan1"], w["plc_poses"], [p["cloud"] for p in w["plc"]], [0] * len(w["plc"]),
+                                  [p["cls"] for p in w["plc"]], list(range(len(w["plc"]))), 0.05, False, 0)
+    assert sha(ids["class_ids"]) == str(g["class_ids_sha"]) and sha(ids["instance_ids"]) == str(g["instance_ids_sha"])
 
 
 def test_headline_sharded_route_is_bit_identical(capi, bench_mod, headline):
@@ -219,6 +225,7 @@ def test_more_headline_rooms_vs_reference(capi, bench_mod, seed):
         assert d_stop < POSE_TOL, f"icp_align with the stop test: {d_stop:.3e} from the reference ({it2} vs {int(g['stop_iters'])} iterations)"
         assert d_sc < SCORE_TOL
         assert (res["order"] == g["order"]).all()
+        assert "reference" in str(g["labels_source"])
         assert sha(res["labels"]) == str(g["labels_sha"]) and sha(res["min_dists"]) == str(g["min_dists_sha"])
     finally:
         _close_workload(w)

@@ -352,12 +352,19 @@ def test_labels_vs_golden(capi, gscene, scene_clouds, fname):
     clouds, _ = scene_clouds
     oc = [capi.Cloud(o["pos"], o["nor"], cell_size=0.1) for o in objs]
     poses = np.stack([p["pose"] for p in plcs])
+    prio = bool(int(d["prioritize_static"]))
     res = capi.arrangement_to_labels(clouds[0.05], poses, [oc[p["object_idx"]] for p in plcs],
                                      [objs[p["object_idx"]]["is_static"] for p in plcs],
-                                     [objs[p["object_idx"]]["class_idx"] for p in plcs], 0.05, False)
+                                     [objs[p["object_idx"]]["class_idx"] for p in plcs], 0.05, prio)
     assert (res["order"] == d["order"]).all()
     assert (res["labels"] == d["labels"]).all()
     assert (res["min_dists"] == d["min_dists"]).all()
+    ids = capi.arrangement_to_ids(clouds[0.05], poses, [oc[p["object_idx"]] for p in plcs],
+                                  [objs[p["object_idx"]]["is_static"] for p in plcs], [objs[p["object_idx"]]["class_idx"] for p in plcs],
+                                  [p["uidx"] for p in plcs], 0.05, prio, 0)
+    assert (ids["class_ids"] == d["class_ids"]).all() and (ids["instance_ids"] == d["instance_ids"]).all()
+    if prio:
+        return        # the rows below model the shared min_dists of the default mode (rs_pointcloud_filters.cpp:841-848)
     # the sharded route: unary rows per placement, then the ordered arg-min, gives the same answer
     order = res["order"]
     first_static = next((k for k, oi in enumerate(order) if objs[plcs[oi]["object_idx"]]["is_static"]), 0)

@@ -64,10 +64,13 @@ def test_label_gate(oracle):
 
 @pytest.mark.parametrize("fname", golden_files("labels_"))
 def test_labels_reproducible(oracle, gscene, fname):
-    """labels_*.npz come from the restatement itself (the reference's label TU cannot be built
-    without gco); this guards the fixture + the rebuild of its inputs."""
+    """labels_*.npz hold the REFERENCE's outputs (rs_pointcloud_filters.cpp:738-879 compiled from its own text,
+    oracle/_ref/libref_filters.so, oracle/gen_golden.py): temporary labels, min_dists, visiting order, class / instance ids —
+    the restatement must reproduce all of them bit for bit (mixed, no static placement, prioritize_static, exact ties
+    between placements, several static placements)."""
     d, objs, plcs = label_case(gscene, fname)
-    res = oracle.arrangement_to_labels(gscene["points"], gscene["normals"], objs, plcs, 0.05, 0, 0)
+    assert "reference" in str(d["source"])
+    res = oracle.arrangement_to_labels(gscene["points"], gscene["normals"], objs, plcs, 0.05, int(d["prioritize_static"]), 0)
     for k in ("labels", "min_dists", "order", "class_ids", "instance_ids"):
         assert (res[k] == d[k]).all(), k
     assert (res["labels"] > 0).mean() > 0.1
@@ -100,6 +103,8 @@ def test_edge_cost(oracle):
 
 
 def test_neighborhood_reproducible(oracle, gscene):
+    """neighborhood_*.npz hold the REFERENCE's edges (rspf_compute_neighborhood, rs_pointcloud_filters.cpp:674-722, compiled
+    from its own text), sorted by pair key."""
     from oracle.pyoracle import edge_digest
     for fname in golden_files("neighborhood_obj"):
         d = load_golden(fname)

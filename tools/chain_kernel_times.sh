@@ -1,6 +1,8 @@
 #!/bin/bash
 # bash tools/chain_kernel_times.sh [tag]: rocprofv3 kernel stats of one whole-scan ICP with the centroid chains (tools/chain_profile.py)
-cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+set -e
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+export TMPDIR=/tmp; cd "$ROOT"
 tag=${1:-x}; rm -rf gpurun_out/prof_chain_$tag
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_chain_$tag -- python tools/chain_profile.py > gpurun_out/chain_prof_$tag.log 2>&1
 python - <<PY
