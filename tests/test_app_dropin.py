@@ -14,7 +14,7 @@ import pytest
 from conftest import ROOT
 
 REF = os.path.join(ROOT, "oracle", "_ref")
-BINS = [os.path.join(REF, b) for b in ("seg2rsdb", "pose_proposal", "pose_proposal_hip", "pose_proposal_hip2")]
+BINS = [os.path.join(REF, b) for b in ("seg2rsdb", "pose_proposal", "pose_proposal_hip", "pose_proposal_hip2", "pose_proposal_hip3")]
 
 pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(not all(os.path.exists(b) for b in BINS), reason="oracle/_ref apps not built")]
@@ -41,13 +41,15 @@ def computed_in(stdout):
     return float(m.group(1)) if m else float("nan")
 
 
-@pytest.mark.parametrize("which", ["icp", "icp+grid"])
+@pytest.mark.parametrize("which", ["icp", "icp+grid", "icp+grid+batched"])
 def test_pose_proposal_app_links_against_the_shim(tmp_path, which):
     """which = "icp": shadow/icp only (icp_align on the GPU); "icp+grid": shadow/icp + shadow/grid — also the app's own
     mgs_compute_object_alignment_score (83 % of its run time), its level builder and its level grids run on
-    the shim's msh_hash_grid_*."""
+    the shim's msh_hash_grid_*; "icp+grid+batched": in addition the app's grid search (mgs_propose_poses) is the batched driver
+    shadow/apps/pose_proposal_batched.cpp: one rsd_alignment_scores (k_score) per object and level instead of one small search
+    per pose — the proposal file must still be the reference build's."""
     from rescan_amd import synth
-    shim_bin = BINS[2] if which == "icp" else BINS[3]
+    shim_bin = {"icp": BINS[2], "icp+grid": BINS[3], "icp+grid+batched": BINS[4]}[which]
     seq = tmp_path / "seq"
     seq.mkdir()
     for t in (0, 1):
@@ -62,6 +64,8 @@ def test_pose_proposal_app_links_against_the_shim(tmp_path, which):
     print("Computed poses in: reference build %.3f s, shim build (%s) %.3f s" % (computed_in(cpu.stdout), which, computed_in(hip.stdout)))
     assert hip.returncode == 0, hip.stdout[-800:] + hip.stderr[-800:]
     assert "[rescan_hip]" not in hip.stderr, hip.stderr[-800:]                      # the shim reported no failure
+    if which == "icp+grid+batched":
+        assert "scored in one batch" in hip.stdout
     a = read_pose_bin(str(seq / "t1_cpu" / "t1_cpu.bin"))
     b = read_pose_bin(str(seq / "t1_hip" / "t1_hip.bin"))
     assert len(a) == len(b)

@@ -17,6 +17,10 @@ unmodified sources under /root/reference, prebuilt in the build container):
     icp     _ref/pose_proposal_hip      shadow/icp: icp_align on the GPU
     grid    _ref/pose_proposal_hip2     shadow/icp + shadow/grid: also the app's score loop, level builder and level grids
                                         on the shim's msh_hash_grid_* (device kernels for batched searches)
+    batched _ref/pose_proposal_hip3     grid + the app's grid search (mgs_propose_poses) bound to shadow/apps/pose_proposal_batched.cpp:
+                                        one rsd_alignment_scores call (k_score) per object and level
+--jobs J runs J sequences of a GPU build at a time on each GPU (the apps' host code is single-threaded and the GPU idles most of
+a run; a box admits few GPU processes, so J <= 4).
 One sequence per GPU (--gpus N: N worker processes, each bound to its device through HIP_VISIBLE_DEVICES); the CPU builds
 run one sequence at a time (omp uses every core by itself).  Per sequence and build: wall-clock of the process, the app's
 own "Computed poses in" (apps/pose_proposal/main.cpp:208), and the distance of its proposal .bin from the ref build's.
@@ -39,7 +43,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 REF = os.path.join(ROOT, "oracle", "_ref")
-BUILDS = {"ref": "pose_proposal", "omp": "pose_proposal_omp", "icp": "pose_proposal_hip", "grid": "pose_proposal_hip2"}
+BUILDS = {"ref": "pose_proposal", "omp": "pose_proposal_omp", "icp": "pose_proposal_hip", "grid": "pose_proposal_hip2", "batched": "pose_proposal_hip3"}
+GPU_BUILDS = ("icp", "grid", "batched")
 
 
 def list_sequences(list_filename):
@@ -83,7 +88,8 @@ def main():
     ap.add_argument("--sequences", type=int, default=8)
     ap.add_argument("--density", type=float, default=6400.0)
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--builds", default="ref,omp,icp,grid")
+    ap.add_argument("--builds", default="ref,omp,icp,grid,batched")
+    ap.add_argument("--jobs", type=int, default=1, help="sequences of a GPU build in flight per GPU")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "scene_list.json"))
     ap.add_argument("--workdir", default=None)
     args = ap.parse_args()
@@ -120,7 +126,7 @@ def main():
         out = []
         for stem in stems[1:]:
             env = dict(os.environ)
-            if build in ("icp", "grid"):
+            if build in GPU_BUILDS:
                 env["HIP_VISIBLE_DEVICES"] = str(device)
             if build == "omp":
                 # The reference's OpenMP split (msh_hash_grid.h:1119-1133) underflows `high_lim - low_lim` whenever
@@ -140,8 +146,8 @@ def main():
     t_total = {}
     for build in builds:
         t = time.perf_counter()
-        if build in ("icp", "grid") and args.gpus > 1:
-            with ThreadPoolExecutor(max_workers=args.gpus) as pool:           # one sequence per GPU
+        if build in GPU_BUILDS and args.gpus * args.jobs > 1:
+            with ThreadPoolExecutor(max_workers=args.gpus * min(args.jobs, 4)) as pool:           # one sequence per GPU (x --jobs)
                 futs = [pool.submit(pose_proposal, name, build, k % args.gpus) for k, name in enumerate(names)]
                 for f in futs:
                     rows += f.result()
@@ -179,7 +185,7 @@ def main():
                               max_pose_delta_good=max([r.get("max_pose_delta_good", 0.0) for r in pr] or [0.0]),
                               identical=int(sum(r.get("identical", 0) for r in pr)), proposals=int(sum(r.get("n_proposals", 0) for r in pr)))
     out = dict(config="BASELINE.json configs[0]/[4]: scene_list batch, seg2rsdb -> pose_proposal (segment_transfer not run: gco-v3.0 is not vendored)",
-               sequences=names, points_per_scan=n_pts, density=args.density, gpus=args.gpus, host_cores=len(os.sched_getaffinity(0)),
+               sequences=names, points_per_scan=n_pts, density=args.density, gpus=args.gpus, jobs_per_gpu=args.jobs, host_cores=len(os.sched_getaffinity(0)),
                omp_threads=int(os.environ.get("RS_SCENE_LIST_OMP_THREADS", "8")),
                builds_missing=missing, summary=summary, rows=rows)
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
