@@ -136,6 +136,16 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
                             float* T1s, int32_t n, const float* T2, float max_dist, float max_angle,
                             int32_t max_iter, int32_t fixed_iters, float* errs, int32_t* iters );
 
+/* Many independent icp_align problems with a DIFFERENT source each against one target — the per-placement refine loop of
+ * lib/rs/rs_database.h:220-230 (rsdb_refine_alignment_of_objects_to_scene) and apps/pose_proposal/main.cpp:190-202 — as one
+ * call: problem p aligns sources[p] from T1s[16 p].  Sources of at most rs_hip_icp_reference_order_below() points (every call
+ * site of the reference) advance in lock-step launches, grid.y = problem, each problem on its own source view; a batch that
+ * holds a larger source runs problem by problem.  Every problem's pose, error and iteration count are what rs_hip_icp_align
+ * returns for it alone, bit for bit. */
+int rs_hip_icp_align_multi( const rs_hip_cloud_t* const* sources, const rs_hip_cloud_t* target,
+                            float* T1s, int32_t n, const float* T2, float max_dist, float max_angle,
+                            int32_t max_iter, int32_t fixed_iters, float* errs, int32_t* iters );
+
 /* icp_find_corrs (lib/rs/icp.h:306-412), one call: compacted correspondences in source
  * order.  Output arrays are caller-allocated with capacity 3*n_source floats (weights:
  * n_source); *n_corrs receives the count. */

@@ -23,7 +23,7 @@ container only; the fixtures are committed so the GPU box, which has no /root/re
         on the same two ~0.98 M-point scans, the three call sites' parameter sets in turn and start poses from
         5 mm / 0.3 deg to 3 cm / 2 deg (MORE_SEEDS, more_stop_case)
 
-Usage:  python oracle/gen_golden_bench.py [--bench-only [--seed N] | --sweep-only | --more [--seed N] | --labels-only [--seed N]]
+Usage:  python oracle/gen_golden_bench.py [--bench-only [--seed N] | --sweep-only | --more [--seed N] | --labels-only [--seed N] | --strong-only]
         --labels-only recomputes the label fields of every bench_seed*.npz from the reference build and leaves the rest as it is
 """
 import ctypes as C
@@ -140,6 +140,29 @@ def label_fields(lab):
                 instance_ids_sha=sha(lab["instance_ids"]))
 
 
+def restrong(seed=11):
+    """--strong-only: the ICP units of `bench.py --scaling strong` — each placement's ~50 k-point model refined against the scan with
+    rsdb_refine_alignment_of_objects_to_scene's parameters (lib/rs/rs_database.h:220-230: 0.075, 50 deg), ten fixed iterations — by the
+    reference (ref_icp_iterate, stop test off), added to bench_seed<seed>.npz; everything else is kept."""
+    import bench
+    path = os.path.join(OUT, "bench_seed%d.npz" % seed)
+    g = dict(np.load(path))
+    w = bench.build_inputs(1_000_000, seed=seed)
+    R = Ref()
+    si = w["strong_icp"]
+    poses, errs = [], []
+    for k, p in enumerate(w["plc"][:bench.N_PLACEMENTS]):
+        t = time.time()
+        T, err, done, nc, _ = ref_iterate(R, p["np"][0], p["np"][1], w["s1"]["points"], w["s1"]["normals"], si["T0s"][k], I4,
+                                          np.float32(si["max_dist"]), np.float32(si["max_angle"]), bench.ICP_ITERS, 0)
+        assert done == bench.ICP_ITERS
+        poses.append(T); errs.append(err)
+        print(f"strong icp unit {k}: {len(p['np'][0])} source points, err {err:.6f}, n_corrs {nc.tolist()} ({time.time()-t:.1f} s)", flush=True)
+    g.update(strong_icp_pose=np.stack(poses), strong_icp_err=np.array(errs, np.float32),
+             strong_icp_sha=np.array([sha(p["np"][0]) for p in w["plc"][:bench.N_PLACEMENTS]] + [sha(si["T0s"])]))
+    np.savez_compressed(path, **g)
+
+
 def relabel(seed):
     """--labels-only: the label fields of bench_seed<seed>.npz again, from the reference build; everything else is kept."""
     import bench
@@ -182,6 +205,9 @@ def gen_sweep(R):
 
 if __name__ == "__main__":
     build(ref=True)
+    if "--strong-only" in sys.argv:
+        restrong(11)
+        sys.exit(0)
     if "--labels-only" in sys.argv:
         for seed in BENCH_SEEDS + MORE_SEEDS:
             if "--seed" not in sys.argv or str(seed) == sys.argv[sys.argv.index("--seed") + 1]:

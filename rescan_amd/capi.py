@@ -44,6 +44,8 @@ SIGNATURES = {
     "rs_hip_icp_chains_gave_up": (C.c_int32, []),
     "rs_hip_icp_align_batch": (C.c_int, [C.c_void_p, C.c_void_p, f32p, C.c_int32, f32p, C.c_float, C.c_float,
                                          C.c_int32, C.c_int32, f32p, i32p]),
+    "rs_hip_icp_align_multi": (C.c_int, [C.c_void_p, C.c_void_p, f32p, C.c_int32, f32p, C.c_float, C.c_float,
+                                         C.c_int32, C.c_int32, f32p, i32p]),
     "rs_hip_icp_find_corrs": (C.c_int, [C.c_void_p, C.c_void_p, f32p, f32p, C.c_float, C.c_float,
                                         f32p, f32p, f32p, f32p, f32p, C.POINTER(C.c_int32)]),
     "rs_hip_alignment_scores": (C.c_int, [C.c_void_p, C.c_void_p, f32p, C.c_int32, C.c_float, C.c_int32, f32p]),
@@ -273,6 +275,18 @@ def icp_align_batch(source, target, T1s, T2=IDENTITY, max_dist=0.1, max_angle=np
     _check(load().rs_hip_icp_align_batch(source.handle, target.handle, T, n, _f32(T2).ravel(), float(max_dist),
                                          float(np.float32(max_angle)), int(max_iter), int(bool(fixed_iters)),
                                          errs, its))
+    return errs, T, its
+
+
+def icp_align_multi(sources, target, T1s, T2=IDENTITY, max_dist=0.1, max_angle=np.deg2rad(60.0), max_iter=100, fixed_iters=False):
+    """rs_hip_icp_align_multi: problem p aligns sources[p] (a Cloud each) to `target` from T1s[p] — one call."""
+    T = _f32(T1s).reshape(-1, 16).copy()
+    n = len(T)
+    assert n == len(sources)
+    handles = (C.c_void_p * max(1, n))(*[s_.handle for s_ in sources])
+    errs = np.zeros(n, np.float32); its = np.zeros(n, np.int32)
+    _check(load().rs_hip_icp_align_multi(C.addressof(handles), target.handle, T, n, _f32(T2).ravel(), float(max_dist),
+                                         float(np.float32(max_angle)), int(max_iter), int(bool(fixed_iters)), errs, its))
     return errs, T, its
 
 

@@ -97,7 +97,7 @@ struct PinBuf
 
 struct Workspace
 {
-  DevBuf state, slot, d2, dot, stat_acc, mom_part, res, wexp, queue, queue_count;   // ICP
+  DevBuf state, slot, d2, dot, stat_acc, mom_part, res, wexp, queue, queue_count, multi;   // ICP (multi: the per-problem views of a multi-source batch)
   DevBuf poses, score_part, scores;                                             // score
   DevBuf plc, labels, mind, fold_off, labels_o, mind_o, rows_o, ids_tab, ids_out, attr_in, attr_out;                 // labels (state in query order; *_o: input order)
   DevBuf q4, rd2, ridx, rnn, rows;                                              // rows / misc
@@ -630,35 +630,70 @@ inline float radius_sq_of( float r ) { return (float)( (double)r * (double)r ); 
 struct IcpCtx
 {
   IcpLaunch L{};
-  int n_waves = 0;
+  int n_waves = 0;             // tiles of the (largest) source: the searches' grid
+  size_t total_pts = 0;        // rows of the per-point arrays over all problems (one source: n_prob x n)
+  size_t total_tiles = 0;      // likewise per tile
+  size_t heavy_words = 0;      // words of one slow-tile buffer over all problems
 };
 
 // Device-resident loop state, one 4-byte word array after the other (n = n_prob):
 //   T1 16n | active n | T1_prev 16n | iters n | err n | prev_err n | queued n | ticket 2n
 constexpr size_t ICP_STATE_WORDS = 16 + 1 + 16 + 1 + 1 + 1 + 1 + 2;
 
-int icp_prepare( IcpCtx& cx, const rs_hip_cloud_t* src, const rs_hip_cloud_t* tgt, int n_prob, const float* T2 )
+// One source for all problems (src), or one per problem (srcs[n_prob], src == null: a multi-source batch — the kernels then bind
+// their problem's view on the device, rs_kernels.hip: icp_bind).
+int icp_prepare( IcpCtx& cx, const rs_hip_cloud_t* src, const rs_hip_cloud_t* tgt, int n_prob, const float* T2, const rs_hip_cloud_t* const* srcs = nullptr )
 {
-  if( !src || !tgt || !src->has_nor || !tgt->has_nor ) { set_err( "icp: source and target clouds need normals" ); return RS_HIP_E_ARG; }
   if( n_prob <= 0 ) { set_err( "icp: empty batch" ); return RS_HIP_E_ARG; }
+  if( !tgt || !tgt->has_nor || ( !src && !srcs ) ) { set_err( "icp: source and target clouds need normals" ); return RS_HIP_E_ARG; }
+  for( int p = 0; p < ( srcs ? n_prob : 1 ); ++p )
+  {
+    const rs_hip_cloud_t* c = srcs ? srcs[p] : src;
+    if( !c || !c->has_nor ) { set_err( "icp: source and target clouds need normals" ); return RS_HIP_E_ARG; }
+  }
   IcpLaunch& L = cx.L;
-  L.tgt = tgt->view; L.tgt.evals = g_prof ? g_evals : nullptr; L.src = src->qview; L.n_prob = n_prob; L.K = 16;   // icp.h:330
+  L.tgt = tgt->view; L.tgt.evals = g_prof ? g_evals : nullptr; L.n_prob = n_prob; L.K = 16;   // icp.h:330
   Mat4 t2; std::memcpy( t2.m, T2, 64 );
   Mat4 t2i = mat4_inverse( t2 );                                                                             // icp.h:329
   std::memcpy( L.T2i.m, t2i.m, 64 );
-  cx.n_waves = src->qview.n_tiles;
-  L.n_mom_blocks = std::max( 1, std::min( 512, ( src->n + 255 ) / 256 ) );    // 512: gathers want more waves in flight than 256 give, the final tree fewer partials than 1024
-  const size_t nq = std::max<size_t>( 1, (size_t)src->n ), np = (size_t)n_prob;
+  const size_t np = (size_t)n_prob;
   int rc;
+  L.multi = nullptr;
+  if( srcs )
+  {
+    std::vector<IcpProblem> P( np );
+    size_t pts = 0, tiles = 0, heavy = 0; int max_n = 0, max_tiles = 0;
+    for( size_t p = 0; p < np; ++p )
+    {
+      P[p].src = srcs[p]->qview; P[p].by_orig = srcs[p]->d_qby_orig;
+      P[p].pt_off = (long long)pts; P[p].tile_off = (long long)tiles; P[p].heavy_off = (long long)heavy;
+      pts += (size_t)srcs[p]->n; tiles += (size_t)srcs[p]->qview.n_tiles; heavy += heavy_stride( srcs[p]->qview.n_tiles );
+      max_n = std::max( max_n, (int)srcs[p]->n ); max_tiles = std::max( max_tiles, srcs[p]->qview.n_tiles );
+    }
+    if( ( rc = g_ws.multi.ensure( np * sizeof( IcpProblem ) ) ) ) return rc;
+    HIP_TRY( hipMemcpyAsync( g_ws.multi.p, P.data(), np * sizeof( IcpProblem ), hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
+    HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );      // (P is a local)
+    L.multi = (const IcpProblem*)g_ws.multi.p; L.src = QueryView{}; L.by_orig = nullptr;
+    L.max_n = max_n; L.max_tiles = max_tiles;
+    cx.total_pts = std::max<size_t>( 1, pts ); cx.total_tiles = std::max<size_t>( 1, tiles ); cx.heavy_words = heavy;
+  }
+  else
+  {
+    L.src = src->qview; L.by_orig = src->d_qby_orig; L.max_n = src->n; L.max_tiles = src->qview.n_tiles;
+    cx.total_pts = np * std::max<size_t>( 1, (size_t)src->n ); cx.total_tiles = np * (size_t)std::max( 1, src->qview.n_tiles );
+    cx.heavy_words = np * heavy_stride( src->qview.n_tiles );
+  }
+  cx.n_waves = L.max_tiles;
+  L.n_mom_blocks = std::max( 1, std::min( 512, ( L.max_n + 255 ) / 256 ) );    // 512: gathers want more waves in flight than 256 give, the final tree fewer partials than 1024
   if( ( rc = g_ws.state.ensure( np * ICP_STATE_WORDS * 4 ) ) ||
-      ( rc = g_ws.slot.ensure( np * nq * 4 ) ) || ( rc = g_ws.d2.ensure( np * nq * 4 ) ) || ( rc = g_ws.dot.ensure( np * nq * 4 ) ) ||
+      ( rc = g_ws.slot.ensure( cx.total_pts * 4 ) ) || ( rc = g_ws.d2.ensure( cx.total_pts * 4 ) ) || ( rc = g_ws.dot.ensure( cx.total_pts * 4 ) ) ||
       ( rc = g_ws.stat_acc.ensure( np * STAT_SHARDS * 4 * 8 ) ) ||
       ( rc = g_ws.mom_part.ensure( np * L.n_mom_blocks * ICP_NMOM * 8 ) ) || ( rc = g_ws.res.ensure( np * ICP_NRES * 8 ) ) ||
       ( rc = g_ws.h_a.ensure( np * ICP_NRES * 8 ) ) || ( rc = g_ws.h_b.ensure( np * ICP_STATE_WORDS * 4 ) ) ||
-      ( rc = g_ws.queue.ensure( np * std::max( 1, cx.n_waves ) * 4 ) ) || ( rc = g_ws.queue_count.ensure( np * 4 ) ) )
+      ( rc = g_ws.queue.ensure( cx.total_tiles * 4 ) ) || ( rc = g_ws.queue_count.ensure( np * 4 ) ) )
     return rc;
   L.queue = g_ws.queue.as<int>(); L.queue_count = g_ws.queue_count.as<int>();
-  L.solo_stages = handoff_threshold( (long long)cx.n_waves * n_prob );
+  L.solo_stages = handoff_threshold( (long long)cx.total_tiles );
   static const int heavy_streamed = getenv( "RS_HIP_HEAVY_STREAMED" ) ? atoi( getenv( "RS_HIP_HEAVY_STREAMED" ) ) : 400;
   static const int heavy_handoff = getenv( "RS_HIP_HEAVY_HANDOFF" ) ? atoi( getenv( "RS_HIP_HEAVY_HANDOFF" ) ) : 600;
   L.heavy_streamed = heavy_streamed; L.heavy_handoff = heavy_handoff;
@@ -676,7 +711,7 @@ int icp_prepare( IcpCtx& cx, const rs_hip_cloud_t* src, const rs_hip_cloud_t* tg
   L.stat_acc = nullptr;       // set by the align loop (fp64 estimator only)
   L.mom_part = g_ws.mom_part.as<double>(); L.res = g_ws.res.as<double>();
   L.w_explicit = nullptr;
-  L.by_orig = src->d_qby_orig; L.faith = nullptr;
+  L.faith = nullptr;
   HIP_TRY( hipMemsetAsync( g_ws.queue_count.p, 0, np * 4, g_stream ), RS_HIP_E_RUNTIME );
   return RS_HIP_OK;
 }
@@ -713,16 +748,17 @@ int icp_upload_state( IcpCtx& cx, const float* T1s, size_t np )
 }
 
 // Certificates on (rs_kernels.hip: icp_certificate): two floats per (problem, source point).
-int icp_enable_certificates( IcpCtx& cx, size_t np, size_t nq )
+int icp_enable_certificates( IcpCtx& cx )
 {
   int rc;
+  const size_t words = cx.total_pts;
   if( getenv( "RS_HIP_NO_CERT" ) || !std::isfinite( cx.L.tgt_nor_max ) ) return RS_HIP_OK;
-  if( ( rc = g_ws.cert_r.ensure( np * nq * 4 ) ) || ( rc = g_ws.cert_dot.ensure( np * nq * 4 ) ) ) return rc;
-  HIP_TRY( hipMemsetAsync( g_ws.cert_r.p, 0xFF, np * nq * 4, g_stream ), RS_HIP_E_RUNTIME );      // NaN: no certificate
+  if( ( rc = g_ws.cert_r.ensure( words * 4 ) ) || ( rc = g_ws.cert_dot.ensure( words * 4 ) ) ) return rc;
+  HIP_TRY( hipMemsetAsync( g_ws.cert_r.p, 0xFF, words * 4, g_stream ), RS_HIP_E_RUNTIME );      // NaN: no certificate
   cx.L.cert_r = g_ws.cert_r.as<float>(); cx.L.cert_dot = g_ws.cert_dot.as<float>();
   if( !getenv( "RS_HIP_NO_RANK_CERT" ) )            // read only next to a valid cert_r, written with every fresh one: no initialisation
   {
-    if( ( rc = g_ws.cert_slack.ensure( np * nq * 4 ) ) ) return rc;
+    if( ( rc = g_ws.cert_slack.ensure( words * 4 ) ) ) return rc;
     cx.L.cert_slack = g_ws.cert_slack.as<float>();
   }
   return RS_HIP_OK;
@@ -842,7 +878,7 @@ int icp_align_batch_impl( const rs_hip_cloud_t* source, const rs_hip_cloud_t* ta
   if( ( rc = icp_prepare( cx, source, target, n, T2 ) ) ) return rc;
   const float tmin = icp_gate_threshold( max_angle );
   if( source->n == 0 ) { for( int p = 0; p < n; ++p ) { errs[p] = 1e6f; if( iters ) iters[p] = 1; } return RS_HIP_OK; }   // n_corrs == 0 on the first search
-  if( ( rc = icp_enable_certificates( cx, (size_t)n, (size_t)source->n ) ) ) return rc;
+  if( ( rc = icp_enable_certificates( cx ) ) ) return rc;
   if( ( rc = icp_upload_state( cx, T1s, (size_t)n ) ) ) return rc;
   const bool ref_order = source->n <= g_ref_order_below.load();
   const bool replay = !ref_order && source->n <= g_replay_below.load();
@@ -896,7 +932,7 @@ int icp_align_batch_impl( const rs_hip_cloud_t* source, const rs_hip_cloud_t* ta
     HIP_TRY( hipMemsetAsync( g_ws.stat_acc.p, 0, (size_t)n * STAT_SHARDS * 4 * 8, g_stream ), RS_HIP_E_RUNTIME );
     cx.L.stat_acc = g_ws.stat_acc.as<unsigned long long>();
   }
-  const size_t heavy_words = (size_t)n * heavy_stride( cx.n_waves );
+  const size_t heavy_words = cx.heavy_words;
   const bool reorder = !getenv( "RS_HIP_NO_LPT" );
   if( reorder )
   {
@@ -914,7 +950,7 @@ int icp_align_batch_impl( const rs_hip_cloud_t* source, const rs_hip_cloud_t* ta
   const size_t np = (size_t)n, state_bytes = np * ICP_STATE_WORDS * 4;
   float* hS = g_ws.h_b.as<float>();
   const int* hActive = (const int*)( hS + np * 16 );
-  const long long total_tiles = (long long)cx.n_waves * n;
+  const long long total_tiles = (long long)cx.total_tiles;
   static const long long coop_all_below = getenv( "RS_HIP_COOP_ALL_BELOW" ) ? atoll( getenv( "RS_HIP_COOP_ALL_BELOW" ) ) : 4096;
   static const int coop_waves_forced = getenv( "RS_HIP_COOP_WAVES" ) ? atoi( getenv( "RS_HIP_COOP_WAVES" ) ) : 0;
   static const int chain_refresh = std::max( 0, getenv( "RS_HIP_CHAIN_REFRESH" ) ? atoi( getenv( "RS_HIP_CHAIN_REFRESH" ) ) : 0 );
@@ -1037,6 +1073,88 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
   int rc = icp_align_batch_impl( source, target, T1s, n, T2, max_dist, max_angle, max_iter, fixed_iters, errs, iters, g_exact_centroids.load() );
   if( rc == ICP_CHAINS_GAVE_UP ) rc = icp_align_batch_impl( source, target, T1s, n, T2, max_dist, max_angle, max_iter, fixed_iters, errs, iters, 2 );
   return rc;
+}
+
+// The per-placement refine loop as one call (lib/rs/rs_database.h:220-230, apps/pose_proposal/main.cpp:190-202 with a different
+// object per proposal): problem p aligns sources[p] to the target from T1s[p].  Sources within the reference-order estimator's
+// range (rs_hip_icp_reference_order_below: every call site of the reference) run as ONE batch — grid.y = problem, the kernels bind
+// their problem's source view on the device (rs_kernels.hip: icp_bind), so the sequential chains of all problems run side by side;
+// every problem's result is what rs_hip_icp_align returns for it alone, bit for bit.  A batch with a larger source is run
+// problem by problem (their estimators are built for one source per launch).
+int rs_hip_icp_align_multi( const rs_hip_cloud_t* const* sources, const rs_hip_cloud_t* target,
+                            float* T1s, int32_t n, const float* T2, float max_dist, float max_angle,
+                            int32_t max_iter, int32_t fixed_iters, float* errs, int32_t* iters )
+{
+  int rc = ensure_ready(); if( rc ) return rc;
+  if( !sources || !T1s || !T2 || !errs || n < 0 ) { set_err( "icp_align_multi: bad arguments" ); return RS_HIP_E_ARG; }
+  if( n == 0 ) return RS_HIP_OK;
+  bool one_batch = n > 1;
+  for( int p = 0; p < n; ++p )
+  {
+    if( !sources[p] ) { set_err( "icp_align_multi: null source" ); return RS_HIP_E_ARG; }
+    one_batch = one_batch && sources[p]->n > 0 && sources[p]->n <= g_ref_order_below.load();
+  }
+  if( !one_batch )
+  {
+    for( int p = 0; p < n; ++p )
+      if( ( rc = rs_hip_icp_align_batch( sources[p], target, T1s + 16 * p, 1, T2, max_dist, max_angle, max_iter, fixed_iters, errs + p, iters ? iters + p : nullptr ) ) ) return rc;
+    return RS_HIP_OK;
+  }
+  IcpCtx cx;
+  if( ( rc = icp_prepare( cx, nullptr, target, n, T2, sources ) ) ) return rc;
+  const float tmin = icp_gate_threshold( max_angle );
+  if( ( rc = icp_enable_certificates( cx ) ) ) return rc;
+  if( ( rc = icp_upload_state( cx, T1s, (size_t)n ) ) ) return rc;
+  if( ( rc = g_ws.faith.ensure( (size_t)FAITH_REC * cx.total_pts * 4 ) ) ) return rc;
+  cx.L.faith = g_ws.faith.as<float>();
+  const bool reorder = !getenv( "RS_HIP_NO_LPT" );
+  if( reorder )
+  {
+    if( ( rc = g_ws.order_a.ensure( cx.heavy_words * 4 ) ) || ( rc = g_ws.order_b.ensure( cx.heavy_words * 4 ) ) ) return rc;
+    HIP_TRY( hipMemsetAsync( g_ws.order_a.p, 0, cx.heavy_words * 4, g_stream ), RS_HIP_E_RUNTIME );
+    HIP_TRY( hipMemsetAsync( g_ws.order_b.p, 0, cx.heavy_words * 4, g_stream ), RS_HIP_E_RUNTIME );
+  }
+  // the loop of icp_align_batch_impl, reference-order estimator only
+  static const int chunk_env = getenv( "RS_HIP_ICP_CHUNK" ) ? atoi( getenv( "RS_HIP_ICP_CHUNK" ) ) : 4;
+  static const long long coop_all_below = getenv( "RS_HIP_COOP_ALL_BELOW" ) ? atoll( getenv( "RS_HIP_COOP_ALL_BELOW" ) ) : 4096;
+  static const int coop_waves_forced = getenv( "RS_HIP_COOP_WAVES" ) ? atoi( getenv( "RS_HIP_COOP_WAVES" ) ) : 0;
+  const size_t np = (size_t)n, state_bytes = np * ICP_STATE_WORDS * 4;
+  float* hS = g_ws.h_b.as<float>();
+  const int* hActive = (const int*)( hS + np * 16 );
+  const long long total_tiles = (long long)cx.total_tiles;
+  cx.L.solve = 1; cx.L.fixed_iters = fixed_iters ? 1 : 0;
+  ProfChain prof;
+  for( int i = 0; i < max_iter; )                                       // icp.h:444
+  {
+    const int chunk = fixed_iters ? max_iter - i : std::min( std::max( 1, chunk_env ), max_iter - i );
+    for( int c = 0; c < chunk; ++c, ++i )
+    {
+      icp_set_radius( cx, max_dist, tmin );
+      cx.L.iter_index = i;
+      cx.L.warm = ( i > 0 && !getenv( "RS_HIP_NO_WARM" ) ) ? 1 : 0;
+      cx.L.coop_all = total_tiles <= coop_all_below ? 1 : 0;
+      cx.L.coop_waves = cx.L.coop_all ? ( total_tiles <= 1536 ? 8 : 4 ) : ( ( i >= 2 && cx.L.cert_r ) ? 8 : 4 );
+      if( coop_waves_forced ) cx.L.coop_waves = coop_waves_forced;
+      if( reorder )
+      {
+        cx.L.heavy_in = i == 0 ? nullptr : ( ( i & 1 ) ? g_ws.order_a.as<int>() : g_ws.order_b.as<int>() );
+        cx.L.heavy_out = ( i & 1 ) ? g_ws.order_b.as<int>() : g_ws.order_a.as<int>();
+      }
+      prof.mark( "nn_icp" ); launch_icp_corr( cx.L, g_stream );
+      prof.mark( "icp_moments" ); launch_icp_faithful( cx.L, g_stream );
+      double nd = max_dist * 0.95;                                      // icp.h:493
+      max_dist = (float)( nd > 0.05 ? nd : 0.05 );
+    }
+    prof.mark( nullptr );
+    HIP_TRY( hipMemcpyAsync( hS, g_ws.state.p, state_bytes, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
+    HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
+    int n_active = 0;
+    for( int p = 0; p < n; ++p ) n_active += hActive[p] ? 1 : 0;
+    if( n_active == 0 ) break;
+  }
+  const int* hIters = (const int*)( hS + np * 33 );
+  for( int p = 0; p < n; ++p ) { std::memcpy( T1s + 16 * p, hS + 16 * p, 64 ); errs[p] = hS[np * 34 + p]; if( iters ) iters[p] = hIters[p]; }
+  return RS_HIP_OK;
 }
 
 int32_t rs_hip_icp_chains_gave_up( void ) { return g_chains_gave_up.load(); }

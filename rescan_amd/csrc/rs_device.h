@@ -61,10 +61,21 @@ constexpr int HEAVY_HDR = HEAVY_CLASSES + 8;                         // header w
 constexpr int HEAVY_MEAN_REF = 320;  // mean up to which the thresholds below apply as they are (the 1 M-point headline: 300 after the cold launch, 200 later); beyond, they grow with it
 __host__ __device__ inline size_t heavy_stride( int n_tiles ) { return (size_t)n_tiles + HEAVY_SLOTS + HEAVY_HDR; }
 
+// One problem of a multi-source batch: its own source view and where its rows of the per-point / per-tile arrays begin.
+struct IcpProblem
+{
+  QueryView  src;
+  const int* by_orig;          // original source index -> query slot
+  long long  pt_off, tile_off, heavy_off;
+};
+
 struct IcpLaunch
 {
   GridView     tgt;
-  QueryView    src;            // source cloud (query order)
+  QueryView    src;            // source cloud (query order); multi-source batches: bound per problem on the device (icp_bind)
+  const IcpProblem* multi;     // device, n_prob entries (null: one source for all problems)
+  long long    pt_off, tile_off, heavy_off;   // set by icp_bind: where this problem's rows begin (points / tiles / slow-tile lists)
+  int          max_n, max_tiles;              // largest problem's (grid sizes); single source: src.n, src.n_tiles
   int          n_prob;         // batch size
   float*       T1;             // device, n_prob x 16: current poses (updated on the device by every iteration)
   int*         active;         // device, n_prob flags (0 = skip; cleared on the device when a problem stops)

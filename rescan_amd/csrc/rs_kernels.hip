@@ -1285,6 +1285,23 @@ __device__ __forceinline__ Match coop_search( const GridView& g, bool active,
 // ICP: correspondence search  (lib/rs/icp.h:339-391)
 // ------------------------------------------------------------------------------------------
 
+// A kernel's view of ITS problem.  One source for the whole batch (rs_hip_icp_align_batch: n start poses of one cloud): the
+// problem's rows of the per-point / per-tile arrays begin at prob * n; a multi-source batch (rs_hip_icp_align_multi: the
+// per-placement refine loop of lib/rs/rs_database.h:220-230, every problem its own cloud) carries one IcpProblem per problem.
+__device__ __forceinline__ void icp_bind( IcpLaunch& L, int prob )
+{
+  if( L.multi )
+  {
+    const IcpProblem& P = L.multi[prob];
+    L.src = P.src; L.by_orig = P.by_orig; L.pt_off = P.pt_off; L.tile_off = P.tile_off; L.heavy_off = P.heavy_off;
+  }
+  else
+  {
+    L.pt_off = (long long)prob * L.src.n; L.tile_off = (long long)prob * L.src.n_tiles;
+    L.heavy_off = (long long)( (size_t)prob * heavy_stride( L.src.n_tiles ) );
+  }
+}
+
 // Source point i of problem `prob` in the target's frame (icp.h:339-347).
 __device__ __forceinline__ void icp_query( const IcpLaunch& L, const Xform& T1, int i, bool active,
                                            float& qx, float& qy, float& qz, float& nx, float& ny, float& nz )
@@ -1347,7 +1364,7 @@ __device__ __forceinline__ Match icp_warm_start( const IcpLaunch& L, int prob, i
   Match m = no_match();
   if( !active ) return m;
   if( !L.warm ) return L.seed ? icp_cell_seed( L, active, qx, qy, qz, nx, ny, nz ) : m;
-  const int s = L.m_slot[(size_t)prob * L.src.n + i];
+  const int s = L.m_slot[(size_t)L.pt_off + i];
   if( s < 0 ) return m;
   const float4 P = L.tgt.pos[s], N = L.tgt.nor[s];
   float vx = P.x - qx, vy = P.y - qy, vz = P.z - qz;
@@ -1379,7 +1396,7 @@ __device__ __forceinline__ bool icp_certificate( const IcpLaunch& L, int prob, i
                                                  float qx, float qy, float qz, float nx, float ny, float nz )
 {
   if( !L.cert_r || !L.warm || !active ) return false;
-  const size_t o = (size_t)prob * L.src.n + i;
+  const size_t o = (size_t)L.pt_off + i;
   const float r = L.cert_r[o];
   if( !( r > 0.0f ) ) return false;
   // the same query under the previous iteration's pose (identical float operations as then)
@@ -1415,7 +1432,7 @@ __device__ __forceinline__ bool icp_certificate( const IcpLaunch& L, int prob, i
 __device__ __forceinline__ void icp_emit( const IcpLaunch& L, int prob, int tile, int i, bool active, int lane, const Match& m,
                                           bool skipped )
 {
-  const size_t o = (size_t)prob * L.src.n + i;
+  const size_t o = (size_t)L.pt_off + i;
   if( active ) { L.m_slot[o] = m.found ? m.slot : -1; if( !L.rec ) { L.m_d2[o] = m.d2; L.m_dot[o] = m.dot; } }
   if( active && L.rec )
   {
@@ -1430,7 +1447,7 @@ __device__ __forceinline__ void icp_emit( const IcpLaunch& L, int prob, int tile
     float4 P = make_float4( 0.0f, 0.0f, 0.0f, 0.0f ), N = P;
     if( m.found ) { P = L.tgt.pos[m.slot]; N = L.tgt.nor[m.slot]; }
     const int orig = __float_as_int( L.src.pos[i].w );
-    float4* R = L.rec + ( (size_t)prob * L.src.n + orig ) * REC_F4;
+    float4* R = L.rec + ( (size_t)L.pt_off + orig ) * REC_F4;
     R[0] = make_float4( qx, qy, qz, m.found ? m.d2 : -1.0f );
     R[1] = make_float4( P.x, P.y, P.z, m.dot );
     R[2] = make_float4( N.x, N.y, N.z, 0.0f );
@@ -1489,7 +1506,7 @@ __device__ __forceinline__ void icp_iteration_reset( const IcpLaunch& L, int pro
     // "slow tile" thresholds are absolute numbers of candidates (a lone wave's time) up to a mean of HEAVY_MEAN_REF and scale with
     // the mean beyond — on a target four times as dense EVERY tile streams four times as many, and a third of them went to the
     // cooperative kernel (2x the search time at 4 M points per scan).
-    int* ho = L.heavy_out + (size_t)prob * heavy_stride( L.src.n_tiles );
+    int* ho = L.heavy_out + (size_t)L.heavy_off;
     const int n_t = L.src.n_tiles, step = max( 1, n_t / ( 4 * WAVE ) );
     unsigned long long acc = 0;                          // sum << 32 | count
 #pragma unroll
@@ -1505,7 +1522,7 @@ __device__ __forceinline__ void icp_iteration_reset( const IcpLaunch& L, int pro
   if( L.stat_acc )
     for( int k = threadIdx.x; k < STAT_SHARDS * 4; k += blockDim.x ) L.stat_acc[(size_t)prob * STAT_SHARDS * 4 + k] = 0ull;
   if( L.heavy_in && threadIdx.x == 0 )      // consumed: it is the next iteration's output buffer
-    for( int k = 0; k < HEAVY_CLASSES; ++k ) const_cast<int*>( L.heavy_in )[(size_t)prob * heavy_stride( L.src.n_tiles ) + k] = 0;
+    for( int k = 0; k < HEAVY_CLASSES; ++k ) const_cast<int*>( L.heavy_in )[(size_t)L.heavy_off + k] = 0;
 }
 
 #ifndef RS_XCD_MAP
@@ -1541,6 +1558,7 @@ __global__ __launch_bounds__( PA_WAVES * WAVE, BOUNDED_ONLY ? RS_ICP_WARM_OCC : 
   __shared__ WaveLds lds[PA_WAVES];
   const int prob = blockIdx.y;
   if( L.active[prob] == 0 ) return;
+  icp_bind( L, prob );
   const int lane = threadIdx.x & ( WAVE - 1 );
   const int wib = threadIdx.x / WAVE;
   EvalScope eval_scope( L.tgt.evals, lds[wib], lane );
@@ -1558,6 +1576,7 @@ __global__ __launch_bounds__( PA_WAVES * WAVE, BOUNDED_ONLY ? RS_ICP_WARM_OCC : 
   {
 #if RS_XCD_MAP
     const int per = icp_blocks_per_xcd( L.src.n_tiles );
+    if( ( block >> 3 ) >= per ) return INT_MAX;      // (a multi-source batch's grid is the largest problem's: beyond this problem's own eighths)
     return ( ( block & 7 ) * per + ( block >> 3 ) ) * PA_WAVES + wib;
 #else
     return block * PA_WAVES + wib;
@@ -1565,7 +1584,7 @@ __global__ __launch_bounds__( PA_WAVES * WAVE, BOUNDED_ONLY ? RS_ICP_WARM_OCC : 
   };
   if( L.heavy_in )
   {
-    const int* hv = L.heavy_in + (size_t)prob * heavy_stride( L.src.n_tiles );
+    const int* hv = L.heavy_in + (size_t)L.heavy_off;
     if( slot < HEAVY_SLOTS )
     {
       // front block b serves XCD class b mod 8 (it runs on the XCD the class's natural blocks run on), entry (b / 8) * 4 + wave
@@ -1585,8 +1604,8 @@ __global__ __launch_bounds__( PA_WAVES * WAVE, BOUNDED_ONLY ? RS_ICP_WARM_OCC : 
         // that could end after ~45): a workgroup of the cooperative kernel takes it from now on, like an unbounded tile
         if( lane == 0 )
         {
-          int q = atomicAdd( L.queue_count + prob, 1 ); L.queue[(size_t)prob * L.src.n_tiles + q] = tile;
-          if( L.heavy_out ) L.heavy_out[(size_t)prob * heavy_stride( L.src.n_tiles ) + HEAVY_HDR + HEAVY_SLOTS + tile] = 2;
+          int q = atomicAdd( L.queue_count + prob, 1 ); L.queue[(size_t)L.tile_off + q] = tile;
+          if( L.heavy_out ) L.heavy_out[(size_t)L.heavy_off + HEAVY_HDR + HEAVY_SLOTS + tile] = 2;
           if( DBG( L ) ) { DBG( L )[2 * tile] = wall_clock64(); DBG( L )[2 * tile + 1] = 1ull << 20; }      // (handed off, no time spent)
         }
         return;
@@ -1611,7 +1630,7 @@ __global__ __launch_bounds__( PA_WAVES * WAVE, BOUNDED_ONLY ? RS_ICP_WARM_OCC : 
   const bool search = active & !icp_certificate( L, prob, i, active & !init.found, qx, qy, qz, nx, ny, nz );
   // thresholds in candidates: as given up to a mean of HEAVY_MEAN_REF candidates per tile in the previous launch, growing with it
   // beyond (the factor, in 1/256ths, was worked out when that iteration ended: icp_iteration_reset)
-  const unsigned scale_q8 = L.heavy_in ? (unsigned)uni( L.heavy_in[(size_t)prob * heavy_stride( L.src.n_tiles ) + HEAVY_MEAN] ) : 256u;
+  const unsigned scale_q8 = L.heavy_in ? (unsigned)uni( L.heavy_in[(size_t)L.heavy_off + HEAVY_MEAN] ) : 256u;
   const unsigned sq8 = scale_q8 < 256u ? 256u : ( scale_q8 > 65536u ? 65536u : scale_q8 );
   const int thr_total = (int)( ( (unsigned)min( L.heavy_total, 0xffff ) * sq8 ) >> 8 );
   const uint32_t thr_streamed = ( (unsigned)min( L.heavy_streamed, 0xffff ) * sq8 ) >> 8;
@@ -1620,7 +1639,7 @@ __global__ __launch_bounds__( PA_WAVES * WAVE, BOUNDED_ONLY ? RS_ICP_WARM_OCC : 
                                lds[wib], lane, L.solo_stages, &handoff, DBG( L ) ? unsettled : nullptr, init, &sweeps, L.by_rows != 0, &streamed, thr_total );
   if( L.heavy_out && lane == 0 )
   {
-    int* hv = L.heavy_out + (size_t)prob * heavy_stride( L.src.n_tiles );
+    int* hv = L.heavy_out + (size_t)L.heavy_off;
     int listed = 0;
     // What will be slow next time.  A warm launch hands its unbounded tiles off at once — they cost it nothing — and its slow
     // tiles are the ones that stream many candidates in their one sweep (p50 150 candidates / 12 us, p99.9 750 / 40 us: left in
@@ -1651,7 +1670,7 @@ __global__ __launch_bounds__( PA_WAVES * WAVE, BOUNDED_ONLY ? RS_ICP_WARM_OCC : 
   }
   if( handoff )
   {
-    if( lane == 0 ) { int q = atomicAdd( L.queue_count + prob, 1 ); L.queue[(size_t)prob * L.src.n_tiles + q] = tile; }
+    if( lane == 0 ) { int q = atomicAdd( L.queue_count + prob, 1 ); L.queue[(size_t)L.tile_off + q] = tile; }
     return;
   }
   icp_emit( L, prob, tile, i, active, lane, m, active & !search );
@@ -1714,6 +1733,7 @@ __global__ __launch_bounds__( NW * WAVE, RS_COOP_OCC ) void k_icp_corr_coop( Icp
   __shared__ unsigned long long s_skip;
   const int prob = blockIdx.y;
   if( L.active[prob] == 0 ) return;
+  icp_bind( L, prob );
   const int lane = threadIdx.x & ( WAVE - 1 );
   const int wib = threadIdx.x / WAVE;
   EvalScope eval_scope( L.tgt.evals, lds[wib], lane );
@@ -1723,7 +1743,7 @@ __global__ __launch_bounds__( NW * WAVE, RS_COOP_OCC ) void k_icp_corr_coop( Icp
   for( int k = 0; k < 16; ++k ) T1.m[k] = L.T1[prob * 16 + k];
   for( int b = blockIdx.x; b < n_queued; b += gridDim.x )
   {
-    const int tile = L.coop_all ? b : L.queue[(size_t)prob * L.src.n_tiles + b];
+    const int tile = L.coop_all ? b : L.queue[(size_t)L.tile_off + b];
     icp_coop_tile<NW>( L, T1, prob, tile, lds[wib], coop, s_skip, wib, lane, b );
   }
 }
@@ -1745,6 +1765,7 @@ __global__ __launch_bounds__( BLOCK ) void k_icp_moments( IcpLaunch L )
   __shared__ double red[WAVES_PER_BLOCK][ICP_NMOM];
   const int prob = blockIdx.y;
   if( L.active[prob] == 0 ) return;
+  icp_bind( L, prob );
   Xform T1;
 #pragma unroll
   for( int k = 0; k < 16; ++k ) T1.m[k] = L.T1[prob * 16 + k];
@@ -1782,7 +1803,7 @@ __global__ __launch_bounds__( BLOCK ) void k_icp_moments( IcpLaunch L )
 
   for( int i = blockIdx.x * BLOCK + threadIdx.x; i < L.src.n; i += gridDim.x * BLOCK )
   {
-    const size_t o = (size_t)prob * L.src.n + i;
+    const size_t o = (size_t)L.pt_off + i;
     const int slot = L.m_slot[o];
     if( slot < 0 ) continue;
     const float d2 = L.m_d2[o];
@@ -1869,6 +1890,7 @@ __global__ __launch_bounds__( UPDATE_WAVES * WAVE ) void k_icp_update( IcpLaunch
 {
   const int prob = blockIdx.x;
   if( L.active[prob] == 0 ) return;
+  icp_bind( L, prob );
   const int lane = threadIdx.x & ( WAVE - 1 ), wib = threadIdx.x / WAVE;
   const double* in = L.mom_part + (size_t)prob * L.n_mom_blocks * ICP_NMOM;
   double* res = L.res + (size_t)prob * ICP_NRES;
@@ -1906,6 +1928,7 @@ __global__ __launch_bounds__( BLOCK ) void k_icp_update_wide( IcpLaunch L, int* 
   __shared__ int s_last;
   const int prob = blockIdx.y, k = blockIdx.x;
   if( L.active[prob] == 0 ) return;
+  icp_bind( L, prob );
   const int lane = threadIdx.x & ( WAVE - 1 ), wib = threadIdx.x / WAVE;
   const double* in = L.mom_part + ( (size_t)prob * ICP_NMOM + k ) * L.n_mom_blocks;
   double v = 0.0;
@@ -1952,11 +1975,12 @@ __global__ __launch_bounds__( BLOCK ) void k_icp_faith_gather( IcpLaunch L )
 {
   const int prob = blockIdx.y;
   if( L.active[prob] == 0 ) return;
+  icp_bind( L, prob );
   const int i = blockIdx.x * BLOCK + threadIdx.x, n = L.src.n;
   if( i >= n ) return;
   const int s = L.by_orig ? L.by_orig[i] : i;
-  const size_t o = (size_t)prob * n + s;
-  float* F = L.faith + (size_t)prob * FAITH_REC * n + i;
+  const size_t o = (size_t)L.pt_off + s;
+  float* F = L.faith + (size_t)FAITH_REC * (size_t)L.pt_off + i;
   const int slot = L.m_slot[o];
   if( slot < 0 ) { F[0] = -1.0f; return; }
   Xform T1;
@@ -2133,10 +2157,11 @@ __global__ __launch_bounds__( FAITH_THREADS ) void k_icp_faithful( IcpLaunch L )
   __shared__ double s_d[2];
   const int prob = blockIdx.x;
   if( L.active[prob] == 0 ) return;
+  icp_bind( L, prob );
   if( L.solve ) icp_iteration_reset( L, prob );            // (the search of this iteration is over: its queue has been consumed)
   const int wib = threadIdx.x / WAVE, lane = threadIdx.x & ( WAVE - 1 );
   const int n = L.src.n;
-  const float* F = L.faith + (size_t)prob * FAITH_REC * n;
+  const float* F = L.faith + (size_t)FAITH_REC * (size_t)L.pt_off;
   FaithPar P;
   P.w_explicit = L.w_explicit != nullptr; P.use_sd = false; P.max_dist = L.radius; P.cut = 0.0f;
   P.c1[0] = P.c1[1] = P.c1[2] = P.c2[0] = P.c2[1] = P.c2[2] = 0.0f;
@@ -2645,6 +2670,7 @@ __global__ __launch_bounds__( WAVE ) void k_replay_finish( IcpLaunch L, ReplayBu
 {
   const int prob = blockIdx.x;
   if( L.active[prob] == 0 ) return;
+  icp_bind( L, prob );
   if( L.solve ) icp_iteration_reset( L, prob );            // (by the whole wave: it averages a sample of per-tile counts)
   if( threadIdx.x != 0 ) return;
   const double* totals = B.totals + (size_t)prob * 3 * ICP_NMOM;
@@ -3775,14 +3801,14 @@ void launch_icp_corr( const IcpLaunch& L, hipStream_t st )
   // A launch of a few hundred tiles leaves every wave alone on its SIMD, i.e. latency-bound, and phase A's slowest tile
   // sets its time: such launches skip phase A and give every tile a workgroup straight away (coop_all).
   static_assert( HEAVY_SLOTS % ( 8 * PA_WAVES ) == 0, "the front slots must not shift the XCD class of the natural part" );
-  dim3 grid( ( L.heavy_in ? HEAVY_SLOTS / PA_WAVES : 0 ) + 8 * icp_blocks_per_xcd( L.src.n_tiles ), L.n_prob );
+  dim3 grid( ( L.heavy_in ? HEAVY_SLOTS / PA_WAVES : 0 ) + 8 * icp_blocks_per_xcd( L.max_tiles ), L.n_prob );      // (max_tiles: the largest problem's)
   if( !L.coop_all )
   {
     if( L.warm && L.bounded_only ) hipLaunchKernelGGL( k_icp_corr<true>, grid, dim3( PA_WAVES * WAVE ), 0, st, L );
     else                           hipLaunchKernelGGL( k_icp_corr<false>, grid, dim3( PA_WAVES * WAVE ), 0, st, L );
   }
   // the queue length is only known on the device: a fixed grid strides over it
-  int coop_blocks = L.src.n_tiles < 2048 ? L.src.n_tiles : 2048;
+  int coop_blocks = L.max_tiles < 2048 ? L.max_tiles : 2048;
   const dim3 cgrid( coop_blocks > 0 ? coop_blocks : 1, L.n_prob );
   // a short queue is latency-bound by its heaviest tile: give every tile more waves
   if( L.coop_waves >= 8 ) hipLaunchKernelGGL( k_icp_corr_coop<8>, cgrid, dim3( 8 * WAVE ), 0, st, L );
@@ -3790,7 +3816,7 @@ void launch_icp_corr( const IcpLaunch& L, hipStream_t st )
 }
 void launch_icp_faithful( const IcpLaunch& L, hipStream_t st )
 {
-  hipLaunchKernelGGL( k_icp_faith_gather, dim3( ( L.src.n + BLOCK - 1 ) / BLOCK, L.n_prob ), dim3( BLOCK ), 0, st, L );
+  hipLaunchKernelGGL( k_icp_faith_gather, dim3( ( L.max_n + BLOCK - 1 ) / BLOCK, L.n_prob ), dim3( BLOCK ), 0, st, L );
   hipLaunchKernelGGL( k_icp_faithful, dim3( L.n_prob ), dim3( FAITH_THREADS ), 0, st, L );
 }
 void launch_icp_moments( const IcpLaunch& L, hipStream_t st )

@@ -153,10 +153,11 @@ def shard_compute(capi, lay, rank, units, send, small_host, threads=None):
         if i1 > i0:
             blk = sh[lay.off_icp: lay.off_icp + 18 * (i1 - i0)].reshape(-1, 18)
             if isinstance(src, (list, tuple)):
-                # one source cloud per problem (the placements of a scene, each refined against the scan: lib/rs/rs_database.h:220-230)
-                for j in range(i0, i1):
-                    e, T, it = capi.icp_align(src[j], tgt, T0s[j], max_dist=max_dist, max_angle=max_angle, max_iter=iters, fixed_iters=True)
-                    blk[j - i0, :16] = T; blk[j - i0, 16] = e; blk[j - i0, 17] = it
+                # one source cloud per problem (the placements of a scene, each refined against the scan: lib/rs/rs_database.h:220-230),
+                # all of this rank's problems in ONE call: their sequential chains run side by side (rs_hip_icp_align_multi)
+                errs, Ts, its = capi.icp_align_multi(list(src[i0:i1]), tgt, np.asarray(T0s)[i0:i1], max_dist=max_dist, max_angle=max_angle,
+                                                     max_iter=iters, fixed_iters=True)
+                blk[:, :16] = Ts.reshape(-1, 16); blk[:, 16] = errs; blk[:, 17] = its
             else:
                 errs, Ts, its = capi.icp_align_batch(src, tgt, T0s[i0:i1], max_dist=max_dist, max_angle=max_angle, max_iter=iters, fixed_iters=True)
                 blk[:, :16] = Ts.reshape(-1, 16); blk[:, 16] = errs; blk[:, 17] = its

@@ -186,6 +186,28 @@ def test_strong_scaling_split_is_bit_identical(capi, bench_mod, headline):
         assert (labels == lab0["labels"]).all() and (mind == lab0["min_dists"]).all(), f"world {world} prefold {prefold}: labels"
 
 
+def test_strong_scaling_icp_units_vs_reference(capi, bench_mod, headline):
+    """The ICP units of bench.py --scaling strong — each placement's ~50 k-point model refined against the ~0.98 M-point scan with
+    rsdb_refine_alignment_of_objects_to_scene's parameters (lib/rs/rs_database.h:220-230), ten fixed iterations — as ONE
+    rs_hip_icp_align_multi call (8 sources, 6 000+ tiles: phase A and the cooperative kernel on per-problem source views) against
+    the reference's own ten iterations of each (oracle/gen_golden_bench.py --strong-only): object-sized sources take the
+    reference-order estimator, so the poses and errors are the reference's bit for bit; and against the eight single calls."""
+    w, g = headline
+    n_plc = bench_mod.N_PLACEMENTS
+    plc = w["plc"][:n_plc]
+    si = w["strong_icp"]
+    assert [sha(p["np"][0]) for p in plc] + [sha(si["T0s"])] == [str(x) for x in g["strong_icp_sha"]], "the generator no longer produces the fixture's inputs"
+    errs, Ts, its = capi.icp_align_multi([p["cloud"] for p in plc], w["scan1"], si["T0s"], I4, si["max_dist"], si["max_angle"],
+                                         max_iter=bench_mod.ICP_ITERS, fixed_iters=True)
+    d = np.linalg.norm(Ts.astype(np.float64).reshape(-1, 16) - g["strong_icp_pose"].astype(np.float64).reshape(-1, 16), axis=1)
+    print("strong-scaling ICP units: pose distance from the reference's", d.tolist(), "errors", errs.tolist(), g["strong_icp_err"].tolist())
+    assert (its == bench_mod.ICP_ITERS).all()
+    assert (d == 0.0).all() and (errs == g["strong_icp_err"]).all()
+    for k in range(n_plc):
+        e, T, it = capi.icp_align(plc[k]["cloud"], w["scan1"], si["T0s"][k], I4, si["max_dist"], si["max_angle"], max_iter=bench_mod.ICP_ITERS, fixed_iters=True)
+        assert (T == Ts[k]).all() and e == errs[k] and it == its[k]
+
+
 MORE_SEEDS = list(range(31, 39))
 
 

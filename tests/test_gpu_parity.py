@@ -223,6 +223,53 @@ def test_icp_batch_matches_single(capi, gscene, scene_clouds, estimator):
         capi.icp_reference_order_below(prev); capi.icp_replay_below(prev_r)
 
 
+def test_icp_multi_source_batch_matches_single(capi, oracle, gscene, scene_clouds):
+    """rs_hip_icp_align_multi: the per-placement refine loop (lib/rs/rs_database.h:220-230 — a DIFFERENT source per problem) as one
+    call.  Every problem's pose, error and iteration count are those of its own rs_hip_icp_align — and, the sources being
+    object-sized (reference-order estimator), the oracle's — bit for bit: sources of very different sizes (3 231 / 1 562 / 1 542
+    points, a 700-point and a 9-point subset, a 30 k-point scan extract), the same source twice, with and without the stop test; a
+    batch that holds a source above the estimator's range takes the problem-by-problem route and returns the same.  (Batches of
+    more than 4 096 tiles — phase A + the cooperative kernel — are the headline suite's: test_strong_scaling_icp_units_vs_reference.)"""
+    from rescan_amd import synth
+    clouds, objs = scene_clouds
+    rng = np.random.default_rng(17)
+    pts, nor = gscene["points"], gscene["normals"]
+    host = [(o["pos"], o["nor"]) for o in gscene["objects"]]
+    poses = [o["pose"] for o in gscene["objects"]]
+    sub = rng.permutation(len(host[0][0]))[:700]; host.append((host[0][0][sub], host[0][1][sub])); poses.append(poses[0])
+    sub = rng.permutation(len(host[1][0]))[:9]; host.append((host[1][0][sub], host[1][1][sub])); poses.append(poses[1])
+    big = np.sort(rng.permutation(len(pts))[:30000])
+    host.append((np.ascontiguousarray(pts[big]), np.ascontiguousarray(nor[big]))); poses.append(I4)
+    srcs = list(objs) + [capi.Cloud(p, n_, cell_size=0.1) for p, n_ in host[len(objs):]]
+    order = [5, 0, 3, 1, 4, 2, 0]                                   # ragged, the big one first, source 0 twice
+    T0s = np.stack([synth.perturbed_pose(poses[k], rng) for k in order])
+    for md, ma, fixed, iters in ((0.1, 60.0, False, 100), (0.075, 50.0, True, 7)):
+        ma = np.float32(np.deg2rad(np.float32(ma)))
+        errs, Ts, its = capi.icp_align_multi([srcs[k] for k in order], clouds[0.1], T0s, I4, md, ma, max_iter=iters, fixed_iters=fixed)
+        for j, k in enumerate(order):
+            e, T, it = capi.icp_align(srcs[k], clouds[0.1], T0s[j], I4, md, ma, max_iter=iters, fixed_iters=fixed)
+            assert (T == Ts[j]).all() and e == errs[j] and it == its[j], (j, k)
+            if not fixed:
+                eo, To, ito = oracle.icp_align(host[k][0], host[k][1], pts, nor, T0s[j], I4, md, ma)
+                assert (To == Ts[j]).all() and np.float32(eo) == errs[j] and ito == its[j], (j, k)
+    # one source above the reference-order range: problem by problem, same answers
+    prev = capi.icp_reference_order_below(-1)
+    try:
+        capi.icp_reference_order_below(20000)
+        errs2, Ts2, its2 = capi.icp_align_multi([srcs[k] for k in order[:3]], clouds[0.1], T0s[:3], I4, 0.1, np.deg2rad(60.0))
+        for j, k in enumerate(order[:3]):
+            e, T, it = capi.icp_align(srcs[k], clouds[0.1], T0s[j], I4, 0.1, np.deg2rad(60.0))
+            assert (T == Ts2[j]).all() and e == errs2[j] and it == its2[j]
+    finally:
+        capi.icp_reference_order_below(prev)
+    # an empty batch, a batch of one
+    e0, T0, i0 = capi.icp_align_multi([], clouds[0.1], np.zeros((0, 16), np.float32))
+    assert len(e0) == 0
+    e1, T1, i1 = capi.icp_align_multi([srcs[1]], clouds[0.1], T0s[3:4])
+    e, T, it = capi.icp_align(srcs[1], clouds[0.1], T0s[3])
+    assert (T == T1[0]).all() and e == e1[0] and it == i1[0]
+
+
 CH_ROWS_TEST = 7
 
 
