@@ -1070,9 +1070,22 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
   // Scan-sized sources: the reference's centroid sums by the grid chains — which give a problem up when a sum keeps changing
   // binade (coordinates that straddle the origin in a cancelling order: rs_kernels.hip, chain_walk_row); the batch is then run
   // again with those sums by pass 2 of the replay: the same bits, 0.9 ms per iteration at a million points instead of 0.09.
-  int rc = icp_align_batch_impl( source, target, T1s, n, T2, max_dist, max_angle, max_iter, fixed_iters, errs, iters, g_exact_centroids.load() );
-  if( rc == ICP_CHAINS_GAVE_UP ) rc = icp_align_batch_impl( source, target, T1s, n, T2, max_dist, max_angle, max_iter, fixed_iters, errs, iters, 2 );
-  return rc;
+  // The estimators of large sources keep per-point records per problem (48 B with the chains, 44 B + the replay's rows when they
+  // give up): many start poses of a whole scan are run in slices of problems whose records stay below RS_HIP_ICP_BATCH_BYTES
+  // (default 4 GB) — the problems are independent, so the results are those of the one batch.
+  static const double cap = getenv( "RS_HIP_ICP_BATCH_BYTES" ) ? atof( getenv( "RS_HIP_ICP_BATCH_BYTES" ) ) : 4e9;
+  const bool per_point_records = source && source->n > g_ref_order_below.load();
+  const int slice = per_point_records ? std::max( 1, (int)std::min<double>( (double)std::max( n, 1 ), cap / ( 48.0 * (double)std::max( source->n, 1 ) ) ) ) : std::max( n, 1 );
+  for( int p0 = 0; p0 < std::max( n, 1 ); p0 += slice )
+  {
+    const int np = std::min( slice, n - p0 );
+    float* T = T1s ? T1s + 16 * (size_t)p0 : nullptr; float* e = errs ? errs + p0 : nullptr; int32_t* it = iters ? iters + p0 : nullptr;
+    int rc = icp_align_batch_impl( source, target, T, np, T2, max_dist, max_angle, max_iter, fixed_iters, e, it, g_exact_centroids.load() );
+    // (a problem of the slice whose chains gave up: that slice again, its seven sums by pass 2 of the replay — nothing of it was written yet)
+    if( rc == ICP_CHAINS_GAVE_UP ) rc = icp_align_batch_impl( source, target, T, np, T2, max_dist, max_angle, max_iter, fixed_iters, e, it, 2 );
+    if( rc ) return rc;
+  }
+  return RS_HIP_OK;
 }
 
 // The per-placement refine loop as one call (lib/rs/rs_database.h:220-230, apps/pose_proposal/main.cpp:190-202 with a different
@@ -1294,6 +1307,7 @@ int rs_hip_icp_estimate_pt2pl( const float* pts1, const float* pts2, const float
   IcpLaunch L{};
   L.tgt.pos = g_ws.tmp_pos2.as<float4>(); L.tgt.nor = g_ws.tmp_nor2.as<float4>(); L.tgt.n = n;
   L.src.pos = g_ws.tmp_pos.as<float4>(); L.src.nor = nullptr; L.src.tiles = nullptr; L.src.n = n; L.src.n_tiles = 0; L.n_prob = 1;
+  L.multi = nullptr; L.max_n = n; L.max_tiles = 0;
   L.T1 = g_ws.state.as<float>(); L.active = (int*)( g_ws.state.as<float>() + 16 ); std::memcpy( L.T2i.m, I.m, 64 );
   L.ticket = (int*)( g_ws.state.as<float>() + 37 ); L.solve = 0;       // reductions only: the solve below runs on the host
   L.radius = 1.0f; L.m_slot = g_ws.slot.as<int>(); L.m_d2 = g_ws.d2.as<float>(); L.m_dot = g_ws.dot.as<float>();
@@ -1367,6 +1381,14 @@ int rs_hip_alignment_scores( const rs_hip_cloud_t* object, const rs_hip_cloud_t*
   // the unmatched ones' reach, and the counting costs what the smaller boxes save (profiles/r03/score_kcap.txt).
   static const float kcap = getenv( "RS_HIP_SCORE_KCAP" ) ? (float)atof( getenv( "RS_HIP_SCORE_KCAP" ) ) : 0.0f;
   L.kcap_frac = ( kcap > 0.0f && kcap < 1.0f ) ? kcap : 0.0f;
+  // (Tried in round 4 and removed: a two-radius search — stage 1 within the distance that is expected to hold 1.5 K candidates, only
+  //  lanes that neither matched nor counted K going on to the radius.  Exact (the bench's 256 scores stayed the reference's bits) and
+  //  slower: 0.99 ms against 0.88 for the batch alone, 897 candidates staged per (tile, pose) wave against 840 — nearly every tile
+  //  of a mediocre pose has a lane in sparse surroundings, which sends the tile to stage 2, and what stage 2 streams again outweighs
+  //  what the dense tiles save.  profiles/r04/score_two_radius.txt)
+  L.hist = nullptr;
+  static DevBuf histbuf;
+  if( RS_DBG && getenv( "RS_HIP_SCORE_HIST" ) && !histbuf.ensure( 6 * 65 * 8 ) ) { (void)hipMemsetAsync( histbuf.p, 0, 6 * 65 * 8, g_stream ); L.hist = histbuf.as<unsigned long long>(); }
   // the launch grid's y dimension is limited to 65535 poses per launch
   for( int p0 = 0; p0 < n_poses; p0 += 65535 )
   {
@@ -1378,6 +1400,20 @@ int rs_hip_alignment_scores( const rs_hip_cloud_t* object, const rs_hip_cloud_t*
   }
   HIP_TRY( hipMemcpyAsync( scores, g_ws.scores.p, (size_t)n_poses * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
   HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
+  if( L.hist )
+  {
+    std::vector<unsigned long long> h( 6 * 65 );
+    (void)hipMemcpy( h.data(), L.hist, h.size() * 8, hipMemcpyDeviceToHost );
+    unsigned long long all = 0; for( auto v : h ) all += v;
+    fprintf( stderr, "[rs_hip score hist] candidates streamed %llu (rows 0-4: shells, by the lanes the shell is swept for; row 5: the rank pass, by the lanes that need their rank)\n", all );
+    for( int sh = 0; sh < 6; ++sh )
+    {
+      unsigned long long t = 0, b[5] = { 0, 0, 0, 0, 0 };      // lanes the shell is swept for: 1-4, 5-8, 9-16, 17-32, 33-64
+      for( int u = 0; u <= 64; ++u ) { t += h[sh * 65 + u]; b[u <= 4 ? 0 : u <= 8 ? 1 : u <= 16 ? 2 : u <= 32 ? 3 : 4] += h[sh * 65 + u]; }
+      if( t ) fprintf( stderr, "[rs_hip score hist]   shell %d: %5.1f %% of all | by unsettled lanes 1-4: %4.1f %%  5-8: %4.1f %%  9-16: %4.1f %%  17-32: %4.1f %%  33-64: %4.1f %%\n", sh,
+                       100.0 * (double)t / (double)all, 100.0 * b[0] / (double)t, 100.0 * b[1] / (double)t, 100.0 * b[2] / (double)t, 100.0 * b[3] / (double)t, 100.0 * b[4] / (double)t );
+    }
+  }
   return RS_HIP_OK;
 }
 

@@ -205,6 +205,7 @@ struct ScoreLaunch
   int          solo_stages;
   int          by_rows;    // launches that hand nothing off: the row-wise cold search (rs_kernels.hip: tile_search_rows)
   float        kcap_frac;  // K-cap distance² as a fraction of radius² (rs_kernels.hip: KCap); 0: off
+  unsigned long long* hist;   // diagnostic builds only (RS_HIP_SCORE_HIST): 6 x 65 counters, see k_score
 };
 void launch_score( const ScoreLaunch& L, hipStream_t st );
 

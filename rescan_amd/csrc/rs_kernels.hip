@@ -888,10 +888,11 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
   {
     cur = grid ? box_grow( core, k, full ) : full;
     const CellBox out = grid ? reach_box( g, cur, unsettled, reach(), qx, qy, qz ) : full;
+    if( dbg_unsettled && sweeps < 5 ) { dbg_unsettled[4 + 2 * sweeps] = __popcll( __ballot( unsettled ) ); dbg_unsettled[5 + 2 * sweeps] = -(int)streamed; }     // [4 + 2 s]: lanes shell s is swept for, [5 + 2 s]: candidates it streamed
     if( !box_empty( out ) )
       streamed += sweep_shell<GATED>( g, out, prev, have_prev, L, lane, 0, 1, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
       { consider4<GATED, WARM, KCAP>( X, Y, Z, k4, L, qx, qy, qz, nx, ny, nz, tmin, bound, m, seen_closer, &cap, K ); } );
-    if( dbg_unsettled ) dbg_unsettled[1] = (int)streamed;
+    if( dbg_unsettled ) { dbg_unsettled[1] = (int)streamed; if( sweeps < 5 ) dbg_unsettled[5 + 2 * sweeps] += (int)streamed; }
     ++sweeps;
     if( n_sweeps ) *n_sweeps = sweeps;
     if( box_same( cur, full ) ) break;
@@ -936,7 +937,7 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
         if( WARM ) { const int c = precede4_bands( X, Y, Z, k4, L, qx, qy, qz, radius_sq, m.d2, m.idx, rbands ); rank += need_rank ? c : 0; }
         else rank += need_rank ? precede4( X, Y, Z, k4, L, qx, qy, qz, radius_sq, m.d2, m.idx ) : 0;
       } );
-      if( dbg_unsettled ) dbg_unsettled[2] = (int)rs;
+      if( dbg_unsettled ) { dbg_unsettled[2] = (int)rs; dbg_unsettled[15] = __popcll( __ballot( need_rank ) ); }
       if( need_rank && rank >= K ) { m.found = false; m.slot = -1; if( WARM ) m.rank_slack = rank_slack_of( rbands, K ); }
       ++sweeps;
       streamed += rs;
@@ -1625,7 +1626,7 @@ __global__ __launch_bounds__( PA_WAVES * WAVE, BOUNDED_ONLY ? RS_ICP_WARM_OCC : 
   bool handoff;
   int sweeps = 0;
   uint32_t streamed = 0;
-  int unsettled[4] = { 0, 0, 0, 0 };
+  int unsettled[16] = { 0 };
   const Match init = icp_warm_start( L, prob, i, active, qx, qy, qz, nx, ny, nz );
   const bool search = active & !icp_certificate( L, prob, i, active & !init.found, qx, qy, qz, nx, ny, nz );
   // thresholds in candidates: as given up to a mean of HEAVY_MEAN_REF candidates per tile in the previous launch, growing with it
@@ -3901,8 +3902,18 @@ __global__ __launch_bounds__( SC_WAVES * WAVE, RB ? RS_SCORE_ROWS_OCC : RS_SCORE
       m = tile_search<true, false, false, true>( L.scene, active, qx, qy, qz, nx, ny, nz, (float)L.sigma, L.radius_sq, L.gate_tmin, L.K,
                              lds[wib], lane, L.solo_stages, &handoff, nullptr, no_match(), nullptr, false, nullptr, 0, L.kcap_frac );
     else
+    {
+      int slog[16] = { 0 };
       m = tile_search<true>( L.scene, active, qx, qy, qz, nx, ny, nz, (float)L.sigma, L.radius_sq, L.gate_tmin, L.K,
-                             lds[wib], lane, L.solo_stages, &handoff, nullptr, no_match() );
+                             lds[wib], lane, L.solo_stages, &handoff, ( RS_DBG && L.hist ) ? slog : nullptr, no_match() );
+      if( RS_DBG && L.hist && lane == 0 )
+      {
+        // diagnostic builds (RS_HIP_SCORE_HIST): candidates streamed by shell s for u unsettled lanes -> hist[s][u]; by the rank pass for u
+        // lanes that need their rank -> hist[5][u]
+        for( int sh = 0; sh < 5; ++sh ) if( slog[5 + 2 * sh] > 0 ) atomicAdd( L.hist + sh * 65 + min( slog[4 + 2 * sh], 64 ), (unsigned long long)slog[5 + 2 * sh] );
+        if( slog[2] > 0 ) atomicAdd( L.hist + 5 * 65 + min( slog[15], 64 ), (unsigned long long)slog[2] );
+      }
+    }
   }
   if( handoff )
   {

@@ -6,7 +6,9 @@ summation order differs)."""
 import numpy as np
 import pytest
 
-from conftest import golden_files, label_case, load_golden, rows_equal_up_to_ties
+import os
+
+from conftest import ROOT, golden_files, label_case, load_golden, rows_equal_up_to_ties
 
 pytestmark = pytest.mark.gpu
 
@@ -268,6 +270,34 @@ def test_icp_multi_source_batch_matches_single(capi, oracle, gscene, scene_cloud
     e1, T1, i1 = capi.icp_align_multi([srcs[1]], clouds[0.1], T0s[3:4])
     e, T, it = capi.icp_align(srcs[1], clouds[0.1], T0s[3])
     assert (T == T1[0]).all() and e == e1[0] and it == i1[0]
+
+
+def test_icp_batch_of_scan_sized_sources_in_slices(capi, gscene):
+    """Many start poses of a source above the reference-order range keep per-point records per problem; rs_hip_icp_align_batch runs
+    them in slices of problems (RS_HIP_ICP_BATCH_BYTES).  The problems are independent: a batch cut into slices of one returns the
+    bits of the batch run whole (a child process: the limit is read once)."""
+    import subprocess, sys, json
+    code = """
+import sys, json, numpy as np
+sys.path.insert(0, %r)
+from rescan_amd import capi, synth
+capi.init(0)
+s = synth.make_scene(seed=5, density=1500.0, timestep=1)
+a = capi.Cloud(s["points"], s["normals"]); 
+rng = np.random.default_rng(2)
+T0s = np.stack([synth.perturbed_pose(np.eye(4, dtype=np.float32).ravel(), rng, 0.01, 0.01) for _ in range(5)])
+capi.icp_reference_order_below(0); capi.icp_replay_below(0)
+errs, Ts, its = capi.icp_align_batch(a, a, T0s, max_iter=12)
+print(json.dumps(dict(errs=errs.view(np.uint32).tolist(), Ts=Ts.view(np.uint32).ravel().tolist(), its=its.tolist())))
+""" % ROOT
+    outs = []
+    for cap in ("4e9", "1"):
+        env = dict(os.environ, RS_HIP_ICP_BATCH_BYTES=cap)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr[-600:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[0] == outs[1]
+    assert max(outs[0]["its"]) > 3
 
 
 CH_ROWS_TEST = 7
