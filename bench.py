@@ -141,7 +141,7 @@ class RoleRunner:
     others are released, the second-longest first), and the caller busy-waits for theirs.  These helpers are the harness's own
     (tools/benchaux/librs_benchaux.so), not part of the product ABI.  With executors every step is three submissions and three future waits, i.e. six wake-ups of sleeping
     threads by the host scheduler — usually tens of microseconds each, but on the shared 256-thread hosts of this pool one
-    step in ~35 lost 1.5-3 ms there while all three library calls took their usual time (tools/throttle_check.sh: no cgroup
+    step in ~35 lost 1.5-3 ms there while all three library calls took their usual time (cpu.stat before / after: no cgroup
     throttling in the region; the time is between the calls).  RS_BENCH_SPIN=0: three single-thread executors as before."""
 
     ICP, SCORE, LABEL = 0, 1, 2

@@ -1,4 +1,5 @@
-"""Pose distance GPU vs oracle after icp_align, by source-cloud size (the reference's fp32 accumulators get noisier with n)."""
+"""Pose distance GPU vs oracle after icp_align, by source-cloud size (the reference's fp32 accumulators get noisier with n).
+usage: python tests/stress/icp_margin.py [seeds]; exit code 1 if a run ends 1e-4 or more from the oracle's pose or an iteration apart."""
 import os, sys, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -7,7 +8,8 @@ from oracle.pyoracle import Oracle
 capi.init(0); O = Oracle()
 I4 = np.eye(4, dtype=np.float32).ravel(); ang = np.float32(np.deg2rad(60.0))
 rows = []
-for seed in range(1, 9):
+n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+for seed in range(1, n_seeds + 1):
     rng = np.random.default_rng(100 + seed)
     dens = [1500.0, 5000.0][seed % 2]
     s0 = synth.make_scene(seed=seed, density=dens, timestep=0); s1 = synth.make_scene(seed=seed, density=dens, timestep=1)
@@ -26,3 +28,8 @@ for seed in range(1, 9):
 rows.sort()
 for n, d, io, ig in rows:
     print(f"n_source {n:7d}: |T_gpu - T_oracle| = {d:.2e}   iterations {io} / {ig}")
+# the default estimators (reference order up to 65 536 source points, its parallel form up to 262 144) return the oracle's bits;
+# whatever the switches select, north_star's bar is 1e-4 with equal iteration counts
+worst = max(d for _, d, _, _ in rows)
+print(f"worst {worst:.2e}; iteration counts equal in {sum(io == ig for _, _, io, ig in rows)} of {len(rows)} runs")
+sys.exit(0 if worst < 1e-4 and all(io == ig for _, _, io, ig in rows) else 1)

@@ -119,7 +119,7 @@ def test_small_searches_from_three_threads(capi, gscene):
 
 
 def test_three_consumers_side_by_side_repeatedly(capi):
-    """tools/concurrency_check.py as a test, at a size that keeps it short: bench.py's step (ICP chain, score batch, label
+    """bench.py's step (ICP chain, score batch, label
     pass) issued from three threads returns the bits of the step issued serially, 12 times in a row."""
     import os
     import sys
