@@ -63,6 +63,7 @@ size_t msh_hash_grid_radius_search( const rsd_hash_grid_t* hg, rsd_search_desc_t
 float icp_align( rsd_vec3_t* pts1, rsd_vec3_t* nor1, int32_t n_pts1,
                  rsd_vec3_t* pts2, rsd_vec3_t* nor2, int32_t n_pts2,
                  rsd_mat4_t* T1, rsd_mat4_t T2, float max_dist, float max_angle, bool verbose );
+float icp_estimate_rigid_xform_pt2pt( rsd_vec3_t* pts1, rsd_vec3_t* pts2, float* weights, int32_t n_pts, rsd_mat4_t* T1 );   /* icp.h:153-206: a stub in the reference (returns 1.0f) */
 float icp_estimate_rigid_xform_pt2pl( rsd_vec3_t* pts1, rsd_vec3_t* pts2, rsd_vec3_t* nor2, float* weights,
                                       int32_t n_pts, rsd_mat4_t* T1 );
 void  icp_find_corrs( rsd_vec3_t* pts1, rsd_vec3_t* nor1, int32_t n_pts1, rsd_hash_grid_t* idx1,

@@ -437,6 +437,10 @@ float icp_align( rsd_vec3_t* pts1, rsd_vec3_t* nor1, int32_t n_pts1, rsd_vec3_t*
   return err;
 }
 
+// lib/rs/icp.h:153-206: the point-to-point estimator's body is commented out in the reference — it returns 1.0f and leaves *T1
+// alone (and is unreachable from icp_align, :473).  Exported so that a TU which names it still links against the shim.
+float icp_estimate_rigid_xform_pt2pt( rsd_vec3_t*, rsd_vec3_t*, float*, int32_t, rsd_mat4_t* ) { return 1.0f; }
+
 float icp_estimate_rigid_xform_pt2pl( rsd_vec3_t* pts1, rsd_vec3_t* pts2, rsd_vec3_t* nor2, float* weights,
                                       int32_t n_pts, rsd_mat4_t* T1 )
 {

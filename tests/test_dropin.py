@@ -43,7 +43,7 @@ def test_symbols_and_layout():
     out = subprocess.check_output(["nm", "-D", "--defined-only", DROPIN], text=True)
     exported = set(re.findall(r" T ([a-z0-9_]+)", out))
     names = declared()
-    assert {"icp_align", "icp_find_corrs", "icp_estimate_rigid_xform_pt2pl", "msh_hash_grid_init_3d",
+    assert {"icp_align", "icp_find_corrs", "icp_estimate_rigid_xform_pt2pl", "icp_estimate_rigid_xform_pt2pt", "msh_hash_grid_init_3d",
             "msh_hash_grid_term", "msh_hash_grid_radius_search"} <= set(names)
     assert set(names) <= exported
     assert C.sizeof(HashGrid) == 120 and HashGrid.data_buffer.offset == 64 and HashGrid._n_pts.offset == 112
