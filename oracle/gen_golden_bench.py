@@ -23,7 +23,7 @@ container only; the fixtures are committed so the GPU box, which has no /root/re
         on the same two ~0.98 M-point scans, the three call sites' parameter sets in turn and start poses from
         5 mm / 0.3 deg to 3 cm / 2 deg (MORE_SEEDS, more_stop_case)
 
-Usage:  python oracle/gen_golden_bench.py [--bench-only [--seed N] | --sweep-only | --more [--seed N] | --labels-only [--seed N] | --strong-only]
+Usage:  python oracle/gen_golden_bench.py [--bench-only [--seed N] | --sweep-only | --more [--seed N] | --labels-only [--seed N] | --strong-only | --static-labels]
         --labels-only recomputes the label fields of every bench_seed*.npz from the reference build and leaves the rest as it is
 """
 import ctypes as C
@@ -163,6 +163,52 @@ def restrong(seed=11):
     np.savez_compressed(path, **g)
 
 
+def static_arrangement(w, seed):
+    """An arrangement of the headline's size WITH static placements, for the label transfer's second pass (rs_pointcloud_filters.cpp:
+    841-848: 1.5 x radius, shared min_dists) and its ordering (:724-736,823-835): the bench's eight ~50 k-point dynamic placements
+    plus three static objects cut from the scan itself — a third of the floor, half of one wall, a quarter of the other (0.1 - 0.3 M
+    points each: "static wall/floor objects up to scan-sized") — shuffled.  Returns (objects, placements) in the
+    oracle's dict form; static objects carry `sub`, their indices into scan 1."""
+    rng = np.random.default_rng(9100 + seed)
+    s1 = w["s1"]
+    objs = [dict(pos=p["np"][0], nor=p["np"][1], class_idx=p["cls"], is_static=0) for p in w["plc"][:8]]
+    plcs = [dict(pose=p["pose"], object_idx=k, uidx=10 + k) for k, p in enumerate(w["plc"][:8])]
+    inst = s1["instance_idx"]
+    for cls_name, which, step in (("floor", 0, 3), ("wall", 1, 2), ("wall", 2, 4)):
+        idx = np.nonzero(inst == which)[0]
+        sub = np.sort(rng.permutation(idx)[::step]).astype(np.int32)
+        objs.append(dict(pos=np.ascontiguousarray(s1["points"][sub]), nor=np.ascontiguousarray(s1["normals"][sub]),
+                         class_idx=synth.CLASS_IDX[cls_name], is_static=1, sub=sub))
+        plcs.append(dict(pose=I4 if which != 2 else synth.perturbed_pose(I4, rng, 0.003, 0.002), object_idx=len(objs) - 1, uidx=100 + which))
+    order = rng.permutation(len(plcs))
+    return objs, [plcs[i] for i in order]
+
+
+def gen_static_labels(seed=11):
+    """--static-labels: bench_labels_static_seed<seed>.npz — the reference's label loops (oracle/_ref/libref_filters.so) on
+    static_arrangement(): digests of labels / min_dists / class ids / instance ids, the visiting order, and the arrangement itself."""
+    import bench
+    w = bench.build_inputs(1_000_000, seed=seed)
+    objs, plcs = static_arrangement(w, seed)
+    t = time.time()
+    RF = RefFilters(synth.CLASS_IDX)
+    out = {}
+    for prio in (0, 1):
+        lab = RF.arrangement_to_labels(w["s1"]["points"], w["s1"]["normals"], objs, plcs, 0.05, prio, synth.CLASS_IDX["unlabelled"])
+        out[prio] = lab
+        print(f"static arrangement, prioritize_static {prio}: {int((lab['labels'] > 0).sum())} of {len(lab['labels'])} labelled, order {lab['order'].tolist()} ({time.time()-t:.1f} s)", flush=True)
+    RF.close()
+    np.savez_compressed(
+        os.path.join(OUT, "bench_labels_static_seed%d.npz" % seed), labels_source=LABEL_SOURCE, seed=seed, n_points=1_000_000,
+        scan_sha=sha(w["s1"]["points"]), n_obj=len(objs), n_plc=len(plcs),
+        **{f"obj{i}_sub_sha": sha(o["sub"]) for i, o in enumerate(objs) if "sub" in o},
+        obj_class=np.array([o["class_idx"] for o in objs], np.int32), obj_static=np.array([o["is_static"] for o in objs], np.int32),
+        plc_pose=np.stack([np.asarray(p["pose"], np.float32) for p in plcs]), plc_obj=np.array([p["object_idx"] for p in plcs], np.int32),
+        plc_uidx=np.array([p["uidx"] for p in plcs], np.int32),
+        **{f"{k}_prio{pr}": (v["order"] if k == "order" else sha(v[k])) for pr, v in out.items() for k in ("order", "labels", "min_dists", "class_ids", "instance_ids")},
+        n_labelled=np.array([int((out[pr]["labels"] > 0).sum()) for pr in (0, 1)]))
+
+
 def relabel(seed):
     """--labels-only: the label fields of bench_seed<seed>.npz again, from the reference build; everything else is kept."""
     import bench
@@ -205,6 +251,9 @@ def gen_sweep(R):
 
 if __name__ == "__main__":
     build(ref=True)
+    if "--static-labels" in sys.argv:
+        gen_static_labels(11)
+        sys.exit(0)
     if "--strong-only" in sys.argv:
         restrong(11)
         sys.exit(0)

@@ -97,3 +97,29 @@ def coverage_case(gscene):
         ks = range(int(d["arr_first"][a]), int(d["arr_first"][a + 1]))
         arrangements.append([(int(d["arr_obj"][k]), d["arr_pose"][k]) for k in ks])
     return d, objs, static, arrangements
+
+
+def static_label_case(w):
+    """The arrangement of tests/golden/bench_labels_static_seed11.npz rebuilt from bench.build_inputs( 1_000_000, seed = 11 ) the way
+    oracle/gen_golden_bench.py: static_arrangement() made it (same generator, same seed; the digests in the fixture guard it):
+    (fixture, objects as dicts with host arrays, placements in the fixture's order)."""
+    import hashlib
+    from rescan_amd import synth
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()  # noqa: E731
+    g = load_golden("bench_labels_static_seed11.npz")
+    s1 = w["s1"]
+    assert str(g["scan_sha"]) == sha(s1["points"]), "the generator no longer produces the scan the fixture was made for"
+    rng = np.random.default_rng(9100 + 11)
+    eye = np.eye(4, dtype=np.float32).ravel()
+    objs = [dict(pos=p["np"][0], nor=p["np"][1], class_idx=p["cls"], is_static=0) for p in w["plc"][:8]]
+    for i, (cls_name, which, step) in enumerate((("floor", 0, 3), ("wall", 1, 2), ("wall", 2, 4))):
+        idx = np.nonzero(s1["instance_idx"] == which)[0]
+        sub = np.sort(rng.permutation(idx)[::step]).astype(np.int32)
+        assert sha(sub) == str(g[f"obj{8 + i}_sub_sha"])
+        if which == 2:
+            synth.perturbed_pose(eye, rng, 0.003, 0.002)          # (keeps the generator in step; the pose itself is in the fixture)
+        objs.append(dict(pos=np.ascontiguousarray(s1["points"][sub]), nor=np.ascontiguousarray(s1["normals"][sub]),
+                         class_idx=synth.CLASS_IDX[cls_name], is_static=1))
+    assert [o["class_idx"] for o in objs] == g["obj_class"].tolist() and [o["is_static"] for o in objs] == g["obj_static"].tolist()
+    plcs = [dict(pose=g["plc_pose"][k], object_idx=int(g["plc_obj"][k]), uidx=int(g["plc_uidx"][k])) for k in range(int(g["n_plc"]))]
+    return g, objs, plcs

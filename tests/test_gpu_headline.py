@@ -99,6 +99,34 @@ def test_headline_labels_vs_reference(capi, headline):
     assert sha(ids["class_ids"]) == str(g["class_ids_sha"]) and sha(ids["instance_ids"]) == str(g["instance_ids_sha"])
 
 
+def test_headline_labels_with_static_placements_vs_reference(capi, bench_mod, headline):
+    """Label transfer at the headline's size WITH static placements — the second pass of rspf_arrangement_to_labels (1.5 x radius, shared
+    or reset min_dists), the (static << 10 | class) ordering, static objects of 0.1 - 0.3 M points cut from the scan — against the
+    reference's own loops (oracle/gen_golden_bench.py --static-labels: tests/golden/bench_labels_static_seed11.npz), both values of
+    prioritize_static: temporary labels, min_dists, class and instance ids, bit-exact."""
+    w, g0 = headline
+    if int(g0["seed"]) != 11:
+        pytest.skip("the static-arrangement fixture was made for seed 11")
+    from conftest import static_label_case
+    g, objs, plcs = static_label_case(w)
+    assert "reference" in str(g["labels_source"])
+    clouds = [p["cloud"] for p in w["plc"][:8]]
+    made = [capi.Cloud(o["pos"], o["nor"]) for o in objs[8:]]
+    clouds += made
+    try:
+        args = (w["scan1"], g["plc_pose"], [clouds[p["object_idx"]] for p in plcs], [objs[p["object_idx"]]["is_static"] for p in plcs],
+                [objs[p["object_idx"]]["class_idx"] for p in plcs])
+        for prio in (0, 1):
+            res = capi.arrangement_to_ids(*args, [p["uidx"] for p in plcs], 0.05, bool(prio), 0)
+            assert (res["order"] == g[f"order_prio{prio}"]).all()
+            assert int((res["labels"] > 0).sum()) == int(g["n_labelled"][prio])
+            for k in ("labels", "min_dists", "class_ids", "instance_ids"):
+                assert sha(res[k]) == str(g[f"{k}_prio{prio}"]), (k, prio)
+    finally:
+        for c in made:
+            c.close()
+
+
 def test_headline_sharded_route_is_bit_identical(capi, bench_mod, headline):
     """bench.py's sharded route (rescan_amd.dist.shard_*) at world 1, and a 2-way split simulated on this device (both
     ranks' send buffers computed one after the other, concatenated as the all-gather would, folded), return the same

@@ -163,3 +163,22 @@ def test_level_poisson(oracle, gscene):
             want = g[f"{name}_l{level}"]
             assert len(got) == len(want) and (got == want).all(), (name, level)
             assert (np.diff(got) > 0).all() and got[0] == 0            # increasing, and the first point is always a sample
+
+
+def test_headline_static_arrangement_restatement(oracle):
+    """The restatement's label loops at the headline's size, with static placements (0.1 - 0.3 M-point objects, the 1.5 x radius pass,
+    both values of prioritize_static), against the reference's digests (tests/golden/bench_labels_static_seed11.npz, generated by
+    the reference's own text: oracle/gen_golden_bench.py --static-labels)."""
+    import hashlib
+    import sys
+    from conftest import ROOT, static_label_case
+    sys.path.insert(0, ROOT)
+    import bench
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()  # noqa: E731
+    w = bench.build_inputs(1_000_000, seed=11)
+    g, objs, plcs = static_label_case(w)
+    for prio in (0, 1):
+        res = oracle.arrangement_to_labels(w["s1"]["points"], w["s1"]["normals"], objs, plcs, 0.05, prio, 0)
+        assert (res["order"] == g[f"order_prio{prio}"]).all()
+        for k in ("labels", "min_dists", "class_ids", "instance_ids"):
+            assert sha(res[k]) == str(g[f"{k}_prio{prio}"]), (k, prio)
