@@ -661,7 +661,8 @@ int icp_prepare( IcpCtx& cx, const rs_hip_cloud_t* src, const rs_hip_cloud_t* tg
   L.multi = nullptr;
   if( srcs )
   {
-    std::vector<IcpProblem> P( np );
+    if( ( rc = g_ws.h_c.ensure( np * sizeof( IcpProblem ) ) ) || ( rc = g_ws.multi.ensure( np * sizeof( IcpProblem ) ) ) ) return rc;
+    IcpProblem* P = g_ws.h_c.as<IcpProblem>();      // (pinned, the workspace's: the copy below needs no synchronisation — every entry point ends with one)
     size_t pts = 0, tiles = 0, heavy = 0; int max_n = 0, max_tiles = 0;
     for( size_t p = 0; p < np; ++p )
     {
@@ -670,9 +671,7 @@ int icp_prepare( IcpCtx& cx, const rs_hip_cloud_t* src, const rs_hip_cloud_t* tg
       pts += (size_t)srcs[p]->n; tiles += (size_t)srcs[p]->qview.n_tiles; heavy += heavy_stride( srcs[p]->qview.n_tiles );
       max_n = std::max( max_n, (int)srcs[p]->n ); max_tiles = std::max( max_tiles, srcs[p]->qview.n_tiles );
     }
-    if( ( rc = g_ws.multi.ensure( np * sizeof( IcpProblem ) ) ) ) return rc;
-    HIP_TRY( hipMemcpyAsync( g_ws.multi.p, P.data(), np * sizeof( IcpProblem ), hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
-    HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );      // (P is a local)
+    HIP_TRY( hipMemcpyAsync( g_ws.multi.p, P, np * sizeof( IcpProblem ), hipMemcpyHostToDevice, g_stream ), RS_HIP_E_RUNTIME );
     L.multi = (const IcpProblem*)g_ws.multi.p; L.src = QueryView{}; L.by_orig = nullptr;
     L.max_n = max_n; L.max_tiles = max_tiles;
     cx.total_pts = std::max<size_t>( 1, pts ); cx.total_tiles = std::max<size_t>( 1, tiles ); cx.heavy_words = heavy;
