@@ -35,8 +35,15 @@ def test_stress_parity_coordinates_of_both_signs():
 
 
 def test_tie_hunt_every_difference_is_an_exact_distance_tie():
-    out = run("tie_hunt.py", 1)
-    assert "unexplained 0" in out
+    """54 ICP runs of voxel-averaged level-2 objects against a level-2 scan (seeds 1-3).  Seed 3 holds the one run in 288 that is NOT
+    the reference's bits (ties): an exact fp32 distance tie, which the reference decides by the cell size its grid was
+    built with — it must be there, be explained as such (the GPU result equals a replay of the reference's loop on per-radius
+    grids), stay within north_star's tolerance, and be the only one."""
+    import re
+    out = run("tie_hunt.py", 3)
+    assert "unexplained 0" in out and "differing correspondences 0" in out
+    ties = re.findall(r"dT ([0-9.e+-]+): GPU == replay with per-radius grids", out)
+    assert len(ties) == 1 and 0.0 < float(ties[0]) < 1e-4, ties
 
 
 def test_icp_margin_by_source_size():
