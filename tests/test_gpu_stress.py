@@ -3,6 +3,7 @@ the parallel reference-order estimator and withdrew a polled zero-copy path whos
 a single pass of the suite cannot see such failures, so these run the same inputs many times — from one thread and from
 several — and demand identical bits every time.  Sized to finish within about a minute on the GPU box.
 
+* the multi-source ICP batch (a different source per problem, bound per problem on the device) against the single runs, 32 times;
 * the batched ICP with the parallel reference-order estimator ("replay") against the one-problem-at-a-time runs, 32 times;
 * replay against the sequential chains on a scan-sized source, 32 times;
 * small radius searches through the zero-copy (pinned-block) route of k_rows_wave from three host threads at once, each
@@ -38,6 +39,26 @@ def clouds(capi, gscene):
 
 def _key(err, T, it):
     return np.float32(err).tobytes() + np.asarray(T, np.float32).tobytes() + np.int32(it).tobytes()
+
+
+def test_multi_source_batch_matches_single_repeatedly(capi, gscene, clouds):
+    """rs_hip_icp_align_multi — every problem its own source cloud, bound on the device per problem (queues, slow-tile lists,
+    certificates and records at per-problem offsets) — REPEATS times against the problems run alone: identical bits every time, also
+    when the same workspace has just served a batch of another shape."""
+    from rescan_amd import synth
+    scn, objs = clouds
+    rng = np.random.default_rng(8)
+    order = [1, 0, 2, 0, 1]
+    T0s = np.stack([synth.perturbed_pose(gscene["objects"][k]["pose"], rng) for k in order])
+    single = [_key(*capi.icp_align(objs[k], scn, T0s[j], I4, 0.1, np.deg2rad(60.0))) for j, k in enumerate(order)]
+    bad = []
+    for rep in range(REPEATS):
+        errs, Ts, its = capi.icp_align_multi([objs[k] for k in order], scn, T0s, I4, 0.1, np.deg2rad(60.0))
+        bad += [(rep, j) for j in range(len(order)) if _key(errs[j], Ts[j], its[j]) != single[j]]
+        if rep % 4 == 3:          # another shape in between: two problems, the other way round
+            e2, T2, i2 = capi.icp_align_multi([objs[order[4]], objs[order[1]]], scn, T0s[[4, 1]], I4, 0.1, np.deg2rad(60.0))
+            bad += [(rep, -1) for a, j in ((0, 4), (1, 1)) if _key(e2[a], T2[a], i2[a]) != single[j]]
+    assert not bad, f"(repeat, problem) that differed: {bad}"
 
 
 def test_parallel_chains_batch_matches_single_repeatedly(capi, gscene, clouds):
