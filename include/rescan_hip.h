@@ -117,6 +117,15 @@ int32_t rs_hip_icp_reference_order_below( int32_t n_points );
  * after the other (a diagnostic: binade crossings, chain starts). */
 int32_t rs_hip_icp_replay_below( int32_t n_points );
 int32_t rs_hip_icp_replay_redone( void );
+/* The sequential estimator (sources up to rs_hip_icp_reference_order_below) runs the reference's dist² statistics and its weighted
+ * centroids in ONE pass, the 2.5 sigma cut of the weights (lib/rs/icp.h:396-401) taken at a guess of sigma; the pass stands when no
+ * dist² lies between the guessed and the real cut, else the centroids are summed again.  Iterations that had to, since rs_hip_init
+ * (diagnostics). */
+int32_t rs_hip_icp_faith_redone( void );
+/* Test switch of that guess, in thousandths: 1000 (default) the guess as made, 0 no guess (statistics, centroids and normal equations
+ * in three passes, as up to round 3), any other value scales the guessed cut — a guess that fails, for the tests of the check and of
+ * the fallback.  Returns the previous value; < 0 only queries. */
+int32_t rs_hip_icp_faith_guess( int32_t permille );
 /* Sources above both thresholds (whole million-point scans): the parallel fp64 reduction, centred on the REFERENCE'S centroids —
  * the seven sums behind icp__compute_weighted_centroid (icp.h:136-148: Σw, Σw·p, Σw·q) are computed as the reference's own
  * sequential fp32 chains, bit for bit.  Those chains carry a systematic rounding drift (parts in a thousand of Σw once the running

@@ -40,6 +40,8 @@ SIGNATURES = {
     "rs_hip_icp_reference_order_below": (C.c_int32, [C.c_int32]),
     "rs_hip_icp_replay_below": (C.c_int32, [C.c_int32]),
     "rs_hip_icp_replay_redone": (C.c_int32, []),
+    "rs_hip_icp_faith_redone": (C.c_int32, []),
+    "rs_hip_icp_faith_guess": (C.c_int32, [C.c_int32]),
     "rs_hip_icp_exact_centroids": (C.c_int32, [C.c_int32]),
     "rs_hip_icp_chains_gave_up": (C.c_int32, []),
     "rs_hip_icp_align_batch": (C.c_int, [C.c_void_p, C.c_void_p, f32p, C.c_int32, f32p, C.c_float, C.c_float,
@@ -254,6 +256,16 @@ def icp_chains_gave_up():
 
 def icp_replay_redone():
     return int(load().rs_hip_icp_replay_redone())
+
+
+def icp_faith_guess(permille=-1):
+    """Test switch of the sequential estimator's guessed cut (1000: as made, 0: three passes, else scaled); returns the previous value."""
+    return int(load().rs_hip_icp_faith_guess(int(permille)))
+
+
+def icp_faith_redone():
+    """Iterations of the sequential estimator whose one-pass statistics + centroids had to be summed again (cumulative)."""
+    return int(load().rs_hip_icp_faith_redone())
 
 
 def icp_align(source, target, T1, T2=IDENTITY, max_dist=0.1, max_angle=np.deg2rad(60.0), max_iter=100,

@@ -109,6 +109,7 @@ struct Workspace
   DevBuf tmp_pos, tmp_pos2, tmp_nor2;                                           // estimate-only
   DevBuf lvl_pos, lvl_nor, lvl_cnt, lvl_within, lvl_offset, lvl_adj, lvl_state, lvl_misc, lvl_flags, lvl_scan, lvl_samples, lvl_tmp, lvl_cursor, lvl_work_a, lvl_work_b;   // level builder
   DevBuf faith;                                                                 // reference-order estimator: correspondences in source order
+  DevBuf faith_redone;                                                                   // (a counter: rs_hip_icp_faith_redone)
   DevBuf rp_segsum, rp_guess, rp_seg, rp_super, rp_totals, rp_redone;                     // ... its parallel form (replay)
   DevBuf ch_rec, ch_segsum, ch_prefix, ch_seg, ch_blk, ch_guess, ch_dbg, ch_done, ch_chk;                                    // the centroid chains of large sources (grid chains)
   PinBuf h_a, h_b, h_c;
@@ -128,6 +129,7 @@ std::atomic<int> g_ref_order_below{ getenv( "RS_HIP_REF_ORDER_BELOW" ) ? atoi( g
 // Sources above both thresholds: the fp64 moments, centred on the reference's own fp32 centroid chains (rs_kernels.hip:
 // launch_icp_exact_centroids; rs_math.h: icp_solve).  RS_HIP_EXACT_CENTROIDS=0: plain fp64 moments.
 std::atomic<int> g_chains_gave_up{ 0 };
+std::atomic<int> g_faith_guess_permille{ getenv( "RS_HIP_FAITH_GUESS" ) ? atoi( getenv( "RS_HIP_FAITH_GUESS" ) ) : 1000 };
 std::atomic<int> g_exact_centroids{ getenv( "RS_HIP_EXACT_CENTROIDS" ) ? atoi( getenv( "RS_HIP_EXACT_CENTROIDS" ) ) : 1 };
 std::atomic<int> g_replay_below{ getenv( "RS_HIP_REPLAY_BELOW" ) ? atoi( getenv( "RS_HIP_REPLAY_BELOW" ) ) : 262144 };
 std::mutex g_prof_mutex;
@@ -231,6 +233,9 @@ struct rs_hip_cloud
   float nor_max = 1.0f;             // max |normal| (bounds how fast a gate value can change with the query normal)
   float cell = 0.0f;
   int64_t bytes = 0;
+  // as an ICP source whose centroid chains gave a problem up (sums that hover around zero: rs_hip_icp_align_batch): the next calls
+  // this many go straight to pass 2 of the replay instead of paying for the attempt first
+  mutable std::atomic<int> chains_wander{ 0 };
 };
 
 namespace {
@@ -711,6 +716,13 @@ int icp_prepare( IcpCtx& cx, const rs_hip_cloud_t* src, const rs_hip_cloud_t* tg
   L.mom_part = g_ws.mom_part.as<double>(); L.res = g_ws.res.as<double>();
   L.w_explicit = nullptr;
   L.faith = nullptr;
+  if( !g_ws.faith_redone.p )
+  {
+    if( int rc = g_ws.faith_redone.ensure( 64 ) ) return rc;
+    HIP_TRY( hipMemsetAsync( g_ws.faith_redone.p, 0, 64, g_stream ), RS_HIP_E_RUNTIME );
+  }
+  L.faith_redone = g_ws.faith_redone.as<int>();
+  L.faith_guess_scale = (float)g_faith_guess_permille.load() / 1000.0f;
   HIP_TRY( hipMemsetAsync( g_ws.queue_count.p, 0, np * 4, g_stream ), RS_HIP_E_RUNTIME );
   return RS_HIP_OK;
 }
@@ -1046,7 +1058,7 @@ int icp_align_batch_impl( const rs_hip_cloud_t* source, const rs_hip_cloud_t* ta
     for( int r = 0; r < CH_ROWS; ++r )
     {
       const int* q = c.data() + (size_t)r * ( 4 + 3 * 4096 );
-      if( q[1] < 0 ) { fprintf( stderr, "[rs_hip chains] chain %d self-check: %d steps, all as the plain sum (%08x)\n", r, q[0], (unsigned)q[3] ); continue; }
+      if( q[1] < 0 ) { fprintf( stderr, "[rs_hip chains] chain %d self-check: %d steps, all as the plain sum (%08x); %d segments end in another binade than they start in\n", r, q[0], (unsigned)q[3], q[2] ); continue; }
       const int k = q[1];
       auto show = [&]( int j ) { const int* e = q + 4 + 3 * j; const int kind = e[2]; fprintf( stderr, "      step %d: ends at segment %d with %08x; type %d chunk %d block %d from %d to %d slot %d, %s\n", j, e[0], (unsigned)e[1], kind & 3, ( kind >> 2 ) & 7, ( kind >> 5 ) & 63, ( kind >> 11 ) & 63, ( kind >> 17 ) & 127, ( kind >> 24 ) & 63, ( kind >> 30 ) & 1 ? "by its record" : "by scans / addend by addend" ); };
       fprintf( stderr, "[rs_hip chains] chain %d self-check: step %d of %d differs from the plain sum (%08x there)\n", r, k, q[0], (unsigned)q[2] );
@@ -1079,9 +1091,17 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
   {
     const int np = std::min( slice, n - p0 );
     float* T = T1s ? T1s + 16 * (size_t)p0 : nullptr; float* e = errs ? errs + p0 : nullptr; int32_t* it = iters ? iters + p0 : nullptr;
-    int rc = icp_align_batch_impl( source, target, T, np, T2, max_dist, max_angle, max_iter, fixed_iters, e, it, g_exact_centroids.load() );
+    // (a source whose chains gave up lately: the attempt — a cold search, the iterations up to the give-up, the launches that idle
+    //  through the rest of the call: ~1.4 ms at a million points — is skipped; every 16th such call tries the chains again)
+    int mode = g_exact_centroids.load();
+    if( mode == 1 && per_point_records && source->chains_wander.load() > 0 ) { source->chains_wander.fetch_sub( 1 ); mode = 2; }
+    int rc = icp_align_batch_impl( source, target, T, np, T2, max_dist, max_angle, max_iter, fixed_iters, e, it, mode );
     // (a problem of the slice whose chains gave up: that slice again, its seven sums by pass 2 of the replay — nothing of it was written yet)
-    if( rc == ICP_CHAINS_GAVE_UP ) rc = icp_align_batch_impl( source, target, T, np, T2, max_dist, max_angle, max_iter, fixed_iters, e, it, 2 );
+    if( rc == ICP_CHAINS_GAVE_UP )
+    {
+      source->chains_wander.store( 15 );
+      rc = icp_align_batch_impl( source, target, T, np, T2, max_dist, max_angle, max_iter, fixed_iters, e, it, 2 );
+    }
     if( rc ) return rc;
   }
   return RS_HIP_OK;
@@ -1190,6 +1210,24 @@ int32_t rs_hip_icp_exact_centroids( int32_t on )
   const int prev = g_exact_centroids.load();
   if( on >= 0 ) g_exact_centroids.store( on > 2 ? 1 : on );
   return prev;
+}
+
+int32_t rs_hip_icp_faith_guess( int32_t permille )
+{
+  const int prev = g_faith_guess_permille.load();
+  if( permille >= 0 ) g_faith_guess_permille.store( permille );
+  return prev;
+}
+
+int32_t rs_hip_icp_faith_redone( void )
+{
+  int v = 0;
+#ifdef RS_FAITH_TIMING
+  { int t[16]; (void)hipStreamSynchronize( g_stream ); if( g_ws.faith_redone.p && hipMemcpy( t, g_ws.faith_redone.p, sizeof t, hipMemcpyDeviceToHost ) == hipSuccess )
+    for( int w = 0; w < 4; ++w ) fprintf( stderr, "[rs_hip faith timing] pass %d wave %d: %d cycles at work, %d at the barrier, %d chunks\n", RS_FAITH_TIMING, w, t[2 + 3 * w], t[3 + 3 * w], t[4 + 3 * w] ); }
+#endif
+  if( g_ws.faith_redone.p && ( hipStreamSynchronize( g_stream ) != hipSuccess || hipMemcpy( &v, g_ws.faith_redone.p, 4, hipMemcpyDeviceToHost ) != hipSuccess ) ) return -1;
+  return v;
 }
 
 int32_t rs_hip_icp_replay_redone( void )

@@ -89,6 +89,8 @@ struct IcpLaunch
   // dist² statistics of the correspondences: n_prob x STAT_SHARDS x {Σ1, Σd²·stat_s1, Σd⁴·stat_s2, -} as integers
   // (null: not wanted — reference-order estimator, find_corrs / estimate-only entry points)
   unsigned long long* stat_acc;
+  float   faith_guess_scale;       // 1: the guess of the cut as made; 0: no guess (three passes); anything else: the guess scaled (tests: a guess that fails)
+  int*    faith_redone;            // (diagnostics, cumulative; may be null) iterations of k_icp_faithful whose one-pass statistics + centroids did not stand
   double  stat_s1, stat_s2, stat_i1, stat_i2;   // fixed-point scales (powers of two chosen from the radius) and their inverses
   double* mom_part;   // n_prob x n_mom_blocks x ICP_NMOM
   double* res;        // n_prob x ICP_NRES : moments [0,35), then n_corr, mean, stddev, queued tiles (written by k_icp_moments)

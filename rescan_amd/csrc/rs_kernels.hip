@@ -1963,13 +1963,17 @@ __global__ __launch_bounds__( BLOCK ) void k_icp_update_wide( IcpLaunch L, int* 
 // for bit.  fp32 addition does not associate, so each accumulator is ONE sequential chain over the
 // correspondences — but the 35 accumulators are independent chains, and producing the addends is parallel:
 //   k_icp_faith_gather   the correspondences in the source's original order, SoA, all threads
-//   k_icp_faithful       one workgroup per problem, four waves on four SIMDs:
-//                          waves 2,3  turn 128 correspondences at a time into the addends of every accumulator (LDS)
+//   k_icp_faithful       one workgroup per problem, six waves:
+//                          waves 2-5  turn 128 correspondences at a time into the addends of every accumulator (LDS; two threads per
+//                                     correspondence)
 //                          wave 0     lane a adds row a, entry after entry, to fp32 accumulator a
-//                          wave 1     the same for the two fp64 accumulators
+//                          wave 1     the same for the two fp64 accumulators (their rows arrive as doubles)
 //                        double-buffered, so the chains never wait for the producers.
-//   Three passes (each needs the previous one's totals): dist² statistics -> weights, centroids -> normal equations,
-//   then thread 0 runs the rest of the iteration exactly as k_icp_update does.
+//   Two passes: dist² statistics AND weights, centroids — the statistics reach the centroids only through the 2.5 sigma cut of the
+//   weights, taken at a guess and checked afterwards (a third pass, the centroids alone, when the guess cut differently: not once
+//   in 349 iterations of 24 object-to-scan runs) — then the normal equations, which need the centroids; thread 0 runs the rest of
+//   the iteration exactly as k_icp_update does.  What a pass costs is its longest chain: ~8.6 cycles per addition and row of
+//   fp32 (6.5 with nothing else on the CU's LDS), 11.5 of fp64.
 // Unmatched source points add +0 (no effect on an accumulator that started at +0).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__( BLOCK ) void k_icp_faith_gather( IcpLaunch L )
@@ -2002,7 +2006,15 @@ __global__ __launch_bounds__( BLOCK ) void k_icp_faith_gather( IcpLaunch L )
 
 #define FAITH_CHUNK 128
 #define FAITH_PITCH ( FAITH_CHUNK + 4 )          // rows stay 16-byte aligned (128-bit LDS reads) and a quarter-wave of them covers all banks once
-#define FAITH_THREADS ( 2 * WAVE + FAITH_CHUNK )   // two chain waves + two producer waves: one wave per SIMD
+// Two threads per correspondence of a chunk — four producer waves, two of them beside the chain waves on their SIMDs: the normal
+// equations' 35 addends (~200 vector instructions, 35 + 2 LDS writes per correspondence) in two halves.  With one thread each the two
+// producer waves set the pace of the last pass (880 k cycles at work over 420 chunks against 465 k of the fp32 chain wave, 620 k
+// of the fp64 one: tools/faith_timing.py); with two they take 575 k and the fp64 chain does.  RS_FAITH_SPLIT=0: one thread each.
+#ifndef RS_FAITH_SPLIT
+#define RS_FAITH_SPLIT 1
+#endif
+#define FAITH_PRODUCERS ( ( RS_FAITH_SPLIT + 1 ) * FAITH_CHUNK )
+#define FAITH_THREADS ( 2 * WAVE + FAITH_PRODUCERS )   // two chain waves + the producer waves
 
 struct FaithRec { float v[FAITH_REC]; };
 struct FaithPar
@@ -2030,18 +2042,23 @@ __device__ __forceinline__ float faith_weight( const FaithRec& r, const FaithPar
   return w;
 }
 
-// the addends of one correspondence for pass PASS, written to column t of `term`
+// the addends of one correspondence for pass PASS, written to column t of `term` (RS_FAITH_SPLIT: of PASS 3 rows [0,18) for half 0,
+// [18,35) for half 1; half 2: all)
 template <int PASS>
-__device__ __forceinline__ void faith_terms( const FaithRec& r, const FaithPar& P, float ( *term )[FAITH_PITCH], int t )
+__device__ __forceinline__ void faith_terms( const FaithRec& r, const FaithPar& P, float ( *term )[FAITH_PITCH], int t, int half = 2,
+                                             double ( *termd )[FAITH_PITCH] = nullptr /* PASS 3: rows 33, 34 also as doubles */ )
 {
+  if( PASS != 3 && half == 1 ) return;
   const bool m = r.v[0] >= 0.0f;
-  if( PASS == 1 )
+  if( PASS == 1 || PASS == 12 )
   {
-    term[0][t] = m ? r.v[0] : 0.0f;                 // msh_compute_mean
-    term[1][t] = m ? r.v[0] * r.v[0] : 0.0f;        // msh_compute_stddev
-    term[2][t] = m ? 1.0f : 0.0f;                   // n_corrs (exact in fp32 below 2^24)
+    constexpr int R0 = PASS == 12 ? 7 : 0;
+    term[R0 + 0][t] = m ? r.v[0] : 0.0f;            // msh_compute_mean
+    term[R0 + 1][t] = m ? r.v[0] * r.v[0] : 0.0f;   // msh_compute_stddev
+    term[R0 + 2][t] = m ? 1.0f : 0.0f;              // n_corrs (exact in fp32 below 2^24)
   }
-  else if( PASS == 2 )
+  if( PASS == 1 ) return;
+  if( PASS == 2 || PASS == 12 )
   {
     const float w = m ? faith_weight( r, P ) : 0.0f;
     term[0][t] = w;                                 // icp.h:141  total += w
@@ -2056,8 +2073,15 @@ __device__ __forceinline__ void faith_terms( const FaithRec& r, const FaithPar& 
   {
     if( !m )
     {
+      if( half != 1 ) {
 #pragma unroll
-      for( int a = 0; a < ICP_NMOM; ++a ) term[a][t] = 0.0f;
+        for( int a = 0; a < 18; ++a ) term[a][t] = 0.0f;
+      }
+      if( half != 0 ) {
+#pragma unroll
+        for( int a = 18; a < ICP_NMOM; ++a ) term[a][t] = 0.0f;
+        if( termd ) { termd[0][t] = 0.0; termd[1][t] = 0.0; }
+      }
       return;
     }
     const float wi = faith_weight( r, P );
@@ -2067,15 +2091,22 @@ __device__ __forceinline__ void faith_terms( const FaithRec& r, const FaithPar& 
     const float d[3] = { p[0] - q[0], p[1] - q[1], p[2] - q[2] };
     const float cv[3] = { p[1] * nv[2] - p[2] * nv[1], p[2] * nv[0] - p[0] * nv[2], p[0] * nv[1] - p[1] * nv[0] };
     const float sd = d[0] * nv[0] + d[1] * nv[1] + d[2] * nv[2];
+    if( half != 1 )
+    {
+#pragma unroll
+      for( int col = 0; col < 3; ++col )
+#pragma unroll
+        for( int row = 0; row < 3; ++row )
+        {
+          term[3 * col + row][t]      = ( cv[row] * cv[col] ) * wi;   // icp.h:239-241, column-major blocks
+          term[9 + 3 * col + row][t]  = ( cv[row] * nv[col] ) * wi;
+        }
+    }
+    if( half == 0 ) return;
 #pragma unroll
     for( int col = 0; col < 3; ++col )
 #pragma unroll
-      for( int row = 0; row < 3; ++row )
-      {
-        term[3 * col + row][t]      = ( cv[row] * cv[col] ) * wi;     // icp.h:239-241, column-major blocks
-        term[9 + 3 * col + row][t]  = ( cv[row] * nv[col] ) * wi;
-        term[18 + 3 * col + row][t] = ( nv[row] * nv[col] ) * wi;
-      }
+      for( int row = 0; row < 3; ++row ) term[18 + 3 * col + row][t] = ( nv[row] * nv[col] ) * wi;
 #pragma unroll
     for( int a = 0; a < 3; ++a )
     {
@@ -2084,78 +2115,138 @@ __device__ __forceinline__ void faith_terms( const FaithRec& r, const FaithPar& 
     }
     term[33][t] = wi * sd * sd;                     // icp.h:249 (a float product, summed in fp64)
     term[34][t] = wi;                               // icp.h:250
+    if( termd ) { termd[0][t] = (double)( wi * sd * sd ); termd[1][t] = (double)wi; }
   }
 }
 
-// A chain wave's two steps for one chunk: pull its row into registers (128-bit LDS reads), and later add the
-// entries one after the other.  Columns past the end of the cloud hold +0, so every chunk is a full one.
-struct FaithRow { float4 v[FAITH_CHUNK / 4]; };
-__device__ __forceinline__ void faith_fetch( const float* row, FaithRow& r )
+// A chain wave's chunk: its row's 128 entries added one after the other, straight from LDS, sixteen at a time — the reads of the next
+// sixteen go out before this group's additions.  Columns past the end of the cloud hold +0, so every chunk is a full one.
+// (A whole row staged in registers first — two of them, 256 registers — pushed the kernel's allocation into AGPRs, one
+// v_accvgpr_read per addend; reads placed between the additions one by one took 50 % longer.  None of it shows: a chunk takes what
+// its 128 dependent additions take, ~8 cycles each.)
+// (the two fp64 accumulators' rows arrive as doubles — the producers' conversion: with a v_cvt_f64_f32 in front of every addition the
+//  fp64 wave took 1.5 times as long as the fp32 wave, and set the pace of the last pass together with the producers)
+__device__ __forceinline__ void faith_chain_lds( const double* row, double& acc )
 {
-  const float4* row4 = reinterpret_cast<const float4*>( row );
+  const double2* row2 = reinterpret_cast<const double2*>( row );
+  double2 a[4], b[4];
 #pragma unroll
-  for( int q = 0; q < FAITH_CHUNK / 4; ++q ) r.v[q] = row4[q];
+  for( int j = 0; j < 4; ++j ) a[j] = row2[j];
+#pragma unroll
+  for( int g = 0; g < FAITH_CHUNK / 8; ++g )
+  {
+    double2* cur = ( g & 1 ) ? b : a; double2* nxt = ( g & 1 ) ? a : b;
+    if( g + 1 < FAITH_CHUNK / 8 )
+    {
+#pragma unroll
+      for( int j = 0; j < 4; ++j ) nxt[j] = row2[( g + 1 ) * 4 + j];
+    }
+#pragma unroll
+    for( int j = 0; j < 4; ++j ) { acc += cur[j].x; acc += cur[j].y; }
+    __builtin_amdgcn_sched_barrier( 0 );
+  }
 }
 template <class ACC>
-__device__ __forceinline__ void faith_chain( const FaithRow& r, ACC& acc )
+__device__ __forceinline__ void faith_chain_lds( const float* row, ACC& acc )
 {
+  const float4* row4 = reinterpret_cast<const float4*>( row );
+  float4 a[4], b[4];
 #pragma unroll
-  for( int q = 0; q < FAITH_CHUNK / 4; ++q ) { acc += (ACC)r.v[q].x; acc += (ACC)r.v[q].y; acc += (ACC)r.v[q].z; acc += (ACC)r.v[q].w; }
+  for( int j = 0; j < 4; ++j ) a[j] = row4[j];
+#pragma unroll
+  for( int g = 0; g < FAITH_CHUNK / 16; ++g )
+  {
+    float4* cur = ( g & 1 ) ? b : a; float4* nxt = ( g & 1 ) ? a : b;
+    if( g + 1 < FAITH_CHUNK / 16 )
+    {
+#pragma unroll
+      for( int j = 0; j < 4; ++j ) nxt[j] = row4[( g + 1 ) * 4 + j];
+    }
+#pragma unroll
+    for( int j = 0; j < 4; ++j ) { acc += (ACC)cur[j].x; acc += (ACC)cur[j].y; acc += (ACC)cur[j].z; acc += (ACC)cur[j].w; }
+    __builtin_amdgcn_sched_barrier( 0 );          // (the scheduler would gather all the row's reads in front of the chain)
+  }
 }
 
 // One pass over the correspondences: rows [0,NF) end in accf of wave 0's lanes, rows [NF,NF+ND) in accd of wave 1's.
 // Iteration k: the producers write chunk k (and keep FAITH_AHEAD chunks of loads in flight: a chunk is consumed faster
-// than a load returns); the chain waves fetch chunk k-1 from LDS while they add up chunk k-2 from registers.
+// than a load returns); the chain waves add up chunk k-1 from LDS.
 #define FAITH_AHEAD 4
+// PASS 12: statistics and centroids in ONE pass, the weights cut at a guess of 2.5 sigma (P.cut); band[0] / band[1] end as the largest
+// dist² not above the guess and the smallest above it (bits: dist² >= 0) — the guess cut the weights exactly as the real value
+// does iff the real value lies in [band[0], band[1]).
 template <int PASS, int NF, int ND>
-__device__ __forceinline__ void faith_pass( const float* F, int n, const FaithPar& P, float ( *term )[ICP_NMOM][FAITH_PITCH],
-                                            float& accf, double& accd )
+__device__ __forceinline__ void faith_pass( const float* F, int n, const FaithPar& P, float ( *term )[ICP_NMOM][FAITH_PITCH], double ( *termd )[2][FAITH_PITCH],
+                                            float& accf, double& accd, unsigned* band = nullptr, int* timing = nullptr /* (experiment: -DRS_FAITH_TIMING=<pass>) */ )
 {
   const int wib = threadIdx.x / WAVE, lane = threadIdx.x & ( WAVE - 1 );
-  const int t = threadIdx.x - 2 * WAVE;            // producer column
+  const int t = ( threadIdx.x - 2 * WAVE ) & ( FAITH_CHUNK - 1 );              // producer column ...
+  const int half = RS_FAITH_SPLIT ? uni( (int)( threadIdx.x - 2 * WAVE ) / FAITH_CHUNK ) : 2;      // ... and which of its addends (RS_FAITH_SPLIT: half of them; wave-uniform)
   const int n_chunks = ( n + FAITH_CHUNK - 1 ) / FAITH_CHUNK;
   const int my_row = wib == 0 ? ( lane < NF ? lane : -1 ) : ( wib == 1 && lane < ND ? NF + lane : -1 );
   accf = 0.0f; accd = 0.0;
   FaithRec ring[FAITH_AHEAD];
-  FaithRow rows[2];
+  float d_below = 0.0f, d_above = INFINITY;
   const bool producer = wib >= 2;
+#ifdef RS_FAITH_TIMING
+  long long t_work = 0, t_wait = 0;
+#endif
   if( producer )
   {
 #pragma unroll
     for( int u = 0; u < FAITH_AHEAD; ++u ) faith_load( F, n, u * FAITH_CHUNK + t, ring[u] );
   }
-  for( int k0 = 0; k0 <= n_chunks + 1; k0 += FAITH_AHEAD )
+  for( int k0 = 0; k0 <= n_chunks; k0 += FAITH_AHEAD )
   {
 #pragma unroll
     for( int u = 0; u < FAITH_AHEAD; ++u )
     {
       const int k = k0 + u;
+#ifdef RS_FAITH_TIMING
+      const long long c0 = clock64();
+#endif
       if( wib >= 2 )
       {
         if( producer && k < n_chunks )
         {
-          faith_terms<PASS>( ring[u], P, term[k & 1], t );
+          if( PASS == 12 && half != 1 && ring[u].v[0] >= 0.0f )
+          {
+            if( ring[u].v[0] > P.cut ) d_above = fminf( d_above, ring[u].v[0] ); else d_below = fmaxf( d_below, ring[u].v[0] );
+          }
+          faith_terms<PASS>( ring[u], P, term[k & 1], t, half, PASS == 3 ? termd[k & 1] : nullptr );
           faith_load( F, n, ( k + FAITH_AHEAD ) * FAITH_CHUNK + t, ring[u] );
         }
       }
       else if( my_row >= 0 )
       {
-        if( k >= 1 && k <= n_chunks ) faith_fetch( term[( k - 1 ) & 1][my_row], rows[( k - 1 ) & 1] );
-        if( k >= 2 && k <= n_chunks + 1 )
+        // chunk k - 1 (written during step k - 1, the barrier since), while the producers write chunk k into the other buffer
+        if( k >= 1 && k <= n_chunks )
         {
-          if( wib == 0 ) faith_chain( rows[k & 1], accf ); else faith_chain( rows[k & 1], accd );
+          if( wib == 0 ) faith_chain_lds( term[( k - 1 ) & 1][my_row], accf ); else faith_chain_lds( termd[( k - 1 ) & 1][my_row - NF], accd );
         }
       }
+#ifdef RS_FAITH_TIMING
+      const long long c1 = clock64();
+#endif
       __syncthreads();
+#ifdef RS_FAITH_TIMING
+      t_work += c1 - c0; t_wait += clock64() - c1;
+#endif
     }
   }
+#ifdef RS_FAITH_TIMING
+  if( lane == 0 && PASS == RS_FAITH_TIMING && timing && wib < 4 ) { int* o = timing + 2 + 3 * wib; o[0] = (int)t_work; o[1] = (int)t_wait; o[2] = n_chunks; }
+#endif
+  if( PASS == 12 && producer ) { atomicMax( band, __float_as_uint( d_below ) ); atomicMin( band + 1, __float_as_uint( d_above ) ); }
 }
 
 __global__ __launch_bounds__( FAITH_THREADS ) void k_icp_faithful( IcpLaunch L )
 {
   __shared__ __attribute__( ( aligned( 16 ) ) ) float term[2][ICP_NMOM][FAITH_PITCH];
+  __shared__ __attribute__( ( aligned( 16 ) ) ) double termd[2][2][FAITH_PITCH];
   __shared__ float s_f[ICP_NMOM];
-  __shared__ double s_d[2];
+  __shared__ double s_d[2], s_g[FAITH_THREADS / WAVE][3];
+  __shared__ unsigned s_band[2];
   const int prob = blockIdx.x;
   if( L.active[prob] == 0 ) return;
   icp_bind( L, prob );
@@ -2168,30 +2259,55 @@ __global__ __launch_bounds__( FAITH_THREADS ) void k_icp_faithful( IcpLaunch L )
   P.c1[0] = P.c1[1] = P.c1[2] = P.c2[0] = P.c2[1] = P.c2[2] = 0.0f;
   float accf; double accd;
 
-  // ---- icp.h:393-402: mean and standard deviation of dist² over the correspondences ----
+  // ---- icp.h:393-402: mean and standard deviation of dist² over the correspondences; icp.h:136-148: Σw and the two weighted centroids ----
+  // The statistics only reach the centroids through the 2.5 sigma cut of the weights (icp.h:396-401), a COMPARISON: with a guess of
+  // sigma (fp64 sums, all threads, a few microseconds) both sets of chains run in one pass — ten rows instead of three, then
+  // seven: a chain wave's time does not depend on how many of its lanes are rows — and the pass stands if no dist² lies between
+  // the guessed and the real cut (and they agree on whether to cut at all).  Otherwise the centroids again, as before.
+  bool have_centroids = false;
   if( !P.w_explicit )
   {
-    faith_pass<1, 3, 0>( F, n, P, term, accf, accd );
-    if( wib == 0 && lane < 3 ) s_f[lane] = accf;
+    {
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+      for( int i = threadIdx.x; i < n; i += FAITH_THREADS ) { const float d = F[i]; if( d >= 0.0f ) { a0 += (double)d; a1 += (double)d * (double)d; a2 += 1.0; } }
+      a0 = wave_sum( a0 ); a1 = wave_sum( a1 ); a2 = wave_sum( a2 );
+      if( lane == 0 ) { s_g[wib][0] = a0; s_g[wib][1] = a1; s_g[wib][2] = a2; }
+      if( threadIdx.x == 0 ) { s_band[0] = 0u; s_band[1] = __float_as_uint( INFINITY ); }
+      __syncthreads();
+      double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+      for( int w = 0; w < FAITH_THREADS / WAVE; ++w ) { t0 += s_g[w][0]; t1 += s_g[w][1]; t2 += s_g[w][2]; }
+      const double mean_g = t2 > 0.0 ? t0 / t2 : 0.0, var_g = t2 > 0.0 ? t1 / t2 - mean_g * mean_g : 0.0;
+      const float sd_g = (float)sqrt( var_g > 0.0 ? var_g : 0.0 );
+      P.use_sd = sd_g > 0.000001; P.cut = 2.5f * sd_g * L.faith_guess_scale;
+    }
+    const bool guessed_use = P.use_sd;
+    if( L.faith_guess_scale != 0.0f ) faith_pass<12, 10, 0>( F, n, P, term, termd, accf, accd, s_band, L.faith_redone );
+    else                              faith_pass<1, 3, 0>( F, n, P, term, termd, accf, accd );
+    const int r0 = L.faith_guess_scale != 0.0f ? 7 : 0;
+    if( wib == 0 && lane < 10 ) s_f[lane] = accf;
     __syncthreads();
-    const float cnt = s_f[2];
+    const float cnt = s_f[r0 + 2];
     if( cnt == 0.0f )                                                   // icp.h:455-459: no correspondences
     {
       if( threadIdx.x == 0 && L.solve ) { L.prev_err[prob] = L.err[prob]; L.iters[prob] += 1; L.active[prob] = 0; }
       return;
     }
-    const float mean = __fdiv_rn( s_f[0], cnt );                        // msh_std.h:1800-1825
-    const float var = __fdiv_rn( s_f[1], cnt ) - mean * mean;
+    const float mean = __fdiv_rn( s_f[r0], cnt );                       // msh_std.h:1800-1825
+    const float var = __fdiv_rn( s_f[r0 + 1], cnt ) - mean * mean;
     const float sd = (float)sqrt( (double)var );
     P.use_sd = sd > 0.000001;
     P.cut = 2.5f * sd;
-    __syncthreads();                                                    // s_f is rewritten below
+    have_centroids = L.faith_guess_scale != 0.0f && P.use_sd == guessed_use && ( !P.use_sd || ( __uint_as_float( s_band[0] ) <= P.cut && P.cut < __uint_as_float( s_band[1] ) ) );
+    if( !have_centroids && L.faith_guess_scale != 0.0f && threadIdx.x == 0 && L.faith_redone ) atomicAdd( L.faith_redone, 1 );
+    __syncthreads();                                                    // (s_f is rewritten below if the pass does not stand)
   }
 
-  // ---- icp.h:136-148: Σw and the two weighted centroids ----
-  faith_pass<2, 7, 0>( F, n, P, term, accf, accd );
-  if( wib == 0 && lane < 7 ) s_f[lane] = accf;
-  __syncthreads();
+  if( !have_centroids )
+  {
+    faith_pass<2, 7, 0>( F, n, P, term, termd, accf, accd );
+    if( wib == 0 && lane < 7 ) s_f[lane] = accf;
+    __syncthreads();
+  }
   const float total = s_f[0];
   if( total <= 1e-7 )                                                   // icp.h:466-470: the weights vanished
   {
@@ -2204,7 +2320,7 @@ __global__ __launch_bounds__( FAITH_THREADS ) void k_icp_faithful( IcpLaunch L )
   __syncthreads();
 
   // ---- icp.h:221-252: the normal equations ----
-  faith_pass<3, 33, 2>( F, n, P, term, accf, accd );
+  faith_pass<3, 33, 2>( F, n, P, term, termd, accf, accd, nullptr, L.faith_redone );
   if( wib == 0 && lane < 33 ) s_f[lane] = accf;
   if( wib == 1 && lane < 2 ) s_d[lane] = accd;
   __syncthreads();
@@ -3174,7 +3290,9 @@ __global__ __launch_bounds__( 3 * WAVE ) void k_chain_compose( IcpLaunch L, Chai
 #define CH_SUPER 8                 // chunks of 64 blocks per round of forecasts
 #define CH_EPS ( 1.0f / 2048.0f )
 #define CH_CHK_MAX 4096            // (RS_HIP_CHAIN_DEBUG) steps of a walk logged for the self-check
+#ifndef CH_BUDGET
 #define CH_BUDGET 384              // segments a walk may add up addend by addend before it gives the problem up (ChainBufs::failed)
+#endif
 #define CH_PIECES 16               // pieces of a fetched block
 #define CH_PIECE_BIG ( 1 << 27 )
 struct ChainPiece { int es, lo, hi, D; };      // exponent | sign << 8 it is made for; M -> M + D [+ tau: ptau / bptau] for lo <= M <= hi
@@ -3712,22 +3830,24 @@ __device__ __forceinline__ void chain_walk_row( const IcpLaunch& L, const ChainB
   if( chk && walker )
   {
     // the plain sum, 64 addends at a time, compared with what the walk had where each of its steps ended
-    float sp = 0.0f; int next = 0, bad = -1, bad_bits = 0;
+    float sp = 0.0f; int next = 0, bad = -1, bad_bits = 0, crossing = 0;
     for( int g = 0; g < B.n_seg; ++g )
     {
+      const uint32_t sp_was = __float_as_uint( sp );
       const int i = g * CH_SEG + lane;
       const float* rp = Rf + (size_t)min( i, L.src.n - 1 ) * ( REC_F4 * 4 );
       const float xr = addend_of( rp[3], rp[7], rp[comp], i < L.src.n );
 #pragma unroll
       for( int j = 0; j < CH_SEG; ++j ) sp = sp + __int_as_float( __builtin_amdgcn_readlane( __float_as_int( xr ), j ) );
       sp = __int_as_float( uni( __float_as_int( sp ) ) );
+      crossing += ( sp_was >> 23 ) != ( __float_as_uint( sp ) >> 23 ) ? 1 : 0;      // (segments that END in another binade than they start in: a lower bound of those that change binade)
       while( next < n_chk && chk[4 + 3 * next] <= g + 1 )
       {
         if( chk[4 + 3 * next] == g + 1 && bad < 0 && chk[4 + 3 * next + 1] != __float_as_int( sp ) ) { bad = next; bad_bits = __float_as_int( sp ); }
         ++next;
       }
     }
-    if( lane == 0 ) { chk[0] = n_chk; chk[1] = bad; chk[2] = bad_bits; chk[3] = __float_as_int( sp ); }
+    if( lane == 0 ) { chk[0] = n_chk; chk[1] = bad; chk[2] = bad < 0 ? crossing : bad_bits; chk[3] = __float_as_int( sp ); }
   }
   // A chain that wanders around zero — coordinates that straddle the origin, summed in an order that keeps cancelling — changes binade
   // not fifteen times but thousands of times, and every such segment is 64 dependent additions on this one wave: milliseconds.  The

@@ -225,6 +225,36 @@ def test_icp_batch_matches_single(capi, gscene, scene_clouds, estimator):
         capi.icp_reference_order_below(prev); capi.icp_replay_below(prev_r)
 
 
+def test_sequential_estimator_one_pass_statistics_and_centroids(capi, oracle, gscene, scene_clouds):
+    """k_icp_faithful sums the dist² statistics (lib/rs/icp.h:393-402) and the weighted centroids (:136-148) in ONE pass, the 2.5
+    sigma cut of the weights (:396-401) taken at a guess of sigma and checked afterwards.  Same bits as the three passes (switch
+    0) and as the oracle, with the stop test on; a guess that is wrong on purpose (cut scaled by 0.5 / 2: points between the two
+    cuts get the other weight) is caught by the check — the centroids are summed again (rs_hip_icp_faith_redone counts it) — and
+    returns the same bits too; the guess as made is never redone here."""
+    from rescan_amd import synth
+    clouds, objs = scene_clouds
+    rng = np.random.default_rng(23)
+    pts, nor = gscene["points"], gscene["normals"]
+    prev = capi.icp_faith_guess(-1)
+    try:
+        for k, o in enumerate(gscene["objects"]):
+            for trial in range(2):
+                T0 = synth.perturbed_pose(o["pose"], rng)
+                got = {}
+                for guess in (1000, 0, 500, 2000):
+                    capi.icp_faith_guess(guess)
+                    before = capi.icp_faith_redone()
+                    e, T, it = capi.icp_align(objs[k], clouds[0.1], T0, I4, 0.1, np.deg2rad(60.0))
+                    got[guess] = (np.float32(e).tobytes(), T.tobytes(), it, capi.icp_faith_redone() - before)
+                assert got[1000][:3] == got[0][:3] == got[500][:3] == got[2000][:3], (k, trial)
+                assert got[1000][3] == 0 and got[0][3] == 0, (k, trial, got[1000][3], got[0][3])
+                assert got[500][3] > 0 or got[2000][3] > 0, (k, trial)          # (no dist² between a cut and half / twice it: not on these clouds)
+                eo, To, ito = oracle.icp_align(o["pos"], o["nor"], pts, nor, T0, I4, 0.1, np.deg2rad(60.0))
+                assert To.tobytes() == got[1000][1] and np.float32(eo).tobytes() == got[1000][0] and ito == got[1000][2], (k, trial)
+    finally:
+        capi.icp_faith_guess(prev)
+
+
 def test_icp_multi_source_batch_matches_single(capi, oracle, gscene, scene_clouds):
     """rs_hip_icp_align_multi: the per-placement refine loop (lib/rs/rs_database.h:220-230 — a DIFFERENT source per problem) as one
     call.  Every problem's pose, error and iteration count are those of its own rs_hip_icp_align — and, the sources being
