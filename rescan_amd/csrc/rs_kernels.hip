@@ -3302,7 +3302,9 @@ struct ChainOne { int es, lo, hi, Dt; };       // a block record's function for 
 // kind = type | chunk << 2 | block in chunk << 5 | from (or the segment) << 11 | to << 17 | slot in S.xs << 24 (63: not fetched)
 enum { CH_IT_BLOCKS = 0, CH_IT_SEGS = 1, CH_IT_SEG = 2, CH_IT_BLOCK = 3 };       // a run of blocks, a run of segments, one segment, one whole block by its segments
 struct ChainItem { int es, lo, hi, D, tp, kind; };
-#define CH_ITEMS 192
+#ifndef CH_ITEMS
+#define CH_ITEMS 448                // (12 fetched blocks of at most 15 crossing segments and the 16 runs around them, the runs of blocks between)
+#endif
 __device__ __forceinline__ int chain_item_kind( int type, int c, int at, int from, int to, int slot ) { return type | ( c << 2 ) | ( at << 5 ) | ( from << 11 ) | ( to << 17 ) | ( slot << 24 ); }
 struct ChainWalkLds
 {
@@ -3328,6 +3330,13 @@ __device__ __forceinline__ bool chain_crosses( float a, float b, float eps )
   if( !( a * b > 0.0f ) ) return true;                   // zero, a sign change, NaN
   const float lo = fminf( fabsf( a ), fabsf( b ) ) * ( 1.0f - eps ), hi = fmaxf( fabsf( a ), fabsf( b ) ) * ( 1.0f + eps );
   return ( __float_as_uint( lo ) >> 23 ) != ( __float_as_uint( hi ) >> 23 );
+}
+// does the record's function hold a forecast value, give or take CH_EPS of it?  (f: the record for the forecast's binade)
+
+__device__ __forceinline__ bool chain_fits_forecast( const ChainFn& f, uint32_t vb )
+{
+  const int M = (int)( vb & 0x7fffffu ) | CH_M_LO, marg = (int)( CH_EPS * 8388608.0f );
+  return f.lo <= f.hi && M - marg >= f.lo && M + marg + max( f.tau & 3, f.tau >> 2 ) <= f.hi;
 }
 // (a forecast needs four digits, not sixteen: fp32 prefix sums, six DPP adds each)
 __device__ __forceinline__ float wave_scan_f32( float v ) { RS_DPP_PREFIX( "v_add_f32_dpp", v ); return v; }
@@ -3497,12 +3506,18 @@ __device__ __forceinline__ void chain_walk_row( const IcpLaunch& L, const ChainB
       const ChainFn f = rc[i].e_sign == -1 ? chain_never() : chain_fn_for( rc[i], vb );
       ChainOne one; one.es = (int)( vb >> 23 ); one.lo = f.lo; one.hi = f.hi; one.Dt = f.D * 16 + f.tau;
       S.ones[c * WAVE + lane] = one; S.bst[c * WAVE + lane] = st;
-      const unsigned long long m = RS_BALLOT( b < B.n_blk && ( b == 0 || chain_crosses( st, en, CH_EPS ) ) );
+      // a crossing block: the forecast changes binade between its ends — or its record does not hold the forecast (the chain leaves the
+      // binade INSIDE the block and is back at its end: a sum that hovers at a power of two does that block after block, and each such
+      // block, not forecast, cost a scan of its segments and a round trip per segment that did not fit)
+      const unsigned long long m = RS_BALLOT( b < B.n_blk && ( b == 0 || chain_crosses( st, en, CH_EPS ) || !chain_fits_forecast( f, vb ) ) );
       fm_mine[i] = m; st_mine[i] = st;
       // ... and the runs of blocks between the forecast's crossing blocks as one record each
-      const bool pieces = __builtin_popcountll( m ) < CH_PIECES;
-      if( lane == 0 ) { S.fmask[c] = m; S.bmode[c] = pieces ? 1 : 0; }
-      if( pieces ) chain_pieces( ( b >= B.n_blk || ( ( m >> lane ) & 1ull ) ) ? chain_identity() : f, (int)( vb >> 23 ), m, lane, &S.bpiece[c * WAVE], S.bptau[c] );
+      // (a round ends at its (CH_PRE_BLKS + 1)-th crossing block at the latest: the pieces beyond a chunk's first CH_PIECES - 1 crossing
+      //  blocks are never walked — a chunk with more of them used to be taken "whole, by scans": a round trip per segment that did not fit)
+      static_assert( CH_PRE_BLKS + 1 < CH_PIECES, "the pieces cover every block a round can reach" );
+      const unsigned long long mp = lowest_bits( m, CH_PIECES - 1 );
+      if( lane == 0 ) { S.fmask[c] = m; S.bmode[c] = 1; }
+      chain_pieces( ( b >= B.n_blk || ( ( mp >> lane ) & 1ull ) ) ? chain_identity() : f, (int)( vb >> 23 ), mp, lane, &S.bpiece[c * WAVE], S.bptau[c] );
     }
     __syncthreads();
     // ---- the blocks to fetch: the first CH_PRE_BLKS of those, in order — every lane knows its block's rank
@@ -3542,13 +3557,19 @@ __device__ __forceinline__ void chain_walk_row( const IcpLaunch& L, const ChainB
         const float incs = wave_scan_f32( sv[i] ), st0 = S.pst[k];
         const float vst = st0 + ( incs - sv[i] );
         const bool in = pb[i] >= 0 && pb[i] * CH_BLK + lane < B.n_seg;
-        const unsigned long long m = RS_BALLOT( in && chain_crosses( vst, st0 + incs, CH_EPS ) );
+        const uint32_t vb = __float_as_uint( vst );
+        const ChainFn fseg = in ? chain_fn_for( got[i], vb ) : chain_identity();
+        const unsigned long long m = RS_BALLOT( in && ( chain_crosses( vst, st0 + incs, CH_EPS ) || !chain_fits_forecast( fseg, vb ) ) );      // (as for the blocks)
         const bool pieces = pb[i] >= 0 && __builtin_popcountll( m ) < CH_PIECES;
-        if( lane == 0 ) { S.flag[k] = m; S.mode[k] = pieces ? 1 : 0; }
+        // (a block of 16 crossing segments or more — a chain's first block when the coordinates straddle the origin — is walked by scans
+        //  of its records, its segments' addends fetched on the way: it takes none of the round's fetch slots — it used to take them all, and
+        //  every later crossing segment of the round then went without.  Loading such a block's 4 096 addends in one go was built too:
+        //  the centred bench step 3.84 instead of 3.89 ms — and 15 us per iteration MORE on scans in one octant, which never run that
+        //  code: the walk is one wave's instruction stream, and it got longer)
+        if( lane == 0 ) { S.flag[k] = pieces ? m : 0ull; S.mode[k] = pieces ? 1 : 0; }
         if( pieces )
         {
-          const uint32_t vb = __float_as_uint( vst );
-          const ChainFn f0 = ( !in || ( ( m >> lane ) & 1ull ) ) ? chain_identity() : chain_fn_for( got[i], vb );
+          const ChainFn f0 = ( !in || ( ( m >> lane ) & 1ull ) ) ? chain_identity() : fseg;
           chain_pieces( f0, (int)( vb >> 23 ), m, lane, S.piece[k], S.ptau[k] );
         }
       }
