@@ -14,8 +14,8 @@ for t in (0, 1):
 synth.write_class_table("classes.rsdb")
 PY
 "$ROOT/oracle/_ref/seg2rsdb" seq/t0.ply classes.rsdb seq/t0.rsdb > /dev/null 2>&1 || true
-for b in pose_proposal pose_proposal_hip2; do
+for b in pose_proposal_hip2 pose_proposal_hip3; do
   echo "== $b"
-  RS_DROPIN_STATS=1 "$ROOT/oracle/_ref/$b" seq/t0.rsdb seq/t1.ply seq/t1_$b.rsdb -v 2> stats_$b.txt | grep -i "computed poses\|processing time\|IO: Done\|Read a scene\|pose proposals made" || true
+  RS_DROPIN_STATS=1 "$ROOT/oracle/_ref/$b" seq/t0.rsdb seq/t1.ply seq/t1_$b.rsdb -v 2> stats_$b.txt | grep -i "computed poses\|processing time\|IO: Done\|Read a scene\|pose proposals made\|Done in\|ICP\|refin\|time" || true
   grep stats stats_$b.txt || true
 done
