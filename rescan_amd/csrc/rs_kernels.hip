@@ -268,10 +268,13 @@ __device__ __forceinline__ void axis_range( float lo, float hi, float r, float g
 {
   float a = floorf( ( lo - r - gmin ) * inv_cell - 0.01f );
   float b = floorf( ( hi + r - gmin ) * inv_cell + 0.01f );
-  a = fmaxf( a, 0.0f );
-  b = fminf( b, (float)( dim - 1 ) );
+  // (clamped to the grid as INTEGERS: as floats the three dim - 1 are wave-uniform values that live in vector registers across every
+  //  search loop — three of the eleven registers k_score spilled; the literals below are encoded in their instructions)
+  a = fminf( fmaxf( a, 0.0f ), 16777216.0f );
+  b = fminf( fmaxf( b, -1.0f ), 16777216.0f );
   c0 = (int)a;
-  c1 = ( b >= a ) ? (int)b : -1;      // empty -> c1 < c0
+  const int bi = min( (int)b, dim - 1 );
+  c1 = ( bi >= c0 ) ? bi : -1;        // empty -> c1 < c0
 }
 
 struct TileBounds { float lx, hx, ly, hy, lz, hz; bool any; };
@@ -1561,7 +1564,7 @@ __global__ __launch_bounds__( PA_WAVES * WAVE, BOUNDED_ONLY ? RS_ICP_WARM_OCC : 
   if( L.active[prob] == 0 ) return;
   icp_bind( L, prob );
   const int lane = threadIdx.x & ( WAVE - 1 );
-  const int wib = threadIdx.x / WAVE;
+  const int wib = PA_WAVES == 1 ? 0 : uni( (int)threadIdx.x / WAVE );
   EvalScope eval_scope( L.tgt.evals, lds[wib], lane );
   // Slowest first: the kernel ends when its slowest tile does, and the slow tiles (several shells, a rank
   // pass) are the same from one iteration to the next.  The previous iteration listed them; the first
@@ -4020,7 +4023,7 @@ __global__ __launch_bounds__( SC_WAVES * WAVE, RB ? RS_SCORE_ROWS_OCC : RS_SCORE
   __shared__ Lds lds[SC_WAVES];
   const int pose = blockIdx.y;
   const int lane = threadIdx.x & ( WAVE - 1 );
-  const int wib = threadIdx.x / WAVE;
+  const int wib = SC_WAVES == 1 ? 0 : uni( (int)threadIdx.x / WAVE );      // (told to be uniform: as threadIdx.x / 64 the tile's number lived in a vector register pair for the whole kernel)
   EvalScope eval_scope( L.scene.evals, lds[wib], lane );
   const int tile = blockIdx.x * SC_WAVES + wib;
   if( tile >= L.obj.n_tiles ) return;
