@@ -2443,6 +2443,53 @@ __device__ __forceinline__ void replay_terms( const IcpLaunch& L, int prob, int 
 }
 static_assert( REPLAY_PITCH == FAITH_PITCH, "replay_terms reuses faith_terms' LDS layout" );
 
+// ONE accumulator's addend of one correspondence — the expressions of faith_terms<PASS>, row by row (the walk re-adds a segment of ONE
+// row: producing all 35 rows' addends for it, as the kernels above do, was most of what a re-added segment cost)
+template <int PASS>
+__device__ __forceinline__ float faith_term_one( const FaithRec& r, const FaithPar& P, int row /* uniform */ )
+{
+  const bool m = r.v[0] >= 0.0f;
+  if( PASS == 1 ) return row == 0 ? ( m ? r.v[0] : 0.0f ) : ( row == 1 ? ( m ? r.v[0] * r.v[0] : 0.0f ) : ( m ? 1.0f : 0.0f ) );
+  if( PASS == 2 )
+  {
+    const float w = m ? faith_weight( r, P ) : 0.0f;
+    if( row == 0 ) return w;
+    const float v = row == 1 ? r.v[2] : row == 2 ? r.v[3] : row == 3 ? r.v[4] : row == 4 ? r.v[5] : row == 5 ? r.v[6] : r.v[7];
+    return m ? v * w : 0.0f;
+  }
+  if( !m ) return 0.0f;
+  const float wi = faith_weight( r, P );
+  if( row == 34 ) return wi;
+  const float p[3] = { r.v[2] - P.c1[0], r.v[3] - P.c1[1], r.v[4] - P.c1[2] };
+  const float q[3] = { r.v[5] - P.c2[0], r.v[6] - P.c2[1], r.v[7] - P.c2[2] };
+  const float nv[3] = { r.v[8], r.v[9], r.v[10] };
+  const float d[3] = { p[0] - q[0], p[1] - q[1], p[2] - q[2] };
+  const float cv[3] = { p[1] * nv[2] - p[2] * nv[1], p[2] * nv[0] - p[0] * nv[2], p[0] * nv[1] - p[1] * nv[0] };
+  const float sd = d[0] * nv[0] + d[1] * nv[1] + d[2] * nv[2];
+  auto pick = []( const float ( &x )[3], int k ) -> float { return k == 0 ? x[0] : ( k == 1 ? x[1] : x[2] ); };
+  if( row < 27 )
+  {
+    const int blk = row / 9, in = row % 9, col = in / 3, rw = in % 3;
+    const float a = blk == 2 ? pick( nv, rw ) : pick( cv, rw );              // cv cv | cv nv | nv nv
+    const float b = blk == 0 ? pick( cv, col ) : pick( nv, col );
+    return ( a * b ) * wi;                                                 // icp.h:239-241
+  }
+  if( row < 30 ) return wi * pick( cv, row - 27 ) * sd;                     // icp.h:242-247
+  if( row < 33 ) return wi * pick( nv, row - 30 ) * sd;
+  return wi * sd * sd;                                                     // icp.h:249
+}
+template <int PASS>
+__device__ __forceinline__ void replay_term_row( const IcpLaunch& L, int prob, int g, const FaithPar& P, float ( *term )[REPLAY_PITCH], int row )
+{
+  const int n = L.src.n;
+  const float* F = L.faith + (size_t)prob * FAITH_REC * n;
+  for( int t = threadIdx.x; t < REPLAY_SEG; t += blockDim.x )
+  {
+    FaithRec r; faith_load( F, n, g * REPLAY_SEG + t, r );
+    term[row][t] = faith_term_one<PASS>( r, P, row );
+  }
+}
+
 template <int PASS>
 __global__ __launch_bounds__( REPLAY_SEG ) void k_replay_sums( IcpLaunch L, ReplayBufs B )
 {
@@ -2731,6 +2778,9 @@ __device__ __forceinline__ T replay_walk_row( const IcpLaunch& L, const ReplayBu
   const ReplaySeg* sups = B.super + ( (size_t)prob * ICP_NMOM + row ) * B.n_super;
   U sb = 0;                                             // the running value's bits (uniform): +0
   int redone = 0;
+  // (Fetching superblock S + 1's segment records while S is walked — they do not depend on the value — was tried for the chains that fit
+  //  none of their superblocks' composed records: 1 028 instead of 970 us per iteration on the centred 1.15 M-point scans, 640 instead of
+  //  628 at 84 k points: the fetch and its 60 instructions of unpacking are then paid at EVERY superblock.)
   for( int s0 = 0; s0 < B.n_super; s0 += WAVE )
   {
     ReplayLaneRec<T> sup; sup.clear();                  // lane l: superblock s0 + l
@@ -2749,7 +2799,7 @@ __device__ __forceinline__ T replay_walk_row( const IcpLaunch& L, const ReplayBu
         // re-add the segment's addends one after the other (uniform over the wave: the value and the record are)
         ++redone;
         __syncthreads();                                // (one wave per block: orders the reuse of `term`)
-        replay_terms<PASS>( L, prob, g0 + j, P, term );
+        replay_term_row<PASS>( L, prob, g0 + j, P, term, row );
         __syncthreads();
         T acc = Bits<T>::from( sb );
         const float4* row4 = reinterpret_cast<const float4*>( term[row] );

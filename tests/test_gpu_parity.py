@@ -236,6 +236,7 @@ def test_sequential_estimator_one_pass_statistics_and_centroids(capi, oracle, gs
     rng = np.random.default_rng(23)
     pts, nor = gscene["points"], gscene["normals"]
     prev = capi.icp_faith_guess(-1)
+    prev_ro = capi.icp_reference_order_below(65536)         # (the sequential estimator, whatever RS_HIP_REF_ORDER_BELOW the suite runs under)
     try:
         for k, o in enumerate(gscene["objects"]):
             for trial in range(2):
@@ -252,7 +253,7 @@ def test_sequential_estimator_one_pass_statistics_and_centroids(capi, oracle, gs
                 eo, To, ito = oracle.icp_align(o["pos"], o["nor"], pts, nor, T0, I4, 0.1, np.deg2rad(60.0))
                 assert To.tobytes() == got[1000][1] and np.float32(eo).tobytes() == got[1000][0] and ito == got[1000][2], (k, trial)
     finally:
-        capi.icp_faith_guess(prev)
+        capi.icp_faith_guess(prev); capi.icp_reference_order_below(prev_ro)
 
 
 def test_icp_multi_source_batch_matches_single(capi, oracle, gscene, scene_clouds):
