@@ -2510,31 +2510,34 @@ __global__ __launch_bounds__( REPLAY_SEG ) void k_replay_sums( IcpLaunch L, Repl
   }
 }
 
-// exclusive prefix over the segments, per accumulator: the guesses (as the accumulator's own type: float rows, double rows)
+// exclusive prefix over the segments, per accumulator: the guesses (as the accumulator's own type: float rows, double rows).  One
+// workgroup per accumulator: every thread a contiguous run of segments, the runs' totals scanned through LDS (any association will
+// do: this is a guess).  (One wave looping over the segments 64 at a time took 76 us on a 1.15 M-point scan's 9 007 segments.)
+#define REPLAY_SCAN_THREADS 256
 template <int PASS>
-__global__ __launch_bounds__( WAVE ) void k_replay_scan( IcpLaunch L, ReplayBufs B )
+__global__ __launch_bounds__( REPLAY_SCAN_THREADS ) void k_replay_scan( IcpLaunch L, ReplayBufs B )
 {
+  __shared__ double part[REPLAY_SCAN_THREADS];
   const int prob = blockIdx.y, row = blockIdx.x;
   if( L.active[prob] == 0 ) return;
-  const int lane = threadIdx.x;
+  const int t = threadIdx.x;
   const double* in = B.segsum + ( (size_t)prob * ICP_NMOM + row ) * B.n_seg;
   double* out = B.guess + ( ( (size_t)prob * 3 + ( PASS - 1 ) ) * ICP_NMOM + row ) * B.n_seg;
-  double carry = 0.0;
-  for( int g0 = 0; g0 < B.n_seg; g0 += WAVE )
+  const int per = ( B.n_seg + REPLAY_SCAN_THREADS - 1 ) / REPLAY_SCAN_THREADS;
+  const int g0 = min( t * per, B.n_seg ), g1 = min( g0 + per, B.n_seg );
+  double sum = 0.0;
+  for( int g = g0; g < g1; ++g ) sum += in[g];
+  part[t] = sum;
+  __syncthreads();
+  for( int d = 1; d < REPLAY_SCAN_THREADS; d <<= 1 )       // inclusive scan of the runs' totals
   {
-    const int g = g0 + lane;
-    double v = g < B.n_seg ? in[g] : 0.0;
-    // inclusive scan over the 64 lanes (any association will do: this is a guess)
-    double incl = v;
-#pragma unroll
-    for( int d = 1; d < WAVE; d <<= 1 )
-    {
-      const double up = __shfl_up( incl, d );
-      if( lane >= d ) incl += up;
-    }
-    if( g < B.n_seg ) out[g] = carry + ( incl - v );
-    carry += __shfl( incl, WAVE - 1 );
+    const double up = t >= d ? part[t - d] : 0.0;
+    __syncthreads();
+    part[t] += up;
+    __syncthreads();
   }
+  double carry = part[t] - sum;                            // what the runs before this one add
+  for( int g = g0; g < g1; ++g ) { out[g] = carry; carry += in[g]; }
 }
 
 // one accumulator type: the bit-level view of fp32 / fp64 the replay needs
@@ -2872,7 +2875,7 @@ static void launch_replay_pass( const IcpLaunch& L, const ReplayBufs& B, hipStre
 {
   constexpr int NR = ReplayRows<PASS>::NF + ReplayRows<PASS>::ND;
   hipLaunchKernelGGL( k_replay_sums<PASS>, dim3( B.n_seg, L.n_prob ), dim3( REPLAY_SEG ), 0, st, L, B );
-  hipLaunchKernelGGL( k_replay_scan<PASS>, dim3( NR, L.n_prob ), dim3( WAVE ), 0, st, L, B );
+  hipLaunchKernelGGL( k_replay_scan<PASS>, dim3( NR, L.n_prob ), dim3( REPLAY_SCAN_THREADS ), 0, st, L, B );
   hipLaunchKernelGGL( k_replay_run<PASS>, dim3( B.n_seg, L.n_prob ), dim3( REPLAY_RUN_THREADS ), 0, st, L, B );
   hipLaunchKernelGGL( k_replay_compose<PASS>, dim3( B.n_super, ( NR + REPLAY_COMPOSE_ROWS - 1 ) / REPLAY_COMPOSE_ROWS, L.n_prob ), dim3( WAVE ), 0, st, L, B );
   hipLaunchKernelGGL( k_replay_walk<PASS>, dim3( NR, L.n_prob ), dim3( WAVE ), 0, st, L, B );
