@@ -897,10 +897,16 @@ int icp_align_batch_impl( const rs_hip_cloud_t* source, const rs_hip_cloud_t* ta
   ReplayBufs RB{};
   ChainBufs CB{};
   const bool chains = exact_centroids && centroid_mode == 1;      // (2: the same sums through pass 2 of the replay — the cross-check, and what a problem the chains give up is run with)
+  // (2 reads the searches' records like the chains do — RS_HIP_REPLAY2_GATHER=1: from k_icp_faith_gather's arrays, as up to round 3)
+  static const bool replay2_gather = getenv( "RS_HIP_REPLAY2_GATHER" ) != nullptr;
+  const bool from_records = exact_centroids && !chains && !replay2_gather;
   if( ref_order || replay || ( exact_centroids && !chains ) )
   {
-    if( ( rc = g_ws.faith.ensure( (size_t)n * FAITH_REC * (size_t)source->n * 4 ) ) ) return rc;
-    cx.L.faith = g_ws.faith.as<float>();
+    if( !from_records )
+    {
+      if( ( rc = g_ws.faith.ensure( (size_t)n * FAITH_REC * (size_t)source->n * 4 ) ) ) return rc;
+      cx.L.faith = g_ws.faith.as<float>();
+    }
     if( ( replay || exact_centroids ) && ( rc = replay_prepare( RB, n, source->n ) ) ) return rc;
   }
   if( chains )
@@ -936,6 +942,18 @@ int icp_align_batch_impl( const rs_hip_cloud_t* source, const rs_hip_cloud_t* ta
     cx.L.rec = (float4*)g_ws.ch_rec.p;
     cx.L.n_mom_blocks = CB.n_blk * 4;              // k_chain_moments: one workgroup, one partial, per quarter block (1 024 source points)
     if( ( rc = g_ws.mom_part.ensure( (size_t)n * CB.n_blk * 4 * ICP_NMOM * 8 ) ) ) return rc;
+    cx.L.mom_part = g_ws.mom_part.as<double>();
+  }
+  if( from_records )
+  {
+    // the searches' records, the chains' moment kernel and update (launch_icp_exact_centroids_from_records)
+    CB.n_seg = chain_segments( source->n ); CB.n_blk = chain_blocks( source->n ); CB.refresh = 0;
+    if( ( rc = g_ws.ch_rec.ensure( (size_t)n * (size_t)source->n * REC_F4 * 16 ) ) || ( rc = g_ws.ch_done.ensure( (size_t)n * 8 ) ) ||
+        ( rc = g_ws.mom_part.ensure( (size_t)n * CB.n_blk * 4 * ICP_NMOM * 8 ) ) ) return rc;
+    HIP_TRY( hipMemsetAsync( g_ws.ch_done.p, 0, (size_t)n * 8, g_stream ), RS_HIP_E_RUNTIME );
+    CB.done = g_ws.ch_done.as<int>();
+    cx.L.rec = (float4*)g_ws.ch_rec.p;
+    cx.L.n_mom_blocks = CB.n_blk * 4;
     cx.L.mom_part = g_ws.mom_part.as<double>();
   }
   if( !ref_order && !replay )
@@ -999,6 +1017,7 @@ int icp_align_batch_impl( const rs_hip_cloud_t* source, const rs_hip_cloud_t* ta
         CB.refresh = ( i == 0 || ( chain_refresh > 0 && ( i % chain_refresh ) == 0 ) ) ? 1 : 0;
         launch_icp_chain_centroids( cx.L, CB, g_stream );
       }
+      else if( from_records ) launch_icp_exact_centroids_from_records( cx.L, RB, CB, g_stream );
       else if( exact_centroids ) launch_icp_exact_centroids( cx.L, RB, g_stream );
       else if( cx.L.faith ) launch_icp_faithful( cx.L, g_stream ); else launch_icp_moments( cx.L, g_stream );
       double nd = max_dist * 0.95;                                      // icp.h:493

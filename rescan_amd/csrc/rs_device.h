@@ -187,6 +187,7 @@ struct ReplayBufs
 void   launch_icp_replay( const IcpLaunch& L, const ReplayBufs& B, hipStream_t st );
 // fp64 moments + the reference's own fp32 chains for Σw, Σw·p, Σw·q (pass 2 of the replay) + solve with those centroids
 void   launch_icp_exact_centroids( const IcpLaunch& L, const ReplayBufs& B, hipStream_t st );
+void   launch_icp_exact_centroids_from_records( const IcpLaunch& L, const ReplayBufs& B, const ChainBufs& C, hipStream_t st );
 int    replay_segments( int n_source );
 int    replay_superblocks( int n_source );
 size_t replay_seg_bytes();

@@ -2429,15 +2429,30 @@ __device__ __forceinline__ bool replay_params( const IcpLaunch& L, int prob, int
   return true;
 }
 
+// One correspondence as the estimators' kernels take it: from k_icp_faith_gather's arrays — or, where the searches left their 48-byte
+// records at the points' ORIGINAL indices (whole scans: the centroid sums by pass 2 here, when the grid chains give a scan up), straight
+// from those: the same eleven numbers, without the gather launch (117 us at a million points).
+template <int PASS>
+__device__ __forceinline__ void replay_load( const IcpLaunch& L, int prob, int i, FaithRec& r )
+{
+  const int n = L.src.n;
+  if( !L.rec ) { faith_load( L.faith + (size_t)prob * FAITH_REC * n, n, i, r ); return; }
+  r.v[0] = -1.0f;
+  if( i < n )
+  {
+    const float4* R = L.rec + ( (size_t)prob * n + i ) * REC_F4;
+    const float4 a = R[0], b = R[1];
+    r.v[0] = a.w; r.v[1] = b.w; r.v[2] = a.x; r.v[3] = a.y; r.v[4] = a.z; r.v[5] = b.x; r.v[6] = b.y; r.v[7] = b.z;
+    if( PASS == 3 ) { const float4 c = R[2]; r.v[8] = c.x; r.v[9] = c.y; r.v[10] = c.z; } else { r.v[8] = r.v[9] = r.v[10] = 0.0f; }
+  }
+}
 // the addends of segment g for pass PASS, into term[row][t] (all rows of the pass, 128 columns; columns past the cloud hold +0)
 template <int PASS>
 __device__ __forceinline__ void replay_terms( const IcpLaunch& L, int prob, int g, const FaithPar& P, float ( *term )[REPLAY_PITCH] )
 {
-  const int n = L.src.n;
-  const float* F = L.faith + (size_t)prob * FAITH_REC * n;
   for( int t = threadIdx.x; t < REPLAY_SEG; t += blockDim.x )
   {
-    FaithRec r; faith_load( F, n, g * REPLAY_SEG + t, r );
+    FaithRec r; replay_load<PASS>( L, prob, g * REPLAY_SEG + t, r );
     faith_terms<PASS>( r, P, reinterpret_cast<float ( * )[FAITH_PITCH]>( term ), t );
   }
 }
@@ -2481,11 +2496,9 @@ __device__ __forceinline__ float faith_term_one( const FaithRec& r, const FaithP
 template <int PASS>
 __device__ __forceinline__ void replay_term_row( const IcpLaunch& L, int prob, int g, const FaithPar& P, float ( *term )[REPLAY_PITCH], int row )
 {
-  const int n = L.src.n;
-  const float* F = L.faith + (size_t)prob * FAITH_REC * n;
   for( int t = threadIdx.x; t < REPLAY_SEG; t += blockDim.x )
   {
-    FaithRec r; faith_load( F, n, g * REPLAY_SEG + t, r );
+    FaithRec r; replay_load<PASS>( L, prob, g * REPLAY_SEG + t, r );
     term[row][t] = faith_term_one<PASS>( r, P, row );
   }
 }
@@ -3989,6 +4002,14 @@ void launch_icp_chain_centroids( const IcpLaunch& L, const ChainBufs& B, hipStre
   hipLaunchKernelGGL( k_icp_update_wide, dim3( ICP_NMOM, L.n_prob ), dim3( BLOCK ), 0, st, L, B.done );                // (centred on the chains' totals: L.exact_centroids)
 }
 
+// The same from the searches' records (L.rec: the grid chains' own inputs — what a scan the chains give up is run with): the fp64
+// moments by the chains' moment kernel (n, mean, stddev into L.res), pass 2 of the replay reading the records, the chains' update.
+void launch_icp_exact_centroids_from_records( const IcpLaunch& L, const ReplayBufs& B, const ChainBufs& C, hipStream_t st )
+{
+  hipLaunchKernelGGL( k_chain_moments, dim3( C.n_blk * CH_QUARTERS, L.n_prob ), dim3( BLOCK ), 0, st, L, C );          // (L.n_mom_blocks == 4 C.n_blk)
+  launch_replay_pass<2>( L, B, st );
+  hipLaunchKernelGGL( k_icp_update_wide, dim3( ICP_NMOM, L.n_prob ), dim3( BLOCK ), 0, st, L, C.done );
+}
 int replay_segments( int n_source ) { return ( n_source + REPLAY_SEG - 1 ) / REPLAY_SEG; }
 int replay_superblocks( int n_source ) { return ( replay_segments( n_source ) + REPLAY_SUPER - 1 ) / REPLAY_SUPER; }
 size_t replay_seg_bytes() { return sizeof( ReplaySeg ); }
