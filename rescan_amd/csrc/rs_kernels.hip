@@ -2569,12 +2569,19 @@ template <> struct Bits<double>
 };
 
 // the chain of one (accumulator, segment, class)
+// (fp32 rows keep their shift bounds in 32-bit integers: a value that RISES more than 7 binades inside one segment makes the record
+//  unusable — the walk re-adds that segment — where the 64-bit form allowed 20; the loop is bound by instruction issue, and 64-bit
+//  compares, selects and shifts were most of its ~40 instructions per addend)
+template <class T> struct ReplayRunInt;
+template <> struct ReplayRunInt<float>  { typedef int W; enum { KUP = 7 }; };
+template <> struct ReplayRunInt<double> { typedef long long W; enum { KUP = 8 }; };
 template <class T>
 __device__ __forceinline__ void replay_run_chain( const float* row, double guess, int c, ReplaySeg& out )
 {
   typedef typename Bits<T>::U U;
+  typedef typename ReplayRunInt<T>::W W;
   constexpr int MB = Bits<T>::MBITS, EB = 8 * sizeof(T) - 1 - MB;
-  constexpr int KMAX = MB == 23 ? 20 : 8;                       // (shifted mantissas must fit 63 bits)
+  constexpr int KUP = ReplayRunInt<T>::KUP, KDN = MB == 23 ? 20 : 8;      // (shifted mantissas must fit W)
   const U mmask = ( (U)1 << MB ) - 1, emax = ( (U)1 << EB ) - 1;
   const T gT = (T)guess;
   const U gb = Bits<T>::of( gT ) & ~(U)( REPLAY_CLS - 1 );
@@ -2583,8 +2590,8 @@ __device__ __forceinline__ void replay_run_chain( const float* row, double guess
   if( c == 0 ) { out.start = (unsigned long long)gb; out.pad = 0ull; }
   const U sb = gb | (U)c;
   T acc = Bits<T>::from( sb );
-  const long long m0 = (long long)( sb & mmask );
-  long long dmin = 1 - m0, dmax = (long long)mmask - 1 - m0;
+  const W m0 = (W)( sb & mmask );
+  W dmin = 1 - m0, dmax = (W)mmask - 1 - m0;
   int need_k = 0, k = 0;
   bool valid = usable;
   for( int t = 0; t < REPLAY_SEG; ++t )
@@ -2593,21 +2600,21 @@ __device__ __forceinline__ void replay_run_chain( const float* row, double guess
     const U b = Bits<T>::of( acc );
     const int e = (int)( ( b >> MB ) & emax );
     k = e - e0;
-    valid = valid && !( ( b ^ sb ) >> ( 8 * sizeof(T) - 1 ) ) && e != 0 && e != (int)emax && k <= KMAX && k >= -KMAX;
+    valid = valid && !( ( b ^ sb ) >> ( 8 * sizeof(T) - 1 ) ) && e != 0 && e != (int)emax && k <= KUP && k >= -KDN;
     const int kk = valid ? k : 0;                              // (keeps the shifts below defined once the chain is lost)
-    const long long M = (long long)( b & mmask );
-    long long lo = 1 - M, hi = (long long)mmask - 1 - M;       // allowed shift of this value, in its own binade's grid steps
-    if( kk >= 0 ) { lo *= ( 1ll << kk ); hi *= ( 1ll << kk ); need_k = kk > need_k ? kk : need_k; }
+    const W M = (W)( b & mmask );
+    W lo = 1 - M, hi = (W)mmask - 1 - M;                       // allowed shift of this value, in its own binade's grid steps
+    if( kk >= 0 ) { lo *= ( (W)1 << kk ); hi *= ( (W)1 << kk ); need_k = kk > need_k ? kk : need_k; }
     else
     {
-      const int sh = -kk; const long long rnd = ( 1ll << sh ) - 1;
+      const int sh = -kk; const W rnd = ( (W)1 << sh ) - 1;
       lo = lo >= 0 ? ( ( lo + rnd ) >> sh ) : -( ( -lo ) >> sh );          // ceil( lo / 2^sh )
       hi = hi >= 0 ? ( hi >> sh ) : -( ( -hi + rnd ) >> sh );              // floor( hi / 2^sh )
     }
     dmin = lo > dmin ? lo : dmin; dmax = hi < dmax ? hi : dmax;
   }
   ReplayCls r;
-  r.dmin = valid ? dmin : 1; r.dmax = valid ? dmax : 0;
+  r.dmin = valid ? (long long)dmin : 1; r.dmax = valid ? (long long)dmax : 0;
   r.end = (unsigned long long)Bits<T>::of( acc );
   r.need_k = need_k; r.k_end = valid ? k : 0;
   out.cls[c] = r;
