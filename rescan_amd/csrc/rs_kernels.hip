@@ -2436,6 +2436,8 @@ template <int PASS>
 __device__ __forceinline__ void replay_load( const IcpLaunch& L, int prob, int i, FaithRec& r )
 {
   const int n = L.src.n;
+#pragma unroll
+  for( int k = 0; k < FAITH_REC; ++k ) r.v[k] = 0.0f;
   if( !L.rec ) { faith_load( L.faith + (size_t)prob * FAITH_REC * n, n, i, r ); return; }
   r.v[0] = -1.0f;
   if( i < n )
@@ -2443,7 +2445,7 @@ __device__ __forceinline__ void replay_load( const IcpLaunch& L, int prob, int i
     const float4* R = L.rec + ( (size_t)prob * n + i ) * REC_F4;
     const float4 a = R[0], b = R[1];
     r.v[0] = a.w; r.v[1] = b.w; r.v[2] = a.x; r.v[3] = a.y; r.v[4] = a.z; r.v[5] = b.x; r.v[6] = b.y; r.v[7] = b.z;
-    if( PASS == 3 ) { const float4 c = R[2]; r.v[8] = c.x; r.v[9] = c.y; r.v[10] = c.z; } else { r.v[8] = r.v[9] = r.v[10] = 0.0f; }
+    if( PASS == 3 ) { const float4 c = R[2]; r.v[8] = c.x; r.v[9] = c.y; r.v[10] = c.z; }      // (the target's normal: the normal equations' alone)
   }
 }
 // the addends of segment g for pass PASS, into term[row][t] (all rows of the pass, 128 columns; columns past the cloud hold +0)
@@ -2746,22 +2748,29 @@ __device__ __forceinline__ unsigned long long first_lane( unsigned long long v )
   return ( (unsigned long long)hi << 32 ) | lo;
 }
 
-// one lane's record, compact and typed, for the scalar walk
+// one lane's record, compact and typed, for the scalar walk.  Per class the tests are prepared as whole-word bounds — the value's sign,
+// exponent and mantissa together: lo <= value <= hi holds the exponent / sign match and the interval of the shift at once — so that a
+// step of the walk is five register reads and a dozen scalar instructions.
 template <class T> struct ReplayLaneRec
 {
   typedef typename Bits<T>::U U; typedef typename ReplayFields<T>::I I;
-  U start; I dmin[REPLAY_CLS], dmax[REPLAY_CLS]; U end[REPLAY_CLS]; int meta[REPLAY_CLS];
-  __device__ __forceinline__ void clear() { start = 0; for( int c = 0; c < REPLAY_CLS; ++c ) { dmin[c] = 1; dmax[c] = 0; end[c] = 0; meta[c] = 64 << 8; } }
+  U lo[REPLAY_CLS], hi[REPLAY_CLS], base[REPLAY_CLS], end[REPLAY_CLS]; int meta[REPLAY_CLS];
+  __device__ __forceinline__ void clear() { for( int c = 0; c < REPLAY_CLS; ++c ) { lo[c] = 1; hi[c] = 0; base[c] = 0; end[c] = 0; meta[c] = 64 << 8; } }
   __device__ __forceinline__ void load( const ReplaySeg& q )
   {
+    const U mmask = ( (U)1 << Bits<T>::MBITS ) - 1;
     const long long clampv = 1ll << ( Bits<T>::MBITS + 2 );       // |delta| < 2^MBITS: bounds beyond that say nothing
-    start = (U)q.start;
+    const U st = (U)q.start, top = st & ~mmask;
 #pragma unroll
     for( int c = 0; c < REPLAY_CLS; ++c )
     {
-      const long long lo = q.cls[c].dmin, hi = q.cls[c].dmax;
-      dmin[c] = (I)( lo < -clampv ? -clampv : ( lo > clampv ? clampv : lo ) );
-      dmax[c] = (I)( hi < -clampv ? -clampv : ( hi > clampv ? clampv : hi ) );
+      const long long dlo = q.cls[c].dmin, dhi = q.cls[c].dmax;
+      const long long bm = (long long)( ( st & mmask ) | (U)c );                                   // the class start's mantissa
+      long long l = bm + ( dlo < -clampv ? -clampv : ( dlo > clampv ? clampv : dlo ) ), h = bm + ( dhi < -clampv ? -clampv : ( dhi > clampv ? clampv : dhi ) );
+      l = l < 0 ? 0 : l; h = h > (long long)mmask ? (long long)mmask : h;
+      const bool never = dhi < dlo || l > h;
+      lo[c] = never ? (U)1 : ( top | (U)l ); hi[c] = never ? (U)0 : ( top | (U)h );
+      base[c] = top | (U)bm;
       end[c] = (U)q.cls[c].end;
       meta[c] = q.cls[c].need_k | ( ( q.cls[c].k_end + 64 ) << 8 );
     }
@@ -2770,19 +2779,18 @@ template <class T> struct ReplayLaneRec
   __device__ __forceinline__ bool apply( int j, U& sb ) const
   {
     const U mmask = ( (U)1 << Bits<T>::MBITS ) - 1;
-    const U st = rl( start, j );
     const int c = (int)( sb & ( REPLAY_CLS - 1 ) );
-    I lo, hi; U eb; int m;
+    U l, h, bs, eb; int m;
     switch( c )                                          // (uniform)
     {
-      case 0:  lo = rl( dmin[0], j ); hi = rl( dmax[0], j ); eb = rl( end[0], j ); m = rl( meta[0], j ); break;
-      case 1:  lo = rl( dmin[1], j ); hi = rl( dmax[1], j ); eb = rl( end[1], j ); m = rl( meta[1], j ); break;
-      case 2:  lo = rl( dmin[2], j ); hi = rl( dmax[2], j ); eb = rl( end[2], j ); m = rl( meta[2], j ); break;
-      default: lo = rl( dmin[3], j ); hi = rl( dmax[3], j ); eb = rl( end[3], j ); m = rl( meta[3], j ); break;
+      case 0:  l = rl( lo[0], j ); h = rl( hi[0], j ); bs = rl( base[0], j ); eb = rl( end[0], j ); m = rl( meta[0], j ); break;
+      case 1:  l = rl( lo[1], j ); h = rl( hi[1], j ); bs = rl( base[1], j ); eb = rl( end[1], j ); m = rl( meta[1], j ); break;
+      case 2:  l = rl( lo[2], j ); h = rl( hi[2], j ); bs = rl( base[2], j ); eb = rl( end[2], j ); m = rl( meta[2], j ); break;
+      default: l = rl( lo[3], j ); h = rl( hi[3], j ); bs = rl( base[3], j ); eb = rl( end[3], j ); m = rl( meta[3], j ); break;
     }
-    const I d = (I)( sb & mmask ) - (I)( ( st & mmask ) | (U)c );                           // a multiple of 4
+    const I d = (I)( sb - bs );                                                               // (same sign and exponent where it counts: the mantissas' difference, a multiple of 4)
     const int need_k = m & 255, k_end = ( m >> 8 ) - 64;
-    const bool ok = ( ( sb ^ st ) & ~mmask ) == 0 && d >= lo && d <= hi && ( d & ( ( (I)2 << need_k ) - 1 ) ) == 0;
+    const bool ok = sb >= l && sb <= h && ( d & ( ( (I)2 << need_k ) - 1 ) ) == 0;
     if( ok )
     {
       const I adv = k_end >= 0 ? ( d >> k_end ) : d * ( (I)1 << -k_end );
