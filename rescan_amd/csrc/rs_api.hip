@@ -935,9 +935,12 @@ int icp_align_batch_impl( const rs_hip_cloud_t* source, const rs_hip_cloud_t* ta
       CB.dbg = g_ws.ch_dbg.as<int>(); CB.dbg_reps = std::max( 1, atoi( getenv( "RS_HIP_CHAIN_DEBUG" ) ) );
       // the walk writes its mismatch marker only where it finds 0: a fresh (or an earlier call's) buffer must not speak for this one
       HIP_TRY( hipMemsetAsync( g_ws.ch_dbg.p, 0, rows * ( 4 + 64 * 8 ) * 4, g_stream ), RS_HIP_E_RUNTIME );
-      if( ( rc = g_ws.ch_chk.ensure( rows * ( 4 + 3 * 4096 ) * 4 ) ) ) return rc;
-      HIP_TRY( hipMemsetAsync( g_ws.ch_chk.p, 0, rows * ( 4 + 3 * 4096 ) * 4, g_stream ), RS_HIP_E_RUNTIME );
-      CB.chk = g_ws.ch_chk.as<int>();
+      if( !getenv( "RS_HIP_CHAIN_DEBUG_NO_SELFCHECK" ) )      // (the self-check redoes every step the slow way: without it the stamps are the walk's real times)
+      {
+        if( ( rc = g_ws.ch_chk.ensure( rows * ( 4 + 3 * 4096 ) * 4 ) ) ) return rc;
+        HIP_TRY( hipMemsetAsync( g_ws.ch_chk.p, 0, rows * ( 4 + 3 * 4096 ) * 4, g_stream ), RS_HIP_E_RUNTIME );
+        CB.chk = g_ws.ch_chk.as<int>();
+      }
     }
     cx.L.rec = (float4*)g_ws.ch_rec.p;
     cx.L.n_mom_blocks = CB.n_blk * 4;              // k_chain_moments: one workgroup, one partial, per quarter block (1 024 source points)
