@@ -7,8 +7,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librescan_hip.so")
 DROPIN = os.path.join(HERE, "librescan_dropin.so")
-SOURCES = ["rs_kernels.hip", "rs_build.hip", "rs_api.hip"]
-HEADERS = ["rs_device.h", "rs_math.h", "rs_dropin.cpp", os.path.join("..", "..", "include", "rescan_hip.h"),
+SOURCES = ["rs_icp_search.hip", "rs_icp_estimate.hip", "rs_score.hip", "rs_rows.hip", "rs_build.hip", "rs_api.hip"]
+HEADERS = ["rs_device.h", "rs_math.h", "rs_search.h", "rs_icp.h", "rs_dropin.cpp", os.path.join("..", "..", "include", "rescan_hip.h"),
            os.path.join("..", "..", "include", "rescan_dropin.h")]
 # -ffp-contract=off: the neighbour-deciding arithmetic must round exactly like the reference's
 # scalar SSE2 code (no FMA); see DESIGN.md.

@@ -122,11 +122,11 @@ bool g_prof = false;
 // (bit-identical poses, errors and iteration counts); larger ones the fp64 moment reduction.  65 536 covers
 // every icp_align call site of the reference (level-2 objects, 2-10 k points; scene extracts of up to ~50 k).
 std::atomic<int> g_ref_order_below{ getenv( "RS_HIP_REF_ORDER_BELOW" ) ? atoi( getenv( "RS_HIP_REF_ORDER_BELOW" ) ) : 65536 };
-// Above that and up to this many source points the SAME sums are computed in parallel (rs_kernels.hip: "replay" — the reference's
+// Above that and up to this many source points the SAME sums are computed in parallel (rs_icp_estimate.hip: "replay" — the reference's
 // bits again, two to three times as fast as the sequential chains on scan-sized sources, still ten times the fp64 moments);
 // beyond — whole million-point scans, where a bit-exact iteration would cost 2.4 ms instead of 0.2 — the fp64 moments, whose
 // distance from the reference is measured (4.7e-5 on the headline workload, 23 of 24 sweep runs under 1e-4).
-// Sources above both thresholds: the fp64 moments, centred on the reference's own fp32 centroid chains (rs_kernels.hip:
+// Sources above both thresholds: the fp64 moments, centred on the reference's own fp32 centroid chains (rs_rows.hip:
 // launch_icp_exact_centroids; rs_math.h: icp_solve).  RS_HIP_EXACT_CENTROIDS=0: plain fp64 moments.
 std::atomic<int> g_chains_gave_up{ 0 };
 std::atomic<int> g_faith_guess_permille{ getenv( "RS_HIP_FAITH_GUESS" ) ? atoi( getenv( "RS_HIP_FAITH_GUESS" ) ) : 1000 };
@@ -615,7 +615,7 @@ namespace {
 // too few tiles to hide such stragglers behind other work (measured on MI355X: 1 M-query ICP,
 // 15.6 k tiles: 0.60 -> 0.47 ms per search with hand-off; 256-pose score batch, 40 k tiles:
 // 1.5 -> 3.0 ms, i.e. worse), so big launches keep everything in phase A.
-// Hand-off rule of a search launch (rs_kernels.hip: tile_search): low 16 bits = candidates a lone wave may
+// Hand-off rule of a search launch (rs_search.h: tile_search): low 16 bits = candidates a lone wave may
 // stream while a lane is unsettled, high bits = the shell after which an unsettled tile is handed off whatever it
 // streamed.  A wave that runs almost alone on its SIMD (few tiles in flight) is latency-bound, so the fewer tiles a
 // launch has, the earlier the cooperative kernel takes over; launches with > 24 k tiles (score batches) keep
@@ -646,7 +646,7 @@ struct IcpCtx
 constexpr size_t ICP_STATE_WORDS = 16 + 1 + 16 + 1 + 1 + 1 + 1 + 2;
 
 // One source for all problems (src), or one per problem (srcs[n_prob], src == null: a multi-source batch — the kernels then bind
-// their problem's view on the device, rs_kernels.hip: icp_bind).
+// their problem's view on the device, rs_icp.h: icp_bind).
 int icp_prepare( IcpCtx& cx, const rs_hip_cloud_t* src, const rs_hip_cloud_t* tgt, int n_prob, const float* T2, const rs_hip_cloud_t* const* srcs = nullptr )
 {
   if( n_prob <= 0 ) { set_err( "icp: empty batch" ); return RS_HIP_E_ARG; }
@@ -758,7 +758,7 @@ int icp_upload_state( IcpCtx& cx, const float* T1s, size_t np )
   return RS_HIP_OK;
 }
 
-// Certificates on (rs_kernels.hip: icp_certificate): two floats per (problem, source point).
+// Certificates on (rs_icp_search.hip: icp_certificate): two floats per (problem, source point).
 int icp_enable_certificates( IcpCtx& cx )
 {
   int rc;
@@ -1101,7 +1101,7 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
                             int32_t max_iter, int32_t fixed_iters, float* errs, int32_t* iters )
 {
   // Scan-sized sources: the reference's centroid sums by the grid chains — which give a problem up when a sum keeps changing
-  // binade (coordinates that straddle the origin in a cancelling order: rs_kernels.hip, chain_walk_row); the batch is then run
+  // binade (coordinates that straddle the origin in a cancelling order: rs_icp_estimate.hip, chain_walk_row); the batch is then run
   // again with those sums by pass 2 of the replay: the same bits, 0.9 ms per iteration at a million points instead of 0.09.
   // The estimators of large sources keep per-point records per problem (48 B with the chains, 44 B + the replay's rows when they
   // give up): many start poses of a whole scan are run in slices of problems whose records stay below RS_HIP_ICP_BATCH_BYTES
@@ -1132,7 +1132,7 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
 // The per-placement refine loop as one call (lib/rs/rs_database.h:220-230, apps/pose_proposal/main.cpp:190-202 with a different
 // object per proposal): problem p aligns sources[p] to the target from T1s[p].  Sources within the reference-order estimator's
 // range (rs_hip_icp_reference_order_below: every call site of the reference) run as ONE batch — grid.y = problem, the kernels bind
-// their problem's source view on the device (rs_kernels.hip: icp_bind), so the sequential chains of all problems run side by side;
+// their problem's source view on the device (rs_icp.h: icp_bind), so the sequential chains of all problems run side by side;
 // every problem's result is what rs_hip_icp_align returns for it alone, bit for bit.  A batch with a larger source is run
 // problem by problem (their estimators are built for one source per launch).
 int rs_hip_icp_align_multi( const rs_hip_cloud_t* const* sources, const rs_hip_cloud_t* target,
@@ -1499,7 +1499,7 @@ static int label_upload_placements( const rs_hip_placement_t* pl, int32_t n )
 }
 
 // The label state of a scene lives on the device in the scene's QUERY order (g_ws.labels / g_ws.mind) while a call works on
-// it; host arrays are in input order.  The two orders are exchanged by gathering (rs_kernels.hip: k_label_to_*_order).
+// it; host arrays are in input order.  The two orders are exchanged by gathering (rs_rows.hip: k_label_to_*_order).
 static int label_state_upload( const rs_hip_cloud_t* scene, const int8_t* labels, const float* min_dists )
 {
   const size_t ns = (size_t)scene->n;
@@ -1971,7 +1971,7 @@ extern "C" int rs_hip_compute_neighborhood( const rs_hip_cloud_t* cloud, int32_t
 }
 
 // ------------------------------------------------------------------------------------------
-// level builder (rs_kernels.hip: k_level_*)
+// level builder (rs_rows.hip: k_level_*)
 // ------------------------------------------------------------------------------------------
 
 // the samples of a level, left on the device in g_ws.lvl_samples (increasing original indices)

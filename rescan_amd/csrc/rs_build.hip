@@ -6,7 +6,7 @@
 //
 // Nothing here decides a search result: results depend on neither the cell size, nor the order of
 // points inside a cell, nor the tiling.  The one expression that must agree with the search kernels is
-// the cell coordinate of a stored point (cell_of_dev; rs_kernels.hip: axis_range covers it with a 0.01-cell margin).
+// the cell coordinate of a stored point (cell_of_dev; rs_search.h: axis_range covers it with a 0.01-cell margin).
 #include "rs_device.h"
 #include <hipcub/hipcub.hpp>
 #include <cfloat>

@@ -52,7 +52,7 @@ struct PlacementDev
 enum { ICP_NMOM = 35,     // raw moments reduced per ICP iteration (see k_icp_moments)
        ICP_NRES = 39 };   // per problem result record: 35 moments + {n_corr, mean, stddev, -}
 
-// ---- launchers (rs_kernels.hip) ----------------------------------------------------------
+// ---- launchers (the rs_*.hip kernel files) ----------------------------------------------------------
 constexpr int HEAVY_SLOTS = 2048;   // wave slots at the front of phase A's grid reserved for the previous iteration's slow tiles
 constexpr int HEAVY_CLASSES = 8;     // one list per XCD class of the natural order: a listed tile stays on the XCD whose L2 holds its part of the target
 constexpr int HEAVY_PER_CLASS = HEAVY_SLOTS / HEAVY_CLASSES;
@@ -112,8 +112,8 @@ struct IcpLaunch
   int     warm;         // m_slot holds last iteration's matches: use them as starting candidates
   int     seed;         // (when !warm) start from the best usable point of the query's own cell
   int     bounded_only; // (when warm) phase A only takes tiles whose lanes all start from a candidate; the rest goes straight to the cooperative kernel
-  int     by_rows;      // (when warm) per-row sweep of the tiles whose lanes all start from a candidate (rs_kernels.hip: sweep_by_rows)
-  // certificates issued by every search and consulted when a point has no usable previous match (rs_kernels.hip: icp_certificate); null = off
+  int     by_rows;      // (when warm) per-row sweep of the tiles whose lanes all start from a candidate (rs_search.h: sweep_by_rows)
+  // certificates issued by every search and consulted when a point has no usable previous match (rs_icp_search.hip: icp_certificate); null = off
   float*  cert_r;       // n_prob x nq
   float*  cert_dot;     // n_prob x nq
   float*  cert_slack;   // n_prob x nq: rank certificates (null: off) — see icp_certificate
@@ -129,21 +129,21 @@ struct IcpLaunch
   int     heavy_streamed;   // a tile that streamed at least this many candidates is listed
   int     heavy_total;      // warm launch: a bounded tile swept tile-wide (boxes too tall for the per-row sweep) is handed off too when the first 64 cell rows of its box hold this many candidates (0: never)
   int     heavy_handoff;    // ... and one that streamed this many in a warm launch goes to the cooperative kernel from the next iteration on (flag 2)
-  // reference-order estimator (rs_kernels.hip: k_icp_faithful); faith == null: fp64 moments
+  // reference-order estimator (rs_icp_estimate.hip: k_icp_faithful); faith == null: fp64 moments
   const int* by_orig;   // original source index -> query slot (null: identity)
   float*  faith;        // n_prob x FAITH_REC x nq: the correspondences in the source's own order
   // "exact centroids" estimator (large sources): the fp64 moments, but the seven sums behind the two weighted centroids
   // (icp.h:136-148: Σw, Σw·p, Σw·q) as the reference's own sequential fp32 chains — see launch_icp_exact_centroids
   int     exact_centroids;
   const double* centroid_totals;   // n_prob x 3 x ICP_NMOM (ReplayBufs::totals): [ICP_NMOM + 0..6] = the seven chain totals
-  // ... and their fast form (rs_kernels.hip: "grid chains"): every search writes one 48-byte record per source point at the point's
+  // ... and their fast form (rs_icp_estimate.hip: "grid chains"): every search writes one 48-byte record per source point at the point's
   // ORIGINAL index — {p.xyz, dist² (< 0: no match)} {q.xyz, dot} {n.xyz, -} — which the estimator's kernels then read in the
   // reference's own order, coalesced (null: not wanted)
   float4* rec;                     // n_prob x n x REC_F4
 };
 
 // The seven centroid chains (Σw, Σw·p, Σw·q: icp.h:136-148) as sequential fp32 sums, computed on the integer grid of the
-// running sum's binade (rs_kernels.hip: "grid chains").  Segments of 64 source points (original order), blocks of 64 segments.
+// running sum's binade (rs_icp_estimate.hip: "grid chains").  Segments of 64 source points (original order), blocks of 64 segments.
 constexpr int CH_ROWS = 7, CH_SEG = 64, CH_BLK = 64;
 constexpr int REC_F4 = 3;        // float4 per correspondence record
 struct ChainRec { int e_sign; int lo[3], hi[3], D[3]; };   // exponent guess | sign << 8; per exponent e-1, e, e+1: the start mantissas it holds for and the advance
@@ -171,7 +171,7 @@ void launch_icp_corr( const IcpLaunch& L, hipStream_t st );     // phase A, phas
 void launch_icp_moments( const IcpLaunch& L, hipStream_t st );  // weights + moments (+ solve and loop-state update if L.solve)
 constexpr int FAITH_REC = 11;   // per correspondence: dist² (< 0: none), dot | weight, p, q, n
 void launch_icp_faithful( const IcpLaunch& L, hipStream_t st ); // the same step with the reference's own accumulation order and precisions
-// ... and the same bits computed in parallel (rs_kernels.hip: "replay"): per problem and accumulator row (ICP_NMOM rows per pass)
+// ... and the same bits computed in parallel (rs_icp_estimate.hip: "replay"): per problem and accumulator row (ICP_NMOM rows per pass)
 struct ReplaySeg;
 struct ReplayBufs
 {
@@ -206,8 +206,8 @@ struct ScoreLaunch
   int*         queue;      // n_poses x n_tiles items (pose*n_tiles + tile) for the cooperative kernel
   int*         queue_count;
   int          solo_stages;
-  int          by_rows;    // launches that hand nothing off: the row-wise cold search (rs_kernels.hip: tile_search_rows)
-  float        kcap_frac;  // K-cap distance² as a fraction of radius² (rs_kernels.hip: KCap); 0: off
+  int          by_rows;    // launches that hand nothing off: the row-wise cold search (rs_search.h: tile_search_rows)
+  float        kcap_frac;  // K-cap distance² as a fraction of radius² (rs_search.h: KCap); 0: off
   unsigned long long* hist;   // diagnostic builds only (RS_HIP_SCORE_HIST): 6 x 65 counters, see k_score
 };
 void launch_score( const ScoreLaunch& L, hipStream_t st );
@@ -293,7 +293,7 @@ int    build_exclusive_scan( void* tmp, size_t bytes, const uint32_t* in, uint32
 
 // Neighbourhood graph (rspf_compute_neighborhood): from self-search rows to unique weighted edges.
 // Level builder (lib/rs/rs_pointcloud.h:984-1106): a self-search of one cloud listing, per point, the LATER points
-// (larger original index) within the radius, then a propagation of decisions along those rows (rs_kernels.hip).
+// (larger original index) within the radius, then a propagation of decisions along those rows (rs_rows.hip).
 struct LevelLaunch
 {
   GridView     tgt;

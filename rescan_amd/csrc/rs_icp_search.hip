@@ -1,0 +1,432 @@
+// librescan_hip device code (gfx950, wave64) — the ICP correspondence search (lib/rs/icp.h:306-412)
+#include "rs_search.h"
+#include "rs_icp.h"
+
+namespace rs {
+
+// ------------------------------------------------------------------------------------------
+// ICP: correspondence search  (lib/rs/icp.h:339-391)
+// ------------------------------------------------------------------------------------------
+
+
+
+// Warm start (iterations >= 2): last iteration's match of this source point, re-evaluated under
+// the current pose.  If it is still within the radius and passes the gate it is a legitimate
+// candidate, so starting the search from it changes nothing in the result and lets most
+// candidates fail the very first compare.
+// First iteration: no previous match to start from.  The first few points of the query's OWN cell serve the
+// same purpose: whichever of them lies within the radius and passes the gate is a legitimate candidate, and
+// starting from it turns the cold search (every candidate within the radius passes the bound test of a lane
+// without a match) into the bounded one the later iterations run.
+template <bool GATED>
+__device__ __forceinline__ Match cell_seed( const GridView& g, bool active, float qx, float qy, float qz, float nx, float ny, float nz,
+                                            float radius_sq, float tmin )
+{
+  Match m = no_match();
+  if( !active || !( g.inv_cell > 0.0f ) ) return m;
+  const float fx = floorf( ( qx - g.minx ) * g.inv_cell ), fy = floorf( ( qy - g.miny ) * g.inv_cell ), fz = floorf( ( qz - g.minz ) * g.inv_cell );
+  if( !( fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx < (float)g.w && fy < (float)g.h && fz < (float)g.d ) ) return m;     // outside the grid (or NaN)
+  const size_t id = ( (size_t)(int)fz * g.h + (int)fy ) * g.w + (int)fx;
+  const uint32_t s0 = g.cell_start[id], s1 = g.cell_start[id + 1];
+  const uint32_t n = min( s1 - s0, 4u );
+  for( uint32_t t = 0; t < n; ++t )
+  {
+    const uint32_t s = s0 + t;
+    const float4 P = g.pos[s];
+    const float vx = P.x - qx, vy = P.y - qy, vz = P.z - qz;
+    const float d2 = vx * vx + vy * vy + vz * vz;
+    float dc = 0.0f;
+    bool ok = d2 < radius_sq;
+    if( GATED )
+    {
+      const float4 N = g.nor[s];
+      const float dot = N.x * nx + N.y * ny + N.z * nz;
+      dc = dot > 0.0f ? dot : 0.0f;
+      ok = ok && dc >= tmin && dc <= 1.0f;
+    }
+    const int idx = __float_as_int( P.w );
+    if( ok && lex_less( d2, idx, m.d2, m.idx ) ) { m.d2 = d2; m.idx = idx; m.dot = dc; m.slot = (int)s; m.found = true; }
+  }
+  return m;
+}
+__device__ __forceinline__ Match icp_cell_seed( const IcpLaunch& L, bool active, float qx, float qy, float qz, float nx, float ny, float nz )
+{ return cell_seed<true>( L.tgt, active, qx, qy, qz, nx, ny, nz, L.radius_sq, L.gate_tmin ); }
+
+__device__ __forceinline__ Match icp_warm_start( const IcpLaunch& L, int prob, int i, bool active,
+                                                 float qx, float qy, float qz, float nx, float ny, float nz )
+{
+  Match m = no_match();
+  if( !active ) return m;
+  if( !L.warm ) return L.seed ? icp_cell_seed( L, active, qx, qy, qz, nx, ny, nz ) : m;
+  const int s = L.m_slot[(size_t)L.pt_off + i];
+  if( s < 0 ) return m;
+  const float4 P = L.tgt.pos[s], N = L.tgt.nor[s];
+  float vx = P.x - qx, vy = P.y - qy, vz = P.z - qz;
+  float d2 = vx * vx + vy * vy + vz * vz;
+  float dot = N.x * nx + N.y * ny + N.z * nz;
+  float dc = dot > 0.0f ? dot : 0.0f;
+  if( d2 < L.radius_sq && dc >= L.gate_tmin && dc <= 1.0f ) { m.d2 = d2; m.idx = __float_as_int( P.w ); m.dot = dc; m.slot = s; m.found = true; }
+  return m;
+}
+
+// Certificates.  Every search ends knowing, for its query, a distance within which EVERY candidate failed the
+// gate, and by how much:
+//   cert_r   = (distance to the nearest gated candidate — the match, or one rejected for its rank — or the radius
+//              when there is none) - margin.  Each later iteration subtracts how far the query has moved since;
+//   cert_dot = tmin - fail_max - margin: how much the gate value of any of those candidates may still rise.  Each
+//              later iteration subtracts |delta n| * max|m|  (dot(m, n') - dot(m, n) <= |m| |n' - n|).
+// A query whose previous match is no longer usable (there was none, or it left the shrinking radius —
+// icp.h:493 — or its gate) consults the certificate: while radius <= cert_r and cert_dot >= 0 the triangle
+// inequality proves that every candidate within the current radius was examined then and cannot pass the gate
+// now, so the result (unmatched) is exactly what the full sweep would return, and the sweep is skipped.  The
+// margins (1e-4 m, 1e-5) are orders of magnitude above the fp32 rounding of dist², dot and the displacement.
+// This removes the one case a search cannot bound — the full-radius sweep of a source point with nothing to
+// match, repeated every iteration — including the points that become unmatched because the radius shrinks.
+//
+// Returns whether the search of this query may be skipped, and writes the aged certificate back at once
+// (keeping it in registers across the search costs a wave of occupancy).  A tile that phase A hands off
+// is aged a second time by the cooperative kernel: that only makes the certificate more conservative.
+__device__ __forceinline__ bool icp_certificate( const IcpLaunch& L, int prob, int i, bool active,
+                                                 float qx, float qy, float qz, float nx, float ny, float nz )
+{
+  if( !L.cert_r || !L.warm || !active ) return false;
+  const size_t o = (size_t)L.pt_off + i;
+  const float r = L.cert_r[o];
+  if( !( r > 0.0f ) ) return false;
+  // the same query under the previous iteration's pose (identical float operations as then)
+  Xform Tp;
+#pragma unroll
+  for( int k = 0; k < 16; ++k ) Tp.m[k] = L.T1_prev[prob * 16 + k];
+  float4 p = L.src.pos[i], n = L.src.nor[i];
+  float tx, ty, tz, px, py, pz, mx, my, mz;
+  xform3( Tp, p.x, p.y, p.z, 1.0f, tx, ty, tz );   xform3( L.T2i, tx, ty, tz, 1.0f, px, py, pz );
+  xform3( Tp, n.x, n.y, n.z, 0.0f, tx, ty, tz );   xform3( L.T2i, tx, ty, tz, 0.0f, mx, my, mz );
+  const float dq = sqrtf( ( qx - px ) * ( qx - px ) + ( qy - py ) * ( qy - py ) + ( qz - pz ) * ( qz - pz ) );
+  const float dn = sqrtf( ( nx - mx ) * ( nx - mx ) + ( ny - my ) * ( ny - my ) + ( nz - mz ) * ( nz - mz ) );
+  const float moved = dq * 1.0001f + 1e-5f;
+  const float r_now = r - moved;
+  const float dot_now = L.cert_dot[o] - ( dn * L.tgt_nor_max * 1.0001f + 1e-6f );
+  bool skip = ( L.radius <= r_now ) & ( dot_now >= 0.0f );
+  if( L.cert_slack )
+  {
+    // rank certificate: the nearest gated candidate (at cert_r) was rejected because K candidates precede it, and K of
+    // them lie closer than cert_r - slack.  They have come closer to the query by at most `moved`, whatever passes
+    // the gate now lies no closer than r_now = cert_r - moved (everything inside failed it, by the margin above): while
+    // slack - 2 moved > 0 those K still precede every candidate that could be chosen, so the point stays unmatched.
+    const float s = L.cert_slack[o];
+    const float s_now = s > 0.0f ? s - 2.0f * moved : 0.0f;
+    skip |= ( s_now > 0.0f ) & ( dot_now >= 0.0f ) & ( r_now > 0.0f );
+    L.cert_slack[o] = s_now;
+  }
+  L.cert_r[o] = skip ? r_now : -1.0f;
+  L.cert_dot[o] = dot_now;
+  return skip;
+}
+
+__device__ __forceinline__ void icp_emit( const IcpLaunch& L, int prob, int tile, int i, bool active, int lane, const Match& m,
+                                          bool skipped )
+{
+  const size_t o = (size_t)L.pt_off + i;
+  if( active ) { L.m_slot[o] = m.found ? m.slot : -1; if( !L.rec ) { L.m_d2[o] = m.d2; L.m_dot[o] = m.dot; } }
+  if( active && L.rec )
+  {
+    // the correspondence as the estimator wants it, at the source point's ORIGINAL index: three 16-byte stores into one 48-byte
+    // record (the estimator's kernels then read the reference's order coalesced, instead of gathering slot / dist² / dot /
+    // source / target point / target normal at random: 5 transactions per point)
+    Xform T1;
+#pragma unroll
+    for( int k = 0; k < 16; ++k ) T1.m[k] = L.T1[prob * 16 + k];
+    float qx, qy, qz, nx, ny, nz;
+    icp_query( L, T1, i, true, qx, qy, qz, nx, ny, nz );           // (the same float operations the search used)
+    float4 P = make_float4( 0.0f, 0.0f, 0.0f, 0.0f ), N = P;
+    if( m.found ) { P = L.tgt.pos[m.slot]; N = L.tgt.nor[m.slot]; }
+    const int orig = __float_as_int( L.src.pos[i].w );
+    float4* R = L.rec + ( (size_t)L.pt_off + orig ) * REC_F4;
+    R[0] = make_float4( qx, qy, qz, m.found ? m.d2 : -1.0f );
+    R[1] = make_float4( P.x, P.y, P.z, m.dot );
+    R[2] = make_float4( N.x, N.y, N.z, 0.0f );
+  }
+  if( active && L.cert_r && !skipped )
+  {
+    // fresh certificate (m.idx != INT_MAX: a gated candidate exists at dist² m.d2, even if its rank rejected it)
+    const float r = ( m.idx != INT_MAX ? sqrtf( m.d2 ) : L.radius ) - 1e-4f;
+    const float d = L.gate_tmin - m.fail_max - 1e-5f;
+    L.cert_r[o] = ( d >= 0.0f ) ? r : -1.0f; L.cert_dot[o] = d;
+    if( L.cert_slack ) L.cert_slack[o] = ( !m.found && m.idx != INT_MAX ) ? m.rank_slack : 0.0f;
+  }
+  if( RS_DBG >= 2 && DBG( L ) )
+  {
+    unsigned long long* cat = DBG( L ) + 6 * (size_t)L.src.n_tiles;
+    const bool margin = L.gate_tmin - m.fail_max - 1e-5f >= 0.0f;
+    const int c_skip = __popcll( __ballot( skipped ) ), c_fresh = __popcll( __ballot( active && !skipped && !m.found && margin ) );
+    const int c_rank = __popcll( __ballot( active && !skipped && !m.found && m.idx != INT_MAX ) );
+    const int c_loose = __popcll( __ballot( active && !skipped && !m.found && !margin && m.idx == INT_MAX ) );
+    if( lane == 0 ) { atomicAdd( cat + 0, (unsigned long long)c_skip ); atomicAdd( cat + 1, (unsigned long long)c_fresh ); atomicAdd( cat + 2, (unsigned long long)c_rank ); atomicAdd( cat + 3, (unsigned long long)c_loose ); }
+  }
+  // statistics of dist² over the correspondences (msh_compute_mean/stddev, msh_std.h:1800-1825): Σ1, Σd², Σd⁴ of the
+  // tile, added as INTEGERS (fixed point, scaled to the radius) to one of STAT_SHARDS accumulators — integer addition
+  // does not care in which order the tiles arrive, so the totals are bit-reproducible without a fixed-order pass
+  // (and without the kernel launch that pass used to be).
+  if( L.stat_acc )
+  {
+    const unsigned long long c = (unsigned long long)__popcll( __ballot( active && m.found ) );
+    double s1 = ( active && m.found ) ? (double)m.d2 : 0.0;
+    double s2 = ( active && m.found ) ? (double)( m.d2 * m.d2 ) : 0.0;
+    s1 = wave_sum( s1 ); s2 = wave_sum( s2 );
+    if( lane == 0 && c != 0 )
+    {
+      unsigned long long* a = L.stat_acc + ( (size_t)prob * STAT_SHARDS + ( tile & ( STAT_SHARDS - 1 ) ) ) * 4;
+      atomicAdd( a + 0, c );
+      atomicAdd( a + 1, (unsigned long long)( s1 * L.stat_s1 ) );
+      atomicAdd( a + 2, (unsigned long long)( s2 * L.stat_s2 ) );
+    }
+  }
+}
+
+
+
+#ifndef RS_XCD_MAP
+#define RS_XCD_MAP 1
+#endif
+// workgroups of phase A's natural part per XCD class (see k_icp_corr)
+// Waves per workgroup of phase A (k_icp_corr).  A workgroup's wave slots and LDS are released when its LAST wave ends, and a
+// warm tile takes its wave 12 us at the median, 17 at the 90th percentile: with four tiles per workgroup a quarter of the slot time
+// was spent waiting for the slowest of four (4 400 of 6 144 slots occupied in the launch's steady state, 5 000-5 200 with one; the
+// concurrent chain's searches 2.22 -> 2.08 ms per step, serial 1.68 -> 1.65: profiles/r02/ab_*experiments.txt).
+#ifndef RS_PA_WAVES
+#define RS_PA_WAVES 1
+#endif
+constexpr int PA_WAVES = RS_PA_WAVES;
+__host__ __device__ inline int icp_blocks_per_xcd( int n_tiles ) { return ( ( n_tiles + PA_WAVES - 1 ) / PA_WAVES + 7 ) / 8; }
+
+// Phase A: one wave per tile, first shell(s) only; unsettled tiles are queued.
+// Waves per SIMD the register allocation aims at.  5 = 83 / 95 VGPRs (warm / cold instantiation), no scratch; 6 = 80 VGPRs with
+// 16 / 40 B of scratch per lane.  Measured on the bench with the consumers on disjoint CUs (interleaved repeats,
+// profiles/r02/ab_*experiments.txt), step time / HBM-side traffic per search: both 6: 2.53-2.55 ms, 148 MB; warm 6, cold 5:
+// 2.55-2.59 ms, 134 MB; both 5: 2.61-2.62 ms, 122 MB (70.5 MB are algorithmic).  The ICP chain is the step's critical path, so
+// the warm launches (nine of ten) keep their sixth wave; the cold one, whose scratch is the larger, does without.
+#ifndef RS_ICP_WARM_OCC
+#define RS_ICP_WARM_OCC 6
+#endif
+#ifndef RS_ICP_OCC
+#define RS_ICP_OCC 5
+#endif
+template <bool BOUNDED_ONLY>
+__global__ __launch_bounds__( PA_WAVES * WAVE, BOUNDED_ONLY ? RS_ICP_WARM_OCC : RS_ICP_OCC ) void k_icp_corr( IcpLaunch L )
+{
+  RS_CHAIN_SETPRIO();
+  __shared__ WaveLds lds[PA_WAVES];
+  const int prob = blockIdx.y;
+  if( L.active[prob] == 0 ) return;
+  icp_bind( L, prob );
+  const int lane = threadIdx.x & ( WAVE - 1 );
+  const int wib = PA_WAVES == 1 ? 0 : uni( (int)threadIdx.x / WAVE );
+  EvalScope eval_scope( L.tgt.evals, lds[wib], lane );
+  // Slowest first: the kernel ends when its slowest tile does, and the slow tiles (several shells, a rank
+  // pass) are the same from one iteration to the next.  The previous iteration listed them; the first
+  // HEAVY_SLOTS wave slots of the grid take that list, the rest walk the tiles in their natural (Hilbert)
+  // order — which the caches depend on — and skip the listed ones.
+  int slot = blockIdx.x * PA_WAVES + wib;
+  int tile;
+  // XCD-aware order of the natural (Hilbert) part: workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8
+  // share one), each XCD with its own 4 MB L2.  Walking the tiles in plain order would have every XCD touch every part of
+  // the 32 MB target cloud; instead XCD class c = b mod 8 walks the c-th eighth of the Hilbert order, so an XCD's L2 only
+  // ever sees its own part of the scene (and the seams).  Which XCD a class lands on does not matter.
+  auto natural_tile = [&]( int block ) -> int
+  {
+#if RS_XCD_MAP
+    const int per = icp_blocks_per_xcd( L.src.n_tiles );
+    if( ( block >> 3 ) >= per ) return INT_MAX;      // (a multi-source batch's grid is the largest problem's: beyond this problem's own eighths)
+    return ( ( block & 7 ) * per + ( block >> 3 ) ) * PA_WAVES + wib;
+#else
+    return block * PA_WAVES + wib;
+#endif
+  };
+  if( L.heavy_in )
+  {
+    const int* hv = L.heavy_in + (size_t)L.heavy_off;
+    if( slot < HEAVY_SLOTS )
+    {
+      // front block b serves XCD class b mod 8 (it runs on the XCD the class's natural blocks run on), entry (b / 8) * 4 + wave
+      const int c = (int)blockIdx.x & ( HEAVY_CLASSES - 1 ), p = ( (int)blockIdx.x >> 3 ) * PA_WAVES + wib;
+      if( p >= min( uni( hv[c] ), HEAVY_PER_CLASS ) ) return;
+      tile = uni( hv[HEAVY_HDR + c * HEAVY_PER_CLASS + p] );
+    }
+    else
+    {
+      tile = natural_tile( (int)blockIdx.x - HEAVY_SLOTS / PA_WAVES );
+      if( tile >= L.src.n_tiles ) return;
+      const int flag = uni( hv[HEAVY_HDR + HEAVY_SLOTS + tile] ) & 3;
+      if( flag == 1 ) return;                                            // a front slot has it
+      if( BOUNDED_ONLY && flag == 2 )
+      {
+        // a tile whose one sweep was so long that a lone wave IS the launch's tail (600+ candidates: 45-60 us, against a launch
+        // that could end after ~45): a workgroup of the cooperative kernel takes it from now on, like an unbounded tile
+        if( lane == 0 )
+        {
+          int q = atomicAdd( L.queue_count + prob, 1 ); L.queue[(size_t)L.tile_off + q] = tile;
+          if( L.heavy_out ) L.heavy_out[(size_t)L.heavy_off + HEAVY_HDR + HEAVY_SLOTS + tile] = 2;
+          if( DBG( L ) ) { DBG( L )[2 * tile] = wall_clock64(); DBG( L )[2 * tile + 1] = 1ull << 20; }      // (handed off, no time spent)
+        }
+        return;
+      }
+    }
+  }
+  else { tile = natural_tile( (int)blockIdx.x ); if( tile >= L.src.n_tiles ) return; }
+  const int i = (int)L.src.tiles[tile] + lane;
+  const bool active = i < (int)L.src.tiles[tile + 1];
+
+  Xform T1;
+#pragma unroll
+  for( int k = 0; k < 16; ++k ) T1.m[k] = __int_as_float( uni( __float_as_int( L.T1[prob * 16 + k] ) ) );
+  float qx, qy, qz, nx, ny, nz;
+  const unsigned long long t_begin = DBG( L ) ? wall_clock64() : 0ull;
+  icp_query( L, T1, i, active, qx, qy, qz, nx, ny, nz );
+  bool handoff;
+  int sweeps = 0;
+  uint32_t streamed = 0;
+  int unsettled[16] = { 0 };
+  const Match init = icp_warm_start( L, prob, i, active, qx, qy, qz, nx, ny, nz );
+  const bool search = active & !icp_certificate( L, prob, i, active & !init.found, qx, qy, qz, nx, ny, nz );
+  // thresholds in candidates: as given up to a mean of HEAVY_MEAN_REF candidates per tile in the previous launch, growing with it
+  // beyond (the factor, in 1/256ths, was worked out when that iteration ended: icp_iteration_reset)
+  const unsigned scale_q8 = L.heavy_in ? (unsigned)uni( L.heavy_in[(size_t)L.heavy_off + HEAVY_MEAN] ) : 256u;
+  const unsigned sq8 = scale_q8 < 256u ? 256u : ( scale_q8 > 65536u ? 65536u : scale_q8 );
+  const int thr_total = (int)( ( (unsigned)min( L.heavy_total, 0xffff ) * sq8 ) >> 8 );
+  const uint32_t thr_streamed = ( (unsigned)min( L.heavy_streamed, 0xffff ) * sq8 ) >> 8;
+  const uint32_t thr_handoff = ( (unsigned)min( L.heavy_handoff, 0xffff ) * sq8 ) >> 8;
+  Match m = tile_search<true, true, BOUNDED_ONLY>( L.tgt, search, qx, qy, qz, nx, ny, nz, L.radius, L.radius_sq, L.gate_tmin, L.K,
+                               lds[wib], lane, L.solo_stages, &handoff, DBG( L ) ? unsettled : nullptr, init, &sweeps, L.by_rows != 0, &streamed, thr_total );
+  if( L.heavy_out && lane == 0 )
+  {
+    int* hv = L.heavy_out + (size_t)L.heavy_off;
+    int listed = 0;
+    // What will be slow next time.  A warm launch hands its unbounded tiles off at once — they cost it nothing — and its slow
+    // tiles are the ones that stream many candidates in their one sweep (p50 150 candidates / 12 us, p99.9 750 / 40 us: left in
+    // natural order those start half way through the launch and ARE its tail); the cold launch's are its multi-shell tiles.
+    const bool slow = BOUNDED_ONLY ? ( !handoff && streamed >= thr_streamed ) : ( handoff || sweeps >= 2 || streamed >= thr_streamed );
+    if( BOUNDED_ONLY && !handoff && streamed >= thr_handoff ) listed = 2;
+    else if( slow )
+    {
+#if RS_XCD_MAP
+      const int c = min( ( tile / PA_WAVES ) / icp_blocks_per_xcd( L.src.n_tiles ), HEAVY_CLASSES - 1 );      // the class whose natural range holds the tile
+#else
+      const int c = ( tile / PA_WAVES ) & ( HEAVY_CLASSES - 1 );
+#endif
+      const int pos = atomicAdd( hv + c, 1 );
+      if( pos < HEAVY_PER_CLASS ) { hv[HEAVY_HDR + c * HEAVY_PER_CLASS + pos] = tile; listed = 1; }
+    }
+    // per tile: flag (bits 0-1) | candidates streamed by this launch (handed off: 0, not counted) — one store; the mean over a sample
+    // of these words is the next launch's yardstick (icp_iteration_reset).  (Summing them with atomics cost 33 us per launch.)
+    hv[HEAVY_HDR + HEAVY_SLOTS + tile] = listed | ( handoff ? 0 : (int)( min( streamed, 0x0fffffffu ) << 2 ) );
+  }
+  if( DBG( L ) && lane == 0 )
+  {
+    // [0] start (absolute, 10 ns ticks) | [1] duration 20 bits | handoff 1 | shells 4 | streamed 16 | rank-pass streamed 16 | unsettled lanes after shell 1: 7
+    auto clipv = []( unsigned long long v, unsigned long long mx ) { return v > mx ? mx : v; };
+    DBG( L )[2 * tile] = t_begin;
+    DBG( L )[2 * tile + 1] = clipv( wall_clock64() - t_begin, 0xfffff ) | ( (unsigned long long)( handoff ? 1 : 0 ) << 20 ) | ( clipv( unsettled[3], 15 ) << 21 ) |
+                             ( clipv( unsettled[1], 0xffff ) << 25 ) | ( clipv( unsettled[2], 0xffff ) << 41 ) | ( clipv( unsettled[0], 127 ) << 57 );
+  }
+  if( handoff )
+  {
+    if( lane == 0 ) { int q = atomicAdd( L.queue_count + prob, 1 ); L.queue[(size_t)L.tile_off + q] = tile; }
+    return;
+  }
+  icp_emit( L, prob, tile, i, active, lane, m, active & !search );
+}
+
+// One tile searched by all NW waves of its workgroup: queries, warm start, certificates (checked by ONE wave — the check ages
+// the certificate in place, and the waves must agree on who searches), cooperative search, results written by wave 0.
+// Returns whether some lane had to search without a starting candidate (the tile is "not bounded": worth a workgroup again
+// next iteration).  Ends with a barrier: the merge slots may be reused at once.
+template <int NW>
+__device__ __forceinline__ bool icp_coop_tile( const IcpLaunch& L, const Xform& T1, int prob, int tile, WaveLds& lds, CoopLds<NW>& coop,
+                                               unsigned long long& s_skip, int wib, int lane, int dbg_slot )
+{
+  const int i = (int)L.src.tiles[tile] + lane;
+  const bool active = i < (int)L.src.tiles[tile + 1];
+  float qx, qy, qz, nx, ny, nz;
+  icp_query( L, T1, i, active, qx, qy, qz, nx, ny, nz );
+  const unsigned long long t_begin = DBG( L ) ? wall_clock64() : 0ull;
+  unsigned long long stamps[8];
+  const Match init = icp_warm_start( L, prob, i, active, qx, qy, qz, nx, ny, nz );
+  if( wib == 0 )
+  {
+    const unsigned long long skip_mask = __ballot( icp_certificate( L, prob, i, active & !init.found, qx, qy, qz, nx, ny, nz ) );
+    if( lane == 0 ) s_skip = skip_mask;
+  }
+  __syncthreads();
+  const bool search = active & !( ( s_skip >> lane ) & 1ull );
+  uint32_t streamed = 0;
+  Match m = coop_search<true, NW, true>( L.tgt, search, qx, qy, qz, nx, ny, nz, L.radius, L.radius_sq, L.gate_tmin, L.K,
+                               lds, coop, wib, lane, init, DBG( L ) ? &streamed : nullptr, DBG( L ) ? stamps : nullptr );
+  if( DBG( L ) && wib == 0 && dbg_slot >= 0 )
+  {
+    const int n_search = __popcll( __ballot( search ) ), n_unm = __popcll( __ballot( search & !m.found ) );
+    if( lane == 0 )
+    {
+      unsigned long long* d = DBG( L ) + 2 * (size_t)L.src.n_tiles + 4 * (size_t)dbg_slot;
+      const unsigned long long t_end = wall_clock64();
+      // [0] total | [1] streamed | lanes | phases packed: setup, shell 1, shell 2, rest (each 16 bits, ticks of 10 ns)
+      auto clip = []( unsigned long long v ) { return v > 0xffffull ? 0xffffull : v; };
+      d[0] = t_end - t_begin; d[1] = streamed; d[2] = (unsigned long long)n_search | ( (unsigned long long)n_unm << 8 );
+      d[3] = clip( stamps[0] - t_begin ) | ( clip( stamps[1] - stamps[0] ) << 16 ) | ( clip( stamps[2] - stamps[1] ) << 32 ) | ( clip( t_end - stamps[2] ) << 48 );
+    }
+  }
+  if( wib == 0 ) icp_emit( L, prob, tile, i, active, lane, m, active & !search );
+  const bool not_bounded = __any( search & !init.found );
+  __syncthreads();                               // merge slots are reused by the next tile
+  return not_bounded;
+}
+
+// Phase B: one workgroup per queued tile, whole box, chunks shared by its waves.
+#ifndef RS_COOP_OCC
+#define RS_COOP_OCC 5      // waves per SIMD the cooperative kernel's register allocation aims at (96 VGPRs: no spills; 6 = 80 VGPRs spilt 56 B per lane for no gain in time)
+#endif
+template <int NW>
+__global__ __launch_bounds__( NW * WAVE, RS_COOP_OCC ) void k_icp_corr_coop( IcpLaunch L )
+{
+  RS_CHAIN_SETPRIO();
+  __shared__ WaveLds lds[NW];
+  __shared__ CoopLds<NW> coop;
+  __shared__ unsigned long long s_skip;
+  const int prob = blockIdx.y;
+  if( L.active[prob] == 0 ) return;
+  icp_bind( L, prob );
+  const int lane = threadIdx.x & ( WAVE - 1 );
+  const int wib = threadIdx.x / WAVE;
+  EvalScope eval_scope( L.tgt.evals, lds[wib], lane );
+  const int n_queued = L.coop_all ? L.src.n_tiles : L.queue_count[prob];     // coop_all: phase A was not launched, every tile is searched here
+  Xform T1;
+#pragma unroll
+  for( int k = 0; k < 16; ++k ) T1.m[k] = L.T1[prob * 16 + k];
+  for( int b = blockIdx.x; b < n_queued; b += gridDim.x )
+  {
+    const int tile = L.coop_all ? b : L.queue[(size_t)L.tile_off + b];
+    icp_coop_tile<NW>( L, T1, prob, tile, lds[wib], coop, s_skip, wib, lane, b );
+  }
+}
+
+
+void launch_icp_corr( const IcpLaunch& L, hipStream_t st )
+{
+  // queue_count is zero on entry: cleared once by the host, then by the workgroup that ends every iteration (icp_iteration_reset)
+  // A launch of a few hundred tiles leaves every wave alone on its SIMD, i.e. latency-bound, and phase A's slowest tile
+  // sets its time: such launches skip phase A and give every tile a workgroup straight away (coop_all).
+  static_assert( HEAVY_SLOTS % ( 8 * PA_WAVES ) == 0, "the front slots must not shift the XCD class of the natural part" );
+  dim3 grid( ( L.heavy_in ? HEAVY_SLOTS / PA_WAVES : 0 ) + 8 * icp_blocks_per_xcd( L.max_tiles ), L.n_prob );      // (max_tiles: the largest problem's)
+  if( !L.coop_all )
+  {
+    if( L.warm && L.bounded_only ) hipLaunchKernelGGL( k_icp_corr<true>, grid, dim3( PA_WAVES * WAVE ), 0, st, L );
+    else                           hipLaunchKernelGGL( k_icp_corr<false>, grid, dim3( PA_WAVES * WAVE ), 0, st, L );
+  }
+  // the queue length is only known on the device: a fixed grid strides over it
+  int coop_blocks = L.max_tiles < 2048 ? L.max_tiles : 2048;
+  const dim3 cgrid( coop_blocks > 0 ? coop_blocks : 1, L.n_prob );
+  // a short queue is latency-bound by its heaviest tile: give every tile more waves
+  if( L.coop_waves >= 8 ) hipLaunchKernelGGL( k_icp_corr_coop<8>, cgrid, dim3( 8 * WAVE ), 0, st, L );
+  else                    hipLaunchKernelGGL( k_icp_corr_coop<COOP_WAVES>, cgrid, dim3( COOP_BLOCK ), 0, st, L );
+}
+
+} // namespace rs

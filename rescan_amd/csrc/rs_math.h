@@ -1,7 +1,7 @@
 // Small linear algebra with the reference's float arithmetic, operation for operation
 // (column-major float[16], lib/msh/msh_vec_math.h): pose composition and the 6x6 solve of
 // lib/rs/icp.h:267-295.  Compiled for the host (drop-in shim, estimate-only entry point) and, under
-// hipcc, for the device as well: the ICP loop finishes every iteration on the GPU (rs_kernels.hip:
+// hipcc, for the device as well: the ICP loop finishes every iteration on the GPU (the rs_*.hip kernel files:
 // k_icp_update), so no host round trip sits between two searches.
 #pragma once
 #include <cmath>
@@ -211,7 +211,7 @@ RS_HD inline void ldlt6_solve( double A[6][6], const double b[6], double x[6] )
   }
 }
 
-// Finish lib/rs/icp.h:210-298 from the 35 uncentred fp64 moments (layout: rs_kernels.hip, k_icp_moments).
+// Finish lib/rs/icp.h:210-298 from the 35 uncentred fp64 moments (layout: rs_icp_estimate.hip, k_icp_moments).
 // Returns false when the reference would have stopped before estimating (Σw <= 1e-7, icp.h:466).
 // cen (may be null): the two weighted centroids c1, c2 to centre on (6 floats) instead of the moments' own Σw·p / Σw, Σw·q / Σw.
 // The reference's centroids are sequential fp32 sums (icp.h:136-148) and carry a SYSTEMATIC rounding error: once the running

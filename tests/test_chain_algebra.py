@@ -1,4 +1,4 @@
-"""The arithmetic behind the centroid chains (rescan_amd/csrc/rs_kernels.hip, "grid chains"), restated in numpy
+"""The arithmetic behind the centroid chains (rescan_amd/csrc/rs_icp_estimate.hip, "grid chains"), restated in numpy
 and held against the thing itself: a sequential fp32 sum (lib/rs/icp.h:136-148 adds a million weighted points that way).
 
   * inside one binade a sequential fp32 sum is an integer sum: s = M u, RN( s + x ) = ( M + rndne( x / u ) ) u;

@@ -774,7 +774,7 @@ def test_quarter_million_points_vs_oracle(capi, oracle):
 
 
 def test_certificates_change_nothing(capi, monkeypatch):
-    """The gate certificates and the rank certificates (rs_kernels.hip: icp_certificate) only decide which source
+    """The gate certificates and the rank certificates (rs_icp_search.hip: icp_certificate) only decide which source
     points are searched again; the poses and errors must be the same bits with either of them switched off
     (the fp64 estimator sums in a fixed order, the dist² statistics are integer sums).  The same holds for the per-row
     sweep of the warm tiles (sweep_by_rows): which lanes test which candidates is no part of the result."""

@@ -1,6 +1,6 @@
 """RS_HIP_CHAIN_DEBUG=1 python tools/chain_selfcheck_sweep.py 2> log; grep -c differs log
 Whole icp_align runs over rooms of several sizes — as generated, moved to the origin, moved along one axis — with the walks'
-self-check on (every step compared with the plain sum of its chain, rs_kernels.hip: chain_walk_row): any line with "differs" or
+self-check on (every step compared with the plain sum of its chain, rs_icp_estimate.hip: chain_walk_row): any line with "differs" or
 "DIFFERS" in the log is a wrong step."""
 import os, sys, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,10 +1,10 @@
-// Unit test of chain_prefix (rs_kernels.hip: the composition of a run of chain records as three integer prefix scans): random
+// Unit test of chain_prefix (rs_icp_estimate.hip: the composition of a run of chain records as three integer prefix scans): random
 // records per lane — valid ones, identities, never-records — against the sequential composition on the host.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -I rescan_amd/csrc tools/micro/chain_scan_test.hip -o tools/micro/chain_scan_test.bin
 // (History: the first form of this scan composed (lo, hi, D) triples with __builtin_amdgcn_update_dpp moves; the compiler folded
 //  the moves into v_subrev_u32_dpp / v_add_u32_dpp ... bound_ctrl and every row's first lane came out "never" on gfx950 — this
 //  test found it.  The scans are inline assembly now, like wave_scan.)
-#include "../../rescan_amd/csrc/rs_kernels.hip"
+#include "../../rescan_amd/csrc/rs_icp_estimate.hip"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>

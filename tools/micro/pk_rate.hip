@@ -1,5 +1,5 @@
 // Issue rate of v_pk_add_f32 / v_pk_mul_f32 against pairs of v_add_f32 / v_mul_f32 on gfx950, at 1 and at 7 waves per SIMD: is the
-// packed distance test of consider4 (rs_kernels.hip) cheaper than the same arithmetic unpacked?
+// packed distance test of consider4 (rs_search.h) cheaper than the same arithmetic unpacked?
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/micro/pk_rate.hip -o tools/micro/pk_rate.bin && tools/micro/pk_rate.bin
 #include <hip/hip_runtime.h>
 #include <cstdio>

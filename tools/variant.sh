@@ -5,8 +5,12 @@ set -e
 cd "$(dirname "$0")/../rescan_amd"
 tag=$1; shift
 F="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -fPIC -Wall -Wno-unused-function"
-/opt/rocm/bin/hipcc $F "$@" -c csrc/rs_kernels.hip -o /tmp/rs_kernels_$tag.o
-/opt/rocm/bin/hipcc $F "$@" -c csrc/rs_api.hip -o /tmp/rs_api_$tag.o
+objs=""
+for tu in rs_icp_search rs_icp_estimate rs_score rs_rows rs_api; do
+  /opt/rocm/bin/hipcc $F "$@" -c csrc/$tu.hip -o /tmp/${tu}_$tag.o &
+  objs="$objs /tmp/${tu}_$tag.o"
+done
+wait
 [ -f csrc/rs_build.o ] || /opt/rocm/bin/hipcc $F -c csrc/rs_build.hip -o csrc/rs_build.o      # (no experiment flags in the index build; hipCUB: ~20 s)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC /tmp/rs_kernels_$tag.o csrc/rs_build.o /tmp/rs_api_$tag.o -o librescan_hip_$tag.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs csrc/rs_build.o -o librescan_hip_$tag.so
 echo "$(pwd)/librescan_hip_$tag.so"
