@@ -172,6 +172,12 @@ int rs_hip_icp_find_corrs( const rs_hip_cloud_t* source, const rs_hip_cloud_t* t
 int rs_hip_alignment_scores( const rs_hip_cloud_t* object, const rs_hip_cloud_t* scene,
                              const float* poses, int32_t n_poses, float radius, int32_t max_n_neigh,
                              float* scores );
+/* Batches of at least `n_queries` (poses x object points) on a scene with a cell grid take the scene-space route: every transformed
+ * query is keyed by the scene-aligned block it falls in (and the way its normal faces), the keys are radix-sorted, and a wave
+ * searches 64 queries of one block whatever poses they come from — a third of the candidate evaluations of the object-space
+ * launch for the same bits.  Default 65536 (environment RS_HIP_SCORE_SCENE_MIN; RS_HIP_SCORE_SCENE=0: never);
+ * n_queries < 0 only reads.  Returns the previous threshold. */
+int64_t rs_hip_score_scene_space_from( int64_t n_queries );
 
 /* ---- label transfer ----------------------------------------------------------------- */
 

@@ -43,6 +43,7 @@ SIGNATURES = {
     "rs_hip_icp_faith_redone": (C.c_int32, []),
     "rs_hip_icp_faith_guess": (C.c_int32, [C.c_int32]),
     "rs_hip_icp_exact_centroids": (C.c_int32, [C.c_int32]),
+    "rs_hip_score_scene_space_from": (C.c_int64, [C.c_int64]),
     "rs_hip_icp_chains_gave_up": (C.c_int32, []),
     "rs_hip_icp_align_batch": (C.c_int, [C.c_void_p, C.c_void_p, f32p, C.c_int32, f32p, C.c_float, C.c_float,
                                          C.c_int32, C.c_int32, f32p, i32p]),
@@ -247,6 +248,12 @@ def icp_exact_centroids(on=-1):
     """Sources above both thresholds: centre the fp64 step on the reference's own fp32 centroid chains (default on); -1 only
     reads.  Returns the previous setting."""
     return int(load().rs_hip_icp_exact_centroids(int(on)))
+
+
+def score_scene_space_from(n_queries=-1):
+    """Score batches of at least n_queries (poses x object points) take the scene-space route (queries sorted by scene block);
+    -1 only reads.  Returns the previous threshold."""
+    return int(load().rs_hip_score_scene_space_from(int(n_queries)))
 
 
 def icp_chains_gave_up():

@@ -99,6 +99,7 @@ struct Workspace
 {
   DevBuf state, slot, d2, dot, stat_acc, mom_part, res, wexp, queue, queue_count, multi;   // ICP (multi: the per-problem views of a multi-source batch)
   DevBuf poses, score_part, scores;                                             // score
+  DevBuf sq_ka, sq_kb, sq_va, sq_vb, sq_pq, sq_tmp;                             // ... scene-space batches: keys / payloads (ping-pong), per-query terms, sort workspace
   DevBuf plc, labels, mind, fold_off, labels_o, mind_o, rows_o, ids_tab, ids_out, attr_in, attr_out;                 // labels (state in query order; *_o: input order)
   DevBuf q4, rd2, ridx, rnn, rows;                                              // rows / misc
   DevBuf enor, ecount, eoffset, e1, e2, ew;                                     // neighbourhood edges
@@ -1410,6 +1411,14 @@ int rs_hip_icp_estimate_pt2pl( const float* pts1, const float* pts2, const float
 // alignment score
 // ------------------------------------------------------------------------------------------
 
+std::atomic<long long> g_score_scene_from{ getenv( "RS_HIP_SCORE_SCENE_MIN" ) ? atoll( getenv( "RS_HIP_SCORE_SCENE_MIN" ) ) : 65536 };
+int64_t rs_hip_score_scene_space_from( int64_t n_queries )
+{
+  const long long prev = g_score_scene_from.load();
+  if( n_queries >= 0 ) g_score_scene_from.store( n_queries );
+  return prev;
+}
+
 int rs_hip_alignment_scores( const rs_hip_cloud_t* object, const rs_hip_cloud_t* scene,
                              const float* poses, int32_t n_poses, float radius, int32_t max_n_neigh,
                              float* scores )
@@ -1439,7 +1448,7 @@ int rs_hip_alignment_scores( const rs_hip_cloud_t* object, const rs_hip_cloud_t*
   // launch against 406 M without, 0.89 against 0.91 ms — the box a tile sweeps is set by its matched lanes' shells as much as by
   // the unmatched ones' reach, and the counting costs what the smaller boxes save (profiles/r03/score_kcap.txt).
   static const float kcap = getenv( "RS_HIP_SCORE_KCAP" ) ? (float)atof( getenv( "RS_HIP_SCORE_KCAP" ) ) : 0.0f;
-  L.kcap_frac = ( kcap > 0.0f && kcap < 1.0f ) ? kcap : 0.0f;
+  L.kcap_frac = ( kcap > 0.0f && kcap < 1.0f ) ? kcap : ( kcap < 0.0f ? kcap : 0.0f );     // (< 0: the K-cap distance follows the shells, scene-space route only)
   // (Tried in round 4 and removed: a two-radius search — stage 1 within the distance that is expected to hold 1.5 K candidates, only
   //  lanes that neither matched nor counted K going on to the radius.  Exact (the bench's 256 scores stayed the reference's bits) and
   //  slower: 0.99 ms against 0.88 for the batch alone, 897 candidates staged per (tile, pose) wave against 840 — nearly every tile
@@ -1447,23 +1456,97 @@ int rs_hip_alignment_scores( const rs_hip_cloud_t* object, const rs_hip_cloud_t*
   //  what the dense tiles save.  profiles/r04/score_two_radius.txt)
   L.hist = nullptr;
   static DevBuf histbuf;
-  if( RS_DBG && getenv( "RS_HIP_SCORE_HIST" ) && !histbuf.ensure( 6 * 65 * 8 ) ) { (void)hipMemsetAsync( histbuf.p, 0, 6 * 65 * 8, g_stream ); L.hist = histbuf.as<unsigned long long>(); }
-  // the launch grid's y dimension is limited to 65535 poses per launch
-  for( int p0 = 0; p0 < n_poses; p0 += 65535 )
+  if( RS_DBG && getenv( "RS_HIP_SCORE_HIST" ) && !histbuf.ensure( 7 * 65 * 8 ) ) { (void)hipMemsetAsync( histbuf.p, 0, 7 * 65 * 8, g_stream ); L.hist = histbuf.as<unsigned long long>(); }
+  // Scene-space route (rs_score.hip: k_score_scene) for batches on a cell grid that are worth a sort: every query keyed by the
+  // scene-aligned block it lands in.  RS_HIP_SCORE_SCENE=0 turns it off, RS_HIP_SCORE_SCENE_MIN sets the batch size it starts at.
+  static const int scene_route = getenv( "RS_HIP_SCORE_SCENE" ) ? atoi( getenv( "RS_HIP_SCORE_SCENE" ) ) : 1;
+  const long long scene_min = g_score_scene_from.load();
+  static const float parent_scale = getenv( "RS_HIP_SCORE_PARENT" ) ? (float)atof( getenv( "RS_HIP_SCORE_PARENT" ) ) : 1.0f;   // parent edge / radius
+  static const int merge_below = getenv( "RS_HIP_SCORE_MERGE" ) ? atoi( getenv( "RS_HIP_SCORE_MERGE" ) ) : 0;
+  int chunk_poses = 65535;      // the launch grid's y dimension is limited to 65535 poses per launch
+  const bool scene_space = scene_route && L.scene.inv_cell > 0.0f && !L.by_rows &&
+                           (long long)n_poses * object->n >= scene_min && object->n < ( 1 << 24 );
+  if( scene_space )
+  {
+    const GridView& g = L.scene;
+    static const int nbin = getenv( "RS_HIP_SCORE_NBIN" ) ? atoi( getenv( "RS_HIP_SCORE_NBIN" ) ) : 2;
+    static const int cull = getenv( "RS_HIP_SCORE_CULL" ) ? atoi( getenv( "RS_HIP_SCORE_CULL" ) ) : 1;
+    // the scene grid's box grown by the radius: a query outside has nothing to match ...
+    float lo[3] = { g.minx - radius, g.miny - radius, g.minz - radius };
+    float hi[3] = { g.minx + g.w * g.cell + radius, g.miny + g.h * g.cell + radius, g.minz + g.d * g.cell + radius };
+    L.sq_lox = lo[0]; L.sq_hix = hi[0]; L.sq_loy = lo[1]; L.sq_hiy = hi[1]; L.sq_loz = lo[2]; L.sq_hiz = hi[2];
+    // ... and the parent lattice only spans where queries CAN fall: the object's box under every pose, cut to that box (fewer key
+    // bits: a radix pass less).  The object's own grid spans its bounding box; a brute-layout object falls back to the scene's box.
+    const GridView& og = object->view;
+    if( og.inv_cell > 0.0f )
+    {
+      float qlo[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, qhi[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+      const float omin[3] = { og.minx, og.miny, og.minz }, omax[3] = { og.minx + og.w * og.cell, og.miny + og.h * og.cell, og.minz + og.d * og.cell };
+      bool finite = true;
+      for( int p = 0; p < n_poses; ++p )
+        for( int c = 0; c < 8; ++c )
+        {
+          const float x = ( c & 1 ) ? omax[0] : omin[0], y = ( c & 2 ) ? omax[1] : omin[1], z = ( c & 4 ) ? omax[2] : omin[2];
+          const float* M = poses + (size_t)p * 16;
+          for( int a = 0; a < 3; ++a )
+          {
+            const float v = M[a] * x + M[4 + a] * y + M[8 + a] * z + M[12 + a];
+            if( !std::isfinite( v ) ) finite = false;
+            qlo[a] = std::min( qlo[a], v ); qhi[a] = std::max( qhi[a], v );
+          }
+        }
+      if( finite )
+        for( int a = 0; a < 3; ++a )
+        {
+          const float pad = 1e-3f + 1e-5f * std::max( std::fabs( qlo[a] ), std::fabs( qhi[a] ) );      // (rounding of the corner transforms; the key only groups anyway)
+          lo[a] = std::max( lo[a], qlo[a] - pad ); hi[a] = std::min( hi[a], qhi[a] + pad );
+          if( hi[a] < lo[a] ) hi[a] = lo[a];
+        }
+    }
+    // parent edge: the radius, as a whole number of cells (a coarser grid: its cell); doubled until the lattice has < 2^24 / 64 parents
+    float parent = g.cell * std::max( 1.0f, roundf( parent_scale * radius / g.cell ) );
+    const int fine_bits = nbin == 3 ? 3 : 6;
+    for( ;; parent *= 2.0f )
+    {
+      L.sq_dpx = (int)ceilf( ( hi[0] - lo[0] ) / parent ) + 1; L.sq_dpy = (int)ceilf( ( hi[1] - lo[1] ) / parent ) + 1; L.sq_dpz = (int)ceilf( ( hi[2] - lo[2] ) / parent ) + 1;
+      const double total = (double)L.sq_dpx * L.sq_dpy * L.sq_dpz;
+      if( total < (double)( 1 << 24 ) ) { L.sq_n_parents = (int)total; break; }
+    }
+    L.sq_ox = lo[0]; L.sq_oy = lo[1]; L.sq_oz = lo[2];
+    int bits = 0;
+    while( ( 1ll << bits ) <= ( (long long)L.sq_n_parents << fine_bits ) ) ++bits;      // the "nothing to match" key n_parents << fine_bits sorts last
+    L.sq_bits = bits; L.sq_fine_bits = fine_bits; L.sq_inv_fine = 4.0f / parent; L.sq_merge = merge_below; L.sq_nbin = nbin; L.sq_cull = cull;
+    chunk_poses = (int)std::min<long long>( 65535, std::max<long long>( 1, ( 1ll << 30 ) / object->n ) );
+    const size_t items = (size_t)std::min( chunk_poses, n_poses ) * object->n;
+    const size_t tmp_bytes = build_sort_temp_bytes( (int)items, bits );
+    if( ( rc = g_ws.sq_ka.ensure( items * 4 ) ) || ( rc = g_ws.sq_kb.ensure( items * 4 ) ) || ( rc = g_ws.sq_va.ensure( items * 4 ) ) ||
+        ( rc = g_ws.sq_vb.ensure( items * 4 ) ) || ( rc = g_ws.sq_pq.ensure( items * 8 ) ) || ( rc = g_ws.sq_tmp.ensure( tmp_bytes ) ) )
+      return rc;
+    L.sq_key_a = g_ws.sq_ka.as<uint32_t>(); L.sq_key_b = g_ws.sq_kb.as<uint32_t>(); L.sq_val_a = g_ws.sq_va.as<uint32_t>(); L.sq_val_b = g_ws.sq_vb.as<uint32_t>();
+    L.sq_pq = g_ws.sq_pq.as<double>(); L.sq_tmp = g_ws.sq_tmp.p; L.sq_tmp_bytes = g_ws.sq_tmp.cap;
+  }
+  else if( L.kcap_frac < 0.0f ) L.kcap_frac = 0.0f;
+  for( int p0 = 0; p0 < n_poses; p0 += chunk_poses )
   {
     ScoreLaunch Lp = L;
-    Lp.n_poses = std::min( 65535, n_poses - p0 );
+    Lp.n_poses = std::min( chunk_poses, n_poses - p0 );
     Lp.poses = L.poses + (size_t)p0 * 16; Lp.part = L.part + (size_t)p0 * n_tiles; Lp.scores = L.scores + p0;
     ProfScope ps( "nn_score" );
     launch_score( Lp, g_stream );
   }
   HIP_TRY( hipMemcpyAsync( scores, g_ws.scores.p, (size_t)n_poses * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
   HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
-  if( L.hist )
+  if( L.hist && n_poses >= 256 )
   {
-    std::vector<unsigned long long> h( 6 * 65 );
+    std::vector<unsigned long long> h( 7 * 65 );
     (void)hipMemcpy( h.data(), L.hist, h.size() * 8, hipMemcpyDeviceToHost );
-    unsigned long long all = 0; for( auto v : h ) all += v;
+    unsigned long long all = 0; for( size_t k = 0; k < 6 * 65; ++k ) all += h[k];
+    {
+      unsigned long long ns = 0, nl = 0, b[5] = { 0, 0, 0, 0, 0 };
+      for( int u = 0; u <= 64; ++u ) { ns += h[6 * 65 + u]; nl += h[6 * 65 + u] * u; b[u <= 4 ? 0 : u <= 8 ? 1 : u <= 16 ? 2 : u <= 32 ? 3 : 4] += h[6 * 65 + u]; }
+      if( ns ) fprintf( stderr, "[rs_hip score hist] scene-space searches %llu, %.1f lanes each | by lanes 1-4: %4.1f %%  5-8: %4.1f %%  9-16: %4.1f %%  17-32: %4.1f %%  33-64: %4.1f %%\n", ns, (double)nl / ns,
+                        100.0 * b[0] / ns, 100.0 * b[1] / ns, 100.0 * b[2] / ns, 100.0 * b[3] / ns, 100.0 * b[4] / ns );
+    }
     fprintf( stderr, "[rs_hip score hist] candidates streamed %llu (rows 0-4: shells, by the lanes the shell is swept for; row 5: the rank pass, by the lanes that need their rank)\n", all );
     for( int sh = 0; sh < 6; ++sh )
     {

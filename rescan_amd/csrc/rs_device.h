@@ -209,6 +209,25 @@ struct ScoreLaunch
   int          by_rows;    // launches that hand nothing off: the row-wise cold search (rs_search.h: tile_search_rows)
   float        kcap_frac;  // K-cap distance² as a fraction of radius² (rs_search.h: KCap); 0: off
   unsigned long long* hist;   // diagnostic builds only (RS_HIP_SCORE_HIST): 6 x 65 counters, see k_score
+  // Scene-space batches (rs_score.hip: k_score_keys / k_score_scene / k_score_gather): the n_poses x n transformed queries sorted by
+  // the scene-aligned block ("parent", edge sq_parent ~ the radius) they fall in, so that a wave's queries share one neighbourhood
+  // whatever pose they come from.  sq_key_a == null: the object-space launch (k_score).
+  uint32_t*    sq_key_a;   // items: keys as computed (parent index << sq_fine_bits | direction of the normal, octant of the parent); sq_n_parents << sq_fine_bits = no candidate can exist
+  uint32_t*    sq_key_b;   // ... sorted
+  uint32_t*    sq_val_a;   // items: pose * n + query slot
+  uint32_t*    sq_val_b;
+  double*      sq_pq;      // n_poses x n: score of every (pose, query slot)
+  void*        sq_tmp;     // radix sort workspace
+  size_t       sq_tmp_bytes;
+  int          sq_bits;    // key bits to sort
+  int          sq_fine_bits;   // low key bits below the parent index (6, or 3: direction only)
+  int          sq_n_parents, sq_dpx, sq_dpy, sq_dpz;
+  float        sq_ox, sq_oy, sq_oz;     // origin of the parent lattice (the scene grid's, moved out by whole parents)
+  float        sq_inv_fine;             // 4 / parent edge
+  float        sq_lox, sq_hix, sq_loy, sq_hiy, sq_loz, sq_hiz;   // the scene grid's box grown by the radius: a query outside has nothing to match
+  int          sq_merge;   // > 0: a parent with at most this many queries in the wave is searched together with its x-neighbour's
+  int          sq_cull;    // sweeps skip the cells farther from the wave's queries than they look (rs_search.h: Cull)
+  int          sq_nbin;    // the key's low bits also carry the query normal's dominant direction (0: off)
 };
 void launch_score( const ScoreLaunch& L, hipStream_t st );
 

@@ -366,9 +366,18 @@ struct EvalScope
 // dist² is +inf: they can never be "within the radius", so f needs no validity test.
 // When several waves sweep the same shell together, wave `share` of `n_share` takes the chunks
 // whose running number is congruent to it.
+// `cull` (optional): the lanes the sweep is for lie in the box [lx,hx] x [ly,hy] x [lz,hz] and none of them looks farther than
+// sqrt( R2 ) — a cell farther than that from the box holds nothing for them, so a (y,z) row of cells beyond it is skipped and the
+// others are clipped in x to what the remaining distance allows: the swept volume is the box grown by a BALL, not by a cube
+// (two thirds of it for a 5 cm tile and a 10 cm reach; half and less of a surface that passes the tile at a distance).
+struct Cull { float lx, hx, ly, hy, lz, hz, R2; };
+#ifndef RS_SWEEP_CENTER_OUT
+#define RS_SWEEP_CENTER_OUT 1
+#endif
 template <bool WITH_NOR, class F>
 __device__ __forceinline__ uint32_t sweep_shell( const GridView& g, const CellBox& out, const CellBox& in, bool in_valid,
-                                                 WaveLds& L, int lane, int share, int n_share, F&& f, uint32_t give_up_from = 0xffffffffu )
+                                                 WaveLds& L, int lane, int share, int n_share, F&& f, uint32_t give_up_from = 0xffffffffu,
+                                                 const bool culled = false, const Cull cull = Cull{} )
 {
   const int ny = out.y1 - out.y0 + 1, nz = out.z1 - out.z0 + 1;
   const int n_rows = ny * nz;
@@ -388,16 +397,42 @@ __device__ __forceinline__ uint32_t sweep_shell( const GridView& g, const CellBo
       int rz = (int)( (float)r * inv_ny );
       rz -= ( rz * ny > r ) ? 1 : 0;
       rz += ( ( rz + 1 ) * ny <= r ) ? 1 : 0;
-      const int y = out.y0 + ( r - rz * ny ), z = out.z0 + rz;
+      int y = out.y0 + ( r - rz * ny ), z = out.z0 + rz;
+      if( culled && RS_SWEEP_CENTER_OUT )
+      {
+        // rows from the middle of the box outwards (c, c + 1, c - 1, c + 2, ...; z slowest): the nearest candidates arrive first, the
+        // lanes' bounds are tight before the bulk comes — fewer candidates pass the bound test (no gate for them) and fewer are
+        // counted as "closer than the match so far", the count that decides whether a rank pass is needed
+        const int iy = r - rz * ny, cy = ( out.y0 + out.y1 ) >> 1, cz = ( out.z0 + out.z1 ) >> 1;
+        y = cy + ( ( iy & 1 ) ? ( ( iy + 1 ) >> 1 ) : -( iy >> 1 ) );
+        z = cz + ( ( rz & 1 ) ? ( ( rz + 1 ) >> 1 ) : -( rz >> 1 ) );
+      }
       const uint32_t* cs = g.cell_start + (size_t)( z * g.h + y ) * g.w;
       const bool inside = in_valid && y >= in.y0 && y <= in.y1 && z >= in.z0 && z <= in.z1;
-      if( !inside ) { sa = cs[out.x0]; la = cs[out.x1 + 1] - sa; }
+      int cx0 = out.x0, cx1 = out.x1;
+      if( culled )
+      {
+        // distance of the row's cells from the lanes' box in y and z (cell faces as box_cover computes them; R2 carries the margin)
+        const float y_lo = g.miny + (float)y * g.cell, y_hi = g.miny + (float)( y + 1 ) * g.cell;
+        const float z_lo = g.minz + (float)z * g.cell, z_hi = g.minz + (float)( z + 1 ) * g.cell;
+        const float dy = fmaxf( fmaxf( cull.ly - y_hi, y_lo - cull.hy ), 0.0f ), dz = fmaxf( fmaxf( cull.lz - z_hi, z_lo - cull.hz ), 0.0f );
+        const float rem = cull.R2 - ( dy * dy + dz * dz );
+        if( rem > 0.0f )
+        {
+          int a, b;
+          axis_range( cull.lx, cull.hx, sqrtf( rem ), g.minx, g.inv_cell, g.w, a, b );
+          cx0 = max( cx0, a ); cx1 = min( cx1, b );
+        }
+        else cx1 = cx0 - 1;
+      }
+      if( cx1 < cx0 ) { }
+      else if( !inside ) { sa = cs[cx0]; la = cs[cx1 + 1] - sa; }
       else
       {
         // the row minus in's x-range (which may stick out of, or miss, out's)
-        const int a1 = min( in.x0 - 1, out.x1 ), b0 = max( in.x1 + 1, out.x0 );
-        if( a1 >= out.x0 ) { sa = cs[out.x0]; la = cs[a1 + 1] - sa; }
-        if( b0 <= out.x1 ) { sb = cs[b0]; lb = cs[out.x1 + 1] - sb; }
+        const int a1 = min( in.x0 - 1, cx1 ), b0 = max( in.x1 + 1, cx0 );
+        if( a1 >= cx0 ) { sa = cs[cx0]; la = cs[a1 + 1] - sa; }
+        if( b0 <= cx1 ) { sb = cs[b0]; lb = cs[cx1 + 1] - sb; }
       }
     }
     const uint32_t incl = wave_scan( la + lb, lane );
@@ -820,7 +855,16 @@ __device__ __forceinline__ CellBox box_clip( const CellBox& a, const CellBox& c 
 // any other tile is handed off at once (*handoff) — the cooperative kernel gives it a workgroup straight away instead of
 // after a lone wave's first shells, and this instantiation carries no shell loop (registers: phase A then fits 6 waves per
 // SIMD without scratch).
-template <bool GATED, bool WARM = false, bool BOUNDED_ONLY = false, bool KCAP = false>
+// The lanes of `mask`, their common box and farthest reach, for sweep_shell's culling.
+__device__ __forceinline__ Cull cull_of( const GridView& g, bool mask, float reach, float qx, float qy, float qz )
+{
+  const TileBounds t = wave_bounds( mask, qx, qy, qz );
+  const float R = wave_max( mask ? reach : 0.0f ) + ( 1e-4f * g.cell + 2e-5f );      // (the margin of box_cover: far above the rounding of the cell faces and of the binning)
+  Cull c; c.lx = t.lx; c.hx = t.hx; c.ly = t.ly; c.hy = t.hy; c.lz = t.lz; c.hz = t.hz; c.R2 = R * R;
+  return c;
+}
+
+template <bool GATED, bool WARM = false, bool BOUNDED_ONLY = false, bool KCAP = false, bool CULL = false>
 __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
                                               float qx, float qy, float qz, float nx, float ny, float nz,
                                               float radius, float radius_sq, float tmin, int K,
@@ -890,14 +934,28 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
   // own box [q - reach, q + reach] touches has then been examined (its reach only shrinks), which is all the
   // cover test below relies on.
   bool unsettled = active;
-  for( int k = 0; ; k = k ? 2 * k : 1 )
+  // KCAP with kcap_frac < 0: the K-cap distance follows the shells — while box k is swept a lane counts what lies within ITS cover
+  // distance of box k (what it counted within the smaller covers before stays counted); K of them settle the lane whatever it holds:
+  // anything outside the box is farther than all K.  -1: the doubling ladder, -2: one more ring of cells per shell.
+  const bool shell_cap = KCAP && kcap_frac < 0.0f;
+  const bool linear = shell_cap && kcap_frac < -1.5f;
+  for( int k = 0; ; k = k ? ( linear ? k + 1 : 2 * k ) : 1 )
   {
     cur = grid ? box_grow( core, k, full ) : full;
+    if( shell_cap )
+    {
+      const float ck = box_same( cur, full ) ? -1.0f : box_cover( g, cur, full, qx, qy, qz );
+      cap.tau2 = ck > 0.0f ? fminf( ck * ck, radius_sq ) : ( box_same( cur, full ) ? radius_sq : 0.0f );
+    }
     const CellBox out = grid ? reach_box( g, cur, unsettled, reach(), qx, qy, qz ) : full;
     if( dbg_unsettled && sweeps < 5 ) { dbg_unsettled[4 + 2 * sweeps] = __popcll( __ballot( unsettled ) ); dbg_unsettled[5 + 2 * sweeps] = -(int)streamed; }     // [4 + 2 s]: lanes shell s is swept for, [5 + 2 s]: candidates it streamed
     if( !box_empty( out ) )
+    {
+      Cull cl{};
+      if( CULL && grid ) cl = cull_of( g, unsettled, reach(), qx, qy, qz );
       streamed += sweep_shell<GATED>( g, out, prev, have_prev, L, lane, 0, 1, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
-      { consider4<GATED, WARM, KCAP>( X, Y, Z, k4, L, qx, qy, qz, nx, ny, nz, tmin, bound, m, seen_closer, &cap, K ); } );
+      { consider4<GATED, WARM, KCAP>( X, Y, Z, k4, L, qx, qy, qz, nx, ny, nz, tmin, bound, m, seen_closer, &cap, K ); }, 0xffffffffu, CULL && grid, cl );
+    }
     if( dbg_unsettled ) { dbg_unsettled[1] = (int)streamed; if( sweeps < 5 ) dbg_unsettled[5 + 2 * sweeps] += (int)streamed; }
     ++sweeps;
     if( n_sweeps ) *n_sweeps = sweeps;
@@ -937,12 +995,14 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
       const CellBox rb = reach_box( g, cur, need_rank, reach_of( m, radius ), qx, qy, qz );
       uint32_t rs = 0;
       RankBands rbands = rank_bands( m );
+      Cull cl{};
+      if( CULL && grid ) cl = cull_of( g, need_rank, reach_of( m, radius ), qx, qy, qz );
       if( !box_empty( rb ) )
       rs = sweep_shell<false>( g, rb, rb, false, L, lane, 0, 1, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
       {
         if( WARM ) { const int c = precede4_bands( X, Y, Z, k4, L, qx, qy, qz, radius_sq, m.d2, m.idx, rbands ); rank += need_rank ? c : 0; }
         else rank += need_rank ? precede4( X, Y, Z, k4, L, qx, qy, qz, radius_sq, m.d2, m.idx ) : 0;
-      } );
+      }, 0xffffffffu, CULL && grid, cl );
       if( dbg_unsettled ) { dbg_unsettled[2] = (int)rs; dbg_unsettled[15] = __popcll( __ballot( need_rank ) ); }
       if( need_rank && rank >= K ) { m.found = false; m.slot = -1; if( WARM ) m.rank_slack = rank_slack_of( rbands, K ); }
       ++sweeps;

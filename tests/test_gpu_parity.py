@@ -452,6 +452,47 @@ def test_scores_vs_golden(capi, scene_clouds, fname):
         assert np.abs(sc.astype(np.float64) - g["scores"]).max() < SCORE_TOL
 
 
+@pytest.mark.parametrize("fname", golden_files("scores_"))
+def test_scores_scene_space_route_vs_golden(capi, scene_clouds, fname):
+    """The same fixtures through the scene-space route (queries sorted by scene block and normal direction, k_score_scene), which
+    batches this small would not take by themselves: the reference's scores, and the object-space route's bits."""
+    g = load_golden(fname)
+    clouds, objs = scene_clouds
+    for cell in (0.05, 0.1, 0.075):
+        a = capi.alignment_scores(objs[int(g["obj"])], clouds[cell], g["poses"], 0.1, int(g["k"]))
+        prev = capi.score_scene_space_from(0)
+        try:
+            b = capi.alignment_scores(objs[int(g["obj"])], clouds[cell], g["poses"], 0.1, int(g["k"]))
+        finally:
+            capi.score_scene_space_from(prev)
+        assert np.abs(b.astype(np.float64) - g["scores"]).max() < SCORE_TOL
+        assert (a == b).all()
+
+
+def test_scores_scene_space_route_edge_cases(capi, scene_clouds):
+    """Poses that put the object outside the scene, far outside, and non-finite poses: both routes agree bit for bit (NaN scores
+    included)."""
+    clouds, objs = scene_clouds
+    rng = np.random.default_rng(7)
+    I4 = np.eye(4, dtype=np.float32)
+    poses = []
+    for shift in (0.0, 0.3, 3.0, 50.0, 1e6):
+        m = I4.copy(); m[3, :3] = rng.uniform(-1, 1, 3) * shift; poses.append(m.ravel())
+    m = I4.copy(); m[3, 0] = np.nan; poses.append(m.ravel())
+    m = I4.copy(); m[3, 1] = np.inf; poses.append(m.ravel())
+    poses = np.stack(poses).astype(np.float32)
+    for cell in (0.05, 0.1, 0.075):
+        a = capi.alignment_scores(objs[0], clouds[cell], poses, 0.1, 64)
+        prev = capi.score_scene_space_from(0)
+        try:
+            b = capi.alignment_scores(objs[0], clouds[cell], poses, 0.1, 64)
+            c = capi.alignment_scores(objs[0], clouds[cell], poses[:1], 0.05, 32)
+        finally:
+            capi.score_scene_space_from(prev)
+        assert (a.view(np.uint32) == b.view(np.uint32)).all(), (a, b)
+        assert (c == capi.alignment_scores(objs[0], clouds[cell], poses[:1], 0.05, 32)).all()
+
+
 # ---- label transfer ----------------------------------------------------------------------
 
 @pytest.mark.parametrize("fname", golden_files("labels_"))
