@@ -287,6 +287,9 @@ __global__ __launch_bounds__( PA_WAVES * WAVE, BOUNDED_ONLY ? RS_ICP_WARM_OCC : 
   uint32_t streamed = 0;
   int unsettled[16] = { 0 };
   const Match init = icp_warm_start( L, prob, i, active, qx, qy, qz, nx, ny, nz );
+  // (Round 5, a timing experiment before building "match certificates" — skip the sweep of every lane whose previous match is still
+  //  usable, results approximate: the warm launch stayed at 67 us and the cooperative one at 36-40.  The warm search is bound by what it
+  //  moves per point — source point, previous match, record, certificate: ~150 B — not by its sweeps; profiles/r05/skip_matched_experiment.txt.)
   const bool search = active & !icp_certificate( L, prob, i, active & !init.found, qx, qy, qz, nx, ny, nz );
   // thresholds in candidates: as given up to a mean of HEAVY_MEAN_REF candidates per tile in the previous launch, growing with it
   // beyond (the factor, in 1/256ths, was worked out when that iteration ended: icp_iteration_reset)
