@@ -56,14 +56,16 @@ N_PLACEMENTS = 8
 I4 = np.eye(4, dtype=np.float32).ravel()
 
 
-def build_inputs(n_points, seed, units=1, centre=False):
+def build_inputs(n_points, seed, units=1, centre=False, t0=0):
     """The step's inputs as numpy arrays only (no device): tests/golden/bench_seed11.npz pins the reference's
     outputs for exactly these (oracle/gen_golden_bench.py imports this function in the build container).
     units > 1 (sharded multi-GPU route): the unit lists are `units` times as long — further ICP start poses, score
     poses and placements of the same scene and objects, drawn after the first unit's, which stays what it is."""
     from rescan_amd import synth
-    s0 = synth.scene_for_point_count(int(n_points * 0.84), seed=seed, timestep=0)
-    s1 = synth.scene_for_point_count(int(n_points * 0.84), seed=seed, timestep=1)
+    # (t0 > 0, --timesteps T: the pair (t0, t0 + 1) of the same sequence — the room after the furniture was moved again; the random
+    #  draws below are the pair's own.  t0 = 0 is the workload the fixtures pin.)
+    s0 = synth.scene_for_point_count(int(n_points * 0.84), seed=seed, timestep=t0)
+    s1 = synth.scene_for_point_count(int(n_points * 0.84), seed=seed, timestep=t0 + 1)
     if centre:
         # the whole world moved so that the scan's median point is the origin: coordinates of both signs — the reference's fp32
         # centroid sums then hover around zero instead of growing, the regime the grid chains give up in (DESIGN.md §4)
@@ -74,7 +76,7 @@ def build_inputs(n_points, seed, units=1, centre=False):
                 q["pose"] = q["pose"].copy(); q["pose"][12:15] += sh
     w = {}
     w["s0"], w["s1"] = s0, s1
-    rng = np.random.default_rng(seed + 5)
+    rng = np.random.default_rng(seed + 5 + 100000 * t0)
     w["icp_T0"] = synth.perturbed_pose(I4, rng, 0.01, 0.01)
     # score object: a table model resampled to ~10k points
     op, on = synth.make_object("table", seed * 13 + 1, density=3800.0)
@@ -89,7 +91,7 @@ def build_inputs(n_points, seed, units=1, centre=False):
         plc.append(dict(np=(lp, ln), pose=synth.perturbed_pose(o["pose"], rng, 0.01, 0.005), cls=o["class_idx"]))
     w["icp_T0s"] = [w["icp_T0"]]
     for u in range(1, units):
-        rng_u = np.random.default_rng(seed + 5 + 1000 * u)
+        rng_u = np.random.default_rng(seed + 5 + 1000 * u + 100000 * t0)
         w["icp_T0s"].append(synth.perturbed_pose(I4, rng_u, 0.01, 0.01))
         w["score_poses"] = np.concatenate([w["score_poses"], np.stack([synth.perturbed_pose(tbl["pose"], rng_u, 0.6, 0.25) for _ in range(N_POSES)])])
         for k in range(N_PLACEMENTS):
@@ -106,10 +108,10 @@ def build_inputs(n_points, seed, units=1, centre=False):
     return w
 
 
-def build_workload(n_points, seed, knn, units=1, centre=False):
+def build_workload(n_points, seed, knn, units=1, centre=False, t0=0):
     """build_inputs + the device-resident clouds (inputs are in HBM before the timed region starts)."""
     from rescan_amd import capi
-    w = build_inputs(n_points, seed, units, centre)
+    w = build_inputs(n_points, seed, units, centre, t0)
     cell = float(os.environ.get("RS_BENCH_CELL", "-1")) if knn == "hash" else 0.0
     s0, s1 = w["s0"], w["s1"]
     w["scan0"] = capi.Cloud(s0["points"], s0["normals"], cell_size=cell)      # ICP target
@@ -469,6 +471,9 @@ class Sharded:
     Two send / receive buffer sets: the exchange of step s (copy of the small results, all-gather, fold, download of the
     folded labels) runs on its own host thread while step s + 1 computes into the other set."""
 
+    _xs = None
+    _xs_bound = False
+
     def __init__(self, w, dist, dev, rank, world, strong=False):
         import torch
         from rescan_amd import dist as rd
@@ -496,8 +501,10 @@ class Sharded:
             self.bufs.append((send, recv, small, out))
         # the exchange thread's stream: non-blocking (see exchange) and of high priority — its few kernels (copy, collective, fold) are
         # dispatched ahead of the next step's tens of thousands of queued workgroups instead of behind them
-        self.xs = torch.cuda.Stream(device=dev, priority=-1) if not os.environ.get("RS_BENCH_XCH_DEFAULT_STREAM") else torch.cuda.default_stream(dev)   # (the variable: A/B of the above)
-        self.xs_bound = False
+        # (one such stream per process: --timesteps > 2 makes one Sharded per pair of scans, and they share the exchange thread)
+        if Sharded._xs is None:
+            Sharded._xs = torch.cuda.Stream(device=dev, priority=-1) if not os.environ.get("RS_BENCH_XCH_DEFAULT_STREAM") else torch.cuda.default_stream(dev)   # (the variable: A/B of the above)
+        self.xs = Sharded._xs
         self.step_index = 0
         self.stat_from = 0
         self.t_compute = self.t_wait = 0.0
@@ -524,9 +531,9 @@ class Sharded:
             if self.dist is not None:
                 all_gather_flat(self.dist, recv, send)
         self.xs.synchronize()
-        if not self.xs_bound:
+        if not Sharded._xs_bound:
             capi.set_stream(self.xs.cuda_stream)         # the library's work of this thread (the fold) goes to the same stream
-            self.xs_bound = True
+            Sharded._xs_bound = True
         t1 = time.perf_counter()
         with torch.cuda.stream(self.xs):                 # (its read-back of the small blocks is a torch copy: same stream, same reason)
             out = rd.shard_fold(capi, self.lay, recv, outbuf, scene=self.w["scan1"])
@@ -720,6 +727,46 @@ def cpu_baseline(w, budget_s=20.0):
     return out
 
 
+def launch_ranks(n, argv, dry_run=False):
+    """Starts bench.py once per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as under torch.distributed.run, rendezvous on
+    127.0.0.1), relays rank 0's stdout — the ONE JSON line — and every rank's stderr, and returns the worst exit code.  The children
+    are new processes started from a parent that never initialised the GPU; a rank that fails takes the others down with it
+    (by PID), so a hung collective cannot outlive the failure."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    argv = [a for a in argv if a != "--launch-dry-run"]
+    plans = []
+    for r in range(n):
+        env = dict(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"),
+                   MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        plans.append(dict(cmd=[sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    if dry_run:
+        print(json.dumps(dict(launcher="bench.py", ranks=plans)))
+        return 0
+    procs = []
+    for r, pl in enumerate(plans):
+        procs.append(subprocess.Popen(pl["cmd"], env=dict(os.environ, **pl["env"]), stdout=None if r == 0 else sys.stderr))
+    worst, live = 0, set(range(n))
+    while live:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0:
+                worst = worst or rc
+                print("bench.py launcher: rank %d exited with %d, stopping the others" % (r, rc), file=sys.stderr)
+                for q in live:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    return worst if worst >= 0 else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -736,7 +783,33 @@ def main():
                     help="strong: ONE fixed scene (8 per-placement ICP problems, 256 score poses, 8 placements) sharded over the ranks; total work does not grow with --gpus")
     ap.add_argument("--centre", action="store_true",
                     help="the same scene moved so that its median point is the origin (coordinates of both signs): times the estimator's fallback for centroid sums that hover around zero; no reference fixture, parity not compared")
+    ap.add_argument("--timesteps", type=int, default=2,
+                    help="scans of the sequence (BASELINE configs[3]: 4): a step then covers every consecutive pair (t, t + 1) — T - 1 times the unit lists, "
+                         "each pair its own two scans, object poses and placements")
+    ap.add_argument("--launch-dry-run", action="store_true",
+                    help="--gpus N > 1 without a launcher: print the N ranks' command and environment as JSON instead of starting them")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as the driver may type it: this process becomes the launcher — it has not touched the GPU (no
+        # torch, no HIP yet) — and starts one FRESH process per GPU with the environment torch.distributed.run would give them.
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], dry_run=args.launch_dry_run))
+
+    if os.environ.get("RS_BENCH_LAUNCH_SELFTEST"):
+        # CPU rehearsal of the launcher (tests/test_bench_launcher.py): the ranks it started find each other (gloo over 127.0.0.1) and
+        # sum their ranks; "fail<r>": rank r dies first, the launcher must stop the others and hand its exit code on
+        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        if os.environ["RS_BENCH_LAUNCH_SELFTEST"] == "fail%d" % rank:
+            sys.exit(3)
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        t = torch.tensor([rank + 1])
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"selftest": int(t.item()), "world": world, "gpus": args.gpus}))
+        dist.destroy_process_group()
+        return
 
     # stdout carries the ONE JSON line and nothing else: whatever libraries print there (RCCL's version banner at the first
     # collective) goes to stderr for the duration of the run
@@ -749,8 +822,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (start it plainly — it launches its own ranks — or under torch.distributed.run with --nproc-per-node equal to --gpus)" % (args.gpus, world))
     # (RS_BENCH_ONE_DEVICE=1: rehearsal of the multi-rank plumbing on a ONE-GPU box — every rank on device 0, exchange over gloo)
     one_device = bool(os.environ.get("RS_BENCH_ONE_DEVICE"))
     if one_device:
@@ -776,11 +848,15 @@ def main():
     sharded = args.shard or strong or (world > 1 and not args.replicas)
     seed = 11 if sharded else 11 + rank
     units = 1 if strong else (world if sharded else 1)
-    w = build_workload(args.points, seed=seed, knn=args.knn, units=units, centre=args.centre)
-    if strong:      # the step's ICP units are the 8 per-placement problems: model points x iterations
-        w["pairs"] = dict(icp=ICP_ITERS * sum(len(p["np"][0]) for p in w["plc"][:N_PLACEMENTS]), score=w["pairs"]["score"], label=w["pairs"]["label"])
+    n_pairs = max(1, args.timesteps - 1)
+    W = [build_workload(args.points, seed=seed, knn=args.knn, units=units, centre=args.centre, t0=k) for k in range(n_pairs)]
+    for wk in W:
+        if strong:      # the step's ICP units are the 8 per-placement problems: model points x iterations
+            wk["pairs"] = dict(icp=ICP_ITERS * sum(len(p["np"][0]) for p in wk["plc"][:N_PLACEMENTS]), score=wk["pairs"]["score"], label=wk["pairs"]["label"])
+    w = W[0]
     dist_ctx = (dist, dev) if dist is not None else None
-    sh = Sharded(w, dist, dev, rank, world, strong=strong) if sharded else None
+    SH = [Sharded(wk, dist, dev, rank, world, strong=strong) for wk in W] if sharded else None
+    sh = SH[0] if sharded else None
 
     def barrier():
         if dist is not None:
@@ -788,28 +864,35 @@ def main():
         torch.cuda.synchronize()
 
     conc = not args.serial
-    last = None
+    last = None            # the newest results of the FIRST pair (the one the fixtures pin)
+    in_flight = []         # sharded route: pair whose exchange is under way
 
     def one_step():
+        """One pass over the sequence: every consecutive pair of scans in turn (one pair at --timesteps 2)."""
         nonlocal last
-        if sh is not None:
-            r = sh.step(conc)
-            if r is not None:
-                last = r
-        else:
-            last = run_step(w, dist_ctx, conc)
+        for k in range(n_pairs):
+            if SH is not None:
+                r = SH[k].step(conc)                # (returns the results of the exchange that was in flight: the pair before)
+                if r is not None and in_flight and in_flight[-1] == 0:
+                    last = r
+                in_flight[:] = [k]
+            else:
+                r = run_step(W[k], dist_ctx, conc)
+                if k == 0:
+                    last = r
 
     def drain():
         nonlocal last
         r = exchange_wait()                         # the last step's exchange belongs to the timed region
-        if sh is not None and r is not None:
+        if SH is not None and r is not None and in_flight and in_flight[-1] == 0:
             last = r
+        in_flight[:] = []
 
     for _ in range(args.warmup):
         one_step()
     drain()
-    if sh is not None:
-        sh.reset_stats()
+    for x in (SH or []):
+        x.reset_stats()
     capi.profile_enable(True)
     capi.profile_reset()
     import gc
@@ -838,7 +921,7 @@ def main():
     if _ROLE_POOLS:
         _ROLE_POOLS[0].close()
 
-    pairs_unit = sum(w["pairs"].values())
+    pairs_unit = sum(sum(wk["pairs"].values()) for wk in W)       # per step: every pair of the sequence
     pairs_total = float(pairs_unit * args.steps * (world if not sharded else units))
     if dist is not None and not sharded:
         # --replicas: every rank has its own scene (its own seed, its own point counts): the pairs of all ranks, summed
@@ -856,27 +939,28 @@ def main():
             out = dict(err=errs[0], T=Ts[0], scores=scores, labels=labels, min_dists=mind, Ts=Ts, errs=errs)
         else:
             out = last
-        # Dominant kernel: the one that takes the largest share of the GPU — time per step x the fraction of the CUs its stream is
-        # confined to (with the CU partition the score batch runs ~2.6 ms on 3/8 of the chip beside the ICP chain's ~2.3 ms of
-        # searches on 5/8; serial or unpartitioned the shares are 1 and this is plain time).  Every domain's figures are in
-        # roofline_by_kernel.
         prof = {k: capi.profile_read(k) for k in ("nn_icp", "icp_moments", "nn_score", "nn_label")}
-        per_step = {k: v[1] / max(1, v[0]) * (ICP_ITERS if k in ("nn_icp", "icp_moments") else 1) for k, v in prof.items()}
+        per_step = {k: v[1] / max(1, v[0]) * (ICP_ITERS if k in ("nn_icp", "icp_moments") else 1) * n_pairs for k, v in prof.items()}
         shares = cu_shares() if conc else {}
-        alg_bytes = {"nn_icp": w["n_scan1"] * 56 + w["n_scan0"] * 16,            # per launch (SURVEY.md §8d / BASELINE.md §3.5)
-                     "nn_score": N_POSES * w["n_obj"] * 40 + w["n_scan1"] * 16,
-                     "nn_label": N_PLACEMENTS * w["n_scan1"] * 46 + sum(len(p["np"][0]) for p in w["plc"][:N_PLACEMENTS]) * 16,
-                     "icp_moments": w["n_scan1"] * 56}
+        mean = lambda f: float(np.mean([f(wk) for wk in W]))
+        # algorithmic bytes per launch (SURVEY.md §8d / BASELINE.md §3.5).  The label pass is ONE fused launch over all
+        # placements: a scene point (24 B) is read once, not once per placement — 24 + n_placements x 22 B per point.
+        alg_bytes = {"nn_icp": mean(lambda x: x["n_scan1"] * 56 + x["n_scan0"] * 16),
+                     "nn_score": mean(lambda x: N_POSES * x["n_obj"] * 40 + x["n_scan1"] * 16),
+                     "nn_label": mean(lambda x: x["n_scan1"] * (24 + N_PLACEMENTS * 22) + sum(len(p["np"][0]) for p in x["plc"][:N_PLACEMENTS]) * 16),
+                     "icp_moments": mean(lambda x: x["n_scan1"] * 56)}
         by_kernel = {}
         for k, (n_k, ms_k) in prof.items():
             avg = (ms_k / max(1, n_k)) * 1e-3
+            tr, _ = read_traffic(k)
             by_kernel[k] = {"avg_launch_ms": avg * 1e3, "launches": n_k, "alg_bytes_per_launch": alg_bytes[k], "cu_share": shares.get(k, 1.0),
-                            "achieved_GBs": alg_bytes[k] / avg / 1e9 if avg > 0 else 0.0, "frac": (alg_bytes[k] / avg / 1e9 / HBM_PEAK_GBS) if avg > 0 else 0.0}
-        # The dominant kernel = the one that holds the largest share of the GPU: time per step x the fraction of the CUs its stream is
-        # confined to (rounds 1-2's rule; round 3 reported the longest interval instead, which on a 6 + 2 partition is the score batch
-        # on its quarter of the chip).  Both are named, and so is the domain furthest below its roofline; roofline_by_kernel has all four.
-        dom = max(per_step, key=lambda k: per_step[k] * shares.get(k, 1.0))
-        longest = max(per_step, key=lambda k: per_step[k])
+                            "achieved_GBs": alg_bytes[k] / avg / 1e9 if avg > 0 else 0.0, "frac": (alg_bytes[k] / avg / 1e9 / HBM_PEAK_GBS) if avg > 0 else 0.0,
+                            # HBM-side bytes per launch by the PMC counters (profiles/pmc_traffic.json, same kernel sources only) and the
+                            # fraction of the HBM peak those bytes make of this run's launch time
+                            "traffic": tr, "traffic_frac": (tr / avg / 1e9 / HBM_PEAK_GBS) if (tr and avg > 0) else None}
+        # roofline.kernel: the domain with the LONGEST time per step (the top row of a rocprofv3 --stats summary of this command).
+        # Round 4 reported the domain with the largest time x CU share instead; the rule now is fixed: longest interval.
+        dom = max(per_step, key=lambda k: per_step[k])
         worst = min((k for k in by_kernel if by_kernel[k]["frac"] > 0), key=lambda k: by_kernel[k]["frac"], default=dom)
         n_l, ms = prof[dom]
         bytes_launch = alg_bytes[dom]
@@ -899,7 +983,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl + (" [--centre: the scene moved so that its median point is the origin]" if args.centre else ""),
+            "config": {"workload": wl + (" [--timesteps %d: every step covers the %d consecutive scan pairs of the sequence, each pair its own scans, poses and placements]" % (args.timesteps, n_pairs) if n_pairs > 1 else "")
+                                   + (" [--centre: the scene moved so that its median point is the origin]" if args.centre else ""),
+                       "timesteps": args.timesteps,
                        "knn": "lds-hash-cells" if args.knn == "hash" else "brute-tile",
                        "route": "sharded" if sharded else ("replicas" if world > 1 else "single"),
                        "n_scan0": w["n_scan0"], "n_scan1": w["n_scan1"], "n_obj": w["n_obj"],
@@ -914,11 +1000,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                          "avg_launch_ms": ms / max(1, n_l), "launches": n_l, "alg_bytes_per_launch": bytes_launch,
-                         "dominant_by": "GPU share: time per step x fraction of the CUs the kernel's stream is confined to", "cu_share": shares.get(dom, 1.0),
-                         "note": "achieved / frac compare a kernel confined to cu_share of the CUs with the whole chip's peak; roofline_by_kernel has every domain",
-                         "longest_interval_per_step": {"kernel": longest, "ms_per_step": per_step[longest], "cu_share": shares.get(longest, 1.0), "frac": by_kernel[longest]["frac"]},
-                         "furthest_below_roofline": {"kernel": worst, "frac": by_kernel[worst]["frac"],
-                                                     "why": "VALU-bound: 406 M wave-VALU instructions per launch, 92-95 % of its SIMDs' issue slots (profiles/r04/pmc_instruction_counts.txt)" if worst == "nn_score" else ""}},
+                         "dominant_by": "longest time per step", "ms_per_step": per_step[dom], "cu_share": shares.get(dom, 1.0),
+                         "note": "achieved / frac compare a kernel confined to cu_share of the CUs with the whole chip's peak; roofline_by_kernel has every domain, each with its counter traffic",
+                         "furthest_below_roofline": {"kernel": worst, "frac": by_kernel[worst]["frac"], "instructions_per_launch": read_instructions(worst)}},
             "roofline_by_kernel": by_kernel,
             "parity": parity_block(out, args.points, seed, args.knn, units, strong) if not args.centre else "not compared (--centre: the fixtures hold the scene as generated)",
             "icp_chains_gave_up_calls": int(capi.icp_chains_gave_up()),     # calls whose centroid chains gave a problem up and were run again by the replay (0 on scenes in one octant)
@@ -964,6 +1048,24 @@ def main():
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
+
+
+def read_instructions(kernel):
+    """Wave-level instruction counts per launch of `kernel` (SQ_INSTS_VALU / SALU / LDS, SQ_WAVES, busy cycles) from the PMC pass
+    (tools/profile.sh pmc -> profiles/pmc_instructions.json), or why they are not reported: like the traffic, only counters collected
+    for the kernel sources of THIS library are."""
+    ipath = os.path.join(ROOT, "profiles", "pmc_instructions.json")
+    if not os.path.exists(ipath):
+        return "no profiles/pmc_instructions.json"
+    try:
+        t = json.load(open(ipath))
+    except Exception as e:
+        return f"unreadable: {e}"
+    from rescan_amd.build import sources_sha
+    want = sources_sha()
+    if t.get("kernels_sha") != want:
+        return "profiles/pmc_instructions.json was collected for other kernel sources (kernels_sha %s, now %s): stale, not reported" % (t.get("kernels_sha"), want)
+    return t.get(kernel)
 
 
 def read_traffic(kernel):
