@@ -553,17 +553,20 @@ class Sharded:
         return prev
 
 
-def parity_block(out, n_points, seed, knn, units, strong=False):
+def parity_block(out, n_points, seed, knn, units, strong=False, centre=False, t0=0):
     """Distance of the LAST step's outputs from tests/golden/bench_seed11.npz — what the compiled reference computes for
     the same inputs (oracle/gen_golden_bench.py: pose / error after the 10 fixed iterations composed from the reference's
     icp_find_corrs + icp_estimate_rigid_xform_pt2pl, the 256 scores of mgs_compute_object_alignment_score; labels and min_dists
     of rspf_arrangement_to_labels by the reference's own text, oracle/_ref/libref_filters.so).  Computed outside the timed region."""
     import hashlib
-    path = os.path.join(ROOT, "tests", "golden", "bench_seed11.npz")
-    if not os.path.exists(path) or n_points != 1_000_000 or seed != 11:
-        return None
+    # (--centre and the further scan pairs of --timesteps have fixtures of their own, made by the same reference build:
+    #  oracle/gen_golden_bench.py --centre / --pair)
+    name = "bench_seed%d%s%s.npz" % (seed, "_centre" if centre else "", "_t%d" % t0 if t0 else "")
+    path = os.path.join(ROOT, "tests", "golden", name)
+    if out is None or not os.path.exists(path) or n_points != 1_000_000:
+        return None if not (centre or t0) else "not compared: no tests/golden/%s" % name
     g = np.load(path)
-    blk = {"fixture": "tests/golden/bench_seed11.npz", "knn": knn}
+    blk = {"fixture": "tests/golden/" + name, "knn": knn}
     if strong and "strong_icp_pose" in g and out.get("Ts") is not None:
         # --scaling strong refines the 8 placements' models against the scan (object-sized sources: the reference-order estimator); the
         # fixture holds the reference's own ten iterations of each (oracle/gen_golden_bench.py --strong-only)
@@ -579,7 +582,11 @@ def parity_block(out, n_points, seed, knn, units, strong=False):
     sc = np.asarray(out["scores"], np.float64)[:N_POSES]
     blk["score_max_abs_err"] = float(np.abs(sc - g["scores"].astype(np.float64)).max())
     if units == 1:
-        blk["label_mismatches"] = int((out["labels"] != g["labels"]).sum())
+        if "labels" in g:
+            blk["label_mismatches"] = int((out["labels"] != g["labels"]).sum())
+        else:      # (the further fixtures hold the labels as a digest and a strided sample)
+            same = hashlib.sha256(np.ascontiguousarray(out["labels"], np.int8).tobytes()).hexdigest() == str(g["labels_sha"])
+            blk["label_mismatches"] = 0 if same else max(1, int((np.asarray(out["labels"])[::257] != g["labels_sample"]).sum()))
         blk["min_dists_identical"] = bool(hashlib.sha256(np.ascontiguousarray(out["min_dists"], np.float32).tobytes()).hexdigest() == str(g["min_dists_sha"]))
     else:
         blk["labels"] = "not compared: %d placements instead of the fixture's %d" % (units * N_PLACEMENTS, N_PLACEMENTS)
@@ -782,7 +789,7 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="strong: ONE fixed scene (8 per-placement ICP problems, 256 score poses, 8 placements) sharded over the ranks; total work does not grow with --gpus")
     ap.add_argument("--centre", action="store_true",
-                    help="the same scene moved so that its median point is the origin (coordinates of both signs): times the estimator's fallback for centroid sums that hover around zero; no reference fixture, parity not compared")
+                    help="the same scene moved so that its median point is the origin (coordinates of both signs, as real scans have): the reference's fp32 centroid sums hover around zero instead of growing; parity against tests/golden/bench_seed11_centre.npz")
     ap.add_argument("--timesteps", type=int, default=2,
                     help="scans of the sequence (BASELINE configs[3]: 4): a step then covers every consecutive pair (t, t + 1) — T - 1 times the unit lists, "
                          "each pair its own two scans, object poses and placements")
@@ -864,7 +871,8 @@ def main():
         torch.cuda.synchronize()
 
     conc = not args.serial
-    last = None            # the newest results of the FIRST pair (the one the fixtures pin)
+    last = None            # the newest results of the FIRST pair
+    last_of = {}           # ... and of every pair (each has its fixture: tests/golden/bench_seed11[_t<k>].npz)
     in_flight = []         # sharded route: pair whose exchange is under way
 
     def one_step():
@@ -873,20 +881,20 @@ def main():
         for k in range(n_pairs):
             if SH is not None:
                 r = SH[k].step(conc)                # (returns the results of the exchange that was in flight: the pair before)
-                if r is not None and in_flight and in_flight[-1] == 0:
-                    last = r
+                if r is not None and in_flight:
+                    last_of[in_flight[-1]] = r
                 in_flight[:] = [k]
             else:
-                r = run_step(W[k], dist_ctx, conc)
-                if k == 0:
-                    last = r
+                last_of[k] = run_step(W[k], dist_ctx, conc)
+        last = last_of.get(0, last)
 
     def drain():
         nonlocal last
         r = exchange_wait()                         # the last step's exchange belongs to the timed region
-        if SH is not None and r is not None and in_flight and in_flight[-1] == 0:
-            last = r
+        if SH is not None and r is not None and in_flight:
+            last_of[in_flight[-1]] = r
         in_flight[:] = []
+        last = last_of.get(0, last)
 
     for _ in range(args.warmup):
         one_step()
@@ -1004,7 +1012,7 @@ def main():
                          "note": "achieved / frac compare a kernel confined to cu_share of the CUs with the whole chip's peak; roofline_by_kernel has every domain, each with its counter traffic",
                          "furthest_below_roofline": {"kernel": worst, "frac": by_kernel[worst]["frac"], "instructions_per_launch": read_instructions(worst)}},
             "roofline_by_kernel": by_kernel,
-            "parity": parity_block(out, args.points, seed, args.knn, units, strong) if not args.centre else "not compared (--centre: the fixtures hold the scene as generated)",
+            "parity": parity_block(out, args.points, seed, args.knn, units, strong, centre=args.centre),
             "icp_chains_gave_up_calls": int(capi.icp_chains_gave_up()),     # calls whose centroid chains gave a problem up and were run again by the replay (0 on scenes in one octant)
             "ms_per_step_spread": {"min": float(step_ms.min()), "median": float(np.median(step_ms)), "max": float(step_ms.max()),
                                    "steps_over_1.3x_median": int((step_ms > 1.3 * np.median(step_ms)).sum())},
@@ -1015,6 +1023,13 @@ def main():
             "kernel_ms_per_step": per_step,
             "profile_sampling": "ICP chain: events on every %s-th call (%d launches timed); score / label: every call" % (os.environ.get("RS_HIP_PROF_EVERY", "1"), n_l),
         }
+        if n_pairs > 1:      # the further scan pairs against their own reference fixtures
+            def as_out(x):
+                if x is None or SH is None:
+                    return x
+                errs, Ts, its, scores, labels, mind = x
+                return dict(err=errs[0], T=Ts[0], scores=scores, labels=labels, min_dists=mind, Ts=Ts, errs=errs)
+            line["parity_pairs"] = [parity_block(as_out(last_of.get(k)), args.points, seed, args.knn, units, strong, centre=args.centre, t0=k) for k in range(1, n_pairs)]
         # "the real limiter is candidate evaluation ... so also report candidate-evals/s"
         # (candidates staged in LDS x the 64 query lanes that test each of them)
         cand = capi.profile_read("candidates")[0]

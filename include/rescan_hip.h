@@ -119,8 +119,8 @@ int32_t rs_hip_icp_replay_below( int32_t n_points );
 int32_t rs_hip_icp_replay_redone( void );
 /* The sequential estimator (sources up to rs_hip_icp_reference_order_below) runs the reference's dist² statistics and its weighted
  * centroids in ONE pass, the 2.5 sigma cut of the weights (lib/rs/icp.h:396-401) taken at a guess of sigma; the pass stands when no
- * dist² lies between the guessed and the real cut, else the centroids are summed again.  Iterations that had to, since rs_hip_init
- * (diagnostics). */
+ * dist² lies between the guessed and the real cut, else the centroids are summed again.  Iterations that had to, over every calling
+ * thread of the process, since the first ICP call (diagnostics). */
 int32_t rs_hip_icp_faith_redone( void );
 /* Test switch of that guess, in thousandths: 1000 (default) the guess as made, 0 no guess (statistics, centroids and normal equations
  * in three passes, as up to round 3), any other value scales the guessed cut — a guess that fails, for the tests of the check and of
@@ -137,6 +137,11 @@ int32_t rs_hip_icp_exact_centroids( int32_t on );
 /* How many rs_hip_icp_align[_batch] calls the grid chains gave up so far (sums that keep changing binade — coordinates that straddle
  * the origin in a cancelling order) and ran again with the centroid sums by pass 2 of the replay: same result, ~10x the estimator time. */
 int32_t rs_hip_icp_chains_gave_up( void );
+/* A source cloud whose chains gave a problem up goes straight to the replay on its next `calls` calls as an ICP source (default 15;
+ * environment RS_HIP_CHAINS_RETRY_AFTER) instead of paying for the failed attempt each time; 0 = every call tries the chains first
+ * (tests that compare the two paths on centred scans use this); calls < 0 only reads.  The skip is per source cloud, whatever the
+ * poses and the target.  Returns the previous value. */
+int32_t rs_hip_icp_chains_retry_after( int32_t calls );
 
 /* Many independent icp_align problems of one (source, target) pair, one per start pose
  * (apps/pose_proposal/main.cpp:190-202 runs exactly this loop): T1s is float[16*n], errs

@@ -23,7 +23,12 @@ container only; the fixtures are committed so the GPU box, which has no /root/re
         on the same two ~0.98 M-point scans, the three call sites' parameter sets in turn and start poses from
         5 mm / 0.3 deg to 3 cm / 2 deg (MORE_SEEDS, more_stop_case)
 
-Usage:  python oracle/gen_golden_bench.py [--bench-only [--seed N] | --sweep-only | --more [--seed N] | --labels-only [--seed N] | --strong-only | --static-labels]
+  tests/golden/bench_seed11_centre.npz, bench_seed31_centre.npz, bench_seed32_centre.npz   (round 5) bench.py --centre's inputs: the same
+        rooms moved so that the scan's median point is the origin — the regime in which the reference's fp32 centroid sums hover
+        around zero — with the same fields as --more's; bench_seed11_t1.npz, _t2.npz: the further scan pairs of bench.py --timesteps 4
+
+Usage:  python oracle/gen_golden_bench.py [--bench-only [--seed N] | --sweep-only | --more [--seed N] | --labels-only [--seed N] | --strong-only | --static-labels
+                                          | --centre [--seed N] | --pair T0 [--seed N]]
         --labels-only recomputes the label fields of every bench_seed*.npz from the reference build and leaves the rest as it is
 """
 import ctypes as C
@@ -83,10 +88,12 @@ def more_stop_case(seed):
     return T0, np.float32(max_dist), np.float32(np.deg2rad(max_angle))
 
 
-def gen_bench(R, O, seed=11, more=False):
+def gen_bench(R, O, seed=11, more=False, centre=False, t0=0):
+    """centre: bench.py --centre's inputs (the world moved so that the scan's median point is the origin: coordinates of both signs, the
+    regime real scans are in) -> bench_seed<seed>_centre.npz; t0: the pair (t0, t0 + 1) of bench.py --timesteps -> bench_seed<seed>_t<t0>.npz."""
     import bench
     t = time.time()
-    w = bench.build_inputs(1_000_000, seed=seed)
+    w = bench.build_inputs(1_000_000, seed=seed, centre=centre, t0=t0)
     s0, s1 = w["s0"], w["s1"]
     print(f"inputs: {w['n_scan0']} / {w['n_scan1']} scan points, {w['n_obj']} object points ({time.time()-t:.1f} s)", flush=True)
     t = time.time()
@@ -111,8 +118,11 @@ def gen_bench(R, O, seed=11, more=False):
         print(f"icp_align (stop test on): r {md:.3f} iters {sdone} err {e:.6f} ({time.time()-t:.1f} s)", flush=True)
         extra = dict(labels_sha=sha(lab["labels"]), labels_sample=lab["labels"][::257].copy(), n_labelled=int((lab["labels"] > 0).sum()),
                      stop_T0=T0s, stop_pose=Ts, stop_err=np.float32(e), stop_iters=np.int32(sdone), stop_params=np.array([md, ma], np.float32))
+    if centre or t0:      # (the further fixtures keep the labels as a digest + sample, like --more's)
+        extra = {k: v for k, v in extra.items() if k != "labels"}
+        extra.update(labels_sha=sha(lab["labels"]), labels_sample=lab["labels"][::257].copy(), n_labelled=int((lab["labels"] > 0).sum()))
     np.savez_compressed(
-        os.path.join(OUT, "bench_seed%d.npz" % seed), **extra,
+        os.path.join(OUT, "bench_seed%d%s%s.npz" % (seed, "_centre" if centre else "", "_t%d" % t0 if t0 else "")), **extra,
         n_points=1_000_000, seed=seed, n_scan0=w["n_scan0"], n_scan1=w["n_scan1"], n_obj=w["n_obj"],
         in_sha=np.array([sha(s0["points"]), sha(s0["normals"]), sha(s1["points"]), sha(s1["normals"]), sha(op), sha(on),
                          sha(w["score_poses"]), sha(w["plc_poses"]), sha(w["icp_T0"])]),
@@ -263,6 +273,10 @@ if __name__ == "__main__":
                 relabel(seed)
         sys.exit(0)
     R, O = Ref(), Oracle()
+    if "--centre" in sys.argv or "--pair" in sys.argv:      # --centre [--seed N] | --pair T0 [--seed N]
+        seed = int(sys.argv[sys.argv.index("--seed") + 1]) if "--seed" in sys.argv else 11
+        gen_bench(R, O, seed, more="--centre" in sys.argv, centre="--centre" in sys.argv, t0=int(sys.argv[sys.argv.index("--pair") + 1]) if "--pair" in sys.argv else 0)
+        sys.exit(0)
     if "--more" in sys.argv:
         for seed in MORE_SEEDS:
             if "--seed" not in sys.argv or str(seed) == sys.argv[sys.argv.index("--seed") + 1]:

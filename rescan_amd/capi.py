@@ -44,6 +44,7 @@ SIGNATURES = {
     "rs_hip_icp_faith_guess": (C.c_int32, [C.c_int32]),
     "rs_hip_icp_exact_centroids": (C.c_int32, [C.c_int32]),
     "rs_hip_score_scene_space_from": (C.c_int64, [C.c_int64]),
+    "rs_hip_icp_chains_retry_after": (C.c_int32, [C.c_int32]),
     "rs_hip_icp_chains_gave_up": (C.c_int32, []),
     "rs_hip_icp_align_batch": (C.c_int, [C.c_void_p, C.c_void_p, f32p, C.c_int32, f32p, C.c_float, C.c_float,
                                          C.c_int32, C.c_int32, f32p, i32p]),
@@ -248,6 +249,12 @@ def icp_exact_centroids(on=-1):
     """Sources above both thresholds: centre the fp64 step on the reference's own fp32 centroid chains (default on); -1 only
     reads.  Returns the previous setting."""
     return int(load().rs_hip_icp_exact_centroids(int(on)))
+
+
+def icp_chains_retry_after(calls=-1):
+    """After a source's centroid chains gave up, its next `calls` ICP calls go straight to the replay (default 15; 0: every call tries
+    the chains first); -1 only reads.  Returns the previous value."""
+    return int(load().rs_hip_icp_chains_retry_after(int(calls)))
 
 
 def score_scene_space_from(n_queries=-1):

@@ -110,18 +110,21 @@ struct Workspace
   DevBuf tmp_pos, tmp_pos2, tmp_nor2;                                           // estimate-only
   DevBuf lvl_pos, lvl_nor, lvl_cnt, lvl_within, lvl_offset, lvl_adj, lvl_state, lvl_misc, lvl_flags, lvl_scan, lvl_samples, lvl_tmp, lvl_cursor, lvl_work_a, lvl_work_b;   // level builder
   DevBuf faith;                                                                 // reference-order estimator: correspondences in source order
-  DevBuf faith_redone;                                                                   // (a counter: rs_hip_icp_faith_redone)
   DevBuf rp_segsum, rp_guess, rp_seg, rp_super, rp_totals, rp_redone;                     // ... its parallel form (replay)
   DevBuf ch_rec, ch_segsum, ch_prefix, ch_seg, ch_blk, ch_guess, ch_dbg, ch_done, ch_chk;                                    // the centroid chains of large sources (grid chains)
-  PinBuf h_a, h_b, h_c;
+  PinBuf h_a, h_b, h_c, h_multi;      // h_c: the label entry points' placements; h_multi: a multi-source batch's problem views (an entry point that returns without a synchronisation — rs_hip_label_partial_device — may still be uploading from h_c)
 };
 thread_local Workspace g_ws;
+DevBuf g_faith_redone;            // (a process-wide counter: rs_hip_icp_faith_redone)
+std::mutex g_faith_redone_mu;
 
 // ---- profiling ---------------------------------------------------------------------------
 bool g_prof = false;
 // Sources of at most this many points run the ICP estimator in the reference's own accumulation order and precisions
 // (bit-identical poses, errors and iteration counts); larger ones the fp64 moment reduction.  65 536 covers
 // every icp_align call site of the reference (level-2 objects, 2-10 k points; scene extracts of up to ~50 k).
+// After a source's centroid chains gave a problem up, its next `g_chains_retry_after` calls go straight to the replay (rs_hip_icp_chains_retry_after).
+std::atomic<int> g_chains_retry_after{ getenv( "RS_HIP_CHAINS_RETRY_AFTER" ) ? atoi( getenv( "RS_HIP_CHAINS_RETRY_AFTER" ) ) : 15 };
 std::atomic<int> g_ref_order_below{ getenv( "RS_HIP_REF_ORDER_BELOW" ) ? atoi( getenv( "RS_HIP_REF_ORDER_BELOW" ) ) : 65536 };
 // Above that and up to this many source points the SAME sums are computed in parallel (rs_icp_estimate.hip: "replay" — the reference's
 // bits again, two to three times as fast as the sequential chains on scan-sized sources, still ten times the fp64 moments);
@@ -667,8 +670,10 @@ int icp_prepare( IcpCtx& cx, const rs_hip_cloud_t* src, const rs_hip_cloud_t* tg
   L.multi = nullptr;
   if( srcs )
   {
-    if( ( rc = g_ws.h_c.ensure( np * sizeof( IcpProblem ) ) ) || ( rc = g_ws.multi.ensure( np * sizeof( IcpProblem ) ) ) ) return rc;
-    IcpProblem* P = g_ws.h_c.as<IcpProblem>();      // (pinned, the workspace's: the copy below needs no synchronisation — every entry point ends with one)
+    if( ( rc = g_ws.h_multi.ensure( np * sizeof( IcpProblem ) ) ) || ( rc = g_ws.multi.ensure( np * sizeof( IcpProblem ) ) ) ) return rc;
+    // (pinned and only ever written here: every ICP entry point ends with a stream synchronisation, so the upload of the previous
+    //  call's views is over before this one overwrites them)
+    IcpProblem* P = g_ws.h_multi.as<IcpProblem>();
     size_t pts = 0, tiles = 0, heavy = 0; int max_n = 0, max_tiles = 0;
     for( size_t p = 0; p < np; ++p )
     {
@@ -717,12 +722,16 @@ int icp_prepare( IcpCtx& cx, const rs_hip_cloud_t* src, const rs_hip_cloud_t* tg
   L.mom_part = g_ws.mom_part.as<double>(); L.res = g_ws.res.as<double>();
   L.w_explicit = nullptr;
   L.faith = nullptr;
-  if( !g_ws.faith_redone.p )
   {
-    if( int rc = g_ws.faith_redone.ensure( 64 ) ) return rc;
-    HIP_TRY( hipMemsetAsync( g_ws.faith_redone.p, 0, 64, g_stream ), RS_HIP_E_RUNTIME );
+    // one counter for the process (every calling thread's kernels add to it; rs_hip_icp_faith_redone reads it from any thread)
+    std::lock_guard<std::mutex> lk( g_faith_redone_mu );
+    if( !g_faith_redone.p )
+    {
+      if( int rc = g_faith_redone.ensure( 64 ) ) return rc;
+      HIP_TRY( hipMemset( g_faith_redone.p, 0, 64 ), RS_HIP_E_RUNTIME );
+    }
   }
-  L.faith_redone = g_ws.faith_redone.as<int>();
+  L.faith_redone = g_faith_redone.as<int>();
   L.faith_guess_scale = (float)g_faith_guess_permille.load() / 1000.0f;
   HIP_TRY( hipMemsetAsync( g_ws.queue_count.p, 0, np * 4, g_stream ), RS_HIP_E_RUNTIME );
   return RS_HIP_OK;
@@ -1109,7 +1118,8 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
   // (default 4 GB) — the problems are independent, so the results are those of the one batch.
   static const double cap = getenv( "RS_HIP_ICP_BATCH_BYTES" ) ? atof( getenv( "RS_HIP_ICP_BATCH_BYTES" ) ) : 4e9;
   const bool per_point_records = source && source->n > g_ref_order_below.load();
-  const int slice = per_point_records ? std::max( 1, (int)std::min<double>( (double)std::max( n, 1 ), cap / ( 48.0 * (double)std::max( source->n, 1 ) ) ) ) : std::max( n, 1 );
+  // (96 B per point: the 48-byte records + what a slice that falls back to the replay adds — its segment rows, ~35 / 128 x ( 8 + 24 + sizeof( ReplaySeg ) ) ≈ 48 B per point)
+  const int slice = per_point_records ? std::max( 1, (int)std::min<double>( (double)std::max( n, 1 ), cap / ( 96.0 * (double)std::max( source->n, 1 ) ) ) ) : std::max( n, 1 );
   for( int p0 = 0; p0 < std::max( n, 1 ); p0 += slice )
   {
     const int np = std::min( slice, n - p0 );
@@ -1117,12 +1127,12 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
     // (a source whose chains gave up lately: the attempt — a cold search, the iterations up to the give-up, the launches that idle
     //  through the rest of the call: ~1.4 ms at a million points — is skipped; every 16th such call tries the chains again)
     int mode = g_exact_centroids.load();
-    if( mode == 1 && per_point_records && source->chains_wander.load() > 0 ) { source->chains_wander.fetch_sub( 1 ); mode = 2; }
+    if( mode == 1 && per_point_records && g_chains_retry_after.load() > 0 && source->chains_wander.load() > 0 ) { source->chains_wander.fetch_sub( 1 ); mode = 2; }
     int rc = icp_align_batch_impl( source, target, T, np, T2, max_dist, max_angle, max_iter, fixed_iters, e, it, mode );
     // (a problem of the slice whose chains gave up: that slice again, its seven sums by pass 2 of the replay — nothing of it was written yet)
     if( rc == ICP_CHAINS_GAVE_UP )
     {
-      source->chains_wander.store( 15 );
+      source->chains_wander.store( g_chains_retry_after.load() );
       rc = icp_align_batch_impl( source, target, T, np, T2, max_dist, max_angle, max_iter, fixed_iters, e, it, 2 );
     }
     if( rc ) return rc;
@@ -1214,6 +1224,13 @@ int rs_hip_icp_align_multi( const rs_hip_cloud_t* const* sources, const rs_hip_c
 
 int32_t rs_hip_icp_chains_gave_up( void ) { return g_chains_gave_up.load(); }
 
+int32_t rs_hip_icp_chains_retry_after( int32_t calls )
+{
+  const int prev = g_chains_retry_after.load();
+  if( calls >= 0 ) g_chains_retry_after.store( calls );
+  return prev;
+}
+
 int32_t rs_hip_icp_reference_order_below( int32_t n_points )
 {
   const int prev = g_ref_order_below.load();
@@ -1246,10 +1263,10 @@ int32_t rs_hip_icp_faith_redone( void )
 {
   int v = 0;
 #ifdef RS_FAITH_TIMING
-  { int t[16]; (void)hipStreamSynchronize( g_stream ); if( g_ws.faith_redone.p && hipMemcpy( t, g_ws.faith_redone.p, sizeof t, hipMemcpyDeviceToHost ) == hipSuccess )
+  { int t[16]; (void)hipStreamSynchronize( g_stream ); if( g_faith_redone.p && hipMemcpy( t, g_faith_redone.p, sizeof t, hipMemcpyDeviceToHost ) == hipSuccess )
     for( int w = 0; w < 4; ++w ) fprintf( stderr, "[rs_hip faith timing] pass %d wave %d: %d cycles at work, %d at the barrier, %d chunks\n", RS_FAITH_TIMING, w, t[2 + 3 * w], t[3 + 3 * w], t[4 + 3 * w] ); }
 #endif
-  if( g_ws.faith_redone.p && ( hipStreamSynchronize( g_stream ) != hipSuccess || hipMemcpy( &v, g_ws.faith_redone.p, 4, hipMemcpyDeviceToHost ) != hipSuccess ) ) return -1;
+  if( g_faith_redone.p && ( hipStreamSynchronize( g_stream ) != hipSuccess || hipMemcpy( &v, g_faith_redone.p, 4, hipMemcpyDeviceToHost ) != hipSuccess ) ) return -1;
   return v;
 }
 
@@ -1455,7 +1472,7 @@ int rs_hip_alignment_scores( const rs_hip_cloud_t* object, const rs_hip_cloud_t*
   //  of a mediocre pose has a lane in sparse surroundings, which sends the tile to stage 2, and what stage 2 streams again outweighs
   //  what the dense tiles save.  profiles/r04/score_two_radius.txt)
   L.hist = nullptr;
-  static DevBuf histbuf;
+  thread_local DevBuf histbuf;
   if( RS_DBG && getenv( "RS_HIP_SCORE_HIST" ) && !histbuf.ensure( 7 * 65 * 8 ) ) { (void)hipMemsetAsync( histbuf.p, 0, 7 * 65 * 8, g_stream ); L.hist = histbuf.as<unsigned long long>(); }
   // Scene-space route (rs_score.hip: k_score_scene) for batches on a cell grid that are worth a sort: every query keyed by the
   // scene-aligned block it lands in.  RS_HIP_SCORE_SCENE=0 turns it off, RS_HIP_SCORE_SCENE_MIN sets the batch size it starts at.

@@ -283,6 +283,60 @@ def test_more_headline_rooms_vs_reference(capi, bench_mod, seed):
         _close_workload(w)
 
 
+def _check_room(capi, bench_mod, g, w, with_stop):
+    s0, s1 = w["s0"], w["s1"]
+    op, on = w["obj_score_np"]
+    got = [sha(s0["points"]), sha(s0["normals"]), sha(s1["points"]), sha(s1["normals"]), sha(op), sha(on),
+           sha(w["score_poses"]), sha(w["plc_poses"]), sha(w["icp_T0"])]
+    assert got == [str(x) for x in g["in_sha"]], "the generator no longer produces the inputs the fixture was made for"
+    gave_up = capi.icp_chains_gave_up()
+    err, T, it = capi.icp_align(w["scan1"], w["scan0"], w["icp_T0"], I4, 0.10, np.deg2rad(60.0), max_iter=bench_mod.ICP_ITERS, fixed_iters=True)
+    d_fixed = np.linalg.norm(T.astype(np.float64) - g["icp_pose"].astype(np.float64))
+    msg = f"10 fixed iterations {d_fixed:.3e} from the reference (err {err:.7f} vs {float(g['icp_err']):.7f})"
+    assert it == bench_mod.ICP_ITERS and d_fixed < POSE_TOL and abs(err - float(g["icp_err"])) < 1e-5, msg
+    if with_stop:
+        md, ma = float(g["stop_params"][0]), float(g["stop_params"][1])
+        e2, T2, it2 = capi.icp_align(w["scan1"], w["scan0"], g["stop_T0"], I4, md, ma)
+        d_stop = np.linalg.norm(T2.astype(np.float64) - g["stop_pose"].astype(np.float64))
+        msg += f"; icp_align r {md:.3f}: {d_stop:.3e}, {it2} vs {int(g['stop_iters'])} iterations"
+        assert d_stop < POSE_TOL, msg
+    sc = capi.alignment_scores(w["obj_score"], w["scan1"], w["score_poses"], 0.1, 64)
+    d_sc = np.abs(sc.astype(np.float64) - g["scores"].astype(np.float64)).max()
+    res = capi.arrangement_to_labels(w["scan1"], w["plc_poses"], [p["cloud"] for p in w["plc"]], [0] * len(w["plc"]),
+                                     [p["cls"] for p in w["plc"]], 0.05, False)
+    print(msg + f"; scores max abs {d_sc:.2e}, {int((sc == g['scores']).sum())} of {len(sc)} bit-identical; calls the centroid chains gave up: {capi.icp_chains_gave_up() - gave_up}")
+    assert d_sc < SCORE_TOL
+    assert (res["order"] == g["order"]).all()
+    assert "reference" in str(g["labels_source"])
+    assert sha(res["labels"]) == str(g["labels_sha"]) and sha(res["min_dists"]) == str(g["min_dists_sha"])
+
+
+@pytest.mark.parametrize("seed", [11, 31, 32])
+def test_centred_rooms_vs_reference(capi, bench_mod, seed):
+    """Round 5: rooms moved so that the scan's median point is the ORIGIN — coordinates of both signs, as real scans have; the
+    reference's fp32 centroid sums then hover around zero (the regime in which the grid chains fall back on the replay) —
+    against the reference build's own results for exactly these inputs (oracle/gen_golden_bench.py --centre): the step's ten fixed
+    iterations, icp_align with its stop test, the 256 scores, labels / min_dists."""
+    g = load_golden("bench_seed%d_centre.npz" % seed)
+    w = bench_mod.build_workload(int(g["n_points"]), seed=int(g["seed"]), knn="hash", centre=True)
+    try:
+        _check_room(capi, bench_mod, g, w, with_stop=True)
+    finally:
+        _close_workload(w)
+
+
+@pytest.mark.parametrize("t0", [1, 2])
+def test_further_scan_pairs_vs_reference(capi, bench_mod, t0):
+    """bench.py --timesteps 4 (BASELINE configs[3]): the pairs (1, 2) and (2, 3) of the sequence against the reference build's results
+    (oracle/gen_golden_bench.py --pair)."""
+    g = load_golden("bench_seed11_t%d.npz" % t0)
+    w = bench_mod.build_workload(int(g["n_points"]), seed=int(g["seed"]), knn="hash", t0=t0)
+    try:
+        _check_room(capi, bench_mod, g, w, with_stop=False)
+    finally:
+        _close_workload(w)
+
+
 def test_label_rows_in_all_three_forms(capi, headline):
     """rs_hip_label_rows: host rows (input order), device rows in input order, device rows in the scene's query order — the
     last folded by rs_hip_fold_label_rows_device with the scene cloud — all give the rows / labels of the placement loop."""

@@ -343,6 +343,7 @@ def test_exact_centroid_chains_are_the_sequential_sums(capi, gscene, scene_cloud
     from rescan_amd import synth
     clouds, objs = scene_clouds
     prev, prev_r, prev_c = capi.icp_reference_order_below(-1), capi.icp_replay_below(-1), capi.icp_exact_centroids(-1)
+    prev_w = capi.icp_chains_retry_after(0)      # (every mode-1 call below tries the chains, also on a source that gave up before)
     try:
         capi.icp_reference_order_below(0); capi.icp_replay_below(0)
         for fname in golden_files("icp_"):
@@ -424,7 +425,7 @@ def test_exact_centroid_chains_are_the_sequential_sums(capi, gscene, scene_cloud
         print(f"{b.n} source points around the origin: calls the chains gave up: {capi.icp_chains_gave_up() - gave_up}")
         a.close(); b.close()
     finally:
-        capi.icp_reference_order_below(prev); capi.icp_replay_below(prev_r); capi.icp_exact_centroids(prev_c)
+        capi.icp_reference_order_below(prev); capi.icp_replay_below(prev_r); capi.icp_exact_centroids(prev_c); capi.icp_chains_retry_after(prev_w)
 
 
 def test_icp_no_correspondences(capi, scene_clouds):

@@ -172,10 +172,13 @@ def test_centroid_chains_sweep_vs_replay(capi):
     outgrew their four bits was once taken whole with the corrections clamped: 4 ulps in one centroid sum, 7e-8 in the pose,
     in four of five start poses of the centred room and in none of the others."""
     from rescan_amd import synth
-    prev, prev_r, prev_c = capi.icp_reference_order_below(-1), capi.icp_replay_below(-1), capi.icp_exact_centroids(-1)
+    prev, prev_r, prev_c, prev_w = capi.icp_reference_order_below(-1), capi.icp_replay_below(-1), capi.icp_exact_centroids(-1), capi.icp_chains_retry_after(-1)
     bad, gave_up = [], 0
     try:
         capi.icp_reference_order_below(0); capi.icp_replay_below(0)
+        # every mode-1 call TRIES the chains (a source that gave up would otherwise go straight to the replay on its next calls, and the
+        # centred clouds' later start poses would compare the replay with itself)
+        capi.icp_chains_retry_after(0)
         for seed in (22, 23):
             s0 = synth.scene_for_point_count(330_000, seed=seed, timestep=0)
             s1 = synth.scene_for_point_count(330_000, seed=seed, timestep=1)
@@ -196,8 +199,9 @@ def test_centroid_chains_sweep_vs_replay(capi):
                 a.close(); b.close()
         print(f"calls the chains gave up: {gave_up} of 20")
         assert not bad, f"(seed, centred, start pose) that differ: {bad}"
+        assert gave_up < 20          # (some of the twenty calls were decided by the chains themselves)
     finally:
-        capi.icp_reference_order_below(prev); capi.icp_replay_below(prev_r); capi.icp_exact_centroids(prev_c)
+        capi.icp_reference_order_below(prev); capi.icp_replay_below(prev_r); capi.icp_exact_centroids(prev_c); capi.icp_chains_retry_after(prev_w)
 
 
 def test_centred_room_costs_a_bounded_multiple(capi):
@@ -206,24 +210,26 @@ def test_centred_room_costs_a_bounded_multiple(capi):
     the walk gives up and the call is run again with those sums by pass 2 of the replay: same bits (test_centroid_chains_sweep_vs_
     replay), 3.6 times the time per iteration at 1.15 M points.  Held here: the multiple stays below 5, and a source that gave up
     does not pay for the attempt again on its next calls (rs_hip_icp_chains_gave_up stands still)."""
-    import time
     from rescan_amd import synth
     s0 = synth.scene_for_point_count(980_000, seed=11, timestep=0)
     s1 = synth.scene_for_point_count(980_000, seed=11, timestep=1)
     T0 = synth.perturbed_pose(I4, np.random.default_rng(1), 0.01, 0.01)
     per_iter = {}
+    n_timed = min(4, max(1, capi.icp_chains_retry_after(-1)))          # (within the calls a source that gave up skips the attempt)
     for name in ("as generated", "centred"):
         shift = -np.median(s1["points"], axis=0).astype(np.float32) if name == "centred" else np.zeros(3, np.float32)
         a, b = capi.Cloud(s0["points"] + shift, s0["normals"]), capi.Cloud(s1["points"] + shift, s1["normals"])
         capi.icp_align(b, a, T0, I4, 0.1, np.deg2rad(60.0), max_iter=10, fixed_iters=True)
         g0 = capi.icp_chains_gave_up()
-        best = 1e9
-        for _ in range(4):
-            t = time.perf_counter()
+        # DEVICE time of the calls' kernels (the library's own events), not the host's clock: the hosts of this pool lose milliseconds
+        # to scheduling now and then
+        capi.profile_enable(True); capi.profile_reset()
+        for _ in range(n_timed):
             capi.icp_align(b, a, T0, I4, 0.1, np.deg2rad(60.0), max_iter=10, fixed_iters=True)
-            best = min(best, (time.perf_counter() - t) / 10)
-        per_iter[name] = (best, capi.icp_chains_gave_up() - g0)
+        ms = sum(capi.profile_read(k)[1] for k in ("nn_icp", "icp_moments"))
+        capi.profile_enable(False)
+        per_iter[name] = (ms * 1e-3 / (10 * n_timed), capi.icp_chains_gave_up() - g0)
         a.close(); b.close()
-    print("us per iteration:", {k: round(v[0] * 1e6, 1) for k, v in per_iter.items()}, "give-ups in the timed calls:", {k: v[1] for k, v in per_iter.items()})
+    print("us per iteration (device):", {k: round(v[0] * 1e6, 1) for k, v in per_iter.items()}, "give-ups in the timed calls:", {k: v[1] for k, v in per_iter.items()})
     assert per_iter["as generated"][1] == 0 and per_iter["centred"][1] == 0
     assert per_iter["centred"][0] < 5.0 * per_iter["as generated"][0], per_iter
