@@ -474,20 +474,26 @@ class Sharded:
     _xs = None
     _xs_bound = False
 
-    def __init__(self, w, dist, dev, rank, world, strong=False):
+    def __init__(self, w, dist, dev, rank, world, strong=False, strong_problems=N_PLACEMENTS):
         import torch
         from rescan_amd import dist as rd
         self.w, self.dist, self.dev, self.rank, self.world = w, dist, dev, rank, world
         n_plc = len(w["plc"])
-        n_icp = N_PLACEMENTS if strong else len(w["icp_T0s"])
+        n_icp = strong_problems if strong else len(w["icp_T0s"])
         # every rank sends the (min_dist, label) partial of its own run of the sorted arrangement (5 B per scene point) instead of its unary
         # rows (4 B per point and placement: 31 MB per rank at 8 placements); RS_BENCH_PREFOLD=0 sends the rows.  Same bits either way.
         self.lay = rd.ShardLayout(world, n_icp, len(w["score_poses"]), n_plc, w["n_scan1"], prefold=os.environ.get("RS_BENCH_PREFOLD", "1") != "0")
         order, _, radii = rd.arrangement_plan([0] * n_plc, [p["cls"] for p in w["plc"]], 0.05)
         self.order = order
         si = w["strong_icp"]
+        if strong and strong_problems > N_PLACEMENTS:
+            # further refines of the same eight models from further (slightly wrong) start poses, drawn after the fixture's eight
+            from rescan_amd import synth
+            rng_s = np.random.default_rng(4242)
+            more = [synth.perturbed_pose(si["T0s"][k % N_PLACEMENTS], rng_s, 0.01, 0.005) for k in range(N_PLACEMENTS, strong_problems)]
+            si = dict(si, T0s=np.concatenate([si["T0s"], np.stack(more)]))
         self.units = dict(
-            icp=([p["cloud"] for p in w["plc"][:N_PLACEMENTS]], w["scan1"], si["T0s"], si["max_dist"], si["max_angle"], ICP_ITERS) if strong else
+            icp=([w["plc"][k % N_PLACEMENTS]["cloud"] for k in range(strong_problems)], w["scan1"], si["T0s"], si["max_dist"], si["max_angle"], ICP_ITERS) if strong else
                 (w["scan1"], w["scan0"], w["icp_T0s"], 0.10, np.deg2rad(60.0), ICP_ITERS),
             score=(w["obj_score"], w["scan1"], w["score_poses"], 0.1, 64),
             label=(w["scan1"], w["plc_poses"][order], [w["plc"][i]["cloud"] for i in order], radii))
@@ -570,10 +576,10 @@ def parity_block(out, n_points, seed, knn, units, strong=False, centre=False, t0
     if strong and "strong_icp_pose" in g and out.get("Ts") is not None:
         # --scaling strong refines the 8 placements' models against the scan (object-sized sources: the reference-order estimator); the
         # fixture holds the reference's own ten iterations of each (oracle/gen_golden_bench.py --strong-only)
-        d = np.linalg.norm(np.asarray(out["Ts"], np.float64).reshape(-1, 16) - g["strong_icp_pose"].astype(np.float64).reshape(-1, 16), axis=1)
+        d = np.linalg.norm(np.asarray(out["Ts"], np.float64).reshape(-1, 16)[:N_PLACEMENTS] - g["strong_icp_pose"].astype(np.float64).reshape(-1, 16), axis=1)
         blk["icp"] = "8 per-placement refines (lib/rs/rs_database.h:220-230) against the reference's"
         blk["pose_dist"] = float(d.max()); blk["poses_bit_identical"] = int((d == 0.0).sum())
-        blk["err_abs_diff"] = float(np.abs(np.asarray(out["errs"], np.float64) - g["strong_icp_err"].astype(np.float64)).max())
+        blk["err_abs_diff"] = float(np.abs(np.asarray(out["errs"], np.float64)[:N_PLACEMENTS] - g["strong_icp_err"].astype(np.float64)).max())
     elif strong:
         blk["icp"] = "not compared: the fixture holds no --scaling strong units"
     else:
@@ -790,6 +796,9 @@ def main():
                     help="strong: ONE fixed scene (8 per-placement ICP problems, 256 score poses, 8 placements) sharded over the ranks; total work does not grow with --gpus")
     ap.add_argument("--centre", action="store_true",
                     help="the same scene moved so that its median point is the origin (coordinates of both signs, as real scans have): the reference's fp32 centroid sums hover around zero instead of growing; parity against tests/golden/bench_seed11_centre.npz")
+    ap.add_argument("--strong-problems", type=int, default=N_PLACEMENTS,
+                    help="--scaling strong: ICP problems of the fixed unit list (default 8: one refine per placement; the app's shape is many object-sized "
+                         "refines per step — 43 icp_align per sequence — so e.g. 512: further start poses of the same eight models)")
     ap.add_argument("--timesteps", type=int, default=2,
                     help="scans of the sequence (BASELINE configs[3]: 4): a step then covers every consecutive pair (t, t + 1) — T - 1 times the unit lists, "
                          "each pair its own two scans, object poses and placements")
@@ -857,12 +866,15 @@ def main():
     units = 1 if strong else (world if sharded else 1)
     n_pairs = max(1, args.timesteps - 1)
     W = [build_workload(args.points, seed=seed, knn=args.knn, units=units, centre=args.centre, t0=k) for k in range(n_pairs)]
+    n_strong = max(N_PLACEMENTS, args.strong_problems) if strong else N_PLACEMENTS
     for wk in W:
-        if strong:      # the step's ICP units are the 8 per-placement problems: model points x iterations
-            wk["pairs"] = dict(icp=ICP_ITERS * sum(len(p["np"][0]) for p in wk["plc"][:N_PLACEMENTS]), score=wk["pairs"]["score"], label=wk["pairs"]["label"])
+        if strong:      # the step's ICP units are the per-placement problems: model points x iterations
+            wk["pairs"] = dict(icp=ICP_ITERS * sum(len(wk["plc"][k % N_PLACEMENTS]["np"][0]) for k in range(n_strong)), score=wk["pairs"]["score"], label=wk["pairs"]["label"])
     w = W[0]
     dist_ctx = (dist, dev) if dist is not None else None
-    SH = [Sharded(wk, dist, dev, rank, world, strong=strong) for wk in W] if sharded else None
+    # RS_BENCH_SIM_WORLD=W (one process, no exchange): rank 0's share of a W-rank world, for the per-rank compute time of a split
+    sim_world = int(os.environ.get("RS_BENCH_SIM_WORLD", "0")) if world == 1 else 0
+    SH = [Sharded(wk, dist, dev, rank, sim_world or world, strong=strong, strong_problems=n_strong) for wk in W] if sharded else None
     sh = SH[0] if sharded else None
 
     def barrier():
@@ -976,7 +988,7 @@ def main():
         achieved = bytes_launch / avg_s / 1e9 if avg_s > 0 else 0.0
         traffic, traffic_note = read_traffic(dom)
         if strong:
-            wl = ("configs[3], strong scaling: ONE FIXED scene (~1M-pt scans) replicated per rank, its units sharded over the ranks: 8 ICP-NN problems "
+            wl = ("configs[3], strong scaling: ONE FIXED scene (~1M-pt scans) replicated per rank, its units sharded over the ranks: " + str(n_strong) + " ICP-NN problems "
                   "(each placement's ~50k-pt model -> scan, 0.075 / 50 deg, 10 it: lib/rs/rs_database.h:220-230), score-NN 256 poses x 10k, label-NN 8 placements; "
                   "per-placement rows all-gathered on the device, ordered fold")
         elif sharded:
@@ -993,7 +1005,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl + (" [--timesteps %d: every step covers the %d consecutive scan pairs of the sequence, each pair its own scans, poses and placements]" % (args.timesteps, n_pairs) if n_pairs > 1 else "")
                                    + (" [--centre: the scene moved so that its median point is the origin]" if args.centre else ""),
-                       "timesteps": args.timesteps,
+                       "timesteps": args.timesteps, "strong_problems": n_strong if strong else None, "simulated_world": sim_world or None,
+                       "rank0_compute_ms_per_step": (sum(x.t_compute for x in SH) / max(1, SH[0].step_index - SH[0].stat_from) * 1e3) if SH else None,
                        "knn": "lds-hash-cells" if args.knn == "hash" else "brute-tile",
                        "route": "sharded" if sharded else ("replicas" if world > 1 else "single"),
                        "n_scan0": w["n_scan0"], "n_scan1": w["n_scan1"], "n_obj": w["n_obj"],
@@ -1012,7 +1025,7 @@ def main():
                          "note": "achieved / frac compare a kernel confined to cu_share of the CUs with the whole chip's peak; roofline_by_kernel has every domain, each with its counter traffic",
                          "furthest_below_roofline": {"kernel": worst, "frac": by_kernel[worst]["frac"], "instructions_per_launch": read_instructions(worst)}},
             "roofline_by_kernel": by_kernel,
-            "parity": parity_block(out, args.points, seed, args.knn, units, strong, centre=args.centre),
+            "parity": parity_block(out, args.points, seed, args.knn, units, strong, centre=args.centre) if not sim_world else "not compared: RS_BENCH_SIM_WORLD runs one rank's share without the exchange",
             "icp_chains_gave_up_calls": int(capi.icp_chains_gave_up()),     # calls whose centroid chains gave a problem up and were run again by the replay (0 on scenes in one octant)
             "ms_per_step_spread": {"min": float(step_ms.min()), "median": float(np.median(step_ms)), "max": float(step_ms.max()),
                                    "steps_over_1.3x_median": int((step_ms > 1.3 * np.median(step_ms)).sum())},
