@@ -16,7 +16,85 @@ def per_kernel(path):
     return {k: {c: (v / cnt[k][c], cnt[k][c]) for c, v in d.items()} for k, d in agg.items()}
 
 
+DOMAINS = ("nn_icp", "icp_moments", "nn_score", "nn_label")
+
+
+def per_domain(path, counters=None):
+    """Totals per bench domain of every counter in a rocprofv3 --pmc CSV, and the number of launch UNITS of each domain, taken dispatch
+    by dispatch in launch order: a score batch is everything from k_score_keys to k_score_gather (its radix-sort passes and fills are
+    rocprim / runtime kernels without our name: only their place in the sequence says whose they are) or one k_score< / k_score_coop /
+    k_score_final group; an ICP search is k_icp_corr< + the k_icp_corr_coop< behind it; the estimator is one k_icp_update*; a label
+    pass one k_label( with its gather to input order.  -> {domain: {"units": n, counter: total}}"""
+    rows = {}
+    for r in csv.DictReader(open(path)):
+        d = rows.setdefault(int(r["Dispatch_Id"]), {"name": r["Kernel_Name"], "c": {}})
+        d["c"][r["Counter_Name"]] = d["c"].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    out = {k: collections.defaultdict(float) for k in DOMAINS}
+    in_score = False
+    for _, d in sorted(rows.items()):
+        n = d["name"]
+        dom = None
+        if "k_score_keys" in n:
+            in_score = True
+        if in_score or "k_score" in n:
+            dom = "nn_score"
+            if "k_score_gather" in n or "k_score_final" in n:
+                out[dom]["units"] += 1
+                in_score = False
+        elif "k_icp_corr" in n:
+            dom = "nn_icp"
+            if "coop" not in n:
+                out[dom]["units"] += 1
+        elif any(x in n for x in ("k_icp_moments", "k_icp_update", "k_chain_", "k_replay_", "k_icp_faith")):
+            dom = "icp_moments"
+            if "k_icp_update" in n or "k_icp_faithful" in n or "k_replay_finish" in n:
+                out[dom]["units"] += 1
+        elif "k_label" in n:
+            dom = "nn_label"
+            if "rs::k_label(" in n:
+                out[dom]["units"] += 1
+        if dom:
+            for c, v in d["c"].items():
+                if counters is None or c in counters:
+                    out[dom][c] += v
+    return {k: dict(v) for k, v in out.items()}
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--fold-domains":
+        # the three PMC passes of tools/profile.sh (pmc, traffic) -> profiles/pmc_traffic.json + profiles/pmc_instructions.json, per launch
+        # unit of each bench domain, stamped with the kernel sources' digest (bench.py refuses files made for other sources)
+        import os
+        sys.path.insert(0, os.getcwd())
+        from rescan_amd.build import sources_sha
+        sha = sources_sha()
+        F = per_domain(glob.glob("gpurun_out/pmc_FETCH_SIZE/*/*counter_collection.csv")[0])
+        Wr = per_domain(glob.glob("gpurun_out/pmc_WRITE_SIZE/*/*counter_collection.csv")[0])
+        tr = {"_note": "HBM-side bytes per launch unit from rocprofv3 PMC (separate FETCH_SIZE and WRITE_SIZE passes of `bench.py --steps 2 --warmup 1 "
+                       "--serial`, tools/profile.sh traffic, folded by tools/pmc_summary.py --fold-domains), FETCH_SIZE (KB) doubled as MI355X_MICROARCH.md "
+                       "\u00a7HBM prescribes for gfx950; WRITE_SIZE as reported.  Units: nn_icp = k_icp_corr<cold|warm> + its k_icp_corr_coop; icp_moments = one "
+                       "estimator step (k_chain_* + k_icp_update_wide); nn_score = one batch: k_score_keys + the radix sort's passes + k_score_scene + "
+                       "k_score_gather; nn_label = k_label + the gather to input order.  Atomics execute at the memory side and count 64 B each.",
+              "kernels_sha": sha}
+        for d in DOMAINS:
+            u = max(1.0, F[d].get("units", 0))
+            tr[d] = (2.0 * F[d].get("FETCH_SIZE", 0.0) + Wr[d].get("WRITE_SIZE", 0.0)) * 1024.0 / u
+            tr[d + "_fetch_x2_write_MB"] = [round(2.0 * F[d].get("FETCH_SIZE", 0.0) * 1024 / u / 1e6, 2), round(Wr[d].get("WRITE_SIZE", 0.0) * 1024 / u / 1e6, 2)]
+        json.dump(tr, open("profiles/pmc_traffic.json", "w"), indent=1)
+        print("traffic, MB per launch unit:", {d: round(tr[d] / 1e6, 1) for d in DOMAINS})
+        ipath = glob.glob("gpurun_out/prof_pmc/*/*counter_collection.csv")
+        if ipath:
+            I = per_domain(ipath[0])
+            ins = {"_note": "wave-level instruction counts per launch unit (SQ_INSTS_VALU / SALU / LDS, SQ_WAVES, SQ_BUSY_CYCLES, SQ_WAVE_CYCLES, SQ_WAIT_*), one "
+                            "rocprofv3 --pmc pass of `bench.py --steps 1 --warmup 0 --serial` (tools/profile.sh pmc), units as in pmc_traffic.json",
+                   "kernels_sha": sha}
+            for d in DOMAINS:
+                u = max(1.0, I[d].get("units", 0))
+                ins[d] = {c: round(v / u) for c, v in I[d].items() if c != "units"}
+                ins[d]["units_in_the_pass"] = int(I[d].get("units", 0))
+            json.dump(ins, open("profiles/pmc_instructions.json", "w"), indent=1)
+            print("instructions, millions per launch unit:", {d: {c: round(v / 1e6, 1) for c, v in ins[d].items() if c.startswith("SQ_INSTS")} for d in DOMAINS})
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "--traffic":
         out = {}
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
