@@ -1290,7 +1290,11 @@ __device__ __forceinline__ Match coop_search( const GridView& g, bool active,
   // have no match at all, so the ladder of small shells only adds row enumerations and barriers:
   // one shell of two cells, then the whole box.
   bool unsettled = active;
-  for( int k = 2; ; k = 1 << 20 )
+  // (WARM, round 5: a tile with a lane that starts from nothing — it had no match last iteration either, or lost it to the shrinking
+  //  radius — almost always ends with that lane still unmatched, i.e. after the whole box: the two-cell shell first only adds a row
+  //  enumeration, a chunk's round trip and two barriers to a tile that is ~20 us of dependent round trips and nothing else)
+  const int k_first = ( WARM && __any( active & !m.found ) ) ? ( 1 << 20 ) : 2;      // (every wave holds the same 64 queries: the same decision)
+  for( int k = k_first; ; k = 1 << 20 )
   {
     cur = ( g.inv_cell > 0.0f ) ? box_grow( core, k, full ) : full;
     // only the part of the shell within reach of a still-unsettled lane (see tile_search); identical in every wave
