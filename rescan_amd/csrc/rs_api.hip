@@ -1457,20 +1457,6 @@ int rs_hip_alignment_scores( const rs_hip_cloud_t* object, const rs_hip_cloud_t*
   L.K = max_n_neigh; L.sigma = (double)radius; L.part = g_ws.score_part.as<double>(); L.scores = g_ws.scores.as<float>();
   L.queue = g_ws.queue.as<int>(); L.queue_count = g_ws.queue_count.as<int>();
   L.solo_stages = handoff_threshold( (long long)n_tiles * n_poses );
-  // opt-in: the cold search row by row (16 lanes) with a K-stop per lane.  Same bits, 383 instead of 841 candidate evaluations per
-  // point pair — and slower: 564 M VALU instructions per launch instead of 471 M, 1.53 ms instead of 1.16
-  L.by_rows = getenv( "RS_HIP_SCORE_ROWS" ) ? 1 : 0;
-  // K-cap (opt-in, RS_HIP_SCORE_KCAP=<fraction of radius², e.g. 0.5>): a lane that has met K candidates within sqrt( kcap ) x radius
-  // stops caring about anything beyond.  Exact (same 256 bits) and measured useless on the bench's poses: 424 M VALU instructions per
-  // launch against 406 M without, 0.89 against 0.91 ms — the box a tile sweeps is set by its matched lanes' shells as much as by
-  // the unmatched ones' reach, and the counting costs what the smaller boxes save (profiles/r03/score_kcap.txt).
-  static const float kcap = getenv( "RS_HIP_SCORE_KCAP" ) ? (float)atof( getenv( "RS_HIP_SCORE_KCAP" ) ) : 0.0f;
-  L.kcap_frac = ( kcap > 0.0f && kcap < 1.0f ) ? kcap : ( kcap < 0.0f ? kcap : 0.0f );     // (< 0: the K-cap distance follows the shells, scene-space route only)
-  // (Tried in round 4 and removed: a two-radius search — stage 1 within the distance that is expected to hold 1.5 K candidates, only
-  //  lanes that neither matched nor counted K going on to the radius.  Exact (the bench's 256 scores stayed the reference's bits) and
-  //  slower: 0.99 ms against 0.88 for the batch alone, 897 candidates staged per (tile, pose) wave against 840 — nearly every tile
-  //  of a mediocre pose has a lane in sparse surroundings, which sends the tile to stage 2, and what stage 2 streams again outweighs
-  //  what the dense tiles save.  profiles/r04/score_two_radius.txt)
   L.hist = nullptr;
   thread_local DevBuf histbuf;
   if( RS_DBG && getenv( "RS_HIP_SCORE_HIST" ) && !histbuf.ensure( 7 * 65 * 8 ) ) { (void)hipMemsetAsync( histbuf.p, 0, 7 * 65 * 8, g_stream ); L.hist = histbuf.as<unsigned long long>(); }
@@ -1479,14 +1465,13 @@ int rs_hip_alignment_scores( const rs_hip_cloud_t* object, const rs_hip_cloud_t*
   static const int scene_route = getenv( "RS_HIP_SCORE_SCENE" ) ? atoi( getenv( "RS_HIP_SCORE_SCENE" ) ) : 1;
   const long long scene_min = g_score_scene_from.load();
   static const float parent_scale = getenv( "RS_HIP_SCORE_PARENT" ) ? (float)atof( getenv( "RS_HIP_SCORE_PARENT" ) ) : 1.0f;   // parent edge / radius
-  static const int merge_below = getenv( "RS_HIP_SCORE_MERGE" ) ? atoi( getenv( "RS_HIP_SCORE_MERGE" ) ) : 0;
   int chunk_poses = 65535;      // the launch grid's y dimension is limited to 65535 poses per launch
-  const bool scene_space = scene_route && L.scene.inv_cell > 0.0f && !L.by_rows &&
+  const bool scene_space = scene_route && L.scene.inv_cell > 0.0f &&
                            (long long)n_poses * object->n >= scene_min && object->n < ( 1 << 24 );
   if( scene_space )
   {
     const GridView& g = L.scene;
-    static const int nbin = getenv( "RS_HIP_SCORE_NBIN" ) ? atoi( getenv( "RS_HIP_SCORE_NBIN" ) ) : 2;
+    static const int nbin = getenv( "RS_HIP_SCORE_NBIN" ) ? atoi( getenv( "RS_HIP_SCORE_NBIN" ) ) : 1;
     static const int cull = getenv( "RS_HIP_SCORE_CULL" ) ? atoi( getenv( "RS_HIP_SCORE_CULL" ) ) : 1;
     // the scene grid's box grown by the radius: a query outside has nothing to match ...
     float lo[3] = { g.minx - radius, g.miny - radius, g.minz - radius };
@@ -1522,7 +1507,7 @@ int rs_hip_alignment_scores( const rs_hip_cloud_t* object, const rs_hip_cloud_t*
     }
     // parent edge: the radius, as a whole number of cells (a coarser grid: its cell); doubled until the lattice has < 2^24 / 64 parents
     float parent = g.cell * std::max( 1.0f, roundf( parent_scale * radius / g.cell ) );
-    const int fine_bits = nbin == 3 ? 3 : 6;
+    const int fine_bits = 6;
     for( ;; parent *= 2.0f )
     {
       L.sq_dpx = (int)ceilf( ( hi[0] - lo[0] ) / parent ) + 1; L.sq_dpy = (int)ceilf( ( hi[1] - lo[1] ) / parent ) + 1; L.sq_dpz = (int)ceilf( ( hi[2] - lo[2] ) / parent ) + 1;
@@ -1532,7 +1517,7 @@ int rs_hip_alignment_scores( const rs_hip_cloud_t* object, const rs_hip_cloud_t*
     L.sq_ox = lo[0]; L.sq_oy = lo[1]; L.sq_oz = lo[2];
     int bits = 0;
     while( ( 1ll << bits ) <= ( (long long)L.sq_n_parents << fine_bits ) ) ++bits;      // the "nothing to match" key n_parents << fine_bits sorts last
-    L.sq_bits = bits; L.sq_fine_bits = fine_bits; L.sq_inv_fine = 4.0f / parent; L.sq_merge = merge_below; L.sq_nbin = nbin; L.sq_cull = cull;
+    L.sq_bits = bits; L.sq_fine_bits = fine_bits; L.sq_inv_fine = 4.0f / parent; L.sq_nbin = nbin ? 1 : 0; L.sq_cull = cull;
     chunk_poses = (int)std::min<long long>( 65535, std::max<long long>( 1, ( 1ll << 30 ) / object->n ) );
     const size_t items = (size_t)std::min( chunk_poses, n_poses ) * object->n;
     const size_t tmp_bytes = build_sort_temp_bytes( (int)items, bits );
@@ -1542,7 +1527,6 @@ int rs_hip_alignment_scores( const rs_hip_cloud_t* object, const rs_hip_cloud_t*
     L.sq_key_a = g_ws.sq_ka.as<uint32_t>(); L.sq_key_b = g_ws.sq_kb.as<uint32_t>(); L.sq_val_a = g_ws.sq_va.as<uint32_t>(); L.sq_val_b = g_ws.sq_vb.as<uint32_t>();
     L.sq_pq = g_ws.sq_pq.as<double>(); L.sq_tmp = g_ws.sq_tmp.p; L.sq_tmp_bytes = g_ws.sq_tmp.cap;
   }
-  else if( L.kcap_frac < 0.0f ) L.kcap_frac = 0.0f;
   for( int p0 = 0; p0 < n_poses; p0 += chunk_poses )
   {
     ScoreLaunch Lp = L;

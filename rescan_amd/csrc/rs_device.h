@@ -206,8 +206,6 @@ struct ScoreLaunch
   int*         queue;      // n_poses x n_tiles items (pose*n_tiles + tile) for the cooperative kernel
   int*         queue_count;
   int          solo_stages;
-  int          by_rows;    // launches that hand nothing off: the row-wise cold search (rs_search.h: tile_search_rows)
-  float        kcap_frac;  // K-cap distance² as a fraction of radius² (rs_search.h: KCap); 0: off
   unsigned long long* hist;   // diagnostic builds only (RS_HIP_SCORE_HIST): 6 x 65 counters, see k_score
   // Scene-space batches (rs_score.hip: k_score_keys / k_score_scene / k_score_gather): the n_poses x n transformed queries sorted by
   // the scene-aligned block ("parent", edge sq_parent ~ the radius) they fall in, so that a wave's queries share one neighbourhood
@@ -220,14 +218,13 @@ struct ScoreLaunch
   void*        sq_tmp;     // radix sort workspace
   size_t       sq_tmp_bytes;
   int          sq_bits;    // key bits to sort
-  int          sq_fine_bits;   // low key bits below the parent index (6, or 3: direction only)
+  int          sq_fine_bits;   // low key bits below the parent index (6)
   int          sq_n_parents, sq_dpx, sq_dpy, sq_dpz;
   float        sq_ox, sq_oy, sq_oz;     // origin of the parent lattice (the scene grid's, moved out by whole parents)
   float        sq_inv_fine;             // 4 / parent edge
   float        sq_lox, sq_hix, sq_loy, sq_hiy, sq_loz, sq_hiz;   // the scene grid's box grown by the radius: a query outside has nothing to match
-  int          sq_merge;   // > 0: a parent with at most this many queries in the wave is searched together with its x-neighbour's
   int          sq_cull;    // sweeps skip the cells farther from the wave's queries than they look (rs_search.h: Cull)
-  int          sq_nbin;    // the key's low bits also carry the query normal's dominant direction (0: off)
+  int          sq_nbin;    // the key's low bits carry the query normal's dominant direction (0: the quarter-parent sub-cell instead)
 };
 void launch_score( const ScoreLaunch& L, hipStream_t st );
 

@@ -40,32 +40,19 @@ __device__ __forceinline__ void score_emit( const ScoreLaunch& L, int pose, int 
   if( lane == 0 ) L.part[(size_t)pose * L.obj.n_tiles + tile] = s;
 }
 
-// (7 waves per SIMD — 72 VGPRs, 44 B of scratch per lane — since round 3: on its quarter of the CUs the batch is bound by vector issue,
-//  and a seventh wave fills more of it than the spills cost: 2.87 -> 2.77 ms there, four interleaved repeats; 5 waves, no spills: 3.00)
+// Object-space launch: small batches, brute-layout scenes.  grid = tiles x poses, one tile (wave) per workgroup.
+// (7 waves per SIMD, 71 VGPRs, no scratch.  One tile per workgroup: a workgroup's slots are released when its LAST wave ends, and the four tiles
+//  of a four-wave workgroup do not take equally long — 1.21 -> 1.09 ms for the 256-pose batch alone in round 2.)
 #ifndef RS_SCORE_OCC
 #define RS_SCORE_OCC 7
 #endif
-#ifndef RS_SCORE_ROWS_OCC
-#define RS_SCORE_ROWS_OCC 5
-#endif
-// RB = 0: the tile-wide search (with hand-off to k_score_coop); RB = 16: the cold search row by row, RB candidates per row and round
-// Waves per workgroup of the score batch's search.  As for phase A of the ICP search: a workgroup's slots are released when its
-// last wave ends, and the four tiles of a workgroup do not take equally long (~180 us each, +-30 %): one tile per workgroup is
-// 1.21 -> 1.09 ms for the batch alone and 2.60 -> 2.29 ms on its 3/8 of the CUs beside the ICP chain.
-#ifndef RS_SC_WAVES
-#define RS_SC_WAVES 1
-#endif
-constexpr int SC_WAVES = RS_SC_WAVES;
-template <int RB, bool KCAP = false>
-__global__ __launch_bounds__( SC_WAVES * WAVE, RB ? RS_SCORE_ROWS_OCC : RS_SCORE_OCC ) void k_score( ScoreLaunch L )
+__global__ __launch_bounds__( WAVE, RS_SCORE_OCC ) void k_score( ScoreLaunch L )
 {
-  typedef WaveLdsT<( RB ? 4 * RB : WAVE )> Lds;
-  __shared__ Lds lds[SC_WAVES];
+  __shared__ WaveLds lds;
   const int pose = blockIdx.y;
-  const int lane = threadIdx.x & ( WAVE - 1 );
-  const int wib = SC_WAVES == 1 ? 0 : uni( (int)threadIdx.x / WAVE );      // (told to be uniform: as threadIdx.x / 64 the tile's number lived in a vector register pair for the whole kernel)
-  EvalScope eval_scope( L.scene.evals, lds[wib], lane );
-  const int tile = blockIdx.x * SC_WAVES + wib;
+  const int lane = threadIdx.x;
+  EvalScope eval_scope( L.scene.evals, lds, lane );
+  const int tile = blockIdx.x;
   if( tile >= L.obj.n_tiles ) return;
   const int i = (int)L.obj.tiles[tile] + lane;
   const bool active = i < (int)L.obj.tiles[tile + 1];
@@ -77,27 +64,15 @@ __global__ __launch_bounds__( SC_WAVES * WAVE, RB ? RS_SCORE_ROWS_OCC : RS_SCORE
   bool handoff;
   // (starting from the query's own cell, as the cold ICP search does, measured 10 % slower here: bad poses leave
   //  most lanes without a usable point in their cell, and the mixed tiles pay for the seed without skipping the shells)
-  Match m;
-  if constexpr( RB > 0 )
-  { handoff = false; m = tile_search_rows<true, RB>( L.scene, active, qx, qy, qz, nx, ny, nz, (float)L.sigma, L.radius_sq, L.gate_tmin, L.K, lds[wib], lane ); }
-  else
+  int slog[16] = { 0 };
+  const Match m = tile_search<true>( L.scene, active, qx, qy, qz, nx, ny, nz, (float)L.sigma, L.radius_sq, L.gate_tmin, L.K,
+                                     lds, lane, L.solo_stages, &handoff, ( RS_DBG && L.hist ) ? slog : nullptr, no_match() );
+  if( RS_DBG && L.hist && lane == 0 )
   {
-    if constexpr( KCAP )
-      m = tile_search<true, false, false, true>( L.scene, active, qx, qy, qz, nx, ny, nz, (float)L.sigma, L.radius_sq, L.gate_tmin, L.K,
-                             lds[wib], lane, L.solo_stages, &handoff, nullptr, no_match(), nullptr, false, nullptr, 0, L.kcap_frac );
-    else
-    {
-      int slog[16] = { 0 };
-      m = tile_search<true>( L.scene, active, qx, qy, qz, nx, ny, nz, (float)L.sigma, L.radius_sq, L.gate_tmin, L.K,
-                             lds[wib], lane, L.solo_stages, &handoff, ( RS_DBG && L.hist ) ? slog : nullptr, no_match() );
-      if( RS_DBG && L.hist && lane == 0 )
-      {
-        // diagnostic builds (RS_HIP_SCORE_HIST): candidates streamed by shell s for u unsettled lanes -> hist[s][u]; by the rank pass for u
-        // lanes that need their rank -> hist[5][u]
-        for( int sh = 0; sh < 5; ++sh ) if( slog[5 + 2 * sh] > 0 ) atomicAdd( L.hist + sh * 65 + min( slog[4 + 2 * sh], 64 ), (unsigned long long)slog[5 + 2 * sh] );
-        if( slog[2] > 0 ) atomicAdd( L.hist + 5 * 65 + min( slog[15], 64 ), (unsigned long long)slog[2] );
-      }
-    }
+    // diagnostic builds (RS_HIP_SCORE_HIST): candidates streamed by shell s for u unsettled lanes -> hist[s][u]; by the rank pass for u
+    // lanes that need their rank -> hist[5][u]
+    for( int sh = 0; sh < 5; ++sh ) if( slog[5 + 2 * sh] > 0 ) atomicAdd( L.hist + sh * 65 + min( slog[4 + 2 * sh], 64 ), (unsigned long long)slog[5 + 2 * sh] );
+    if( slog[2] > 0 ) atomicAdd( L.hist + 5 * 65 + min( slog[15], 64 ), (unsigned long long)slog[2] );
   }
   if( handoff )
   {
@@ -183,15 +158,17 @@ __global__ __launch_bounds__( BLOCK ) void k_score_keys( ScoreLaunch L )
     const int ix = min( max( (int)( ( qx - L.sq_ox ) * L.sq_inv_fine ), 0 ), 4 * L.sq_dpx - 1 );
     const int iy = min( max( (int)( ( qy - L.sq_oy ) * L.sq_inv_fine ), 0 ), 4 * L.sq_dpy - 1 );
     const int iz = min( max( (int)( ( qz - L.sq_oz ) * L.sq_inv_fine ), 0 ), 4 * L.sq_dpz - 1 );
-    // low bits: [the transformed normal's dominant axis and sign, so that a wave's queries also face the same way — what they can
-    // match, and how far away, is then much the same for all 64 —] and the Morton code of the quarter-parent sub-cell
-    uint32_t fine = morton_2bit( ix & 3, iy & 3, iz & 3 );
+    // low bits: the octant of the parent the query falls in, then the dominant axis and sign of its TRANSFORMED normal — a wave's
+    // queries then also face the same way: what they can match, and how far away, is much the same for all 64 (16.4 M candidates
+    // staged instead of 21.1 M)
+    uint32_t fine = morton_2bit( ix & 3, iy & 3, iz & 3 ) >> 3;
     if( L.sq_nbin )
     {
       const float ax = fabsf( nx ), ay = fabsf( ny ), az = fabsf( nz );
       const uint32_t nb = ax >= ay && ax >= az ? ( nx < 0.0f ? 1u : 0u ) : ay >= az ? ( ny < 0.0f ? 3u : 2u ) : ( nz < 0.0f ? 5u : 4u );
-      fine = L.sq_nbin == 1 ? ( ( nb << 3 ) | ( fine >> 3 ) ) : L.sq_nbin == 2 ? ( ( ( fine >> 3 ) << 3 ) | nb ) : nb;     // 1: direction first, then the half-parent octant; 2: octant first; 3: direction only
+      fine = ( fine << 3 ) | nb;
     }
+    else fine = morton_2bit( ix & 3, iy & 3, iz & 3 );      // (the quarter-parent sub-cell instead)
     key = ( (uint32_t)( ( ( iz >> 2 ) * L.sq_dpy + ( iy >> 2 ) ) * L.sq_dpx + ( ix >> 2 ) ) << L.sq_fine_bits ) | fine;
   }
   const uint32_t j = (uint32_t)pose * (uint32_t)L.obj.n + (uint32_t)i;
@@ -201,7 +178,7 @@ __global__ __launch_bounds__( BLOCK ) void k_score_keys( ScoreLaunch L )
 #ifndef RS_SCORE_SCENE_OCC
 #define RS_SCORE_SCENE_OCC 7
 #endif
-template <bool KCAP, bool CULL>
+template <bool CULL>
 __global__ __launch_bounds__( WAVE, RS_SCORE_SCENE_OCC ) void k_score_scene( ScoreLaunch L, uint32_t items )
 {
   __shared__ WaveLds lds;
@@ -227,20 +204,14 @@ __global__ __launch_bounds__( WAVE, RS_SCORE_SCENE_OCC ) void k_score_scene( Sco
   bool found = false; float r_dot = 0.0f, r_d2 = 0.0f;
   while( pending != 0ull )
   {
-    // the entries of the first unserved lane's parent (sorted: a run of lanes) — with sq_merge, of its x-neighbour too while the
-    // run stays short: a sparse block's few queries share their shells with the next block's instead of paying for them alone
+    // the entries of the first unserved lane's parent (sorted: a run of lanes)
     const int first = __builtin_ctzll( pending );
     const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane( (int)par, first );
-    bool act = valid && par == pk;
-    if( L.sq_merge > 0 )
-    {
-      const bool row_end = ( pk % (uint32_t)L.sq_dpx ) == (uint32_t)L.sq_dpx - 1u;
-      if( !row_end && __popcll( RS_BALLOT( act ) ) <= L.sq_merge ) act = valid && ( par == pk || par == pk + 1u );
-    }
+    const bool act = valid && par == pk;
     int slog[16] = { 0 };
     if( RS_DBG ) slog[14] = __popcll( RS_BALLOT( act ) );
-    const Match m = tile_search<true, false, false, KCAP, CULL>( L.scene, act, qx, qy, qz, nx, ny, nz, (float)L.sigma, L.radius_sq, L.gate_tmin, L.K,
-                                       lds, lane, 0x7fffffff, nullptr, ( RS_DBG && L.hist ) ? slog : nullptr, no_match(), nullptr, false, nullptr, 0, L.kcap_frac );
+    const Match m = tile_search<true, false, false, CULL>( L.scene, act, qx, qy, qz, nx, ny, nz, (float)L.sigma, L.radius_sq, L.gate_tmin, L.K,
+                                                           lds, lane, 0x7fffffff, nullptr, ( RS_DBG && L.hist ) ? slog : nullptr, no_match() );
     if( RS_DBG && L.hist && lane == 0 )
     {
       // diagnostic builds (RS_HIP_SCORE_HIST), as in k_score; row 6: searches by the number of lanes they serve
@@ -292,25 +263,13 @@ void launch_score( const ScoreLaunch& L, hipStream_t st )
     hipLaunchKernelGGL( k_score_keys, dim3( ( L.obj.n + BLOCK - 1 ) / BLOCK, L.n_poses ), dim3( BLOCK ), 0, st, L );
     (void)build_sort_pairs( L.sq_tmp, L.sq_tmp_bytes, L.sq_key_a, L.sq_key_b, L.sq_val_a, L.sq_val_b, (int)items, L.sq_bits, st );
     const dim3 sgrid( ( items + WAVE - 1 ) / WAVE );
-    if( L.kcap_frac != 0.0f ) { if( L.sq_cull ) hipLaunchKernelGGL( ( k_score_scene<true, true> ), sgrid, dim3( WAVE ), 0, st, L, items ); else hipLaunchKernelGGL( ( k_score_scene<true, false> ), sgrid, dim3( WAVE ), 0, st, L, items ); }
-    else                      { if( L.sq_cull ) hipLaunchKernelGGL( ( k_score_scene<false, true> ), sgrid, dim3( WAVE ), 0, st, L, items ); else hipLaunchKernelGGL( ( k_score_scene<false, false> ), sgrid, dim3( WAVE ), 0, st, L, items ); }
+    if( L.sq_cull ) hipLaunchKernelGGL( k_score_scene<true>, sgrid, dim3( WAVE ), 0, st, L, items );
+    else            hipLaunchKernelGGL( k_score_scene<false>, sgrid, dim3( WAVE ), 0, st, L, items );
     hipLaunchKernelGGL( k_score_gather, dim3( L.n_poses ), dim3( SCORE_GATHER_THREADS ), 0, st, L );
     return;
   }
   (void)hipMemsetAsync( L.queue_count, 0, sizeof(int), st );
-  dim3 grid( ( L.obj.n_tiles + SC_WAVES - 1 ) / SC_WAVES, L.n_poses );
-  // by_rows: big batches on a cell grid only — nothing is handed off there.  (16 candidates per row and round; 32 and 64 were
-  // measured too: 1.70 and 2.15 ms against 1.53 — rows of unequal length evaluate sentinels up to the longest one's count.)
-  if( L.by_rows && L.solo_stages == 0x7fffffff && L.scene.inv_cell > 0.0f ) hipLaunchKernelGGL( k_score<16>, grid, dim3( SC_WAVES * WAVE ), 0, st, L );
-  else if( L.kcap_frac > 0.0f ) hipLaunchKernelGGL( ( k_score<0, true> ), grid, dim3( SC_WAVES * WAVE ), 0, st, L );      // (opt-in experiment: RS_HIP_SCORE_KCAP)
-  else
-  {
-    // RS_HIP_SCORE_LDS_PAD=<bytes>: dynamic LDS nobody uses — caps how many of this kernel's single-wave workgroups a CU holds, so
-    // that a latency-bound chain of kernels issued beside the batch finds free slots on every CU (bench.py: the alternative to
-    // confining the two to disjoint CUs)
-    static const int pad = getenv( "RS_HIP_SCORE_LDS_PAD" ) ? atoi( getenv( "RS_HIP_SCORE_LDS_PAD" ) ) : 0;
-    hipLaunchKernelGGL( ( k_score<0, false> ), grid, dim3( SC_WAVES * WAVE ), (size_t)( pad > 0 ? pad : 0 ), st, L );
-  }
+  hipLaunchKernelGGL( k_score, dim3( L.obj.n_tiles, L.n_poses ), dim3( WAVE ), 0, st, L );
   long long items = (long long)L.obj.n_tiles * L.n_poses;
   hipLaunchKernelGGL( k_score_coop, dim3( items < 4096 ? (int)( items > 0 ? items : 1 ) : 4096 ), dim3( COOP_BLOCK ), 0, st, L );
   hipLaunchKernelGGL( k_score_final, dim3( L.n_poses ), dim3( BLOCK ), 0, st, L );

@@ -634,17 +634,10 @@ __device__ __forceinline__ void count_lanes( int& cnt, lanemask mask )
   asm( "v_addc_co_u32 %0, %1, 0, %0, %2" : "+v"( cnt ), "=s"( carry_out ) : "s"( mask ) );
 }
 
-// K-cap of a cold gated search (KCAP; the score batch): the consumers only walk the K NEAREST candidates, so once a lane has met K
-// candidates closer than some distance, nothing at or beyond that distance can ever be its match (its rank would be >= K).  One
-// such distance is tested, tau2 = a fixed fraction of radius²: a lane counts what it meets below it (cap_count) and, at K, lowers
-// its bound to it — a match it may hold beyond is dropped (rank >= K, proven).  Exact, and it turns the lanes that have nothing
-// compatible nearby — whose bound otherwise stays at the radius, which keeps the whole wave gating every candidate and sweeping
-// the full box — into lanes with the reach of their K-th neighbour.
-struct KCap { float tau2; int count; };
-template <bool GATED, bool SELF, bool KCAP = false, class LDS>
+template <bool GATED, bool SELF, class LDS>
 __device__ __forceinline__ void consider4( const float4& X, const float4& Y, const float4& Z, int k, const LDS& L,
                                            float qx, float qy, float qz, float nx, float ny, float nz,
-                                           float tmin, float& bound, Match& m, int& seen_closer, KCap* cap = nullptr, int K = 0 )
+                                           float tmin, float& bound, Match& m, int& seen_closer )
 {
   float d[4];
   dist2x4( X, Y, Z, qx, qy, qz, d[0], d[1], d[2], d[3] );
@@ -652,23 +645,6 @@ __device__ __forceinline__ void consider4( const float4& X, const float4& Y, con
 #pragma unroll
   for( int i = 0; i < 4; ++i ) in[i] = RS_BALLOT( d[i] < bound );
   if( ( in[0] | in[1] | in[2] | in[3] ) == 0ull ) return;
-  if( KCAP )
-  {
-    // (a candidate below tau2 that is not below the lane's bound any more is closer than nothing the lane still cares about:
-    //  not counting it only delays the cap)
-#pragma unroll
-    for( int i = 0; i < 4; ++i ) count_lanes( cap->count, in[i] & RS_BALLOT( d[i] < cap->tau2 ) );
-    const bool capit = cap->count >= K && bound > cap->tau2;
-    if( RS_BALLOT( capit ) != 0ull )                     // (uniform: the lane masks below are taken with every lane present)
-    {
-      const bool drop = capit && m.found && !( m.d2 < cap->tau2 );
-      bound = capit ? cap->tau2 : bound;
-      m.found = drop ? false : m.found; m.slot = drop ? -1 : m.slot; m.d2 = drop ? INFINITY : m.d2; m.idx = drop ? INT_MAX : m.idx;
-#pragma unroll
-      for( int i = 0; i < 4; ++i ) in[i] = RS_BALLOT( d[i] < bound );
-      if( ( in[0] | in[1] | in[2] | in[3] ) == 0ull ) return;
-    }
-  }
   int4 I = make_int4( 0, 0, 0, 0 );
   if( SELF )
   {
@@ -872,7 +848,7 @@ __device__ __forceinline__ CellBox cull_cells( const GridView& g, const Cull& c,
   return box_clip( cell_box( g, t, 0.0f ), clip );
 }
 
-template <bool GATED, bool WARM = false, bool BOUNDED_ONLY = false, bool KCAP = false, bool CULL = false>
+template <bool GATED, bool WARM = false, bool BOUNDED_ONLY = false, bool CULL = false>
 __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
                                               float qx, float qy, float qz, float nx, float ny, float nz,
                                               float radius, float radius_sq, float tmin, int K,
@@ -881,17 +857,15 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
                                               int* n_sweeps = nullptr /* out: shells swept + rank pass: the tile's cost class */,
                                               bool by_rows = false /* WARM: sweep_by_rows for tiles whose lanes all start from a candidate */,
                                               uint32_t* n_streamed = nullptr /* out: candidates streamed, rank pass included */,
-                                              int bounded_give_up_total = 0 /* BOUNDED_ONLY: hand a bounded tile off too when, swept tile-wide, the first 64 cell rows of its box hold this many candidates (0: never) */,
-                                              float kcap_frac = 0.5f /* KCAP: tau² / radius² */ )
+                                              int bounded_give_up_total = 0 /* BOUNDED_ONLY: hand a bounded tile off too when, swept tile-wide, the first 64 cell rows of its box hold this many candidates (0: never) */ )
 {
   if( handoff ) *handoff = false;
   int sweeps = 0;
   if( !__any( active ) ) return m;
   int seen_closer = 0;   // candidates that were no farther than the best-so-far when they were met
   float bound = bound_of( active, radius_sq, m );
-  KCap cap; cap.tau2 = radius_sq * kcap_frac; cap.count = 0;
-  // how far a lane still has to look: to its match, or — without one — as far as its bound lets anything in (the radius, or the K-cap)
-  auto reach = [&]() -> float { return ( KCAP && !m.found && active ) ? sqrtf( bound ) * 1.0001f + 1e-5f : reach_of( m, radius ); };
+  // how far a lane still has to look: to its match, or — without one — the radius
+  auto reach = [&]() -> float { return reach_of( m, radius ); };
   uint32_t streamed = 0;
   const bool grid = g.inv_cell > 0.0f;
   const bool all_bounded = WARM && grid && !__any( active & !m.found );
@@ -942,21 +916,11 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
   // own box [q - reach, q + reach] touches has then been examined (its reach only shrinks), which is all the
   // cover test below relies on.
   bool unsettled = active;
-  // KCAP with kcap_frac < 0: the K-cap distance follows the shells — while box k is swept a lane counts what lies within ITS cover
-  // distance of box k (what it counted within the smaller covers before stays counted); K of them settle the lane whatever it holds:
-  // anything outside the box is farther than all K.  -1: the doubling ladder, -2: one more ring of cells per shell.
-  const bool shell_cap = KCAP && kcap_frac < 0.0f;
-  const bool linear = shell_cap && kcap_frac < -1.5f;
   // (CULL — the scene-space score batch, whose tiles are a few centimetres across: the tile's own cells and the first ring in ONE sweep;
   //  a sweep of a dozen candidates costs its set-up, not its candidates)
-  for( int k = ( CULL && grid ) ? 1 : 0; ; k = k ? ( linear ? k + 1 : 2 * k ) : 1 )
+  for( int k = ( CULL && grid ) ? 1 : 0; ; k = k ? 2 * k : 1 )
   {
     cur = grid ? box_grow( core, k, full ) : full;
-    if( shell_cap )
-    {
-      const float ck = box_same( cur, full ) ? -1.0f : box_cover( g, cur, full, qx, qy, qz );
-      cap.tau2 = ck > 0.0f ? fminf( ck * ck, radius_sq ) : ( box_same( cur, full ) ? radius_sq : 0.0f );
-    }
     Cull cl{};
     if( CULL && grid ) cl = cull_of( g, unsettled, reach(), qx, qy, qz );
     // (CULL: the box from the lanes' common box and farthest reach — seven wave reductions instead of thirteen; the rows are clipped to the ball anyway)
@@ -965,16 +929,15 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
     if( !box_empty( out ) )
     {
       streamed += sweep_shell<GATED>( g, out, prev, have_prev, L, lane, 0, 1, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
-      { consider4<GATED, WARM, KCAP>( X, Y, Z, k4, L, qx, qy, qz, nx, ny, nz, tmin, bound, m, seen_closer, &cap, K ); }, 0xffffffffu, CULL && grid, cl );
+      { consider4<GATED, WARM>( X, Y, Z, k4, L, qx, qy, qz, nx, ny, nz, tmin, bound, m, seen_closer ); }, 0xffffffffu, CULL && grid, cl );
     }
     if( dbg_unsettled ) { dbg_unsettled[1] = (int)streamed; if( sweeps < 5 ) dbg_unsettled[5 + 2 * sweeps] += (int)streamed; }
     ++sweeps;
     if( n_sweeps ) *n_sweeps = sweeps;
     if( box_same( cur, full ) ) break;
-    // a lane is settled when nothing outside `cur` can precede its match (or reach it at all: beyond the radius, or beyond its K-cap)
+    // a lane is settled when nothing outside `cur` can precede its match (or reach it at all: beyond the radius)
     const float cov = box_cover( g, cur, full, qx, qy, qz );
-    const bool settled = !active | ( cov >= radius ) | ( m.found & ( cov > 0.0f ) & ( m.d2 < cov * cov ) ) |
-                         ( KCAP & !m.found & ( cov > 0.0f ) & ( bound <= cov * cov ) );
+    const bool settled = !active | ( cov >= radius ) | ( m.found & ( cov > 0.0f ) & ( m.d2 < cov * cov ) );
     unsettled = !settled;
     if( dbg_unsettled ) { if( k == 1 ) dbg_unsettled[0] = __popcll( __ballot( !settled ) ); dbg_unsettled[1] = (int)streamed; dbg_unsettled[3] += 1; }
     if( !__any( !settled ) ) break;
@@ -1025,227 +988,6 @@ __device__ __forceinline__ Match tile_search( const GridView& g, bool active,
   return m;
 }
 
-// ------------------------------------------------------------------------------------------
-// Row-wise cold search (the score batch)
-//
-// tile_search sweeps, for all 64 queries of a tile, the union of their search regions: a 13 cm patch with a 10 cm radius is a
-// 33 cm box, every candidate of which is tested by every lane (~840 evaluations per query in the score batch, most of them far
-// outside the lane's own ball).  Here the wave's four ROWS of 16 lanes (16 Hilbert-consecutive queries: a 6.5 cm patch) each
-// run their own shells around their own boxes, streaming their own candidates into their quarter of the wave's LDS arrays
-// (like sweep_by_rows), and every lane keeps count of the candidates within its cover distance: once K of them are known,
-// nothing unseen can be among the K nearest (the consumers only walk those), so a query without a gate-passing neighbour — most
-// queries of a bad pose — stops at the distance of its K-th neighbour (~5.6 cm at 6 400 pts/m², K = 64) instead of the radius.
-// At tile granularity that rule was useless (the cover distance of a lane at the rim of a 13 cm tile lags far behind); with
-// 6.5 cm rows it fires.  Same results as tile_search (the K-nearest rule is the reference's own).
-// ------------------------------------------------------------------------------------------
-struct RowBox { int x0, x1, y0, y1, z0, z1; };            // per lane; identical within a row of 16 lanes
-__device__ __forceinline__ bool rbox_empty( const RowBox& b ) { return ( b.x1 < b.x0 ) | ( b.y1 < b.y0 ) | ( b.z1 < b.z0 ); }
-__device__ __forceinline__ bool rbox_same( const RowBox& a, const RowBox& b )
-{ return a.x0 == b.x0 && a.x1 == b.x1 && a.y0 == b.y0 && a.y1 == b.y1 && a.z0 == b.z0 && a.z1 == b.z1; }
-
-// cells that can hold a point within r of the row's masked lanes' boxes [q - reach, q + reach] (empty if no lane is masked)
-__device__ __forceinline__ RowBox row_cell_box( const GridView& g, bool mask, float reach, float r, float qx, float qy, float qz )
-{
-  const float big = FLT_MAX;
-  const float lx = row_min( mask ? qx - reach : big ), hx = row_max( mask ? qx + reach : -big );
-  const float ly = row_min( mask ? qy - reach : big ), hy = row_max( mask ? qy + reach : -big );
-  const float lz = row_min( mask ? qz - reach : big ), hz = row_max( mask ? qz + reach : -big );
-  RowBox b;
-  axis_range( lx, hx, r, g.minx, g.inv_cell, g.w, b.x0, b.x1 );
-  axis_range( ly, hy, r, g.miny, g.inv_cell, g.h, b.y0, b.y1 );
-  axis_range( lz, hz, r, g.minz, g.inv_cell, g.d, b.z0, b.z1 );
-  if( hx < lx ) { b.x0 = 0; b.x1 = -1; }
-  return b;
-}
-__device__ __forceinline__ RowBox rbox_grow( const RowBox& core, int k, const RowBox& full )
-{
-  RowBox b;
-  b.x0 = max( core.x0 - k, full.x0 ); b.x1 = min( core.x1 + k, full.x1 );
-  b.y0 = max( core.y0 - k, full.y0 ); b.y1 = min( core.y1 + k, full.y1 );
-  b.z0 = max( core.z0 - k, full.z0 ); b.z1 = min( core.z1 + k, full.z1 );
-  return b;
-}
-__device__ __forceinline__ RowBox rbox_clip( const RowBox& a, const RowBox& c )
-{
-  RowBox b;
-  b.x0 = max( a.x0, c.x0 ); b.x1 = min( a.x1, c.x1 ); b.y0 = max( a.y0, c.y0 ); b.y1 = min( a.y1, c.y1 ); b.z0 = max( a.z0, c.z0 ); b.z1 = min( a.z1, c.z1 );
-  return b;
-}
-__device__ __forceinline__ float rbox_cover( const GridView& g, const RowBox& cur, const RowBox& full, float qx, float qy, float qz )
-{
-  float c = FLT_MAX;
-  if( cur.x0 > full.x0 ) c = fminf( c, qx - ( g.minx + (float)cur.x0 * g.cell ) );
-  if( cur.x1 < full.x1 ) c = fminf( c, ( g.minx + (float)( cur.x1 + 1 ) * g.cell ) - qx );
-  if( cur.y0 > full.y0 ) c = fminf( c, qy - ( g.miny + (float)cur.y0 * g.cell ) );
-  if( cur.y1 < full.y1 ) c = fminf( c, ( g.miny + (float)( cur.y1 + 1 ) * g.cell ) - qy );
-  if( cur.z0 > full.z0 ) c = fminf( c, qz - ( g.minz + (float)cur.z0 * g.cell ) );
-  if( cur.z1 < full.z1 ) c = fminf( c, ( g.minz + (float)( cur.z1 + 1 ) * g.cell ) - qz );
-  return c - ( 1e-4f * g.cell + 2e-5f );
-}
-
-// Every row streams (its out \ its in) through its quarter of the wave's LDS arrays, RB candidates per row and round (RB / 16
-// loads in flight per lane: with 16 a round is four candidate groups per lane, too little work to cover the loads of the next):
-// f( X, Y, Z, k ) for every group of four staged candidates k..k+3 of the calling lane's row (k differs between rows).
-// Sentinels as in sweep_shell.  LDS = WaveLdsT<4 * RB>.
-template <bool WITH_NOR, int RB, class LDS, class F>
-__device__ __forceinline__ uint32_t sweep_rows_shell( const GridView& g, const RowBox& out, const RowBox& in, bool in_valid,
-                                                      LDS& L, int lane, F&& f )
-{
-  constexpr int NF = RB / 16;
-  const int l16 = lane & 15, tbase = lane & 48, sbase = ( lane >> 4 ) * RB;
-  const int ny = out.y1 - out.y0 + 1, nz = out.z1 - out.z0 + 1;
-  const int n_rows = rbox_empty( out ) ? 0 : ny * nz;
-  const float inv_ny = 1.0f / (float)max( ny, 1 );
-  uint32_t streamed = 0;
-  for( int r0 = 0; __any( r0 < n_rows ); r0 += 16 )
-  {
-    const int r = r0 + l16;
-    uint32_t sa = 0, la = 0, sb = 0, lb = 0;
-    if( r < n_rows )
-    {
-      int rz = (int)( (float)r * inv_ny );
-      rz -= ( rz * ny > r ) ? 1 : 0;
-      rz += ( ( rz + 1 ) * ny <= r ) ? 1 : 0;
-      const int y = out.y0 + ( r - rz * ny ), z = out.z0 + rz;
-      const uint32_t* cs = g.cell_start + (size_t)( z * g.h + y ) * g.w;
-      const bool inside = in_valid && y >= in.y0 && y <= in.y1 && z >= in.z0 && z <= in.z1;
-      if( !inside ) { sa = cs[out.x0]; la = cs[out.x1 + 1] - sa; }
-      else
-      {
-        const int a1 = min( in.x0 - 1, out.x1 ), b0 = max( in.x1 + 1, out.x0 );
-        if( a1 >= out.x0 ) { sa = cs[out.x0]; la = cs[a1 + 1] - sa; }
-        if( b0 <= out.x1 ) { sb = cs[b0]; lb = cs[out.x1 + 1] - sb; }
-      }
-    }
-    const uint32_t incl = row_scan( la + lb );
-    const uint32_t total = row_max_u( incl );                 // of this lane's row
-    L.seg_a[lane] = sa; L.len_a[lane] = la; L.seg_b[lane] = sb; L.pre[lane] = incl - ( la + lb );
-    wave_lds_fence();
-    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane( (int)total, 15 ), t1 = (uint32_t)__builtin_amdgcn_readlane( (int)total, 31 );
-    const uint32_t t2 = (uint32_t)__builtin_amdgcn_readlane( (int)total, 47 ), t3 = (uint32_t)__builtin_amdgcn_readlane( (int)total, 63 );
-    const uint32_t longest = max( max( t0, t1 ), max( t2, t3 ) );
-    streamed += t0 + t1 + t2 + t3;
-    float4 P[NF], N[NF]; uint32_t src[NF];
-    auto fetch = [&]( uint32_t c0 )
-    {
-#pragma unroll
-      for( int q = 0; q < NF; ++q )
-      {
-        const uint32_t j = c0 + (uint32_t)( 16 * q + l16 );
-        P[q] = make_float4( FLT_MAX, FLT_MAX, FLT_MAX, 0.0f ); N[q] = make_float4( 0.0f, 0.0f, 0.0f, 0.0f ); src[q] = 0;
-        if( j < total )
-        {
-          int row = 0;                                 // last cell row of this lane's row whose first candidate number is <= j
-#pragma unroll
-          for( int step = 8; step > 0; step >>= 1 ) { if( L.pre[tbase + row + step] <= j ) row += step; }
-          const uint32_t off = j - L.pre[tbase + row];
-          const uint32_t la_r = L.len_a[tbase + row];
-          src[q] = ( off < la_r ) ? ( L.seg_a[tbase + row] + off ) : ( L.seg_b[tbase + row] + ( off - la_r ) );
-          P[q] = g.pos[src[q]];
-          if( WITH_NOR ) N[q] = g.nor[src[q]];
-        }
-      }
-    };
-    uint32_t c0 = 0;
-    if( c0 < longest ) fetch( c0 );
-    while( c0 < longest )
-    {
-#pragma unroll
-      for( int q = 0; q < NF; ++q )
-      {
-        const int e = sbase + 16 * q + l16;
-        L.px[e] = P[q].x; L.py[e] = P[q].y; L.pz[e] = P[q].z; L.pidx[e] = __float_as_int( P[q].w );
-        if( WITH_NOR ) { L.nx[e] = N[q].x; L.ny[e] = N[q].y; L.nz[e] = N[q].z; }
-        L.slot[e] = src[q];
-      }
-      wave_lds_fence();
-      const uint32_t cn = c0 + (uint32_t)RB;
-      if( cn < longest ) fetch( cn );                  // in flight during the evaluation
-      const uint32_t left = longest - c0;
-      const int n4 = left >= (uint32_t)RB ? RB / 4 : (int)( ( left + 3u ) >> 2 );
-#pragma unroll 1
-      for( int k4 = 0; k4 < n4; ++k4 )
-      {
-        const int k = sbase + 4 * k4;
-        const float4 X = *reinterpret_cast<const float4*>( &L.px[k] );
-        const float4 Y = *reinterpret_cast<const float4*>( &L.py[k] );
-        const float4 Z = *reinterpret_cast<const float4*>( &L.pz[k] );
-        f( X, Y, Z, k );
-      }
-      wave_lds_fence();
-      c0 = cn;
-    }
-    wave_lds_fence();
-  }
-  if( g.evals && lane == 0 ) L.evals += streamed / 4;      // (each candidate is tested by 16 lanes, not 64)
-  return streamed;
-}
-
-// The cold search of one tile, row by row.  Same result as tile_search<GATED>( ..., no hand-off, no starting candidate ).
-template <bool GATED, int RB, class LDS>
-__device__ __forceinline__ Match tile_search_rows( const GridView& g, bool active,
-                                                   float qx, float qy, float qz, float nx, float ny, float nz,
-                                                   float radius, float radius_sq, float tmin, int K, LDS& L, int lane )
-{
-  Match m = no_match();
-  if( !__any( active ) ) return m;
-  int seen_closer = 0, within_cover = 0;
-  float bound = bound_of( active, radius_sq, m );
-  const RowBox full = row_cell_box( g, active, 0.0f, radius, qx, qy, qz );
-  RowBox core = rbox_grow( row_cell_box( g, active, 0.0f, 0.0f, qx, qy, qz ), 0, full );
-  if( rbox_empty( core ) ) core = full;                // the row lies outside the grid but within reach of it
-  RowBox cur = core, prev = core;
-  bool have_prev = false, row_done = rbox_empty( full );
-  bool unsettled = active & !row_done;
-  for( int k = 0; ; ++k )
-  {
-    cur = row_done ? cur : rbox_grow( core, k, full );
-    RowBox out = rbox_clip( row_cell_box( g, unsettled, reach_of( m, radius ), 0.0f, qx, qy, qz ), cur );
-    if( row_done ) { out.x0 = 0; out.x1 = -1; }
-    const float cov = rbox_cover( g, cur, full, qx, qy, qz );
-    const float cov_sq = cov > 0.0f ? cov * cov : 0.0f;
-    sweep_rows_shell<GATED, RB>( g, out, prev, have_prev, L, lane, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
-    {
-      // how many candidates of this shell lie within the lane's cover distance (a lower bound of those within it overall)
-      float d0, d1, d2, d3;
-      dist2x4( X, Y, Z, qx, qy, qz, d0, d1, d2, d3 );
-      within_cover += ( d0 < cov_sq ? 1 : 0 ) + ( d1 < cov_sq ? 1 : 0 ) + ( d2 < cov_sq ? 1 : 0 ) + ( d3 < cov_sq ? 1 : 0 );
-      consider4<GATED, false>( X, Y, Z, k4, L, qx, qy, qz, nx, ny, nz, tmin, bound, m, seen_closer );
-    } );
-    if( !row_done )
-    {
-      const bool at_full = rbox_same( cur, full );
-      bool settled = !active | at_full | ( cov >= radius ) | ( m.found & ( cov > 0.0f ) & ( m.d2 < cov * cov ) );
-      if( !settled && within_cover >= K )
-      {
-        // K candidates within the cover distance: nothing unseen can be among the K nearest, and neither can a match beyond it
-        settled = true; m.found = false; m.slot = -1; bound = -1.0f;
-      }
-      unsettled = !settled;
-      const bool none_left = row_max_u( unsettled ? 1u : 0u ) == 0u;
-      row_done = at_full | none_left;
-      prev = cur; have_prev = true;
-    }
-    if( !__any( !row_done ) ) break;
-  }
-  if( K > 1 || GATED )
-  {
-    // the exact rank where the running count does not settle it (see tile_search); everything closer than a match lies inside
-    // the row's swept box: a match is only kept when it is closer than the cover distance or the row swept its whole region
-    bool need_rank = m.found && ( seen_closer - 1 >= K );
-    if( __any( need_rank ) )
-    {
-      int rank = 0;
-      const RowBox rb = rbox_clip( row_cell_box( g, need_rank, reach_of( m, radius ), 0.0f, qx, qy, qz ), cur );
-      sweep_rows_shell<false, RB>( g, rb, rb, false, L, lane, [&]( const float4& X, const float4& Y, const float4& Z, int k4 )
-      { rank += need_rank ? precede4( X, Y, Z, k4, L, qx, qy, qz, radius_sq, m.d2, m.idx ) : 0; } );
-      if( need_rank && rank >= K ) { m.found = false; m.slot = -1; }
-    }
-  }
-  return m;
-}
-
-// Merge slots of the cooperative search.
 template <int NW>
 struct CoopLds
 {
