@@ -1023,6 +1023,10 @@ def main():
                          "avg_launch_ms": ms / max(1, n_l), "launches": n_l, "alg_bytes_per_launch": bytes_launch,
                          "dominant_by": "longest time per step", "ms_per_step": per_step[dom], "cu_share": shares.get(dom, 1.0),
                          "note": "achieved / frac compare a kernel confined to cu_share of the CUs with the whole chip's peak; roofline_by_kernel has every domain, each with its counter traffic",
+                         # the longest SINGLE launch (the top row of `rocprofv3 --stats` of this command goes to its kernel) — named beside the
+                         # longest domain so that neither reading of "dominant" hides the other
+                         "longest_launch": (lambda k: {"kernel": k, "avg_launch_ms": by_kernel[k]["avg_launch_ms"], "frac": by_kernel[k]["frac"],
+                                                        "traffic_frac": by_kernel[k]["traffic_frac"], "cu_share": by_kernel[k]["cu_share"]})(max(by_kernel, key=lambda k: by_kernel[k]["avg_launch_ms"])),
                          "furthest_below_roofline": {"kernel": worst, "frac": by_kernel[worst]["frac"], "instructions_per_launch": read_instructions(worst)}},
             "roofline_by_kernel": by_kernel,
             "parity": parity_block(out, args.points, seed, args.knn, units, strong, centre=args.centre) if not sim_world else "not compared: RS_BENCH_SIM_WORLD runs one rank's share without the exchange",
