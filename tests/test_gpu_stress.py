@@ -9,6 +9,7 @@ several — and demand identical bits every time.  Sized to finish within about 
 * small radius searches through the zero-copy (pinned-block) route of k_rows_wave from three host threads at once, each
   thread with its own queries, 300 calls per thread, every call compared with the first answer;
 * the three consumers of bench.py's step issued from three threads against the same step issued serially;
+* the score batch's two routes (object tiles / queries sorted by scene block) on random batches: every object, near and far poses, three grids;
 * the time of a whole-scan ICP on a room moved to the origin (centroid sums that hover around zero: the grid chains give up, the
   replay takes over) against the same room as generated: a bounded multiple, and the attempt is not paid again on the next calls.
 """
@@ -162,6 +163,49 @@ def test_three_consumers_side_by_side_repeatedly(capi):
     finally:
         bench.close_roles()                                      # (the runner's worker threads busy-wait between steps)
     assert not bad, f"steps that differ: {bad}"
+
+
+def test_score_routes_agree_on_random_batches(capi, gscene, clouds):
+    """The scene-space score route (queries of every pose sorted by scene block and normal direction; round 5) against the object-space
+    launch on batches it was not tuned on: every object of the scene, poses from a hair off the true one to metres away and rotated about
+    all three axes, radii / K of the reference's three scoring call sites, three scene grids (the reference's 2 r cells, a finer one, the
+    density-derived one), batch sizes that end inside a wave — bit for bit, and repeated (the route's sort is not stable against ties in
+    the KEY, which must not matter)."""
+    from rescan_amd import synth
+    scn_ref, objs = clouds
+    scenes = [scn_ref, capi.Cloud(gscene["points"], gscene["normals"], cell_size=0.05), capi.Cloud(gscene["points"], gscene["normals"])]
+    rng = np.random.default_rng(2025)
+    prev = capi.score_scene_space_from(-1)
+    bad = []
+    try:
+        for trial in range(24):
+            k = trial % len(objs)
+            o = gscene["objects"][k]
+            n_poses = int(rng.choice([1, 3, 17, 64, 129]))
+            poses = []
+            for _ in range(n_poses):
+                scale = float(rng.choice([0.01, 0.1, 0.5, 3.0]))
+                P = synth.perturbed_pose(o["pose"], rng, 0.6 * min(1.0, scale * 4), 0.25 * scale).reshape(4, 4).T.astype(np.float64)
+                ax = rng.normal(size=3); ax /= np.linalg.norm(ax); a = rng.uniform(-0.5, 0.5) * min(1.0, scale * 4)
+                Kx = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+                R = np.eye(3) + np.sin(a) * Kx + (1 - np.cos(a)) * Kx @ Kx
+                P[:3, :3] = P[:3, :3] @ R
+                poses.append(np.ascontiguousarray(P.T.astype(np.float32).ravel()))
+            poses = np.stack(poses)
+            radius, K = [(0.1, 64), (0.1, 32), (0.05, 64)][trial % 3]
+            scn = scenes[trial % 3]
+            capi.score_scene_space_from(1 << 60)
+            a = capi.alignment_scores(objs[k], scn, poses, radius, K)
+            capi.score_scene_space_from(0)
+            b = capi.alignment_scores(objs[k], scn, poses, radius, K)
+            c = capi.alignment_scores(objs[k], scn, poses, radius, K)
+            if not ((a.view(np.uint32) == b.view(np.uint32)).all() and (b.view(np.uint32) == c.view(np.uint32)).all()):
+                bad.append((trial, k, n_poses, radius, K, float(np.abs(a - b).max())))
+        assert not bad, bad
+    finally:
+        capi.score_scene_space_from(prev)
+        for c in scenes[1:]:
+            c.close()
 
 
 def test_centroid_chains_sweep_vs_replay(capi):
