@@ -101,6 +101,13 @@ int rs_hip_icp_align( const rs_hip_cloud_t* source, const rs_hip_cloud_t* target
                       float* T1, const float* T2, float max_dist, float max_angle,
                       int32_t max_iter, int32_t fixed_iters, float* err, int32_t* n_iters );
 
+/* The same call, also leaving the error after every iteration in errs_per_iter[0 .. *n_iters) (room for max_iter floats): what
+ * icp_align( ..., verbose = true ) prints per iteration (icp.h:482-486).  Same result; the loop state is read after every iteration
+ * instead of every few, so it is slower by a synchronisation per iteration. */
+int rs_hip_icp_align_traced( const rs_hip_cloud_t* source, const rs_hip_cloud_t* target,
+                             float* T1, const float* T2, float max_dist, float max_angle,
+                             int32_t max_iter, int32_t fixed_iters, float* err, int32_t* n_iters, float* errs_per_iter );
+
 /* The estimator step (icp.h:136-148,210-298,393-402) has two implementations.  Sources of at most
  * `n_points` points use the reference's own accumulation order and precisions (one sequential fp32 chain
  * per accumulator): poses, errors and iteration counts are bit-identical to the reference's.  Larger

@@ -37,6 +37,8 @@ SIGNATURES = {
                                        C.POINTER(C.c_uint64)]),
     "rs_hip_icp_align": (C.c_int, [C.c_void_p, C.c_void_p, f32p, f32p, C.c_float, C.c_float, C.c_int32, C.c_int32,
                                    C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
+    "rs_hip_icp_align_traced": (C.c_int, [C.c_void_p, C.c_void_p, f32p, f32p, C.c_float, C.c_float, C.c_int32, C.c_int32,
+                                          C.POINTER(C.c_float), C.POINTER(C.c_int32), f32p]),
     "rs_hip_icp_reference_order_below": (C.c_int32, [C.c_int32]),
     "rs_hip_icp_replay_below": (C.c_int32, [C.c_int32]),
     "rs_hip_icp_replay_redone": (C.c_int32, []),
@@ -291,6 +293,18 @@ def icp_align(source, target, T1, T2=IDENTITY, max_dist=0.1, max_angle=np.deg2ra
                                    float(np.float32(max_angle)), int(max_iter), int(bool(fixed_iters)),
                                    C.byref(err), C.byref(it)))
     return err.value, T, it.value
+
+
+def icp_align_traced(source, target, T1, T2=IDENTITY, max_dist=0.1, max_angle=np.deg2rad(60.0), max_iter=100, fixed_iters=False):
+    """icp_align, also returning the error after every iteration (what the reference prints with verbose = true).
+    Returns (err, T1_new, n_iters, errs[n_iters])."""
+    T = _f32(T1).ravel().copy()
+    err = C.c_float(); it = C.c_int32()
+    errs = np.zeros(max(1, int(max_iter)), np.float32)
+    _check(load().rs_hip_icp_align_traced(source.handle, target.handle, T, _f32(T2).ravel(), float(max_dist),
+                                          float(np.float32(max_angle)), int(max_iter), int(bool(fixed_iters)),
+                                          C.byref(err), C.byref(it), errs))
+    return err.value, T, it.value, errs[: it.value].copy()
 
 
 def icp_align_batch(source, target, T1s, T2=IDENTITY, max_dist=0.1, max_angle=np.deg2rad(60.0), max_iter=100,

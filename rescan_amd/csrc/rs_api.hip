@@ -115,6 +115,10 @@ struct Workspace
   PinBuf h_a, h_b, h_c, h_multi;      // h_c: the label entry points' placements; h_multi: a multi-source batch's problem views (an entry point that returns without a synchronisation — rs_hip_label_partial_device — may still be uploading from h_c)
 };
 thread_local Workspace g_ws;
+// rs_hip_icp_align_traced: the calling thread's next single-problem alignment leaves its per-iteration errors here (the loop then
+// reads its state after every iteration instead of every few)
+thread_local float* g_icp_trace = nullptr;
+thread_local int g_icp_trace_cap = 0;
 DevBuf g_faith_redone;            // (a process-wide counter: rs_hip_icp_faith_redone)
 std::mutex g_faith_redone_mu;
 
@@ -1000,7 +1004,7 @@ int icp_align_batch_impl( const rs_hip_cloud_t* source, const rs_hip_cloud_t* ta
   ProfChain prof;
   for( int i = 0; i < max_iter; )                                       // icp.h:444
   {
-    const int chunk = debug ? 1 : ( fixed_iters ? max_iter - i : std::min( std::max( 1, chunk_env ), max_iter - i ) );
+    const int chunk = ( debug || g_icp_trace ) ? 1 : ( fixed_iters ? max_iter - i : std::min( std::max( 1, chunk_env ), max_iter - i ) );
     for( int c = 0; c < chunk; ++c, ++i )
     {
       icp_set_radius( cx, max_dist, tmin );
@@ -1039,6 +1043,7 @@ int icp_align_batch_impl( const rs_hip_cloud_t* source, const rs_hip_cloud_t* ta
     prof.mark( nullptr );
     HIP_TRY( hipMemcpyAsync( hS, g_ws.state.p, state_bytes, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
     HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
+    if( g_icp_trace && n == 1 && i >= 1 && i - 1 < g_icp_trace_cap ) g_icp_trace[i - 1] = hS[np * 34];      // the error after iteration i - 1
     int n_active = 0;
     for( int p = 0; p < n; ++p ) n_active += hActive[p] ? 1 : 0;
     if( n_active == 0 ) break;
@@ -1191,7 +1196,7 @@ int rs_hip_icp_align_multi( const rs_hip_cloud_t* const* sources, const rs_hip_c
   ProfChain prof;
   for( int i = 0; i < max_iter; )                                       // icp.h:444
   {
-    const int chunk = fixed_iters ? max_iter - i : std::min( std::max( 1, chunk_env ), max_iter - i );
+    const int chunk = g_icp_trace ? 1 : ( fixed_iters ? max_iter - i : std::min( std::max( 1, chunk_env ), max_iter - i ) );
     for( int c = 0; c < chunk; ++c, ++i )
     {
       icp_set_radius( cx, max_dist, tmin );
@@ -1213,6 +1218,7 @@ int rs_hip_icp_align_multi( const rs_hip_cloud_t* const* sources, const rs_hip_c
     prof.mark( nullptr );
     HIP_TRY( hipMemcpyAsync( hS, g_ws.state.p, state_bytes, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
     HIP_TRY( hipStreamSynchronize( g_stream ), RS_HIP_E_RUNTIME );
+    if( g_icp_trace && n == 1 && i >= 1 && i - 1 < g_icp_trace_cap ) g_icp_trace[i - 1] = hS[np * 34];      // the error after iteration i - 1
     int n_active = 0;
     for( int p = 0; p < n; ++p ) n_active += hActive[p] ? 1 : 0;
     if( n_active == 0 ) break;
@@ -1275,6 +1281,16 @@ int32_t rs_hip_icp_replay_redone( void )
   int v = 0;
   if( g_ws.rp_redone.p && hipMemcpy( &v, g_ws.rp_redone.p, 4, hipMemcpyDeviceToHost ) != hipSuccess ) return -1;
   return v;
+}
+
+int rs_hip_icp_align_traced( const rs_hip_cloud_t* source, const rs_hip_cloud_t* target,
+                             float* T1, const float* T2, float max_dist, float max_angle,
+                             int32_t max_iter, int32_t fixed_iters, float* err, int32_t* n_iters, float* errs_per_iter )
+{
+  g_icp_trace = errs_per_iter; g_icp_trace_cap = errs_per_iter ? std::max( 0, max_iter ) : 0;
+  const int rc = rs_hip_icp_align( source, target, T1, T2, max_dist, max_angle, max_iter, fixed_iters, err, n_iters );
+  g_icp_trace = nullptr; g_icp_trace_cap = 0;
+  return rc;
 }
 
 int rs_hip_icp_align( const rs_hip_cloud_t* source, const rs_hip_cloud_t* target,

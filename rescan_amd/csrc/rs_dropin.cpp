@@ -430,10 +430,31 @@ float icp_align( rsd_vec3_t* pts1, rsd_vec3_t* nor1, int32_t n_pts1, rsd_vec3_t*
   float err = 1e6f; int32_t iters = 0;
   if( !src || !tgt ) return err;
   rsd_mat4_t t = *T1;
-  int rc = rs_hip_icp_align( src.get(), tgt.get(), t.data, T2.data, max_dist, max_angle, 100, 0, &err, &iters );
+  if( !verbose )
+  {
+    int rc = rs_hip_icp_align( src.get(), tgt.get(), t.data, T2.data, max_dist, max_angle, 100, 0, &err, &iters );
+    if( rc ) { complain( "icp_align" ); return 1e6f; }
+    *T1 = t;
+    return err;
+  }
+  // verbose: the reference's lines (icp.h:440,482-486,498).  Its two times per iteration are the search's and the estimator's host
+  // times; here an iteration is one piece of device work: its share of the call's time is printed as the first, 0 as the second.
+  const auto t0 = std::chrono::steady_clock::now();
+  float errs[100];
+  int rc = rs_hip_icp_align_traced( src.get(), tgt.get(), t.data, T2.data, max_dist, max_angle, 100, 0, &err, &iters, errs );
   if( rc ) { complain( "icp_align" ); return 1e6f; }
   *T1 = t;
-  if( verbose ) printf( " ICP: %d iterations on the GPU, final error %7.5f\n", iters, err );
+  const double ms = std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - t0 ).count();
+  printf( " ICP: Search indexes build time: %fms\n", 0.0 );          // (the clouds' indices are cached device objects)
+  float prev = 1e6f, md = max_dist;
+  for( int i = 0; i < iters; ++i )
+  {
+    printf( " ICP: Iter %3d {Error: %7.5f; Err.Delta: %7.5f; Params: (%5.4f, %5.4f); Times: (%5.3fms, %5.3fms)}\n",
+            i, errs[i], fabsf( prev - errs[i] ), md, max_angle, ms / ( iters > 0 ? iters : 1 ), 0.0 );
+    prev = errs[i];
+    const double nd = md * 0.95; md = (float)( nd > 0.05 ? nd : 0.05 );          // icp.h:493
+  }
+  printf( " ICP: Full time to estimate transform: %fms\n", ms );
   return err;
 }
 

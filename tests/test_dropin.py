@@ -152,6 +152,31 @@ def test_icp_align_by_reference_name(dropin, gscene, fname):
         assert np.linalg.norm(got.astype(np.float64) - g["T_out"]) < 1e-4 and abs(err - float(g["err"])) < 1e-5
 
 
+@pytest.mark.gpu
+def test_icp_align_verbose_prints_the_reference_lines(dropin, gscene, capfd):
+    """icp_align( ..., verbose = true ) through the shim: the reference's per-iteration lines (lib/rs/icp.h:482-486) — one per
+    iteration, the last one's error the returned one — and the same pose as the quiet call."""
+    import re
+    g = load_golden(golden_files("icp_")[0])
+    o = gscene["objects"][int(g["obj"])]
+    T2 = Mat4(); T2.data[:] = [float(x) for x in g["T2"]]
+    pts2, nor2 = gscene["points"], gscene["normals"]
+    out = []
+    for verbose in (False, True):
+        T = Mat4(); T.data[:] = [float(x) for x in g["T1"]]
+        err = dropin.icp_align(o["pos"].ctypes.data, o["nor"].ctypes.data, len(o["pos"]), pts2.ctypes.data,
+                               nor2.ctypes.data, len(pts2), C.byref(T), T2, float(g["max_dist"]), float(g["max_angle"]), verbose)
+        out.append((err, list(T.data[:])))
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    text = capfd.readouterr().out
+    assert out[0] == out[1]
+    lines = re.findall(r" ICP: Iter +(\d+) \{Error: ([0-9.]+); Err.Delta: ([0-9.]+); Params: \(([0-9.]+), ([0-9.]+)\); Times:", text)
+    assert len(lines) >= 6 and [int(l[0]) for l in lines] == list(range(len(lines)))
+    assert abs(float(lines[-1][1]) - out[1][0]) < 6e-6 and abs(float(lines[0][3]) - float(g["max_dist"])) < 1e-4
+    assert "Full time to estimate transform" in text
+
+
 def _search(dropin, hg, q, radius, k, sort=1):
     # (defined before its first use at run time; test_search_survives_a_device_failure above calls it too)
     q = np.ascontiguousarray(q, np.float32).reshape(-1, 3)

@@ -283,6 +283,25 @@ def test_more_headline_rooms_vs_reference(capi, bench_mod, seed):
         _close_workload(w)
 
 
+def test_traced_icp_is_the_same_call(capi, headline):
+    """rs_hip_icp_align_traced (behind the shim's icp_align( ..., verbose = true ), lib/rs/icp.h:482-486): the per-iteration errors of the
+    headline's ten fixed iterations against the reference's (fixture icp_errs), the result the untraced call's bit for bit; and an
+    object-sized source with the stop test on."""
+    w, g = headline
+    e0, T0, it0 = capi.icp_align(w["scan1"], w["scan0"], w["icp_T0"], I4, 0.10, np.deg2rad(60.0), max_iter=10, fixed_iters=True)
+    e1, T1, it1, errs = capi.icp_align_traced(w["scan1"], w["scan0"], w["icp_T0"], I4, 0.10, np.deg2rad(60.0), max_iter=10, fixed_iters=True)
+    assert it1 == it0 == 10 and e1 == e0 and (T1 == T0).all() and len(errs) == 10 and errs[-1] == e1
+    # (whole scans: the fp64-moment estimator evaluates the residual algebraically where the reference sums fp32 terms — 4e-5 apart in the
+    #  first two iterations, where the error is 5e-3 ... 2e-2 and no stop test looks at it, 1e-6 once it has settled)
+    d = np.abs(errs.astype(np.float64) - g["icp_errs"].astype(np.float64))
+    assert d.max() < 1e-4 and d[5:].max() < 1e-5, d
+    p = w["plc"][0]
+    a = capi.icp_align(p["cloud"], w["scan1"], p["pose"], I4, 0.075, np.deg2rad(50.0))
+    b = capi.icp_align_traced(p["cloud"], w["scan1"], p["pose"], I4, 0.075, np.deg2rad(50.0))
+    assert a[0] == b[0] and (a[1] == b[1]).all() and a[2] == b[2] == len(b[3]) and b[3][-1] == b[0]
+    assert (np.diff(b[3]) < 1e-3).all()      # (the error settles)
+
+
 def _check_room(capi, bench_mod, g, w, with_stop):
     s0, s1 = w["s0"], w["s1"]
     op, on = w["obj_score_np"]
