@@ -3,7 +3,12 @@ UNMODIFIED from /root/reference with shadow/icp first on the include path and li
 librescan_dropin.so (oracle/Makefile: _ref/pose_proposal_hip), against the same sources built
 the reference's way (_ref/pose_proposal), on a synthetic 2-timestep scene (BASELINE.json
 configs[0]).  The binaries are built in the container that has /root/reference and travel to
-the GPU box as prebuilt files; the test skips where they are absent."""
+the GPU box as prebuilt files; the test skips where they are absent.
+
+Round 5: apps/segment_transfer likewise — minus its graph-cut smoothing.  gco-v3.0 is not vendored and no stand-in for it is written;
+oracle/Makefile builds the reference's own text minus three lines (two gco includes and main.cpp's one call of rspf_smooth_labels),
+the reference's way and against the shim: the app's three call sites on the hot path (the refine of the optimised poses, the label
+loops, the database update's icp include) reached THROUGH THE APP.  Nothing here says anything about rspf_smooth_labels."""
 import os
 import struct
 import subprocess
@@ -92,3 +97,62 @@ def test_pose_proposal_app_links_against_the_shim(tmp_path, which):
     print("pose deltas: good proposals median %.2e max %.2e, all max %.2e over %d proposals"
           % (np.median(good), max(good), max(d for _, d in worst), len(worst)))
     print("nonzero:", [(round(sc, 4), "%.2e" % d) for sc, d in worst if d > 0])
+
+
+ST_BINS = [os.path.join(REF, b) for b in ("segment_transfer_nosmooth", "segment_transfer_nosmooth_hip2")]
+
+
+def read_prediction_ply(path):
+    """The segmented cloud segment_transfer writes (rs_pointcloud__save_ply: binary little-endian vertices); returns the header's
+    property names and the vertex block as bytes per property."""
+    b = open(path, "rb").read()
+    end = b.index(b"end_header\n") + len(b"end_header\n")
+    hdr = b[:end].decode()
+    n = int([l for l in hdr.splitlines() if l.startswith("element vertex")][0].split()[-1])
+    props = [l.split()[1:] for l in hdr.splitlines() if l.startswith("property") and "list" not in l]
+    np_t = {"float": "<f4", "uchar": "u1", "int": "<i4", "uint": "<u4", "double": "<f8", "short": "<i2", "ushort": "<u2", "char": "i1"}
+    dt = np.dtype([(name, np_t[t]) for t, name in props])
+    return np.frombuffer(b[end:end + n * dt.itemsize], dt)
+
+
+@pytest.mark.skipif(not all(os.path.exists(b) for b in ST_BINS), reason="oracle/_ref segment_transfer builds absent")
+def test_segment_transfer_app_links_against_the_shim(tmp_path):
+    """seg2rsdb -> pose_proposal (reference build) -> segment_transfer minus its smoothing, reference build against shim build
+    (shadow/icp + shadow/grid) on the same proposal file: the poses of the optimised and REFINED arrangement in the output .rsdb
+    (rsdb_refine_alignment_of_objects_to_scene -> icp_align, lib/rs/rs_database.h:216-232) and the per-vertex class / instance ids
+    of the segmented cloud (rspf_arrangement_to_labels + the wall / floor relabelling, before any smoothing) must be the reference build's."""
+    import shutil
+    from rescan_amd import synth
+    seq = tmp_path / "seq"
+    seq.mkdir()
+    for t in (0, 1):
+        synth.write_ply(str(seq / f"t{t}.ply"), synth.make_scene(seed=7, density=2000.0, timestep=t))
+    synth.write_class_table(str(tmp_path / "classes.rsdb"))
+    run = lambda *a: subprocess.run(list(a), cwd=str(tmp_path), capture_output=True, text=True, timeout=900)  # noqa: E731
+    run(BINS[0], "seq/t0.ply", "classes.rsdb", "seq/t0.rsdb", "-v")
+    assert os.path.exists(seq / "t0.rsdb")
+    pp = run(BINS[1], "seq/t0.rsdb", "seq/t1.ply", "seq/t1_pp.rsdb", "-v")
+    assert pp.returncode == 0, pp.stdout[-800:]
+    outs = {}
+    for tag, b in zip(("cpu", "hip"), ST_BINS):
+        r = run(b, "seq/t1_pp.rsdb", "-o", f"seq/t1_{tag}.rsdb", "-v")
+        assert r.returncode == 0, r.stdout[-1200:] + r.stderr[-800:]
+        if tag == "hip":
+            assert "[rescan_hip]" not in r.stderr, r.stderr[-800:]
+        import re
+        stages = dict(re.findall(r"(Refining optimized poses done|Segmentation finished|Optimization finished) in ([0-9.]+)s", r.stdout))
+        print(tag, {k: float(v) for k, v in stages.items()})
+        rsdb = open(seq / f"t1_{tag}.rsdb").read()
+        poses = [l for l in rsdb.splitlines() if l.strip().startswith("pose")]
+        pred = read_prediction_ply(str(seq / "predictions" / f"t1_{tag}.ply"))
+        outs[tag] = (poses, pred)
+        shutil.rmtree(seq / f"t1_{tag}", ignore_errors=True)
+    (pa, ca), (pb, cb) = outs["cpu"], outs["hip"]
+    assert len(pa) == len(pb) and len(pa) >= 6
+    assert pa == pb, [x for x in zip(pa, pb) if x[0] != x[1]][:3]                   # every pose line of the .rsdb, character for character
+    names = ca.dtype.names
+    ids = [n for n in names if "class" in n or "instance" in n]
+    assert len(ids) >= 2, names
+    for n in ids:
+        assert (ca[n] == cb[n]).all(), (n, int((ca[n] != cb[n]).sum()))
+    assert len(np.unique(ca[ids[0]])) >= 3                                          # (floor, walls, furniture: the labels are not trivial)
