@@ -5,10 +5,10 @@ the hot path on the CPU (the reference's build) and on the GPU (the same sources
 Follows scripts/run_segmentation_pipeline.py:62-72 and scripts/common.py:6-16 of the reference: per sequence of
 scene_list.txt (one name per line), the sorted stems of <sequence>/gt_segmentation/*.ply; the first goes through
 `seg2rsdb <ply> nyu40_classes.txt <seq>/<t0>.rsdb -v`, every later one through
-`pose_proposal <prev.rsdb> <ply> <seq>/<t>_pp.rsdb -v`.  NOT run: `segment_transfer` (its lib/rs/rs_pointcloud_filters.cpp
-and database_update.cpp include the un-vendored gco-v3.0 header, SURVEY.md §8c — the binary cannot be built here) and the
-model fusion that follows it (PoissonRecon, external).  Sequences therefore have two timesteps: a third would need
-segment_transfer's output of the second.
+`pose_proposal <prev.rsdb> <ply> <seq>/<t>_pp.rsdb -v`, then (round 5) `segment_transfer <t>_pp.rsdb -o <t>.rsdb -v` MINUS its
+graph-cut smoothing: gco-v3.0 is not vendored, so oracle/Makefile builds the app's own text less its two gco
+includes and its one call of rspf_smooth_labels — no stand-in — the reference's way and against the shim.  NOT run: the model
+fusion that follows (PoissonRecon, external).  Sequences have two timesteps.
 
 The sequences are synthetic (rescan_amd/synth.py, seeds 100, 101, ...).  Builds compared (oracle/Makefile, all from the
 unmodified sources under /root/reference, prebuilt in the build container):
@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--jobs", type=int, default=1, help="sequences of a GPU build in flight per GPU")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "scene_list.json"))
     ap.add_argument("--workdir", default=None)
+    ap.add_argument("--no-segment-transfer", action="store_true", help="skip the segment_transfer (minus smoothing) leg")
     args = ap.parse_args()
     from rescan_amd import synth
     builds = [b for b in args.builds.split(",") if os.path.exists(os.path.join(REF, BUILDS[b]))]
@@ -156,6 +157,40 @@ def main():
                 rows += pose_proposal(name, build, 0)
         t_total[build] = time.perf_counter() - t
 
+    # stage 3 (round 5): segment_transfer MINUS its graph-cut smoothing (oracle/Makefile: the reference's text less two gco includes and
+    # main.cpp's one call of rspf_smooth_labels; no stand-in for gco) — the reference build on the ref build's proposals, the shim build
+    # (shadow/icp + shadow/grid) on the batched build's (bit-identical) proposals: wall-clock, the app's own stage timers
+    # (apps/segment_transfer/main.cpp:362-400) and whether the output .rsdb's pose lines are the reference build's.
+    st_bins = {"ref": os.path.join(REF, "segment_transfer_nosmooth"), "shim": os.path.join(REF, "segment_transfer_nosmooth_hip2")}
+    st_rows, st_total = [], {}
+    if all(os.path.exists(b) for b in st_bins.values()) and not args.no_segment_transfer:
+        def seg_transfer(name, which, device):
+            stems = list_subsequences(os.path.join(work, name, "gt_segmentation"))
+            src_build = "ref" if which == "ref" or "batched" not in builds else "batched"
+            src = os.path.join(name, f"{stems[1]}_pp_{src_build}.rsdb")
+            if not os.path.exists(os.path.join(work, src)):
+                return []
+            env = dict(os.environ)
+            if which == "shim":
+                env["HIP_VISIBLE_DEVICES"] = str(device)
+            dst = os.path.join(name, f"{stems[1]}_st_{which}.rsdb")
+            r, dt = run([st_bins[which], src, "-o", dst, "-v"], work, env)
+            ok = r.returncode == 0 and "[rescan_hip]" not in r.stderr and os.path.exists(os.path.join(work, dst))
+            stages = {k: float(v) for k, v in re.findall(r"(Optimization finished|Refining optimized poses done|Segmentation finished|Database augmentation finished) in ([0-9.]+)s", r.stdout)}
+            poses = [l for l in open(os.path.join(work, dst)).read().splitlines() if l.strip().startswith("pose")] if ok else []
+            print(f"[scene_list] {name} segment_transfer (no smoothing) {which}: {dt:.1f} s {stages} ok={ok}", file=sys.stderr, flush=True)
+            return [dict(sequence=name, stage="segment_transfer_nosmooth", build=which, wall_s=dt, ok=ok, stages=stages, poses=poses)]
+        for which in ("ref", "shim"):
+            t = time.perf_counter()
+            for k, name in enumerate(names):
+                st_rows += seg_transfer(name, which, k % args.gpus)
+            st_total[which] = time.perf_counter() - t
+        ref_poses = {r["sequence"]: r["poses"] for r in st_rows if r["build"] == "ref"}
+        for r in st_rows:
+            if r["build"] != "ref":
+                r["pose_lines_identical"] = bool(r["ok"] and r["poses"] == ref_poses.get(r["sequence"]))
+            r["n_pose_lines"] = len(r.pop("poses"))
+
     # distance of every build's proposals from the ref build's
     ref_bins = {r["sequence"]: r["bin"] for r in rows if r.get("build") == "ref" and r["stage"] == "pose_proposal"}
     for r in rows:
@@ -187,13 +222,25 @@ def main():
     out = dict(config="BASELINE.json configs[0]/[4]: scene_list batch, seg2rsdb -> pose_proposal (segment_transfer not run: gco-v3.0 is not vendored)",
                sequences=names, points_per_scan=n_pts, density=args.density, gpus=args.gpus, jobs_per_gpu=args.jobs, host_cores=len(os.sched_getaffinity(0)),
                omp_threads=int(os.environ.get("RS_SCENE_LIST_OMP_THREADS", "8")),
-               builds_missing=missing, summary=summary, rows=rows)
+               builds_missing=missing, summary=summary, rows=rows,
+               segment_transfer_nosmooth=dict(note="apps/segment_transfer minus its gco lines (no smoothing: says nothing about rspf_smooth_labels); ref build on the ref proposals, shim build on the batched build's",
+                                              batch_wall_s=st_total, rows=st_rows,
+                                              sum_stage_s={w: {k: sum(r["stages"].get(k, 0.0) for r in st_rows if r["build"] == w) for k in ("Optimization finished", "Refining optimized poses done", "Segmentation finished")} for w in st_total},
+                                              pose_lines_identical=int(sum(bool(r.get("pose_lines_identical")) for r in st_rows)), sequences=len(names)))
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     json.dump(out, open(args.out, "w"), indent=1)
     print("| build | sequences ok | batch wall-clock s | sum of 'Computed poses in' s | proposals identical to ref | max pose delta (score > 0.9) |")
     print("|---|---|---|---|---|---|")
     for b, v in summary.items():
         print(f"| {b} | {v['ok']}/{v['sequences']} | {v['batch_wall_s']:.2f} | {v['sum_computed_poses_s']:.2f} | {v['identical']}/{v['proposals']} | {v['max_pose_delta_good']:.2e} |")
+    if st_rows:
+        st = out["segment_transfer_nosmooth"]
+        print()
+        print("| segment_transfer minus its smoothing | batch wall-clock s | sum 'Optimization' s | sum 'Refining optimized poses' s | sum 'Segmentation' s | .rsdb pose lines identical to the ref build's |")
+        print("|---|---|---|---|---|---|")
+        for w in st_total:
+            ss = st["sum_stage_s"][w]
+            print(f"| {w} | {st_total[w]:.2f} | {ss['Optimization finished']:.2f} | {ss['Refining optimized poses done']:.3f} | {ss['Segmentation finished']:.3f} | " + ("—" if w == "ref" else f"{st['pose_lines_identical']}/{len(names)}") + " |")
 
 
 if __name__ == "__main__":
