@@ -187,7 +187,9 @@ int rs_hip_alignment_scores( const rs_hip_cloud_t* object, const rs_hip_cloud_t*
 /* Batches of at least `n_queries` (poses x object points) on a scene with a cell grid take the scene-space route: every transformed
  * query is keyed by the scene-aligned block it falls in (and the way its normal faces), the keys are radix-sorted, and a wave
  * searches 64 queries of one block whatever poses they come from — a third of the candidate evaluations of the object-space
- * launch for the same bits.  Default 65536 (environment RS_HIP_SCORE_SCENE_MIN; RS_HIP_SCORE_SCENE=0: never);
+ * launch for the same bits.  Default 65536 (environment RS_HIP_SCORE_SCENE_MIN; RS_HIP_SCORE_SCENE=0: never), and only
+ * batches whose queries are dense in the scene take it (>= 128 per 0.1 m block of the lattice they span, RS_HIP_SCORE_SCENE_DENSITY: a
+ * proposal's verification, not a grid search over the whole room); a threshold of 0 takes it whatever the density.
  * n_queries < 0 only reads.  Returns the previous threshold. */
 int64_t rs_hip_score_scene_space_from( int64_t n_queries );
 

@@ -1536,12 +1536,25 @@ int rs_hip_alignment_scores( const rs_hip_cloud_t* object, const rs_hip_cloud_t*
     L.sq_bits = bits; L.sq_fine_bits = fine_bits; L.sq_inv_fine = 4.0f / parent; L.sq_nbin = nbin ? 1 : 0; L.sq_cull = cull;
     chunk_poses = (int)std::min<long long>( 65535, std::max<long long>( 1, ( 1ll << 30 ) / object->n ) );
     const size_t items = (size_t)std::min( chunk_poses, n_poses ) * object->n;
-    const size_t tmp_bytes = build_sort_temp_bytes( (int)items, bits );
-    if( ( rc = g_ws.sq_ka.ensure( items * 4 ) ) || ( rc = g_ws.sq_kb.ensure( items * 4 ) ) || ( rc = g_ws.sq_va.ensure( items * 4 ) ) ||
-        ( rc = g_ws.sq_vb.ensure( items * 4 ) ) || ( rc = g_ws.sq_pq.ensure( items * 8 ) ) || ( rc = g_ws.sq_tmp.ensure( tmp_bytes ) ) )
-      return rc;
-    L.sq_key_a = g_ws.sq_ka.as<uint32_t>(); L.sq_key_b = g_ws.sq_kb.as<uint32_t>(); L.sq_val_a = g_ws.sq_va.as<uint32_t>(); L.sq_val_b = g_ws.sq_vb.as<uint32_t>();
-    L.sq_pq = g_ws.sq_pq.as<double>(); L.sq_tmp = g_ws.sq_tmp.p; L.sq_tmp_bytes = g_ws.sq_tmp.cap;
+    // The route pays where MANY queries share a block — a proposal's verification, a refinement's neighbourhood: the bench's 256 poses put
+    // ~650 queries into each of ~4 000 blocks.  The grid search of a pyramid level scatters its poses over the whole room (a dozen queries
+    // per block): its waves would be no better filled with neighbours than object tiles are, and the sort — more key bits, millions of
+    // items — costs more than the searches (level 2: 3.4 ms against 2.8; level 3: 2.7 against 1.85, tools/score_grid_timing.py).  Such
+    // batches keep the object-space launch.  (A threshold of 0 queries, as the tests set it, takes the route whatever the density.)
+    static const double density_min = getenv( "RS_HIP_SCORE_SCENE_DENSITY" ) ? atof( getenv( "RS_HIP_SCORE_SCENE_DENSITY" ) ) : 128.0;
+    if( scene_min > 0 && (double)n_poses * object->n < density_min * (double)L.sq_n_parents )
+    {
+      L.sq_key_a = nullptr; chunk_poses = 65535;
+    }
+    else
+    {
+      const size_t tmp_bytes = build_sort_temp_bytes( (int)items, bits );
+      if( ( rc = g_ws.sq_ka.ensure( items * 4 ) ) || ( rc = g_ws.sq_kb.ensure( items * 4 ) ) || ( rc = g_ws.sq_va.ensure( items * 4 ) ) ||
+          ( rc = g_ws.sq_vb.ensure( items * 4 ) ) || ( rc = g_ws.sq_pq.ensure( items * 8 ) ) || ( rc = g_ws.sq_tmp.ensure( tmp_bytes ) ) )
+        return rc;
+      L.sq_key_a = g_ws.sq_ka.as<uint32_t>(); L.sq_key_b = g_ws.sq_kb.as<uint32_t>(); L.sq_val_a = g_ws.sq_va.as<uint32_t>(); L.sq_val_b = g_ws.sq_vb.as<uint32_t>();
+      L.sq_pq = g_ws.sq_pq.as<double>(); L.sq_tmp = g_ws.sq_tmp.p; L.sq_tmp_bytes = g_ws.sq_tmp.cap;
+    }
   }
   for( int p0 = 0; p0 < n_poses; p0 += chunk_poses )
   {
