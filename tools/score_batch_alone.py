@@ -1,6 +1,6 @@
 """Score batch alone (bench workload: 256 poses x 10 157 points against the 0.98 M-point scan): kernel time, candidates staged and
 parity with tests/golden/bench_seed11.npz for the library selected by RS_HIP_LIB and the switches in the environment
-(e.g. RS_HIP_SCORE_KCAP, RS_HIP_SCORE_ROWS; with the diagnostic build — tools/variant.sh dbg -DRS_DBG=1 — RS_HIP_SCORE_HIST=1 prints where the candidates are streamed: by shell and number of unsettled lanes, and by the rank pass).
+(e.g. RS_HIP_SCORE_SCENE=0, RS_HIP_SCORE_CULL=0, RS_HIP_SCORE_NBIN=0, RS_HIP_SCORE_PARENT=2; with the diagnostic build — tools/variant.sh dbg -DRS_DBG=1 — RS_HIP_SCORE_HIST=1 prints where the candidates are streamed: by shell and number of unsettled lanes, and by the rank pass).
 usage: python tools/score_batch_alone.py [repeats]"""
 import os, sys, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
