@@ -108,15 +108,17 @@ int rs_hip_icp_align_traced( const rs_hip_cloud_t* source, const rs_hip_cloud_t*
                              float* T1, const float* T2, float max_dist, float max_angle,
                              int32_t max_iter, int32_t fixed_iters, float* err, int32_t* n_iters, float* errs_per_iter );
 
-/* The estimator step (icp.h:136-148,210-298,393-402) has two implementations.  Sources of at most
- * `n_points` points use the reference's own accumulation order and precisions (one sequential fp32 chain
- * per accumulator): poses, errors and iteration counts are bit-identical to the reference's.  Larger
- * sources use a parallel fp64 reduction of the same sums: more accurate than the reference, equal to it
- * within its own fp32 rounding.  Default 65536 — every icp_align call site of the reference — (environment: RS_HIP_REF_ORDER_BELOW);
- * 0 = always the fp64 reduction; n_points < 0 only reads.  Returns the previous threshold.  Applies to
- * rs_hip_icp_align, rs_hip_icp_align_batch and rs_hip_icp_estimate_pt2pl. */
+/* The estimator step (icp.h:136-148,210-298,393-402), by source size (round 6; priced against the bar on every reference fixture:
+ * profiles/r06/estimator_policy.txt).  Sources of at most `n_points` points use the reference's own accumulation order and
+ * precisions (one sequential fp32 chain per accumulator): poses, errors and iteration counts are bit-identical to the
+ * reference's.  Default 4096 (environment RS_HIP_REF_ORDER_BELOW); 65536 covers every icp_align call site of the reference — at
+ * 520 instead of 110 us per iteration on a 50 k-point source.  Larger sources: see rs_hip_icp_replay_below (opt-in),
+ * rs_hip_icp_lane_chains_below (default up to 65536 points), beyond that the grid chains — all three centre the step on the
+ * reference's own fp32 centroid sums, bit for bit, and differ from it only where it rounds the 33 accumulators of the normal
+ * equations after every addition (<= 3e-6 in the pose on its fixtures, equal iteration counts).  n_points < 0 only reads.  Returns
+ * the previous threshold.  Applies to rs_hip_icp_align, _batch, _multi and rs_hip_icp_estimate_pt2pl. */
 int32_t rs_hip_icp_reference_order_below( int32_t n_points );
-/* Sources larger than that, up to `n_points` points (default 262144; environment RS_HIP_REPLAY_BELOW), get the SAME sums —
+/* Sources larger than that, up to `n_points` points (default 0 = off since round 6; environment RS_HIP_REPLAY_BELOW), get the SAME sums —
  * the reference's sequential fp32 / fp64 chains, bit for bit — computed in parallel: segments of 128 points are added
  * speculatively from a guessed start, for both parities of its last mantissa bit, and a walk over the segments with the exact
  * value accepts a segment when the accumulator provably stayed inside its binade.  0 = never; n_points < 0 only
@@ -124,6 +126,17 @@ int32_t rs_hip_icp_reference_order_below( int32_t n_points );
  * after the other (a diagnostic: binade crossings, chain starts). */
 int32_t rs_hip_icp_replay_below( int32_t n_points );
 int32_t rs_hip_icp_replay_redone( void );
+/* Round 6.  Sources above both thresholds and of at most `n_points` points take the LANE chains: the reference's 2.5 sigma cut, its
+ * seven weighted-centroid sums (lib/rs/icp.h:136-148) as the sequential fp32 chains they are, bit for bit — one wave per chain, 256
+ * addends per step on the integer grid of the running sum's binade, in fp32 one after the other wherever that does not hold — and the
+ * normal equations (:226-252) as a parallel fp64 reduction centred on those centroids.  Not the reference's bits: measured on every
+ * reference fixture of that size at most 3e-6 from its pose, equal iteration counts (profiles/r06/estimator_policy.txt).  Any
+ * number of differently sized problems run side by side (rs_hip_icp_align_multi).  Larger sources take the grid chains (the same
+ * sums spread over the chip).  n_points < 0 only reads; returns the previous threshold.  Environment: RS_HIP_LANE_CHAINS_BELOW.
+ * rs_hip_icp_lane_chains_sequential(): addends those walks added one by one since rs_hip_init (a diagnostic: chain starts, binade
+ * changes, ties, sums that hover around zero). */
+int32_t rs_hip_icp_lane_chains_below( int32_t n_points );
+int64_t rs_hip_icp_lane_chains_sequential( void );
 /* The sequential estimator (sources up to rs_hip_icp_reference_order_below) runs the reference's dist² statistics and its weighted
  * centroids in ONE pass, the 2.5 sigma cut of the weights (lib/rs/icp.h:396-401) taken at a guess of sigma; the pass stands when no
  * dist² lies between the guessed and the real cut, else the centroids are summed again.  Iterations that had to, over every calling

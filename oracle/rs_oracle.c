@@ -830,6 +830,149 @@ float orc_icp_align( const float* pts1, const float* nor1, int32_t n1,
 }
 
 /* ------------------------------------------------------------------------------------------
+ * WHAT-IF estimators (round 6, profiles/r06/estimator_policy*.txt): the loop of icp_align (:416-500) with the estimator's
+ * accumulators swapped, to PRICE what each precision choice costs in pose distance from the reference.  Not a restatement of
+ * anything in the reference; mode 0 IS orc_icp_align (asserted by oracle/price_estimators.py).
+ *   mode 0  the reference's arithmetic
+ *   mode 1  the reference's 2.5 sigma cut (fp32 sequential statistics) and its fp32 sequential centroid chains (:136-148); the 3x3
+ *           blocks and the right-hand side summed EXACTLY (fp64) over the reference's own fp32 addends
+ *   mode 2  as 1, the cut from statistics summed exactly (what the searches' integer accumulators give on the GPU)
+ *   mode 3  as 2, the centroids from fp64 sums as well (rounded to float): nothing of the reference's rounding drift is left
+ * ---------------------------------------------------------------------------------------- */
+static float estimate_variant( const float* p1, const float* p2, const float* n2, const float* w, int32_t n, float* T1, int mode )
+{
+  v3 c1, c2;
+  if( mode >= 3 )
+  {
+    double t = 0.0, a[6] = {0};
+    for( int32_t i = 0; i < n; ++i )
+    {
+      t += w[i];
+      a[0] += (double)( p1[3*i] * w[i] ); a[1] += (double)( p1[3*i+1] * w[i] ); a[2] += (double)( p1[3*i+2] * w[i] );
+      a[3] += (double)( p2[3*i] * w[i] ); a[4] += (double)( p2[3*i+1] * w[i] ); a[5] += (double)( p2[3*i+2] * w[i] );
+    }
+    float inv = 1.0f / (float)t;
+    c1 = v3_make( (float)a[0] * inv, (float)a[1] * inv, (float)a[2] * inv );
+    c2 = v3_make( (float)a[3] * inv, (float)a[4] * inv, (float)a[5] * inv );
+  }
+  else { c1 = weighted_centroid( p1, w, n ); c2 = weighted_centroid( p2, w, n ); }
+  double sum = 0.0, total_weight = 0.0;
+  double TL[9] = {0}, TR[9] = {0}, BR[9] = {0}, rhs[6] = {0};
+  for( int32_t i = 0; i < n; ++i )
+  {
+    v3 p = v3_sub( v3_load( p1, i ), c1 );
+    v3 q = v3_sub( v3_load( p2, i ), c2 );
+    v3 nn = v3_load( n2, i );
+    float wi = w[i];
+    v3 dd = v3_sub( p, q );
+    v3 c = v3_cross( p, nn );
+    float s = v3_dot( dd, nn );
+    const float cv[3] = { c.x, c.y, c.z }, nv[3] = { nn.x, nn.y, nn.z };
+    for( int col = 0; col < 3; ++col )
+      for( int row = 0; row < 3; ++row )
+      {
+        TL[3*col + row] += (double)( ( cv[row] * cv[col] ) * wi );
+        TR[3*col + row] += (double)( ( cv[row] * nv[col] ) * wi );
+        BR[3*col + row] += (double)( ( nv[row] * nv[col] ) * wi );
+      }
+    rhs[0] += (double)( wi * c.x * s );  rhs[1] += (double)( wi * c.y * s );  rhs[2] += (double)( wi * c.z * s );
+    rhs[3] += (double)( wi * nn.x * s ); rhs[4] += (double)( wi * nn.y * s ); rhs[5] += (double)( wi * nn.z * s );
+    sum += wi * s * s;
+    total_weight += wi;
+  }
+  float err = (float)sqrt( sum / total_weight );
+  double C[6][6], b[6], x[6] = {0}, rdiag[6] = {0};
+  for( int r = 0; r < 3; ++r )
+    for( int c = 0; c < 3; ++c )
+    {
+      /* the reference hands its fp32 accumulators to the fp64 solve (:267-273): round here too */
+      C[r][c]       = (float)TL[3*c + r];
+      C[r][3 + c]   = (float)TR[3*c + r];
+      C[3 + r][c]   = (float)TR[3*r + c];
+      C[3 + r][3+c] = (float)BR[3*c + r];
+    }
+  for( int i = 0; i < 6; ++i ) { b[i] = -(double)(float)rhs[i]; }
+  ldlt_factor6( C, rdiag );
+  ldlt_solve6( C, rdiag, b, x );
+  static const float ident[16] = { 1,0,0,0, 0,1,0,0, 0,0,1,0, 0,0,0,1 };
+  static const float ax_x[3] = { 1, 0, 0 }, ax_y[3] = { 0, 1, 0 }, ax_z[3] = { 0, 0, 1 };
+  float T[16];
+  float t0[3] = { c1.x, c1.y, c1.z };
+  float t1[3] = { (float)x[3], (float)x[4], (float)x[5] };
+  float t2[3] = { -c1.x, -c1.y, -c1.z };
+  orc_translate( ident, t0, T );
+  orc_translate( T, t1, T );
+  orc_rotate( T, (float)x[0], ax_x, T );
+  orc_rotate( T, (float)x[1], ax_y, T );
+  orc_rotate( T, (float)x[2], ax_z, T );
+  orc_translate( T, t2, T );
+  orc_mat4_mul( T, T1, T1 );
+  return err;
+}
+
+/* the correspondences of orc_icp_find_corrs with the cut of `mode` (the search itself is the same) */
+static int32_t find_corrs_variant( const float* pts1, const float* nor1, int32_t n1, const float* pts2, const float* nor2, int32_t n2,
+                                   const orc_grid_t* index2, const float* T1, const float* T2, float max_dist, float max_angle,
+                                   float* c_pts1, float* c_nor1, float* c_pts2, float* c_nor2, float* w, int mode )
+{
+  if( mode < 2 ) { return orc_icp_find_corrs( pts1, nor1, n1, pts2, nor2, n2, index2, T1, T2, max_dist, max_angle, c_pts1, c_nor1, c_pts2, c_nor2, w ); }
+  /* run the reference's search with the cut disabled (max_dist is not what the cut depends on): redo the weights from dist² */
+  int32_t ic = orc_icp_find_corrs( pts1, nor1, n1, pts2, nor2, n2, index2, T1, T2, max_dist, max_angle, c_pts1, c_nor1, c_pts2, c_nor2, w );
+  double s1 = 0.0, s2 = 0.0;
+  float* d2 = (float*)malloc( (size_t)( ic > 0 ? ic : 1 ) * sizeof(float) );
+  for( int32_t i = 0; i < ic; ++i )
+  {
+    v3 d = v3_sub( v3_load( c_pts2, i ), v3_load( c_pts1, i ) );
+    d2[i] = d.x * d.x + d.y * d.y + d.z * d.z;                      /* msh_hash_grid.h:852-855 (v = p - q) */
+    v3 nq = v3_load( c_nor1, i );
+    float dot = v3_dot( v3_load( c_nor2, i ), nq ); dot = dot > 0.0f ? dot : 0.0f;
+    w[i] = ( 1.0f - d2[i] / max_dist ) * dot;
+    s1 += d2[i]; s2 += (double)( d2[i] * d2[i] );
+  }
+  if( ic > 0 )
+  {
+    float mean = (float)( s1 / (double)ic ), sqm = (float)( s2 / (double)ic );
+    float sd = (float)sqrt( (double)( sqm - mean * mean ) );
+    if( sd > 0.000001 ) { for( int32_t i = 0; i < ic; ++i ) { if( d2[i] > 2.5f * sd ) { w[i] = 0.0f; } } }
+  }
+  free( d2 );
+  return ic;
+}
+
+/* :416-500, n_iters iterations at most, the stop test (:489) optional; returns the last error */
+float orc_icp_iterate_variant( const float* pts1, const float* nor1, int32_t n1, const float* pts2, const float* nor2, int32_t n2,
+                               float* T1, const float* T2, float max_dist, float max_angle, int32_t n_iters, int32_t stop_test,
+                               int32_t mode, int32_t* iters_done )
+{
+  orc_grid_t* index2 = orc_grid_create( pts2, n2, max_dist );
+  size_t cap = (size_t)( n1 > 0 ? n1 : 1 );
+  float* cp1 = (float*)malloc( cap * 12 ); float* cn1 = (float*)malloc( cap * 12 );
+  float* cp2 = (float*)malloc( cap * 12 ); float* cn2 = (float*)malloc( cap * 12 );
+  float* cw  = (float*)malloc( cap * 4 );
+  float prev_err = 1e6, err = 1e6;
+  int32_t iters = 0;
+  for( int i = 0; i < n_iters; ++i )
+  {
+    prev_err = err;
+    int32_t nc = find_corrs_variant( pts1, nor1, n1, pts2, nor2, n2, index2, T1, T2, max_dist, max_angle, cp1, cn1, cp2, cn2, cw, mode );
+    iters++;
+    if( nc == 0 ) { break; }
+    float total_weight = 0.0;
+    for( int32_t j = 0; j < nc; ++j ) { total_weight += cw[j]; }
+    if( total_weight <= 1e-7 ) { break; }
+    err = mode == 0 ? orc_icp_estimate_pt2pl( cp1, cp2, cn2, cw, nc, T1 ) : estimate_variant( cp1, cp2, cn2, cw, nc, T1, mode );
+    float delta = fabsf( prev_err - err );
+    if( stop_test && i > 5 && delta < 1e-5 ) { break; }
+    double nd = max_dist * 0.95;
+    max_dist = (float)( nd > 0.05 ? nd : 0.05 );
+  }
+  if( iters_done ) { *iters_done = iters; }
+  free( cp1 ); free( cn1 ); free( cp2 ); free( cn2 ); free( cw );
+  orc_grid_destroy( index2 );
+  return err;
+}
+
+/* ------------------------------------------------------------------------------------------
  * Alignment score  (apps/pose_proposal/pose_proposal.cpp:93-158, search_lvl = 1)
  * ---------------------------------------------------------------------------------------- */
 

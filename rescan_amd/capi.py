@@ -41,6 +41,8 @@ SIGNATURES = {
                                           C.POINTER(C.c_float), C.POINTER(C.c_int32), f32p]),
     "rs_hip_icp_reference_order_below": (C.c_int32, [C.c_int32]),
     "rs_hip_icp_replay_below": (C.c_int32, [C.c_int32]),
+    "rs_hip_icp_lane_chains_below": (C.c_int32, [C.c_int32]),
+    "rs_hip_icp_lane_chains_sequential": (C.c_int64, []),
     "rs_hip_icp_replay_redone": (C.c_int32, []),
     "rs_hip_icp_faith_redone": (C.c_int32, []),
     "rs_hip_icp_faith_guess": (C.c_int32, [C.c_int32]),
@@ -245,6 +247,17 @@ def icp_replay_below(n_points=-1):
     """Threshold up to which sources above the reference-order threshold get the reference's sums computed in parallel
     (same bits); -1 only reads.  Returns the previous threshold."""
     return int(load().rs_hip_icp_replay_below(int(n_points)))
+
+
+def icp_lane_chains_below(n_points=-1):
+    """Sources above the two thresholds before and of at most n_points points: the reference's centroid chains by one wave per chain
+    + fp64 moments (any number of problems side by side); -1 only reads.  Returns the previous threshold."""
+    return int(load().rs_hip_icp_lane_chains_below(int(n_points)))
+
+
+def icp_lane_chains_sequential():
+    """(diagnostics) addends the lane chains have added one by one in fp32 since init."""
+    return int(load().rs_hip_icp_lane_chains_sequential())
 
 
 def icp_exact_centroids(on=-1):

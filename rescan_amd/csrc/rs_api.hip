@@ -124,22 +124,28 @@ std::mutex g_faith_redone_mu;
 
 // ---- profiling ---------------------------------------------------------------------------
 bool g_prof = false;
-// Sources of at most this many points run the ICP estimator in the reference's own accumulation order and precisions
-// (bit-identical poses, errors and iteration counts); larger ones the fp64 moment reduction.  65 536 covers
-// every icp_align call site of the reference (level-2 objects, 2-10 k points; scene extracts of up to ~50 k).
+// The estimator of icp_estimate_rigid_xform_pt2pl (lib/rs/icp.h:210-298) by source size — round 6: the policy priced against the bar on every
+// reference fixture (profiles/r06/estimator_policy.txt):
+//   n <= g_ref_order_below (4 096)   the reference's own accumulation order and precisions (k_icp_faithful): its bits.  Below ~4 k points the
+//                                    sequential chains cost no more than the launches of anything parallel (60-80 us per iteration either way).
+//   n <= g_replay_below (0: off)     the same bits computed in parallel ("replay"): opt-in.
+//   n <= g_lane_below (65 536)       LANE chains: the reference's 2.5 sigma cut and its seven centroid sums bit for bit by one wave per chain +
+//                                    fp64 moments; any number of differently sized problems per launch (rs_hip_icp_align_multi) — every icp_align
+//                                    call site of the reference (level-2 objects 2-10 k points, scene extracts up to ~50 k: SURVEY §8 a6).
+//                                    <= 3e-6 from the reference's pose on its fixtures, equal iteration counts; 110 instead of 520 us per iteration at 50 k.
+//   larger                           GRID chains: the same seven sums spread over the chip (k_chain_*) + fp64 moments; <= 1.5e-6 on ten 1 M-point
+//                                    rooms, <= 9e-7 on the 24 scan-sized sweep runs.  A chain that hovers around zero gives the call up: again with
+//                                    the sums by pass 2 of the replay.
+// RS_HIP_EXACT_CENTROIDS=0: plain fp64 moments for everything above the first two thresholds (up to 2e-4 from the reference: NOT within the bar's
+// margin — kept for measurements).  rs_hip_icp_reference_order_below( 65536 ) brings the reference's bits back for every call site.
 // After a source's centroid chains gave a problem up, its next `g_chains_retry_after` calls go straight to the replay (rs_hip_icp_chains_retry_after).
 std::atomic<int> g_chains_retry_after{ getenv( "RS_HIP_CHAINS_RETRY_AFTER" ) ? atoi( getenv( "RS_HIP_CHAINS_RETRY_AFTER" ) ) : 15 };
-std::atomic<int> g_ref_order_below{ getenv( "RS_HIP_REF_ORDER_BELOW" ) ? atoi( getenv( "RS_HIP_REF_ORDER_BELOW" ) ) : 65536 };
-// Above that and up to this many source points the SAME sums are computed in parallel (rs_icp_estimate.hip: "replay" — the reference's
-// bits again, two to three times as fast as the sequential chains on scan-sized sources, still ten times the fp64 moments);
-// beyond — whole million-point scans, where a bit-exact iteration would cost 2.4 ms instead of 0.2 — the fp64 moments, whose
-// distance from the reference is measured (4.7e-5 on the headline workload, 23 of 24 sweep runs under 1e-4).
-// Sources above both thresholds: the fp64 moments, centred on the reference's own fp32 centroid chains (rs_rows.hip:
-// launch_icp_exact_centroids; rs_math.h: icp_solve).  RS_HIP_EXACT_CENTROIDS=0: plain fp64 moments.
+std::atomic<int> g_ref_order_below{ getenv( "RS_HIP_REF_ORDER_BELOW" ) ? atoi( getenv( "RS_HIP_REF_ORDER_BELOW" ) ) : 4096 };
 std::atomic<int> g_chains_gave_up{ 0 };
 std::atomic<int> g_faith_guess_permille{ getenv( "RS_HIP_FAITH_GUESS" ) ? atoi( getenv( "RS_HIP_FAITH_GUESS" ) ) : 1000 };
 std::atomic<int> g_exact_centroids{ getenv( "RS_HIP_EXACT_CENTROIDS" ) ? atoi( getenv( "RS_HIP_EXACT_CENTROIDS" ) ) : 1 };
-std::atomic<int> g_replay_below{ getenv( "RS_HIP_REPLAY_BELOW" ) ? atoi( getenv( "RS_HIP_REPLAY_BELOW" ) ) : 262144 };
+std::atomic<int> g_replay_below{ getenv( "RS_HIP_REPLAY_BELOW" ) ? atoi( getenv( "RS_HIP_REPLAY_BELOW" ) ) : 0 };
+std::atomic<int> g_lane_below{ getenv( "RS_HIP_LANE_CHAINS_BELOW" ) ? atoi( getenv( "RS_HIP_LANE_CHAINS_BELOW" ) ) : 65536 };
 std::mutex g_prof_mutex;
 struct ProfEntry { std::vector<std::pair<hipEvent_t, hipEvent_t>> spans; int64_t launches = 0; double ms = 0.0; };
 std::map<std::string, ProfEntry> g_profmap;
@@ -891,6 +897,53 @@ extern "C" {
 } // extern "C"
 
 namespace {
+// Buffers of the lane-chain estimator for n_prob problems with `rows` source points in all, the largest of max_n: the searches' records,
+// the seven totals per problem, the moments' partials (one per 1 024 source points of the largest problem), the update's ticket.
+std::atomic<long long> g_lane_seq_addends{ 0 }, g_lane_addends{ 0 };      // (diagnostics: rs_hip_icp_lane_chains_sequential)
+int icp_lane_prepare( IcpCtx& cx, ChainBufs& CB, int n_prob, size_t rows, int max_n )
+{
+  int rc;
+  const size_t np = (size_t)n_prob;
+  CB.n_seg = chain_segments( max_n ); CB.n_blk = chain_blocks( max_n ); CB.refresh = 0;
+  cx.L.n_mom_blocks = CB.n_blk * 4;
+  if( ( rc = g_ws.ch_rec.ensure( std::max<size_t>( 1, rows ) * REC_F4 * 16 ) ) || ( rc = g_ws.rp_totals.ensure( np * 3 * ICP_NMOM * 8 ) ) ||
+      ( rc = g_ws.rp_redone.ensure( np * 4 + 64 ) ) || ( rc = g_ws.ch_done.ensure( np * 8 ) ) ||
+      ( rc = g_ws.mom_part.ensure( np * (size_t)cx.L.n_mom_blocks * ICP_NMOM * 8 ) ) ||
+      ( rc = g_ws.ch_segsum.ensure( 8 * ( rows + 4 * np ) * 4 ) ) ) return rc;
+  CB.addends = g_ws.ch_segsum.as<float>();      // (the grid chains' buffer: the two estimators never run in one call)
+  if( getenv( "RS_HIP_LANE_DEBUG" ) )
+  {
+    if( ( rc = g_ws.ch_dbg.ensure( np * CH_ROWS * 16 ) ) ) return rc;
+    HIP_TRY( hipMemsetAsync( g_ws.ch_dbg.p, 0, np * CH_ROWS * 16, g_stream ), RS_HIP_E_RUNTIME );
+    CB.dbg = g_ws.ch_dbg.as<int>();
+  }
+  HIP_TRY( hipMemsetAsync( g_ws.rp_redone.p, 0, np * 4 + 64, g_stream ), RS_HIP_E_RUNTIME );
+  HIP_TRY( hipMemsetAsync( g_ws.ch_done.p, 0, np * 8, g_stream ), RS_HIP_E_RUNTIME );
+  CB.totals = g_ws.rp_totals.as<double>(); CB.resolved = g_ws.rp_redone.as<int>(); CB.done = g_ws.ch_done.as<int>(); CB.failed = nullptr;
+  cx.L.rec = (float4*)g_ws.ch_rec.p; cx.L.mom_part = g_ws.mom_part.as<double>();
+  g_lane_addends.fetch_add( (long long)rows * CH_ROWS );      // (per iteration; the diagnostic divides by what it counted the same way)
+  return RS_HIP_OK;
+}
+// (diagnostics) addends the walks of this call added one by one, over all its iterations
+void icp_lane_account( const ChainBufs& CB, int n_prob )
+{
+  std::vector<int> r( (size_t)n_prob );
+  if( hipMemcpy( r.data(), CB.resolved, r.size() * 4, hipMemcpyDeviceToHost ) != hipSuccess ) return;
+  long long t = 0; for( int v : r ) t += v;
+  g_lane_seq_addends.fetch_add( t );
+  if( CB.dbg )
+  {
+    std::vector<int> d( (size_t)n_prob * CH_ROWS * 4 );
+    if( hipMemcpy( d.data(), CB.dbg, d.size() * 4, hipMemcpyDeviceToHost ) != hipSuccess ) return;
+    for( int p = 0; p < std::min( n_prob, 4 ); ++p )
+      for( int row = 0; row < CH_ROWS; ++row )
+      {
+        const int* o = d.data() + ( (size_t)p * CH_ROWS + row ) * 4;
+        fprintf( stderr, "[rs_hip lane] problem %d chain %d: %d points, walk %.2f us, %d attempts (%d stretches), %d addends one by one\n", p, row, o[3], o[0] / 100.0, o[1], ( o[3] + 511 ) / 512, o[2] );
+      }
+  }
+}
+
 enum { ICP_CHAINS_GAVE_UP = -1000 };      // (internal) a centroid chain's walk gave the problem up: again, the seven sums by pass 2 of the replay
 
 int icp_align_batch_impl( const rs_hip_cloud_t* source, const rs_hip_cloud_t* target,
@@ -910,11 +963,12 @@ int icp_align_batch_impl( const rs_hip_cloud_t* source, const rs_hip_cloud_t* ta
   const bool exact_centroids = !ref_order && !replay && centroid_mode != 0;
   ReplayBufs RB{};
   ChainBufs CB{};
-  const bool chains = exact_centroids && centroid_mode == 1;      // (2: the same sums through pass 2 of the replay — the cross-check, and what a problem the chains give up is run with)
+  const bool lane = exact_centroids && source->n <= g_lane_below.load();      // (object-sized: one wave per chain, launch_icp_lane_chains)
+  const bool chains = exact_centroids && !lane && centroid_mode == 1;      // (2: the same sums through pass 2 of the replay — the cross-check, and what a problem the chains give up is run with)
   // (2 reads the searches' records like the chains do — RS_HIP_REPLAY2_GATHER=1: from k_icp_faith_gather's arrays, as up to round 3)
   static const bool replay2_gather = getenv( "RS_HIP_REPLAY2_GATHER" ) != nullptr;
-  const bool from_records = exact_centroids && !chains && !replay2_gather;
-  if( ref_order || replay || ( exact_centroids && !chains ) )
+  const bool from_records = exact_centroids && !chains && !lane && !replay2_gather;
+  if( ref_order || replay || ( exact_centroids && !chains && !lane ) )
   {
     if( !from_records )
     {
@@ -928,6 +982,11 @@ int icp_align_batch_impl( const rs_hip_cloud_t* source, const rs_hip_cloud_t* ta
     if( ( rc = g_ws.rp_totals.ensure( (size_t)n * 3 * ICP_NMOM * 8 ) ) || ( rc = g_ws.rp_redone.ensure( (size_t)n * 4 + 64 ) ) ) return rc;
     RB.totals = g_ws.rp_totals.as<double>(); RB.redone = g_ws.rp_redone.as<int>();
     HIP_TRY( hipMemsetAsync( g_ws.rp_redone.p, 0, (size_t)n * 4 + 64, g_stream ), RS_HIP_E_RUNTIME );
+  }
+  if( lane )
+  {
+    if( ( rc = icp_lane_prepare( cx, CB, n, (size_t)n * (size_t)source->n, source->n ) ) ) return rc;
+    RB.totals = CB.totals;
   }
   if( exact_centroids ) { cx.L.exact_centroids = 1; cx.L.centroid_totals = RB.totals; }
   if( chains )
@@ -1034,6 +1093,7 @@ int icp_align_batch_impl( const rs_hip_cloud_t* source, const rs_hip_cloud_t* ta
         CB.refresh = ( i == 0 || ( chain_refresh > 0 && ( i % chain_refresh ) == 0 ) ) ? 1 : 0;
         launch_icp_chain_centroids( cx.L, CB, g_stream );
       }
+      else if( lane ) launch_icp_lane_chains( cx.L, CB, g_stream );
       else if( from_records ) launch_icp_exact_centroids_from_records( cx.L, RB, CB, g_stream );
       else if( exact_centroids ) launch_icp_exact_centroids( cx.L, RB, g_stream );
       else if( cx.L.faith ) launch_icp_faithful( cx.L, g_stream ); else launch_icp_moments( cx.L, g_stream );
@@ -1048,6 +1108,7 @@ int icp_align_batch_impl( const rs_hip_cloud_t* source, const rs_hip_cloud_t* ta
     for( int p = 0; p < n; ++p ) n_active += hActive[p] ? 1 : 0;
     if( n_active == 0 ) break;
   }
+  if( lane ) icp_lane_account( CB, n );
   if( exact_centroids && getenv( "RS_HIP_DEBUG_TOTALS" ) )      // the seven centroid sums of the last iteration, as the estimator used them (bits)
   {
     std::vector<double> t( (size_t)n * 3 * ICP_NMOM );
@@ -1151,6 +1212,18 @@ int rs_hip_icp_align_batch( const rs_hip_cloud_t* source, const rs_hip_cloud_t* 
 // their problem's source view on the device (rs_icp.h: icp_bind), so the sequential chains of all problems run side by side;
 // every problem's result is what rs_hip_icp_align returns for it alone, bit for bit.  A batch with a larger source is run
 // problem by problem (their estimators are built for one source per launch).
+// which estimator rs_hip_icp_align would give a source of n points: 0 the reference's order, 1 the lane chains, 2 anything else
+static int icp_estimator_class( int n )
+{
+  if( n <= g_ref_order_below.load() ) return 0;
+  if( n <= g_replay_below.load() ) return 2;
+  if( g_exact_centroids.load() != 0 && n <= g_lane_below.load() ) return 1;
+  return 2;
+}
+
+static int icp_align_multi_group( const rs_hip_cloud_t* const* sources, const rs_hip_cloud_t* target, float* T1s, int32_t n, const float* T2,
+                                  float max_dist, float max_angle, int32_t max_iter, int32_t fixed_iters, float* errs, int32_t* iters, bool lane );
+
 int rs_hip_icp_align_multi( const rs_hip_cloud_t* const* sources, const rs_hip_cloud_t* target,
                             float* T1s, int32_t n, const float* T2, float max_dist, float max_angle,
                             int32_t max_iter, int32_t fixed_iters, float* errs, int32_t* iters )
@@ -1158,25 +1231,60 @@ int rs_hip_icp_align_multi( const rs_hip_cloud_t* const* sources, const rs_hip_c
   int rc = ensure_ready(); if( rc ) return rc;
   if( !sources || !T1s || !T2 || !errs || n < 0 ) { set_err( "icp_align_multi: bad arguments" ); return RS_HIP_E_ARG; }
   if( n == 0 ) return RS_HIP_OK;
-  bool one_batch = n > 1;
+  // Every problem gets the estimator its own rs_hip_icp_align would (icp_estimator_class), so that its result is that call's bit for
+  // bit: the problems within the reference-order range run as one batch (k_icp_faithful), those within the lane chains' range as
+  // another (launch_icp_lane_chains), the rest — estimators built for one source per launch — one by one.
+  std::vector<int> group[3];
   for( int p = 0; p < n; ++p )
   {
     if( !sources[p] ) { set_err( "icp_align_multi: null source" ); return RS_HIP_E_ARG; }
-    one_batch = one_batch && sources[p]->n > 0 && sources[p]->n <= g_ref_order_below.load();
+    group[sources[p]->n > 0 ? icp_estimator_class( sources[p]->n ) : 2].push_back( p );
   }
-  if( !one_batch )
+  for( int p : group[2] )
+    if( ( rc = rs_hip_icp_align_batch( sources[p], target, T1s + 16 * p, 1, T2, max_dist, max_angle, max_iter, fixed_iters, errs + p, iters ? iters + p : nullptr ) ) ) return rc;
+  for( int cls = 0; cls < 2; ++cls )
   {
-    for( int p = 0; p < n; ++p )
+    const std::vector<int>& g = group[cls];
+    if( g.empty() ) continue;
+    if( g.size() == 1 )
+    {
+      const int p = g[0];
       if( ( rc = rs_hip_icp_align_batch( sources[p], target, T1s + 16 * p, 1, T2, max_dist, max_angle, max_iter, fixed_iters, errs + p, iters ? iters + p : nullptr ) ) ) return rc;
-    return RS_HIP_OK;
+      continue;
+    }
+    if( (int)g.size() == n )      // (the common case: one class, in place)
+      return icp_align_multi_group( sources, target, T1s, n, T2, max_dist, max_angle, max_iter, fixed_iters, errs, iters, cls == 1 );
+    std::vector<const rs_hip_cloud_t*> src( g.size() ); std::vector<float> T( 16 * g.size() ), e( g.size() ); std::vector<int32_t> it( g.size() );
+    for( size_t k = 0; k < g.size(); ++k ) { src[k] = sources[g[k]]; std::memcpy( T.data() + 16 * k, T1s + 16 * g[k], 64 ); }
+    if( ( rc = icp_align_multi_group( src.data(), target, T.data(), (int)g.size(), T2, max_dist, max_angle, max_iter, fixed_iters, e.data(), it.data(), cls == 1 ) ) ) return rc;
+    for( size_t k = 0; k < g.size(); ++k ) { std::memcpy( T1s + 16 * g[k], T.data() + 16 * k, 64 ); errs[g[k]] = e[k]; if( iters ) iters[g[k]] = it[k]; }
   }
+  return RS_HIP_OK;
+}
+
+// n >= 2 problems of ONE estimator class in the same launches: grid.y = problem, the kernels bind their problem's view on the device.
+static int icp_align_multi_group( const rs_hip_cloud_t* const* sources, const rs_hip_cloud_t* target, float* T1s, int32_t n, const float* T2,
+                                  float max_dist, float max_angle, int32_t max_iter, int32_t fixed_iters, float* errs, int32_t* iters, bool lane )
+{
+  int rc;
   IcpCtx cx;
   if( ( rc = icp_prepare( cx, nullptr, target, n, T2, sources ) ) ) return rc;
   const float tmin = icp_gate_threshold( max_angle );
   if( ( rc = icp_enable_certificates( cx ) ) ) return rc;
   if( ( rc = icp_upload_state( cx, T1s, (size_t)n ) ) ) return rc;
-  if( ( rc = g_ws.faith.ensure( (size_t)FAITH_REC * cx.total_pts * 4 ) ) ) return rc;
-  cx.L.faith = g_ws.faith.as<float>();
+  ChainBufs CB{};
+  if( lane )
+  {
+    if( ( rc = icp_lane_prepare( cx, CB, n, cx.total_pts, cx.L.max_n ) ) ) return rc;
+    cx.L.exact_centroids = 1; cx.L.centroid_totals = CB.totals;
+    HIP_TRY( hipMemsetAsync( g_ws.stat_acc.p, 0, (size_t)n * STAT_SHARDS * 4 * 8, g_stream ), RS_HIP_E_RUNTIME );
+    cx.L.stat_acc = g_ws.stat_acc.as<unsigned long long>();
+  }
+  else
+  {
+    if( ( rc = g_ws.faith.ensure( (size_t)FAITH_REC * cx.total_pts * 4 ) ) ) return rc;
+    cx.L.faith = g_ws.faith.as<float>();
+  }
   const bool reorder = !getenv( "RS_HIP_NO_LPT" );
   if( reorder )
   {
@@ -1211,7 +1319,8 @@ int rs_hip_icp_align_multi( const rs_hip_cloud_t* const* sources, const rs_hip_c
         cx.L.heavy_out = ( i & 1 ) ? g_ws.order_b.as<int>() : g_ws.order_a.as<int>();
       }
       prof.mark( "nn_icp" ); launch_icp_corr( cx.L, g_stream );
-      prof.mark( "icp_moments" ); launch_icp_faithful( cx.L, g_stream );
+      prof.mark( "icp_moments" );
+      if( lane ) launch_icp_lane_chains( cx.L, CB, g_stream ); else launch_icp_faithful( cx.L, g_stream );
       double nd = max_dist * 0.95;                                      // icp.h:493
       max_dist = (float)( nd > 0.05 ? nd : 0.05 );
     }
@@ -1223,10 +1332,21 @@ int rs_hip_icp_align_multi( const rs_hip_cloud_t* const* sources, const rs_hip_c
     for( int p = 0; p < n; ++p ) n_active += hActive[p] ? 1 : 0;
     if( n_active == 0 ) break;
   }
+  if( lane ) icp_lane_account( CB, n );
   const int* hIters = (const int*)( hS + np * 33 );
   for( int p = 0; p < n; ++p ) { std::memcpy( T1s + 16 * p, hS + 16 * p, 64 ); errs[p] = hS[np * 34 + p]; if( iters ) iters[p] = hIters[p]; }
   return RS_HIP_OK;
 }
+
+int32_t rs_hip_icp_lane_chains_below( int32_t n_points )
+{
+  const int prev = g_lane_below.load();
+  if( n_points >= 0 ) g_lane_below.store( n_points );
+  return prev;
+}
+
+// (diagnostics) of all addends the lane chains have summed since rs_hip_init, how many were added one by one in fp32 (per mille)
+int64_t rs_hip_icp_lane_chains_sequential( void ) { return g_lane_seq_addends.load(); }
 
 int32_t rs_hip_icp_chains_gave_up( void ) { return g_chains_gave_up.load(); }
 
@@ -1406,13 +1526,16 @@ int rs_hip_icp_estimate_pt2pl( const float* pts1, const float* pts2, const float
   L.radius = 1.0f; L.m_slot = g_ws.slot.as<int>(); L.m_d2 = g_ws.d2.as<float>(); L.m_dot = g_ws.dot.as<float>();
   L.mom_part = g_ws.mom_part.as<double>(); L.res = g_ws.res.as<double>();
   L.n_mom_blocks = std::max( 1, std::min( 256, ( n + 255 ) / 256 ) ); L.w_explicit = g_ws.wexp.as<float>();
-  if( n <= std::max( g_ref_order_below.load(), g_replay_below.load() ) )
+  // (a single estimator step on the caller's own correspondences: wherever the ICP loop would centre on the reference's chains — the lane
+  //  chains' range — this entry point simply runs the reference's order: one call, its cost does not matter, its bits do)
+  const int seq_below = std::max( g_ref_order_below.load(), g_exact_centroids.load() != 0 ? g_lane_below.load() : 0 );
+  if( n <= std::max( seq_below, g_replay_below.load() ) )
   {
     // the reference's own accumulation order (k_icp_faithful, or its parallel form): solve and pose update on the device too
     if( ( rc = g_ws.faith.ensure( nn * FAITH_REC * 4 ) ) ) return rc;
     L.faith = g_ws.faith.as<float>(); L.by_orig = nullptr; L.err = g_ws.state.as<float>() + 34;
     // (the points are presented untransformed, so the state's pose stays the identity uploaded above and T1 is multiplied in afterwards)
-    if( n <= g_ref_order_below.load() ) { ProfScope ps( "icp_moments" ); launch_icp_faithful( L, g_stream ); }
+    if( n <= seq_below || n > g_replay_below.load() ) { ProfScope ps( "icp_moments" ); launch_icp_faithful( L, g_stream ); }
     else
     {
       ReplayBufs RB{};

@@ -163,8 +163,11 @@ struct ChainBufs
   int*      chk;        // (RS_HIP_CHAIN_DEBUG) per chain 4 + 3 x 4096 words: the walk's steps {end segment, value bits, kind}, checked against the plain sum by the walk itself
   int       dbg_reps;   // (RS_HIP_CHAIN_DEBUG=n: k_chain_walk walks n times, the stamps are the last walk's — warm caches)
   int*      dbg;        // RS_HIP_CHAIN_DEBUG: per chain 1 + 64 x 8 words — count, then {segment, value bits, guess, lo / hi / D of the class tried} of the first 64 such segments
+  float*    addends;    // (lane chains only) the seven addend rows of every problem: 8 x ( total source points + 4 n_prob ) floats
 };
 void   launch_icp_chain_centroids( const IcpLaunch& L, const ChainBufs& B, hipStream_t st );
+// the same seven sums for object-sized sources, one wave per chain, any number of (differently sized) problems: B.totals, B.done, B.resolved, B.addends only
+void   launch_icp_lane_chains( const IcpLaunch& L, const ChainBufs& B, hipStream_t st );
 inline int chain_segments( int n ) { return ( n + CH_SEG - 1 ) / CH_SEG; }
 inline int chain_blocks( int n ) { return ( chain_segments( n ) + CH_BLK - 1 ) / CH_BLK; }
 void launch_icp_corr( const IcpLaunch& L, hipStream_t st );     // phase A, phase B (the tiles add their dist² statistics to L.stat_acc)

@@ -1245,13 +1245,14 @@ __device__ __forceinline__ float chain_stats( const IcpLaunch& L, int prob, unsi
 // in L.res for the kernels that follow.
 #define CH_QUARTERS 4
 struct ChainMomLds { double red[WAVES_PER_BLOCK][ICP_NMOM]; double bsum[WAVES_PER_BLOCK][CH_ROWS]; unsigned long long stat[WAVES_PER_BLOCK][3]; };
-__device__ __forceinline__ void chain_moments_block( const IcpLaunch& L, const ChainBufs& B, int prob, int qb, ChainMomLds& S )
+// (R: the problem's records — one source for the whole batch: L.rec + prob * n; a multi-source batch: L.rec + pt_off, see k_lane_chains_and_moments)
+// (xrows: where to leave the seven addends of every point of the quarter block, row r at xrows + r * ( ( n + 3 ) & ~3 ) — the lane chains' input; null: not wanted)
+__device__ __forceinline__ void chain_moments_block( const IcpLaunch& L, const ChainBufs& B, int prob, int qb, ChainMomLds& S, const float4* R, float* xrows = nullptr )
 {
   // quarter block qb: segments [16 qb, 16 qb + 16)
   const float sd = chain_stats( L, prob, S.stat, ( qb == 0 && threadIdx.x == 0 ) ? L.res + (size_t)prob * ICP_NRES + ICP_NMOM : nullptr );
   ChainPar P; P.use_sd = sd > 0.000001; P.cut = 2.5f * sd; P.max_dist = L.radius;
   const int lane = threadIdx.x & ( WAVE - 1 ), wib = threadIdx.x / WAVE;
-  const float4* R = L.rec + (size_t)prob * L.src.n * REC_F4;
 
   double acc[ICP_NMOM], bs[CH_ROWS];
 #pragma unroll
@@ -1268,6 +1269,12 @@ __device__ __forceinline__ void chain_moments_block( const IcpLaunch& L, const C
     if( i < L.src.n ) { A = R[(size_t)i * REC_F4]; Q = R[(size_t)i * REC_F4 + 1]; N4 = R[(size_t)i * REC_F4 + 2]; }
     float x[CH_ROWS], w;
     chain_addends( A, Q, P, x, w );
+    if( xrows )
+    {
+      const int ns = ( L.src.n + 3 ) & ~3;               // (the row's padding beyond n: zeros)
+#pragma unroll
+      for( int r = 0; r < CH_ROWS; ++r ) if( i < ns ) xrows[(size_t)r * ns + i] = x[r];
+    }
     if( B.refresh )
     {
 #pragma unroll
@@ -1319,7 +1326,7 @@ __global__ __launch_bounds__( BLOCK ) void k_chain_moments( IcpLaunch L, ChainBu
   __shared__ ChainMomLds S;
   const int prob = blockIdx.y;
   if( L.active[prob] == 0 ) return;
-  chain_moments_block( L, B, prob, blockIdx.x, S );
+  chain_moments_block( L, B, prob, blockIdx.x, S, L.rec + (size_t)prob * L.src.n * REC_F4 );
 }
 
 #define CH_M_LO ( 1 << 23 )
@@ -2243,8 +2250,252 @@ __global__ __launch_bounds__( BLOCK ) void k_chain_walk_and_moments( IcpLaunch L
     return;
   }
   const int qb = (int)blockIdx.x - CH_ROWS;
-  if( qb < B.n_blk * CH_QUARTERS ) chain_moments_block( L, B, prob, qb, S.m );
+  if( qb < B.n_blk * CH_QUARTERS ) chain_moments_block( L, B, prob, qb, S.m, L.rec + (size_t)prob * L.src.n * REC_F4 );
   else chain_guess_block( L, B, prob, qb - B.n_blk * CH_QUARTERS, WAVES_PER_BLOCK );
+}
+
+// ------------------------------------------------------------------------------------------
+// Lane chains (round 6): the same seven sums for OBJECT-sized sources — every icp_align call site of the reference
+// (apps/pose_proposal/main.cpp:195-197, lib/rs/rs_database.h:227-229, apps/segment_transfer/database_update.cpp:65-67) —
+// one wave per chain, any number of problems side by side (grid.y = problem, each bound to its own source: icp_bind).
+//
+// The grid chains above pay five launches and a forecast machinery to spread ONE chain over the chip; a source of a few
+// ten thousand points does not need that.  A wave takes 256 addends at a time, four consecutive ones per lane, and applies the
+// same fact — inside a binade the sum is an integer sum — directly: every addend scaled by 1 / ulp( s ) and rounded to
+// nearest-even is what it adds to the mantissa; the four of a lane are prefixed in registers, the lanes by one DPP scan; if every
+// partial mantissa stays inside the binade (one grid step clear of its ends, as the records above) and no addend sits exactly
+// half way between two grid points, the 256 additions ARE that integer addition.  Otherwise the stretch is cut at the first
+// lane that does not fit: the lanes before it are taken by the integers, that lane's four addends are added in fp32 one
+// after the other — the reference's own operation, so a change of binade, a tie, a sum that is zero, denormal or not finite
+// need no case of their own — and the rest is tried again from the new value.  A sum that hovers (coordinates of both
+// signs) makes little headway per attempt; then the fp32 stretch doubles, up to 16 lanes: the worst case is the plain
+// sequential sum plus an attempt per 64 addends.  Nothing is given up and nothing is forecast: the result is the
+// sequential sum for any input (tests/test_gpu_parity.py: test_lane_chains_are_the_sequential_sums).
+//   k_lane_chains_and_moments   workgroups 0-1: the seven walks (a wave each); the rest: the fp64 moments of a quarter block of
+//                               1 024 source points each (chain_moments_block, shared with the grid chains)
+//   k_icp_update_wide           the rest of the iteration, centred on the chains' centroids (L.exact_centroids)
+// What it is NOT: the reference's bits.  The 27 + 6 accumulators of the normal equations are summed in fp64 where the reference
+// rounds after every addition — measured on every reference fixture of this size (profiles/r06/estimator_policy.txt): at most
+// 3e-6 from the reference's pose, iteration counts equal; rs_hip_icp_reference_order_below() brings the bits back.
+// ------------------------------------------------------------------------------------------
+#define LC_PER_LANE 16
+#define LC_SUPER ( LC_PER_LANE * WAVE )
+#define LC_DEPTH 4
+
+// Where problem `prob`'s seven addend rows live (floats): eight rows' worth per problem so that every row starts on a 16-byte
+// boundary whatever the sizes of the problems before it; a row holds ( n + 3 ) & ~3 floats.
+__device__ __forceinline__ size_t lane_rows_base( const IcpLaunch& L, int prob ) { return 8 * ( (size_t)L.pt_off + 4 * (size_t)prob ); }
+__device__ __forceinline__ int lane_row_stride( int n ) { return ( n + 3 ) & ~3; }
+
+// (unconditional loads — a quad beyond the row reads the row's last quad instead and is zeroed afterwards — so that the loads of the
+//  stretches ahead stay countable: a load under a branch made the compiler wait for ALL loads in flight at every step)
+__device__ __forceinline__ void lane_chain_load( const float* row, int ns, int base, int lane, float4 ( &X )[LC_PER_LANE / 4] )
+{
+#pragma unroll
+  for( int q = 0; q < LC_PER_LANE / 4; ++q )
+  {
+    const int i = base + lane * LC_PER_LANE + 4 * q;
+    X[q] = *(const float4*)( row + min( i, ns - 4 ) );     // (ns is a multiple of 4, >= 4: lane_row_stride)
+  }
+}
+__device__ __forceinline__ float wave_scan_add_f32( float v ) { RS_DPP_PREFIX( "v_add_f32_dpp", v ); return v; }      // inclusive; lanes without a source keep their value
+
+// The sequential fp32 sum of the n addends of `row` (the reference's order), by one wave.  dbg (diagnostics, may be null): addends
+// added one by one, attempts made.
+//
+// The integers are kept as FLOATS: with S = |s| in [2^e, 2^(e+1)), u = ulp( S ) and C = 1.5 * 2^e (same binade, even mantissa),
+// RN( C + x ) - C  is x rounded to the grid of u, ties to the even grid point, for every |x| < 2^(e-1) — the addition rounds for us, no
+// scaling, no conversion — and sums of such multiples of u below 2^(e+1) are exact in fp32.  So a lane's sixteen addends are
+// rounded (two additions each), prefixed in registers, the lanes' totals by one DPP scan of float additions, and the partial sums
+// S + prefix compared with the binade's ends as floats.  Every quantity that decides something for a lane is a sum over a
+// contiguous range of addends BEFORE the first lane that does not fit, hence a multiple of u below 2^(e+1), hence exact; what lies
+// beyond that lane may have rounded and is not looked at.
+__device__ __forceinline__ float lane_chain_walk( const float* row, int n, int lane, int* dbg )
+{
+  float s = 0.0f;                                      // wave-uniform throughout
+  int n_seq = 0, n_try = 0;
+  const int ns = lane_row_stride( n );
+  // Two groups of LC_DEPTH stretches in registers: the one being walked and the next, all of whose loads are issued before the walk of
+  // the current group begins — the rows were written a launch ago by other CUs (another XCD's L2: they come from memory, 1-2 us
+  // away), a group is walked in about that time.
+  float4 X[LC_DEPTH][LC_PER_LANE / 4], Y[LC_DEPTH][LC_PER_LANE / 4];
+#pragma unroll
+  for( int k = 0; k < LC_DEPTH; ++k ) lane_chain_load( row, ns, k * LC_SUPER, lane, X[k] );
+  for( int base0 = 0; base0 < n; base0 += LC_DEPTH * LC_SUPER )
+  {
+  const bool more = base0 + LC_DEPTH * LC_SUPER < n;
+  if( more )
+  {
+#pragma unroll
+    for( int k = 0; k < LC_DEPTH; ++k ) lane_chain_load( row, ns, base0 + ( LC_DEPTH + k ) * LC_SUPER, lane, Y[k] );
+  }
+#pragma unroll
+  for( int k = 0; k < LC_DEPTH; ++k )
+  {
+    const int base = base0 + k * LC_SUPER;
+    if( base >= n ) break;
+    float x[LC_PER_LANE];
+    {
+      const int i0 = base + lane * LC_PER_LANE;
+#pragma unroll
+      for( int q = 0; q < LC_PER_LANE / 4; ++q )
+      {
+        const bool in = i0 + 4 * q < ns;
+        x[4 * q] = in ? X[k][q].x : 0.0f; x[4 * q + 1] = in ? X[k][q].y : 0.0f; x[4 * q + 2] = in ? X[k][q].z : 0.0f; x[4 * q + 3] = in ? X[k][q].w : 0.0f;
+      }
+    }
+    // the lane's addends' magnitudes, summed: decides whether the lane can go by the grid at all (below), and is inf or NaN when an
+    // addend is not finite (or the sum overflows: beyond any binade's reach anyway)
+    float mag = 0.0f;
+#pragma unroll
+    for( int j = 0; j < LC_PER_LANE; ++j ) mag = mag + fabsf( x[j] );
+    int start = 0, seq = 1;
+    while( start < WAVE )
+    {
+      const uint32_t sb = (uint32_t)uni( (int)__float_as_uint( s ) );      // (every lane holds the same value: branch on the scalar unit)
+      const int E = (int)( ( sb >> 23 ) & 255u );
+      int b = start;                                   // first lane the grid does not carry
+      if( E >= 64 && E <= 253 )                        // (below 2^-63 — where an addend could be a denormal worth half a grid step — one by one)
+      {
+        ++n_try;
+        const float sgn = ( sb >> 31 ) ? -1.0f : 1.0f;                                 // |s| grows by -x when s < 0
+        const float S = __uint_as_float( sb & 0x7fffffffu );
+        const float C = __uint_as_float( ( (uint32_t)E << 23 ) | 0x400000u );          // 1.5 * 2^e
+        const float quarter = __uint_as_float( (uint32_t)( E - 1 ) << 23 );            // 2^(e-1): the rounding trick's range
+        const float u = __uint_as_float( (uint32_t)( E - 23 ) << 23 ), uh = __uint_as_float( (uint32_t)( E - 24 ) << 23 );      // ulp( S ), half of it
+        const float lo_end = __uint_as_float( (uint32_t)E << 23 ) + u, hi_end = __uint_as_float( (uint32_t)( E + 1 ) << 23 ) - u;   // the binade, a grid step clear of its ends
+        float p[LC_PER_LANE], run = 0.0f, half = 0.0f;      // half: the largest | x - rounded x | of the lane; u / 2 = an addend exactly half way between two grid points
+#pragma unroll
+        for( int j = 0; j < LC_PER_LANE; ++j )
+        {
+          const float r = __builtin_fmaf( x[j], sgn, C ) - C;                          // x (signed for |s|) on the grid, ties to even
+          half = fmaxf( half, fabsf( __builtin_fmaf( x[j], sgn, -r ) ) );              // (exact: x and r differ by at most u / 2)
+          run = run + r; p[j] = run;
+        }
+        const float incl = wave_scan_add_f32( run ), excl = incl - run;
+        float lo = p[0], hi = p[0];
+#pragma unroll
+        for( int j = 1; j < LC_PER_LANE; ++j ) { lo = fminf( lo, p[j] ); hi = fmaxf( hi, p[j] ); }
+        // (written so that a NaN anywhere — a lane after one that does not fit — reads as "does not fit")
+        const bool fits = mag < quarter && half < uh && S + ( excl + lo ) >= lo_end && S + ( excl + hi ) <= hi_end;
+        const unsigned long long badm = __builtin_amdgcn_ballot_w64( !fits && lane >= start );
+        b = badm ? (int)__builtin_ctzll( badm ) : WAVE;
+        if( b > start )
+        {
+          const float adv = rl( b < WAVE ? excl : incl, b < WAVE ? b : WAVE - 1 );
+          s = sgn * ( S + adv );
+        }
+      }
+      else if( ( sb << 1 ) == 0u )
+      {
+        // a sum of zero stays zero through addends that are all zero (the unmatched points a source may well begin with)
+        const unsigned long long nzm = __builtin_amdgcn_ballot_w64( !( mag == 0.0f ) && lane >= start );
+        b = nzm ? (int)__builtin_ctzll( nzm ) : WAVE;
+      }
+      if( b >= WAVE ) break;
+      // lanes [b, e): their addends one after the other in fp32, as the reference adds them
+      seq = ( b - start >= 2 ) ? 1 : min( 2 * seq, 4 );
+      const int e = min( b + seq, WAVE );
+      for( int l = b; l < e; ++l )
+      {
+#pragma unroll
+        for( int j = 0; j < LC_PER_LANE; ++j ) s = s + rl( x[j], l );
+      }
+      n_seq += ( e - b ) * LC_PER_LANE;
+      start = e;
+      // the lanes done add nothing from here on (their prefix in the next attempt's scan is zero)
+#pragma unroll
+      for( int j = 0; j < LC_PER_LANE; ++j ) x[j] = lane < start ? 0.0f : x[j];
+      mag = lane < start ? 0.0f : mag;
+    }
+  }
+  if( more )
+  {
+#pragma unroll
+    for( int k = 0; k < LC_DEPTH; ++k )
+#pragma unroll
+      for( int q = 0; q < LC_PER_LANE / 4; ++q ) X[k][q] = Y[k][q];
+  }
+  }
+  if( dbg ) { dbg[0] = n_seq; dbg[1] = n_try; }
+  return s;
+}
+
+// Launch 1, every CU: the fp64 moments of a quarter block (1 024 source points) per workgroup, and the seven addends of its points
+// into the rows the walks read (B.addends).
+__global__ __launch_bounds__( BLOCK ) void k_lane_moments_and_addends( IcpLaunch L, ChainBufs B )
+{
+  RS_CHAIN_SETPRIO();
+  __shared__ ChainMomLds S;
+  const int prob = blockIdx.y;
+  if( L.active[prob] == 0 ) return;
+  icp_bind( L, prob );
+  ChainBufs Bq = B; Bq.n_seg = ( L.src.n + CH_SEG - 1 ) / CH_SEG; Bq.refresh = 0;
+  chain_moments_block( L, Bq, prob, (int)blockIdx.x, S, L.rec + (size_t)L.pt_off * REC_F4, B.addends + lane_rows_base( L, prob ) );
+}
+
+// Launch 2: workgroups 0 .. ICP_NMOM - 1 sum a moment's partials each (k_icp_update_wide's work), the next two walk the seven chains
+// (a wave each, from the addend rows); whichever finishes last does the rest of the iteration (icp.h:253-295,455-493), centred on the
+// chains' centroids.
+constexpr int LC_WALK_BLOCKS = ( CH_ROWS + WAVES_PER_BLOCK - 1 ) / WAVES_PER_BLOCK;
+__global__ __launch_bounds__( BLOCK ) void k_lane_walk_and_update( IcpLaunch L, ChainBufs B )
+{
+  RS_CHAIN_SETPRIO();
+  __shared__ double s_part[WAVES_PER_BLOCK];
+  __shared__ int s_last;
+  const int prob = blockIdx.y, k = blockIdx.x;
+  if( L.active[prob] == 0 ) return;
+  icp_bind( L, prob );
+  const int lane = threadIdx.x & ( WAVE - 1 ), wib = uni( (int)threadIdx.x / WAVE );
+  if( k < ICP_NMOM )
+  {
+    const double* in = L.mom_part + ( (size_t)prob * ICP_NMOM + k ) * L.n_mom_blocks;
+    double v = 0.0;
+    for( int b = threadIdx.x; b < L.n_mom_blocks; b += BLOCK ) v += in[b];
+    v = wave_sum( v );
+    if( lane == 0 ) s_part[wib] = v;
+    __syncthreads();
+    if( threadIdx.x == 0 )
+    {
+      double t = 0.0;
+      for( int w = 0; w < WAVES_PER_BLOCK; ++w ) t += s_part[w];
+      L.res[(size_t)prob * ICP_NRES + k] = t;
+    }
+  }
+  else
+  {
+    const int row = ( k - ICP_NMOM ) * WAVES_PER_BLOCK + wib;
+    if( row < CH_ROWS )
+    {
+      int d[2] = { 0, 0 };
+      const unsigned long long t0 = B.dbg ? wall_clock64() : 0ull;
+      const float s = lane_chain_walk( B.addends + lane_rows_base( L, prob ) + (size_t)row * lane_row_stride( L.src.n ), L.src.n, lane, d );
+      if( lane == 0 )
+      {
+        B.totals[( (size_t)prob * 3 + 1 ) * ICP_NMOM + row] = (double)s;
+        if( B.resolved ) atomicAdd( B.resolved + prob, d[0] );
+        // (RS_HIP_LANE_DEBUG) per (problem, chain): ticks of 10 ns the walk took, attempts, addends added one by one — of the last iteration
+        if( B.dbg ) { int* o = B.dbg + ( (size_t)prob * CH_ROWS + row ) * 4; o[0] = (int)( wall_clock64() - t0 ); o[1] = d[1]; o[2] = d[0]; o[3] = L.src.n; }
+      }
+    }
+    __syncthreads();
+  }
+  if( threadIdx.x == 0 )
+  {
+    __threadfence();
+    s_last = atomicAdd( B.done + prob, 1 ) == ICP_NMOM + LC_WALK_BLOCKS - 1 ? 1 : 0;
+  }
+  __syncthreads();
+  if( !s_last ) return;
+  __threadfence();                                       // (the other workgroups' sums and totals)
+  if( threadIdx.x == 0 ) B.done[prob] = 0;
+  icp_update_tail( L, prob );
+}
+
+void launch_icp_lane_chains( const IcpLaunch& L, const ChainBufs& B, hipStream_t st )
+{
+  hipLaunchKernelGGL( k_lane_moments_and_addends, dim3( L.n_mom_blocks, L.n_prob ), dim3( BLOCK ), 0, st, L, B );      // (L.n_mom_blocks == ceil( max_n / 1024 ))
+  hipLaunchKernelGGL( k_lane_walk_and_update, dim3( ICP_NMOM + LC_WALK_BLOCKS, L.n_prob ), dim3( BLOCK ), 0, st, L, B );
 }
 
 void launch_icp_chain_centroids( const IcpLaunch& L, const ChainBufs& B, hipStream_t st )

@@ -113,15 +113,35 @@ def test_find_corrs_vs_golden(capi, gscene, scene_clouds, fname):
         assert (a == g[name]).all(), name
 
 
+POLICY_TOL = 2e-5      # what the default estimator of object-sized sources is held to on the reference's fixtures (5 x inside north_star's 1e-4; measured <= 1.5e-5)
+
+
 @pytest.mark.parametrize("fname", golden_files("icp_"))
 def test_icp_align_vs_golden(capi, gscene, scene_clouds, fname):
+    """The nine icp_align fixtures of the reference under the estimator POLICY (round 6, profiles/r06/estimator_policy.txt):
+    the default at this size (<= 4 096 source points: the reference's own order) returns the reference's bits; the default of larger
+    object-sized sources — lane chains: reference cut + reference centroid chains + fp64 moments, forced here by lowering the
+    reference-order threshold — stays within POLICY_TOL of the reference's pose with the reference's iteration count; and the opt-in
+    rs_hip_icp_reference_order_below( 65536 ) is bit-identical whatever the size."""
     g = load_golden(fname)
     clouds, objs = scene_clouds
     md = float(g["max_dist"])
-    err, T, iters = capi.icp_align(objs[int(g["obj"])], clouds[round(md, 3)], g["T1"], g["T2"], md, g["max_angle"])
+    src, tgt = objs[int(g["obj"])], clouds[round(md, 3)]
+    err, T, iters = capi.icp_align(src, tgt, g["T1"], g["T2"], md, g["max_angle"])
     assert np.linalg.norm(T.astype(np.float64) - g["T_out"].astype(np.float64)) < POSE_TOL
     assert abs(err - float(g["err"])) < 1e-5
     assert iters == int(g["iters"])
+    if "RS_HIP_REF_ORDER_BELOW" not in os.environ and "RS_HIP_LANE_CHAINS_BELOW" not in os.environ:
+        assert src.n <= capi.icp_reference_order_below(-1) and T.tobytes() == np.asarray(g["T_out"], np.float32).ravel().tobytes()
+    prev = capi.icp_reference_order_below(0)
+    try:
+        e2, T2, it2 = capi.icp_align(src, tgt, g["T1"], g["T2"], md, g["max_angle"])                 # the lane chains
+        assert np.linalg.norm(T2.astype(np.float64) - g["T_out"].astype(np.float64)) < POLICY_TOL and abs(e2 - float(g["err"])) < 1e-5 and it2 == int(g["iters"])
+        capi.icp_reference_order_below(65536)
+        e3, T3, it3 = capi.icp_align(src, tgt, g["T1"], g["T2"], md, g["max_angle"])                 # the opt-in
+        assert T3.tobytes() == np.asarray(g["T_out"], np.float32).ravel().tobytes() and np.float32(e3) == np.float32(g["err"]) and it3 == int(g["iters"])
+    finally:
+        capi.icp_reference_order_below(prev)
 
 
 @pytest.mark.parametrize("fname", golden_files("icp_"))
@@ -176,11 +196,7 @@ def test_icp_reference_order_vs_oracle_seeded(capi, oracle):
     try:
         o = s1["objects"][1]
         oc = capi.Cloud(o["pos"], o["nor"])
-        import os
-        if "RS_HIP_REF_ORDER_BELOW" in os.environ:
-            capi.icp_reference_order_below(65536)
-        else:
-            assert oc.n <= prev == 65536                      # the default threshold covers object-sized sources
+        capi.icp_reference_order_below(65536)                 # (the opt-in: every call site of the reference in the reference's own order)
         T0s = np.stack([synth.perturbed_pose(o["pose"], rng, 0.05, 0.05) for _ in range(4)])
         errs, Ts, its = capi.icp_align_batch(oc, a, T0s, I4, 0.075, ang)
         for k in range(4):
@@ -276,25 +292,45 @@ def test_icp_multi_source_batch_matches_single(capi, oracle, gscene, scene_cloud
     srcs = list(objs) + [capi.Cloud(p, n_, cell_size=0.1) for p, n_ in host[len(objs):]]
     order = [5, 0, 3, 1, 4, 2, 0]                                   # ragged, the big one first, source 0 twice
     T0s = np.stack([synth.perturbed_pose(poses[k], rng) for k in order])
-    for md, ma, fixed, iters in ((0.1, 60.0, False, 100), (0.075, 50.0, True, 7)):
-        ma = np.float32(np.deg2rad(np.float32(ma)))
-        errs, Ts, its = capi.icp_align_multi([srcs[k] for k in order], clouds[0.1], T0s, I4, md, ma, max_iter=iters, fixed_iters=fixed)
-        for j, k in enumerate(order):
-            e, T, it = capi.icp_align(srcs[k], clouds[0.1], T0s[j], I4, md, ma, max_iter=iters, fixed_iters=fixed)
-            assert (T == Ts[j]).all() and e == errs[j] and it == its[j], (j, k)
-            if not fixed:
-                eo, To, ito = oracle.icp_align(host[k][0], host[k][1], pts, nor, T0s[j], I4, md, ma)
-                assert (To == Ts[j]).all() and np.float32(eo) == errs[j] and ito == its[j], (j, k)
-    # one source above the reference-order range: problem by problem, same answers
-    prev = capi.icp_reference_order_below(-1)
+    prev = capi.icp_reference_order_below(65536)                    # the opt-in: every problem in the reference's own order
     try:
-        capi.icp_reference_order_below(20000)
-        errs2, Ts2, its2 = capi.icp_align_multi([srcs[k] for k in order[:3]], clouds[0.1], T0s[:3], I4, 0.1, np.deg2rad(60.0))
-        for j, k in enumerate(order[:3]):
-            e, T, it = capi.icp_align(srcs[k], clouds[0.1], T0s[j], I4, 0.1, np.deg2rad(60.0))
-            assert (T == Ts2[j]).all() and e == errs2[j] and it == its2[j]
+        for md, ma, fixed, iters in ((0.1, 60.0, False, 100), (0.075, 50.0, True, 7)):
+            ma = np.float32(np.deg2rad(np.float32(ma)))
+            errs, Ts, its = capi.icp_align_multi([srcs[k] for k in order], clouds[0.1], T0s, I4, md, ma, max_iter=iters, fixed_iters=fixed)
+            for j, k in enumerate(order):
+                e, T, it = capi.icp_align(srcs[k], clouds[0.1], T0s[j], I4, md, ma, max_iter=iters, fixed_iters=fixed)
+                assert (T == Ts[j]).all() and e == errs[j] and it == its[j], (j, k)
+                if not fixed:
+                    eo, To, ito = oracle.icp_align(host[k][0], host[k][1], pts, nor, T0s[j], I4, md, ma)
+                    assert (To == Ts[j]).all() and np.float32(eo) == errs[j] and ito == its[j], (j, k)
+        # Mixed batches: every problem gets the estimator its own call would get.  Threshold 2 000: the 30 k-point extract and the
+        # 3 231-point table take the lane chains (one batch), the chairs and the subsets the reference's order (another); threshold
+        # 20 000 with the lane chains off: the extract runs alone on the grid chains.  Same answers as the single calls, bit for bit.
+        for ro, ln in ((2000, 65536), (20000, 0)):
+            capi.icp_reference_order_below(ro); prev_l = capi.icp_lane_chains_below(ln)
+            try:
+                errs2, Ts2, its2 = capi.icp_align_multi([srcs[k] for k in order], clouds[0.1], T0s, I4, 0.1, np.deg2rad(60.0))
+                for j, k in enumerate(order):
+                    e, T, it = capi.icp_align(srcs[k], clouds[0.1], T0s[j], I4, 0.1, np.deg2rad(60.0))
+                    assert (T == Ts2[j]).all() and e == errs2[j] and it == its2[j], (ro, ln, j, k)
+            finally:
+                capi.icp_lane_chains_below(prev_l)
     finally:
         capi.icp_reference_order_below(prev)
+    # the DEFAULT policy on the same batch: within POLICY_TOL of the oracle (= the reference), equal iteration counts
+    errs, Ts, its = capi.icp_align_multi([srcs[k] for k in order], clouds[0.1], T0s, I4, 0.1, np.deg2rad(60.0))
+    for j, k in enumerate(order):
+        eo, To, ito = oracle.icp_align(host[k][0], host[k][1], pts, nor, T0s[j], I4, 0.1, np.deg2rad(60.0))
+        d = float(np.linalg.norm(Ts[j].astype(np.float64) - To))
+        if k == 5:
+            # The 30 k-point extract is a SUBSET OF ITS OWN TARGET: once aligned its residuals are the rounding noise of the coordinates
+            # (error 3e-4, moving in the third digit with every rounding of the estimator), and the stop test |delta err| < 1e-5 fires two
+            # iterations apart for any estimator that is not the reference's own order — including one that is exact everywhere
+            # (oracle/price_estimators.py, mode 3).  Reported, held to 1e-3; the reference-order opt-in above returns the bits.
+            print(f"self-alignment of a scan extract under the default estimator: {d:.2e} from the reference, {its[j]} vs {ito} iterations")
+            assert d < 1e-3
+            continue
+        assert d < POLICY_TOL and its[j] == ito, (j, k, d)
     # an empty batch, a batch of one
     e0, T0, i0 = capi.icp_align_multi([], clouds[0.1], np.zeros((0, 16), np.float32))
     assert len(e0) == 0
@@ -344,6 +380,7 @@ def test_exact_centroid_chains_are_the_sequential_sums(capi, gscene, scene_cloud
     clouds, objs = scene_clouds
     prev, prev_r, prev_c = capi.icp_reference_order_below(-1), capi.icp_replay_below(-1), capi.icp_exact_centroids(-1)
     prev_w = capi.icp_chains_retry_after(0)      # (every mode-1 call below tries the chains, also on a source that gave up before)
+    prev_l = capi.icp_lane_chains_below(0)       # (the GRID chains at every size: object-sized sources would take the lane chains, test_lane_chains_are_the_sequential_sums)
     try:
         capi.icp_reference_order_below(0); capi.icp_replay_below(0)
         for fname in golden_files("icp_"):
@@ -425,7 +462,85 @@ def test_exact_centroid_chains_are_the_sequential_sums(capi, gscene, scene_cloud
         print(f"{b.n} source points around the origin: calls the chains gave up: {capi.icp_chains_gave_up() - gave_up}")
         a.close(); b.close()
     finally:
-        capi.icp_reference_order_below(prev); capi.icp_replay_below(prev_r); capi.icp_exact_centroids(prev_c); capi.icp_chains_retry_after(prev_w)
+        capi.icp_reference_order_below(prev); capi.icp_replay_below(prev_r); capi.icp_exact_centroids(prev_c); capi.icp_chains_retry_after(prev_w); capi.icp_lane_chains_below(prev_l)
+
+
+def test_lane_chains_are_the_sequential_sums(capi, gscene, scene_clouds):
+    """Round 6: object-sized sources above the reference-order threshold take the LANE chains (one wave per centroid chain, 256 addends
+    per step on the integer grid of the sum's binade, fp32 one by one where that does not hold: rs_icp_estimate.hip).  The seven sums
+    must be the sequential fp32 sums whatever the input: whole icp_align runs against the same estimator with the sums by pass 2 of
+    the replay (itself held against the sequential kernel) — poses, errors and iteration counts bit for bit — on every object
+    fixture, batches, a scan whose x coordinates straddle zero (a chain that changes sign), a scan that begins with unmatched points
+    (sums that stay exactly zero), scans centred on the origin (sums that hover: the fp32 stretches), and through
+    rs_hip_icp_align_multi with sources of very different sizes; and every such pose within 1e-5 of the reference-order
+    estimator's (the reference's bits) where that one is affordable."""
+    from rescan_amd import synth
+    clouds, objs = scene_clouds
+    prev, prev_r, prev_c, prev_l = capi.icp_reference_order_below(-1), capi.icp_replay_below(-1), capi.icp_exact_centroids(-1), capi.icp_lane_chains_below(-1)
+    try:
+        capi.icp_reference_order_below(0); capi.icp_replay_below(0)
+
+        def both(fn):
+            capi.icp_lane_chains_below(1 << 30); capi.icp_exact_centroids(1)
+            a = fn()
+            capi.icp_lane_chains_below(0); capi.icp_exact_centroids(2)
+            b = fn()
+            return a, b
+
+        for fname in golden_files("icp_"):
+            g = load_golden(fname)
+            o = objs[int(g["obj"])]
+            md = float(g["max_dist"])
+            a, b = both(lambda: capi.icp_align(o, clouds[round(md, 3)], g["T1"], g["T2"], md, g["max_angle"]))
+            assert (a[1] == b[1]).all() and a[0] == b[0] and a[2] == b[2], fname
+            assert np.linalg.norm(a[1].astype(np.float64) - g["T_out"]) < 2e-5 and a[2] == int(g["iters"]), fname
+        rng = np.random.default_rng(5)
+        o = gscene["objects"][1]
+        T0s = np.stack([synth.perturbed_pose(o["pose"], rng) for _ in range(4)])
+        a, b = both(lambda: capi.icp_align_batch(objs[1], clouds[0.1], T0s, I4, 0.1, np.deg2rad(60.0)))
+        assert (a[1] == b[1]).all() and (a[0] == b[0]).all() and (a[2] == b[2]).all()
+        for n_pts, seed, centre in ((70_000, 3, "x"), (120_000, 8, None), (120_000, 22, "xyz"), (40_000, 23, "xyz")):
+            s0 = synth.scene_for_point_count(n_pts, seed=seed, timestep=0)
+            s1 = synth.scene_for_point_count(n_pts, seed=seed, timestep=1)
+            shift = np.zeros(3, np.float32)
+            if centre == "x":
+                shift[0] = -float(np.median(s1["points"][:, 0]))
+            if centre == "xyz":
+                shift = -np.median(s1["points"], axis=0).astype(np.float32)
+            p1 = s1["points"] + shift
+            if seed == 8:
+                p1 = p1.copy(); p1[: len(p1) // 5] += np.array([50.0, 0.0, 0.0], np.float32)      # (a fifth of it matches nothing, at the START of the chains)
+            ca, cb = capi.Cloud(s0["points"] + shift, s0["normals"]), capi.Cloud(p1, s1["normals"])
+            T0 = synth.perturbed_pose(I4, rng, 0.02, 0.01)
+            seq0 = capi.icp_lane_chains_sequential()
+            a, b = both(lambda: capi.icp_align(cb, ca, T0, I4, 0.1, np.deg2rad(60.0), max_iter=8, fixed_iters=True))
+            print(f"{cb.n} source points (seed {seed}, centred {centre}): {capi.icp_lane_chains_sequential() - seq0} of {8 * 7 * cb.n} addends added one by one")
+            assert (a[1] == b[1]).all() and a[0] == b[0] and a[2] == b[2], (n_pts, seed)
+            capi.icp_reference_order_below(1 << 30)
+            r = capi.icp_align(cb, ca, T0, I4, 0.1, np.deg2rad(60.0), max_iter=8, fixed_iters=True)
+            capi.icp_reference_order_below(0)
+            d = float(np.linalg.norm(a[1].astype(np.float64) - r[1].astype(np.float64)))
+            print(f"   {d:.2e} from the reference-order estimator's pose")
+            assert d < 1e-5
+            ca.close(); cb.close()
+        # rs_hip_icp_align_multi: problems of very different sizes side by side, each the bits of its own single call
+        pts, nor = gscene["points"], gscene["normals"]
+        host = [(o["pos"], o["nor"]) for o in gscene["objects"]]
+        poses = [o["pose"] for o in gscene["objects"]]
+        sub = rng.permutation(len(host[1][0]))[:9]; host.append((host[1][0][sub], host[1][1][sub])); poses.append(poses[1])
+        big = np.sort(rng.permutation(len(pts))[:30000])
+        host.append((np.ascontiguousarray(pts[big]), np.ascontiguousarray(nor[big]))); poses.append(I4)
+        srcs = list(objs) + [capi.Cloud(p, n_, cell_size=0.1) for p, n_ in host[len(objs):]]
+        order = [4, 0, 3, 1, 2, 0]
+        T0m = np.stack([synth.perturbed_pose(poses[k], rng) for k in order])
+        capi.icp_lane_chains_below(1 << 30); capi.icp_exact_centroids(1)
+        for fixed, iters in ((False, 100), (True, 7)):
+            errs, Ts, its = capi.icp_align_multi([srcs[k] for k in order], clouds[0.1], T0m, I4, 0.075, np.deg2rad(50.0), max_iter=iters, fixed_iters=fixed)
+            for j, k in enumerate(order):
+                e, T, it = capi.icp_align(srcs[k], clouds[0.1], T0m[j], I4, 0.075, np.deg2rad(50.0), max_iter=iters, fixed_iters=fixed)
+                assert (T == Ts[j]).all() and e == errs[j] and it == its[j], (j, k)
+    finally:
+        capi.icp_reference_order_below(prev); capi.icp_replay_below(prev_r); capi.icp_exact_centroids(prev_c); capi.icp_lane_chains_below(prev_l)
 
 
 def test_icp_no_correspondences(capi, scene_clouds):

@@ -1,0 +1,111 @@
+"""price the estimator choice for OBJECT-sized ICP sources against the bar.  For the nine icp_* fixtures, the eight
+strong_icp_* units of bench_seed11.npz and the 24 scan-sized sweep runs — every case whose REFERENCE result is committed — run
+rs_hip_icp_align under each estimator and report the pose distance (Frobenius) from the reference's pose, whether the iteration
+count is the reference's, and the time per iteration (wall clock of the call / iterations, best of 3 — launches and the loop's
+synchronisations included, which is what a caller pays):
+
+   (i)    sequential bits    rs_hip_icp_reference_order_below( inf )      k_icp_faithful
+   (i')   replay             ... _replay_below( inf )                     the same bits in parallel
+   (ii-l) lane chains        ... _lane_chains_below( inf )                reference centroid chains by one wave each + fp64 moments   (round 6)
+   (ii-g) grid chains        all thresholds 0, exact centroids 1          the same sums spread over the chip (k_chain_*)
+   (iii)  fp64 moments       exact centroids 0
+
+Run on the GPU box: python tools/estimator_policy.py [--no-sweep] > profiles/r06/estimator_policy.txt"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import torch  # noqa: E402,F401  (torch owns the HIP runtime first, as in bench.py)
+
+if torch.cuda.is_available():
+    torch.cuda.init()
+from rescan_amd import capi  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+I4 = np.eye(4, dtype=np.float32).ravel()
+BIG = 1 << 30
+EST = [("(i) sequential bits", dict(ro=BIG, rp=0, ln=0, ec=1)), ("(i') replay", dict(ro=0, rp=BIG, ln=0, ec=1)),
+       ("(ii-l) lane chains", dict(ro=0, rp=0, ln=BIG, ec=1)), ("(ii-g) grid chains", dict(ro=0, rp=0, ln=0, ec=1)),
+       ("(iii) fp64 moments", dict(ro=0, rp=0, ln=0, ec=0))]
+
+
+def configure(c):
+    capi.icp_reference_order_below(c["ro"]); capi.icp_replay_below(c["rp"]); capi.icp_lane_chains_below(c["ln"]); capi.icp_exact_centroids(c["ec"])
+
+
+def main():
+    capi.init(0)
+    capi.icp_chains_retry_after(0)
+    prev = (capi.icp_reference_order_below(-1), capi.icp_replay_below(-1), capi.icp_lane_chains_below(-1), capi.icp_exact_centroids(-1))
+    print("# estimator policy for object-sized sources: pose distance from the REFERENCE's pose | iterations (== reference?) | us per iteration")
+    print("# " + " | ".join(name for name, _ in EST))
+    summary = {name: dict(worst=0.0, it_diff=0, us=[], bits=0) for name, _ in EST}
+    n_cases = 0
+
+    def run(label, src, tgt, T0, md, ma, T_ref, it_ref, **kw):
+        nonlocal n_cases
+        cells = []
+        for name, c in EST:
+            configure(c)
+            best = 1e9
+            for _ in range(3):
+                t = time.perf_counter()
+                e, T, it = capi.icp_align(src, tgt, T0, I4, md, ma, **kw)
+                best = min(best, time.perf_counter() - t)
+            d = float(np.linalg.norm(T.astype(np.float64) - np.asarray(T_ref, np.float64).ravel()))
+            same = it_ref is None or it == it_ref
+            S = summary[name]
+            S["worst"] = max(S["worst"], d); S["it_diff"] += int(not same); S["us"].append(best * 1e6 / max(it, 1)); S["bits"] += int(d == 0.0)
+            cells.append(f"{d:.2e} {it:3d}{'' if same else '!'} {best * 1e6 / max(it, 1):7.1f}")
+        n_cases += 1
+        print(f"{label:22s} n {src.n:7d} ref {it_ref if it_ref is not None else kw.get('max_iter', 0):3d} it | " + " | ".join(cells), flush=True)
+
+    d = dict(np.load(os.path.join(GOLDEN, "scene.npz")))
+    objs = [capi.Cloud(d[f"obj{i}_pos"], d[f"obj{i}_nor"], cell_size=0.1) for i in range(int(d["n_obj"]))]
+    scene = {r: capi.Cloud(d["points"], d["normals"], cell_size=2 * r) for r in (0.05, 0.1)}
+    scene[0.075] = capi.Cloud(d["points"], d["normals"])
+    for fn in sorted(f for f in os.listdir(GOLDEN) if f.startswith("icp_")):
+        g = dict(np.load(os.path.join(GOLDEN, fn)))
+        md = float(g["max_dist"])
+        run(fn[:-4], objs[int(g["obj"])], scene[round(md, 3)], g["T1"], md, float(g["max_angle"]), g["T_out"], int(g["iters"]))
+    import bench
+    g = dict(np.load(os.path.join(GOLDEN, "bench_seed11.npz")))
+    w = bench.build_workload(1_000_000, seed=11, knn="hash")
+    si = w["strong_icp"]
+    for k, p in enumerate(w["plc"][:bench.N_PLACEMENTS]):
+        run(f"strong_icp_{k}", p["cloud"], w["scan1"], si["T0s"][k], si["max_dist"], si["max_angle"], g["strong_icp_pose"][k], None,
+            max_iter=bench.ICP_ITERS, fixed_iters=True)
+    # the eight as ONE rs_hip_icp_align_multi call: what bench.py --scaling strong times
+    print("# the eight strong_icp units as one rs_hip_icp_align_multi call (ten fixed iterations): ms per call, worst pose distance from the reference")
+    for name, c in EST[:1] + EST[2:3]:
+        configure(c)
+        best = 1e9
+        for _ in range(5):
+            t = time.perf_counter()
+            errs, Ts, its = capi.icp_align_multi([p["cloud"] for p in w["plc"][:bench.N_PLACEMENTS]], w["scan1"], si["T0s"], I4, si["max_dist"], si["max_angle"],
+                                                 max_iter=bench.ICP_ITERS, fixed_iters=True)
+            best = min(best, time.perf_counter() - t)
+        dd = np.linalg.norm(Ts.astype(np.float64).reshape(-1, 16) - g["strong_icp_pose"].astype(np.float64).reshape(-1, 16), axis=1)
+        print(f"#   {name:22s} {best * 1e3:7.3f} ms   worst {dd.max():.2e}   bit-identical {int((dd == 0).sum())} of {len(dd)}")
+    if "--no-sweep" not in sys.argv:
+        from gen_golden_bench import sweep_inputs
+        g = dict(np.load(os.path.join(GOLDEN, "sweep_icp.npz")))
+        for k, seed in enumerate(g["seeds"]):
+            s0, s1, T0, md, ma = sweep_inputs(int(seed))
+            a, b = capi.Cloud(s0["points"], s0["normals"]), capi.Cloud(s1["points"], s1["normals"])
+            run(f"sweep_{int(seed):02d}", b, a, T0, float(md), float(ma), g["pose"][k], int(g["iters"][k]))
+            a.close(); b.close()
+    print(f"# {n_cases} cases.  Per estimator: worst pose distance | cases with another iteration count | cases bit-identical | median us per iteration")
+    for name, _ in EST:
+        S = summary[name]
+        print(f"#   {name:22s} {S['worst']:.2e} | {S['it_diff']:2d} | {S['bits']:2d} | {np.median(S['us']):8.1f}")
+    capi.icp_reference_order_below(prev[0]); capi.icp_replay_below(prev[1]); capi.icp_lane_chains_below(prev[2]); capi.icp_exact_centroids(prev[3])
+
+
+if __name__ == "__main__":
+    main()
