@@ -76,6 +76,10 @@ void            rs_hip_cloud_destroy( rs_hip_cloud_t* c );
 int32_t         rs_hip_cloud_size( const rs_hip_cloud_t* c );
 /* bytes of HBM held by the cloud */
 int64_t         rs_hip_cloud_bytes( const rs_hip_cloud_t* c );
+/* (diagnostics) Where cloud construction went, in seconds of the calling threads' wall clock, summed over every cloud the process
+ * built since the last reset: out[0] host copy of the arrays, [1] upload + bounds, [2] cell index (sort by cell, offset table),
+ * [3] Hilbert order + tiles.  Returns the number of clouds counted; reset != 0 clears the counters. */
+int64_t         rs_hip_cloud_build_seconds( double out[4], int32_t reset );
 
 /* ---- bounded-K radius search ------------------------------------------------------- */
 
@@ -265,7 +269,8 @@ int rs_hip_fold_label_partials_device( const float* base_device, const int64_t* 
  * sorts placement indices (dynamic first, then by class index; stable), runs the dynamic
  * pass with `radius` and the static pass with 1.5*radius (or resets min_dists when
  * prioritize_static).  is_static / class_idx are per placement.  sorted_order (may be NULL)
- * receives the permutation; labels index into the sorted order, 1-based, 0 = unlabelled. */
+ * receives the permutation; labels index into the sorted order, 1-based, 0 = unlabelled.  min_dists may be NULL (the reference
+ * frees its own before it returns, :871-872: the shim's rsd_arrangement_to_labels does not download them). */
 int rs_hip_arrangement_to_labels( const rs_hip_cloud_t* scene,
                                   const float* poses /* 16*n */, const rs_hip_cloud_t* const* objects /* n */,
                                   const int32_t* is_static, const int32_t* class_idx, int32_t n,

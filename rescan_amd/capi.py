@@ -33,6 +33,7 @@ SIGNATURES = {
     "rs_hip_cloud_destroy": (None, [C.c_void_p]),
     "rs_hip_cloud_size": (C.c_int32, [C.c_void_p]),
     "rs_hip_cloud_bytes": (C.c_int64, [C.c_void_p]),
+    "rs_hip_cloud_build_seconds": (C.c_int64, [C.POINTER(C.c_double), C.c_int32]),
     "rs_hip_radius_search": (C.c_int, [C.c_void_p, f32p, C.c_int64, C.c_float, C.c_int32, f32p, i32p, u64p,
                                        C.POINTER(C.c_uint64)]),
     "rs_hip_icp_align": (C.c_int, [C.c_void_p, C.c_void_p, f32p, f32p, C.c_float, C.c_float, C.c_int32, C.c_int32,
@@ -235,6 +236,13 @@ def radius_search(target, query, radius, k):
     tot = C.c_uint64()
     _check(load().rs_hip_radius_search(target.handle, query, nq, float(radius), int(k), d, i, nn, C.byref(tot)))
     return d, i, nn.astype(np.int64), tot.value
+
+
+def cloud_build_seconds(reset=False):
+    """(diagnostics) seconds spent building clouds since the last reset: (host copy, upload + bounds, cell index, Hilbert order + tiles), clouds counted."""
+    out = (C.c_double * 4)()
+    n = load().rs_hip_cloud_build_seconds(out, 1 if reset else 0)
+    return [float(x) for x in out], int(n)
 
 
 def icp_reference_order_below(n_points=-1):

@@ -146,11 +146,46 @@ uint64_t sampled_hash( const void* a, const void* b, size_t bytes )
   return h;
 }
 
+// Round 6 — the middle tier.  An arrangement's placements are 8-40 arrays of 0.1-0.6 MB each: full hashes of all of them were the
+// 0.5 ms the label entry spent on the host before its 0.38 ms kernel.  Arrays between RS_DROPIN_FULL_HASH_SMALL
+// (default 64 KB: every level-2 object of the reference's call sites stays on the full hash) and RS_DROPIN_FULL_HASH_BELOW are keyed by
+// every eighth 64-byte block plus both ends — an edit of 512 consecutive bytes anywhere is seen at once, any edit at the next
+// periodic full-hash check (first hit, then every kVerifyEvery-th), rsd_cache_invalidate / msh_hash_grid_term at once.
+size_t full_hash_small()
+{
+  static const size_t v = getenv( "RS_DROPIN_FULL_HASH" ) ? ~(size_t)0 : getenv( "RS_DROPIN_FULL_HASH_SMALL" ) ? (size_t)atoll( getenv( "RS_DROPIN_FULL_HASH_SMALL" ) ) : ( (size_t)64 << 10 );
+  return v;
+}
+uint64_t strided_hash( const void* a, const void* b, size_t bytes )
+{
+  uint64_t h = 0x2545f4914f6cdd1dull ^ bytes;
+  for( const void* src : { a, b } )
+  {
+    if( !src ) { h = mix( h, 0x51ull ); continue; }
+    const unsigned char* p = (const unsigned char*)src;
+    uint64_t w[8];
+    uint64_t l0 = h, l1 = h ^ 0x165667b19e3779f9ull, l2 = h ^ 0x27d4eb2f165667c5ull, l3 = h ^ 0x85ebca77c2b2ae63ull;
+    auto block = [&]( const unsigned char* q )
+    {
+      std::memcpy( w, q, 64 );
+      l0 = ( l0 ^ w[0] ^ ( w[4] << 1 ) ) * 0xff51afd7ed558ccdull; l0 ^= l0 >> 29;
+      l1 = ( l1 ^ w[1] ^ ( w[5] << 1 ) ) * 0xc4ceb9fe1a85ec53ull; l1 ^= l1 >> 31;
+      l2 = ( l2 ^ w[2] ^ ( w[6] << 1 ) ) * 0x9fb21c651e98df25ull; l2 ^= l2 >> 30;
+      l3 = ( l3 ^ w[3] ^ ( w[7] << 1 ) ) * 0xd6e8feb86659fd93ull; l3 ^= l3 >> 32;
+    };
+    for( size_t i = 0; i + 64 <= bytes; i += 512 ) block( p + i );
+    block( p + bytes - 64 );
+    h = ( ( l0 * 31 + l1 ) * 31 + l2 ) * 31 + l3;
+  }
+  return h;
+}
+
 CloudRef cached_cloud( const rsd_vec3_t* pos, const rsd_vec3_t* nor, int32_t n, float cell )
 {
   const size_t bytes = (size_t)( n > 0 ? n : 0 ) * 12;
-  const bool sampled = bytes > full_hash_below() && bytes > 2048;
-  const uint64_t h = sampled ? sampled_hash( pos, nor, bytes ) : full_hash( pos, nor, bytes );
+  const bool sparse = bytes > full_hash_below() && bytes > 2048;
+  const bool sampled = sparse || ( bytes > full_hash_small() && bytes > 2048 );
+  const uint64_t h = sparse ? sampled_hash( pos, nor, bytes ) : sampled ? strided_hash( pos, nor, bytes ) : full_hash( pos, nor, bytes );
   {
     std::unique_lock<std::mutex> lock( g_cache_mutex );
     for( auto it = g_cache.begin(); it != g_cache.end(); ++it )
@@ -541,9 +576,10 @@ int rsd_arrangement_to_labels( const rsd_vec3_t* scn_pos, const rsd_vec3_t* scn_
     if( !held[i] ) return RS_HIP_E_RUNTIME;
     objs[i] = held[i].get();
   }
-  std::vector<float> min_dists( (size_t)( n_scn > 0 ? n_scn : 0 ) );
+  // (the reference frees its min_dists before it returns, rs_pointcloud_filters.cpp:871-872: nobody wants them back — round 6: no 4 MB
+  //  vector, no second download)
   int rc = rs_hip_arrangement_to_labels( scn.get(), (const float*)poses, objs.data(), is_static, class_idx, n_plc, radius,
-                                         prioritize_static ? 1 : 0, labels, min_dists.data(), sorted_order );
+                                         prioritize_static ? 1 : 0, labels, nullptr, sorted_order );
   if( rc ) complain( "arrangement_to_labels" );
   return rc;
 }

@@ -32,14 +32,14 @@ __device__ __forceinline__ Match cell_seed( const GridView& g, bool active, floa
   for( uint32_t t = 0; t < n; ++t )
   {
     const uint32_t s = s0 + t;
-    const float4 P = g.pos[s];
+    const float4 P = g.pn ? g.pn[2 * (size_t)s] : g.pos[s];
     const float vx = P.x - qx, vy = P.y - qy, vz = P.z - qz;
     const float d2 = vx * vx + vy * vy + vz * vz;
     float dc = 0.0f;
     bool ok = d2 < radius_sq;
     if( GATED )
     {
-      const float4 N = g.nor[s];
+      const float4 N = g.pn ? g.pn[2 * (size_t)s + 1] : g.nor[s];
       const float dot = N.x * nx + N.y * ny + N.z * nz;
       dc = dot > 0.0f ? dot : 0.0f;
       ok = ok && dc >= tmin && dc <= 1.0f;
@@ -60,7 +60,8 @@ __device__ __forceinline__ Match icp_warm_start( const IcpLaunch& L, int prob, i
   if( !L.warm ) return L.seed ? icp_cell_seed( L, active, qx, qy, qz, nx, ny, nz ) : m;
   const int s = L.m_slot[(size_t)L.pt_off + i];
   if( s < 0 ) return m;
-  const float4 P = L.tgt.pos[s], N = L.tgt.nor[s];
+  // (one 32-byte gather from the interleaved copy where the cloud has one: the point's position and normal share a cache line)
+  const float4 P = L.tgt.pn ? L.tgt.pn[2 * (size_t)s] : L.tgt.pos[s], N = L.tgt.pn ? L.tgt.pn[2 * (size_t)s + 1] : L.tgt.nor[s];
   float vx = P.x - qx, vy = P.y - qy, vz = P.z - qz;
   float d2 = vx * vx + vy * vy + vz * vz;
   float dot = N.x * nx + N.y * ny + N.z * nz;
@@ -123,10 +124,16 @@ __device__ __forceinline__ bool icp_certificate( const IcpLaunch& L, int prob, i
   return skip;
 }
 
-__device__ __forceinline__ void icp_emit( const IcpLaunch& L, int prob, int tile, int i, bool active, int lane, const Match& m,
+__device__ __forceinline__ void icp_emit( const IcpLaunch& L, int prob, int tile, int i, bool active, int lane, const Match& ms,
                                           bool skipped )
 {
   const size_t o = (size_t)L.pt_off + i;
+  // A first iteration searched with a larger radius than the reference's (for the certificates' sake, rs_api.hip: icp_search_launch):
+  // the nearest gated candidate of the K nearest within the LARGER radius is, when it lies within the reference's radius, the
+  // reference's pick (everything that precedes it lies within that radius too: same rank); when it lies beyond, nothing gated lies
+  // within — the point has no correspondence.  The certificate below is issued from the search as it was (ms).
+  Match m = ms;
+  if( m.found && !( m.d2 < L.match_radius_sq ) ) { m.found = false; }
   if( active ) { L.m_slot[o] = m.found ? m.slot : -1; if( !L.rec ) { L.m_d2[o] = m.d2; L.m_dot[o] = m.dot; } }
   if( active && L.rec )
   {
@@ -139,7 +146,11 @@ __device__ __forceinline__ void icp_emit( const IcpLaunch& L, int prob, int tile
     float qx, qy, qz, nx, ny, nz;
     icp_query( L, T1, i, true, qx, qy, qz, nx, ny, nz );           // (the same float operations the search used)
     float4 P = make_float4( 0.0f, 0.0f, 0.0f, 0.0f ), N = P;
-    if( m.found ) { P = L.tgt.pos[m.slot]; N = L.tgt.nor[m.slot]; }
+    if( m.found )
+    {
+      if( L.tgt.pn ) { P = L.tgt.pn[2 * (size_t)m.slot]; N = L.tgt.pn[2 * (size_t)m.slot + 1]; }
+      else { P = L.tgt.pos[m.slot]; N = L.tgt.nor[m.slot]; }
+    }
     const int orig = __float_as_int( L.src.pos[i].w );
     float4* R = L.rec + ( (size_t)L.pt_off + orig ) * REC_F4;
     R[0] = make_float4( qx, qy, qz, m.found ? m.d2 : -1.0f );
@@ -149,10 +160,10 @@ __device__ __forceinline__ void icp_emit( const IcpLaunch& L, int prob, int tile
   if( active && L.cert_r && !skipped )
   {
     // fresh certificate (m.idx != INT_MAX: a gated candidate exists at dist² m.d2, even if its rank rejected it)
-    const float r = ( m.idx != INT_MAX ? sqrtf( m.d2 ) : L.radius ) - 1e-4f;
-    const float d = L.gate_tmin - m.fail_max - 1e-5f;
+    const float r = ( ms.idx != INT_MAX ? sqrtf( ms.d2 ) : L.radius ) - 1e-4f;
+    const float d = L.gate_tmin - ms.fail_max - 1e-5f;
     L.cert_r[o] = ( d >= 0.0f ) ? r : -1.0f; L.cert_dot[o] = d;
-    if( L.cert_slack ) L.cert_slack[o] = ( !m.found && m.idx != INT_MAX ) ? m.rank_slack : 0.0f;
+    if( L.cert_slack ) L.cert_slack[o] = ( !ms.found && ms.idx != INT_MAX ) ? ms.rank_slack : 0.0f;
   }
   if( RS_DBG >= 2 && DBG( L ) )
   {
