@@ -595,7 +595,24 @@ def parity_block(out, n_points, seed, knn, units, strong=False, centre=False, t0
             blk["label_mismatches"] = 0 if same else max(1, int((np.asarray(out["labels"])[::257] != g["labels_sample"]).sum()))
         blk["min_dists_identical"] = bool(hashlib.sha256(np.ascontiguousarray(out["min_dists"], np.float32).tobytes()).hexdigest() == str(g["min_dists_sha"]))
     else:
-        blk["labels"] = "not compared: %d placements instead of the fixture's %d" % (units * N_PLACEMENTS, N_PLACEMENTS)
+        # Weak scaling at N = units ranks (round 6): the FURTHER unit lists — one more ICP start pose, 256 more score poses, 8 more
+        # placements per rank — against the reference build's results for them (tests/golden/bench_seed11_units.npz,
+        # oracle/gen_golden_bench.py --units): every pose, every score, and the labels / min_dists of the whole 8 N-placement arrangement.
+        upath = os.path.join(ROOT, "tests", "golden", "bench_seed%d_units.npz" % seed)
+        gu = np.load(upath) if (os.path.exists(upath) and not strong and not centre and not t0) else None
+        if gu is None or ("labels_sha_u%d" % units) not in gu or out.get("Ts") is None:
+            blk["labels"] = "not compared: %d placements instead of the fixture's %d (tests/golden/bench_seed%d_units.npz holds N = 2, 4, 8)" % (units * N_PLACEMENTS, N_PLACEMENTS, seed)
+        else:
+            blk["units_fixture"] = "tests/golden/bench_seed%d_units.npz" % seed
+            Ts = np.asarray(out["Ts"], np.float64).reshape(-1, 16)[:units]
+            blk["pose_dist_all_units"] = float(np.linalg.norm(Ts - gu["icp_pose"][:units].astype(np.float64).reshape(-1, 16), axis=1).max())
+            blk["err_abs_diff_all_units"] = float(np.abs(np.asarray(out["errs"], np.float64)[:units] - gu["icp_err"][:units].astype(np.float64)).max())
+            sc_all = np.asarray(out["scores"], np.float64)[:units * N_POSES]
+            blk["score_max_abs_err_all_units"] = float(np.abs(sc_all - gu["scores"][:units * N_POSES].astype(np.float64)).max())
+            same = hashlib.sha256(np.ascontiguousarray(out["labels"], np.int8).tobytes()).hexdigest() == str(gu["labels_sha_u%d" % units])
+            blk["label_mismatches"] = 0 if same else max(1, int((np.asarray(out["labels"])[::257] != gu["labels_sample_u%d" % units]).sum()))
+            blk["min_dists_identical"] = bool(hashlib.sha256(np.ascontiguousarray(out["min_dists"], np.float32).tobytes()).hexdigest() == str(gu["min_dists_sha_u%d" % units]))
+            blk["placements"] = units * N_PLACEMENTS
     blk["tolerance"] = {"pose_dist": 1e-4, "score_max_abs_err": 2e-6, "label_mismatches": 0}
     return blk
 
@@ -778,7 +795,7 @@ def launch_ranks(n, argv, dry_run=False):
     procs = []
     for r, pl in enumerate(plans):
         procs.append(subprocess.Popen(pl["cmd"], env=dict(os.environ, **pl["env"]), stdout=None if r == 0 else sys.stderr))
-    worst, live = 0, set(range(n))
+    worst, live, killed_at = 0, set(range(n)), 0.0
     while live:
         for r in sorted(live):
             rc = procs[r].poll()
@@ -790,6 +807,11 @@ def launch_ranks(n, argv, dry_run=False):
                 print("bench.py launcher: rank %d exited with %d, stopping the others" % (r, rc), file=sys.stderr)
                 for q in live:
                     procs[q].terminate()
+                killed_at = time.time()
+        # a rank blocked inside a collective (a native call) may sit on SIGTERM: after 5 s it is killed by PID
+        if worst and live and time.time() - killed_at > 5.0:
+            for q in live:
+                procs[q].kill()
         time.sleep(0.05)
     return worst if worst >= 0 else 1
 
@@ -836,6 +858,15 @@ def main():
         dist.init_process_group("gloo")
         t = torch.tensor([rank + 1])
         dist.all_reduce(t)
+        if os.environ["RS_BENCH_LAUNCH_SELFTEST"].startswith("die"):
+            # "die<r>": the group has formed and exchanged once; rank r then dies WITHOUT entering the next collective while the others
+            # block in it — the launcher must notice the death, stop the blocked ranks and hand the exit code on (no hang)
+            if os.environ["RS_BENCH_LAUNCH_SELFTEST"] == "die%d" % rank:
+                os._exit(5)
+            big = torch.zeros(1 << 20)
+            dist.all_reduce(big)          # never completes: a rank is gone
+            time.sleep(600)               # (gloo may return with an error instead of blocking: the launcher still has to end this process)
+            return
         if rank == 0:
             print(json.dumps({"selftest": int(t.item()), "world": world, "gpus": args.gpus}))
         dist.destroy_process_group()
@@ -922,7 +953,12 @@ def main():
         in_flight[:] = []
         last = last_of.get(0, last)
 
-    for _ in range(args.warmup):
+    # (rehearsal of the failure path, tools/r06_bench_modes.sh: RS_BENCH_DIE="<rank>:<warm-up step>" — that rank exits hard in the middle of
+    #  the run, with the others' exchange of the step before in flight; the launcher must end them and return its code)
+    die_rank, die_step = ([int(x) for x in os.environ["RS_BENCH_DIE"].split(":")] if os.environ.get("RS_BENCH_DIE") else (-1, -1))
+    for k_w in range(args.warmup):
+        if rank == die_rank and k_w == die_step:
+            os._exit(7)
         one_step()
     drain()
     for x in (SH or []):

@@ -56,8 +56,13 @@ typedef struct rsd_search_desc                                         /* == msh
 
 /* lib/msh/msh_hash_grid.h:218-230 */
 void   msh_hash_grid_init_3d( rsd_hash_grid_t* hg, const float* pts, const int32_t n_pts, const float radius );
+void   msh_hash_grid_init_2d( rsd_hash_grid_t* hg, const float* pts, const int32_t n_pts, const float radius );   /* :544-548: (x, y) pairs, kept as (x, y, 0) */
 void   msh_hash_grid_term( rsd_hash_grid_t* hg );
 size_t msh_hash_grid_radius_search( const rsd_hash_grid_t* hg, rsd_search_desc_t* search_desc );
+/* :1294-1447 — the reference's shell-by-shell traversal (not an exact k-nearest search: it stops one shell of bins after k points are
+ * stored), restated on the host on a grid of the reference's own geometry; no caller on the hot path.  Rows ascending in
+ * (dist², index); ends where the reference would overrun its 128-bin stack array or never return (rs_dropin.cpp: KnnGrid). */
+size_t msh_hash_grid_knn_search( const rsd_hash_grid_t* hg, rsd_search_desc_t* search_desc );
 
 /* lib/rs/icp.h:83-115 */
 float icp_align( rsd_vec3_t* pts1, rsd_vec3_t* nor1, int32_t n_pts1,

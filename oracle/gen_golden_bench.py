@@ -28,7 +28,8 @@ container only; the fixtures are committed so the GPU box, which has no /root/re
         around zero — with the same fields as --more's; bench_seed11_t1.npz, _t2.npz: the further scan pairs of bench.py --timesteps 4
 
 Usage:  python oracle/gen_golden_bench.py [--bench-only [--seed N] | --sweep-only | --more [--seed N] | --labels-only [--seed N] | --strong-only | --static-labels
-                                          | --centre [--seed N] | --pair T0 [--seed N]]
+                                          | --centre [--seed N] | --pair T0 [--seed N] | --units]
+        --units (round 6) -> tests/golden/bench_seed11_units.npz: the further unit lists of bench.py --gpus N (weak scaling), N <= 8
         --labels-only recomputes the label fields of every bench_seed*.npz from the reference build and leaves the rest as it is
 """
 import ctypes as C
@@ -173,6 +174,54 @@ def restrong(seed=11):
     np.savez_compressed(path, **g)
 
 
+def gen_units(seed=11, units=8):
+    """--units: tests/golden/bench_seed<seed>_units.npz — what the WEAK-scaling line of bench.py --gpus N computes beyond the first rank's
+    unit list (bench.build_inputs( ..., units = N ): per further unit one more ICP start pose, 256 more score poses, 8 more placements of
+    the same scene), by the reference build: the ten fixed iterations of every start pose, every score, and — per N in {2, 4, 8} — the
+    label transfer of the 8 N placements (digests + a strided sample).  The unit lists are prefixes of one another, so one fixture
+    serves every N <= units; the labels depend on the whole arrangement and are kept per N."""
+    import bench
+    from multiprocessing.pool import ThreadPool
+    w = bench.build_inputs(1_000_000, seed=seed, units=units)
+    s0, s1 = w["s0"], w["s1"]
+    R = Ref()
+    t = time.time()
+
+    def one(u):
+        Ru = Ref()      # (ctypes releases the GIL inside the call; every thread its own handle)
+        T, err, done, nc, errs = ref_iterate(Ru, s1["points"], s1["normals"], s0["points"], s0["normals"], w["icp_T0s"][u], I4,
+                                             0.10, np.float32(np.deg2rad(60.0)), bench.ICP_ITERS, 0)
+        assert done == bench.ICP_ITERS
+        print(f"unit {u}: icp err {err}, n_corrs {nc.tolist()} ({time.time()-t:.1f} s)", flush=True)
+        return T, err
+    res = ThreadPool(min(units, 7)).map(one, range(units))
+    poses = np.stack([r[0] for r in res]); errs = np.array([r[1] for r in res], np.float32)
+    g0 = dict(np.load(os.path.join(OUT, "bench_seed%d.npz" % seed)))
+    assert (poses[0] == g0["icp_pose"]).all(), "unit 0 must be the headline fixture's problem"
+    op, on = w["obj_score_np"]
+    t = time.time()
+    scores = R.alignment_scores(s1["points"], s1["normals"], op, on, w["score_poses"], 64)
+    assert (scores[:bench.N_POSES] == g0["scores"]).all()
+    print(f"scores: {len(scores)} poses ({time.time()-t:.1f} s)", flush=True)
+    out = dict(seed=seed, n_points=1_000_000, units=units, icp_T0s=w["icp_T0s"], icp_pose=poses, icp_err=errs, scores=scores,
+               in_sha=np.array([sha(s0["points"]), sha(s1["points"]), sha(w["icp_T0s"]), sha(w["score_poses"]), sha(w["plc_poses"])]),
+               labels_source=LABEL_SOURCE)
+    for n in (2, 4, 8):
+        if n > units:
+            continue
+        t = time.time()
+        plc = w["plc"][:n * bench.N_PLACEMENTS]
+        objs = [dict(pos=p["np"][0], nor=p["np"][1], class_idx=p["cls"], is_static=0) for p in plc]
+        plcs = [dict(pose=p["pose"], object_idx=k, uidx=k) for k, p in enumerate(plc)]
+        RF = RefFilters(synth.CLASS_IDX)
+        lab = RF.arrangement_to_labels(s1["points"], s1["normals"], objs, plcs, 0.05, 0, synth.CLASS_IDX["unlabelled"])
+        RF.close()
+        print(f"labels, {len(plc)} placements: {int((lab['labels'] > 0).sum())} labelled ({time.time()-t:.1f} s)", flush=True)
+        out.update({f"labels_sha_u{n}": sha(lab["labels"]), f"labels_sample_u{n}": lab["labels"][::257].copy(), f"min_dists_sha_u{n}": sha(lab["min_dists"]),
+                    f"order_u{n}": lab["order"], f"n_labelled_u{n}": int((lab["labels"] > 0).sum())})
+    np.savez_compressed(os.path.join(OUT, "bench_seed%d_units.npz" % seed), **out)
+
+
 def static_arrangement(w, seed):
     """An arrangement of the headline's size WITH static placements, for the label transfer's second pass (rs_pointcloud_filters.cpp:
     841-848: 1.5 x radius, shared min_dists) and its ordering (:724-736,823-835): the bench's eight ~50 k-point dynamic placements
@@ -263,6 +312,9 @@ if __name__ == "__main__":
     build(ref=True)
     if "--static-labels" in sys.argv:
         gen_static_labels(11)
+        sys.exit(0)
+    if "--units" in sys.argv:
+        gen_units(11, 8)
         sys.exit(0)
     if "--strong-only" in sys.argv:
         restrong(11)

@@ -326,12 +326,119 @@ struct HostGrid
   }
 };
 
+// msh_hash_grid_knn_search (lib/msh/msh_hash_grid.h:1291-1447) is NOT an exact k-nearest search: it visits the bins around the query's
+// own bin shell by shell (Chebyshev distance 0, 1, 2, ... in bins), skips a bin farther than the k-th distance so far, and stops ONE
+// shell after k points are stored — what it returns depends on the grid's own geometry (cell = 2 radius, the bounding box grown by
+// 1e-4, bins by truncation: :413-448,471-475).  Nothing on the hot path calls it (SURVEY §8b lists it with the boundary's exports,
+// VERDICT r05 missing 3): it is restated here on the HOST, on a grid of exactly that geometry built from the handle's copy of the
+// points at the first call, so that a maintainer's translation unit that uses it links against the shim and gets the reference's
+// rows.  Where the reference's behaviour is undefined or it does not return, the shim answers: a third shell's 218 bins overrun the
+// reference's 128-entry stack array (:1330,1412-1414) — a vector here; a cloud with fewer than k points, or a query outside the
+// grid's box, makes the reference spin forever — here the search ends when every bin has been visited.  Rows are returned ascending
+// in (dist², index), like every row of this library.
+struct KnnGrid
+{
+  float min_pt[3] = { 0, 0, 0 };
+  double cell = 0.0, inv_cell = 0.0;
+  int64_t w = 1, h = 1, d = 1;
+  std::vector<uint32_t> start;            // w h d + 1
+  std::vector<float> rec;                 // x, y, z, bitcast(index), bin order, input order inside a bin
+  void build( const HostGrid& hg, float radius )
+  {
+    const int32_t n = hg.n;
+    std::vector<float> pts( (size_t)n * 3 );
+    for( int32_t s = 0; s < n; ++s ) { int32_t i; std::memcpy( &i, &hg.rec[4 * (size_t)s + 3], 4 ); std::memcpy( &pts[3 * (size_t)i], &hg.rec[4 * (size_t)s], 12 ); }
+    float mn[3] = { 1e9f, 1e9f, 1e9f }, mx[3] = { -1e9f, -1e9f, -1e9f };                        // :413-414
+    for( int32_t i = 0; i < n; ++i ) for( int a = 0; a < 3; ++a ) { const float v = pts[3 * (size_t)i + a]; mn[a] = ( mn[a] > v ) ? v : mn[a]; mx[a] = ( mx[a] < v ) ? v : mx[a]; }
+    for( int a = 0; a < 3; ++a ) { mx[a] += 0.0001f; mn[a] -= 0.0001f; min_pt[a] = mn[a]; }   // :433-434
+    const float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+    const float max_dim = std::max( dx, std::max( dy, dz ) );
+    if( radius > 0.0 ) cell = 2.0 * radius; else cell = max_dim / ( 32 * sqrtf( 3.0f ) );          // :443-444
+    w = (int)( dx / cell + 1.0 ); h = (int)( dy / cell + 1.0 ); d = (int)( dz / cell + 1.0 );     // :446-448
+    w = std::max<int64_t>( w, 1 ); h = std::max<int64_t>( h, 1 ); d = std::max<int64_t>( d, 1 );
+    inv_cell = 1.0f / cell;                                                                       // :449
+    const size_t n_bins = (size_t)w * h * d;
+    start.assign( n_bins + 1, 0u );
+    std::vector<uint64_t> id( (size_t)n );
+    for( int32_t i = 0; i < n; ++i )
+    {
+      const float* p = &pts[3 * (size_t)i];
+      uint64_t ix = (uint64_t)( ( p[0] - min_pt[0] ) * inv_cell ), iy = (uint64_t)( ( p[1] - min_pt[1] ) * inv_cell ), iz = (uint64_t)( ( p[2] - min_pt[2] ) * inv_cell );   // :471-473
+      ix = std::min<uint64_t>( ix, (uint64_t)w - 1 ); iy = std::min<uint64_t>( iy, (uint64_t)h - 1 ); iz = std::min<uint64_t>( iz, (uint64_t)d - 1 );       // (never for finite points: the box is the points' own)
+      id[i] = ( iz * (uint64_t)h + iy ) * (uint64_t)w + ix;
+      start[id[i] + 1]++;
+    }
+    for( size_t b = 0; b < n_bins; ++b ) start[b + 1] += start[b];
+    std::vector<uint32_t> cur( start.begin(), start.end() - 1 );
+    rec.resize( (size_t)n * 4 );
+    for( int32_t i = 0; i < n; ++i ) { const size_t s = cur[id[i]]++; std::memcpy( &rec[4 * s], &pts[3 * (size_t)i], 12 ); std::memcpy( &rec[4 * s + 3], &i, 4 ); }
+  }
+  // the reference's traversal for one query (q: 3 floats; a 2-D grid's queries carry z = 0, like its points)
+  size_t search( const float* q, size_t k, float* out_d2, int32_t* out_idx ) const
+  {
+    const float px = q[0] - min_pt[0], py = q[1] - min_pt[1], pz = q[2] - min_pt[2];           // pt_prime (:1350-1361)
+    auto base = []( float v, double inv, int64_t dim ) { double t = (double)v * inv; if( !( t >= 0.0 ) ) t = 0.0; if( t > (double)( dim - 1 ) ) t = (double)( dim - 1 ); return (int64_t)t; };
+    const int64_t ix = base( px, inv_cell, w ), iy = base( py, inv_cell, h ), iz = base( pz, inv_cell, d );      // :1363-1365 (clamped: see above)
+    const float cs = (float)cell;                                                                                   // `float cs = hg->cell_size` (:1312)
+    thread_local std::vector<std::pair<float, int32_t>> kept;
+    thread_local std::vector<int64_t> bins;
+    kept.clear();
+    float max_dist = 0.0f;      // the k-th distance so far (valid once kept.size() >= k)
+    bool should_break = false;
+    const int64_t last_layer = std::max( w, std::max( h, d ) );
+    for( int64_t layer = 0; layer <= last_layer; ++layer )
+    {
+      bins.clear();
+      for( int64_t oz = -layer; oz <= layer; ++oz )
+      {
+        const int64_t cz = iz + oz;
+        if( cz < 0 || cz >= d ) continue;
+        float ddz; if( oz < 0 ) ddz = pz - ( cz + 1 ) * cs; else if( oz > 0 ) ddz = cz * cs - pz; else ddz = 0.0f;                 // :1378-1380
+        for( int64_t oy = -layer; oy <= layer; ++oy )
+        {
+          const int64_t cy = iy + oy;
+          if( cy < 0 || cy >= h ) continue;
+          float ddy; if( oy < 0 ) ddy = py - ( cy + 1 ) * cs; else if( oy > 0 ) ddy = cy * cs - py; else ddy = 0.0f;               // :1388-1390
+          const int64_t inc_x = ( std::llabs( oy ) != layer && std::llabs( oz ) != layer ) ? 2 * layer : 1;                          // :1392-1393 (the shell's faces only)
+          for( int64_t ox = -layer; ox <= layer; ox += inc_x )
+          {
+            const int64_t cx = ix + ox;
+            if( cx < 0 || cx >= w ) continue;
+            float ddx; if( ox < 0 ) ddx = px - ( cx + 1 ) * cs; else if( ox > 0 ) ddx = cx * cs - px; else ddx = 0.0f;             // :1400-1402
+            const float dist_sq = ddz * ddz + ddy * ddy + ddx * ddx;                                                                // :1404
+            if( kept.size() >= k && dist_sq > max_dist ) continue;                                                                  // :1406-1407
+            bins.push_back( ( cz * h + cy ) * w + cx );
+          }
+        }
+      }
+      for( int64_t b : bins )
+        for( uint32_t s = start[(size_t)b]; s < start[(size_t)b + 1]; ++s )
+        {
+          const float* p = &rec[4 * (size_t)s];
+          const float vx = p[0] - q[0], vy = p[1] - q[1], vz = p[2] - q[2];                                                         // :1278-1287
+          int32_t i; std::memcpy( &i, p + 3, 4 );
+          kept.emplace_back( vx * vx + vy * vy + vz * vz, i );
+        }
+      if( kept.size() > k ) { std::nth_element( kept.begin(), kept.begin() + (ptrdiff_t)k, kept.end() ); kept.resize( k ); }   // the heap of the k nearest (:797-824)
+      if( kept.size() >= k ) { max_dist = 0.0f; for( const auto& e : kept ) max_dist = std::max( max_dist, e.first ); }
+      if( should_break ) break;                                                                                                      // :1428-1429: one more shell after k were stored
+      if( kept.size() >= k ) should_break = true;
+    }
+    std::sort( kept.begin(), kept.end() );
+    for( size_t t = 0; t < kept.size(); ++t ) { out_d2[t] = kept[t].first; out_idx[t] = kept[t].second; }
+    return kept.size();
+  }
+};
+
 struct GridHandle
 {
   const float* src = nullptr;         // the array the grid was built on (identity only: never dereferenced after init)
   HostGrid host;
   rs_hip_cloud_t* dev = nullptr;      // built at the first batched search
   bool dev_failed = false;
+  int dim = 3;                        // 2: msh_hash_grid_init_2d — points and queries are (x, y), kept as (x, y, 0)
+  float radius = 0.0f;                // as given to init (the k-NN grid's geometry)
+  std::unique_ptr<KnnGrid> knn;       // built at the first msh_hash_grid_knn_search
   std::mutex mutex;
 };
 
@@ -366,21 +473,35 @@ void rsd_cache_invalidate( const void* host_array ) { invalidate_pointer( host_a
 
 // ---- msh_hash_grid ------------------------------------------------------------------------
 
-void msh_hash_grid_init_3d( rsd_hash_grid_t* hg, const float* pts, const int32_t n_pts, const float radius )
+static void hash_grid_init( rsd_hash_grid_t* hg, const float* pts, const int32_t n_pts, const float radius, int dim );
+void msh_hash_grid_init_3d( rsd_hash_grid_t* hg, const float* pts, const int32_t n_pts, const float radius ) { hash_grid_init( hg, pts, n_pts, radius, 3 ); }
+// msh_hash_grid.h:544-548: points are (x, y) pairs; the reference keeps them as (x, y, 0) in the same structure, and so does the shim
+void msh_hash_grid_init_2d( rsd_hash_grid_t* hg, const float* pts, const int32_t n_pts, const float radius ) { hash_grid_init( hg, pts, n_pts, radius, 2 ); }
+
+static void hash_grid_init( rsd_hash_grid_t* hg, const float* pts, const int32_t n_pts, const float radius, int dim )
 {
   // cell = 2*radius like the reference (msh_hash_grid.h:443); a non-positive radius asks the
   // reference for an extent-derived cell (:444) — any positive cell gives the same results here.
   const float cell = radius > 0.0f ? 2.0f * radius : 0.1f;
   hg->bin_table = nullptr; hg->offsets = nullptr; hg->data_buffer = nullptr;
   hg->cell_size = cell; hg->_inv_cell_size = 1.0 / cell;
-  hg->_pts_dim = 3; hg->_num_threads = 1; hg->_n_pts = (size_t)( n_pts > 0 ? n_pts : 0 );
+  hg->_pts_dim = (uint8_t)dim; hg->_num_threads = 1; hg->_n_pts = (size_t)( n_pts > 0 ? n_pts : 0 );
   // No HIP device: no grid (there is no CPU fallback; every search on it returns 0 neighbours).  RS_DROPIN_INIT_WITHOUT_DEVICE=1
   // is for tests of the failure path on a machine without a GPU: the grid is initialised, and every batched search then
   // fails on the device side exactly as after a runtime error.
   if( rs_hip_synchronize() != RS_HIP_OK && !getenv( "RS_DROPIN_INIT_WITHOUT_DEVICE" ) ) { complain( "msh_hash_grid_init_3d" ); return; }
   GridHandle* h = new GridHandle();
-  h->src = pts;
-  { Timed t( 0, (unsigned long long)( n_pts > 0 ? n_pts : 0 ) ); h->host.build( pts, n_pts, cell ); }
+  h->src = pts; h->dim = dim; h->radius = radius;
+  {
+    Timed t( 0, (unsigned long long)( n_pts > 0 ? n_pts : 0 ) );
+    if( dim == 2 )
+    {
+      std::vector<float> p3( (size_t)( n_pts > 0 ? n_pts : 0 ) * 3 );
+      for( int32_t i = 0; i < n_pts; ++i ) { p3[3 * (size_t)i] = pts[2 * (size_t)i]; p3[3 * (size_t)i + 1] = pts[2 * (size_t)i + 1]; p3[3 * (size_t)i + 2] = 0.0f; }
+      h->host.build( p3.data(), n_pts, cell );
+    }
+    else h->host.build( pts, n_pts, cell );
+  }
   hg->data_buffer = h;
   hg->width = (size_t)h->host.dims[0]; hg->height = (size_t)h->host.dims[1]; hg->depth = (size_t)h->host.dims[2];
 }
@@ -413,6 +534,7 @@ static size_t host_search_all( const GridHandle* h, rsd_search_desc_t* d )
   return total;
 }
 
+static size_t radius_search_3d( GridHandle* h, rsd_search_desc_t* d );
 size_t msh_hash_grid_radius_search( const rsd_hash_grid_t* hg, rsd_search_desc_t* d )
 {
   if( !hg || !d || !d->query_pts || !d->distances_sq || !d->indices || d->max_n_neigh == 0 ) return 0;
@@ -424,6 +546,19 @@ size_t msh_hash_grid_radius_search( const rsd_hash_grid_t* hg, rsd_search_desc_t
     return 0;
   }
   GridHandle* h = (GridHandle*)hg->data_buffer;
+  if( h->dim == 2 )
+  {
+    // (x, y) queries of a 2-D grid (msh_hash_grid_init_2d): the same search on (x, y, 0), like the reference's own (:1150-1162)
+    std::vector<float> q3( d->n_query_pts * 3 );
+    for( size_t i = 0; i < d->n_query_pts; ++i ) { q3[3 * i] = d->query_pts[2 * i]; q3[3 * i + 1] = d->query_pts[2 * i + 1]; q3[3 * i + 2] = 0.0f; }
+    rsd_search_desc_t d3 = *d; d3.query_pts = q3.data();
+    return radius_search_3d( h, &d3 );
+  }
+  return radius_search_3d( h, d );
+}
+
+static size_t radius_search_3d( GridHandle* h, rsd_search_desc_t* d )
+{
   const size_t host_queries = getenv( "RS_DROPIN_HOST_QUERIES" ) ? (size_t)atoll( getenv( "RS_DROPIN_HOST_QUERIES" ) ) : 4;      // (read per call: tests switch it)
   if( d->n_query_pts <= host_queries )
   {
@@ -449,6 +584,32 @@ size_t msh_hash_grid_radius_search( const rsd_hash_grid_t* hg, rsd_search_desc_t
                      "from the grid's host copy (slow).  rsd_device_failures() counts them.\n" );
   Timed t( 2, d->n_query_pts );
   return host_search_all( h, d );
+}
+
+// msh_hash_grid.h:1294-1447 — see KnnGrid.  Host code: no caller of the hot path uses it; rows ascending in (dist², index).
+size_t msh_hash_grid_knn_search( const rsd_hash_grid_t* hg, rsd_search_desc_t* d )
+{
+  if( !hg || !d || !d->query_pts || !d->distances_sq || !d->indices || d->k == 0 ) return 0;
+  if( !hg->data_buffer )
+  {
+    if( d->n_neighbors ) for( size_t i = 0; i < d->n_query_pts; ++i ) d->n_neighbors[i] = 0;
+    return 0;
+  }
+  GridHandle* h = (GridHandle*)hg->data_buffer;
+  {
+    std::lock_guard<std::mutex> lock( h->mutex );
+    if( !h->knn ) { h->knn.reset( new KnnGrid() ); h->knn->build( h->host, h->radius ); }
+  }
+  Timed t( 2, d->n_query_pts );
+  size_t total = 0;
+  for( size_t i = 0; i < d->n_query_pts; ++i )
+  {
+    float q[3] = { d->query_pts[(size_t)h->dim * i], d->query_pts[(size_t)h->dim * i + 1], h->dim == 3 ? d->query_pts[3 * i + 2] : 0.0f };
+    const size_t c = h->knn->search( q, d->k, d->distances_sq + i * d->k, d->indices + i * d->k );
+    if( d->n_neighbors ) d->n_neighbors[i] = c;
+    total += c;
+  }
+  return total;
 }
 
 // ---- icp ----------------------------------------------------------------------------------

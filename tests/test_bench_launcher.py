@@ -42,3 +42,16 @@ def test_launcher_hands_on_a_failing_rank():
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2"], capture_output=True, text=True, env=_env(RS_BENCH_LAUNCH_SELFTEST="fail1"), timeout=300)
     assert r.returncode == 3, (r.returncode, r.stderr)
     assert "rank 1 exited with 3" in r.stderr
+
+
+def test_launcher_ends_ranks_blocked_in_a_collective():
+    """Round 6: a rank that dies AFTER the group has formed, while the others are blocked inside the next collective (the failure mode
+    of a multi-GPU run: an out-of-memory or a fault on one rank mid-step): the launcher notices, stops the blocked ranks by PID —
+    SIGTERM, SIGKILL after 5 s — and returns the dead rank's exit code.  No hang: the whole thing ends well inside the timeout."""
+    import time
+    t = time.time()
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2"], capture_output=True, text=True, env=_env(RS_BENCH_LAUNCH_SELFTEST="die1"), timeout=240)
+    assert r.returncode == 5, (r.returncode, r.stderr[-600:])
+    assert "rank 1 exited with 5" in r.stderr
+    assert time.time() - t < 120
+    assert not [l for l in r.stdout.strip().splitlines() if l.startswith("{")]      # no result line from a run that failed
