@@ -161,6 +161,50 @@ def test_headline_sharded_route_is_bit_identical(capi, bench_mod, headline):
         assert (labels == lab0["labels"]).all() and (mind == lab0["min_dists"]).all(), f"world {world}: labels"
 
 
+@pytest.mark.parametrize("n_ranks", [2, 4, 8])
+def test_weak_scaling_unit_lists_vs_reference(capi, bench_mod, n_ranks):
+    """Round 6 (missing 1a): what bench.py --gpus N computes at N > 1 under weak scaling — N ICP start poses, 256 N score
+    poses, 8 N placements of the one scene — against the reference build's results for exactly those unit lists
+    (tests/golden/bench_seed11_units.npz, oracle/gen_golden_bench.py --units): through the sharded route with the N ranks simulated
+    on this device (every rank's send buffer computed in turn, concatenated as the all-gather would, the (min_dist, label) partials
+    folded in rank order) AND through bench.parity_block, the function the bench line's `parity` comes from.  Every pose within
+    1e-4 (measured ~1e-6), every score within 2e-6, labels / min_dists of the whole 8 N-placement arrangement bit for bit."""
+    import torch
+    from rescan_amd import dist as rd
+    g = load_golden("bench_seed11_units.npz")
+    w = bench_mod.build_workload(1_000_000, seed=11, knn="hash", units=n_ranks)
+    try:
+        assert [sha(w["s0"]["points"]), sha(w["s1"]["points"])] == [str(x) for x in g["in_sha"][:2]]
+        assert np.array_equal(w["icp_T0s"], g["icp_T0s"][:n_ranks])
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        n_plc = len(w["plc"])
+        assert n_plc == 8 * n_ranks
+        order, _, radii = rd.arrangement_plan([0] * n_plc, [p["cls"] for p in w["plc"]], 0.05)
+        assert (np.asarray(order) == g["order_u%d" % n_ranks]).all()
+        units = dict(icp=(w["scan1"], w["scan0"], w["icp_T0s"], 0.10, np.deg2rad(60.0), bench_mod.ICP_ITERS),
+                     score=(w["obj_score"], w["scan1"], w["score_poses"], 0.1, 64),
+                     label=(w["scan1"], w["plc_poses"][order], [w["plc"][i]["cloud"] for i in order], radii))
+        lay = rd.ShardLayout(n_ranks, n_ranks, len(w["score_poses"]), n_plc, w["n_scan1"], prefold=True)
+        recv = torch.zeros(n_ranks * lay.words, dtype=torch.float32, device=dev)
+        for rank in range(n_ranks):
+            send = recv[rank * lay.words:(rank + 1) * lay.words]
+            small = torch.zeros(lay.small_words, dtype=torch.float32)
+            rd.shard_compute(capi, lay, rank, units, send, small)
+            rd.shard_publish(lay, send, small)
+        torch.cuda.synchronize()
+        errs, Ts, its, scores, labels, mind = rd.shard_fold(capi, lay, recv, scene=w["scan1"])
+        d = np.linalg.norm(Ts.astype(np.float64).reshape(-1, 16) - g["icp_pose"][:n_ranks].astype(np.float64).reshape(-1, 16), axis=1)
+        print(f"N = {n_ranks}: pose distances {d.tolist()}, scores max abs {np.abs(scores.astype(np.float64) - g['scores'][:256 * n_ranks]).max():.2e}")
+        assert (d < POSE_TOL).all() and (its == bench_mod.ICP_ITERS).all()
+        assert np.abs(scores.astype(np.float64) - g["scores"][:256 * n_ranks].astype(np.float64)).max() < SCORE_TOL
+        assert sha(labels) == str(g["labels_sha_u%d" % n_ranks]) and sha(mind) == str(g["min_dists_sha_u%d" % n_ranks])
+        blk = bench_mod.parity_block(dict(err=errs[0], T=Ts[0], scores=scores, labels=labels, min_dists=mind, Ts=Ts, errs=errs), 1_000_000, 11, "hash", n_ranks)
+        assert blk["label_mismatches"] == 0 and blk["min_dists_identical"] and blk["pose_dist_all_units"] < POSE_TOL and blk["score_max_abs_err_all_units"] < SCORE_TOL, blk
+    finally:
+        _close_workload(w)
+
+
 def test_brute_tile_step_vs_reference(capi, bench_mod):
     """BASELINE.json configs[1] names the brute-tile k-NN: one full-size step with every target — both scans and the eight placed
     models — stored as ONE cell (bench.py --knn brute; every tile streams the whole target through LDS: ~3.4 s), against the
@@ -252,8 +296,10 @@ MORE_SEEDS = list(range(31, 39))
 
 
 def _close_workload(w):
-    for c in [w["scan0"], w["scan1"], w["obj_score"]] + [p["cloud"] for p in w["plc"]]:
-        c.close()
+    seen = set()
+    for c in [w["scan0"], w["scan1"], w["obj_score"]] + [p["cloud"] for p in w["plc"]]:      # (units > 1: further placements share their model's cloud)
+        if id(c) not in seen:
+            seen.add(id(c)); c.close()
 
 
 @pytest.mark.parametrize("seed", MORE_SEEDS)
