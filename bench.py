@@ -649,6 +649,8 @@ def dropin_block(w):
     labels = np.zeros(w["n_scan1"], np.int8); order = np.zeros(len(plc), np.int32)
 
     def step():
+        if os.environ.get("RS_BENCH_MARK"):
+            capi.profile_marker()                   # (a kernel trace of this block: tools/profile.sh trace_dropin)
         T = Mat4(); T.data[:] = [float(x) for x in w["icp_T0"]]
         t = [time.perf_counter()]
         lib.icp_align(s1["points"].ctypes.data, s1["normals"].ctypes.data, len(s1["points"]), s0["points"].ctypes.data, s0["normals"].ctypes.data,
@@ -825,6 +827,9 @@ def main():
     ap.add_argument("--knn", choices=["hash", "brute"], default="hash",
                     help="candidate layout: LDS spatial-hash cells (default) or one brute tile")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="only the warm-up and the timed steps: no serial re-timing, no drop-in block afterwards (profiling runs: "
+                    "every kernel the process launches after its clouds are built then belongs to a step; RS_BENCH_MARK=1 starts each step with the "
+                    "library's marker kernel)")
     ap.add_argument("--serial", action="store_true", help="issue the three consumers one after another")
     ap.add_argument("--shard", action="store_true", help="the sharded route (default for --gpus > 1) also at N = 1")
     ap.add_argument("--replicas", action="store_true", help="--gpus > 1: every rank its own scene (configs[4]) instead of one sharded scene")
@@ -932,9 +937,13 @@ def main():
     last_of = {}           # ... and of every pair (each has its fixture: tests/golden/bench_seed11[_t<k>].npz)
     in_flight = []         # sharded route: pair whose exchange is under way
 
+    mark_steps = bool(os.environ.get("RS_BENCH_MARK"))
+
     def one_step():
         """One pass over the sequence: every consecutive pair of scans in turn (one pair at --timesteps 2)."""
         nonlocal last
+        if mark_steps:
+            capi.profile_marker()                   # (rs::k_step_marker: where this step begins in a rocprofv3 kernel trace)
         for k in range(n_pairs):
             if SH is not None:
                 r = SH[k].step(conc)                # (returns the results of the exchange that was in flight: the pair before)
@@ -1103,7 +1112,7 @@ def main():
         line["candidate_evals"] = {"per_step": cand * 64 / args.steps, "per_s": cand * 64 / elapsed,
                                    "candidates_staged_per_step": cand / args.steps,
                                    "per_point_pair": cand * 64 / args.steps / max(1, pairs_unit)}
-        if world == 1 and not sharded:
+        if world == 1 and not sharded and not args.no_extras:
             # outside the timed region: the same step with the consumers issued one after the other, and through the drop-in boundary
             try:
                 capi.profile_enable(False)

@@ -56,6 +56,8 @@ const char* rs_hip_version( void );
 int         rs_hip_profile_enable( int on );
 int         rs_hip_profile_reset( void );
 int         rs_hip_profile_read( const char* name, int64_t* launches, double* total_ms );
+/* A named no-op kernel (rs::k_step_marker) on the calling thread's stream: marks where a caller's unit of work begins in a kernel trace. */
+int         rs_hip_profile_marker( void );
 
 /* ---- device-resident clouds -------------------------------------------------------- */
 
@@ -115,7 +117,7 @@ int rs_hip_icp_align_traced( const rs_hip_cloud_t* source, const rs_hip_cloud_t*
 /* The estimator step (icp.h:136-148,210-298,393-402), by source size (round 6; priced against the bar on every reference fixture:
  * profiles/r06/estimator_policy.txt).  Sources of at most `n_points` points use the reference's own accumulation order and
  * precisions (one sequential fp32 chain per accumulator): poses, errors and iteration counts are bit-identical to the
- * reference's.  Default 4096 (environment RS_HIP_REF_ORDER_BELOW); 65536 covers every icp_align call site of the reference — at
+ * reference's.  Default 16384 — every level-2 object of the reference's call sites — (environment RS_HIP_REF_ORDER_BELOW); 65536 covers all of them, at
  * 520 instead of 110 us per iteration on a 50 k-point source.  Larger sources: see rs_hip_icp_replay_below (opt-in),
  * rs_hip_icp_lane_chains_below (default up to 65536 points), beyond that the grid chains — all three centre the step on the
  * reference's own fp32 centroid sums, bit for bit, and differ from it only where it rounds the 33 accumulators of the normal
@@ -141,6 +143,13 @@ int32_t rs_hip_icp_replay_redone( void );
  * changes, ties, sums that hover around zero). */
 int32_t rs_hip_icp_lane_chains_below( int32_t n_points );
 int64_t rs_hip_icp_lane_chains_sequential( void );
+/* The stop test's guard (round 6).  The estimators above that are not the reference's own order follow its per-iteration errors to
+ * 1e-8 ... 6e-7; icp_align's stop test |err - prev_err| < 1e-5 (icp.h:489) decided by less than that can fall the other way (one
+ * iteration more or less: 1e-4 in the pose).  A problem whose decisive difference comes within 1.5e-6 of the threshold (environment
+ * RS_HIP_STOP_GUARD, 0 = off) is run AGAIN in the reference's own order — its bits — where one exists (sources up to 262144 points).
+ * Returns how many problems were, since rs_hip_init. */
+int64_t rs_hip_icp_stop_guard_redone( void );
+float   rs_hip_icp_stop_guard( float guard );      /* sets the guard's width (0: off); < 0 only reads; returns the previous width */
 /* The sequential estimator (sources up to rs_hip_icp_reference_order_below) runs the reference's dist² statistics and its weighted
  * centroids in ONE pass, the 2.5 sigma cut of the weights (lib/rs/icp.h:396-401) taken at a guess of sigma; the pass stands when no
  * dist² lies between the guessed and the real cut, else the centroids are summed again.  Iterations that had to, over every calling

@@ -26,14 +26,17 @@ I4 = np.eye(4, dtype=np.float32).ravel()
 MODES = (0, 1, 2, 3)
 
 
-def variant(O, p1, n1, p2, n2, T0, T2, md, ma, n_iters, stop, mode):
+def variant(O, p1, n1, p2, n2, T0, T2, md, ma, n_iters, stop, mode, errs=False):
     f = O.lib.orc_icp_iterate_variant
     f.restype = C.c_float
     f.argtypes = [f32p, f32p, C.c_int32, f32p, f32p, C.c_int32, f32p, f32p, C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_int32,
-                  C.POINTER(C.c_int32)]
+                  C.POINTER(C.c_int32), f32p]
     c = lambda a: np.ascontiguousarray(a, np.float32)  # noqa: E731
     T = c(T0).ravel().copy(); it = C.c_int32()
-    e = f(c(p1), c(n1), len(p1), c(p2), c(n2), len(p2), T, c(T2).ravel(), float(md), float(ma), int(n_iters), int(stop), int(mode), C.byref(it))
+    eo = np.zeros(max(1, int(n_iters)), np.float32)
+    e = f(c(p1), c(n1), len(p1), c(p2), c(n2), len(p2), T, c(T2).ravel(), float(md), float(ma), int(n_iters), int(stop), int(mode), C.byref(it), eo)
+    if errs:
+        return np.float32(e), T, it.value, eo[:it.value]
     return np.float32(e), T, it.value
 
 

@@ -838,11 +838,42 @@ float orc_icp_align( const float* pts1, const float* nor1, int32_t n1,
  *           blocks and the right-hand side summed EXACTLY (fp64) over the reference's own fp32 addends
  *   mode 2  as 1, the cut from statistics summed exactly (what the searches' integer accumulators give on the GPU)
  *   mode 3  as 2, the centroids from fp64 sums as well (rounded to float): nothing of the reference's rounding drift is left
+ *   mode 4  as 2, but each of the seven centroid chains adds in fp64 WHILE |s| < 2^14 ("hovering": VERDICT r05 item 4 — the stretches
+ *           in which a sum that wanders around zero keeps changing binade) and as the reference's fp32 chain elsewhere; the rigorous bound
+ *           on what that changes, the sum of ulp( s ) / 2 over the addends met while hovering, is reported through orc_hover_bound
  * ---------------------------------------------------------------------------------------- */
+static double g_hover_bound[7];      /* last estimate_variant( mode 4 ) call: per chain, sum of half-ulps over the hovering addends */
+static double g_hover_total_w;
+void orc_hover_bound( double out[8] ) { for( int k = 0; k < 7; ++k ) { out[k] = g_hover_bound[k]; } out[7] = g_hover_total_w; }
+static float hover_chain( const float* v, const float* w, int32_t n, int stride, int with_v, int chain )
+{
+  /* the chain  s <- RN( s + x ),  x = w[i] or v[stride i] * w[i]  (fp32 product, icp.h:141-142), in fp32 — except that while |s| < 2^14 the
+     running value is kept in fp64 (exact sums of the same fp32 addends) and rounded to fp32 only when it leaves that range */
+  float s = 0.0f; double acc = 0.0; int hovering = 1; double bound = 0.0;
+  for( int32_t i = 0; i < n; ++i )
+  {
+    const float x = with_v ? v[(size_t)stride * i] * w[i] : w[i];
+    if( hovering )
+    {
+      const float sf = (float)acc;
+      bound += 0.5 * (double)( nextafterf( fabsf( sf ), INFINITY ) - fabsf( sf ) );
+      acc += (double)x;
+      if( fabs( acc ) >= 16384.0 ) { s = (float)acc; hovering = 0; }
+    }
+    else
+    {
+      s = s + x;
+      if( fabsf( s ) < 16384.0f ) { acc = (double)s; hovering = 1; }
+    }
+  }
+  g_hover_bound[chain] = bound;
+  return hovering ? (float)acc : s;
+}
+
 static float estimate_variant( const float* p1, const float* p2, const float* n2, const float* w, int32_t n, float* T1, int mode )
 {
   v3 c1, c2;
-  if( mode >= 3 )
+  if( mode == 3 )
   {
     double t = 0.0, a[6] = {0};
     for( int32_t i = 0; i < n; ++i )
@@ -854,6 +885,14 @@ static float estimate_variant( const float* p1, const float* p2, const float* n2
     float inv = 1.0f / (float)t;
     c1 = v3_make( (float)a[0] * inv, (float)a[1] * inv, (float)a[2] * inv );
     c2 = v3_make( (float)a[3] * inv, (float)a[4] * inv, (float)a[5] * inv );
+  }
+  else if( mode == 4 )
+  {
+    const float t = hover_chain( NULL, w, n, 0, 0, 0 );
+    const float inv = 1.0f / t;
+    g_hover_total_w = t;
+    c1 = v3_make( hover_chain( p1, w, n, 3, 1, 1 ) * inv, hover_chain( p1 + 1, w, n, 3, 1, 2 ) * inv, hover_chain( p1 + 2, w, n, 3, 1, 3 ) * inv );
+    c2 = v3_make( hover_chain( p2, w, n, 3, 1, 4 ) * inv, hover_chain( p2 + 1, w, n, 3, 1, 5 ) * inv, hover_chain( p2 + 2, w, n, 3, 1, 6 ) * inv );
   }
   else { c1 = weighted_centroid( p1, w, n ); c2 = weighted_centroid( p2, w, n ); }
   double sum = 0.0, total_weight = 0.0;
@@ -942,7 +981,7 @@ static int32_t find_corrs_variant( const float* pts1, const float* nor1, int32_t
 /* :416-500, n_iters iterations at most, the stop test (:489) optional; returns the last error */
 float orc_icp_iterate_variant( const float* pts1, const float* nor1, int32_t n1, const float* pts2, const float* nor2, int32_t n2,
                                float* T1, const float* T2, float max_dist, float max_angle, int32_t n_iters, int32_t stop_test,
-                               int32_t mode, int32_t* iters_done )
+                               int32_t mode, int32_t* iters_done, float* errs_out /* n_iters floats or NULL: the error after every iteration */ )
 {
   orc_grid_t* index2 = orc_grid_create( pts2, n2, max_dist );
   size_t cap = (size_t)( n1 > 0 ? n1 : 1 );
@@ -961,6 +1000,7 @@ float orc_icp_iterate_variant( const float* pts1, const float* nor1, int32_t n1,
     for( int32_t j = 0; j < nc; ++j ) { total_weight += cw[j]; }
     if( total_weight <= 1e-7 ) { break; }
     err = mode == 0 ? orc_icp_estimate_pt2pl( cp1, cp2, cn2, cw, nc, T1 ) : estimate_variant( cp1, cp2, cn2, cw, nc, T1, mode );
+    if( errs_out ) { errs_out[i] = err; }
     float delta = fabsf( prev_err - err );
     if( stop_test && i > 5 && delta < 1e-5 ) { break; }
     double nd = max_dist * 0.95;

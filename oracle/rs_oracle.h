@@ -71,10 +71,11 @@ int32_t orc_icp_find_corrs( const float* pts1, const float* nor1, int32_t n1,
 /* lib/rs/icp.h:210-298 */
 float orc_icp_estimate_pt2pl( const float* p1, const float* p2, const float* n2, const float* w,
                               int32_t n, float* T1 );
+void orc_hover_bound( double out[8] );   /* mode 4's last estimator call: per centroid chain the sum of half-ulps over its hovering addends; [7] = the weight total */
 /* WHAT-IF estimators (rs_oracle.c): icp_align's loop with the estimator's accumulators swapped (mode 0 = the reference's own) */
 float orc_icp_iterate_variant( const float* pts1, const float* nor1, int32_t n1, const float* pts2, const float* nor2, int32_t n2,
                                float* T1, const float* T2, float max_dist, float max_angle, int32_t n_iters, int32_t stop_test,
-                               int32_t mode, int32_t* iters_done );
+                               int32_t mode, int32_t* iters_done, float* errs_out );
 /* lib/rs/icp.h:416-500; n_iters (optional) receives the number of find_corrs calls made */
 float orc_icp_align( const float* pts1, const float* nor1, int32_t n1,
                      const float* pts2, const float* nor2, int32_t n2,

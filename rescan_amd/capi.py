@@ -31,6 +31,7 @@ SIGNATURES = {
     "rs_hip_profile_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "rs_hip_cloud_create": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_int32, C.c_float]),
     "rs_hip_cloud_destroy": (None, [C.c_void_p]),
+    "rs_hip_profile_marker": (C.c_int, []),
     "rs_hip_cloud_size": (C.c_int32, [C.c_void_p]),
     "rs_hip_cloud_bytes": (C.c_int64, [C.c_void_p]),
     "rs_hip_cloud_build_seconds": (C.c_int64, [C.POINTER(C.c_double), C.c_int32]),
@@ -44,6 +45,8 @@ SIGNATURES = {
     "rs_hip_icp_replay_below": (C.c_int32, [C.c_int32]),
     "rs_hip_icp_lane_chains_below": (C.c_int32, [C.c_int32]),
     "rs_hip_icp_lane_chains_sequential": (C.c_int64, []),
+    "rs_hip_icp_stop_guard_redone": (C.c_int64, []),
+    "rs_hip_icp_stop_guard": (C.c_float, [C.c_float]),
     "rs_hip_icp_replay_redone": (C.c_int32, []),
     "rs_hip_icp_faith_redone": (C.c_int32, []),
     "rs_hip_icp_faith_guess": (C.c_int32, [C.c_int32]),
@@ -238,6 +241,11 @@ def radius_search(target, query, radius, k):
     return d, i, nn.astype(np.int64), tot.value
 
 
+def profile_marker():
+    """A named no-op kernel on the calling thread's stream (marks a step's start in a rocprofv3 kernel trace)."""
+    _check(load().rs_hip_profile_marker())
+
+
 def cloud_build_seconds(reset=False):
     """(diagnostics) seconds spent building clouds since the last reset: (host copy, upload + bounds, cell index, Hilbert order + tiles), clouds counted."""
     out = (C.c_double * 4)()
@@ -266,6 +274,16 @@ def icp_lane_chains_below(n_points=-1):
 def icp_lane_chains_sequential():
     """(diagnostics) addends the lane chains have added one by one in fp32 since init."""
     return int(load().rs_hip_icp_lane_chains_sequential())
+
+
+def icp_stop_guard_redone():
+    """(diagnostics) problems run again in the reference's order because a stop test was decided inside the guard, since init."""
+    return int(load().rs_hip_icp_stop_guard_redone())
+
+
+def icp_stop_guard(guard=-1.0):
+    """Width of the stop test's guard (0: off; default 1.5e-6); < 0 only reads.  Returns the previous width."""
+    return float(load().rs_hip_icp_stop_guard(float(guard)))
 
 
 def icp_exact_centroids(on=-1):

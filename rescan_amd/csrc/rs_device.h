@@ -114,7 +114,8 @@ struct IcpLaunch
   float*  err;          // n_prob: last RMS error (icp.h:253)
   float*  prev_err;     // n_prob
   int*    queued;       // n_prob: tiles phase A handed off in the last iteration (host heuristics, diagnostics)
-  int*    ticket;       // (unused, kept zero)
+  int*    ticket;       // n_prob (of 2 n_prob words, zero at the start of a call): [prob] = 1 when a stop test of the problem came within stop_guard of its threshold
+  float   stop_guard;   // (0: off) estimators that are not the reference's own order flag a problem whose |delta err| passes within this of 1e-5 (icp.h:489): the host runs it again in reference order
   int     warm;         // m_slot holds last iteration's matches: use them as starting candidates
   int     seed;         // (when !warm) start from the best usable point of the query's own cell
   int     bounded_only; // (when warm) phase A only takes tiles whose lanes all start from a candidate; the rest goes straight to the cooperative kernel

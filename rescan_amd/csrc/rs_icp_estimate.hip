@@ -134,6 +134,9 @@ __device__ __forceinline__ void icp_update_tail( const IcpLaunch& L, int prob )
   for( int k = 0; k < 16; ++k ) L.T1[prob * 16 + k] = T.m[k];           // icp.h:295
   L.err[prob] = e;
   const float delta = fabsf( L.prev_err[prob] - e );
+  // (an estimator that is not the reference's own order follows the reference's errors to ~1e-7; a stop test decided by less than
+  //  that margin may fall the other way — one iteration more or less, 1e-4 in the pose.  Such a problem is flagged: rs_api.hip)
+  if( !L.fixed_iters && L.iter_index > 5 && L.stop_guard > 0.0f && fabsf( delta - 1e-5f ) < L.stop_guard ) L.ticket[prob] = 1;
   if( !L.fixed_iters && L.iter_index > 5 && delta < 1e-5 ) L.active[prob] = 0;   // icp.h:489
 }
 

@@ -31,19 +31,26 @@ I4 = np.eye(4, dtype=np.float32).ravel()
 BIG = 1 << 30
 EST = [("(i) sequential bits", dict(ro=BIG, rp=0, ln=0, ec=1)), ("(i') replay", dict(ro=0, rp=BIG, ln=0, ec=1)),
        ("(ii-l) lane chains", dict(ro=0, rp=0, ln=BIG, ec=1)), ("(ii-g) grid chains", dict(ro=0, rp=0, ln=0, ec=1)),
-       ("(iii) fp64 moments", dict(ro=0, rp=0, ln=0, ec=0))]
+       ("(iii) fp64 moments", dict(ro=0, rp=0, ln=0, ec=0)),
+       # what ships: the thresholds as they are, the stop test's guard on (a problem decided within 1.5e-6 of the threshold runs again in reference order)
+       ("DEFAULT policy", dict(ro=None, rp=None, ln=None, ec=1, guard=None))]
+DEFAULTS = {}
 
 
 def configure(c):
-    capi.icp_reference_order_below(c["ro"]); capi.icp_replay_below(c["rp"]); capi.icp_lane_chains_below(c["ln"]); capi.icp_exact_centroids(c["ec"])
+    capi.icp_reference_order_below(c["ro"] if c["ro"] is not None else DEFAULTS["ro"]); capi.icp_replay_below(c["rp"] if c["rp"] is not None else DEFAULTS["rp"])
+    capi.icp_lane_chains_below(c["ln"] if c["ln"] is not None else DEFAULTS["ln"]); capi.icp_exact_centroids(c["ec"])
+    capi.icp_stop_guard(DEFAULTS["guard"] if "guard" in c else 0.0)      # (the raw estimators: guard off)
 
 
 def main():
     capi.init(0)
     capi.icp_chains_retry_after(0)
     prev = (capi.icp_reference_order_below(-1), capi.icp_replay_below(-1), capi.icp_lane_chains_below(-1), capi.icp_exact_centroids(-1))
+    DEFAULTS.update(ro=prev[0], rp=prev[1], ln=prev[2], guard=capi.icp_stop_guard(-1.0))
+    print(f"# defaults: reference order <= {prev[0]} points, replay <= {prev[1]}, lane chains <= {prev[2]}, grid chains above; stop-test guard {DEFAULTS['guard']:g}")
     print("# estimator policy for object-sized sources: pose distance from the REFERENCE's pose | iterations (== reference?) | us per iteration")
-    print("# " + " | ".join(name for name, _ in EST))
+    print("# columns: " + " | ".join(name for name, _ in EST))
     summary = {name: dict(worst=0.0, it_diff=0, us=[], bits=0) for name, _ in EST}
     n_cases = 0
 
@@ -82,7 +89,7 @@ def main():
             max_iter=bench.ICP_ITERS, fixed_iters=True)
     # the eight as ONE rs_hip_icp_align_multi call: what bench.py --scaling strong times
     print("# the eight strong_icp units as one rs_hip_icp_align_multi call (ten fixed iterations): ms per call, worst pose distance from the reference")
-    for name, c in EST[:1] + EST[2:3]:
+    for name, c in EST[:1] + EST[2:3] + EST[5:]:
         configure(c)
         best = 1e9
         for _ in range(5):
@@ -104,7 +111,8 @@ def main():
     for name, _ in EST:
         S = summary[name]
         print(f"#   {name:22s} {S['worst']:.2e} | {S['it_diff']:2d} | {S['bits']:2d} | {np.median(S['us']):8.1f}")
-    capi.icp_reference_order_below(prev[0]); capi.icp_replay_below(prev[1]); capi.icp_lane_chains_below(prev[2]); capi.icp_exact_centroids(prev[3])
+    print(f"# problems the DEFAULT policy ran again in reference order (stop test inside the guard): {capi.icp_stop_guard_redone()}")
+    capi.icp_reference_order_below(prev[0]); capi.icp_replay_below(prev[1]); capi.icp_lane_chains_below(prev[2]); capi.icp_exact_centroids(prev[3]); capi.icp_stop_guard(DEFAULTS["guard"])
 
 
 if __name__ == "__main__":

@@ -45,9 +45,9 @@ def per_domain(path, counters=None):
             dom = "nn_icp"
             if "coop" not in n:
                 out[dom]["units"] += 1
-        elif any(x in n for x in ("k_icp_moments", "k_icp_update", "k_chain_", "k_replay_", "k_icp_faith")):
+        elif any(x in n for x in ("k_icp_moments", "k_icp_update", "k_chain_", "k_replay_", "k_icp_faith", "k_lane_")):
             dom = "icp_moments"
-            if "k_icp_update" in n or "k_icp_faithful" in n or "k_replay_finish" in n:
+            if "k_icp_update" in n or "k_icp_faithful" in n or "k_replay_finish" in n or "k_lane_walk_and_update" in n:
                 out[dom]["units"] += 1
         elif "k_label" in n:
             dom = "nn_label"
@@ -117,7 +117,7 @@ if __name__ == "__main__":
         def total(names):
             return sum((2 * F[k][0] + W.get(k, (0, 0))[0]) * F[k][1] for k in F if any(n in k for n in names)) * 1024
         # domain -> (kernels that belong to it, kernels whose launches count as ONE unit of it)
-        doms = {"nn_icp": (["k_icp_corr"], ["k_icp_corr<"]), "icp_moments": (["k_icp_moments", "k_icp_update", "k_chain_"], ["k_icp_update"]),       # the estimator: one k_icp_update per iteration (round 3: + the centroid chains' kernels)
+        doms = {"nn_icp": (["k_icp_corr"], ["k_icp_corr<"]), "icp_moments": (["k_icp_moments", "k_icp_update", "k_chain_", "k_lane_"], ["k_icp_update", "k_lane_walk_and_update"]),       # the estimator: one k_icp_update per iteration (round 3: + the centroid chains' kernels)
                 "nn_score": (["k_score"], ["rs::k_score<"]), "nn_label": (["k_label"], ["rs::k_label("])}
         out = {"_note": "HBM-side bytes per launch from rocprofv3 PMC (separate FETCH_SIZE and WRITE_SIZE passes of `bench.py --steps 2 "
                         "--warmup 1 --serial`, tools/profile.sh traffic, folded by tools/pmc_summary.py --fold), FETCH_SIZE doubled as "
@@ -133,21 +133,31 @@ if __name__ == "__main__":
         json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
         print({d: round(out[d] / 1e6, 1) for d in doms}, "MB per launch")
     elif len(sys.argv) > 2 and sys.argv[1] == "--trace":
+        # A rocprofv3 --kernel-trace of `RS_BENCH_MARK=1 python bench.py --serial --no-cpu-baseline --no-extras ...`: every step of the
+        # run starts with the library's marker kernel (rs::k_step_marker) and nothing follows the last timed step, so the rows from
+        # the LAST marker to the end are exactly one step of the timed workload (round 5 took "the last third of the rows", which
+        # landed in the drop-in block that used to follow the timed steps).  Written whole.  `--trace <csv> <out> [all]`: every
+        # marked step, separated (the drop-in trace: tools/profile.sh trace_dropin).
         rows = sorted(csv.DictReader(open(sys.argv[2])), key=lambda r: int(r["Start_Timestamp"]))
         rows = [r for r in rows if "rs::" in r["Kernel_Name"]]
-        # bench.py --steps 2 --warmup 1 --serial with RS_HIP_PROF_EVERY=1000: cloud construction, then three identical steps; show the
-        # LAST one — the first timed step carries the live profile's event records between its kernels (a ~6 us bubble each: what
-        # round 1's trace showed as "launch gaps"), the later ones do not
-        last_build = max([k for k, r in enumerate(rows) if "k_build_" in r["Kernel_Name"]], default=-1)
-        rows = rows[last_build + 1:]
-        n_steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-        start = len(rows) * (n_steps - 1) // n_steps
+        marks = [k for k, r in enumerate(rows) if "k_step_marker" in r["Kernel_Name"]]
+        out_path = sys.argv[3] if len(sys.argv) > 3 else "gpurun_out/trace_last_step.txt"
+        every = len(sys.argv) > 4 and sys.argv[4] == "all"
+        if not marks:
+            sys.exit("no rs::k_step_marker in the trace: run bench.py with RS_BENCH_MARK=1")
+        spans = [(marks[i] + 1, marks[i + 1] if i + 1 < len(marks) else len(rows)) for i in range(len(marks))]
         lines = []
-        for r in rows[start:]:
-            s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-            lines.append(f'{(s - int(rows[start]["Start_Timestamp"])) / 1e3:9.1f} us  +{(e - s) / 1e3:8.1f} us  {r["Kernel_Name"].split("(")[0].replace("void ", "")}')
-        open("gpurun_out/trace_last_step.txt", "w").write("\n".join(lines) + "\n")
-        print("\n".join(lines[:80]))
+        for n, (a, b) in enumerate(spans if every else spans[-1:]):
+            if every:
+                lines.append(f"# marked unit {n}")
+            t0 = int(rows[a]["Start_Timestamp"]) if a < b else 0
+            for r in rows[a:b]:
+                s_, e_ = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+                lines.append(f'{(s_ - t0) / 1e3:9.1f} us  +{(e_ - s_) / 1e3:8.1f} us  {r["Kernel_Name"].split("(")[0].replace("void ", "")}')
+            if a < b:
+                lines.append(f"# {b - a} kernels, first start to last end {(int(rows[b - 1]['End_Timestamp']) - t0) / 1e3:.1f} us")
+        open(out_path, "w").write("\n".join(lines) + "\n")
+        print("\n".join(lines))
     else:
         for k, d in per_kernel(sys.argv[1]).items():
             if k.startswith("rs::"):
