@@ -244,7 +244,6 @@ struct rs_hip_cloud
   GridView view{};
   float4* d_pos = nullptr;
   float4* d_nor = nullptr;
-  float4* d_pn = nullptr;       // {pos, nor} interleaved (GridView::pn), clouds with normals only
   uint32_t* d_cell_start = nullptr;
   // query layout: the same points in Hilbert order, cut into tiles (one wave each)
   QueryView qview{};
@@ -554,11 +553,6 @@ static rs_hip_cloud_t* cloud_create_impl( const float* pos, const float* nor, in
     if( build_exclusive_scan( W.bld_tmp.p, tmp_bytes, c->d_cell_start, c->d_cell_start, n_cells + 1, g_stream ) ) return failrc( "device scan failed" );
     if( build_sort_pairs( W.bld_tmp.p, tmp_bytes, k0, k1, v0, v1, n, key_bits, g_stream ) ) return failrc( "device sort failed" );
     launch_build_gather( d_raw, d_rawn, v1, n, c->d_pos, c->d_nor, g_stream );
-    if( nor && !getenv( "RS_HIP_NO_INTERLEAVED" ) )
-    {
-      CC( hipMalloc( (void**)&c->d_pn, 2 * pb ) );
-      launch_build_interleave( c->d_pos, c->d_nor, n, c->d_pn, g_stream );
-    }
     CC( hipMemsetAsync( d_small, 0, 4, g_stream ) );
     launch_build_count_runs( k1, n, (int*)d_small, g_stream );
     int occ = 0;
@@ -568,11 +562,11 @@ static rs_hip_cloud_t* cloud_create_impl( const float* pos, const float* nor, in
     CC( hipStreamSynchronize( g_stream ) );
     occupied = (size_t)occ;
   }
-  c->bytes = (int64_t)( pb * ( nor ? 2 : 1 ) + ( c->d_pn ? 2 * pb : 0 ) + ( n_cells + 1 ) * 4 );
+  c->bytes = (int64_t)( pb * ( nor ? 2 : 1 ) + ( n_cells + 1 ) * 4 );
 
   clk.lap( 2 );
   GridView& v = c->view;
-  v.pos = c->d_pos; v.nor = c->d_nor; v.pn = c->d_pn; v.cell_start = c->d_cell_start;
+  v.pos = c->d_pos; v.nor = c->d_nor; v.cell_start = c->d_cell_start;
   v.minx = mn[0]; v.miny = mn[1]; v.minz = mn[2]; v.inv_cell = inv_cell; v.cell = inv_cell > 0.0f ? cell : 0.0f;
   v.w = dims[0]; v.h = dims[1]; v.d = dims[2]; v.n = n;
 
@@ -647,7 +641,6 @@ void rs_hip_cloud_destroy( rs_hip_cloud_t* c )
   if( !c ) return;
   if( c->d_pos ) (void)hipFree( c->d_pos );
   if( c->d_nor ) (void)hipFree( c->d_nor );
-  if( c->d_pn ) (void)hipFree( c->d_pn );
   if( c->d_cell_start ) (void)hipFree( c->d_cell_start );
   if( c->d_qpos ) (void)hipFree( c->d_qpos );
   if( c->d_qnor ) (void)hipFree( c->d_qnor );

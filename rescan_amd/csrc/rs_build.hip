@@ -200,15 +200,6 @@ void launch_build_gather( const float* pos3, const float* nor3, const uint32_t* 
 {
   hipLaunchKernelGGL( k_build_gather, dim3( blocks_for( n ) ), dim3( B_BLOCK ), 0, st, pos3, nor3, order, n, spos, snor );
 }
-__global__ void k_build_interleave( const float4* spos, const float4* snor, int n, float4* pn )
-{
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if( i < n ) { pn[2 * (size_t)i] = spos[i]; pn[2 * (size_t)i + 1] = snor[i]; }
-}
-void launch_build_interleave( const float4* spos, const float4* snor, int n, float4* pn, hipStream_t st )
-{
-  if( n > 0 ) hipLaunchKernelGGL( k_build_interleave, dim3( blocks_for( n ) ), dim3( B_BLOCK ), 0, st, spos, snor, n, pn );
-}
 void launch_build_count_runs( const uint32_t* sorted, int n, int* out, hipStream_t st )
 {
   hipLaunchKernelGGL( k_build_count_runs, dim3( blocks_for( n ) ), dim3( B_BLOCK ), 0, st, sorted, n, out );

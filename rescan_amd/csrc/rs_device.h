@@ -16,9 +16,6 @@ struct GridView
 {
   const float4*   pos;
   const float4*   nor;          // may be null
-  // the same two arrays interleaved, {pos[s], nor[s]} = pn[2 s], pn[2 s + 1] (may be null): what a kernel reads when it GATHERS single
-  // points by slot — the ICP searches' previous matches — so that a point's 32 bytes come with one cache line instead of two
-  const float4*   pn = nullptr;
   const uint32_t* cell_start;   // w*h*d + 1 entries
   float minx, miny, minz;       // grid origin
   float inv_cell;               // 1 / cell edge (0 for the one-cell brute layout)
@@ -307,7 +304,6 @@ void   launch_build_bounds( const float* pos3, const float* nor3, int n, unsigne
 void   launch_build_mark( const float* pos3, int n, const float mn[3], float inv, unsigned long long db, unsigned long long dc, uint32_t* bits, hipStream_t st );
 void   launch_build_cellids( const float* pos3, int n, const float mn[3], float inv_cell, const int dims[3], uint32_t* cid, uint32_t* iota, uint32_t* counts, hipStream_t st );
 void   launch_build_gather( const float* pos3, const float* nor3, const uint32_t* order, int n, float4* spos, float4* snor, hipStream_t st );
-void   launch_build_interleave( const float4* spos, const float4* snor, int n, float4* pn, hipStream_t st );
 void   launch_build_count_runs( const uint32_t* sorted, int n, int* out, hipStream_t st );
 void   launch_build_hilbert( const float* pos3, int n, const float mn[3], float scale, uint32_t* key, uint32_t* iota, hipStream_t st );
 void   launch_build_tile_flags( const float4* qpos, int n, float max_extent, uint32_t* flags, uint32_t* jump_a, uint32_t* jump_b, hipStream_t st );

@@ -139,7 +139,8 @@ if __name__ == "__main__":
         # landed in the drop-in block that used to follow the timed steps).  Written whole.  `--trace <csv> <out> [all]`: every
         # marked step, separated (the drop-in trace: tools/profile.sh trace_dropin).
         rows = sorted(csv.DictReader(open(sys.argv[2])), key=lambda r: int(r["Start_Timestamp"]))
-        rows = [r for r in rows if "rs::" in r["Kernel_Name"]]
+        # (every kernel of the process: the library's rs::, the radix sort's rocprim:: passes, the runtime's fills and copies; the marker
+        #  sits in an extern "C" block, so its name carries no namespace)
         marks = [k for k, r in enumerate(rows) if "k_step_marker" in r["Kernel_Name"]]
         out_path = sys.argv[3] if len(sys.argv) > 3 else "gpurun_out/trace_last_step.txt"
         every = len(sys.argv) > 4 and sys.argv[4] == "all"
@@ -153,7 +154,7 @@ if __name__ == "__main__":
             t0 = int(rows[a]["Start_Timestamp"]) if a < b else 0
             for r in rows[a:b]:
                 s_, e_ = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-                lines.append(f'{(s_ - t0) / 1e3:9.1f} us  +{(e_ - s_) / 1e3:8.1f} us  {r["Kernel_Name"].split("(")[0].replace("void ", "")}')
+                lines.append(f'{(s_ - t0) / 1e3:9.1f} us  +{(e_ - s_) / 1e3:8.1f} us  {r["Kernel_Name"].split("(")[0].replace("void ", "")[:90]}')
             if a < b:
                 lines.append(f"# {b - a} kernels, first start to last end {(int(rows[b - 1]['End_Timestamp']) - t0) / 1e3:.1f} us")
         open(out_path, "w").write("\n".join(lines) + "\n")
