@@ -999,7 +999,9 @@ float orc_icp_iterate_variant( const float* pts1, const float* nor1, int32_t n1,
     float total_weight = 0.0;
     for( int32_t j = 0; j < nc; ++j ) { total_weight += cw[j]; }
     if( total_weight <= 1e-7 ) { break; }
-    err = mode == 0 ? orc_icp_estimate_pt2pl( cp1, cp2, cn2, cw, nc, T1 ) : estimate_variant( cp1, cp2, cn2, cw, nc, T1, mode );
+    /* mode 100 + k (round 6, a what-if for scan-sized sources): plain fp64 (mode 3) in the first k iterations, the shipped arithmetic (mode 2) from then on */
+    const int m_it = mode >= 100 ? ( i < mode - 100 ? 3 : 2 ) : mode;
+    err = m_it == 0 ? orc_icp_estimate_pt2pl( cp1, cp2, cn2, cw, nc, T1 ) : estimate_variant( cp1, cp2, cn2, cw, nc, T1, m_it );
     if( errs_out ) { errs_out[i] = err; }
     float delta = fabsf( prev_err - err );
     if( stop_test && i > 5 && delta < 1e-5 ) { break; }

@@ -47,6 +47,7 @@ SIGNATURES = {
     "rs_hip_icp_lane_chains_sequential": (C.c_int64, []),
     "rs_hip_icp_stop_guard_redone": (C.c_int64, []),
     "rs_hip_icp_stop_guard": (C.c_float, [C.c_float]),
+    "rs_hip_icp_early_plain": (C.c_int32, [C.c_int32]),
     "rs_hip_icp_replay_redone": (C.c_int32, []),
     "rs_hip_icp_faith_redone": (C.c_int32, []),
     "rs_hip_icp_faith_guess": (C.c_int32, [C.c_int32]),
@@ -279,6 +280,11 @@ def icp_lane_chains_sequential():
 def icp_stop_guard_redone():
     """(diagnostics) problems run again in the reference's order because a stop test was decided inside the guard, since init."""
     return int(load().rs_hip_icp_stop_guard_redone())
+
+
+def icp_early_plain(on=-1):
+    """Plain (chain-free) early iterations of the lane / grid chain estimators (default on); -1 only reads.  Returns the previous setting."""
+    return int(load().rs_hip_icp_early_plain(int(on)))
 
 
 def icp_stop_guard(guard=-1.0):

@@ -156,6 +156,23 @@ std::atomic<int> g_lane_below{ getenv( "RS_HIP_LANE_CHAINS_BELOW" ) ? atoi( gete
 // to fall back on (0.5 ms per iteration at 1 M points were never the default) and keep their result.  RS_HIP_STOP_GUARD=0: off.
 std::atomic<float> g_stop_guard{ getenv( "RS_HIP_STOP_GUARD" ) ? (float)atof( getenv( "RS_HIP_STOP_GUARD" ) ) : 1.5e-6f };
 std::atomic<long long> g_stop_guard_redone{ 0 };      // (diagnostics: rs_hip_icp_stop_guard_redone)
+// PLAIN early iterations (round 6).  The reference's centroid chains decide where the iteration CONVERGES; an iteration far from the end only has
+// to bring the pose near, and ICP forgets how it got there at its own contraction rate (measured on the headline, the chains in the last m
+// iterations of ten: m = 10 / 7 / 5 / 3 / 1 -> 9.9e-7 / 6.9e-7 / 1.3e-6 / 2.5e-6 / 1.0e-5 from the reference's pose; profiles/r06/early_plain.txt).
+// Rule, for sources on the GRID chains (above g_lane_below): at least THREE chain iterations precede any iteration whose result can be
+// returned — a call of fixed length runs the plain step (fp64 moments centred on their own fp64 centroids: two launches instead of six)
+// until three iterations before its end; a call with the stop test (first decision at i = 6, icp.h:489) in its first four iterations, and
+// only where no bit-exact estimator guards the decision anyway (sources above 262 144 points: g_stop_guard).  Six 1 M-point rooms: <= 2.6e-6
+// from the reference's pose (<= 1.2e-6 without), a ten-iteration call 2.52 -> 2.26 ms.  RS_HIP_EARLY_PLAIN=0: off; rs_hip_icp_early_plain().
+std::atomic<int> g_early_plain{ getenv( "RS_HIP_EARLY_PLAIN" ) ? atoi( getenv( "RS_HIP_EARLY_PLAIN" ) ) : 1 };
+inline int icp_plain_iterations( int n_source, int max_iter, bool fixed_iters )
+{
+  if( !g_early_plain.load() ) return 0;
+  static const int keep = getenv( "RS_HIP_EARLY_TAIL" ) ? atoi( getenv( "RS_HIP_EARLY_TAIL" ) ) : 3;      // chain iterations before a result can be returned
+  const int tail = std::max( 0, max_iter - keep );
+  if( fixed_iters ) return tail;
+  return n_source > 262144 ? std::min( std::max( 0, 7 - keep ), tail ) : 0;
+}
 std::mutex g_prof_mutex;
 struct ProfEntry { std::vector<std::pair<hipEvent_t, hipEvent_t>> spans; int64_t launches = 0; double ms = 0.0; };
 std::map<std::string, ProfEntry> g_profmap;
@@ -921,27 +938,9 @@ void icp_debug_after( IcpCtx& cx, int n_src, int n, int i, float max_dist )
   pr( "p10", rows.size() / 10 ); pr( "p50", rows.size() / 2 ); pr( "p90", rows.size() * 9 / 10 ); pr( "p99", rows.size() * 99 / 100 ); pr( "max", rows.size() - 1 );
 }
 
-// The searches of iteration i.  Round 6, VERDICT r05 1(b) — built, measured, off by default: the FIRST search of a call that keeps
-// certificates may look RS_HIP_CERT_EXTRA of the radius farther than the reference does (matches stay what the reference's radius
-// gives: icp_emit), so that the certificates it issues — "nothing gated within r" — survive the first pose step, the largest of the
-// call (the radius shrinks by 5 % per iteration, icp.h:493: 5 mm of slack at 0.1 m).  On the headline (profiles/r06/cert_extra.txt):
-// tiles queued again in iteration 1: 1 966 -> 1 449 (5 %) -> 909 (10 %, 20 %: the rest lost a MATCH, not a certificate); searches per step
-// 1.678 -> 1.688 -> 1.700 -> 1.745 ms: what the first search pays for the wider boxes of all its tiles is more than the second saves.
-static const float g_cert_extra = getenv( "RS_HIP_CERT_EXTRA" ) ? (float)atof( getenv( "RS_HIP_CERT_EXTRA" ) ) : 0.0f;
-void icp_search_launch( const IcpCtx& cx, int i )
-{
-  if( i == 0 && cx.L.cert_r && g_cert_extra > 0.0f )
-  {
-    IcpLaunch Ls = cx.L;
-    Ls.radius = cx.L.radius * ( 1.0f + g_cert_extra ); Ls.radius_sq = radius_sq_of( Ls.radius );
-    launch_icp_corr( Ls, g_stream );
-  }
-  else launch_icp_corr( cx.L, g_stream );
-}
-
 void icp_set_radius( IcpCtx& cx, float max_dist, float tmin )
 {
-  cx.L.radius = max_dist; cx.L.radius_sq = radius_sq_of( max_dist ); cx.L.gate_tmin = tmin; cx.L.match_radius_sq = cx.L.radius_sq;
+  cx.L.radius = max_dist; cx.L.radius_sq = radius_sq_of( max_dist ); cx.L.gate_tmin = tmin;
   // fixed-point scales of the dist² statistics: r²·2^e1 and r⁴·2^e2 just below 2^36, so that a tile's sum (64 terms)
   // and the sum over 2^22 tiles stay below 2^64, with 36 bits below the radius
   const double r2 = cx.L.radius_sq;
@@ -1128,6 +1127,9 @@ int icp_align_batch_impl( const rs_hip_cloud_t* source, const rs_hip_cloud_t* ta
   static const int coop_waves_forced = getenv( "RS_HIP_COOP_WAVES" ) ? atoi( getenv( "RS_HIP_COOP_WAVES" ) ) : 0;
   static const int chain_refresh = std::max( 0, getenv( "RS_HIP_CHAIN_REFRESH" ) ? atoi( getenv( "RS_HIP_CHAIN_REFRESH" ) ) : 0 );
   cx.L.solve = 1; cx.L.fixed_iters = fixed_iters ? 1 : 0;
+  // (see g_early_plain.  Scan-sized sources only: the eight 50 k-point refines of bench.py --scaling strong end 2.2e-6 from the reference with the
+  //  chains throughout, 8.7e-6 with three plain iterations, 2.0e-5 with seven — an object refine contracts more slowly than a scan-to-scan fit)
+  const int n_plain = ( chains || from_records ) ? icp_plain_iterations( source->n, max_iter, fixed_iters != 0 ) : 0;
   ProfChain prof;
   for( int i = 0; i < max_iter; )                                       // icp.h:444
   {
@@ -1152,7 +1154,7 @@ int icp_align_batch_impl( const rs_hip_cloud_t* source, const rs_hip_cloud_t* ta
         cx.L.heavy_out = ( i & 1 ) ? g_ws.order_b.as<int>() : g_ws.order_a.as<int>();
       }
       if( debug ) icp_debug_before( cx, n );
-      prof.mark( "nn_icp" ); icp_search_launch( cx, i );
+      prof.mark( "nn_icp" ); launch_icp_corr( cx.L, g_stream );
       if( debug ) icp_debug_after( cx, source->n, n, i, max_dist );
       prof.mark( "icp_moments" );
       if( replay ) launch_icp_replay( cx.L, RB, g_stream );
@@ -1160,10 +1162,19 @@ int icp_align_batch_impl( const rs_hip_cloud_t* source, const rs_hip_cloud_t* ta
       {
         // the binade guesses of the chains' records: made from the sums of the iteration before (k_chain_walk_and_moments) — in the first
         // iteration from its own, so the records and the walks wait for the moments there (RS_HIP_CHAIN_REFRESH=k: in every k-th as well)
-        CB.refresh = ( i == 0 || ( chain_refresh > 0 && ( i % chain_refresh ) == 0 ) ) ? 1 : 0;
-        launch_icp_chain_centroids( cx.L, CB, g_stream );
+        if( i < n_plain )
+        {
+          IcpLaunch Lp = cx.L; Lp.exact_centroids = 0;
+          launch_icp_plain_from_records( Lp, CB, g_stream );
+        }
+        else
+        {
+          CB.refresh = ( i == n_plain || ( chain_refresh > 0 && ( i % chain_refresh ) == 0 ) ) ? 1 : 0;
+          launch_icp_chain_centroids( cx.L, CB, g_stream );
+        }
       }
       else if( lane ) launch_icp_lane_chains( cx.L, CB, g_stream );
+      else if( from_records && i < n_plain ) { IcpLaunch Lp = cx.L; Lp.exact_centroids = 0; launch_icp_plain_from_records( Lp, CB, g_stream ); }
       else if( from_records ) launch_icp_exact_centroids_from_records( cx.L, RB, CB, g_stream );
       else if( exact_centroids ) launch_icp_exact_centroids( cx.L, RB, g_stream );
       else if( cx.L.faith ) launch_icp_faithful( cx.L, g_stream ); else launch_icp_moments( cx.L, g_stream );
@@ -1413,7 +1424,7 @@ static int icp_align_multi_group( const rs_hip_cloud_t* const* sources, const rs
         cx.L.heavy_in = i == 0 ? nullptr : ( ( i & 1 ) ? g_ws.order_a.as<int>() : g_ws.order_b.as<int>() );
         cx.L.heavy_out = ( i & 1 ) ? g_ws.order_b.as<int>() : g_ws.order_a.as<int>();
       }
-      prof.mark( "nn_icp" ); icp_search_launch( cx, i );
+      prof.mark( "nn_icp" ); launch_icp_corr( cx.L, g_stream );
       prof.mark( "icp_moments" );
       if( lane ) launch_icp_lane_chains( cx.L, CB, g_stream ); else launch_icp_faithful( cx.L, g_stream );
       double nd = max_dist * 0.95;                                      // icp.h:493
@@ -1447,6 +1458,12 @@ static int icp_align_multi_group( const rs_hip_cloud_t* const* sources, const rs
 
 // (diagnostics) problems run again in the reference's order because a stop test of theirs was decided inside the guard, since rs_hip_init
 int64_t rs_hip_icp_stop_guard_redone( void ) { return g_stop_guard_redone.load(); }
+int32_t rs_hip_icp_early_plain( int32_t on )
+{
+  const int prev = g_early_plain.load();
+  if( on >= 0 ) g_early_plain.store( on ? 1 : 0 );
+  return prev;
+}
 float rs_hip_icp_stop_guard( float guard )
 {
   const float prev = g_stop_guard.load();

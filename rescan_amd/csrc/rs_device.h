@@ -81,9 +81,6 @@ struct IcpLaunch
   int*         active;         // device, n_prob flags (0 = skip; cleared on the device when a problem stops)
   Xform        T2i;
   float        radius, radius_sq, gate_tmin;
-  // What counts as a correspondence: dist² < match_radius_sq (= radius_sq, except in a first iteration searched with a LARGER radius for the
-  // sake of its certificates — rs_api.hip: icp_search_launch; a nearest gated candidate beyond it means "none within it")
-  float        match_radius_sq;
   int          K;
   // outputs / workspace (device)
   int*    m_slot;   // n_prob x nq : matched target slot or -1
@@ -170,6 +167,7 @@ struct ChainBufs
   float*    addends;    // (lane chains only) the seven addend rows of every problem: 8 x ( total source points + 4 n_prob ) floats
 };
 void   launch_icp_chain_centroids( const IcpLaunch& L, const ChainBufs& B, hipStream_t st );
+void   launch_icp_plain_from_records( const IcpLaunch& L, const ChainBufs& B, hipStream_t st );      // fp64 moments + update, no chains (L.exact_centroids == 0)
 // the same seven sums for object-sized sources, one wave per chain, any number of (differently sized) problems: B.totals, B.done, B.resolved, B.addends only
 void   launch_icp_lane_chains( const IcpLaunch& L, const ChainBufs& B, hipStream_t st );
 inline int chain_segments( int n ) { return ( n + CH_SEG - 1 ) / CH_SEG; }

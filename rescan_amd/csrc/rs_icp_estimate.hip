@@ -2501,6 +2501,15 @@ void launch_icp_lane_chains( const IcpLaunch& L, const ChainBufs& B, hipStream_t
   hipLaunchKernelGGL( k_lane_walk_and_update, dim3( ICP_NMOM + LC_WALK_BLOCKS, L.n_prob ), dim3( BLOCK ), 0, st, L, B );
 }
 
+// The step WITHOUT the chains: the fp64 moments from the searches' records, centred on their own fp64 centroids (icp_solve without the
+// reference's) — what an early iteration of a scan-sized call runs (rs_api.hip: g_early_plain).  L.exact_centroids must be 0.
+void launch_icp_plain_from_records( const IcpLaunch& L, const ChainBufs& B, hipStream_t st )
+{
+  ChainBufs Bq = B; Bq.refresh = 0;
+  hipLaunchKernelGGL( k_chain_moments, dim3( B.n_blk * CH_QUARTERS, L.n_prob ), dim3( BLOCK ), 0, st, L, Bq );
+  hipLaunchKernelGGL( k_icp_update_wide, dim3( ICP_NMOM, L.n_prob ), dim3( BLOCK ), 0, st, L, B.done );
+}
+
 void launch_icp_chain_centroids( const IcpLaunch& L, const ChainBufs& B, hipStream_t st )
 {
   const int n_tasks = ( B.n_seg + CHAIN_REC_TASK - 1 ) / CHAIN_REC_TASK;

@@ -477,6 +477,7 @@ def test_lane_chains_are_the_sequential_sums(capi, gscene, scene_clouds):
     from rescan_amd import synth
     clouds, objs = scene_clouds
     prev, prev_r, prev_c, prev_l = capi.icp_reference_order_below(-1), capi.icp_replay_below(-1), capi.icp_exact_centroids(-1), capi.icp_lane_chains_below(-1)
+    prev_p = capi.icp_early_plain(0)      # (the replay route of a fixed-length call would run its early iterations without the sums this test is about)
     try:
         capi.icp_reference_order_below(0); capi.icp_replay_below(0)
 
@@ -540,7 +541,7 @@ def test_lane_chains_are_the_sequential_sums(capi, gscene, scene_clouds):
                 e, T, it = capi.icp_align(srcs[k], clouds[0.1], T0m[j], I4, 0.075, np.deg2rad(50.0), max_iter=iters, fixed_iters=fixed)
                 assert (T == Ts[j]).all() and e == errs[j] and it == its[j], (j, k)
     finally:
-        capi.icp_reference_order_below(prev); capi.icp_replay_below(prev_r); capi.icp_exact_centroids(prev_c); capi.icp_lane_chains_below(prev_l)
+        capi.icp_reference_order_below(prev); capi.icp_replay_below(prev_r); capi.icp_exact_centroids(prev_c); capi.icp_lane_chains_below(prev_l); capi.icp_early_plain(prev_p)
 
 
 def test_stop_test_guard_restores_the_reference_decision(capi, oracle):
