@@ -889,6 +889,8 @@ void icp_debug_after( IcpCtx& cx, int n_src, int n, int i, float max_dist )
     std::vector<int> words( (size_t)cx.n_waves );
     (void)hipMemcpy( words.data(), cx.L.heavy_out + HEAVY_HDR + HEAVY_SLOTS, words.size() * 4, hipMemcpyDeviceToHost );
     for( int v : words ) if( (unsigned)v >> 2 ) { st_sum += (unsigned)v >> 2; ++st_cnt; }
+    long long heavy = 0; for( int v : words ) heavy += ( v & 3 ) == 2;
+    fprintf( stderr, "[rs_hip icp]   of the queued tiles, handed off as HEAVY bounded tiles (flag 2): %lld\n", heavy );
   }
   fprintf( stderr, "[rs_hip icp] it %d (max_dist %g, coop waves %d): prob 0 queued tiles %d of %d, unmatched %zu of %d, certificates %zu, candidates streamed per tile of phase A %lld\n",
            i, (double)max_dist, cx.L.coop_waves, qc[0], cx.n_waves, unm, n_src, cert, st_cnt ? st_sum / st_cnt : 0ll );

@@ -1,12 +1,10 @@
 #!/bin/bash
-# Step time under different CU partitions / label placements (interleaved, two rounds): bash tools/ab_cu_split.sh
+# bash tools/ab_cu_split.sh: the bench's CU partition measured again (interleaved, 2 rounds): fraction of the CU mask for the ICP chain x where the label pass runs
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
-mkdir -p gpurun_out; out=gpurun_out/ab_cu_split.txt; : > $out
-one() { r=$(env "$@" python bench.py --no-cpu-baseline --steps 40 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],3), 'median', round(d['ms_per_step_spread']['median'],3), {k: round(v,2) for k,v in d['kernel_ms_per_step'].items()})"); echo "$* -> $r" >> $out; }
-for rep in 1 2; do
-one RS_BENCH_CU_SPLIT=0.75 RS_BENCH_LABEL_ON=chain
-one RS_BENCH_CU_SPLIT=1.0 RS_BENCH_CU_BATCH_LO=0.75 RS_BENCH_LABEL_ON=batch
-one RS_BENCH_CU_SPLIT=1.0 RS_BENCH_CU_BATCH_LO=0.75 RS_BENCH_LABEL_ON=chain
-one RS_BENCH_CU_SPLIT=0.875 RS_BENCH_CU_BATCH_LO=0.75 RS_BENCH_LABEL_ON=batch
+for r in 1 2; do
+  for cfg in "0.75 chain" "0.75 batch" "0.625 chain" "0.875 chain" "0.75 all" "0 chain"; do
+    set -- $cfg
+    RS_BENCH_CU_SPLIT=$1 RS_BENCH_LABEL_ON=$2 python bench.py --no-cpu-baseline --no-extras --steps 20 2>/dev/null > /tmp/ab.json
+    python -c "import json; d=json.loads(open('/tmp/ab.json').read().strip().splitlines()[-1]); print('split $1 label on $2:', round(d['ms_per_step'],4), {k: round(x,3) for k,x in d['kernel_ms_per_step'].items()})"
+  done
 done
-cat $out
