@@ -159,16 +159,19 @@ std::atomic<long long> g_stop_guard_redone{ 0 };      // (diagnostics: rs_hip_ic
 // PLAIN early iterations (round 6).  The reference's centroid chains decide where the iteration CONVERGES; an iteration far from the end only has
 // to bring the pose near, and ICP forgets how it got there at its own contraction rate (measured on the headline, the chains in the last m
 // iterations of ten: m = 10 / 7 / 5 / 3 / 1 -> 9.9e-7 / 6.9e-7 / 1.3e-6 / 2.5e-6 / 1.0e-5 from the reference's pose; profiles/r06/early_plain.txt).
-// Rule, for sources on the GRID chains (above g_lane_below): at least THREE chain iterations precede any iteration whose result can be
-// returned — a call of fixed length runs the plain step (fp64 moments centred on their own fp64 centroids: two launches instead of six)
-// until three iterations before its end; a call with the stop test (first decision at i = 6, icp.h:489) in its first four iterations, and
-// only where no bit-exact estimator guards the decision anyway (sources above 262 144 points: g_stop_guard).  Six 1 M-point rooms: <= 2.6e-6
-// from the reference's pose (<= 1.2e-6 without), a ten-iteration call 2.52 -> 2.26 ms.  RS_HIP_EARLY_PLAIN=0: off; rs_hip_icp_early_plain().
+// Rule, for sources on the GRID chains (above g_lane_below): chain iterations precede any iteration whose result can be returned — TWO in a
+// call of fixed length, which runs the plain step (fp64 moments centred on their own fp64 centroids: two launches instead of six) until two
+// iterations before its end (m = 2 and m = 3 are the same few 1e-6 from the reference's pose on six rooms — <= 3.7e-6 / <= 2.6e-6, neither
+// monotone in m — m = 1 is not: 1.1e-5, outside the 1e-5 this policy is held to); three in a call with the stop test (first decision at
+// i = 6, icp.h:489), which runs plain in its first four iterations, and only where no bit-exact estimator guards the decision anyway
+// (sources above 262 144 points: g_stop_guard).  A ten-iteration call at 1 M points: 2.52 -> 2.14 ms.  RS_HIP_EARLY_PLAIN=0: off;
+// rs_hip_icp_early_plain().  RS_HIP_EARLY_TAIL=m: m chain iterations kept in both kinds of call (tools/early_plain_table.py).
 std::atomic<int> g_early_plain{ getenv( "RS_HIP_EARLY_PLAIN" ) ? atoi( getenv( "RS_HIP_EARLY_PLAIN" ) ) : 1 };
 inline int icp_plain_iterations( int n_source, int max_iter, bool fixed_iters )
 {
   if( !g_early_plain.load() ) return 0;
-  static const int keep = getenv( "RS_HIP_EARLY_TAIL" ) ? atoi( getenv( "RS_HIP_EARLY_TAIL" ) ) : 3;      // chain iterations before a result can be returned
+  static const int forced = getenv( "RS_HIP_EARLY_TAIL" ) ? atoi( getenv( "RS_HIP_EARLY_TAIL" ) ) : 0;
+  const int keep = forced > 0 ? forced : ( fixed_iters ? 2 : 3 );      // chain iterations before a result can be returned
   const int tail = std::max( 0, max_iter - keep );
   if( fixed_iters ) return tail;
   return n_source > 262144 ? std::min( std::max( 0, 7 - keep ), tail ) : 0;
@@ -1130,7 +1133,7 @@ int icp_align_batch_impl( const rs_hip_cloud_t* source, const rs_hip_cloud_t* ta
   static const int chain_refresh = std::max( 0, getenv( "RS_HIP_CHAIN_REFRESH" ) ? atoi( getenv( "RS_HIP_CHAIN_REFRESH" ) ) : 0 );
   cx.L.solve = 1; cx.L.fixed_iters = fixed_iters ? 1 : 0;
   // (see g_early_plain.  Scan-sized sources only: the eight 50 k-point refines of bench.py --scaling strong end 2.2e-6 from the reference with the
-  //  chains throughout, 8.7e-6 with three plain iterations, 2.0e-5 with seven — an object refine contracts more slowly than a scan-to-scan fit)
+  //  chains throughout, 8.7e-6 with three plain iterations, 2.0e-5 with seven or eight — an object refine contracts more slowly than a scan-to-scan fit)
   const int n_plain = ( chains || from_records ) ? icp_plain_iterations( source->n, max_iter, fixed_iters != 0 ) : 0;
   ProfChain prof;
   for( int i = 0; i < max_iter; )                                       // icp.h:444

@@ -349,8 +349,9 @@ def test_traced_icp_is_the_same_call(capi, headline):
     assert it1 == it0 == 10 and e1 == e0 and (T1 == T0).all() and len(errs) == 10 and errs[-1] == e1
     # (whole scans: the fp64-moment estimator evaluates the residual algebraically where the reference sums fp32 terms — 4e-5 apart in the
     #  first two iterations, where the error is 5e-3 ... 2e-2 and no stop test looks at it, 1e-6 once it has settled.  Round 6: a
-    #  fixed-length call runs the PLAIN step — its own fp64 centroids — until three iterations before its end (rs_hip_icp_early_plain):
-    #  those iterations' errors are the plain step's, 1.3e-3 ... 2e-6 from the reference's (of errors of 2e-2 ... 1e-3); the last three are the chains')
+    #  fixed-length call runs the PLAIN step — its own fp64 centroids — until two iterations before its end (rs_hip_icp_early_plain):
+    #  those iterations' errors are the plain step's, 1.3e-3 ... 2e-6 from the reference's (of errors of 2e-2 ... 1e-3); the last two are the
+    #  chains', and the plain one before them has settled as far)
     d = np.abs(errs.astype(np.float64) - g["icp_errs"].astype(np.float64))
     assert d.max() < 5e-3 and d[-3:].max() < 1e-5, d
     prev_p = capi.icp_early_plain(0)
