@@ -811,6 +811,18 @@ int icp_prepare( IcpCtx& cx, const rs_hip_cloud_t* src, const rs_hip_cloud_t* tg
   return RS_HIP_OK;
 }
 
+// Waves per queued tile in the cooperative kernel.  A short queue is bound by its heaviest tile (8 waves: from the third iteration on the
+// certificates have emptied it; launches that skip phase A: while there are few tiles), a long one by throughput (4).  Batches of many
+// problems (round 6): object refines keep a long queue in every iteration — the rim of every object has nothing to match — and the
+// launch is throughput-bound however late: 512 50 k-point refines (410 k tiles) 33.8 ms per step with 8 waves per tile, 30.2 with 4,
+// 28.9 with 2.
+inline int icp_coop_waves( const IcpLaunch& L, long long total_tiles, int n_prob, int i )
+{
+  if( n_prob > 8 && total_tiles >= 131072 ) return 2;
+  if( n_prob > 8 && total_tiles >= 32768 ) return 4;
+  return L.coop_all ? ( total_tiles <= 1536 ? 8 : 4 ) : ( ( i >= 2 && L.cert_r ) ? 8 : 4 );
+}
+
 // buffers of the parallel reference-order estimator for n_prob problems of n_source points
 int replay_prepare( ReplayBufs& B, int n_prob, int n_source )
 {
@@ -1151,7 +1163,7 @@ int icp_align_batch_impl( const rs_hip_cloud_t* source, const rs_hip_cloud_t* ta
       // launches of a few thousand tiles go straight to the cooperative kernel (launch_icp_corr); it is bound by its
       // heaviest tile while the list is short (8 waves per tile), by throughput beyond (4)
       cx.L.coop_all = total_tiles <= coop_all_below ? 1 : 0;
-      cx.L.coop_waves = cx.L.coop_all ? ( total_tiles <= 1536 ? 8 : 4 ) : ( ( i >= 2 && cx.L.cert_r ) ? 8 : 4 );
+      cx.L.coop_waves = icp_coop_waves( cx.L, total_tiles, n, i );
       if( coop_waves_forced ) cx.L.coop_waves = coop_waves_forced;
       if( reorder )
       {
@@ -1422,7 +1434,7 @@ static int icp_align_multi_group( const rs_hip_cloud_t* const* sources, const rs
       cx.L.iter_index = i;
       cx.L.warm = ( i > 0 && !getenv( "RS_HIP_NO_WARM" ) ) ? 1 : 0;
       cx.L.coop_all = total_tiles <= coop_all_below ? 1 : 0;
-      cx.L.coop_waves = cx.L.coop_all ? ( total_tiles <= 1536 ? 8 : 4 ) : ( ( i >= 2 && cx.L.cert_r ) ? 8 : 4 );
+      cx.L.coop_waves = icp_coop_waves( cx.L, total_tiles, n, i );
       if( coop_waves_forced ) cx.L.coop_waves = coop_waves_forced;
       if( reorder )
       {

@@ -98,7 +98,7 @@ struct IcpLaunch
   int*    queue;        // n_prob x n_tiles : tiles handed to the cooperative kernel
   int*    queue_count;  // n_prob
   int     solo_stages;  // candidates a lone wave streams before handing an unsettled tile off
-  int     coop_waves;   // waves per queued tile in the cooperative kernel (4 or 8)
+  int     coop_waves;   // waves per queued tile in the cooperative kernel (2, 4 or 8)
   int     coop_all;     // 1: no phase A, the cooperative kernel searches every tile (small launches)
   // loop state kept on the device (lib/rs/icp.h:441-493): k_icp_update solves and updates it
   int     solve;        // 0: reductions only (estimate-only / find_corrs entry points), 1: also solve + update the state

@@ -2437,68 +2437,62 @@ __global__ __launch_bounds__( BLOCK ) void k_lane_moments_and_addends( IcpLaunch
   chain_moments_block( L, Bq, prob, (int)blockIdx.x, S, L.rec + (size_t)L.pt_off * REC_F4, B.addends + lane_rows_base( L, prob ) );
 }
 
-// Launch 2: workgroups 0 .. ICP_NMOM - 1 sum a moment's partials each (k_icp_update_wide's work), the next two walk the seven chains
-// (a wave each, from the addend rows); whichever finishes last does the rest of the iteration (icp.h:253-295,455-493), centred on the
-// chains' centroids.
-constexpr int LC_WALK_BLOCKS = ( CH_ROWS + WAVES_PER_BLOCK - 1 ) / WAVES_PER_BLOCK;
-__global__ __launch_bounds__( BLOCK ) void k_lane_walk_and_update( IcpLaunch L, ChainBufs B )
+// Launch 2: ONE workgroup per problem — seven waves walk the seven chains (from the addend rows), the eighth sums the moments' partials
+// (k_icp_update_wide's work, in the order a 256-thread workgroup per moment added them: thread t takes partials t, t + 256, ...; a wave
+// tree per 64; the four waves' sums in turn), a barrier, and the rest of the iteration (icp.h:253-295,455-493) centred on the chains'
+// centroids.  (Until late in round 6 this was 35 + 2 workgroups per problem and a ticket for "who finishes last": every one of them a
+// release fence, i.e. an L2 write-back — 19 000 of them per launch at 512 problems, 1.19 ms for walks that take 50 us; a barrier
+// inside one workgroup needs none.)
+constexpr int LW_WAVES = 8;
+static_assert( CH_ROWS < LW_WAVES, "a wave per chain and one for the moments" );
+__global__ __launch_bounds__( LW_WAVES * WAVE ) void k_lane_walk_and_update( IcpLaunch L, ChainBufs B )
 {
   RS_CHAIN_SETPRIO();
-  __shared__ double s_part[WAVES_PER_BLOCK];
-  __shared__ int s_last;
-  const int prob = blockIdx.y, k = blockIdx.x;
+  const int prob = blockIdx.x;
   if( L.active[prob] == 0 ) return;
   icp_bind( L, prob );
   const int lane = threadIdx.x & ( WAVE - 1 ), wib = uni( (int)threadIdx.x / WAVE );
-  if( k < ICP_NMOM )
+  if( wib < CH_ROWS )
   {
-    const double* in = L.mom_part + ( (size_t)prob * ICP_NMOM + k ) * L.n_mom_blocks;
-    double v = 0.0;
-    for( int b = threadIdx.x; b < L.n_mom_blocks; b += BLOCK ) v += in[b];
-    v = wave_sum( v );
-    if( lane == 0 ) s_part[wib] = v;
-    __syncthreads();
-    if( threadIdx.x == 0 )
+    const int row = wib;
+    int d[2] = { 0, 0 };
+    const unsigned long long t0 = B.dbg ? wall_clock64() : 0ull;
+    const float s = lane_chain_walk( B.addends + lane_rows_base( L, prob ) + (size_t)row * lane_row_stride( L.src.n ), L.src.n, lane, d );
+    if( lane == 0 )
     {
-      double t = 0.0;
-      for( int w = 0; w < WAVES_PER_BLOCK; ++w ) t += s_part[w];
-      L.res[(size_t)prob * ICP_NRES + k] = t;
+      B.totals[( (size_t)prob * 3 + 1 ) * ICP_NMOM + row] = (double)s;
+      if( B.resolved ) atomicAdd( B.resolved + prob, d[0] );
+      // (RS_HIP_LANE_DEBUG) per (problem, chain): ticks of 10 ns the walk took, attempts, addends added one by one — of the last iteration
+      if( B.dbg ) { int* o = B.dbg + ( (size_t)prob * CH_ROWS + row ) * 4; o[0] = (int)( wall_clock64() - t0 ); o[1] = d[1]; o[2] = d[0]; o[3] = L.src.n; }
     }
   }
-  else
+  else if( wib == CH_ROWS )
   {
-    const int row = ( k - ICP_NMOM ) * WAVES_PER_BLOCK + wib;
-    if( row < CH_ROWS )
+    for( int k = 0; k < ICP_NMOM; ++k )
     {
-      int d[2] = { 0, 0 };
-      const unsigned long long t0 = B.dbg ? wall_clock64() : 0ull;
-      const float s = lane_chain_walk( B.addends + lane_rows_base( L, prob ) + (size_t)row * lane_row_stride( L.src.n ), L.src.n, lane, d );
-      if( lane == 0 )
+      const double* in = L.mom_part + ( (size_t)prob * ICP_NMOM + k ) * L.n_mom_blocks;
+      double r[WAVES_PER_BLOCK];
+#pragma unroll
+      for( int w = 0; w < WAVES_PER_BLOCK; ++w )
       {
-        B.totals[( (size_t)prob * 3 + 1 ) * ICP_NMOM + row] = (double)s;
-        if( B.resolved ) atomicAdd( B.resolved + prob, d[0] );
-        // (RS_HIP_LANE_DEBUG) per (problem, chain): ticks of 10 ns the walk took, attempts, addends added one by one — of the last iteration
-        if( B.dbg ) { int* o = B.dbg + ( (size_t)prob * CH_ROWS + row ) * 4; o[0] = (int)( wall_clock64() - t0 ); o[1] = d[1]; o[2] = d[0]; o[3] = L.src.n; }
+        double v = 0.0;
+        for( int b = w * WAVE + lane; b < L.n_mom_blocks; b += BLOCK ) v += in[b];
+        r[w] = wave_sum( v );
       }
+      double t = 0.0;
+#pragma unroll
+      for( int w = 0; w < WAVES_PER_BLOCK; ++w ) t += r[w];
+      if( lane == 0 ) L.res[(size_t)prob * ICP_NRES + k] = t;
     }
-    __syncthreads();
   }
-  if( threadIdx.x == 0 )
-  {
-    __threadfence();
-    s_last = atomicAdd( B.done + prob, 1 ) == ICP_NMOM + LC_WALK_BLOCKS - 1 ? 1 : 0;
-  }
-  __syncthreads();
-  if( !s_last ) return;
-  __threadfence();                                       // (the other workgroups' sums and totals)
-  if( threadIdx.x == 0 ) B.done[prob] = 0;
+  __syncthreads();                                       // (the sums and totals above: this workgroup's own global writes)
   icp_update_tail( L, prob );
 }
 
 void launch_icp_lane_chains( const IcpLaunch& L, const ChainBufs& B, hipStream_t st )
 {
   hipLaunchKernelGGL( k_lane_moments_and_addends, dim3( L.n_mom_blocks, L.n_prob ), dim3( BLOCK ), 0, st, L, B );      // (L.n_mom_blocks == ceil( max_n / 1024 ))
-  hipLaunchKernelGGL( k_lane_walk_and_update, dim3( ICP_NMOM + LC_WALK_BLOCKS, L.n_prob ), dim3( BLOCK ), 0, st, L, B );
+  hipLaunchKernelGGL( k_lane_walk_and_update, dim3( L.n_prob ), dim3( LW_WAVES * WAVE ), 0, st, L, B );
 }
 
 // The step WITHOUT the chains: the fp64 moments from the searches' records, centred on their own fp64 centroids (icp_solve without the

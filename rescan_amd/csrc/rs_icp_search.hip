@@ -433,10 +433,14 @@ void launch_icp_corr( const IcpLaunch& L, hipStream_t st )
   }
   // the queue length is only known on the device: a fixed grid strides over it
   int coop_blocks = L.max_tiles < 2048 ? L.max_tiles : 2048;
+  // (a batch of many problems: the queues are short — a few dozen tiles each — and a grid of n_prob x max_tiles workgroups that find
+  //  nothing to do is the launch: 410 000 of them, 0.54 ms, at 512 50 k-point problems.  ~16 k workgroups in all stride over whatever there is.)
+  if( L.n_prob > 8 ) coop_blocks = std::max( 8, std::min( coop_blocks, ( 16384 + L.n_prob - 1 ) / L.n_prob ) );
   const dim3 cgrid( coop_blocks > 0 ? coop_blocks : 1, L.n_prob );
   // a short queue is latency-bound by its heaviest tile: give every tile more waves
-  if( L.coop_waves >= 8 ) hipLaunchKernelGGL( k_icp_corr_coop<8>, cgrid, dim3( 8 * WAVE ), 0, st, L );
-  else                    hipLaunchKernelGGL( k_icp_corr_coop<COOP_WAVES>, cgrid, dim3( COOP_BLOCK ), 0, st, L );
+  if( L.coop_waves >= 8 )      hipLaunchKernelGGL( k_icp_corr_coop<8>, cgrid, dim3( 8 * WAVE ), 0, st, L );
+  else if( L.coop_waves <= 2 ) hipLaunchKernelGGL( k_icp_corr_coop<2>, cgrid, dim3( 2 * WAVE ), 0, st, L );
+  else                         hipLaunchKernelGGL( k_icp_corr_coop<COOP_WAVES>, cgrid, dim3( COOP_BLOCK ), 0, st, L );
 }
 
 } // namespace rs
