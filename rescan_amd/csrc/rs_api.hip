@@ -99,7 +99,7 @@ struct Workspace
 {
   DevBuf state, slot, d2, dot, stat_acc, mom_part, res, wexp, queue, queue_count, multi;   // ICP (multi: the per-problem views of a multi-source batch)
   DevBuf poses, score_part, scores;                                             // score
-  DevBuf sq_ka, sq_kb, sq_va, sq_vb, sq_pq, sq_tmp;                             // ... scene-space batches: keys / payloads (ping-pong), per-query terms, sort workspace
+  DevBuf sq_ka, sq_kb, sq_va, sq_vb, sq_pq, sq_tmp, sq_hist;                             // ... scene-space batches: keys / payloads (ping-pong), per-query terms, sort workspace
   DevBuf plc, labels, mind, fold_off, labels_o, mind_o, rows_o, ids_tab, ids_out, attr_in, attr_out;                 // labels (state in query order; *_o: input order)
   DevBuf q4, rd2, ridx, rnn, rows;                                              // rows / misc
   DevBuf enor, ecount, eoffset, e1, e2, ew;                                     // neighbourhood edges
@@ -1821,10 +1821,16 @@ int rs_hip_alignment_scores( const rs_hip_cloud_t* object, const rs_hip_cloud_t*
     }
     else
     {
-      const size_t tmp_bytes = build_sort_temp_bytes( (int)items, bits );
+      // (counting instead of a radix sort while a table of 2^bits counters is small next to the batch: rs_score.hip, k_score_scatter; RS_HIP_SCORE_COUNTING=0: the radix sort)
+      static const int counting_max_bits = getenv( "RS_HIP_SCORE_COUNTING" ) ? atoi( getenv( "RS_HIP_SCORE_COUNTING" ) ) : 22;
+      const bool counting = bits <= counting_max_bits;
+      const size_t n_bins = ( (size_t)1 << bits ) + 1;
+      const size_t tmp_bytes = counting ? build_scan_temp_bytes( n_bins ) : build_sort_temp_bytes( (int)items, bits );
       if( ( rc = g_ws.sq_ka.ensure( items * 4 ) ) || ( rc = g_ws.sq_kb.ensure( items * 4 ) ) || ( rc = g_ws.sq_va.ensure( items * 4 ) ) ||
-          ( rc = g_ws.sq_vb.ensure( items * 4 ) ) || ( rc = g_ws.sq_pq.ensure( items * 8 ) ) || ( rc = g_ws.sq_tmp.ensure( tmp_bytes ) ) )
+          ( rc = g_ws.sq_vb.ensure( items * 4 ) ) || ( rc = g_ws.sq_pq.ensure( items * 8 ) ) || ( rc = g_ws.sq_tmp.ensure( tmp_bytes ) ) ||
+          ( counting && ( rc = g_ws.sq_hist.ensure( n_bins * 4 ) ) ) )
         return rc;
+      L.sq_hist = counting ? g_ws.sq_hist.as<uint32_t>() : nullptr;
       L.sq_key_a = g_ws.sq_ka.as<uint32_t>(); L.sq_key_b = g_ws.sq_kb.as<uint32_t>(); L.sq_val_a = g_ws.sq_va.as<uint32_t>(); L.sq_val_b = g_ws.sq_vb.as<uint32_t>();
       L.sq_pq = g_ws.sq_pq.as<double>(); L.sq_tmp = g_ws.sq_tmp.p; L.sq_tmp_bytes = g_ws.sq_tmp.cap;
     }

@@ -223,6 +223,8 @@ struct ScoreLaunch
   void*        sq_tmp;     // radix sort workspace
   size_t       sq_tmp_bytes;
   int          sq_bits;    // key bits to sort
+  uint32_t*    sq_hist;    // round 6: 2^sq_bits + 1 counters — the keys are ordered by COUNTING (k_score_keys counts, a scan, k_score_scatter places) instead of
+                           // by three radix passes; null: the radix sort (more key bits than a table is worth)
   int          sq_fine_bits;   // low key bits below the parent index (6)
   int          sq_n_parents, sq_dpx, sq_dpy, sq_dpz;
   float        sq_ox, sq_oy, sq_oz;     // origin of the parent lattice (the scene grid's, moved out by whole parents)

@@ -140,6 +140,33 @@ __device__ __forceinline__ uint32_t morton_2bit( int x, int y, int z )
   return (uint32_t)( ( x & 1 ) | ( ( y & 1 ) << 1 ) | ( ( z & 1 ) << 2 ) | ( ( x & 2 ) << 2 ) | ( ( y & 2 ) << 3 ) | ( ( z & 2 ) << 4 ) );
 }
 
+// One atomic per DISTINCT key of the wave: consecutive threads are neighbouring object points under one pose — they land in the same scene
+// block, i.e. on a handful of counters (64 same-address atomics serialise at the memory side: the first form of this was slower than
+// the radix sort it replaced).  A loop over the wave's distinct keys only forms the groups — lane masks, no memory operation — then the
+// groups' leaders add their sizes in ONE atomic instruction (a returning atomic inside the loop made it a chain of 10-30 round trips
+// per wave), and every lane takes its leader's result + its rank in the group.  COUNT_ONLY: nothing comes back.
+template <bool COUNT_ONLY>
+__device__ __forceinline__ uint32_t wave_key_slots( uint32_t* counters, uint32_t key, bool active )
+{
+  const int lane = (int)( threadIdx.x & ( WAVE - 1 ) );
+  lanemask pending = RS_BALLOT( active );
+  uint32_t rank = 0u, size = 0u;
+  int leader = lane;
+  while( pending != 0ull )
+  {
+    const int first = __builtin_ctzll( pending );
+    const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane( (int)key, first );
+    const lanemask same = RS_BALLOT( active && key == k0 );
+    if( active && key == k0 ) { rank = (uint32_t)__popcll( same & ( ( 1ull << lane ) - 1ull ) ); size = (uint32_t)__popcll( same ); leader = first; }
+    pending &= ~same;
+  }
+  if( COUNT_ONLY ) { if( active && lane == leader ) atomicAdd( counters + key, size ); return 0u; }
+  uint32_t base = 0u;
+  if( active && lane == leader ) base = atomicAdd( counters + key, size );
+  base = (uint32_t)__shfl( (int)base, leader );
+  return base + rank;
+}
+
 __global__ __launch_bounds__( BLOCK ) void k_score_keys( ScoreLaunch L )
 {
   const int pose = blockIdx.y;
@@ -172,7 +199,22 @@ __global__ __launch_bounds__( BLOCK ) void k_score_keys( ScoreLaunch L )
     key = ( (uint32_t)( ( ( iz >> 2 ) * L.sq_dpy + ( iy >> 2 ) ) * L.sq_dpx + ( ix >> 2 ) ) << L.sq_fine_bits ) | fine;
   }
   const uint32_t j = (uint32_t)pose * (uint32_t)L.obj.n + (uint32_t)i;
-  L.sq_key_a[j] = key; L.sq_val_a[j] = j;
+  L.sq_key_a[j] = key;
+  if( L.sq_hist ) (void)wave_key_slots<true>( L.sq_hist, key, true ); else L.sq_val_a[j] = j;
+}
+
+// Ordering by counting (round 6).  The keys only GROUP the queries (a lane's result never depended on its companions), so within a key any
+// order will do: k_score_keys counts the keys (2.6 M adds onto ~10^5 occupied counters), one exclusive scan turns counts into offsets, and
+// every query takes the next free place of its key — two passes over 10 MB of keys instead of a stable radix sort's three over 21 MB
+// of pairs (0.15 ms of the 0.60 ms batch with its fills).  Which of two equal keys comes first now varies from run to run; the scores
+// cannot (tests/test_gpu_parity.py::test_scores_scene_space_route_vs_golden: both routes, bit for bit).
+__global__ __launch_bounds__( BLOCK ) void k_score_scatter( ScoreLaunch L, uint32_t items )
+{
+  const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
+  const bool have = j < items;
+  const uint32_t key = have ? L.sq_key_a[j] : 0u;
+  const uint32_t pos = wave_key_slots<false>( L.sq_hist, key, have );
+  if( have ) { L.sq_key_b[pos] = key; L.sq_val_b[pos] = j; }
 }
 
 #ifndef RS_SCORE_SCENE_OCC
@@ -260,8 +302,19 @@ void launch_score( const ScoreLaunch& L, hipStream_t st )
   if( L.sq_key_a )
   {
     const uint32_t items = (uint32_t)L.n_poses * (uint32_t)L.obj.n;
-    hipLaunchKernelGGL( k_score_keys, dim3( ( L.obj.n + BLOCK - 1 ) / BLOCK, L.n_poses ), dim3( BLOCK ), 0, st, L );
-    (void)build_sort_pairs( L.sq_tmp, L.sq_tmp_bytes, L.sq_key_a, L.sq_key_b, L.sq_val_a, L.sq_val_b, (int)items, L.sq_bits, st );
+    if( L.sq_hist )
+    {
+      const size_t n_bins = ( (size_t)1 << L.sq_bits ) + 1;
+      (void)hipMemsetAsync( L.sq_hist, 0, n_bins * 4, st );
+      hipLaunchKernelGGL( k_score_keys, dim3( ( L.obj.n + BLOCK - 1 ) / BLOCK, L.n_poses ), dim3( BLOCK ), 0, st, L );
+      (void)build_exclusive_scan( L.sq_tmp, L.sq_tmp_bytes, L.sq_hist, L.sq_hist, n_bins, st );      // (in place: counts -> offsets)
+      hipLaunchKernelGGL( k_score_scatter, dim3( ( items + BLOCK - 1 ) / BLOCK ), dim3( BLOCK ), 0, st, L, items );
+    }
+    else
+    {
+      hipLaunchKernelGGL( k_score_keys, dim3( ( L.obj.n + BLOCK - 1 ) / BLOCK, L.n_poses ), dim3( BLOCK ), 0, st, L );
+      (void)build_sort_pairs( L.sq_tmp, L.sq_tmp_bytes, L.sq_key_a, L.sq_key_b, L.sq_val_a, L.sq_val_b, (int)items, L.sq_bits, st );
+    }
     const dim3 sgrid( ( items + WAVE - 1 ) / WAVE );
     if( L.sq_cull ) hipLaunchKernelGGL( k_score_scene<true>, sgrid, dim3( WAVE ), 0, st, L, items );
     else            hipLaunchKernelGGL( k_score_scene<false>, sgrid, dim3( WAVE ), 0, st, L, items );
