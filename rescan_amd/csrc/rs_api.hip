@@ -642,6 +642,42 @@ static rs_hip_cloud_t* cloud_create_impl( const float* pos, const float* nor, in
   return c;
 }
 
+// The fills an ICP call begins with (queue lengths, tickets, statistics accumulators, the two lists of slow tiles, "no certificate") as ONE
+// launch.  Each was a hipMemsetAsync — a kernel of the runtime's, 7-9 us apart on the stream: ten of them put 84 us in front of the first
+// search of every call (profiles/r06/trace_one_serial_step.txt before this), 3 % of the headline's step.
+namespace rs {
+struct FillRanges { static constexpr int MAX = 16; uint32_t* p[MAX]; unsigned long long words[MAX]; uint32_t value[MAX]; int n; };
+__global__ __launch_bounds__( 256 ) void k_fill_ranges( FillRanges R )
+{
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x, step = (size_t)gridDim.x * 256;
+  for( int r = 0; r < R.n; ++r )
+    for( size_t i = t; i < R.words[r]; i += step ) R.p[r][i] = R.value[r];
+}
+}
+namespace {
+thread_local rs::FillRanges g_fills{};
+int icp_fills_flush()
+{
+  if( g_fills.n == 0 ) return RS_HIP_OK;
+  unsigned long long most = 0;
+  for( int r = 0; r < g_fills.n; ++r ) most = std::max( most, g_fills.words[r] );
+  const int blocks = (int)std::min<unsigned long long>( 1024ull, std::max<unsigned long long>( 1ull, ( most + 1023 ) / 1024 ) );
+  hipLaunchKernelGGL( rs::k_fill_ranges, dim3( blocks ), dim3( 256 ), 0, g_stream, g_fills );
+  g_fills.n = 0;
+  HIP_TRY( hipGetLastError(), RS_HIP_E_RUNTIME );
+  return RS_HIP_OK;
+}
+// hipMemsetAsync( p, byte, bytes, g_stream ), deferred to the call's one fill launch (icp_fills_flush: before the first kernel that reads p)
+int icp_fill( void* p, int byte, size_t bytes )
+{
+  if( bytes == 0 ) return RS_HIP_OK;
+  if( ( bytes & 3 ) || ( (uintptr_t)p & 3 ) ) { HIP_TRY( hipMemsetAsync( p, byte, bytes, g_stream ), RS_HIP_E_RUNTIME ); return RS_HIP_OK; }
+  if( g_fills.n == rs::FillRanges::MAX ) { if( int rc = icp_fills_flush() ) return rc; }
+  const uint32_t b = (uint32_t)( byte & 0xff );
+  g_fills.p[g_fills.n] = (uint32_t*)p; g_fills.words[g_fills.n] = bytes / 4; g_fills.value[g_fills.n] = b | ( b << 8 ) | ( b << 16 ) | ( b << 24 ); ++g_fills.n;
+  return RS_HIP_OK;
+}
+}
 extern "C" int64_t rs_hip_cloud_build_seconds( double out[4], int32_t reset )
 {
   std::lock_guard<std::mutex> lk( g_build_mu );
@@ -807,7 +843,8 @@ int icp_prepare( IcpCtx& cx, const rs_hip_cloud_t* src, const rs_hip_cloud_t* tg
   }
   L.faith_redone = g_faith_redone.as<int>();
   L.faith_guess_scale = (float)g_faith_guess_permille.load() / 1000.0f;
-  HIP_TRY( hipMemsetAsync( g_ws.queue_count.p, 0, np * 4, g_stream ), RS_HIP_E_RUNTIME );
+  g_fills.n = 0;      // (fills an earlier call queued and never launched — it failed before its first kernel — are not this call's)
+  if( int rcf = icp_fill( g_ws.queue_count.p, 0, np * 4 ) ) return rcf;
   return RS_HIP_OK;
 }
 
@@ -834,7 +871,7 @@ int replay_prepare( ReplayBufs& B, int n_prob, int n_source )
       ( rc = g_ws.rp_totals.ensure( (size_t)n_prob * 3 * ICP_NMOM * 8 ) ) || ( rc = g_ws.rp_redone.ensure( (size_t)n_prob * 4 + 64 ) ) ) return rc;
   B.segsum = g_ws.rp_segsum.as<double>(); B.guess = g_ws.rp_guess.as<double>(); B.seg = (ReplaySeg*)g_ws.rp_seg.p; B.super = (ReplaySeg*)g_ws.rp_super.p;
   B.totals = g_ws.rp_totals.as<double>(); B.redone = g_ws.rp_redone.as<int>();
-  HIP_TRY( hipMemsetAsync( g_ws.rp_redone.p, 0, (size_t)n_prob * 4 + 64, g_stream ), RS_HIP_E_RUNTIME );
+  if( int rcf = icp_fill( g_ws.rp_redone.p, 0, (size_t)n_prob * 4 + 64 ) ) return rcf;
   return RS_HIP_OK;
 }
 
@@ -861,7 +898,7 @@ int icp_enable_certificates( IcpCtx& cx )
   const size_t words = cx.total_pts;
   if( getenv( "RS_HIP_NO_CERT" ) || !std::isfinite( cx.L.tgt_nor_max ) ) return RS_HIP_OK;
   if( ( rc = g_ws.cert_r.ensure( words * 4 ) ) || ( rc = g_ws.cert_dot.ensure( words * 4 ) ) ) return rc;
-  HIP_TRY( hipMemsetAsync( g_ws.cert_r.p, 0xFF, words * 4, g_stream ), RS_HIP_E_RUNTIME );      // NaN: no certificate
+  if( int rcf = icp_fill( g_ws.cert_r.p, 0xFF, words * 4 ) ) return rcf;      // NaN: no certificate
   cx.L.cert_r = g_ws.cert_r.as<float>(); cx.L.cert_dot = g_ws.cert_dot.as<float>();
   if( !getenv( "RS_HIP_NO_RANK_CERT" ) )            // read only next to a valid cert_r, written with every fresh one: no initialisation
   {
@@ -995,8 +1032,8 @@ int icp_lane_prepare( IcpCtx& cx, ChainBufs& CB, int n_prob, size_t rows, int ma
     HIP_TRY( hipMemsetAsync( g_ws.ch_dbg.p, 0, np * CH_ROWS * 16, g_stream ), RS_HIP_E_RUNTIME );
     CB.dbg = g_ws.ch_dbg.as<int>();
   }
-  HIP_TRY( hipMemsetAsync( g_ws.rp_redone.p, 0, np * 4 + 64, g_stream ), RS_HIP_E_RUNTIME );
-  HIP_TRY( hipMemsetAsync( g_ws.ch_done.p, 0, np * 8, g_stream ), RS_HIP_E_RUNTIME );
+  if( int rcf = icp_fill( g_ws.rp_redone.p, 0, np * 4 + 64 ) ) return rcf;
+  if( int rcf = icp_fill( g_ws.ch_done.p, 0, np * 8 ) ) return rcf;
   CB.totals = g_ws.rp_totals.as<double>(); CB.resolved = g_ws.rp_redone.as<int>(); CB.done = g_ws.ch_done.as<int>(); CB.failed = nullptr;
   cx.L.rec = (float4*)g_ws.ch_rec.p; cx.L.mom_part = g_ws.mom_part.as<double>();
   g_lane_addends.fetch_add( (long long)rows * CH_ROWS );      // (per iteration; the diagnostic divides by what it counted the same way)
@@ -1065,7 +1102,7 @@ int icp_align_batch_impl( const rs_hip_cloud_t* source, const rs_hip_cloud_t* ta
   {
     if( ( rc = g_ws.rp_totals.ensure( (size_t)n * 3 * ICP_NMOM * 8 ) ) || ( rc = g_ws.rp_redone.ensure( (size_t)n * 4 + 64 ) ) ) return rc;
     RB.totals = g_ws.rp_totals.as<double>(); RB.redone = g_ws.rp_redone.as<int>();
-    HIP_TRY( hipMemsetAsync( g_ws.rp_redone.p, 0, (size_t)n * 4 + 64, g_stream ), RS_HIP_E_RUNTIME );
+    if( int rcf = icp_fill( g_ws.rp_redone.p, 0, (size_t)n * 4 + 64 ) ) return rcf;
   }
   if( lane )
   {
@@ -1084,7 +1121,7 @@ int icp_align_batch_impl( const rs_hip_cloud_t* source, const rs_hip_cloud_t* ta
     CB.segsum = g_ws.ch_segsum.as<double>(); CB.blksum = g_ws.ch_prefix.as<double>(); CB.seg = (ChainRec*)g_ws.ch_seg.p; CB.blk = (ChainRec*)g_ws.ch_blk.p; CB.guess = g_ws.ch_guess.as<int>();
     CB.totals = RB.totals; CB.resolved = RB.redone;
     if( ( rc = g_ws.ch_done.ensure( (size_t)n * 8 ) ) ) return rc;
-    HIP_TRY( hipMemsetAsync( g_ws.ch_done.p, 0, (size_t)n * 8, g_stream ), RS_HIP_E_RUNTIME );
+    if( int rcf = icp_fill( g_ws.ch_done.p, 0, (size_t)n * 8 ) ) return rcf;
     CB.done = g_ws.ch_done.as<int>(); CB.failed = CB.done + n;
     if( getenv( "RS_HIP_CHAIN_DEBUG" ) )
     {
@@ -1110,7 +1147,7 @@ int icp_align_batch_impl( const rs_hip_cloud_t* source, const rs_hip_cloud_t* ta
     CB.n_seg = chain_segments( source->n ); CB.n_blk = chain_blocks( source->n ); CB.refresh = 0;
     if( ( rc = g_ws.ch_rec.ensure( (size_t)n * (size_t)source->n * REC_F4 * 16 ) ) || ( rc = g_ws.ch_done.ensure( (size_t)n * 8 ) ) ||
         ( rc = g_ws.mom_part.ensure( (size_t)n * CB.n_blk * 4 * ICP_NMOM * 8 ) ) ) return rc;
-    HIP_TRY( hipMemsetAsync( g_ws.ch_done.p, 0, (size_t)n * 8, g_stream ), RS_HIP_E_RUNTIME );
+    if( int rcf = icp_fill( g_ws.ch_done.p, 0, (size_t)n * 8 ) ) return rcf;
     CB.done = g_ws.ch_done.as<int>();
     cx.L.rec = (float4*)g_ws.ch_rec.p;
     cx.L.n_mom_blocks = CB.n_blk * 4;
@@ -1118,7 +1155,7 @@ int icp_align_batch_impl( const rs_hip_cloud_t* source, const rs_hip_cloud_t* ta
   }
   if( !ref_order && !replay )
   {
-    HIP_TRY( hipMemsetAsync( g_ws.stat_acc.p, 0, (size_t)n * STAT_SHARDS * 4 * 8, g_stream ), RS_HIP_E_RUNTIME );
+    if( int rcf = icp_fill( g_ws.stat_acc.p, 0, (size_t)n * STAT_SHARDS * 4 * 8 ) ) return rcf;
     cx.L.stat_acc = g_ws.stat_acc.as<unsigned long long>();
   }
   const size_t heavy_words = cx.heavy_words;
@@ -1126,8 +1163,8 @@ int icp_align_batch_impl( const rs_hip_cloud_t* source, const rs_hip_cloud_t* ta
   if( reorder )
   {
     if( ( rc = g_ws.order_a.ensure( heavy_words * 4 ) ) || ( rc = g_ws.order_b.ensure( heavy_words * 4 ) ) ) return rc;
-    HIP_TRY( hipMemsetAsync( g_ws.order_a.p, 0, heavy_words * 4, g_stream ), RS_HIP_E_RUNTIME );
-    HIP_TRY( hipMemsetAsync( g_ws.order_b.p, 0, heavy_words * 4, g_stream ), RS_HIP_E_RUNTIME );
+    if( int rcf = icp_fill( g_ws.order_a.p, 0, heavy_words * 4 ) ) return rcf;
+    if( int rcf = icp_fill( g_ws.order_b.p, 0, heavy_words * 4 ) ) return rcf;
   }
 
   // The whole iteration runs on the device (search, statistics, moments, solve, pose update, stop
@@ -1147,6 +1184,7 @@ int icp_align_batch_impl( const rs_hip_cloud_t* source, const rs_hip_cloud_t* ta
   // (see g_early_plain.  Scan-sized sources only: the eight 50 k-point refines of bench.py --scaling strong end 2.2e-6 from the reference with the
   //  chains throughout, 8.7e-6 with three plain iterations, 2.0e-5 with seven or eight — an object refine contracts more slowly than a scan-to-scan fit)
   const int n_plain = ( chains || from_records ) ? icp_plain_iterations( source->n, max_iter, fixed_iters != 0 ) : 0;
+  if( ( rc = icp_fills_flush() ) ) return rc;      // everything the call's first kernels expect zeroed, in one launch
   ProfChain prof;
   for( int i = 0; i < max_iter; )                                       // icp.h:444
   {
@@ -1400,7 +1438,7 @@ static int icp_align_multi_group( const rs_hip_cloud_t* const* sources, const rs
     if( ( rc = icp_lane_prepare( cx, CB, n, cx.total_pts, cx.L.max_n ) ) ) return rc;
     cx.L.exact_centroids = 1; cx.L.centroid_totals = CB.totals;
     if( !fixed_iters ) { cx.L.stop_guard = g_stop_guard.load(); T_in.assign( T1s, T1s + 16 * (size_t)n ); }      // (see icp_align_batch_impl)
-    HIP_TRY( hipMemsetAsync( g_ws.stat_acc.p, 0, (size_t)n * STAT_SHARDS * 4 * 8, g_stream ), RS_HIP_E_RUNTIME );
+    if( int rcf = icp_fill( g_ws.stat_acc.p, 0, (size_t)n * STAT_SHARDS * 4 * 8 ) ) return rcf;
     cx.L.stat_acc = g_ws.stat_acc.as<unsigned long long>();
   }
   else
@@ -1412,8 +1450,8 @@ static int icp_align_multi_group( const rs_hip_cloud_t* const* sources, const rs
   if( reorder )
   {
     if( ( rc = g_ws.order_a.ensure( cx.heavy_words * 4 ) ) || ( rc = g_ws.order_b.ensure( cx.heavy_words * 4 ) ) ) return rc;
-    HIP_TRY( hipMemsetAsync( g_ws.order_a.p, 0, cx.heavy_words * 4, g_stream ), RS_HIP_E_RUNTIME );
-    HIP_TRY( hipMemsetAsync( g_ws.order_b.p, 0, cx.heavy_words * 4, g_stream ), RS_HIP_E_RUNTIME );
+    if( int rcf = icp_fill( g_ws.order_a.p, 0, cx.heavy_words * 4 ) ) return rcf;
+    if( int rcf = icp_fill( g_ws.order_b.p, 0, cx.heavy_words * 4 ) ) return rcf;
   }
   // the loop of icp_align_batch_impl, reference-order estimator only
   static const int chunk_env = getenv( "RS_HIP_ICP_CHUNK" ) ? atoi( getenv( "RS_HIP_ICP_CHUNK" ) ) : 4;
@@ -1424,6 +1462,7 @@ static int icp_align_multi_group( const rs_hip_cloud_t* const* sources, const rs
   const int* hActive = (const int*)( hS + np * 16 );
   const long long total_tiles = (long long)cx.total_tiles;
   cx.L.solve = 1; cx.L.fixed_iters = fixed_iters ? 1 : 0;
+  if( ( rc = icp_fills_flush() ) ) return rc;
   ProfChain prof;
   for( int i = 0; i < max_iter; )                                       // icp.h:444
   {
@@ -1589,6 +1628,7 @@ int rs_hip_icp_find_corrs( const rs_hip_cloud_t* source, const rs_hip_cloud_t* t
   std::vector<Mat4> T( 1 ); std::memcpy( T[0].m, T1, 64 );
   if( ( rc = icp_upload_state( cx, T1, 1 ) ) ) return rc;
   icp_set_radius( cx, max_dist, icp_gate_threshold( max_angle ) );
+  if( ( rc = icp_fills_flush() ) ) return rc;
   { ProfScope ps( "nn_icp" ); launch_icp_corr( cx.L, g_stream ); }
   std::vector<int> slot( nq ); std::vector<float> d2( nq ), dot( nq );
   HIP_TRY( hipMemcpyAsync( slot.data(), cx.L.m_slot, (size_t)nq * 4, hipMemcpyDeviceToHost, g_stream ), RS_HIP_E_RUNTIME );
@@ -1641,6 +1681,7 @@ int rs_hip_icp_estimate_pt2pl( const float* pts1, const float* pts2, const float
 {
   int rc = ensure_ready(); if( rc ) return rc;
   if( !pts1 || !pts2 || !nor2 || !weights || !T1 || n <= 0 ) { set_err( "icp_estimate: bad arguments" ); return RS_HIP_E_ARG; }
+  g_fills.n = 0;      // (see icp_prepare)
   // Present the correspondences to k_icp_moments as "query i matched slot i" with explicit weights.
   const size_t nn = (size_t)n;
   if( ( rc = g_ws.tmp_pos.ensure( nn * 16 ) ) || ( rc = g_ws.tmp_pos2.ensure( nn * 16 ) ) || ( rc = g_ws.tmp_nor2.ensure( nn * 16 ) ) ||
@@ -1689,7 +1730,7 @@ int rs_hip_icp_estimate_pt2pl( const float* pts1, const float* pts2, const float
     else
     {
       ReplayBufs RB{};
-      if( ( rc = replay_prepare( RB, 1, n ) ) ) return rc;
+      if( ( rc = replay_prepare( RB, 1, n ) ) || ( rc = icp_fills_flush() ) ) return rc;
       ProfScope ps( "icp_moments" ); launch_icp_replay( L, RB, g_stream );
     }
     float out[ICP_STATE_WORDS];
