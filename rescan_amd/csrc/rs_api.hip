@@ -173,6 +173,9 @@ inline int icp_plain_iterations( int n_source, int max_iter, bool fixed_iters )
   static const int forced = getenv( "RS_HIP_EARLY_TAIL" ) ? atoi( getenv( "RS_HIP_EARLY_TAIL" ) ) : 0;
   const int keep = forced > 0 ? forced : ( fixed_iters ? 2 : 3 );      // chain iterations before a result can be returned
   const int tail = std::max( 0, max_iter - keep );
+  // (by SIZE, not by which kernels run the chains: an object refine contracts too slowly for this — rs_hip_icp_lane_chains_below( 0 ) puts
+  //  50 k-point refines on the grid chains, and they keep them in every iteration)
+  if( n_source <= 65536 ) return 0;
   if( fixed_iters ) return tail;
   return n_source > 262144 ? std::min( std::max( 0, 7 - keep ), tail ) : 0;
 }

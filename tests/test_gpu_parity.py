@@ -330,6 +330,13 @@ def test_icp_multi_source_batch_matches_single(capi, oracle, gscene, scene_cloud
             print(f"self-alignment of a scan extract under the default estimator: {d:.2e} from the reference, {its[j]} vs {ito} iterations")
             assert d < 1e-3
             continue
+        if len(host[k][0]) <= capi.icp_reference_order_below(-1):      # the reference's own order at this size: its bits
+            assert d == 0.0 and its[j] == ito, (j, k, d)
+            continue
+        if len(host[k][0]) < 64:
+            # (only under RS_HIP_REF_ORDER_BELOW=0 — tools/switch_matrix.sh — which puts the chains on the 9-point subset: six unknowns from
+            #  nine correspondences, a system whose answer is its rounding noise; nothing but the reference's own order reproduces that)
+            continue
         assert d < POLICY_TOL and its[j] == ito, (j, k, d)
     # an empty batch, a batch of one
     e0, T0, i0 = capi.icp_align_multi([], clouds[0.1], np.zeros((0, 16), np.float32))
