@@ -150,13 +150,13 @@ int64_t rs_hip_icp_lane_chains_sequential( void );
  * Returns how many problems were, since rs_hip_init. */
 int64_t rs_hip_icp_stop_guard_redone( void );
 /* Plain early iterations (round 6).  The chains above fix where the iteration CONVERGES; far from the end an iteration only has to bring the
- * pose near.  With this on (default; environment RS_HIP_EARLY_PLAIN=0 turns it off) a call on the GRID chains (a scan-sized source) runs the
+ * pose near.  With this on (default; environment RS_HIP_EARLY_PLAIN=0 turns it off) a call on a scan-sized source (more than 65536 points) runs the
  * plain step — fp64 moments centred on their own fp64 centroids, two launches instead of six — in its early iterations, keeping chain
  * iterations before any iteration whose result can be returned: a fixed-length call (fixed_iters) runs plain until TWO before its end; a call
  * with the stop test in its first four iterations (three chain iterations before the first decision), and only for sources above 262144
  * points (below, the stop test's guard wants the reference's errors from the start).  Measured on six 1 M-point rooms: <= 3.7e-6 from the
  * reference's pose (<= 1.2e-6 without; with ONE chain iteration 1.1e-5: not shipped; profiles/r06/early_plain.txt).
- * Object-sized sources (lane chains) keep their chains in every iteration.  on < 0 only reads; returns the previous setting. */
+ * Object-sized sources (up to 65536 points, whichever kernels run their chains) keep them in every iteration.  on < 0 only reads; returns the previous setting. */
 int32_t rs_hip_icp_early_plain( int32_t on );
 float   rs_hip_icp_stop_guard( float guard );      /* sets the guard's width (0: off); < 0 only reads; returns the previous width */
 /* The sequential estimator (sources up to rs_hip_icp_reference_order_below) runs the reference's dist² statistics and its weighted

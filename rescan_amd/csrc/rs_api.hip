@@ -159,7 +159,7 @@ std::atomic<long long> g_stop_guard_redone{ 0 };      // (diagnostics: rs_hip_ic
 // PLAIN early iterations (round 6).  The reference's centroid chains decide where the iteration CONVERGES; an iteration far from the end only has
 // to bring the pose near, and ICP forgets how it got there at its own contraction rate (measured on the headline, the chains in the last m
 // iterations of ten: m = 10 / 7 / 5 / 3 / 1 -> 9.9e-7 / 6.9e-7 / 1.3e-6 / 2.5e-6 / 1.0e-5 from the reference's pose; profiles/r06/early_plain.txt).
-// Rule, for sources on the GRID chains (above g_lane_below): chain iterations precede any iteration whose result can be returned — TWO in a
+// Rule, for scan-sized sources (more than 65 536 points): chain iterations precede any iteration whose result can be returned — TWO in a
 // call of fixed length, which runs the plain step (fp64 moments centred on their own fp64 centroids: two launches instead of six) until two
 // iterations before its end (m = 2 and m = 3 are the same few 1e-6 from the reference's pose on six rooms — <= 3.7e-6 / <= 2.6e-6, neither
 // monotone in m — m = 1 is not: 1.1e-5, outside the 1e-5 this policy is held to); three in a call with the stop test (first decision at
