@@ -161,6 +161,41 @@ def test_headline_sharded_route_is_bit_identical(capi, bench_mod, headline):
         assert (labels == lab0["labels"]).all() and (mind == lab0["min_dists"]).all(), f"world {world}: labels"
 
 
+def test_many_problem_batches_take_the_narrow_cooperative_tiles(capi, bench_mod):
+    """Round 6: a batch of more than eight ICP problems runs its cooperative searches at 4 waves per queued tile from 32 768 tiles in
+    all, at 2 from 131 072 (rs_api.hip: icp_coop_waves — such launches are throughput-bound; 512 refines: 33.8 -> 28.9 ms per step).
+    Ten start poses of the headline scan (156 k tiles: 2 waves) — the eight of the units fixture, two of them twice — end where the
+    reference's ten iterations end and where the single calls end, bit for bit; nine start poses of every fourth point of the scan
+    (~35 k tiles: 4 waves) where their single calls end."""
+    g = load_golden("bench_seed11_units.npz")
+    w = bench_mod.build_workload(1_000_000, seed=11, knn="hash", units=8)
+    try:
+        assert np.array_equal(w["icp_T0s"], g["icp_T0s"][:8])
+        T0s = np.concatenate([w["icp_T0s"], w["icp_T0s"][:2]])
+        assert len(T0s) * (w["scan1"].n // 64) >= 131072          # (a tile holds at most 64 points: at least this many tiles)
+        errs, Ts, its = capi.icp_align_batch(w["scan1"], w["scan0"], T0s, I4, 0.10, np.deg2rad(60.0), max_iter=bench_mod.ICP_ITERS, fixed_iters=True)
+        ref = np.concatenate([g["icp_pose"][:8], g["icp_pose"][:2]]).astype(np.float64).reshape(-1, 16)
+        d = np.linalg.norm(Ts.astype(np.float64).reshape(-1, 16) - ref, axis=1)
+        print(f"ten start poses of the headline scan as one batch: pose distances from the reference's {d.max():.2e}")
+        assert (d < 1e-5).all() and (its == bench_mod.ICP_ITERS).all()
+        assert (Ts[8] == Ts[0]).all() and (Ts[9] == Ts[1]).all() and errs[8] == errs[0]
+        for j in (0, 5):
+            e, T, it = capi.icp_align(w["scan1"], w["scan0"], T0s[j], I4, 0.10, np.deg2rad(60.0), max_iter=bench_mod.ICP_ITERS, fixed_iters=True)
+            assert (T == Ts[j]).all() and e == errs[j], j
+        sub = capi.Cloud(np.ascontiguousarray(w["s1"]["points"][::4]), np.ascontiguousarray(w["s1"]["normals"][::4]))
+        try:
+            T9 = np.concatenate([w["icp_T0s"], w["icp_T0s"][:1]])
+            assert 32768 <= len(T9) * (sub.n // 64) and len(T9) * (sub.n // 32) < 131072
+            errs, Ts, its = capi.icp_align_batch(sub, w["scan0"], T9, I4, 0.10, np.deg2rad(60.0), max_iter=6, fixed_iters=True)
+            for j in (0, 3, 8):
+                e, T, it = capi.icp_align(sub, w["scan0"], T9[j], I4, 0.10, np.deg2rad(60.0), max_iter=6, fixed_iters=True)
+                assert (T == Ts[j]).all() and e == errs[j] and it == its[j], j
+        finally:
+            sub.close()
+    finally:
+        _close_workload(w)
+
+
 @pytest.mark.parametrize("n_ranks", [2, 4, 8])
 def test_weak_scaling_unit_lists_vs_reference(capi, bench_mod, n_ranks):
     """Round 6 (missing 1a): what bench.py --gpus N computes at N > 1 under weak scaling — N ICP start poses, 256 N score
