@@ -138,7 +138,9 @@ int32_t rs_hip_icp_replay_redone( void );
  * normal equations (:226-252) as a parallel fp64 reduction centred on those centroids.  Not the reference's bits: measured on every
  * reference fixture of that size at most 3e-6 from its pose, equal iteration counts (profiles/r06/estimator_policy.txt).  Any
  * number of differently sized problems run side by side (rs_hip_icp_align_multi).  Larger sources take the grid chains (the same
- * sums spread over the chip).  n_points < 0 only reads; returns the previous threshold.  Environment: RS_HIP_LANE_CHAINS_BELOW.
+ * sums spread over the chip) — and so does a call with ONE problem from 28672 points on: same sums, same poses bit for bit, faster with
+ * the chip to itself (tools/lane_vs_grid.py); a threshold set beyond 65536 keeps such calls on the lane chains too.  n_points < 0 only
+ * reads; returns the previous threshold.  Environment: RS_HIP_LANE_CHAINS_BELOW.
  * rs_hip_icp_lane_chains_sequential(): addends those walks added one by one since rs_hip_init (a diagnostic: chain starts, binade
  * changes, ties, sums that hover around zero). */
 int32_t rs_hip_icp_lane_chains_below( int32_t n_points );

@@ -147,6 +147,17 @@ std::atomic<int> g_faith_guess_permille{ getenv( "RS_HIP_FAITH_GUESS" ) ? atoi( 
 std::atomic<int> g_exact_centroids{ getenv( "RS_HIP_EXACT_CENTROIDS" ) ? atoi( getenv( "RS_HIP_EXACT_CENTROIDS" ) ) : 1 };
 std::atomic<int> g_replay_below{ getenv( "RS_HIP_REPLAY_BELOW" ) ? atoi( getenv( "RS_HIP_REPLAY_BELOW" ) ) : 0 };
 std::atomic<int> g_lane_below{ getenv( "RS_HIP_LANE_CHAINS_BELOW" ) ? atoi( getenv( "RS_HIP_LANE_CHAINS_BELOW" ) ) : 65536 };
+// ... of a call with ONE problem, whose grid chains have the chip to themselves: the same sums — the same poses, bit for bit — faster from
+// ~28 k points on (tools/lane_vs_grid.py, us per iteration lane | grid: 17 k 74 | 80, 25 k 80 | 80, 30 k 84 | 80, 40 k 101 | 90, 50 k 111 | 91,
+// 65 k 130 | 97); batches keep the lane chains up to g_lane_below (a walk per problem side by side: eight 50 k-point refines 20 us per
+// problem and iteration).  A threshold set beyond 65 536 (rs_hip_icp_lane_chains_below) means "the lane chains, whatever the call" and
+// holds for single calls too; any other setting caps them at 28 672.
+inline int lane_single_cap( int lane_below ) { return lane_below > 65536 ? lane_below : std::min( lane_below, 28672 ); }
+inline bool icp_takes_lane_chains( int n_source, int n_problems )
+{
+  const int below = g_lane_below.load();
+  return n_source <= ( n_problems > 1 ? below : lane_single_cap( below ) );
+}
 // The stop test's guard (round 6).  icp_align stops when |err - prev_err| < 1e-5 (icp.h:489).  The lane / grid chains follow the
 // reference's errors to 1e-8 ... 6e-7 (their moments are exact where the reference rounds): when a decisive difference passes within
 // that of 1e-5 the decision can fall the other way — one iteration more or less, 1e-4 ... 2e-4 in the pose; measured: 2 of 49
@@ -1085,7 +1096,7 @@ int icp_align_batch_impl( const rs_hip_cloud_t* source, const rs_hip_cloud_t* ta
   const bool exact_centroids = !ref_order && !replay && centroid_mode != 0;
   ReplayBufs RB{};
   ChainBufs CB{};
-  const bool lane = exact_centroids && source->n <= g_lane_below.load();      // (object-sized: one wave per chain, launch_icp_lane_chains)
+  const bool lane = exact_centroids && icp_takes_lane_chains( source->n, n );      // (object-sized: one wave per chain, launch_icp_lane_chains)
   // the stop test's guard: only where the estimator is not the reference's order AND a bit-exact one exists to run the problem again with
   cx.L.stop_guard = ( exact_centroids && !fixed_iters && edge && source->n <= 262144 ) ? g_stop_guard.load() : 0.0f;
   const bool chains = exact_centroids && !lane && centroid_mode == 1;      // (2: the same sums through pass 2 of the replay — the cross-check, and what a problem the chains give up is run with)
